@@ -1,0 +1,113 @@
+"""Synthetic motion-primitive models in the reference's legacy JSON layout.
+
+The reference ships no model data, so tests and bench.py run on
+seeded synthetic primitives with the shapes of BASELINE.json's configs
+(SURVEY.md §8(d)).  The dictionaries produced here have exactly the keys that
+``MotionPrimitive._initialize_from_json`` consumes
+(reference morphablegraphs/motion_model/motion_primitive.py:96-163), so the same
+dictionary can be fed to the reference, to the oracle and to the HIP backend.
+
+Layout conventions that are binding for the hot path:
+  * knots: clamped cubic, ``[0,0,0, linspace(0, F-1, NB-2), F-1,F-1,F-1]``
+    (reference morphablegraphs/construction/utils.py:187-198)
+  * ``eigen_vectors_spatial`` is (L, NB*D); flat column index = coeff_idx*D + d
+    (reference morphablegraphs/construction/fpca/pca_functional_data.py:132-142)
+  * pose channel d<3 = root translation, 3+4j..3+4j+3 = joint j quaternion (w,x,y,z)
+"""
+import numpy as np
+
+LEN_ROOT = 3
+LEN_QUAT = 4
+
+
+def cubic_b_spline_knots(n_basis, n_canonical_frames):
+    """Clamped cubic knot vector of length n_basis + 4."""
+    knots = np.zeros(n_basis + 4)
+    knots[3:-3] = np.linspace(0, n_canonical_frames - 1, n_basis - 2)
+    knots[-3:] = n_canonical_frames - 1
+    return knots
+
+
+def make_primitive(seed=0, n_components=40, n_frames=156, n_basis=None, n_dim=79, n_gmm=8,
+                   translation_maxima=(1.0, 1.0, 1.0), root_scale=100.0, realistic=True,
+                   dirichlet_weights=False, name=None):
+    """Seeded synthetic primitive ("walk" sized by default: L=40, F=156, NB=31, D=79, K=8)."""
+    rng = np.random.default_rng(seed)
+    L, F, D, K = int(n_components), int(n_frames), int(n_dim), int(n_gmm)
+    NB = int(0.2 * F) if n_basis is None else int(n_basis)
+    eigen = 0.05 * rng.standard_normal((L, NB * D))
+    mean = rng.standard_normal(NB * D)
+    if realistic:
+        m = mean.reshape(NB, D)
+        e = eigen.reshape(L, NB, D)
+        m[:, :LEN_ROOT] *= root_scale
+        e[:, :, :LEN_ROOT] *= root_scale
+        n_joints = (D - LEN_ROOT) // LEN_QUAT
+        for j in range(n_joints):
+            q = 0.1 * rng.standard_normal(4)
+            q[0] = 1.0
+            q /= np.linalg.norm(q)
+            m[:, LEN_ROOT + LEN_QUAT * j:LEN_ROOT + LEN_QUAT * (j + 1)] = q
+    if dirichlet_weights:
+        weights = rng.dirichlet(np.ones(K))
+    else:
+        weights = np.full(K, 1.0 / K)
+    means = rng.standard_normal((K, L))
+    covars = np.empty((K, L, L))
+    for k in range(K):
+        a = 0.3 * rng.standard_normal((L, L))
+        covars[k] = a @ a.T + 0.5 * np.eye(L)
+    n_joints = (D - LEN_ROOT) // LEN_QUAT
+    return {
+        "name": name or ("synthetic_%d" % seed),
+        "n_canonical_frames": F,
+        "translation_maxima": [float(v) for v in translation_maxima],
+        "eigen_vectors_spatial": eigen.tolist(),
+        "mean_spatial_vector": mean.tolist(),
+        "n_basis_spatial": NB,
+        "n_dim_spatial": D,
+        "b_spline_knots_spatial": cubic_b_spline_knots(NB, F).tolist(),
+        "gmm_weights": weights.tolist(),
+        "gmm_means": means.tolist(),
+        "gmm_covars": covars.tolist(),
+        "animated_joints": ["joint_%d" % j for j in range(n_joints)],
+    }
+
+
+def make_walk_primitive(seed=0, **kw):
+    """BASELINE.json configs 1/2/4/5: L=40, F=156, NB=31, D=79, K=8."""
+    return make_primitive(seed=seed, n_components=40, n_frames=156, n_dim=79, n_gmm=8, name="walk", **kw)
+
+
+def make_tiny_primitive(seed=1, **kw):
+    """Tiny case the pure-Python oracle loops finish instantly: L=3, F=12, NB=7, D=7, K=2."""
+    return make_primitive(seed=seed, n_components=3, n_frames=12, n_basis=7, n_dim=7, n_gmm=2,
+                          name="tiny", **kw)
+
+
+def make_graph_primitives(n_primitives=16, seed=100):
+    """BASELINE.json config 3: ~16 primitives with (L, F, K) drawn per primitive, D=79."""
+    out = []
+    for p in range(n_primitives):
+        rng = np.random.default_rng(seed + p)
+        L = int(rng.integers(12, 41))
+        F = int(rng.integers(40, 161))
+        K = int(rng.integers(1, 9))
+        out.append(make_primitive(seed=seed + p, n_components=L, n_frames=F, n_dim=79, n_gmm=K,
+                                  name="prim_%02d" % p))
+    return out
+
+
+def to_mgrd_v3_json(data):
+    """Re-express a legacy dict in the v3 ``sspm/tspm/gmm`` layout
+    (reference morphablegraphs/motion_model/motion_primitive_wrapper.py:87-115)."""
+    F = int(data["n_canonical_frames"])
+    return {
+        "name": data.get("name", ""),
+        "sspm": {"eigen": data["eigen_vectors_spatial"], "mean": data["mean_spatial_vector"],
+                 "n_coeffs": data["n_basis_spatial"], "n_dims": data["n_dim_spatial"],
+                 "knots": data["b_spline_knots_spatial"],
+                 "animated_joints": data.get("animated_joints", [])},
+        "tspm": {"knots": [0.0, 0.0, 0.0, 0.0, float(F - 1), float(F - 1), float(F - 1), float(F - 1)]},
+        "gmm": {"covars": data["gmm_covars"], "means": data["gmm_means"], "weights": data["gmm_weights"]},
+    }

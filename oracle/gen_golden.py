@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own, unmodified
+motion_primitive.py / motion_spline.py (imported from /root/reference through a
+stub parent package that only supplies B_SPLINE_DEGREE = 3)
+with the installed numpy/scipy/scikit-learn on seeded synthetic models.
+
+Run in the build container only:   python oracle/gen_golden.py
+The reference cannot travel to the GPU box; only the vectors written here do.
+No reference source is copied: the fixtures hold inputs and expected outputs.
+"""
+import hashlib
+import importlib
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from morphablegraphs_amd import synthetic  # noqa: E402
+
+REF_DIR = "/root/reference/morphablegraphs/motion_model"
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    warnings.filterwarnings("ignore")
+    pkg = types.ModuleType("mg_ref_motion_model")
+    pkg.__path__ = [REF_DIR]
+    pkg.B_SPLINE_DEGREE = 3
+    sys.modules["mg_ref_motion_model"] = pkg
+    return importlib.import_module("mg_ref_motion_model.motion_primitive")
+
+
+def model_digest(data):
+    h = hashlib.sha256()
+    for key in ("eigen_vectors_spatial", "mean_spatial_vector", "b_spline_knots_spatial",
+                "gmm_weights", "gmm_means", "gmm_covars", "translation_maxima"):
+        h.update(np.ascontiguousarray(np.asarray(data[key], dtype=np.float64)).tobytes())
+    return h.hexdigest()
+
+
+def run_case(ref, name, data, n_samples, eval_times, seed, store_model, n_score=64):
+    mp = ref.MotionPrimitive(None)
+    mp._initialize_from_json(data)
+    np.random.seed(seed)
+    S = mp.sample_low_dimensional_vector(n_samples)          # sklearn GaussianMixture.sample
+    np.random.seed(seed + 1)
+    X = mp.sample_low_dimensional_vector(n_score)
+    X[: max(1, n_score // 8)] *= 3.0                          # push some rows into the tails
+    coeffs = np.stack([mp.back_project_spatial_coeffs(s) for s in S])
+    splines = [mp.back_project(s, use_time_parameters=False) for s in S]
+    frames = np.stack([sp.get_motion_vector() for sp in splines])
+    evals = np.stack([sp.evaluate(np.asarray(eval_times, dtype=float)) for sp in splines])
+    evals_scalar = np.stack([splines[0].evaluate(float(t)) for t in eval_times])
+    gmm = mp.gaussian_mixture_model
+    logp = gmm.score_samples(X)
+    logp_S = gmm.score_samples(S)
+    out = dict(
+        S=S, X=X, coeffs=coeffs, frames=frames, eval_times=np.asarray(eval_times, dtype=float),
+        evals=evals, evals_scalar=evals_scalar, logp=logp, logp_S=logp_S,
+        score_mean=np.float64(gmm.score(X)),
+        precisions_cholesky=gmm.precisions_cholesky_,
+        time_function=splines[0].time_function, knots=np.asarray(splines[0].knots),
+        seed=np.int64(seed), digest=np.array(model_digest(data)),
+        n_canonical_frames=np.int64(mp.get_n_canonical_frames()),
+        n_spatial_components=np.int64(mp.get_n_spatial_components()),
+    )
+    if store_model:
+        for key in ("eigen_vectors_spatial", "mean_spatial_vector", "b_spline_knots_spatial",
+                    "gmm_weights", "gmm_means", "gmm_covars", "translation_maxima"):
+            out["model_" + key] = np.asarray(data[key], dtype=np.float64)
+        out["model_n_basis"] = np.int64(data["n_basis_spatial"])
+        out["model_n_dim"] = np.int64(data["n_dim_spatial"])
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def main():
+    ref = import_reference()
+    os.makedirs(OUT_DIR, exist_ok=True)
+    # (i) tiny model, non-unit translation maxima, times incl. out-of-range (extrapolated) ones
+    tiny = synthetic.make_tiny_primitive(seed=1, translation_maxima=(1.5, 2.0, 0.5))
+    run_case(ref, "tiny_tm", tiny, 5, [0.0, 0.25, 5.5, 10.999, 11.0, 11.5, 12.0, -0.5], 3, True, n_score=16)
+    # (ii) walk-sized, realistic magnitudes, v3 load path translation maxima [1,1,1]
+    walk = synthetic.make_walk_primitive(seed=0)
+    run_case(ref, "walk_seed0", walk, 4, [0.0, 77.5, 155.0, 156.0, 33.3, 154.999], 0, False)
+    # (iii) walk-sized, scaled translation, Dirichlet weights, unrealistic O(1) magnitudes
+    walk_tm = synthetic.make_walk_primitive(seed=7, translation_maxima=(1.5, 2.0, 0.5),
+                                            dirichlet_weights=True, realistic=False)
+    run_case(ref, "walk_seed7_tm", walk_tm, 3, [0.0, 77.5, 155.0], 11, False)
+    # (iv) single component with a nearly singular covariance
+    k1 = synthetic.make_primitive(seed=5, n_components=6, n_frames=40, n_dim=11, n_gmm=1, name="k1")
+    rng = np.random.default_rng(55)
+    a = rng.standard_normal((6, 2))
+    k1["gmm_covars"] = [(a @ a.T + 1e-6 * np.eye(6)).tolist()]
+    run_case(ref, "k1_near_singular", k1, 4, [0.0, 19.5, 39.0, 40.0], 21, True, n_score=16)
+    # (v) small odd shape (D not a multiple of 4, L not a multiple of 4)
+    odd = synthetic.make_primitive(seed=9, n_components=13, n_frames=47, n_dim=15, n_gmm=3, name="odd",
+                                   translation_maxima=(2.0, 1.0, 3.0))
+    run_case(ref, "odd_shape", odd, 6, [0.0, 23.0, 46.0, 47.0], 31, True, n_score=32)
+
+
+if __name__ == "__main__":
+    main()

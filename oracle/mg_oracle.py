@@ -1,0 +1,289 @@
+"""ORACLE (test infrastructure, NOT product code) -- NumPy restatement of the
+morphablegraphs motion-primitive hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; nothing under morphablegraphs_amd/ does.  It is the CPU checker the
+HIP path is compared against, never the thing shipped or measured.
+
+Parity status: PINNED.  The reference holds no tests or golden vectors for this
+path, so the restatement is pinned against outputs of the
+reference's own, unmodified motion_primitive.py / motion_spline.py imported in
+the build container (oracle/gen_golden.py -> tests/golden/*.npz) and is checked
+against those fixtures by tests/test_oracle_golden.py.
+
+Each function cites the reference file:line (relative to /root/reference) it
+restates.  Arithmetic that lives in third-party code is restated from its
+published algorithm:
+  * scipy.interpolate.splev  = FITPACK splev.f / fpbspl.f (reference pins
+    scipy==1.2.1; call sites motion_spline.py:86,92)
+  * sklearn GaussianMixture.score_samples / sample / _compute_precision_cholesky
+    (reference pins scikit_learn==0.23.2; call sites motion_primitive.py:136-144,189)
+"""
+import math
+import numpy as np
+
+B_SPLINE_DEGREE = 3  # morphablegraphs/motion_model/__init__.py:7
+
+
+# --------------------------------------------------------------------------
+# knots and FITPACK B-spline evaluation
+# --------------------------------------------------------------------------
+def cubic_b_spline_knots(n_basis, n_canonical_frames):
+    """morphablegraphs/construction/utils.py:187-198 (get_cubic_b_spline_knots)."""
+    knots = np.zeros(4 + n_basis)
+    knots[3:-3] = np.linspace(0, n_canonical_frames - 1, n_basis - 2)
+    knots[-3:] = n_canonical_frames - 1
+    return knots
+
+
+def fitpack_find_span(t, k, x):
+    """FITPACK splev.f interval search: returns 0-based l with t[l] <= x < t[l+1],
+    clamped to [k, n-k-2].  Points outside [t[k], t[n-k-1]] keep the first/last
+    interval, i.e. ext=0 extrapolates with the end polynomial (the only mode
+    motion_spline.py:86,92 uses)."""
+    n = len(t)
+    l = k
+    while not (x < t[l + 1] or l == n - k - 2):
+        l += 1
+    return l
+
+
+def fitpack_basis(t, k, x, l):
+    """FITPACK fpbspl.f: the k+1 non-zero B-splines of degree k at x on span l
+    (0-based), evaluated with the de Boor-Cox recurrence in fpbspl's operation order."""
+    h = [0.0] * (k + 2)
+    hh = [0.0] * (k + 1)
+    h[0] = 1.0
+    for j in range(1, k + 1):
+        for i in range(j):
+            hh[i] = h[i]
+        h[0] = 0.0
+        for i in range(1, j + 1):
+            li = l + i
+            lj = li - j
+            if t[li] == t[lj]:
+                h[i] = 0.0
+                continue
+            f = hh[i - 1] / (t[li] - t[lj])
+            h[i - 1] = h[i - 1] + f * (t[li] - x)
+            h[i] = f * (x - t[lj])
+    return h[:k + 1]
+
+
+def basis_rows(knots, time_points, k=B_SPLINE_DEGREE):
+    """For every time point: first contributing coefficient index i0 (= l-k) and
+    the k+1 weights.  frames[f, d] = sum_j w[f, j] * coeffs[i0[f] + j, d]."""
+    knots = np.asarray(knots, dtype=np.float64)
+    tp = np.atleast_1d(np.asarray(time_points, dtype=np.float64))
+    i0 = np.empty(len(tp), dtype=np.int64)
+    w = np.empty((len(tp), k + 1), dtype=np.float64)
+    for f, x in enumerate(tp):
+        l = fitpack_find_span(knots, k, x)
+        i0[f] = l - k
+        w[f] = fitpack_basis(knots, k, x, l)
+    return i0, w
+
+
+def splev(time_points, knots, coeffs_1d, k=B_SPLINE_DEGREE):
+    """scipy.interpolate.splev(x, (t, c, k)) restated (ext=0)."""
+    i0, w = basis_rows(knots, time_points, k)
+    c = np.asarray(coeffs_1d, dtype=np.float64)
+    out = np.zeros(len(i0))
+    for j in range(k + 1):          # splev.f: sp = sp + c(ll)*h(j), j ascending
+        out = out + c[i0 + j] * w[:, j]
+    return out
+
+
+def spline_frames(knots, coeffs, time_points, k=B_SPLINE_DEGREE):
+    """motion_spline.py:71-92: all channels of coeffs (NB, D) at time_points -> (T, D)."""
+    i0, w = basis_rows(knots, time_points, k)
+    coeffs = np.asarray(coeffs, dtype=np.float64)
+    out = np.zeros((len(i0), coeffs.shape[1]))
+    for j in range(k + 1):
+        out = out + coeffs[i0 + j, :] * w[:, j:j + 1]
+    return out
+
+
+# --------------------------------------------------------------------------
+# Gaussian mixture (sklearn restated)
+# --------------------------------------------------------------------------
+def precision_cholesky(covars):
+    """sklearn _compute_precision_cholesky(covariance_type='full'), used at
+    motion_primitive.py:141-142 and motion_primitive_wrapper.py:366:
+    P_k = solve_triangular(cholesky(S_k, lower), I, lower).T  (upper triangular)."""
+    covars = np.asarray(covars, dtype=np.float64)
+    K, L, _ = covars.shape
+    out = np.empty_like(covars)
+    for k in range(K):
+        c = np.linalg.cholesky(covars[k])
+        # forward substitution, column by column of the identity
+        inv = np.zeros((L, L))
+        for col in range(L):
+            for r in range(col, L):
+                s = 1.0 if r == col else 0.0
+                s -= np.dot(c[r, col:r], inv[col:r, col])
+                inv[r, col] = s / c[r, r]
+        out[k] = inv.T
+    return out
+
+
+def gmm_component_log_prob(X, weights, means, prec_chol):
+    """Weighted per-component log densities, (B, K):
+    log w_k - 0.5 (L log 2pi + ||(x-mu_k) P_k||^2) + sum log diag P_k
+    (sklearn _estimate_log_gaussian_prob + _estimate_log_weights; formula twin at
+    morphablegraphs/motion_model/extended_mgrd_mixture_model.py:60-108)."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+    K, L = means.shape
+    out = np.empty((X.shape[0], K))
+    for k in range(K):
+        y = (X - means[k]) @ prec_chol[k]
+        log_det = np.sum(np.log(np.diagonal(prec_chol[k])))
+        out[:, k] = -0.5 * (L * math.log(2.0 * math.pi) + np.sum(y * y, axis=1)) + log_det + math.log(weights[k])
+    return out
+
+
+def logsumexp_rows(a):
+    """extended_mgrd_mixture_model.py:85-96 (max-shifted log-sum-exp)."""
+    vmax = a.max(axis=1)
+    return np.log(np.sum(np.exp(a - vmax[:, None]), axis=1)) + vmax
+
+
+def gmm_log_prob(X, weights, means, prec_chol):
+    """Per-sample log p(x) == sklearn GaussianMixture.score_samples(X)."""
+    return logsumexp_rows(gmm_component_log_prob(X, weights, means, prec_chol))
+
+
+def gmm_sample(n_samples, weights, means, covars, rng):
+    """sklearn GaussianMixture.sample restated (motion_primitive.py:189):
+    counts = multinomial(n, w); rows grouped by component, not shuffled."""
+    counts = rng.multinomial(n_samples, weights)
+    X = np.vstack([rng.multivariate_normal(m, c, int(cnt)) for m, c, cnt in zip(means, covars, counts)])
+    y = np.concatenate([np.full(int(cnt), j, dtype=int) for j, cnt in enumerate(counts)])
+    return X, y
+
+
+# --------------------------------------------------------------------------
+# candidate scoring
+# --------------------------------------------------------------------------
+def first_min_argmin(errors):
+    """motion_primitive_generator.py:251-257: strict '>' keeps the FIRST minimum;
+    returns (0, inf) for an empty list, NaN errors never win."""
+    best_idx, min_error = 0, np.inf
+    for idx, e in enumerate(errors):
+        if min_error > e:
+            min_error, best_idx = e, idx
+    return best_idx, min_error
+
+
+def point_distance(target, p):
+    """global_transform_constraint.py:135-143: distance ignoring None axes."""
+    d = 0.0
+    for i in range(3):
+        if target[i] is not None and not (isinstance(target[i], float) and math.isnan(target[i])):
+            d += (target[i] - p[i]) ** 2
+    return math.sqrt(d)
+
+
+def quaternion_rotate(q, v):
+    """Rotate v by unit-or-not quaternion q = (w, x, y, z) through the rotation
+    matrix of q (as transformations.quaternion_matrix does: normalises by |q|^2)."""
+    w, x, y, z = [float(c) for c in q]
+    n = w * w + x * x + y * y + z * z
+    s = 2.0 / n
+    m = np.array([[1 - s * (y * y + z * z), s * (x * y - z * w), s * (x * z + y * w)],
+                  [s * (x * y + z * w), 1 - s * (x * x + z * z), s * (y * z - x * w)],
+                  [s * (x * z - y * w), s * (y * z + x * w), 1 - s * (x * x + y * y)]])
+    return m @ np.asarray(v, dtype=np.float64)
+
+
+def direction_2d_error(target_dir_xz, root_quat, ref_dir=(0.0, 0.0, 1.0)):
+    """direction_2d_constraint.py:42-52 with the anim_utils FK call replaced by its
+    root-joint special case (PARITY UNPINNED: anim_utils source is not under
+    /root/reference).  Heading = xz of the root rotation applied to ref_dir."""
+    t = np.asarray(target_dir_xz, dtype=np.float64)
+    t = t / np.linalg.norm(t)
+    p = quaternion_rotate(root_quat, ref_dir)
+    m = np.array([p[0], p[2]])
+    m = m / np.linalg.norm(m)
+    cos_angle = float(np.dot(t, m) / (np.linalg.norm(t) * np.linalg.norm(m)))
+    cos_angle = min(1.0, max(cos_angle, -1.0))
+    return abs(math.degrees(math.acos(cos_angle)))
+
+
+# --------------------------------------------------------------------------
+# the primitive
+# --------------------------------------------------------------------------
+class OraclePrimitive(object):
+    """motion_primitive.py:41-256 restated for the use_time_parameters=False path."""
+
+    def __init__(self, data):
+        # motion_primitive.py:96-163
+        self.name = data.get("name", "")
+        self.n_canonical_frames = int(data["n_canonical_frames"])
+        self.translation_maxima = np.array(data["translation_maxima"], dtype=np.float64)
+        self.eigen_vectors = np.transpose(np.array(data["eigen_vectors_spatial"], dtype=np.float64))  # (NB*D, L)
+        self.mean_vector = np.array(data["mean_spatial_vector"], dtype=np.float64)
+        self.n_basis = int(data["n_basis_spatial"])
+        self.n_dim = int(data["n_dim_spatial"])
+        self.n_components = self.eigen_vectors.shape[1]
+        self.knots = np.asarray(data["b_spline_knots_spatial"], dtype=np.float64)
+        self.weights = np.array(data["gmm_weights"], dtype=np.float64)
+        self.means = np.array(data["gmm_means"], dtype=np.float64)
+        self.covars = np.array(data["gmm_covars"], dtype=np.float64)
+        self.prec_chol = precision_cholesky(self.covars)
+
+    # motion_primitive.py:236-256
+    def back_project_spatial_coeffs(self, alpha):
+        coefs = np.dot(self.eigen_vectors, np.asarray(alpha, dtype=np.float64))
+        coefs = coefs + self.mean_vector
+        coefs = coefs.reshape((self.n_basis, self.n_dim))
+        coefs[:, :3] *= self.translation_maxima
+        return coefs
+
+    # motion_primitive.py:233
+    def canonical_time_function(self, speed=1.0):
+        return np.linspace(0, self.n_canonical_frames, int(self.n_canonical_frames * (1.0 / speed)))
+
+    # motion_primitive.py:206-234 + motion_spline.py:71-86
+    def back_project_frames(self, s, time_points=None):
+        coeffs = self.back_project_spatial_coeffs(np.asarray(s)[:self.n_components])
+        tp = self.canonical_time_function() if time_points is None else time_points
+        return spline_frames(self.knots, coeffs, tp)
+
+    def back_project_frames_batch(self, S, time_points=None):
+        """Vectorised over candidates: (B, L) -> (B, T, D)."""
+        S = np.atleast_2d(np.asarray(S, dtype=np.float64))
+        tp = self.canonical_time_function() if time_points is None else np.atleast_1d(time_points)
+        i0, w = basis_rows(self.knots, tp)
+        coeffs = S[:, :self.n_components] @ self.eigen_vectors.T + self.mean_vector
+        coeffs = coeffs.reshape(S.shape[0], self.n_basis, self.n_dim)
+        coeffs[:, :, :3] *= self.translation_maxima
+        out = np.zeros((S.shape[0], len(tp), self.n_dim))
+        for j in range(4):
+            out = out + coeffs[:, i0 + j, :] * w[None, :, j:j + 1]
+        return out
+
+    def score_samples(self, X):
+        return gmm_log_prob(X, self.weights, self.means, self.prec_chol)
+
+    def sample_low_dimensional_vector(self, n_samples=1, rng=None):
+        rng = np.random.mtrand._rand if rng is None else rng
+        return gmm_sample(n_samples, self.weights, self.means, self.covars, rng)[0]
+
+    # motion_primitive_constraints.py:100-122 restricted to the FK-free constraints
+    def keyframe_errors(self, S, constraints):
+        """constraints: list of dicts {"type": "position"|"direction", "t": float,
+        "weight": w, "target": [x|None,y|None,z|None] or [dx, dz]}.  Root joint only."""
+        S = np.atleast_2d(S)
+        out = np.zeros(S.shape[0])
+        for b in range(S.shape[0]):
+            coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
+            err = 0.0
+            for c in constraints:
+                frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
+                if c["type"] == "position":
+                    err += c["weight"] * point_distance(c["target"], frame[:3])
+                else:
+                    err += c["weight"] * direction_2d_error(c["target"], frame[3:7], c.get("ref_dir", (0, 0, 1)))
+            out[b] = err
+        return out

@@ -1,0 +1,82 @@
+"""The NumPy oracle against the golden vectors made by the reference's own code
+(oracle/gen_golden.py).  CPU only."""
+import numpy as np
+
+from oracle import mg_oracle as orc
+
+
+def test_back_project_coeffs_and_frames(golden_case):
+    name, data, g = golden_case
+    prim = orc.OraclePrimitive(data)
+    S = g["S"]
+    for b in range(S.shape[0]):
+        c = prim.back_project_spatial_coeffs(S[b])
+        np.testing.assert_allclose(c, g["coeffs"][b], rtol=0, atol=1e-12 * max(1.0, np.abs(g["coeffs"][b]).max()))
+        f = prim.back_project_frames(S[b])
+        assert f.shape == g["frames"][b].shape                      # (F, D) indexing is exact
+        np.testing.assert_allclose(f, g["frames"][b], rtol=0, atol=2e-12 * max(1.0, np.abs(g["frames"][b]).max()))
+    fb = prim.back_project_frames_batch(S)
+    np.testing.assert_allclose(fb, g["frames"], rtol=0, atol=2e-12 * max(1.0, np.abs(g["frames"]).max()))
+
+
+def test_time_function_and_knots(golden_case):
+    name, data, g = golden_case
+    prim = orc.OraclePrimitive(data)
+    np.testing.assert_array_equal(prim.canonical_time_function(), g["time_function"])
+    np.testing.assert_array_equal(orc.cubic_b_spline_knots(prim.n_basis, prim.n_canonical_frames), g["knots"])
+    assert prim.n_components == int(g["n_spatial_components"])
+
+
+def test_evaluate_arbitrary_times(golden_case):
+    name, data, g = golden_case
+    prim = orc.OraclePrimitive(data)
+    S, times = g["S"], g["eval_times"]
+    for b in range(S.shape[0]):
+        c = prim.back_project_spatial_coeffs(S[b])
+        e = orc.spline_frames(prim.knots, c, times)
+        np.testing.assert_allclose(e, g["evals"][b], rtol=0, atol=2e-12 * max(1.0, np.abs(g["evals"][b]).max()))
+    c0 = prim.back_project_spatial_coeffs(S[0])
+    for i, t in enumerate(times):
+        e = orc.spline_frames(prim.knots, c0, [t])[0]
+        np.testing.assert_allclose(e, g["evals_scalar"][i], rtol=0, atol=2e-12 * max(1.0, np.abs(g["evals_scalar"]).max()))
+
+
+def test_splev_against_installed_scipy():
+    import scipy.interpolate as si
+    rng = np.random.default_rng(3)
+    for nb, F in ((7, 12), (31, 156), (8, 40), (4, 9)):
+        knots = orc.cubic_b_spline_knots(nb, F)
+        c = rng.standard_normal(nb)
+        x = np.concatenate([np.linspace(-1.0, F + 1.0, 301), knots])
+        np.testing.assert_allclose(orc.splev(x, knots, c), si.splev(x, (knots, c, 3)), rtol=0, atol=1e-12)
+
+
+def test_precision_cholesky_and_log_prob(golden_case):
+    name, data, g = golden_case
+    prim = orc.OraclePrimitive(data)
+    pc = g["precisions_cholesky"]
+    np.testing.assert_allclose(prim.prec_chol, pc, rtol=1e-9, atol=1e-9 * np.abs(pc).max())
+    lp = prim.score_samples(g["X"])
+    np.testing.assert_allclose(lp, g["logp"], rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(prim.score_samples(g["S"]), g["logp_S"], rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(lp.mean(), float(g["score_mean"]), rtol=1e-9, atol=1e-7)
+
+
+def test_sample_matches_sklearn_stream(golden_case):
+    name, data, g = golden_case
+    prim = orc.OraclePrimitive(data)
+    np.random.seed(int(g["seed"]))
+    S = prim.sample_low_dimensional_vector(g["S"].shape[0])
+    np.testing.assert_allclose(S, g["S"], rtol=1e-12, atol=1e-12)
+
+
+def test_first_min_argmin_rule():
+    assert orc.first_min_argmin([3.0, 1.0, 1.0, 2.0]) == (1, 1.0)
+    assert orc.first_min_argmin([]) == (0, np.inf)
+    assert orc.first_min_argmin([np.nan, 2.0, np.nan, 2.0]) == (1, 2.0)
+    assert orc.first_min_argmin([np.inf, np.inf])[0] == 0
+
+
+def test_point_distance_ignores_none_axes():
+    assert orc.point_distance([1.0, None, 3.0], [0.0, 100.0, 1.0]) == np.sqrt(1.0 + 4.0)
+    assert orc.point_distance([None, None, None], [1.0, 2.0, 3.0]) == 0.0
