@@ -1,0 +1,238 @@
+/* mg_hip.h -- C ABI of the MI355X (gfx950) motion-primitive back-projection /
+ * GMM-scoring library (libmg_hip.so).
+ *
+ * The reference (dfki-asr/morphablegraphs) is 100 % Python and has no FFI; the
+ * seam this library sits behind is the duck-typed attribute
+ * MotionPrimitiveModelWrapper.motion_primitive
+ * (reference morphablegraphs/motion_model/motion_primitive_wrapper.py:49-53,61-85)
+ * and the batched scoring seam MotionPrimitiveGenerator.evaluate_samples_using_constraints
+ * (reference morphablegraphs/motion_generator/motion_primitive_generator.py:230-261).
+ * Each entry point below names the reference function it replaces.  The ctypes
+ * stub a maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions: extern "C", opaque handles, plain pointers and sizes, int status
+ * return (0 = MG_OK, negative = error; text via mg_last_error()), no exceptions
+ * cross the boundary, caller-owned buffers.  One context per (process, device);
+ * one handle <-> one host thread.  Pointers named *_dev are device pointers on
+ * the context's device, everything else is host memory.  All device work is
+ * enqueued on the context's stream; *_host convenience entry points synchronise.
+ *
+ * Index layout is the reference's and is exact: frames[b][f][d] row-major with
+ * d < 3 root translation and 3+4j..3+4j+3 the (w,x,y,z) quaternion of joint j;
+ * coefficient flat index = coeff_idx * n_dim + d.
+ */
+#ifndef MG_HIP_H
+#define MG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mg_context mg_context;
+typedef struct mg_primitive mg_primitive;
+typedef struct mg_time_grid mg_time_grid;
+typedef struct mg_constraint_set mg_constraint_set;
+
+enum {
+    MG_OK = 0,
+    MG_ERR_INVALID_ARGUMENT = -1,
+    MG_ERR_NO_DEVICE = -2,      /* no HIP device / HIP runtime error at init  */
+    MG_ERR_HIP = -3,            /* a HIP call failed; see mg_last_error()     */
+    MG_ERR_UNSUPPORTED = -4,    /* shape outside what the kernels support     */
+    MG_ERR_NOT_POSITIVE_DEFINITE = -5,
+    MG_ERR_OUT_OF_MEMORY = -6
+};
+
+/* element types of latent inputs / score outputs */
+enum { MG_F32 = 0, MG_F64 = 1 };
+
+/* which kernel back_project_frames uses */
+enum {
+    MG_PATH_AUTO = 0,   /* MFMA tile kernel when it fits, else direct */
+    MG_PATH_MFMA = 1,   /* LDS-staged f32 MFMA contraction + spline    */
+    MG_PATH_DIRECT = 2  /* one thread per output element               */
+};
+
+/* Model arrays exactly as the reference's JSON holds them
+ * (reference motion_primitive.py:126-163, _init_gmm_from_json /
+ * _init_spatial_parameters_from_json).  All float64, host memory. */
+typedef struct mg_primitive_desc {
+    int32_t n_basis;             /* n_basis_spatial                                   */
+    int32_t n_dim;               /* n_dim_spatial                                     */
+    int32_t n_components;        /* L = rows of eigen_vectors_spatial                 */
+    int32_t n_canonical_frames;  /* n_canonical_frames                                */
+    int32_t n_gmm;               /* K = len(gmm_weights); 0 = no mixture              */
+    int32_t eigen_is_transposed; /* 0: JSON layout (L, NB*D); 1: (NB*D, L) as loaded  */
+    const double *eigen_vectors; /* eigen_vectors_spatial                             */
+    const double *mean_vector;   /* mean_spatial_vector (NB*D)                        */
+    const double *translation_maxima; /* 3 values; NULL = [1,1,1] (v3 load path)      */
+    const double *knots;         /* b_spline_knots_spatial (NB+4)                     */
+    const double *gmm_weights;   /* (K)                                               */
+    const double *gmm_means;     /* (K, L)                                            */
+    const double *gmm_covars;    /* (K, L, L)                                         */
+} mg_primitive_desc;
+
+/* One keyframe constraint on the ROOT joint, the FK-free subset of
+ * MotionPrimitiveConstraints.evaluate (reference
+ * morphablegraphs/constraints/motion_primitive_constraints.py:100-122):
+ *  MG_CONSTRAINT_POSITION  -> GlobalTransformConstraint._point_distance
+ *      (reference .../keyframe_constraints/global_transform_constraint.py:135-143),
+ *      target axes set to NaN are unconstrained (the reference's None);
+ *  MG_CONSTRAINT_DIRECTION_2D -> Direction2DConstraint.evaluate_motion_spline
+ *      (reference .../keyframe_constraints/direction_2d_constraint.py:42-52), heading =
+ *      xz of the root quaternion applied to ref_dir, error in degrees. */
+enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1 };
+typedef struct mg_keyframe_constraint {
+    int32_t type;
+    int32_t reserved;
+    double canonical_keyframe;  /* t; may be fractional (graph_walk_planner.py:203) */
+    double weight_factor;
+    double target[3];           /* position xyz (NaN = free) or direction (x, z, unused) */
+    double ref_dir[3];          /* direction only: skeleton.aligning_root_dir, e.g. (0,0,1) */
+} mg_keyframe_constraint;
+
+/* ---- library / context ------------------------------------------------------ */
+const char *mg_version(void);
+/* message of the last failed call on this thread */
+const char *mg_last_error(void);
+const char *mg_status_string(int status);
+
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream) or NULL for a
+ * stream owned by the context. */
+int mg_context_create(int device, void *stream, mg_context **out);
+void mg_context_destroy(mg_context *ctx);
+int mg_context_set_stream(mg_context *ctx, void *stream);
+int mg_context_synchronize(mg_context *ctx);
+/* name (256 bytes), CU count, total bytes of the context's device */
+int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *total_mem);
+
+/* plain device memory helpers so a host language needs no HIP binding of its own */
+int mg_device_malloc(mg_context *ctx, int64_t bytes, void **out_dev);
+int mg_device_free(mg_context *ctx, void *ptr_dev);
+int mg_memcpy_h2d(mg_context *ctx, void *dst_dev, const void *src, int64_t bytes);
+int mg_memcpy_d2h(mg_context *ctx, void *dst, const void *src_dev, int64_t bytes);
+int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);
+
+/* Kernel timing with HIP events on the context's stream.  When enabled, each hot
+ * kernel launch is bracketed by an event pair; totals are resolved on query.
+ * slot: 0 = back_project_frames, 1 = gmm_log_prob, 2 = score_constraints, 3 = argmin,
+ *       4 = gmm_sample, 5 = spline_evaluate, 6 = fused step. */
+int mg_profile_enable(mg_context *ctx, int enabled);
+int mg_profile_reset(mg_context *ctx);
+int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64_t *launches);
+
+/* ---- primitive -------------------------------------------------------------------
+ * Replaces MotionPrimitive._initialize_from_json (reference motion_primitive.py:96-163):
+ * transposes/scales/packs the eigenvectors, computes precisions_cholesky_ in float64
+ * on the host exactly as sklearn's _compute_precision_cholesky does
+ * (reference motion_primitive.py:141-142) and uploads all constants once. */
+int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *desc, mg_primitive **out);
+void mg_primitive_destroy(mg_primitive *prim);
+/* out[8] = {n_basis, n_dim, n_components, n_canonical_frames, n_gmm, kk (MFMA k-steps),
+ *           mfma_supported, reserved} */
+int mg_primitive_info(const mg_primitive *prim, int32_t *out8);
+/* (K, L, L) float64, upper triangular: sklearn's precisions_cholesky_ */
+int mg_primitive_get_precisions_cholesky(const mg_primitive *prim, double *out);
+
+/* ---- time grids ---------------------------------------------------------------------
+ * A set of canonical times with its B-spline basis rows (FITPACK splev semantics,
+ * ext=0 extrapolation; reference motion_spline.py:86,92) and mean frames, prepared
+ * once in float64 on the host.  mg_primitive_canonical_grid = np.linspace(0, F, F)
+ * (reference motion_primitive.py:233), owned by the primitive. */
+int mg_time_grid_create(mg_primitive *prim, const double *times, int32_t n_times, mg_time_grid **out);
+void mg_time_grid_destroy(mg_time_grid *grid);
+mg_time_grid *mg_primitive_canonical_grid(mg_primitive *prim);
+int mg_time_grid_size(const mg_time_grid *grid);
+/* copies the grid's tables: i0 (T) int32, weights (T,4) float64, times (T) float64; any may be NULL */
+int mg_time_grid_get_tables(const mg_time_grid *grid, int32_t *i0, double *weights, double *times);
+
+/* ---- hot path, device pointers ------------------------------------------------------ */
+
+/* MotionPrimitive.back_project(s, False).get_motion_vector() for a batch
+ * (reference motion_primitive.py:206-256 + motion_spline.py:71-86), or
+ * MotionSpline.evaluate(t) when grid holds arbitrary times (motion_spline.py:89-92).
+ * latents: (B, ld) of latent_dtype, first n_components columns used.
+ * frames_dev: (B, T, D) float32, written completely.  grid NULL = canonical grid. */
+int mg_back_project_frames(mg_primitive *prim, const mg_time_grid *grid,
+                           const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,
+                           float *frames_dev, int path);
+
+/* Same in float64 throughout (all channels), frames_dev (B, T, D) float64.  Used by the
+ * single-sample adaptor calls where the reference's float64 results are expected. */
+int mg_back_project_frames_f64(mg_primitive *prim, const mg_time_grid *grid,
+                               const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,
+                               double *frames_dev);
+
+/* MotionPrimitive.back_project_spatial_coeffs for a batch
+ * (reference motion_primitive.py:236-256): coeffs_dev (B, NB, D), float64 when
+ * out_dtype == MG_F64 else float32. */
+int mg_back_project_coeffs(mg_primitive *prim, const void *latents_dev, int latent_dtype,
+                           int64_t n_samples, int64_t ld, void *coeffs_dev, int out_dtype);
+
+/* MotionSpline.get_motion_vector()/evaluate(t) from explicit coefficient arrays
+ * (reference motion_spline.py:71-92; callers overwrite spline.coeffs with aligned
+ * coefficients, motion_primitive_constraints.py:113): coeffs_dev (n, NB, D) float64 ->
+ * frames_dev (n, T, D) float64. */
+int mg_spline_evaluate(mg_primitive *prim, const mg_time_grid *grid, const double *coeffs_dev,
+                       int64_t n_splines, double *frames_dev);
+
+/* GaussianMixture.score_samples (reference motion_primitive.py:126-144; formula twin
+ * extended_mgrd_mixture_model.py:60-108): per-row log p(x), float64 arithmetic.
+ * x_dev (B, ld) of x_dtype; logp_dev (B) of out_dtype. */
+int mg_gmm_log_prob(mg_primitive *prim, const void *x_dev, int x_dtype, int64_t n_samples, int64_t ld,
+                    void *logp_dev, int out_dtype);
+
+/* GaussianMixture.sample on the device (reference motion_primitive.py:182-189):
+ * Philox4x32-10 + Cholesky; rows grouped by component like sklearn, but NOT
+ * bit-compatible with sklearn's Mersenne stream (validated distributionally).
+ * counts: host array (K) of rows per component summing to n_samples.
+ * x_dev (n, ld) of x_dtype, component_dev (n) int32 or NULL. */
+int mg_gmm_sample(mg_primitive *prim, int64_t n_samples, const int64_t *counts, uint64_t seed,
+                  void *x_dev, int x_dtype, int64_t ld, int32_t *component_dev);
+
+/* ---- fused candidate scoring ------------------------------------------------------------
+ * MotionPrimitiveConstraints.evaluate summed over root-joint keyframe constraints
+ * (reference motion_primitive_constraints.py:100-122, local-coordinate mode: no
+ * alignment), float64 arithmetic, without materialising frames. */
+int mg_constraint_set_create(mg_primitive *prim, const mg_keyframe_constraint *cons, int32_t n,
+                             mg_constraint_set **out);
+void mg_constraint_set_destroy(mg_constraint_set *cs);
+int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
+                         const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,
+                         void *errors_dev, int out_dtype);
+
+/* The argmin rule of evaluate_samples_using_constraints
+ * (reference motion_primitive_generator.py:251-257): FIRST strict minimum, NaN never
+ * wins, (0, +inf) when nothing wins.  values_dev (n) of dtype; result written to host. */
+int mg_argmin_first(mg_context *ctx, const void *values_dev, int dtype, int64_t n,
+                    int64_t *best_index, double *min_value);
+/* device-side result for use inside a stream: out_dev = {int64 index, float64 value} (16 bytes) */
+int mg_argmin_first_dev(mg_context *ctx, const void *values_dev, int dtype, int64_t n, void *out_dev);
+
+/* One bench "step": frames (float32, MFMA path) + log p(x) (float32) for the same
+ * latent batch, enqueued back to back on the context's stream. */
+int mg_step_frames_and_logp(mg_primitive *prim, const void *latents_dev, int latent_dtype,
+                            int64_t n_samples, int64_t ld, float *frames_dev, float *logp_dev);
+
+/* ---- host-pointer convenience variants (H2D, launch, D2H, synchronise) ---------------- */
+int mg_back_project_frames_host(mg_primitive *prim, const mg_time_grid *grid, const void *latents,
+                                int latent_dtype, int64_t n_samples, int64_t ld, float *frames, int path);
+int mg_back_project_frames_f64_host(mg_primitive *prim, const mg_time_grid *grid, const void *latents,
+                                    int latent_dtype, int64_t n_samples, int64_t ld, double *frames);
+int mg_back_project_coeffs_host(mg_primitive *prim, const void *latents, int latent_dtype,
+                                int64_t n_samples, int64_t ld, void *coeffs, int out_dtype);
+int mg_spline_evaluate_host(mg_primitive *prim, const mg_time_grid *grid, const double *coeffs,
+                            int64_t n_splines, double *frames);
+int mg_gmm_log_prob_host(mg_primitive *prim, const void *x, int x_dtype, int64_t n_samples, int64_t ld,
+                         void *logp, int out_dtype);
+int mg_gmm_sample_host(mg_primitive *prim, int64_t n_samples, const int64_t *counts, uint64_t seed,
+                       void *x, int x_dtype, int64_t ld, int32_t *component);
+int mg_score_constraints_host(mg_primitive *prim, const mg_constraint_set *cs, const void *latents,
+                              int latent_dtype, int64_t n_samples, int64_t ld, void *errors, int out_dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MG_HIP_H */

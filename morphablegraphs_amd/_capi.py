@@ -1,0 +1,479 @@
+"""ctypes binding of libmg_hip.so (include/mg_hip.h) -- the only way host code reaches
+the HIP kernels.  There is no CPU fallback: if the library or a gfx950 device is missing
+every compute call raises.
+
+The thin object layer here (Context / Primitive / TimeGrid / ConstraintSet / DeviceBuffer)
+only owns handles and converts NumPy arrays; the reference-shaped classes live in
+motion_primitive.py / motion_spline.py / gaussian_mixture.py.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmg_hip.so")
+
+MG_OK = 0
+MG_F32, MG_F64 = 0, 1
+MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
+MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D = 0, 1
+PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
+                 "gmm_sample": 4, "spline_evaluate": 5, "step": 6}
+
+# every symbol include/mg_hip.h declares (tests check the built library exports them all)
+EXPORTED_SYMBOLS = [
+    "mg_version", "mg_last_error", "mg_status_string",
+    "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_synchronize",
+    "mg_context_device_info", "mg_device_malloc", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
+    "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get",
+    "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_get_precisions_cholesky",
+    "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
+    "mg_time_grid_get_tables",
+    "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
+    "mg_gmm_log_prob", "mg_gmm_sample", "mg_constraint_set_create", "mg_constraint_set_destroy",
+    "mg_score_constraints", "mg_argmin_first", "mg_argmin_first_dev", "mg_step_frames_and_logp",
+    "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
+    "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
+]
+
+
+class MGError(RuntimeError):
+    def __init__(self, status, message):
+        RuntimeError.__init__(self, "libmg_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+class PrimitiveDesc(C.Structure):
+    _fields_ = [("n_basis", C.c_int32), ("n_dim", C.c_int32), ("n_components", C.c_int32),
+                ("n_canonical_frames", C.c_int32), ("n_gmm", C.c_int32), ("eigen_is_transposed", C.c_int32),
+                ("eigen_vectors", C.c_void_p), ("mean_vector", C.c_void_p), ("translation_maxima", C.c_void_p),
+                ("knots", C.c_void_p), ("gmm_weights", C.c_void_p), ("gmm_means", C.c_void_p),
+                ("gmm_covars", C.c_void_p)]
+
+
+class KeyframeConstraint(C.Structure):
+    _fields_ = [("type", C.c_int32), ("reserved", C.c_int32), ("canonical_keyframe", C.c_double),
+                ("weight_factor", C.c_double), ("target", C.c_double * 3), ("ref_dir", C.c_double * 3)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libmg_hip.so; raises OSError with a build hint if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError("libmg_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "or `make -C morphablegraphs_amd/csrc` (there is no CPU fallback)" % p)
+    lib = C.CDLL(p)
+    lib.mg_version.restype = C.c_char_p
+    lib.mg_last_error.restype = C.c_char_p
+    lib.mg_status_string.restype = C.c_char_p
+    lib.mg_status_string.argtypes = [C.c_int]
+    lib.mg_primitive_canonical_grid.restype = C.c_void_p
+    lib.mg_primitive_canonical_grid.argtypes = [C.c_void_p]
+    lib.mg_time_grid_size.argtypes = [C.c_void_p]
+    for name in ("mg_context_destroy", "mg_primitive_destroy", "mg_time_grid_destroy", "mg_constraint_set_destroy"):
+        getattr(lib, name).restype = None
+        getattr(lib, name).argtypes = [C.c_void_p]
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
+    sigs = {
+        "mg_context_create": [i32, vp, C.POINTER(vp)],
+        "mg_context_set_stream": [vp, vp],
+        "mg_context_synchronize": [vp],
+        "mg_context_device_info": [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(i64)],
+        "mg_device_malloc": [vp, i64, C.POINTER(vp)],
+        "mg_device_free": [vp, vp],
+        "mg_memcpy_h2d": [vp, vp, vp, i64],
+        "mg_memcpy_d2h": [vp, vp, vp, i64],
+        "mg_memset": [vp, vp, i32, i64],
+        "mg_profile_enable": [vp, i32],
+        "mg_profile_reset": [vp],
+        "mg_profile_get": [vp, i32, C.POINTER(dbl), C.POINTER(i64)],
+        "mg_primitive_create": [vp, C.POINTER(PrimitiveDesc), C.POINTER(vp)],
+        "mg_primitive_info": [vp, C.POINTER(C.c_int32)],
+        "mg_primitive_get_precisions_cholesky": [vp, vp],
+        "mg_time_grid_create": [vp, vp, C.c_int32, C.POINTER(vp)],
+        "mg_time_grid_get_tables": [vp, vp, vp, vp],
+        "mg_back_project_frames": [vp, vp, vp, i32, i64, i64, vp, i32],
+        "mg_back_project_frames_f64": [vp, vp, vp, i32, i64, i64, vp],
+        "mg_back_project_coeffs": [vp, vp, i32, i64, i64, vp, i32],
+        "mg_spline_evaluate": [vp, vp, vp, i64, vp],
+        "mg_gmm_log_prob": [vp, vp, i32, i64, i64, vp, i32],
+        "mg_gmm_sample": [vp, i64, vp, u64, vp, i32, i64, vp],
+        "mg_constraint_set_create": [vp, vp, C.c_int32, C.POINTER(vp)],
+        "mg_score_constraints": [vp, vp, vp, i32, i64, i64, vp, i32],
+        "mg_argmin_first": [vp, vp, i32, i64, C.POINTER(i64), C.POINTER(dbl)],
+        "mg_argmin_first_dev": [vp, vp, i32, i64, vp],
+        "mg_step_frames_and_logp": [vp, vp, i32, i64, i64, vp, vp],
+        "mg_back_project_frames_host": [vp, vp, vp, i32, i64, i64, vp, i32],
+        "mg_back_project_frames_f64_host": [vp, vp, vp, i32, i64, i64, vp],
+        "mg_back_project_coeffs_host": [vp, vp, i32, i64, i64, vp, i32],
+        "mg_spline_evaluate_host": [vp, vp, vp, i64, vp],
+        "mg_gmm_log_prob_host": [vp, vp, i32, i64, i64, vp, i32],
+        "mg_gmm_sample_host": [vp, i64, vp, u64, vp, i32, i64, vp],
+        "mg_score_constraints_host": [vp, vp, vp, i32, i64, i64, vp, i32],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(status):
+    if status != MG_OK:
+        raise MGError(status, load_library().mg_last_error().decode("utf-8", "replace"))
+
+
+def _dtype_code(arr):
+    if arr.dtype == np.float32:
+        return MG_F32
+    if arr.dtype == np.float64:
+        return MG_F64
+    raise TypeError("expected float32 or float64 array, got %s" % arr.dtype)
+
+
+def _latents(a):
+    """2-D C-contiguous float32/float64 view of a latent batch."""
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2:
+        raise ValueError("latents must be (n_samples, n_components)")
+    return np.ascontiguousarray(a)
+
+
+class Context(object):
+    """One per (process, device).  stream: raw hipStream_t (int) or None."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib.mg_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.mg_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self.lib.mg_context_synchronize(self.handle))
+
+    def set_stream(self, stream):
+        _check(self.lib.mg_context_set_stream(self.handle, C.c_void_p(stream) if stream else None))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu, mem = C.c_int32(), C.c_int64()
+        _check(self.lib.mg_context_device_info(self.handle, name, C.byref(ncu), C.byref(mem)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "total_mem": mem.value}
+
+    def malloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, arr.nbytes)
+        _check(self.lib.mg_memcpy_h2d(self.handle, buf.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return buf
+
+    def download(self, buf, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        ptr = buf.ptr if isinstance(buf, DeviceBuffer) else C.c_void_p(int(buf))
+        _check(self.lib.mg_memcpy_d2h(self.handle, out.ctypes.data_as(C.c_void_p), ptr, out.nbytes))
+        return out
+
+    def profile_enable(self, on=True):
+        _check(self.lib.mg_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(self.lib.mg_profile_reset(self.handle))
+
+    def profile_get(self, slot):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.lib.mg_profile_get(self.handle, PROFILE_SLOTS.get(slot, slot), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def argmin_first(self, values_dev, n, dtype=np.float32):
+        idx, val = C.c_int64(), C.c_double()
+        ptr = values_dev.ptr if isinstance(values_dev, DeviceBuffer) else C.c_void_p(int(values_dev))
+        code = MG_F64 if np.dtype(dtype) == np.float64 else MG_F32
+        _check(self.lib.mg_argmin_first(self.handle, ptr, code, int(n), C.byref(idx), C.byref(val)))
+        return idx.value, val.value
+
+
+class DeviceBuffer(object):
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(ctx.lib.mg_device_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    @property
+    def address(self):
+        return self.ptr.value
+
+    def free(self):
+        if getattr(self, "ptr", None) and self.ctx.handle:
+            self.ctx.lib.mg_device_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _dev_ptr(x):
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    return C.c_void_p(int(x))
+
+
+class TimeGrid(object):
+    def __init__(self, prim, times=None, handle=None):
+        self.prim = prim
+        self.owned = handle is None
+        if handle is None:
+            t = np.ascontiguousarray(np.atleast_1d(times), dtype=np.float64)
+            h = C.c_void_p()
+            _check(prim.lib.mg_time_grid_create(prim.handle, t.ctypes.data_as(C.c_void_p), len(t), C.byref(h)))
+            handle = h
+        self.handle = handle
+        self.size = prim.lib.mg_time_grid_size(self.handle)
+
+    def tables(self):
+        i0 = np.empty(self.size, dtype=np.int32)
+        w = np.empty((self.size, 4))
+        t = np.empty(self.size)
+        _check(self.prim.lib.mg_time_grid_get_tables(self.handle, i0.ctypes.data_as(C.c_void_p),
+                                                     w.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p)))
+        return i0, w, t
+
+    def close(self):
+        if self.owned and getattr(self, "handle", None) and self.prim.handle:
+            self.prim.lib.mg_time_grid_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ConstraintSet(object):
+    """constraints: list of dicts {"type": "position"|"direction", "t": float, "weight": float,
+    "target": [x|None, y|None, z|None] | [dx, dz], "ref_dir": (rx, ry, rz)}."""
+
+    def __init__(self, prim, constraints):
+        self.prim = prim
+        n = len(constraints)
+        arr = (KeyframeConstraint * max(n, 1))()
+        for i, c in enumerate(constraints):
+            k = arr[i]
+            k.canonical_keyframe = float(c["t"])
+            k.weight_factor = float(c.get("weight", 1.0))
+            if c["type"] == "position":
+                k.type = MG_CONSTRAINT_POSITION
+                for a in range(3):
+                    v = c["target"][a]
+                    k.target[a] = float("nan") if v is None else float(v)
+            elif c["type"] == "direction":
+                k.type = MG_CONSTRAINT_DIRECTION_2D
+                k.target[0], k.target[1], k.target[2] = float(c["target"][0]), float(c["target"][1]), 0.0
+                rd = c.get("ref_dir", (0.0, 0.0, 1.0))
+                for a in range(3):
+                    k.ref_dir[a] = float(rd[a])
+            else:
+                raise ValueError("unknown constraint type %r" % (c["type"],))
+        h = C.c_void_p()
+        _check(prim.lib.mg_constraint_set_create(prim.handle, C.cast(arr, C.c_void_p), n, C.byref(h)))
+        self.handle = h
+        self.n = n
+
+    def close(self):
+        if getattr(self, "handle", None) and self.prim.handle:
+            self.prim.lib.mg_constraint_set_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Primitive(object):
+    """Device-resident constants of one motion primitive, built from the reference's JSON dict."""
+
+    def __init__(self, ctx, data):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        eig = np.ascontiguousarray(np.asarray(data["eigen_vectors_spatial"], dtype=np.float64))
+        mean = np.ascontiguousarray(np.asarray(data["mean_spatial_vector"], dtype=np.float64))
+        knots = np.ascontiguousarray(np.asarray(data["b_spline_knots_spatial"], dtype=np.float64))
+        tm = np.ascontiguousarray(np.asarray(data.get("translation_maxima", [1.0, 1.0, 1.0]), dtype=np.float64))
+        nb, nd = int(data["n_basis_spatial"]), int(data["n_dim_spatial"])
+        if eig.ndim != 2 or eig.shape[1] != nb * nd:
+            raise ValueError("eigen_vectors_spatial must be (n_components, n_basis*n_dim)")
+        if mean.shape != (nb * nd,) or knots.shape != (nb + 4,) or tm.shape != (3,):
+            raise ValueError("mean/knots/translation_maxima have the wrong shape")
+        d = PrimitiveDesc()
+        d.n_basis, d.n_dim, d.n_components = nb, nd, eig.shape[0]
+        d.n_canonical_frames = int(data["n_canonical_frames"])
+        d.eigen_is_transposed = 0
+        d.eigen_vectors = eig.ctypes.data
+        d.mean_vector = mean.ctypes.data
+        d.translation_maxima = tm.ctypes.data
+        d.knots = knots.ctypes.data
+        keep = [eig, mean, knots, tm]
+        if "gmm_weights" in data and data["gmm_weights"] is not None:
+            gw = np.ascontiguousarray(np.asarray(data["gmm_weights"], dtype=np.float64))
+            gm = np.ascontiguousarray(np.asarray(data["gmm_means"], dtype=np.float64))
+            gc = np.ascontiguousarray(np.asarray(data["gmm_covars"], dtype=np.float64))
+            L = eig.shape[0]
+            if gm.shape != (len(gw), L) or gc.shape != (len(gw), L, L):
+                raise ValueError("gmm_means/gmm_covars have the wrong shape")
+            d.n_gmm = len(gw)
+            d.gmm_weights, d.gmm_means, d.gmm_covars = gw.ctypes.data, gm.ctypes.data, gc.ctypes.data
+            keep += [gw, gm, gc]
+        else:
+            d.n_gmm = 0
+        h = C.c_void_p()
+        _check(self.lib.mg_primitive_create(ctx.handle, C.byref(d), C.byref(h)))
+        self.handle = h
+        info = (C.c_int32 * 8)()
+        _check(self.lib.mg_primitive_info(self.handle, info))
+        (self.n_basis, self.n_dim, self.n_components, self.n_canonical_frames, self.n_gmm,
+         self.kk, mfma, self.n_chunks) = [int(v) for v in info]
+        self.mfma_supported = bool(mfma)
+        self.canonical_grid = TimeGrid(self, handle=C.c_void_p(self.lib.mg_primitive_canonical_grid(self.handle)))
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.lib.mg_primitive_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- queries -----------------------------------------------------------------------
+    def precisions_cholesky(self):
+        out = np.empty((self.n_gmm, self.n_components, self.n_components))
+        _check(self.lib.mg_primitive_get_precisions_cholesky(self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def time_grid(self, times):
+        return TimeGrid(self, times)
+
+    def _grid_handle(self, grid):
+        return None if grid is None else grid.handle
+
+    def _grid_size(self, grid):
+        return self.canonical_grid.size if grid is None else grid.size
+
+    # ---- host-array entry points (upload, launch, download) -------------------------------
+    def back_project_frames(self, S, grid=None, path=MG_PATH_AUTO):
+        S = _latents(S)
+        out = np.empty((S.shape[0], self._grid_size(grid), self.n_dim), dtype=np.float32)
+        _check(self.lib.mg_back_project_frames_host(self.handle, self._grid_handle(grid), S.ctypes.data_as(C.c_void_p),
+                                                    _dtype_code(S), S.shape[0], S.shape[1],
+                                                    out.ctypes.data_as(C.c_void_p), path))
+        return out
+
+    def back_project_frames_f64(self, S, grid=None):
+        S = _latents(S)
+        out = np.empty((S.shape[0], self._grid_size(grid), self.n_dim), dtype=np.float64)
+        _check(self.lib.mg_back_project_frames_f64_host(self.handle, self._grid_handle(grid), S.ctypes.data_as(C.c_void_p),
+                                                        _dtype_code(S), S.shape[0], S.shape[1],
+                                                        out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def back_project_coeffs(self, S, dtype=np.float64):
+        S = _latents(S)
+        out = np.empty((S.shape[0], self.n_basis, self.n_dim), dtype=dtype)
+        _check(self.lib.mg_back_project_coeffs_host(self.handle, S.ctypes.data_as(C.c_void_p), _dtype_code(S),
+                                                    S.shape[0], S.shape[1], out.ctypes.data_as(C.c_void_p),
+                                                    _dtype_code(out)))
+        return out
+
+    def spline_evaluate(self, coeffs, grid=None):
+        c = np.ascontiguousarray(coeffs, dtype=np.float64)
+        if c.ndim == 2:
+            c = c.reshape(1, c.shape[0], c.shape[1])
+        if c.shape[1:] != (self.n_basis, self.n_dim):
+            raise ValueError("coeffs must be (n, %d, %d)" % (self.n_basis, self.n_dim))
+        out = np.empty((c.shape[0], self._grid_size(grid), self.n_dim), dtype=np.float64)
+        _check(self.lib.mg_spline_evaluate_host(self.handle, self._grid_handle(grid), c.ctypes.data_as(C.c_void_p),
+                                                c.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def gmm_log_prob(self, X, dtype=np.float64):
+        X = _latents(X)
+        out = np.empty(X.shape[0], dtype=dtype)
+        _check(self.lib.mg_gmm_log_prob_host(self.handle, X.ctypes.data_as(C.c_void_p), _dtype_code(X), X.shape[0],
+                                             X.shape[1], out.ctypes.data_as(C.c_void_p), _dtype_code(out)))
+        return out
+
+    def gmm_sample(self, counts, seed, dtype=np.float64):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        n = int(counts.sum())
+        X = np.empty((n, self.n_components), dtype=dtype)
+        comp = np.empty(n, dtype=np.int32)
+        _check(self.lib.mg_gmm_sample_host(self.handle, n, counts.ctypes.data_as(C.c_void_p), C.c_uint64(int(seed)),
+                                           X.ctypes.data_as(C.c_void_p), _dtype_code(X), self.n_components,
+                                           comp.ctypes.data_as(C.c_void_p)))
+        return X, comp
+
+    def score_constraints(self, cset, S, dtype=np.float64):
+        S = _latents(S)
+        out = np.empty(S.shape[0], dtype=dtype)
+        _check(self.lib.mg_score_constraints_host(self.handle, cset.handle, S.ctypes.data_as(C.c_void_p), _dtype_code(S),
+                                                  S.shape[0], S.shape[1], out.ctypes.data_as(C.c_void_p),
+                                                  _dtype_code(out)))
+        return out
+
+    # ---- device-pointer entry points (no copies, asynchronous on the context stream) ----------
+    def back_project_frames_dev(self, lat_dev, lat_dtype, n, ld, frames_dev, grid=None, path=MG_PATH_AUTO):
+        code = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        _check(self.lib.mg_back_project_frames(self.handle, self._grid_handle(grid), _dev_ptr(lat_dev), code,
+                                               int(n), int(ld), _dev_ptr(frames_dev), path))
+
+    def gmm_log_prob_dev(self, x_dev, x_dtype, n, ld, out_dev, out_dtype=np.float32):
+        xc = MG_F64 if np.dtype(x_dtype) == np.float64 else MG_F32
+        oc = MG_F64 if np.dtype(out_dtype) == np.float64 else MG_F32
+        _check(self.lib.mg_gmm_log_prob(self.handle, _dev_ptr(x_dev), xc, int(n), int(ld), _dev_ptr(out_dev), oc))
+
+    def score_constraints_dev(self, cset, lat_dev, lat_dtype, n, ld, out_dev, out_dtype=np.float64):
+        lc = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        oc = MG_F64 if np.dtype(out_dtype) == np.float64 else MG_F32
+        _check(self.lib.mg_score_constraints(self.handle, cset.handle, _dev_ptr(lat_dev), lc, int(n), int(ld),
+                                             _dev_ptr(out_dev), oc))
+
+    def step_frames_and_logp_dev(self, lat_dev, lat_dtype, n, ld, frames_dev, logp_dev):
+        code = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        _check(self.lib.mg_step_frames_and_logp(self.handle, _dev_ptr(lat_dev), code, int(n), int(ld),
+                                                _dev_ptr(frames_dev), _dev_ptr(logp_dev)))

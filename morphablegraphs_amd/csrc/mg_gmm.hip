@@ -1,0 +1,183 @@
+// Gaussian-mixture kernels for gfx950 (MI355X), float64 arithmetic.
+//
+// log p(x) = logsumexp_k [ log w_k + sum log diag P_k - 0.5 L log 2pi - 0.5 |x P_k - mu_k P_k|^2 ]
+// which is sklearn's GaussianMixture.score_samples as the reference builds it
+// (reference morphablegraphs/motion_model/motion_primitive.py:126-144; formula twin
+//  morphablegraphs/motion_model/extended_mgrd_mixture_model.py:60-108).
+#include "mg_internal.h"
+
+#define MG_GMM_CANDS 64    // candidates per workgroup: one per lane
+#define MG_GMM_WAVES 8     // waves per workgroup: components are dealt round-robin to waves
+
+struct mg_gmm_args {
+    const double *P;       // [K][j][i], column j of the upper-triangular P_k contiguous over i <= j
+    const double *mP;      // [K][L]   mu_k . P_k
+    const double *cst;     // [K]      log w_k + log det - 0.5 L log 2pi
+    const void *x;         // (B, ld)
+    void *out;             // (B)
+    int64_t B, ld;
+    int32_t K, L;
+};
+
+// The latent tile is staged in LDS ([64][L+1] float64, conflict-free for lane-per-row
+// ds_read_b64); every lane owns one candidate, every wave one component at a time, so the
+// precision-Cholesky entries are wave-uniform (scalar loads) and the Mahalanobis sum needs
+// no cross-lane reduction.  Component terms meet in LDS and lane-owners finish the
+// log-sum-exp in component order (the order sklearn/scipy sum in).
+template <bool X_F64, bool OUT_F64>
+__global__ __launch_bounds__(MG_GMM_CANDS *MG_GMM_WAVES) void mg_gmm_logp_kernel(mg_gmm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = a.L, K = a.K;
+    const int xs = L + 1;
+    double *lds_x = (double *)smem;                       // [64][L+1]
+    double *lds_t = lds_x + (size_t)MG_GMM_CANDS * xs;    // [K][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b0 = (int64_t)blockIdx.x * MG_GMM_CANDS;
+    const int ncand = (int)((a.B - b0) < MG_GMM_CANDS ? (a.B - b0) : MG_GMM_CANDS);
+
+    for (int e = tid; e < MG_GMM_CANDS * L; e += MG_GMM_CANDS * MG_GMM_WAVES) {
+        int c = e / L, i = e - c * L;
+        double v = 0.0;
+        if (c < ncand) v = X_F64 ? ((const double *)a.x)[(b0 + c) * a.ld + i] : (double)((const float *)a.x)[(b0 + c) * a.ld + i];
+        lds_x[c * xs + i] = v;
+    }
+    __syncthreads();
+
+    const double *xr = lds_x + lane * xs;
+    for (int k = wave; k < K; k += MG_GMM_WAVES) {
+        const double *Pk = a.P + (size_t)k * L * L;
+        const double *mPk = a.mP + (size_t)k * L;
+        double maha = 0.0;
+        for (int j = 0; j < L; j++) {
+            const double *col = Pk + (size_t)j * L;
+            double y = -mPk[j];
+            for (int i = 0; i <= j; i++) y = fma(xr[i], col[i], y);
+            maha = fma(y, y, maha);
+        }
+        lds_t[k * MG_GMM_CANDS + lane] = a.cst[k] - 0.5 * maha;
+    }
+    __syncthreads();
+
+    if (wave == 0 && lane < ncand) {
+        double vmax = -INFINITY;
+        for (int k = 0; k < K; k++) vmax = fmax(vmax, lds_t[k * MG_GMM_CANDS + lane]);
+        double r;
+        if (vmax == -INFINITY) {
+            r = -INFINITY;
+        } else {
+            double acc = 0.0;
+            for (int k = 0; k < K; k++) acc += exp(lds_t[k * MG_GMM_CANDS + lane] - vmax);
+            r = log(acc) + vmax;
+        }
+        if (OUT_F64) ((double *)a.out)[b0 + lane] = r;
+        else ((float *)a.out)[b0 + lane] = (float)r;
+    }
+}
+
+int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
+    mg_gmm_args a;
+    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
+    int64_t grid = (B + MG_GMM_CANDS - 1) / MG_GMM_CANDS;
+    size_t lds = ((size_t)MG_GMM_CANDS * (p->L + 1) + (size_t)p->K * MG_GMM_CANDS) * 8;
+    if (lds > 150 * 1024 || grid > 0x7fffffff) {
+        mg_set_error("mg_gmm_log_prob: n_components %d / n_gmm %d too large for the LDS-staged kernel", p->L, p->K);
+        return MG_ERR_UNSUPPORTED;
+    }
+    dim3 blk(MG_GMM_CANDS * MG_GMM_WAVES);
+    hipStream_t st = p->ctx->stream;
+    const bool xf = xdt == MG_F64, of = odt == MG_F64;
+    if (lds > 64 * 1024) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (xf && of) hipLaunchKernelGGL((mg_gmm_logp_kernel<true, true>), dim3((int)grid), blk, lds, st, a);
+    else if (xf) hipLaunchKernelGGL((mg_gmm_logp_kernel<true, false>), dim3((int)grid), blk, lds, st, a);
+    else if (of) hipLaunchKernelGGL((mg_gmm_logp_kernel<false, true>), dim3((int)grid), blk, lds, st, a);
+    else hipLaunchKernelGGL((mg_gmm_logp_kernel<false, false>), dim3((int)grid), blk, lds, st, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// Sampler: x = mu_c + chol(Sigma_c) z,  z ~ N(0, I) from Philox4x32-10 + Box-Muller.
+// Rows [cum[c], cum[c+1]) belong to component c (sklearn groups rows by component,
+// reference motion_primitive.py:182-189).  Not bit-compatible with sklearn's stream.
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void mg_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1, uint32_t *out) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+        uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct mg_sample_args {
+    const double *chol;   // [K][L][L] lower
+    const double *mean;   // [K][L]
+    const int64_t *cum;   // [K+1]
+    void *x;
+    int32_t *comp;
+    int64_t n, ld;
+    uint64_t seed;
+    int32_t K, L;
+};
+
+template <bool X_F64>
+__global__ __launch_bounds__(256) void mg_gmm_sample_kernel(mg_sample_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = a.L, zs = L + 1;
+    double *lds_z = (double *)smem;   // [256][L+1]
+    const int tid = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * 256 + tid;
+    if (b < a.n) {
+        double *z = lds_z + (size_t)tid * zs;
+        for (int i = 0; i < L; i += 4) {
+            uint32_t r[4];
+            mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)(i >> 2), 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+            // two Box-Muller pairs from four 32-bit draws; u in (0, 1]
+            const double inv = 1.0 / 4294967296.0;
+            double u0 = ((double)r[0] + 1.0) * inv, u1 = (double)r[1] * inv;
+            double u2 = ((double)r[2] + 1.0) * inv, u3 = (double)r[3] * inv;
+            double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
+            double zz[4] = {m0 * cos(2.0 * M_PI * u1), m0 * sin(2.0 * M_PI * u1), m1 * cos(2.0 * M_PI * u3), m1 * sin(2.0 * M_PI * u3)};
+            for (int q = 0; q < 4 && i + q < L; q++) z[i + q] = zz[q];
+        }
+        int c = 0;
+        while (c + 1 < a.K && b >= a.cum[c + 1]) c++;
+        const double *Lc = a.chol + (size_t)c * L * L;
+        const double *mu = a.mean + (size_t)c * L;
+        for (int i = 0; i < L; i++) {
+            double acc = mu[i];
+            for (int j = 0; j <= i; j++) acc = fma(Lc[i * L + j], z[j], acc);
+            if (X_F64) ((double *)a.x)[b * a.ld + i] = acc;
+            else ((float *)a.x)[b * a.ld + i] = (float)acc;
+        }
+        if (a.comp) a.comp[b] = c;
+    }
+}
+
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
+    mg_sample_args a;
+    a.chol = p->d_gchol; a.mean = p->d_gmean; a.cum = cum_dev; a.x = x; a.comp = comp; a.n = n; a.ld = ld; a.seed = seed; a.K = p->K; a.L = p->L;
+    size_t lds = (size_t)256 * (p->L + 1) * 8;
+    if (lds > 150 * 1024) { mg_set_error("mg_gmm_sample: n_components %d too large", p->L); return MG_ERR_UNSUPPORTED; }
+    int64_t grid = (n + 255) / 256;
+    if (grid > 0x7fffffff) { mg_set_error("mg_gmm_sample: too many samples"); return MG_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_kernel<true>), dim3((int)grid), dim3(256), lds, p->ctx->stream, a);
+    else hipLaunchKernelGGL((mg_gmm_sample_kernel<false>), dim3((int)grid), dim3(256), lds, p->ctx->stream, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}

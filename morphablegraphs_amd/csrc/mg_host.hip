@@ -1,0 +1,954 @@
+// libmg_hip host side: context, primitive constants, time grids, C-ABI entry points.
+// gfx950 (MI355X) only.  All model preparation is float64 on the host; kernels live in
+// mg_backproject.hip / mg_gmm.hip / mg_score.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "mg_internal.h"
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void mg_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mg_hip_fail(hipError_t e, const char *what) {
+    mg_set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    if (e == hipErrorOutOfMemory) return MG_ERR_OUT_OF_MEMORY;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return MG_ERR_NO_DEVICE;
+    return MG_ERR_HIP;
+}
+
+extern "C" const char *mg_version(void) { return "mg_hip 0.1 (gfx950)"; }
+extern "C" const char *mg_last_error(void) { return g_err; }
+extern "C" const char *mg_status_string(int s) {
+    switch (s) {
+        case MG_OK: return "ok";
+        case MG_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case MG_ERR_NO_DEVICE: return "no HIP device";
+        case MG_ERR_HIP: return "HIP runtime error";
+        case MG_ERR_UNSUPPORTED: return "unsupported shape";
+        case MG_ERR_NOT_POSITIVE_DEFINITE: return "covariance not positive definite";
+        case MG_ERR_OUT_OF_MEMORY: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+#define MG_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            mg_set_error(__VA_ARGS__);   \
+            return MG_ERR_INVALID_ARGUMENT; \
+        }                                \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+extern "C" int mg_context_create(int device, void *stream, mg_context **out) {
+    MG_REQUIRE(out != nullptr, "mg_context_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        mg_set_error("mg_context_create: no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return MG_ERR_NO_DEVICE;
+    }
+    MG_REQUIRE(device >= 0 && device < n, "mg_context_create: device %d out of range [0,%d)", device, n);
+    MG_HIP_CHECK(hipSetDevice(device));
+    mg_context *ctx = new (std::nothrow) mg_context();
+    if (!ctx) return MG_ERR_OUT_OF_MEMORY;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete ctx; return mg_hip_fail(e, "hipGetDeviceProperties"); }
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->total_mem = (int64_t)prop.totalGlobalMem;
+    ctx->max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        mg_set_error("mg_context_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        delete ctx;
+        return MG_ERR_UNSUPPORTED;
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return mg_hip_fail(e, "hipStreamCreate"); }
+        ctx->own_stream = true;
+    }
+    e = hipMalloc(&ctx->argmin_out, 16);
+    if (e != hipSuccess) { mg_context_destroy(ctx); return mg_hip_fail(e, "hipMalloc"); }
+    int rc = mg_setup_kernel_attributes(ctx);
+    if (rc != MG_OK) { mg_context_destroy(ctx); return rc; }
+    *out = ctx;
+    return MG_OK;
+}
+
+extern "C" void mg_context_destroy(mg_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto &ev : ctx->free_events) (void)hipEventDestroy(ev);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int mg_context_set_stream(mg_context *ctx, void *stream) {
+    MG_REQUIRE(ctx != nullptr, "mg_context_set_stream: ctx is NULL");
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        MG_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return MG_OK;
+}
+
+extern "C" int mg_context_synchronize(mg_context *ctx) {
+    MG_REQUIRE(ctx != nullptr, "mg_context_synchronize: ctx is NULL");
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MG_OK;
+}
+
+extern "C" int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *total_mem) {
+    MG_REQUIRE(ctx != nullptr, "mg_context_device_info: ctx is NULL");
+    if (name) { strncpy(name, ctx->name, 255); name[255] = 0; }
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (total_mem) *total_mem = ctx->total_mem;
+    return MG_OK;
+}
+
+extern "C" int mg_device_malloc(mg_context *ctx, int64_t bytes, void **out_dev) {
+    MG_REQUIRE(ctx && out_dev && bytes >= 0, "mg_device_malloc: bad arguments");
+    *out_dev = nullptr;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    if (bytes == 0) bytes = 16;
+    MG_HIP_CHECK(hipMalloc(out_dev, (size_t)bytes));
+    return MG_OK;
+}
+extern "C" int mg_device_free(mg_context *ctx, void *p) {
+    MG_REQUIRE(ctx != nullptr, "mg_device_free: ctx is NULL");
+    if (!p) return MG_OK;
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MG_HIP_CHECK(hipFree(p));
+    return MG_OK;
+}
+extern "C" int mg_memcpy_h2d(mg_context *ctx, void *dst, const void *src, int64_t bytes) {
+    MG_REQUIRE(ctx && (bytes == 0 || (dst && src)) && bytes >= 0, "mg_memcpy_h2d: bad arguments");
+    if (bytes == 0) return MG_OK;
+    MG_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MG_OK;
+}
+extern "C" int mg_memcpy_d2h(mg_context *ctx, void *dst, const void *src, int64_t bytes) {
+    MG_REQUIRE(ctx && (bytes == 0 || (dst && src)) && bytes >= 0, "mg_memcpy_d2h: bad arguments");
+    if (bytes == 0) return MG_OK;
+    MG_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MG_OK;
+}
+extern "C" int mg_memset(mg_context *ctx, void *dst, int value, int64_t bytes) {
+    MG_REQUIRE(ctx && (bytes == 0 || dst) && bytes >= 0, "mg_memset: bad arguments");
+    if (bytes == 0) return MG_OK;
+    MG_HIP_CHECK(hipMemsetAsync(dst, value, (size_t)bytes, ctx->stream));
+    return MG_OK;
+}
+
+int mg_ctx_scratch(mg_context *ctx, int64_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) { MG_HIP_CHECK(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+        int64_t want = std::max<int64_t>(bytes, 1 << 20);
+        MG_HIP_CHECK(hipMalloc(&ctx->scratch, (size_t)want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// profiling with HIP events on the context's stream
+// ---------------------------------------------------------------------------------------
+static hipEvent_t mg_get_event(mg_context *ctx) {
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void mg_prof_begin(mg_context *ctx, int slot) {
+    if (!ctx->profile) return;
+    if (ctx->pending.size() > 4096) (void)mg_prof_resolve(ctx);
+    mg_event_pair p;
+    p.a = mg_get_event(ctx);
+    p.b = mg_get_event(ctx);
+    p.slot = slot;
+    (void)hipEventRecord(p.a, ctx->stream);
+    ctx->pending.push_back(p);
+}
+void mg_prof_end(mg_context *ctx, int slot) {
+    if (!ctx->profile || ctx->pending.empty()) return;
+    mg_event_pair &p = ctx->pending.back();
+    if (p.slot == slot) (void)hipEventRecord(p.b, ctx->stream);
+}
+int mg_prof_resolve(mg_context *ctx) {
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof_ms[p.slot] += (double)ms;
+            ctx->prof_n[p.slot] += 1;
+        }
+        ctx->free_events.push_back(p.a);
+        ctx->free_events.push_back(p.b);
+    }
+    ctx->pending.clear();
+    return MG_OK;
+}
+extern "C" int mg_profile_enable(mg_context *ctx, int enabled) {
+    MG_REQUIRE(ctx != nullptr, "mg_profile_enable: ctx is NULL");
+    if (!enabled) (void)mg_prof_resolve(ctx);
+    ctx->profile = enabled != 0;
+    return MG_OK;
+}
+extern "C" int mg_profile_reset(mg_context *ctx) {
+    MG_REQUIRE(ctx != nullptr, "mg_profile_reset: ctx is NULL");
+    (void)mg_prof_resolve(ctx);
+    for (int i = 0; i < MG_PROFILE_SLOTS; i++) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    return MG_OK;
+}
+extern "C" int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64_t *launches) {
+    MG_REQUIRE(ctx && slot >= 0 && slot < MG_PROFILE_SLOTS, "mg_profile_get: bad arguments");
+    (void)mg_prof_resolve(ctx);
+    if (total_ms) *total_ms = ctx->prof_ms[slot];
+    if (launches) *launches = ctx->prof_n[slot];
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// float64 host helpers
+// ---------------------------------------------------------------------------------------
+// FITPACK splev.f interval search + fpbspl.f recurrence (scipy.interpolate.splev, ext=0),
+// the arithmetic behind reference motion_spline.py:86,92.
+void mg_basis_row(const double *t, int n, double x, int32_t *i0, double *h) {
+    const int k = 3;
+    int l = k;
+    while (!(x < t[l + 1] || l == n - k - 2)) l++;
+    double hh[4];
+    h[0] = 1.0; h[1] = h[2] = h[3] = 0.0;
+    for (int j = 1; j <= k; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 1; i <= j; i++) {
+            int li = l + i, lj = li - j;
+            if (t[li] == t[lj]) { h[i] = 0.0; continue; }
+            double f = hh[i - 1] / (t[li] - t[lj]);
+            h[i - 1] = h[i - 1] + f * (t[li] - x);
+            h[i] = f * (x - t[lj]);
+        }
+    }
+    *i0 = l - k;
+}
+
+// lower Cholesky factor; returns false if not positive definite
+static bool mg_cholesky_lower(const double *S, int L, double *c) {
+    std::fill(c, c + (size_t)L * L, 0.0);
+    for (int j = 0; j < L; j++) {
+        double sum = S[j * L + j];
+        for (int p = 0; p < j; p++) sum -= c[j * L + p] * c[j * L + p];
+        if (!(sum > 0.0) || !std::isfinite(sum)) return false;
+        c[j * L + j] = std::sqrt(sum);
+        for (int i = j + 1; i < L; i++) {
+            double s2 = S[i * L + j];
+            for (int p = 0; p < j; p++) s2 -= c[i * L + p] * c[j * L + p];
+            c[i * L + j] = s2 / c[j * L + j];
+        }
+    }
+    return true;
+}
+
+template <typename T>
+static int mg_upload(mg_context *ctx, const std::vector<T> &h, T **d) {
+    *d = nullptr;
+    size_t bytes = std::max<size_t>(h.size() * sizeof(T), 16);
+    MG_HIP_CHECK(hipMalloc((void **)d, bytes));
+    if (!h.empty()) MG_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// time grids
+// ---------------------------------------------------------------------------------------
+static void mg_free_grid_device(mg_time_grid *g) {
+    if (g->d_i0) (void)hipFree(g->d_i0);
+    if (g->d_w) (void)hipFree(g->d_w);
+    if (g->d_mf) (void)hipFree(g->d_mf);
+    if (g->d_chunks) (void)hipFree(g->d_chunks);
+    g->d_i0 = nullptr; g->d_w = nullptr; g->d_mf = nullptr; g->d_chunks = nullptr;
+}
+
+static int mg_round_stride(int nlocal) {
+    // floats per candidate in the LDS coefficient image: == 4 (mod 32) makes the
+    // 16-candidate ds_write_b128 of an MFMA accumulator tile conflict-free.
+    int s = nlocal;
+    while (s % 32 != 4) s++;
+    return s;
+}
+
+static int mg_lds_bytes(const mg_primitive *p, int stride, int wi) {
+    int coef = MG_NCAND * stride * 4;
+    int root = MG_NCAND * (wi * p->nroot + 1) * 8;
+    int s64 = MG_NCAND * (p->L + 1) * 8;
+    return coef + root + s64;
+}
+
+// Split the grid into chunks whose coefficient window fits the LDS budget.
+static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
+    const int D = p->D;
+    g->chunks.clear();
+    g->mfma_ok = false;
+    if (p->KK == 0 || g->T == 0) return;
+    // window budget: three workgroups per CU (160 KiB LDS) when possible, else one
+    const int budget3 = 53 * 1024, budget1 = 156 * 1024;
+    auto fits = [&](int wi, int budget) {
+        int nlocal = ((wi * D + 15) / 16 + 1) * 16;
+        return mg_lds_bytes(p, mg_round_stride(nlocal), wi) <= budget;
+    };
+    int W = 0;
+    for (int w = 12; w >= 4; w--)
+        if (fits(w, budget3)) { W = w; break; }
+    if (W == 0)
+        for (int w = 8; w >= 4; w--)
+            if (fits(w, budget1)) { W = w; break; }
+    if (W == 0) return;  // n_dim too large for the LDS-staged kernel
+    if (W > 8) W = 8;    // wider windows only add redundant contraction work
+    const int max_nT = 64;
+    int a = 0;
+    int max_stride = 0, max_wi = 0;
+    while (a < g->T) {
+        int imin = g->i0[a], imax = g->i0[a];
+        int b = a + 1;
+        while (b < g->T && b - a < max_nT) {
+            int lo = std::min(imin, g->i0[b]), hi = std::max(imax, g->i0[b]);
+            if (hi - lo + 4 > W) break;
+            imin = lo; imax = hi;
+            b++;
+        }
+        mg_chunk c;
+        memset(&c, 0, sizeof(c));
+        c.t0 = a;
+        c.nT = b - a;
+        c.imin = imin;
+        c.wi = imax - imin + 4;
+        c.rt0 = (imin * D) / 16;
+        int rt1 = ((imin + c.wi) * D + 15) / 16;
+        c.ntiles = rt1 - c.rt0;
+        g->chunks.push_back(c);
+        max_stride = std::max(max_stride, mg_round_stride(c.ntiles * 16));
+        max_wi = std::max(max_wi, c.wi);
+        a = b;
+    }
+    g->stride = max_stride;
+    g->max_wi = max_wi;
+    g->lds_bytes = mg_lds_bytes(p, max_stride, max_wi);
+    g->n_chunks = (int32_t)g->chunks.size();
+    g->mfma_ok = g->lds_bytes <= budget1;
+}
+
+static int mg_grid_build(mg_primitive *p, mg_time_grid *g, const double *times, int32_t T,
+                         const int32_t *i0_override, const double *w_override) {
+    g->prim = p;
+    g->T = T;
+    g->times.assign(times, times + T);
+    g->i0.resize(T);
+    g->w.resize((size_t)T * 4);
+    for (int f = 0; f < T; f++) {
+        if (i0_override) {
+            g->i0[f] = i0_override[f];
+            for (int j = 0; j < 4; j++) g->w[4 * f + j] = w_override[4 * f + j];
+        } else {
+            mg_basis_row(p->knots.data(), (int)p->knots.size(), times[f], &g->i0[f], &g->w[4 * f]);
+        }
+    }
+    // mean frames in float64: MF[f][d] = sum_j w_j * mean'[(i0+j) D + d]  (j ascending, no fma)
+    std::vector<double> mf((size_t)T * p->D);
+    for (int f = 0; f < T; f++)
+        for (int d = 0; d < p->D; d++) {
+            double acc = 0.0;
+            for (int j = 0; j < 4; j++) acc = acc + g->w[4 * f + j] * p->means_[(size_t)(g->i0[f] + j) * p->D + d];
+            mf[(size_t)f * p->D + d] = acc;
+        }
+    mg_plan_chunks(p, g);
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    int rc;
+    if ((rc = mg_upload(p->ctx, g->i0, &g->d_i0)) != MG_OK) return rc;
+    if ((rc = mg_upload(p->ctx, g->w, &g->d_w)) != MG_OK) return rc;
+    if ((rc = mg_upload(p->ctx, mf, &g->d_mf)) != MG_OK) return rc;
+    if ((rc = mg_upload(p->ctx, g->chunks, &g->d_chunks)) != MG_OK) return rc;
+    return MG_OK;
+}
+
+extern "C" int mg_time_grid_create(mg_primitive *prim, const double *times, int32_t n_times, mg_time_grid **out) {
+    MG_REQUIRE(prim && out && n_times >= 0 && (n_times == 0 || times), "mg_time_grid_create: bad arguments");
+    *out = nullptr;
+    for (int i = 0; i < n_times; i++) MG_REQUIRE(std::isfinite(times[i]), "mg_time_grid_create: times[%d] is not finite", i);
+    mg_time_grid *g = new (std::nothrow) mg_time_grid();
+    if (!g) return MG_ERR_OUT_OF_MEMORY;
+    int rc = mg_grid_build(prim, g, times, n_times, nullptr, nullptr);
+    if (rc != MG_OK) { mg_free_grid_device(g); delete g; return rc; }
+    *out = g;
+    return MG_OK;
+}
+extern "C" void mg_time_grid_destroy(mg_time_grid *g) {
+    if (!g || g->owned_by_prim) return;
+    if (g->prim) (void)hipStreamSynchronize(g->prim->ctx->stream);
+    mg_free_grid_device(g);
+    delete g;
+}
+extern "C" mg_time_grid *mg_primitive_canonical_grid(mg_primitive *prim) { return prim ? prim->canonical : nullptr; }
+extern "C" int mg_time_grid_size(const mg_time_grid *g) { return g ? g->T : 0; }
+extern "C" int mg_time_grid_get_tables(const mg_time_grid *g, int32_t *i0, double *weights, double *times) {
+    MG_REQUIRE(g != nullptr, "mg_time_grid_get_tables: grid is NULL");
+    if (i0) std::copy(g->i0.begin(), g->i0.end(), i0);
+    if (weights) std::copy(g->w.begin(), g->w.end(), weights);
+    if (times) std::copy(g->times.begin(), g->times.end(), times);
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// primitive
+// ---------------------------------------------------------------------------------------
+static void mg_primitive_free(mg_primitive *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Eroot, p->d_mean, p->d_gP, p->d_gmP,
+                    p->d_gconst, p->d_gmean, p->d_gchol};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    for (mg_time_grid *g : {p->canonical, p->coeff_grid})
+        if (g) { mg_free_grid_device(g); delete g; }
+    delete p;
+}
+
+extern "C" void mg_primitive_destroy(mg_primitive *p) { mg_primitive_free(p); }
+
+extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, mg_primitive **out) {
+    MG_REQUIRE(ctx && d && out, "mg_primitive_create: NULL argument");
+    *out = nullptr;
+    MG_REQUIRE(d->n_basis >= 4, "mg_primitive_create: n_basis = %d, a cubic spline needs >= 4", d->n_basis);
+    MG_REQUIRE(d->n_dim >= 1 && d->n_components >= 1 && d->n_canonical_frames >= 1,
+               "mg_primitive_create: n_dim/n_components/n_canonical_frames must be >= 1");
+    MG_REQUIRE(d->n_gmm >= 0, "mg_primitive_create: n_gmm < 0");
+    MG_REQUIRE(d->eigen_vectors && d->mean_vector && d->knots, "mg_primitive_create: eigen_vectors/mean_vector/knots are required");
+    MG_REQUIRE(d->n_gmm == 0 || (d->gmm_weights && d->gmm_means && d->gmm_covars),
+               "mg_primitive_create: gmm arrays are required when n_gmm > 0");
+    MG_REQUIRE((int64_t)d->n_basis * d->n_dim < (1 << 24), "mg_primitive_create: n_basis*n_dim too large");
+    const int NB = d->n_basis, D = d->n_dim, L = d->n_components, K = d->n_gmm, R = NB * D;
+    for (int i = 0; i + 1 < NB + 4; i++)
+        MG_REQUIRE(d->knots[i] <= d->knots[i + 1] && std::isfinite(d->knots[i + 1]), "mg_primitive_create: knots must be finite and non-decreasing");
+    MG_REQUIRE(d->knots[3] < d->knots[NB], "mg_primitive_create: knot vector has an empty domain");
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+
+    mg_primitive *p = new (std::nothrow) mg_primitive();
+    if (!p) return MG_ERR_OUT_OF_MEMORY;
+    p->ctx = ctx;
+    p->NB = NB; p->D = D; p->L = L; p->F = d->n_canonical_frames; p->K = K; p->R = R;
+    p->nroot = std::min(3, D);
+    p->KK = (L <= 4 * MG_MAX_KK) ? (((L + 3) / 4 + 1) / 2) * 2 : 0;
+    p->RT = (R + 15) / 16;
+    p->knots.assign(d->knots, d->knots + NB + 4);
+    double tm[3] = {1.0, 1.0, 1.0};
+    if (d->translation_maxima)
+        for (int i = 0; i < 3; i++) tm[i] = d->translation_maxima[i];
+
+    // E' = E * scale_d, mean' = mean * scale_d (float64 products): the reference applies
+    // translation_maxima after adding the mean (motion_primitive.py:251-255), which is
+    // the same linear map.
+    p->Es.resize((size_t)R * L);
+    p->means_.resize(R);
+    for (int r = 0; r < R; r++) {
+        double sc = (r % D < 3) ? tm[r % D] : 1.0;
+        for (int k = 0; k < L; k++) {
+            double e = d->eigen_is_transposed ? d->eigen_vectors[(size_t)r * L + k] : d->eigen_vectors[(size_t)k * R + r];
+            p->Es[(size_t)r * L + k] = e * sc;
+        }
+        p->means_[r] = d->mean_vector[r] * sc;
+    }
+
+    int rc = MG_OK;
+    {   // device images of E'
+        std::vector<float> et32((size_t)L * R);
+        std::vector<double> et64((size_t)L * R);
+        for (int r = 0; r < R; r++)
+            for (int k = 0; k < L; k++) {
+                et64[(size_t)k * R + r] = p->Es[(size_t)r * L + k];
+                et32[(size_t)k * R + r] = (float)p->Es[(size_t)r * L + k];
+            }
+        std::vector<double> eroot((size_t)NB * p->nroot * L);
+        for (int i = 0; i < NB; i++)
+            for (int dd = 0; dd < p->nroot; dd++)
+                for (int k = 0; k < L; k++) eroot[((size_t)i * p->nroot + dd) * L + k] = p->Es[((size_t)i * D + dd) * L + k];
+        if (rc == MG_OK) rc = mg_upload(ctx, et32, &p->d_Et32);
+        if (rc == MG_OK) rc = mg_upload(ctx, et64, &p->d_Et64);
+        if (rc == MG_OK) rc = mg_upload(ctx, eroot, &p->d_Eroot);
+        if (rc == MG_OK) rc = mg_upload(ctx, p->means_, &p->d_mean);
+        if (rc == MG_OK && p->KK > 0) {
+            // MFMA A-operand fragments of v_mfma_f32_16x16x4_f32: lane l supplies
+            // A[row = l & 15][k = 4*kk + (l >> 4)].  Image [rt][kk/2][lane][2].
+            const int KK = p->KK;
+            std::vector<float> pack((size_t)p->RT * KK * 64, 0.0f);
+            for (int rt = 0; rt < p->RT; rt++)
+                for (int kk = 0; kk < KK; kk++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        int r = rt * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
+                        float v = (r < R && k < L) ? (float)p->Es[(size_t)r * L + k] : 0.0f;
+                        pack[(((size_t)rt * (KK / 2) + kk / 2) * 64 + lane) * 2 + (kk & 1)] = v;
+                    }
+            rc = mg_upload(ctx, pack, &p->d_Epack);
+        }
+    }
+    if (rc != MG_OK) { mg_primitive_free(p); return rc; }
+
+    if (K > 0) {
+        p->gw.assign(d->gmm_weights, d->gmm_weights + K);
+        p->gm.assign(d->gmm_means, d->gmm_means + (size_t)K * L);
+        p->gc.assign(d->gmm_covars, d->gmm_covars + (size_t)K * L * L);
+        p->gp.assign((size_t)K * L * L, 0.0);
+        std::vector<double> chol((size_t)K * L * L), inv((size_t)L * L);
+        std::vector<double> gP((size_t)K * L * L, 0.0), gmP((size_t)K * L), gconst(K);
+        const double log2pi = std::log(2.0 * M_PI);
+        for (int k = 0; k < K; k++) {
+            double *c = &chol[(size_t)k * L * L];
+            if (!(p->gw[k] >= 0.0) || !std::isfinite(p->gw[k])) {
+                mg_set_error("mg_primitive_create: gmm_weights[%d] is negative or not finite", k);
+                mg_primitive_free(p);
+                return MG_ERR_INVALID_ARGUMENT;
+            }
+            if (!mg_cholesky_lower(&p->gc[(size_t)k * L * L], L, c)) {
+                mg_set_error("mg_primitive_create: gmm_covars[%d] is not positive definite", k);
+                mg_primitive_free(p);
+                return MG_ERR_NOT_POSITIVE_DEFINITE;
+            }
+            // sklearn _compute_precision_cholesky: P = solve_triangular(chol, I, lower=True).T
+            std::fill(inv.begin(), inv.end(), 0.0);
+            for (int col = 0; col < L; col++)
+                for (int r = col; r < L; r++) {
+                    double s = (r == col) ? 1.0 : 0.0;
+                    for (int q = col; q < r; q++) s -= c[r * L + q] * inv[(size_t)q * L + col];
+                    inv[(size_t)r * L + col] = s / c[r * L + r];
+                }
+            double *P = &p->gp[(size_t)k * L * L];
+            double logdet = 0.0;
+            for (int i = 0; i < L; i++) {
+                for (int j = 0; j < L; j++) P[i * L + j] = inv[(size_t)j * L + i];
+                logdet += std::log(P[i * L + i]);
+            }
+            for (int j = 0; j < L; j++) {
+                double acc = 0.0;
+                for (int i = 0; i <= j; i++) {
+                    gP[((size_t)k * L + j) * L + i] = P[i * L + j];
+                    acc += p->gm[(size_t)k * L + i] * P[i * L + j];
+                }
+                gmP[(size_t)k * L + j] = acc;
+            }
+            gconst[k] = std::log(p->gw[k]) + logdet - 0.5 * (double)L * log2pi;
+        }
+        if (rc == MG_OK) rc = mg_upload(ctx, gP, &p->d_gP);
+        if (rc == MG_OK) rc = mg_upload(ctx, gmP, &p->d_gmP);
+        if (rc == MG_OK) rc = mg_upload(ctx, gconst, &p->d_gconst);
+        if (rc == MG_OK) rc = mg_upload(ctx, p->gm, &p->d_gmean);
+        if (rc == MG_OK) rc = mg_upload(ctx, chol, &p->d_gchol);
+        if (rc != MG_OK) { mg_primitive_free(p); return rc; }
+    }
+
+    {   // canonical grid: np.linspace(0, F, int(F * 1.0))  (reference motion_primitive.py:233)
+        const int F = p->F;
+        std::vector<double> t(F);
+        if (F == 1) {
+            t[0] = 0.0;
+        } else {
+            double step = (double)F / (double)(F - 1);
+            for (int f = 0; f < F; f++) t[f] = (double)f * step;
+            t[F - 1] = (double)F;
+        }
+        p->canonical = new (std::nothrow) mg_time_grid();
+        if (!p->canonical) { mg_primitive_free(p); return MG_ERR_OUT_OF_MEMORY; }
+        p->canonical->owned_by_prim = true;
+        rc = mg_grid_build(p, p->canonical, t.data(), F, nullptr, nullptr);
+        if (rc != MG_OK) { mg_primitive_free(p); return rc; }
+    }
+    {   // identity grid: row i selects coefficient i, so "frames" are the coefficients
+        std::vector<double> t(NB, 0.0), w((size_t)NB * 4, 0.0);
+        std::vector<int32_t> i0(NB);
+        for (int i = 0; i < NB; i++) {
+            int base = std::min(i, NB - 4);
+            i0[i] = base;
+            w[4 * i + (i - base)] = 1.0;
+            t[i] = (double)i;
+        }
+        p->coeff_grid = new (std::nothrow) mg_time_grid();
+        if (!p->coeff_grid) { mg_primitive_free(p); return MG_ERR_OUT_OF_MEMORY; }
+        p->coeff_grid->owned_by_prim = true;
+        rc = mg_grid_build(p, p->coeff_grid, t.data(), NB, i0.data(), w.data());
+        if (rc != MG_OK) { mg_primitive_free(p); return rc; }
+    }
+    *out = p;
+    return MG_OK;
+}
+
+extern "C" int mg_primitive_info(const mg_primitive *p, int32_t *o) {
+    MG_REQUIRE(p && o, "mg_primitive_info: NULL argument");
+    o[0] = p->NB; o[1] = p->D; o[2] = p->L; o[3] = p->F; o[4] = p->K; o[5] = p->KK;
+    o[6] = (p->canonical && p->canonical->mfma_ok) ? 1 : 0;
+    o[7] = p->canonical ? p->canonical->n_chunks : 0;
+    return MG_OK;
+}
+
+extern "C" int mg_primitive_get_precisions_cholesky(const mg_primitive *p, double *out) {
+    MG_REQUIRE(p && out, "mg_primitive_get_precisions_cholesky: NULL argument");
+    MG_REQUIRE(p->K > 0, "mg_primitive_get_precisions_cholesky: primitive has no mixture");
+    std::copy(p->gp.begin(), p->gp.end(), out);
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// hot-path entry points (validation, then launch)
+// ---------------------------------------------------------------------------------------
+static int mg_check_latents(const char *fn, const mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld) {
+    MG_REQUIRE(p != nullptr, "%s: primitive is NULL", fn);
+    MG_REQUIRE(B >= 0, "%s: n_samples = %lld < 0", fn, (long long)B);
+    MG_REQUIRE(dt == MG_F32 || dt == MG_F64, "%s: latent dtype %d is neither MG_F32 nor MG_F64", fn, dt);
+    MG_REQUIRE(B == 0 || lat != nullptr, "%s: latents pointer is NULL", fn);
+    MG_REQUIRE(ld >= p->L, "%s: leading dimension %lld < n_components %d", fn, (long long)ld, p->L);
+    return MG_OK;
+}
+
+extern "C" int mg_back_project_frames(mg_primitive *p, const mg_time_grid *g, const void *lat, int dt,
+                                      int64_t B, int64_t ld, float *out, int path) {
+    int rc = mg_check_latents("mg_back_project_frames", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    if (!g) g = p->canonical;
+    MG_REQUIRE(g->prim == p, "mg_back_project_frames: grid belongs to another primitive");
+    MG_REQUIRE(path == MG_PATH_AUTO || path == MG_PATH_MFMA || path == MG_PATH_DIRECT, "mg_back_project_frames: unknown path %d", path);
+    if (B == 0 || g->T == 0) return MG_OK;
+    MG_REQUIRE(out != nullptr, "mg_back_project_frames: frames pointer is NULL");
+    MG_REQUIRE(B * (int64_t)g->T * p->D < ((int64_t)1 << 40), "mg_back_project_frames: output too large");
+    bool use_mfma;
+    if (path == MG_PATH_MFMA) {
+        if (!g->mfma_ok) {
+            mg_set_error("mg_back_project_frames: MFMA path unsupported for this shape (n_components %d > 64 or n_dim %d too large for LDS)", p->L, p->D);
+            return MG_ERR_UNSUPPORTED;
+        }
+        use_mfma = true;
+    } else if (path == MG_PATH_DIRECT) {
+        use_mfma = false;
+    } else {
+        use_mfma = g->mfma_ok && B >= 8;
+    }
+    mg_prof_begin(p->ctx, 0);
+    rc = use_mfma ? mg_launch_frames_mfma(p, g, lat, dt, B, ld, out) : mg_launch_frames_direct(p, g, lat, dt, B, ld, out, false);
+    mg_prof_end(p->ctx, 0);
+    return rc;
+}
+
+extern "C" int mg_back_project_frames_f64(mg_primitive *p, const mg_time_grid *g, const void *lat, int dt,
+                                          int64_t B, int64_t ld, double *out) {
+    int rc = mg_check_latents("mg_back_project_frames_f64", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    if (!g) g = p->canonical;
+    MG_REQUIRE(g->prim == p, "mg_back_project_frames_f64: grid belongs to another primitive");
+    if (B == 0 || g->T == 0) return MG_OK;
+    MG_REQUIRE(out != nullptr, "mg_back_project_frames_f64: frames pointer is NULL");
+    mg_prof_begin(p->ctx, 0);
+    rc = mg_launch_frames_direct(p, g, lat, dt, B, ld, out, true);
+    mg_prof_end(p->ctx, 0);
+    return rc;
+}
+
+extern "C" int mg_back_project_coeffs(mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld,
+                                      void *out, int odt) {
+    int rc = mg_check_latents("mg_back_project_coeffs", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_back_project_coeffs: bad output dtype %d", odt);
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(out != nullptr, "mg_back_project_coeffs: coeffs pointer is NULL");
+    const mg_time_grid *g = p->coeff_grid;
+    if (odt == MG_F64) return mg_launch_frames_direct(p, g, lat, dt, B, ld, out, true);
+    if (g->mfma_ok && B >= 8) return mg_launch_frames_mfma(p, g, lat, dt, B, ld, (float *)out);
+    return mg_launch_frames_direct(p, g, lat, dt, B, ld, out, false);
+}
+
+extern "C" int mg_spline_evaluate(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out) {
+    MG_REQUIRE(p != nullptr && n >= 0, "mg_spline_evaluate: bad arguments");
+    if (!g) g = p->canonical;
+    MG_REQUIRE(g->prim == p, "mg_spline_evaluate: grid belongs to another primitive");
+    if (n == 0 || g->T == 0) return MG_OK;
+    MG_REQUIRE(coeffs && out, "mg_spline_evaluate: NULL pointer");
+    mg_prof_begin(p->ctx, 5);
+    int rc = mg_launch_spline_eval(p, g, coeffs, n, out);
+    mg_prof_end(p->ctx, 5);
+    return rc;
+}
+
+extern "C" int mg_gmm_log_prob(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
+    int rc = mg_check_latents("mg_gmm_log_prob", p, x, xdt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(p->K > 0, "mg_gmm_log_prob: primitive has no mixture");
+    MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_gmm_log_prob: bad output dtype %d", odt);
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(out != nullptr, "mg_gmm_log_prob: output pointer is NULL");
+    mg_prof_begin(p->ctx, 1);
+    rc = mg_launch_gmm_logp(p, x, xdt, B, ld, out, odt);
+    mg_prof_end(p->ctx, 1);
+    return rc;
+}
+
+extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, void *x, int xdt,
+                             int64_t ld, int32_t *comp) {
+    MG_REQUIRE(p != nullptr && n >= 0, "mg_gmm_sample: bad arguments");
+    MG_REQUIRE(p->K > 0, "mg_gmm_sample: primitive has no mixture");
+    MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_gmm_sample: bad dtype %d", xdt);
+    MG_REQUIRE(counts != nullptr, "mg_gmm_sample: counts is NULL");
+    MG_REQUIRE(ld >= p->L, "mg_gmm_sample: leading dimension %lld < n_components %d", (long long)ld, p->L);
+    std::vector<int64_t> cum(p->K + 1, 0);
+    for (int k = 0; k < p->K; k++) {
+        MG_REQUIRE(counts[k] >= 0, "mg_gmm_sample: counts[%d] < 0", k);
+        cum[k + 1] = cum[k] + counts[k];
+    }
+    MG_REQUIRE(cum[p->K] == n, "mg_gmm_sample: counts sum to %lld, expected %lld", (long long)cum[p->K], (long long)n);
+    if (n == 0) return MG_OK;
+    MG_REQUIRE(x != nullptr, "mg_gmm_sample: output pointer is NULL");
+    void *scr = nullptr;
+    int rc = mg_ctx_scratch(p->ctx, (int64_t)cum.size() * 8, &scr);
+    if (rc != MG_OK) return rc;
+    MG_HIP_CHECK(hipMemcpyAsync(scr, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, p->ctx->stream));
+    MG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));  // cum is a stack-lifetime host buffer
+    mg_prof_begin(p->ctx, 4);
+    rc = mg_launch_gmm_sample(p, n, (const int64_t *)scr, seed, x, xdt, ld, comp);
+    mg_prof_end(p->ctx, 4);
+    return rc;
+}
+
+// ---- constraint sets ---------------------------------------------------------------------
+extern "C" int mg_constraint_set_create(mg_primitive *p, const mg_keyframe_constraint *cons, int32_t n, mg_constraint_set **out) {
+    MG_REQUIRE(p && out && n >= 0 && (n == 0 || cons), "mg_constraint_set_create: bad arguments");
+    *out = nullptr;
+    const int nch = std::min(7, p->D), L = p->L, D = p->D;
+    for (int c = 0; c < n; c++) {
+        MG_REQUIRE(cons[c].type == MG_CONSTRAINT_POSITION || cons[c].type == MG_CONSTRAINT_DIRECTION_2D,
+                   "mg_constraint_set_create: constraint %d has unknown type %d", c, cons[c].type);
+        MG_REQUIRE(std::isfinite(cons[c].canonical_keyframe), "mg_constraint_set_create: constraint %d keyframe not finite", c);
+        MG_REQUIRE(cons[c].type == MG_CONSTRAINT_POSITION ? D >= 3 : D >= 7,
+                   "mg_constraint_set_create: constraint %d needs more pose channels than n_dim = %d", c, D);
+    }
+    mg_constraint_set *cs = new (std::nothrow) mg_constraint_set();
+    if (!cs) return MG_ERR_OUT_OF_MEMORY;
+    cs->prim = p; cs->n = n; cs->nch = nch;
+    std::vector<double> W((size_t)n * nch * L, 0.0), bias((size_t)n * nch, 0.0), par((size_t)n * 8, 0.0);
+    for (int c = 0; c < n; c++) {
+        int32_t i0; double w[4];
+        mg_basis_row(p->knots.data(), (int)p->knots.size(), cons[c].canonical_keyframe, &i0, w);
+        for (int d = 0; d < nch; d++) {
+            double b = 0.0;
+            for (int j = 0; j < 4; j++) b = b + w[j] * p->means_[(size_t)(i0 + j) * D + d];
+            bias[(size_t)c * nch + d] = b;
+            for (int k = 0; k < L; k++) {
+                double acc = 0.0;
+                for (int j = 0; j < 4; j++) acc = acc + w[j] * p->Es[((size_t)(i0 + j) * D + d) * L + k];
+                W[((size_t)c * nch + d) * L + k] = acc;
+            }
+        }
+        double *q = &par[(size_t)c * 8];
+        q[0] = (double)cons[c].type; q[1] = cons[c].weight_factor;
+        for (int i = 0; i < 3; i++) { q[2 + i] = cons[c].target[i]; q[5 + i] = cons[c].ref_dir[i]; }
+    }
+    int rc = mg_upload(p->ctx, W, &cs->d_W);
+    if (rc == MG_OK) rc = mg_upload(p->ctx, bias, &cs->d_bias);
+    if (rc == MG_OK) rc = mg_upload(p->ctx, par, &cs->d_par);
+    if (rc != MG_OK) { mg_constraint_set_destroy(cs); return rc; }
+    *out = cs;
+    return MG_OK;
+}
+extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
+    if (!cs) return;
+    if (cs->prim) (void)hipStreamSynchronize(cs->prim->ctx->stream);
+    if (cs->d_W) (void)hipFree(cs->d_W);
+    if (cs->d_bias) (void)hipFree(cs->d_bias);
+    if (cs->d_par) (void)hipFree(cs->d_par);
+    delete cs;
+}
+
+extern "C" int mg_score_constraints(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt,
+                                    int64_t B, int64_t ld, void *out, int odt) {
+    int rc = mg_check_latents("mg_score_constraints", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(cs && cs->prim == p, "mg_score_constraints: constraint set is NULL or belongs to another primitive");
+    MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_score_constraints: bad output dtype %d", odt);
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(out != nullptr, "mg_score_constraints: output pointer is NULL");
+    mg_prof_begin(p->ctx, 2);
+    rc = mg_launch_score(p, cs, lat, dt, B, ld, out, odt);
+    mg_prof_end(p->ctx, 2);
+    return rc;
+}
+
+extern "C" int mg_argmin_first_dev(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev) {
+    MG_REQUIRE(ctx && out_dev && n >= 0 && (n == 0 || v), "mg_argmin_first_dev: bad arguments");
+    MG_REQUIRE(dt == MG_F32 || dt == MG_F64, "mg_argmin_first_dev: bad dtype %d", dt);
+    mg_prof_begin(ctx, 3);
+    int rc = mg_launch_argmin(ctx, v, dt, n, out_dev);
+    mg_prof_end(ctx, 3);
+    return rc;
+}
+
+extern "C" int mg_argmin_first(mg_context *ctx, const void *v, int dt, int64_t n, int64_t *best, double *minv) {
+    MG_REQUIRE(ctx != nullptr, "mg_argmin_first: ctx is NULL");
+    int rc = mg_argmin_first_dev(ctx, v, dt, n, ctx->argmin_out);
+    if (rc != MG_OK) return rc;
+    struct { int64_t i; double v; } h;
+    MG_HIP_CHECK(hipMemcpyAsync(&h, ctx->argmin_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (best) *best = h.i;
+    if (minv) *minv = h.v;
+    return MG_OK;
+}
+
+extern "C" int mg_step_frames_and_logp(mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld,
+                                       float *frames, float *logp) {
+    mg_context *ctx = p ? p->ctx : nullptr;
+    if (ctx) mg_prof_begin(ctx, 6);
+    int rc = mg_back_project_frames(p, nullptr, lat, dt, B, ld, frames, MG_PATH_AUTO);
+    if (rc == MG_OK) rc = mg_gmm_log_prob(p, lat, dt, B, ld, logp, MG_F32);
+    if (ctx) mg_prof_end(ctx, 6);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-pointer convenience variants
+// ---------------------------------------------------------------------------------------
+static size_t mg_dt_size(int dt) { return dt == MG_F64 ? 8 : 4; }
+
+struct mg_host_io {
+    mg_context *ctx;
+    void *d_in = nullptr, *d_out = nullptr;
+    int stage(mg_context *c, const void *in, int64_t in_bytes, int64_t out_bytes) {
+        ctx = c;
+        void *base = nullptr;
+        int64_t in_al = (in_bytes + 255) / 256 * 256;
+        int rc = mg_ctx_scratch(c, in_al + out_bytes + 256, &base);
+        if (rc != MG_OK) return rc;
+        d_in = base;
+        d_out = (char *)base + in_al;
+        if (in_bytes > 0) MG_HIP_CHECK(hipMemcpyAsync(d_in, in, (size_t)in_bytes, hipMemcpyHostToDevice, c->stream));
+        return MG_OK;
+    }
+    int finish(void *out, int64_t out_bytes) {
+        if (out_bytes > 0) MG_HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return MG_OK;
+    }
+};
+
+extern "C" int mg_back_project_frames_host(mg_primitive *p, const mg_time_grid *g, const void *lat, int dt,
+                                           int64_t B, int64_t ld, float *frames, int path) {
+    int rc = mg_check_latents("mg_back_project_frames_host", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    if (!g) g = p->canonical;
+    int64_t ob = B * (int64_t)g->T * p->D * 4;
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, lat, B * ld * (int64_t)mg_dt_size(dt), ob)) != MG_OK) return rc;
+    if ((rc = mg_back_project_frames(p, g, io.d_in, dt, B, ld, (float *)io.d_out, path)) != MG_OK) return rc;
+    return io.finish(frames, ob);
+}
+extern "C" int mg_back_project_frames_f64_host(mg_primitive *p, const mg_time_grid *g, const void *lat, int dt,
+                                               int64_t B, int64_t ld, double *frames) {
+    int rc = mg_check_latents("mg_back_project_frames_f64_host", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    if (!g) g = p->canonical;
+    int64_t ob = B * (int64_t)g->T * p->D * 8;
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, lat, B * ld * (int64_t)mg_dt_size(dt), ob)) != MG_OK) return rc;
+    if ((rc = mg_back_project_frames_f64(p, g, io.d_in, dt, B, ld, (double *)io.d_out)) != MG_OK) return rc;
+    return io.finish(frames, ob);
+}
+extern "C" int mg_back_project_coeffs_host(mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld,
+                                           void *coeffs, int odt) {
+    int rc = mg_check_latents("mg_back_project_coeffs_host", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_back_project_coeffs_host: bad output dtype %d", odt);
+    int64_t ob = B * (int64_t)p->R * (int64_t)mg_dt_size(odt);
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, lat, B * ld * (int64_t)mg_dt_size(dt), ob)) != MG_OK) return rc;
+    if ((rc = mg_back_project_coeffs(p, io.d_in, dt, B, ld, io.d_out, odt)) != MG_OK) return rc;
+    return io.finish(coeffs, ob);
+}
+extern "C" int mg_spline_evaluate_host(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *frames) {
+    MG_REQUIRE(p != nullptr && n >= 0, "mg_spline_evaluate_host: bad arguments");
+    if (!g) g = p->canonical;
+    int64_t ib = n * (int64_t)p->R * 8, ob = n * (int64_t)g->T * p->D * 8;
+    mg_host_io io;
+    int rc;
+    if ((rc = io.stage(p->ctx, coeffs, ib, ob)) != MG_OK) return rc;
+    if ((rc = mg_spline_evaluate(p, g, (const double *)io.d_in, n, (double *)io.d_out)) != MG_OK) return rc;
+    return io.finish(frames, ob);
+}
+extern "C" int mg_gmm_log_prob_host(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *logp, int odt) {
+    int rc = mg_check_latents("mg_gmm_log_prob_host", p, x, xdt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_gmm_log_prob_host: bad output dtype %d", odt);
+    int64_t ob = B * (int64_t)mg_dt_size(odt);
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, x, B * ld * (int64_t)mg_dt_size(xdt), ob)) != MG_OK) return rc;
+    if ((rc = mg_gmm_log_prob(p, io.d_in, xdt, B, ld, io.d_out, odt)) != MG_OK) return rc;
+    return io.finish(logp, ob);
+}
+extern "C" int mg_gmm_sample_host(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, void *x, int xdt,
+                                  int64_t ld, int32_t *comp) {
+    MG_REQUIRE(p != nullptr && n >= 0 && ld >= (p ? p->L : 0), "mg_gmm_sample_host: bad arguments");
+    MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_gmm_sample_host: bad dtype %d", xdt);
+    int64_t xb = n * ld * (int64_t)mg_dt_size(xdt), cb = n * 4;
+    void *dx = nullptr, *dc = nullptr;
+    int rc = mg_device_malloc(p->ctx, xb, &dx);
+    if (rc != MG_OK) return rc;
+    rc = mg_device_malloc(p->ctx, cb, &dc);
+    if (rc == MG_OK) rc = mg_memset(p->ctx, dx, 0, xb);
+    if (rc == MG_OK) rc = mg_gmm_sample(p, n, counts, seed, dx, xdt, ld, (int32_t *)dc);
+    if (rc == MG_OK) rc = mg_memcpy_d2h(p->ctx, x, dx, xb);
+    if (rc == MG_OK && comp) rc = mg_memcpy_d2h(p->ctx, comp, dc, cb);
+    (void)mg_device_free(p->ctx, dx);
+    (void)mg_device_free(p->ctx, dc);
+    return rc;
+}
+extern "C" int mg_score_constraints_host(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt,
+                                         int64_t B, int64_t ld, void *errors, int odt) {
+    int rc = mg_check_latents("mg_score_constraints_host", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_score_constraints_host: bad output dtype %d", odt);
+    int64_t ob = B * (int64_t)mg_dt_size(odt);
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, lat, B * ld * (int64_t)mg_dt_size(dt), ob)) != MG_OK) return rc;
+    if ((rc = mg_score_constraints(p, cs, io.d_in, dt, B, ld, io.d_out, odt)) != MG_OK) return rc;
+    return io.finish(errors, ob);
+}

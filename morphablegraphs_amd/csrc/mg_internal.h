@@ -1,0 +1,134 @@
+// Internal declarations shared by the libmg_hip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mg_hip.h"
+
+#define MG_NCAND 16         // candidates per MFMA tile (N of v_mfma_f32_16x16x4_f32)
+#define MG_ROWTILE 16       // coefficient rows per MFMA tile (M)
+#define MG_MAX_KK 16        // k-steps of 4 -> n_components <= 64 on the MFMA path
+#define MG_BLOCK 256        // threads per workgroup of the frames kernels
+#define MG_PROFILE_SLOTS 8
+
+void mg_set_error(const char *fmt, ...);
+int mg_hip_fail(hipError_t e, const char *what);
+
+#define MG_HIP_CHECK(expr)                                   \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return mg_hip_fail(_e, #expr); \
+    } while (0)
+
+struct mg_event_pair {
+    hipEvent_t a, b;
+    int slot;
+};
+
+struct mg_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 0;
+    int64_t total_mem = 0;
+    int max_lds = 0;
+    char name[256] = {0};
+    // profiling
+    bool profile = false;
+    std::vector<mg_event_pair> pending;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[MG_PROFILE_SLOTS] = {0};
+    int64_t prof_n[MG_PROFILE_SLOTS] = {0};
+    // scratch for host convenience variants / argmin
+    void *scratch = nullptr;
+    int64_t scratch_bytes = 0;
+    void *argmin_out = nullptr;  // 16 bytes device
+};
+
+int mg_ctx_scratch(mg_context *ctx, int64_t bytes, void **out);
+void mg_prof_begin(mg_context *ctx, int slot);
+void mg_prof_end(mg_context *ctx, int slot);
+int mg_prof_resolve(mg_context *ctx);
+
+// One chunk of a time grid handled by one workgroup of the MFMA kernel.
+struct mg_chunk {
+    int32_t t0;      // first time index
+    int32_t nT;      // number of time samples
+    int32_t rt0;     // first global 16-row tile of the coefficient window
+    int32_t ntiles;  // number of 16-row tiles
+    int32_t imin;    // first coefficient index of the window
+    int32_t wi;      // coefficient rows (basis functions) in the window
+    int32_t pad0, pad1;
+};
+
+struct mg_time_grid {
+    mg_primitive *prim = nullptr;
+    bool owned_by_prim = false;
+    int32_t T = 0;
+    std::vector<double> times;
+    std::vector<int32_t> i0;
+    std::vector<double> w;  // (T,4)
+    std::vector<mg_chunk> chunks;
+    // device tables
+    int32_t *d_i0 = nullptr;
+    double *d_w = nullptr;   // (T,4)
+    double *d_mf = nullptr;  // (T,D) mean frames, float64
+    mg_chunk *d_chunks = nullptr;
+    int32_t n_chunks = 0;
+    int32_t stride = 0;      // floats per candidate in the LDS coefficient image
+    int32_t max_wi = 0;
+    int32_t lds_bytes = 0;   // dynamic LDS of the MFMA kernel for this grid
+    bool mfma_ok = false;
+};
+
+struct mg_primitive {
+    mg_context *ctx = nullptr;
+    int32_t NB = 0, D = 0, L = 0, F = 0, K = 0, R = 0;
+    int32_t nroot = 0;  // min(3, D): channels computed in float64
+    int32_t KK = 0;     // MFMA k-steps (even), 0 when L > 64
+    int32_t RT = 0;     // 16-row tiles
+    // host float64 copies (already scaled by translation_maxima)
+    std::vector<double> Es;    // (R, L)
+    std::vector<double> means_;  // mean' (R)
+    std::vector<double> knots;
+    std::vector<double> gw, gm, gc, gp;  // weights (K), means (K,L), covars (K,L,L), prec chol (K,L,L)
+    // device constants
+    float *d_Epack = nullptr;    // [RT][KK/2][64][2] MFMA A fragments, f32
+    float *d_Et32 = nullptr;     // [L][R] f32
+    double *d_Et64 = nullptr;    // [L][R] f64
+    double *d_Eroot = nullptr;   // [NB*nroot][L] f64
+    double *d_mean = nullptr;    // (R) f64
+    // GMM device constants
+    double *d_gP = nullptr;      // [K][L(j)][L(i)]: column j of P_k contiguous over i
+    double *d_gmP = nullptr;     // [K][L]: mu_k . P_k
+    double *d_gconst = nullptr;  // [K]: log w_k + sum log diag P_k - 0.5 L log 2pi
+    double *d_gmean = nullptr;   // [K][L]
+    double *d_gchol = nullptr;   // [K][L][L] lower Cholesky of covars (sampler)
+    mg_time_grid *canonical = nullptr;
+    mg_time_grid *coeff_grid = nullptr;  // identity basis: "frames" == coefficients
+};
+
+struct mg_constraint_set {
+    mg_primitive *prim = nullptr;
+    int32_t n = 0;
+    int32_t nch = 0;            // channels evaluated per constraint (<= 7)
+    double *d_W = nullptr;      // [n][nch][L]
+    double *d_bias = nullptr;   // [n][nch]
+    double *d_par = nullptr;    // [n][8]: type, weight, target[3], ref_dir[3]
+};
+
+// launchers (each validates nothing: the C-ABI entry points did)
+int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out);
+int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
+int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);
+int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt);
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
+int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt);
+int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
+int mg_setup_kernel_attributes(mg_context *ctx);
+
+// host-side float64 spline basis (FITPACK splev/fpbspl semantics)
+void mg_basis_row(const double *knots, int n_knots, double x, int32_t *i0, double *w4);

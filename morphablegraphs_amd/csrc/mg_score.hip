@@ -1,0 +1,148 @@
+// Fused candidate scoring for gfx950 (MI355X), float64 arithmetic, no frames materialised:
+//   error_b = sum_c weight_c * constraint_c( root pose of candidate b at keyframe t_c )
+// replacing the per-sample loop of evaluate_samples_using_constraints
+// (reference morphablegraphs/motion_generator/motion_primitive_generator.py:230-261) over
+// MotionPrimitiveConstraints.evaluate (reference .../constraints/motion_primitive_constraints.py:100-122)
+// for root-joint position / 2-D direction constraints, and its first-minimum argmin.
+#include "mg_internal.h"
+
+struct mg_score_args {
+    const double *W;      // [n][nch][L]   sum_j w_j E'[(i0+j) D + d]
+    const double *bias;   // [n][nch]      mean frame at t_c
+    const double *par;    // [n][8]        type, weight, target[3], ref_dir[3]
+    const void *lat;
+    void *out;
+    int64_t B, ld;
+    int32_t n, nch, L;
+};
+
+// lane-per-candidate; the latent tile is staged in LDS ([256][L+1] float64), the fused
+// keyframe matrices are wave-uniform (scalar loads).
+template <bool LAT_F64, bool OUT_F64>
+__global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = a.L, xs = L + 1;
+    double *lds_x = (double *)smem;
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * 256;
+    const int ncand = (int)((a.B - b0) < 256 ? (a.B - b0) : 256);
+    for (int e = tid; e < 256 * L; e += 256) {
+        int c = e / L, i = e - c * L;
+        double v = 0.0;
+        if (c < ncand) v = LAT_F64 ? ((const double *)a.lat)[(b0 + c) * a.ld + i] : (double)((const float *)a.lat)[(b0 + c) * a.ld + i];
+        lds_x[c * xs + i] = v;
+    }
+    __syncthreads();
+    if (tid >= ncand) return;
+    const double *x = lds_x + tid * xs;
+    double err = 0.0;
+    for (int c = 0; c < a.n; c++) {
+        const double *par = a.par + (size_t)c * 8;
+        const int type = (int)par[0];
+        double fr[7];
+#pragma unroll
+        for (int d = 0; d < 7; d++) fr[d] = 0.0;
+        const int d_lo = (type == MG_CONSTRAINT_POSITION) ? 0 : 3;
+        const int d_hi = (type == MG_CONSTRAINT_POSITION) ? 3 : 7;
+#pragma unroll
+        for (int d = 0; d < 7; d++) {
+            if (d >= d_lo && d < d_hi && d < a.nch) {
+                const double *wr = a.W + ((size_t)c * a.nch + d) * L;
+                double acc = a.bias[(size_t)c * a.nch + d];
+                for (int k = 0; k < L; k++) acc = fma(wr[k], x[k], acc);
+                fr[d] = acc;
+            }
+        }
+        if (type == MG_CONSTRAINT_POSITION) {
+            // _point_distance: axes whose target is NaN (the reference's None) are ignored
+            double ds = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double t = par[2 + i];
+                if (t == t) ds += (t - fr[i]) * (t - fr[i]);
+            }
+            err += par[1] * sqrt(ds);
+        } else {
+            // heading = xz of (rotation of the root quaternion (w,x,y,z)) applied to ref_dir
+            const double qw = fr[3], qx = fr[4], qy = fr[5], qz = fr[6];
+            const double nq = qw * qw + qx * qx + qy * qy + qz * qz, s2 = 2.0 / nq;
+            const double rx = par[5], ry = par[6], rz = par[7];
+            const double px = (1.0 - s2 * (qy * qy + qz * qz)) * rx + s2 * (qx * qy - qz * qw) * ry + s2 * (qx * qz + qy * qw) * rz;
+            const double pz = s2 * (qx * qz - qy * qw) * rx + s2 * (qy * qz + qx * qw) * ry + (1.0 - s2 * (qx * qx + qy * qy)) * rz;
+            const double tn = sqrt(par[2] * par[2] + par[3] * par[3]);
+            const double tx = par[2] / tn, tz = par[3] / tn;
+            const double mn = sqrt(px * px + pz * pz);
+            const double mx = px / mn, mz = pz / mn;
+            double cosang = (tx * mx + tz * mz) / (sqrt(tx * tx + tz * tz) * sqrt(mx * mx + mz * mz));
+            cosang = fmin(1.0, fmax(cosang, -1.0));
+            err += par[1] * fabs(acos(cosang) * (180.0 / M_PI));
+        }
+    }
+    if (OUT_F64) ((double *)a.out)[b0 + tid] = err;
+    else ((float *)a.out)[b0 + tid] = (float)err;
+}
+
+int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt) {
+    mg_score_args a;
+    a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
+    size_t lds = (size_t)256 * (p->L + 1) * 8;
+    if (lds > 150 * 1024) { mg_set_error("mg_score_constraints: n_components %d too large", p->L); return MG_ERR_UNSUPPORTED; }
+    int64_t grid = (B + 255) / 256;
+    if (grid > 0x7fffffff) { mg_set_error("mg_score_constraints: too many samples"); return MG_ERR_UNSUPPORTED; }
+    hipStream_t st = p->ctx->stream;
+    const bool lf = ldt == MG_F64, of = odt == MG_F64;
+    if (lds > 64 * 1024) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (lf && of) hipLaunchKernelGGL((mg_score_kernel<true, true>), dim3((int)grid), dim3(256), lds, st, a);
+    else if (lf) hipLaunchKernelGGL((mg_score_kernel<true, false>), dim3((int)grid), dim3(256), lds, st, a);
+    else if (of) hipLaunchKernelGGL((mg_score_kernel<false, true>), dim3((int)grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((mg_score_kernel<false, false>), dim3((int)grid), dim3(256), lds, st, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// First-minimum argmin (reference motion_primitive_generator.py:251-257: `if min_error > error`):
+// the smallest value wins, ties go to the smallest index, NaN never wins, (0, +inf) if
+// nothing wins.  One workgroup: strided scan, wave shuffle reduction, LDS across waves.
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void mg_min_combine(double &v, int64_t &i, double ov, int64_t oi) {
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+template <bool F64>
+__global__ __launch_bounds__(1024) void mg_argmin_kernel(const void *vals, int64_t n, void *out) {
+    __shared__ double sv[16];
+    __shared__ int64_t si[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double best = INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t i = tid; i < n; i += 1024) {
+        double v = F64 ? ((const double *)vals)[i] : (double)((const float *)vals)[i];
+        if (v < best) { best = v; bi = i; }   // ascending i per thread: strict '<' keeps the first
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_down(best, off, 64);
+        long long oi = __shfl_down((long long)bi, off, 64);
+        mg_min_combine(best, bi, ov, (int64_t)oi);
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) mg_min_combine(best, bi, sv[w], si[w]);
+        if (bi == INT64_MAX) { bi = 0; best = INFINITY; }
+        ((int64_t *)out)[0] = bi;
+        ((double *)out)[1] = best;
+    }
+}
+
+int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev) {
+    if (dt == MG_F64) hipLaunchKernelGGL((mg_argmin_kernel<true>), dim3(1), dim3(1024), 0, ctx->stream, v, n, out_dev);
+    else hipLaunchKernelGGL((mg_argmin_kernel<false>), dim3(1), dim3(1024), 0, ctx->stream, v, n, out_dev);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}

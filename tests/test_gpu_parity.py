@@ -1,0 +1,252 @@
+"""GPU parity tests: HIP kernels (through the C-ABI in include/mg_hip.h) against the oracle
+and the golden vectors made by the reference's own code.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from morphablegraphs_amd import _capi, synthetic
+from oracle import c_oracle
+from oracle import mg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+# north-star tolerance on float32 pose values against the reference's float64 path:
+# 1e-5 absolute, widened only where 1e-5 is below float32 resolution of the value itself
+# (|v| >= 128: half an f32 ulp = 2^-24 |v|).
+def pose_tol(ref):
+    return 1e-5 + 2.0 ** -24 * np.abs(ref)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _capi.Context(0)
+    yield c
+    c.close()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_device_is_gfx950(ctx):
+    info = ctx.device_info()
+    assert "gfx950" in info["name"]
+    assert info["n_cu"] >= 200
+
+
+def test_frames_golden_all_paths(ctx, golden_case):
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    S = g["S"]
+    ref = g["frames"]
+    model = cp.frames_f32model(S)
+    paths = [_capi.MG_PATH_DIRECT] + ([_capi.MG_PATH_MFMA] if prim.mfma_supported else [])
+    for path in paths:
+        got = prim.back_project_frames(S, path=path)
+        assert got.shape == ref.shape and got.dtype == np.float32
+        err = np.abs(got.astype(np.float64) - ref)
+        assert np.all(err <= pose_tol(ref)), (name, path, float((err / pose_tol(ref)).max()))
+        # bit-exact against the CPU model of the f32 contract: pins frame/joint indexing exactly
+        np.testing.assert_array_equal(_bits(got), _bits(model), err_msg="%s path %d" % (name, path))
+    # float32 latents: same contract, the float32 values are the inputs
+    S32 = S.astype(np.float32)
+    model32 = cp.frames_f32model(S32.astype(np.float64))
+    for path in paths:
+        np.testing.assert_array_equal(_bits(prim.back_project_frames(S32, path=path)), _bits(model32))
+    prim.close()
+
+
+def test_frames_f64_and_coeffs_golden(ctx, golden_case):
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    scale = max(1.0, np.abs(g["frames"]).max())
+    got = prim.back_project_frames_f64(g["S"])
+    np.testing.assert_allclose(got, g["frames"], rtol=0, atol=4e-12 * scale)
+    coeffs = prim.back_project_coeffs(g["S"])
+    assert coeffs.shape == g["coeffs"].shape
+    np.testing.assert_allclose(coeffs, g["coeffs"], rtol=0, atol=4e-12 * scale)
+    c32 = prim.back_project_coeffs(g["S"], dtype=np.float32)
+    assert np.all(np.abs(c32 - g["coeffs"]) <= pose_tol(g["coeffs"]))
+    prim.close()
+
+
+def test_evaluate_arbitrary_times_golden(ctx, golden_case):
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    times = g["eval_times"]
+    grid = prim.time_grid(times)
+    i0, w, t = grid.tables()
+    i0_o, w_o = orc.basis_rows(cp.knots, times)
+    np.testing.assert_array_equal(i0, i0_o)
+    np.testing.assert_array_equal(w, w_o)
+    scale = max(1.0, np.abs(g["evals"]).max())
+    np.testing.assert_allclose(prim.back_project_frames_f64(g["S"], grid), g["evals"], rtol=0, atol=4e-12 * scale)
+    got = prim.back_project_frames(g["S"], grid)
+    assert np.all(np.abs(got - g["evals"]) <= pose_tol(g["evals"]))
+    np.testing.assert_array_equal(_bits(got), _bits(cp.frames_f32model(g["S"], times)))
+    # spline evaluation from explicit (mutable) coefficient arrays
+    ev = prim.spline_evaluate(g["coeffs"], grid)
+    np.testing.assert_allclose(ev, g["evals"], rtol=0, atol=4e-12 * scale)
+    fr = prim.spline_evaluate(g["coeffs"][0])
+    np.testing.assert_allclose(fr[0], g["frames"][0], rtol=0, atol=4e-12 * scale)
+    grid.close()
+    prim.close()
+
+
+def test_gmm_log_prob_golden(ctx, golden_case):
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    pc = g["precisions_cholesky"]
+    np.testing.assert_allclose(prim.precisions_cholesky(), pc, rtol=1e-9, atol=1e-9 * np.abs(pc).max())
+    lp = prim.gmm_log_prob(g["X"])
+    np.testing.assert_allclose(lp, g["logp"], rtol=1e-9, atol=1e-7)
+    lp32 = prim.gmm_log_prob(g["X"].astype(np.float32), dtype=np.float32)
+    cp = c_oracle.COraclePrimitive(data)
+    ref32 = cp.log_prob_f64(g["X"].astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(lp32, ref32, rtol=3e-7, atol=1e-6)
+    prim.close()
+
+
+@pytest.mark.parametrize("B", [1, 7, 16, 17, 255, 1000])
+def test_frames_ragged_batches_bit_exact(ctx, B):
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(B)
+    S = rng.standard_normal((B, 40)).astype(np.float32)
+    model = cp.frames_f32model(S.astype(np.float64))
+    for path in (_capi.MG_PATH_MFMA, _capi.MG_PATH_DIRECT, _capi.MG_PATH_AUTO):
+        got = prim.back_project_frames(S, path=path)
+        np.testing.assert_array_equal(_bits(got), _bits(model), err_msg="B=%d path=%d" % (B, path))
+    prim.close()
+
+
+def test_frames_leading_dimension_and_extra_columns(ctx):
+    """back_project uses s[:n_components] (reference motion_primitive.py:229); extra time
+    columns in the latent rows are ignored."""
+    data = synthetic.make_primitive(seed=3, n_components=10, n_frames=50, n_dim=23, n_gmm=2)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(0)
+    S = rng.standard_normal((33, 14))
+    got = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+    np.testing.assert_array_equal(_bits(got), _bits(cp.frames_f32model(np.ascontiguousarray(S[:, :10]))))
+    prim.close()
+
+
+def test_empty_batch_and_bad_arguments(ctx):
+    data = synthetic.make_tiny_primitive()
+    prim = _capi.Primitive(ctx, data)
+    assert prim.back_project_frames(np.zeros((0, 3), dtype=np.float32)).shape == (0, 12, 7)
+    assert prim.gmm_log_prob(np.zeros((0, 3))).shape == (0,)
+    with pytest.raises(_capi.MGError):
+        prim.back_project_frames(np.zeros((4, 2), dtype=np.float32))      # ld < n_components
+    bad = dict(data)
+    cov = np.array(data["gmm_covars"])
+    cov[0] = -np.eye(3)
+    bad["gmm_covars"] = cov.tolist()
+    with pytest.raises(_capi.MGError) as ei:
+        _capi.Primitive(ctx, bad)
+    assert ei.value.status == -5
+    prim.close()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE.json config 2 size (B = 8192): size-independent properties instead of a full
+    oracle pass -- linearity of the delta in the latent, row independence, and a seeded
+    subset against the oracle."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    B = 8192
+    rng = np.random.default_rng(1)
+    S = rng.standard_normal((B, 40)).astype(np.float32)
+    F = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+    assert F.shape == (B, 156, 79) and np.isfinite(F).all()
+    idx = rng.choice(B, size=48, replace=False)
+    np.testing.assert_array_equal(_bits(F[idx]), _bits(cp.frames_f32model(S[idx].astype(np.float64))))
+    # a candidate's frames do not depend on its batch position or neighbours
+    perm = rng.permutation(B)
+    Fp = prim.back_project_frames(S[perm], path=_capi.MG_PATH_MFMA)
+    np.testing.assert_array_equal(_bits(Fp), _bits(F[perm]))
+    # linearity: frames(s) - frames(0) is linear in s (float64 entry point)
+    z = prim.back_project_frames_f64(np.zeros((1, 40)))[0]
+    a, b = S[:4].astype(np.float64), S[4:8].astype(np.float64)
+    fa, fb = prim.back_project_frames_f64(a) - z, prim.back_project_frames_f64(b) - z
+    fab = prim.back_project_frames_f64(2.0 * a - 0.5 * b) - z
+    np.testing.assert_allclose(fab, 2.0 * fa - 0.5 * fb, rtol=0, atol=1e-9)
+    # log-likelihood at full size against the oracle
+    lp = prim.gmm_log_prob(S, dtype=np.float64)
+    np.testing.assert_allclose(lp, cp.log_prob_f64(S.astype(np.float64)), rtol=1e-10, atol=1e-8)
+    prim.close()
+
+
+def test_score_constraints_and_argmin(ctx):
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(2)
+    S = rng.standard_normal((513, 40))
+    cons = [
+        {"type": "position", "t": 155.0, "weight": 1.0, "target": [30.0, None, -40.0]},
+        {"type": "position", "t": 77.5, "weight": 0.5, "target": [5.0, 90.0, 3.0]},
+        {"type": "direction", "t": 155.0, "weight": 2.0, "target": [0.3, -1.0], "ref_dir": (0.0, 0.0, 1.0)},
+    ]
+    nan = np.nan
+    cons_c = np.array([[0, 155.0, 1.0, 30.0, nan, -40.0, 0, 0],
+                       [0, 77.5, 0.5, 5.0, 90.0, 3.0, 0, 0],
+                       [1, 155.0, 2.0, 0.3, -1.0, 0.0, 0.0, 1.0]])
+    cset = _capi.ConstraintSet(prim, cons)
+    err = prim.score_constraints(cset, S)
+    ref = cp.keyframe_errors_f64(S, cons_c)
+    np.testing.assert_allclose(err, ref, rtol=1e-10, atol=1e-9)
+    # argmin: first strict minimum, NaN never wins
+    for vals in (err, np.array([3.0, 1.0, 1.0, 2.0]), np.array([np.nan, 2.0, np.nan, 2.0]),
+                 np.array([np.inf, np.inf]), np.array([np.nan]), np.full(5000, 7.0)):
+        for dt in (np.float64, np.float32):
+            v = np.ascontiguousarray(vals, dtype=dt)
+            buf = ctx.upload(v)
+            i, m = ctx.argmin_first(buf, len(v), dt)
+            io, mo = c_oracle.first_min_argmin(v)
+            assert (i, m) == (io, mo) or (np.isinf(m) and np.isinf(mo) and i == io)
+            buf.free()
+    assert int(np.argmin(ref)) == ctx.argmin_first(ctx.upload(err), len(err), np.float64)[0]
+    cset.close()
+    prim.close()
+
+
+def test_device_sampler_distribution(ctx):
+    """Philox sampler is validated distributionally (not bit-compatible with sklearn)."""
+    data = synthetic.make_primitive(seed=2, n_components=6, n_frames=40, n_dim=11, n_gmm=3)
+    prim = _capi.Primitive(ctx, data)
+    counts = np.array([40000, 25000, 35000])
+    X, comp = prim.gmm_sample(counts, seed=1234)
+    assert X.shape == (100000, 6)
+    np.testing.assert_array_equal(comp, np.repeat(np.arange(3), counts))      # grouped by component
+    means, covars = np.array(data["gmm_means"]), np.array(data["gmm_covars"])
+    for k in range(3):
+        xs = X[comp == k]
+        se = np.sqrt(np.diag(covars[k]) / len(xs))
+        assert np.all(np.abs(xs.mean(axis=0) - means[k]) < 5 * se)
+        emp = np.cov(xs.T)
+        assert np.max(np.abs(emp - covars[k])) < 0.05 * np.abs(covars[k]).max() + 0.02
+    X2, _ = prim.gmm_sample(counts, seed=1234)
+    np.testing.assert_array_equal(X, X2)                                         # reproducible
+    X3, _ = prim.gmm_sample(counts, seed=1235)
+    assert np.abs(X - X3).max() > 0.1
+    prim.close()
+
+
+def test_graph_of_primitives_shapes(ctx):
+    """BASELINE.json config 3 shapes: 16 primitives with varying (L, F, K)."""
+    rng = np.random.default_rng(5)
+    for data in synthetic.make_graph_primitives(16)[:6]:
+        prim = _capi.Primitive(ctx, data)
+        cp = c_oracle.COraclePrimitive(data)
+        S = rng.standard_normal((40, prim.n_components)).astype(np.float32)
+        got = prim.back_project_frames(S)
+        np.testing.assert_array_equal(_bits(got), _bits(cp.frames_f32model(S.astype(np.float64))))
+        np.testing.assert_allclose(prim.gmm_log_prob(S, dtype=np.float64), cp.log_prob_f64(S.astype(np.float64)),
+                                   rtol=1e-10, atol=1e-8)
+        prim.close()
