@@ -303,9 +303,9 @@ static int mg_upload(mg_context *ctx, const std::vector<T> &h, T **d) {
 static void mg_free_grid_device(mg_time_grid *g) {
     if (g->d_i0) (void)hipFree(g->d_i0);
     if (g->d_w) (void)hipFree(g->d_w);
-    if (g->d_mf) (void)hipFree(g->d_mf);
+    if (g->d_w32) (void)hipFree(g->d_w32);
     if (g->d_chunks) (void)hipFree(g->d_chunks);
-    g->d_i0 = nullptr; g->d_w = nullptr; g->d_mf = nullptr; g->d_chunks = nullptr;
+    g->d_i0 = nullptr; g->d_w = nullptr; g->d_w32 = nullptr; g->d_chunks = nullptr;
 }
 
 static int mg_round_stride(int nlocal) {
@@ -316,40 +316,42 @@ static int mg_round_stride(int nlocal) {
     return s;
 }
 
+// LDS of the MFMA kernel: coefficient image, float64 root image, float32 root outputs,
+// per-sample weight / first-tap tables.
 static int mg_lds_bytes(const mg_primitive *p, int stride, int wi) {
     int coef = MG_NCAND * stride * 4;
     int root = MG_NCAND * (wi * p->nroot + 1) * 8;
-    int s64 = MG_NCAND * (p->L + 1) * 8;
-    return coef + root + s64;
+    int rout = MG_NCAND * MG_MAX_NT * 4 * 4;
+    int tabs = MG_MAX_NT * (16 + 4);
+    return coef + root + rout + tabs;
 }
 
-// Split the grid into chunks whose coefficient window fits the LDS budget.
+// Split the grid into chunks (runs of consecutive time samples) whose coefficient window
+// fits the LDS budget.
 static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
-    const int D = p->D;
+    const int Dp = p->Dp;
     g->chunks.clear();
     g->mfma_ok = false;
-    if (p->KK == 0 || g->T == 0) return;
+    if (p->KK == 0 || g->T == 0 || Dp > 256) return;
     // window budget: three workgroups per CU (160 KiB LDS) when possible, else one
     const int budget3 = 53 * 1024, budget1 = 156 * 1024;
     auto fits = [&](int wi, int budget) {
-        int nlocal = ((wi * D + 15) / 16 + 1) * 16;
+        int nlocal = ((wi * Dp + 15) / 16 + 1) * 16;
         return mg_lds_bytes(p, mg_round_stride(nlocal), wi) <= budget;
     };
     int W = 0;
-    for (int w = 12; w >= 4; w--)
+    for (int w = MG_MAX_WI; w >= 4; w--)
         if (fits(w, budget3)) { W = w; break; }
     if (W == 0)
-        for (int w = 8; w >= 4; w--)
+        for (int w = MG_MAX_WI; w >= 4; w--)
             if (fits(w, budget1)) { W = w; break; }
     if (W == 0) return;  // n_dim too large for the LDS-staged kernel
-    if (W > 8) W = 8;    // wider windows only add redundant contraction work
-    const int max_nT = 64;
     int a = 0;
     int max_stride = 0, max_wi = 0;
     while (a < g->T) {
         int imin = g->i0[a], imax = g->i0[a];
         int b = a + 1;
-        while (b < g->T && b - a < max_nT) {
+        while (b < g->T && b - a < MG_MAX_NT) {
             int lo = std::min(imin, g->i0[b]), hi = std::max(imax, g->i0[b]);
             if (hi - lo + 4 > W) break;
             imin = lo; imax = hi;
@@ -361,9 +363,11 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
         c.nT = b - a;
         c.imin = imin;
         c.wi = imax - imin + 4;
-        c.rt0 = (imin * D) / 16;
-        int rt1 = ((imin + c.wi) * D + 15) / 16;
+        c.rt0 = (imin * Dp) / 16;
+        int rt1 = ((imin + c.wi) * Dp + 15) / 16;
         c.ntiles = rt1 - c.rt0;
+        c.rrt0 = (imin * p->nroot) / 16;
+        c.nrt = ((imin + c.wi) * p->nroot + 15) / 16 - c.rrt0;
         g->chunks.push_back(c);
         max_stride = std::max(max_stride, mg_round_stride(c.ntiles * 16));
         max_wi = std::max(max_wi, c.wi);
@@ -391,20 +395,14 @@ static int mg_grid_build(mg_primitive *p, mg_time_grid *g, const double *times, 
             mg_basis_row(p->knots.data(), (int)p->knots.size(), times[f], &g->i0[f], &g->w[4 * f]);
         }
     }
-    // mean frames in float64: MF[f][d] = sum_j w_j * mean'[(i0+j) D + d]  (j ascending, no fma)
-    std::vector<double> mf((size_t)T * p->D);
-    for (int f = 0; f < T; f++)
-        for (int d = 0; d < p->D; d++) {
-            double acc = 0.0;
-            for (int j = 0; j < 4; j++) acc = acc + g->w[4 * f + j] * p->means_[(size_t)(g->i0[f] + j) * p->D + d];
-            mf[(size_t)f * p->D + d] = acc;
-        }
     mg_plan_chunks(p, g);
+    std::vector<float> w32(g->w.size());
+    for (size_t q = 0; q < g->w.size(); q++) w32[q] = (float)g->w[q];
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
     int rc;
     if ((rc = mg_upload(p->ctx, g->i0, &g->d_i0)) != MG_OK) return rc;
     if ((rc = mg_upload(p->ctx, g->w, &g->d_w)) != MG_OK) return rc;
-    if ((rc = mg_upload(p->ctx, mf, &g->d_mf)) != MG_OK) return rc;
+    if ((rc = mg_upload(p->ctx, w32, &g->d_w32)) != MG_OK) return rc;
     if ((rc = mg_upload(p->ctx, g->chunks, &g->d_chunks)) != MG_OK) return rc;
     return MG_OK;
 }
@@ -443,8 +441,8 @@ static void mg_primitive_free(mg_primitive *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Eroot, p->d_mean, p->d_gP, p->d_gmP,
-                    p->d_gconst, p->d_gmean, p->d_gchol};
+    void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean,
+                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (mg_time_grid *g : {p->canonical, p->coeff_grid})
@@ -477,7 +475,8 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
     p->NB = NB; p->D = D; p->L = L; p->F = d->n_canonical_frames; p->K = K; p->R = R;
     p->nroot = std::min(3, D);
     p->KK = (L <= 4 * MG_MAX_KK) ? (((L + 3) / 4 + 1) / 2) * 2 : 0;
-    p->RT = (R + 15) / 16;
+    p->Dp = (D + 3) & ~3;
+    p->RT = (NB * p->Dp + 15) / 16;
     p->knots.assign(d->knots, d->knots + NB + 4);
     double tm[3] = {1.0, 1.0, 1.0};
     if (d->translation_maxima)
@@ -506,24 +505,44 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                 et64[(size_t)k * R + r] = p->Es[(size_t)r * L + k];
                 et32[(size_t)k * R + r] = (float)p->Es[(size_t)r * L + k];
             }
-        std::vector<double> eroot((size_t)NB * p->nroot * L);
-        for (int i = 0; i < NB; i++)
-            for (int dd = 0; dd < p->nroot; dd++)
-                for (int k = 0; k < L; k++) eroot[((size_t)i * p->nroot + dd) * L + k] = p->Es[((size_t)i * D + dd) * L + k];
         if (rc == MG_OK) rc = mg_upload(ctx, et32, &p->d_Et32);
         if (rc == MG_OK) rc = mg_upload(ctx, et64, &p->d_Et64);
-        if (rc == MG_OK) rc = mg_upload(ctx, eroot, &p->d_Eroot);
         if (rc == MG_OK) rc = mg_upload(ctx, p->means_, &p->d_mean);
+        {
+            std::vector<float> m32((size_t)p->RT * 16, 0.0f);
+            for (int i = 0; i < NB; i++)
+                for (int dd = 0; dd < D; dd++) m32[(size_t)i * p->Dp + dd] = (float)p->means_[(size_t)i * D + dd];
+            if (rc == MG_OK) rc = mg_upload(ctx, m32, &p->d_mean32);
+        }
+        if (rc == MG_OK && p->KK > 0) {
+            // root rows (row = i*nroot + d) as v_mfma_f64_16x16x4_f64 A fragments:
+            // lane l supplies A[row = l & 15][k = 4*kk + (l >> 4)].  Image [tile][kk][lane].
+            const int KK = p->KK, nr = p->nroot, RR = NB * nr;
+            p->RRT = (RR + 15) / 16;
+            std::vector<double> rpack((size_t)p->RRT * KK * 64, 0.0), mroot((size_t)p->RRT * 16, 0.0);
+            for (int rr = 0; rr < RR; rr++) mroot[rr] = p->means_[(size_t)(rr / nr) * D + rr % nr];
+            for (int t = 0; t < p->RRT; t++)
+                for (int kk = 0; kk < KK; kk++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        int rr = t * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
+                        if (rr < RR && k < L)
+                            rpack[((size_t)t * KK + kk) * 64 + lane] = p->Es[((size_t)(rr / nr) * D + rr % nr) * L + k];
+                    }
+            rc = mg_upload(ctx, rpack, &p->d_Erpack);
+            if (rc == MG_OK) rc = mg_upload(ctx, mroot, &p->d_meanroot);
+        }
         if (rc == MG_OK && p->KK > 0) {
             // MFMA A-operand fragments of v_mfma_f32_16x16x4_f32: lane l supplies
-            // A[row = l & 15][k = 4*kk + (l >> 4)].  Image [rt][kk/2][lane][2].
-            const int KK = p->KK;
+            // A[row = l & 15][k = 4*kk + (l >> 4)].  Rows are the padded coefficient rows
+            // r' = i*Dp + d (zero rows for d >= D).  Image [rt][kk/2][lane][2].
+            const int KK = p->KK, Dp = p->Dp;
             std::vector<float> pack((size_t)p->RT * KK * 64, 0.0f);
             for (int rt = 0; rt < p->RT; rt++)
                 for (int kk = 0; kk < KK; kk++)
                     for (int lane = 0; lane < 64; lane++) {
-                        int r = rt * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
-                        float v = (r < R && k < L) ? (float)p->Es[(size_t)r * L + k] : 0.0f;
+                        int rp = rt * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
+                        int i = rp / Dp, dd = rp - i * Dp;
+                        float v = (i < NB && dd < D && k < L) ? (float)p->Es[((size_t)i * D + dd) * L + k] : 0.0f;
                         pack[(((size_t)rt * (KK / 2) + kk / 2) * 64 + lane) * 2 + (kk & 1)] = v;
                     }
             rc = mg_upload(ctx, pack, &p->d_Epack);

@@ -54,14 +54,17 @@ void mg_prof_end(mg_context *ctx, int slot);
 int mg_prof_resolve(mg_context *ctx);
 
 // One chunk of a time grid handled by one workgroup of the MFMA kernel.
+#define MG_MAX_WI 8          // basis functions per chunk window
+#define MG_MAX_NT 32         // time samples per chunk
 struct mg_chunk {
-    int32_t t0;      // first time index
-    int32_t nT;      // number of time samples
-    int32_t rt0;     // first global 16-row tile of the coefficient window
-    int32_t ntiles;  // number of 16-row tiles
-    int32_t imin;    // first coefficient index of the window
-    int32_t wi;      // coefficient rows (basis functions) in the window
-    int32_t pad0, pad1;
+    int32_t t0;        // first time index (chunks are runs of consecutive time indices)
+    int32_t nT;        // number of time samples in the chunk, <= MG_MAX_NT
+    int32_t rt0;       // first global 16-row tile of the (padded-row) coefficient window
+    int32_t ntiles;    // number of 16-row tiles
+    int32_t imin;      // first coefficient index of the window
+    int32_t wi;        // coefficient rows (basis functions) in the window, <= MG_MAX_WI
+    int32_t rrt0;      // first 16-row tile of the root-row window (rows = i*nroot + d)
+    int32_t nrt;       // number of root tiles
 };
 
 struct mg_time_grid {
@@ -74,8 +77,8 @@ struct mg_time_grid {
     std::vector<mg_chunk> chunks;
     // device tables
     int32_t *d_i0 = nullptr;
-    double *d_w = nullptr;   // (T,4)
-    double *d_mf = nullptr;  // (T,D) mean frames, float64
+    double *d_w = nullptr;      // (T,4) float64 weights
+    float *d_w32 = nullptr;     // (T,4) float32 weights
     mg_chunk *d_chunks = nullptr;
     int32_t n_chunks = 0;
     int32_t stride = 0;      // floats per candidate in the LDS coefficient image
@@ -89,18 +92,22 @@ struct mg_primitive {
     int32_t NB = 0, D = 0, L = 0, F = 0, K = 0, R = 0;
     int32_t nroot = 0;  // min(3, D): channels computed in float64
     int32_t KK = 0;     // MFMA k-steps (even), 0 when L > 64
-    int32_t RT = 0;     // 16-row tiles
+    int32_t RT = 0;     // 16-row tiles of the padded-row space NB*Dp
     // host float64 copies (already scaled by translation_maxima)
     std::vector<double> Es;    // (R, L)
     std::vector<double> means_;  // mean' (R)
     std::vector<double> knots;
     std::vector<double> gw, gm, gc, gp;  // weights (K), means (K,L), covars (K,L,L), prec chol (K,L,L)
     // device constants
-    float *d_Epack = nullptr;    // [RT][KK/2][64][2] MFMA A fragments, f32
+    int32_t Dp = 0;              // n_dim rounded up to a multiple of 4: row pitch of the padded coefficient rows
+    float *d_Epack = nullptr;    // [RT][KK/2][64][2] MFMA A fragments, f32, padded rows r' = i*Dp + d
     float *d_Et32 = nullptr;     // [L][R] f32
     double *d_Et64 = nullptr;    // [L][R] f64
-    double *d_Eroot = nullptr;   // [NB*nroot][L] f64
+    double *d_Erpack = nullptr;  // [RRT][KK][64] f64 MFMA A fragments of the root rows (row = i*nroot + d)
+    double *d_meanroot = nullptr;  // [RRT*16] f64 mean' of the root rows
+    float *d_mean32 = nullptr;   // [RT*16] f32 mean' in padded-row order (zero padded)
     double *d_mean = nullptr;    // (R) f64
+    int32_t RRT = 0;             // 16-row tiles of the root-row space
     // GMM device constants
     double *d_gP = nullptr;      // [K][L(j)][L(i)]: column j of P_k contiguous over i
     double *d_gmP = nullptr;     // [K][L]: mu_k . P_k

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Profile bench.py on the GPU box: kernel trace + PMC passes (each in its own run).
+# usage: tools/prof_bench.sh <tag> [extra bench args]
+set -o pipefail
+tag=${1:-r01}; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+B="$GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-profile-events $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $B > $out/trace.log 2>&1 || { echo trace failed; tail -5 $out/trace.log; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $B > $out/pmc_fetch.log 2>&1 || { echo fetch failed; tail -5 $out/pmc_fetch.log; exit 1; }
+rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $out/pmc_write -- python3 $B > $out/pmc_write.log 2>&1 || { echo write failed; tail -5 $out/pmc_write.log; exit 1; }
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $out/pmc_sq1 -- python3 $B > $out/pmc_sq1.log 2>&1 || { echo sq1 failed; tail -5 $out/pmc_sq1.log; exit 1; }
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $out/pmc_sq2 -- python3 $B > $out/pmc_sq2.log 2>&1 || { echo sq2 failed; tail -5 $out/pmc_sq2.log; exit 1; }
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_misc -- python3 $B > $out/pmc_misc.log 2>&1 || { echo misc failed; tail -5 $out/pmc_misc.log; exit 1; }
+find $out -name '*.csv' | head -40
+du -sh $out
