@@ -75,7 +75,120 @@ __global__ __launch_bounds__(MG_GMM_CANDS *MG_GMM_WAVES) void mg_gmm_logp_kernel
     }
 }
 
+// -----------------------------------------------------------------------------------------
+// MFMA variant (n_components <= 64): one workgroup = 16 candidates, one wave = one mixture
+// component at a time.  Y = X P_k - mu_k P_k by v_mfma_f64_16x16x4_f64: A = the latent tile
+// (registers), B = precision-Cholesky fragments streamed from L2 (only the k-steps at or above
+// the diagonal of each 16-column tile), C-in = -mu_k P_k.  Each lane squares its 4 results,
+// sums over the column tiles, and the Mahalanobis term is finished by a wavefront
+// (butterfly) reduction over the 16 lanes that share the candidate rows.
+// -----------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct mg_gmm_mfma_args {
+    int64_t B, ld;
+    int32_t K, L, JT;
+};
+
+template <int KK, bool X_F64, bool OUT_F64>
+__global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__restrict__ Ppack,  // [K][JT][KK][64]
+                                                              const double *__restrict__ mP,     // [K][JT*16]
+                                                              const double *__restrict__ cst,    // [K]
+                                                              const void *__restrict__ x, void *__restrict__ out,
+                                                              const mg_gmm_mfma_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *lds_t = (double *)smem;   // [K][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t b0 = (int64_t)blockIdx.x * 16;
+    const int ncand = (int)((a.B - b0) < 16 ? (a.B - b0) : 16);
+    // A fragments: lane l supplies A[row = l & 15 (candidate)][k = 4*kk + (l >> 4)]
+    double xf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        const int k = 4 * kk + g;
+        double v = 0.0;
+        if (cl < ncand && k < a.L) v = X_F64 ? ((const double *)x)[(b0 + cl) * a.ld + k] : (double)((const float *)x)[(b0 + cl) * a.ld + k];
+        xf[kk] = v;
+    }
+    for (int k = wave; k < a.K; k += 4) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int jt = 0; jt < a.JT; jt++) {
+            const double *pp = Ppack + (((size_t)k * a.JT + jt) * KK) * 64 + lane;
+            const double c0 = -mP[((size_t)k * a.JT + jt) * 16 + cl];
+            f64x4 acc = {c0, c0, c0, c0};
+            const int kmax = 4 * (jt + 1) < KK ? 4 * (jt + 1) : KK;   // P_k is upper triangular
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++)
+                if (kk < kmax) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], pp[kk * 64], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[r] = fma(acc[r], acc[r], part[r]);
+        }
+        // C/D layout: col = lane & 15, row (candidate) = (lane >> 4) + 4*reg: reduce over the 16 columns
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = part[r];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            part[r] = v;
+        }
+        if (cl == 0) {
+            const double ck = cst[k];
+#pragma unroll
+            for (int r = 0; r < 4; r++) lds_t[k * 16 + g + 4 * r] = ck - 0.5 * part[r];
+        }
+    }
+    __syncthreads();
+    if (tid < ncand) {
+        double vmax = -INFINITY;
+        for (int k = 0; k < a.K; k++) vmax = fmax(vmax, lds_t[k * 16 + tid]);
+        double r;
+        if (vmax == -INFINITY) {
+            r = -INFINITY;
+        } else {
+            double acc = 0.0;
+            for (int k = 0; k < a.K; k++) acc += exp(lds_t[k * 16 + tid] - vmax);
+            r = log(acc) + vmax;
+        }
+        if (OUT_F64) ((double *)out)[b0 + tid] = r;
+        else ((float *)out)[b0 + tid] = (float)r;
+    }
+}
+
+template <int KK>
+static int mg_launch_gmm_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
+    mg_gmm_mfma_args a;
+    a.B = B; a.ld = ld; a.K = p->K; a.L = p->L; a.JT = (p->L + 15) / 16;
+    const int64_t grid = (B + 15) / 16;
+    if (grid > 0x7fffffff) { mg_set_error("mg_gmm_log_prob: too many samples"); return MG_ERR_UNSUPPORTED; }
+    const size_t lds = (size_t)p->K * 16 * 8;
+    hipStream_t st = p->ctx->stream;
+    const bool xf = xdt == MG_F64, of = odt == MG_F64;
+    if (xf && of) hipLaunchKernelGGL((mg_gmm_logp_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a);
+    else if (xf) hipLaunchKernelGGL((mg_gmm_logp_mfma_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a);
+    else if (of) hipLaunchKernelGGL((mg_gmm_logp_mfma_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a);
+    else hipLaunchKernelGGL((mg_gmm_logp_mfma_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
+    if (p->d_gPpack && p->K * 16 * 8 <= 60 * 1024) {
+        switch (p->KK) {
+            case 2: return mg_launch_gmm_mfma_kk<2>(p, x, xdt, B, ld, out, odt);
+            case 4: return mg_launch_gmm_mfma_kk<4>(p, x, xdt, B, ld, out, odt);
+            case 6: return mg_launch_gmm_mfma_kk<6>(p, x, xdt, B, ld, out, odt);
+            case 8: return mg_launch_gmm_mfma_kk<8>(p, x, xdt, B, ld, out, odt);
+            case 10: return mg_launch_gmm_mfma_kk<10>(p, x, xdt, B, ld, out, odt);
+            case 12: return mg_launch_gmm_mfma_kk<12>(p, x, xdt, B, ld, out, odt);
+            case 14: return mg_launch_gmm_mfma_kk<14>(p, x, xdt, B, ld, out, odt);
+            case 16: return mg_launch_gmm_mfma_kk<16>(p, x, xdt, B, ld, out, odt);
+            default: break;
+        }
+    }
     mg_gmm_args a;
     a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
     int64_t grid = (B + MG_GMM_CANDS - 1) / MG_GMM_CANDS;

@@ -442,7 +442,7 @@ static void mg_primitive_free(mg_primitive *p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean,
-                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol};
+                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (mg_time_grid *g : {p->canonical, p->coeff_grid})
@@ -593,6 +593,23 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                 gmP[(size_t)k * L + j] = acc;
             }
             gconst[k] = std::log(p->gw[k]) + logdet - 0.5 * (double)L * log2pi;
+        }
+        if (p->KK > 0) {
+            // B fragments of v_mfma_f64_16x16x4_f64: lane l supplies B[k = 4*kk + (l >> 4)][col = l & 15]
+            const int KK = p->KK, JT = (L + 15) / 16;
+            std::vector<double> ppack((size_t)K * JT * KK * 64, 0.0), mpad((size_t)K * JT * 16, 0.0);
+            for (int k = 0; k < K; k++) {
+                for (int j = 0; j < L; j++) mpad[(size_t)k * JT * 16 + j] = gmP[(size_t)k * L + j];
+                for (int jt = 0; jt < JT; jt++)
+                    for (int kk = 0; kk < KK; kk++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            int i = 4 * kk + (lane >> 4), j = 16 * jt + (lane & 15);
+                            if (i < L && j < L && i <= j)
+                                ppack[((((size_t)k * JT + jt) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * L * L + (size_t)i * L + j];
+                        }
+            }
+            if (rc == MG_OK) rc = mg_upload(ctx, ppack, &p->d_gPpack);
+            if (rc == MG_OK) rc = mg_upload(ctx, mpad, &p->d_gmPpad);
         }
         if (rc == MG_OK) rc = mg_upload(ctx, gP, &p->d_gP);
         if (rc == MG_OK) rc = mg_upload(ctx, gmP, &p->d_gmP);

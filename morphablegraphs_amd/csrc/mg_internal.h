@@ -109,6 +109,8 @@ struct mg_primitive {
     double *d_mean = nullptr;    // (R) f64
     int32_t RRT = 0;             // 16-row tiles of the root-row space
     // GMM device constants
+    double *d_gPpack = nullptr;  // [K][JT][KK][64]: v_mfma_f64_16x16x4_f64 B fragments of P_k (L <= 64)
+    double *d_gmPpad = nullptr;  // [K][JT*16]: mu_k . P_k, zero padded
     double *d_gP = nullptr;      // [K][L(j)][L(i)]: column j of P_k contiguous over i
     double *d_gmP = nullptr;     // [K][L]: mu_k . P_k
     double *d_gconst = nullptr;  // [K]: log w_k + sum log diag P_k - 0.5 L log 2pi
