@@ -9,18 +9,23 @@
 //       (== the v_mfma_f32_16x16x4_f32 accumulation order with C-in = mean),
 //       out = w0*c0, fmaf(w1,c1,.), fmaf(w2,c2,.), fmaf(w3,c3,.)
 //   channels d <  nroot : the same in float64 (v_mfma_f64_16x16x4_f64 / fma), out = (float)v64.
+#include <cstdio>
 #include <cstdlib>
 
 #include "mg_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte store
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 // scalars of one launch; the pointers are separate __restrict__ kernel parameters
 struct mg_frames_args {
     int64_t B, ld;
-    int32_t T, D, Dp, L, nroot, n_chunks, n_tiles, stride, max_wi;
-    int32_t debug;   // MG_DEBUG_FLAGS (bench ablations only): 1 = skip stage 1, 2 = skip stage 2 stores
+    int32_t T, D, Dp, cshift, L, nroot, n_chunks, n_tiles, stride, max_wi;
+    int32_t debug;   // MG_DEBUG_FLAGS (bench ablations only): 1 = producers idle, 2 = consumers idle, 16 = phase timers
+    int32_t pad;
 };
 
 template <bool F64>
@@ -29,24 +34,130 @@ __device__ __forceinline__ double mg_load_lat(const void *lat, int64_t idx) {
     return (double)((const float *)lat)[idx];
 }
 
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte store
+// diagnostic phase timers (MG_DEBUG_FLAGS & 16): per-wave s_memtime deltas accumulated in
+// registers over all units and written once at kernel end (a store inside the loop would put
+// the producers' loads behind it in vmcnt order and distort what is being measured).
+__device__ unsigned long long mg_dbg_stamps[16][8];   // [wave][phase] of workgroup 0
+#define MG_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define MG_STAMP(ph)                                                     \
+    do {                                                                 \
+        if (a.debug & 16) {                                              \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            st_acc[ph] += now_ - st_prev;                                \
+            st_prev = now_;                                              \
+        }                                                                \
+    } while (0)
+#define MG_STAMP_DUMP                                                    \
+    do {                                                                 \
+        if ((a.debug & 16) && blockIdx.x == 0 && lane == 0)              \
+            for (int ph_ = 0; ph_ < 8; ph_++) mg_dbg_stamps[wave][ph_] = st_acc[ph_]; \
+    } while (0)
 
-// One workgroup = 16 candidates x one time chunk (consecutive time samples whose taps fall in
-// a window of <= 8 basis functions).
-//   stage 1: the window's coefficients for the 16 candidates by v_mfma_f32_16x16x4_f32
-//            (A = E' fragments of the padded rows r' = i*Dp + d streamed from L2, next tiles
-//            prefetched; B = the latent tile held in registers; C-in = mean'); accumulators ->
-//            LDS image [cand][i_local*Dp + d].  Root-translation rows by
-//            v_mfma_f64_16x16x4_f64 -> LDS (float64), then their spline taps in float64 ->
-//            float32 root outputs in LDS.  The chunk's weights / first taps are staged in LDS, so
-//            no memory read follows the first store of the workgroup.
-//   stage 2: "quad-row" sweep.  A wave owns one candidate at a time; a lane owns 4 consecutive
-//            channels of one time sample (ds_read_b128 per tap, 16 FMAs) and 64/(Dp/4) samples are
-//            in flight per wave, so one wave store instruction writes ~1 KB of consecutive
-//            bytes and consecutive instructions continue where the last one ended -- the store
-//            stream every candidate's (F, D) block wants.
+extern "C" int mg_debug_dump_stamps(void) {
+    unsigned long long h[16][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(mg_dbg_stamps), sizeof(h)) != hipSuccess) return -1;
+    printf("per-wave cycles summed over the units of workgroup 0; phase p = time from stamp p-1 to stamp p\n");
+    printf("  (0: loop top, 1: loads issued / root taps, 2: MFMA, 3: root staging, 4: consume / work end, 5: barrier wait)\n");
+    for (int w = 0; w < 12; w++) {
+        printf("wave %2d:", w);
+        for (int ph = 0; ph < 6; ph++) printf(" %9llu", h[w][ph]);
+        printf("\n");
+    }
+    return 0;
+}
+
+// -----------------------------------------------------------------------------------------
+// The hot-path kernel: persistent, wave-specialised.
+//
+// A unit = 16 candidates x one time chunk (consecutive samples whose spline taps fall in a
+// window of <= 8 basis functions).  One workgroup per CU walks a contiguous run of units.
+//
+// Why the roles are split: (1) vmcnt retires in issue order, so a wave with stores in flight
+// cannot consume a later load until the stores drain -- producers therefore only LOAD and
+// consumers only STORE; (2) the contraction is L2-latency bound and the sweep is HBM bound:
+// in one-shot workgroups they run in lockstep and add up instead of overlapping.
+//
+//   producer wave 0    : unit it+1's per-sample tables -> tb[(it+1)%3]; unit it+1's root-translation
+//                        rows by v_mfma_f64_16x16x4_f64 (C-in = mean') -> rs[(it+1)&1]
+//   producer waves 1-3 : unit it's window of padded coefficient rows by v_mfma_f32_16x16x4_f32
+//                        (A = E' fragments from L2, two tiles in flight + two prefetched; B = the
+//                        latent tile in registers; C-in = mean') -> buf[it&1].img [cand][i*Dp + d + cshift]
+//   consumer waves 4-11: their share of unit it's root taps (float64) -> buf[it&1].ro, then the
+//                        "quad-row" sweep of unit it-1: a wave owns two candidates; a lane owns 4
+//                        consecutive channels of one sample (4 ds_read_b128 taps, 16 FMAs, one
+//                        dwordx4 store), the last lane of each row group owns the root channels;
+//                        64/20 samples per wave instruction, so one store instruction writes ~1 KB
+//                        of consecutive bytes and the next continues where it ended.
+//   one raw s_barrier per unit with lgkmcnt(0) only: the consumers' stores stay in flight across it.
+//
+// LDS: buf[2] = image [16][stride] f32 + root outputs [16][MG_MAX_NT][4] f32; tb[3] = w32 [MG_MAX_NT]
+// float4, image tap byte offsets [MG_MAX_NT] int, root image tap offsets [MG_MAX_NT] int, w64 [MG_MAX_NT][4]
+// double; rs[2] = float64 root image.
+// -----------------------------------------------------------------------------------------
+#define MG_WS_NPW 4      // producer waves
+#define MG_WS_NCW 8      // consumer waves, two candidates each
+#define MG_WS_BLOCK (64 * (MG_WS_NPW + MG_WS_NCW))
+#define MG_TB_BYTES (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32)
+
+__device__ __forceinline__ void mg_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct mg_unit {
+    mg_chunk ck;
+    int64_t b0;
+    int ncand;
+    int tile;
+};
+struct mg_cursor {   // (tile, chunk) cursor over a workgroup's run of units: no division inside the unit loop
+    int tile, chunk;
+};
+__device__ __forceinline__ mg_unit mg_unit_at(const mg_chunk *__restrict__ chunks, const mg_frames_args &a, const mg_cursor &c) {
+    mg_unit r;
+    r.tile = c.tile;
+    r.ck = chunks[c.chunk];
+    r.b0 = (int64_t)c.tile * MG_NCAND;
+    r.ncand = (int)((a.B - r.b0) < MG_NCAND ? (a.B - r.b0) : MG_NCAND);
+    return r;
+}
+__device__ __forceinline__ void mg_cursor_next(mg_cursor &c, int n_chunks) {
+    if (++c.chunk == n_chunks) { c.chunk = 0; c.tile++; }
+}
+
+// 4 channels of one sample: taps are 4 consecutive basis rows of the image (byte pitch dp4)
+__device__ __forceinline__ f32x4 mg_quad_taps(const unsigned char *tp, const float4 w, int dp4) {
+    const f32x4 t0 = *(const f32x4 *)tp;
+    const f32x4 t1 = *(const f32x4 *)(tp + dp4);
+    const f32x4 t2 = *(const f32x4 *)(tp + 2 * dp4);
+    const f32x4 t3 = *(const f32x4 *)(tp + 3 * dp4);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float x = w.x * t0[e];
+        x = fmaf(w.y, t1[e], x);
+        x = fmaf(w.z, t2[e], x);
+        x = fmaf(w.w, t3[e], x);
+        v[e] = x;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {
+    if (n == 4) {
+        *(f32x4u *)op = v;
+    } else if (n == 3) {
+        f32x3u t = {v[0], v[1], v[2]};
+        *(f32x3u *)op = t;
+    } else if (n == 2) {
+        f32x2u t = {v[0], v[1]};
+        *(f32x2u *)op = t;
+    } else if (n == 1) {
+        op[0] = v[0];
+    }
+}
+
 template <int KK, bool LAT_F64>
-__global__ __launch_bounds__(MG_BLOCK) void mg_frames_mfma_kernel(
+__global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const float *__restrict__ Epack,      // [RT][KK/2][64][2]
     const float *__restrict__ mean32,     // [RT*16]
     const double *__restrict__ Erpack,    // [RRT][KK][64]
@@ -57,170 +168,281 @@ __global__ __launch_bounds__(MG_BLOCK) void mg_frames_mfma_kernel(
     const double *__restrict__ w64,       // (T, 4)
     const mg_chunk *__restrict__ chunks,
     float *__restrict__ out,              // (B,T,D)
-    const mg_frames_args a) {
+    const mg_frames_args a, const int buf_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // XCD-aware block -> (tile, chunk): blocks that share blockIdx % 8 (one XCD under
-    // round-robin dispatch; a speed assumption only) take all chunks of the same tiles, so a
-    // candidate's neighbouring output ranges are written through one L2.
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int tile = (slot / a.n_chunks) * 8 + xcd;
-    const int chunk_id = slot % a.n_chunks;
-    if (tile >= a.n_tiles) return;
-    const mg_chunk ck = chunks[chunk_id];
-    const int64_t b0 = (int64_t)tile * MG_NCAND;
-    const int ncand = (int)((a.B - b0) < MG_NCAND ? (a.B - b0) : MG_NCAND);
     const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
-
-    // LDS carve-up (all 16-byte aligned: stride % 4 == 0)
-    float *lds_c = (float *)smem;                                          // [16][stride]
-    float4 *lds_w = (float4 *)(lds_c + (size_t)MG_NCAND * stride);         // [MG_MAX_NT] weights
-    float *lds_ro = (float *)(lds_w + MG_MAX_NT);                          // [16][MG_MAX_NT][4] root outputs
-    int *lds_m = (int *)(lds_ro + MG_NCAND * MG_MAX_NT * 4);               // [MG_MAX_NT] first tap - imin
-    double *lds_root = (double *)(lds_m + MG_MAX_NT);                      // [16][max_wi*nroot+1]
     const int root_stride = a.max_wi * nroot + 1;
+    unsigned char *tb_base = smem + 2 * (size_t)buf_bytes;
+    unsigned char *rs_base = tb_base + 3 * MG_TB_BYTES;
+    const int rs_bytes = MG_NCAND * root_stride * 8;
 
-    if (tid < ck.nT) {
-        lds_w[tid] = w32[ck.t0 + tid];
-        lds_m[tid] = i0tab[ck.t0 + tid] - ck.imin;
-    }
-
-    // latent tile as MFMA B fragments: lane l supplies B[k = 4*kk + (l >> 4)][n = l & 15]
+    const int64_t U = (int64_t)a.n_tiles * a.n_chunks;
+    const int64_t u_begin = (int64_t)blockIdx.x * U / gridDim.x;
+    const int64_t u_end = ((int64_t)blockIdx.x + 1) * U / gridDim.x;
+    const int n_units = (int)(u_end - u_begin);
+    mg_cursor cur;
+    cur.tile = (int)(u_begin / a.n_chunks);
+    cur.chunk = (int)(u_begin - (int64_t)cur.tile * a.n_chunks);
     const int cl = lane & 15, g = lane >> 4;
-    float sfrag[KK];
-    double s64frag[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        const int k = 4 * kk + g;
-        const double v = (cl < ncand && k < L) ? mg_load_lat<LAT_F64>(lat, (b0 + cl) * a.ld + k) : 0.0;
-        s64frag[kk] = v;
-        sfrag[kk] = (float)v;
-    }
 
-    // ---- stage 1a: f32 MFMA over the window's 16-row tiles, two tiles in flight, next two prefetched
-    if (!(a.debug & 1)) {
-        constexpr int NW = MG_BLOCK / 64;
+    if (wave >= MG_WS_NPW) {
+        // ================= consumers =================
+        const int cj = wave - MG_WS_NPW;                  // candidates cj and cj + 8
+        const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
+        const int gl = nql + 1;                           // + the root lane
+        const int rpi = 64 / gl;                          // samples per wave instruction
+        const int fsub = lane / gl, ql = lane - fsub * gl;
+        const bool lane_on = lane < rpi * gl;
+        const bool root_lane = ql == nql;
+        const int d0 = root_lane ? 0 : nroot + 4 * ql;    // first channel of this lane
+        const int nst = root_lane ? nroot : (D - d0 < 4 ? D - d0 : 4);
+        const int64_t TD = (int64_t)a.T * D;
+        const int dp4 = Dp * 4;
+        const int lane_img = (d0 + a.cshift) * 4;         // byte offset of the lane's quad inside a basis row
+        const int lane_out = fsub * D + d0;               // float offset inside a row group
+        mg_unit un_prev;
+        MG_STAMP_DECL
+        mg_lds_barrier();   // prologue barrier (unit 0's tables and root rows)
+        for (int it = 0; it <= n_units; it++) {
+            MG_STAMP(0);
+            mg_unit un;
+            if (it < n_units) {
+                un = mg_unit_at(chunks, a, cur);
+                mg_cursor_next(cur, a.n_chunks);
+                if (!(a.debug & 1)) {
+                    // root taps of unit it: round r (64 items: sample fl = r, channel slot d of 4, candidate c)
+                    // belongs to consumer r % 8; two rounds in flight
+                    const mg_chunk &ck = un.ck;
+                    const float4 *tw = (const float4 *)(tb_base + (size_t)(it % 3) * MG_TB_BYTES);
+                    const int *tmr = (const int *)(tw + MG_MAX_NT) + MG_MAX_NT;
+                    const double *tw64 = (const double *)(tmr + MG_MAX_NT);
+                    const double *rs = (const double *)(rs_base + (size_t)(it & 1) * rs_bytes);
+                    float *ro = (float *)(smem + (size_t)(it & 1) * buf_bytes) + (size_t)MG_NCAND * stride;
+                    const int c = lane & 15, d = (lane >> 4) & 3;
+                    const bool dok = d < nroot;
+                    const int ds = dok ? d : 0;
+                    for (int r0 = cj; r0 < ck.nT; r0 += 2 * MG_WS_NCW) {
+                        const int r1 = r0 + MG_WS_NCW;
+                        const bool ok1 = r1 < ck.nT;
+                        const int f1 = ok1 ? r1 : r0;
+                        const double *wa = tw64 + 4 * r0, *wb = tw64 + 4 * f1;
+                        const double *qa = rs + c * root_stride + tmr[r0] + ds;
+                        const double *qb = rs + c * root_stride + tmr[f1] + ds;
+                        double va = wa[0] * qa[0], vb = wb[0] * qb[0];
+                        va = fma(wa[1], qa[nroot], va);         vb = fma(wb[1], qb[nroot], vb);
+                        va = fma(wa[2], qa[2 * nroot], va);     vb = fma(wb[2], qb[2 * nroot], vb);
+                        va = fma(wa[3], qa[3 * nroot], va);     vb = fma(wb[3], qb[3 * nroot], vb);
+                        if (dok) ro[(c * MG_MAX_NT + r0) * 4 + d] = (float)va;
+                        if (dok && ok1) ro[(c * MG_MAX_NT + r1) * 4 + d] = (float)vb;
+                    }
+                }
+            }
+            MG_STAMP(1);
+            if (it >= 1 && !(a.debug & 2) && cj < un_prev.ncand) {
+                const mg_chunk &ck = un_prev.ck;
+                const unsigned char *img = smem + (size_t)((it - 1) & 1) * buf_bytes;
+                const float *lds_ro = (const float *)img + (size_t)MG_NCAND * stride;
+                const float4 *lds_w = (const float4 *)(tb_base + (size_t)((it - 1) % 3) * MG_TB_BYTES);
+                const int *lds_mo = (const int *)(lds_w + MG_MAX_NT);
+                const int col0 = ck.imin * Dp - ck.rt0 * 16;
+                const bool has1 = cj + MG_WS_NCW < un_prev.ncand;
+                const int c1 = has1 ? cj + MG_WS_NCW : cj;
+                const unsigned char *img0 = img + (size_t)(cj * stride + col0) * 4 + lane_img;
+                const unsigned char *img1 = img + (size_t)(c1 * stride + col0) * 4 + lane_img;
+                const float *ro0 = lds_ro + cj * MG_MAX_NT * 4, *ro1 = lds_ro + c1 * MG_MAX_NT * 4;
+                float *or0 = out + (size_t)(un_prev.b0 + cj) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
+                float *or1 = out + (size_t)(un_prev.b0 + c1) * TD + (size_t)ck.t0 * D;
+                // two row groups x two candidates in flight per trip
+                for (int f0 = 0; f0 < ck.nT; f0 += 2 * rpi) {
+                    const int fla = f0 + fsub, flb = fla + rpi;
+                    const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
+                    const int fa_ = fla < ck.nT ? fla : ck.nT - 1, fb_ = flb < ck.nT ? flb : ck.nT - 1;
+                    f32x4 v0a, v0b, v1a, v1b;
+                    if (!root_lane) {
+                        const float4 wa = lds_w[fa_], wb = lds_w[fb_];
+                        const int moa = lds_mo[fa_], mob = lds_mo[fb_];
+                        v0a = mg_quad_taps(img0 + moa, wa, dp4);
+                        v0b = mg_quad_taps(img0 + mob, wb, dp4);
+                        v1a = mg_quad_taps(img1 + moa, wa, dp4);
+                        v1b = mg_quad_taps(img1 + mob, wb, dp4);
+                    } else {
+                        v0a = *(const f32x4 *)&ro0[fa_ * 4];
+                        v0b = *(const f32x4 *)&ro0[fb_ * 4];
+                        v1a = *(const f32x4 *)&ro1[fa_ * 4];
+                        v1b = *(const f32x4 *)&ro1[fb_ * 4];
+                    }
+                    float *pa0 = or0 + (size_t)f0 * D, *pa1 = or1 + (size_t)f0 * D;          // uniform
+                    float *pb0 = pa0 + (size_t)rpi * D, *pb1 = pa1 + (size_t)rpi * D;
+                    if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
+                    if (ob) mg_store_n(pb0 + lane_out, v0b, nst);
+                    if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                    if (ob && has1) mg_store_n(pb1 + lane_out, v1b, nst);
+                }
+            }
+            un_prev = un;
+            MG_STAMP(4);
+            mg_lds_barrier();
+            MG_STAMP(5);
+        }
+        MG_STAMP_DUMP;
+    } else if (wave != 0) {
+        // ================= f32 producers (waves 1..3): E' fragments -> MFMA -> LDS image =================
+        float sfrag[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) sfrag[kk] = 0.f;
+        int cur_tile = -1;
         const float2 *ep = (const float2 *)Epack;
-        float2 a0[KK / 2], a1[KK / 2], n0[KK / 2], n1[KK / 2];
-        f32x4 m0, m1, mn0, mn1;
-        auto load_tile = [&](int t, float2(&fr)[KK / 2], f32x4 &cin) {
-            const int tc = t < ck.ntiles ? t : ck.ntiles - 1;   // clamp: redundant but in-bounds
-            const float2 *p = ep + ((size_t)(ck.rt0 + tc) * (KK / 2)) * 64 + lane;
+        constexpr int NP = MG_WS_NPW - 1;
+        MG_STAMP_DECL
+        mg_lds_barrier();   // prologue barrier
+        for (int it = 0; it <= n_units; it++) {
+            MG_STAMP(0);
+            if (it < n_units && !(a.debug & 1)) {
+                const mg_unit un = mg_unit_at(chunks, a, cur);
+                mg_cursor_next(cur, a.n_chunks);
+                const mg_chunk &ck = un.ck;
+                float *lds_c = (float *)(smem + (size_t)(it & 1) * buf_bytes);
+                if (un.tile != cur_tile) {
+                    cur_tile = un.tile;
 #pragma unroll
-            for (int q = 0; q < KK / 2; q++) fr[q] = p[q * 64];
-            cin = *(const f32x4 *)(mean32 + (size_t)(ck.rt0 + tc) * 16 + 4 * g);
+                    for (int kk = 0; kk < KK; kk++) {
+                        const int k = 4 * kk + g;
+                        sfrag[kk] = (cl < un.ncand && k < L) ? (float)mg_load_lat<LAT_F64>(lat, (un.b0 + cl) * a.ld + k) : 0.0f;
+                    }
+                }
+                // tile t belongs to wave 1 + t % 3; two tiles in flight, the next two prefetched
+                float2 fa[2][KK / 2], na[2][KK / 2];
+                f32x4 fm[2], nm[2];
+                auto load_tile = [&](int t, float2(&fr)[KK / 2], f32x4 &cin) {
+                    const int tc = t < ck.ntiles ? t : ck.ntiles - 1;   // clamp: redundant but in bounds
+                    const float2 *p = ep + ((size_t)(ck.rt0 + tc) * (KK / 2)) * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < KK / 2; q++) fr[q] = p[q * 64];
+                    cin = *(const f32x4 *)(mean32 + (size_t)(ck.rt0 + tc) * 16 + 4 * g);
+                };
+                int t = wave - 1;
+                load_tile(t, fa[0], fm[0]);
+                load_tile(t + NP, fa[1], fm[1]);
+                MG_STAMP(1);
+                while (t < ck.ntiles) {
+                    // unconditional (clamped) prefetch: the compiler can then count the younger loads and wait
+                    // with a counted vmcnt instead of draining the prefetch it has just issued
+                    const int tn = t + 2 * NP;
+                    load_tile(tn, na[0], nm[0]);
+                    load_tile(tn + NP, na[1], nm[1]);
+                    f32x4 acc0 = fm[0], acc1 = fm[1];
+#pragma unroll
+                    for (int q = 0; q < KK / 2; q++) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q].x, sfrag[2 * q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][q].x, sfrag[2 * q], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q].y, sfrag[2 * q + 1], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][q].y, sfrag[2 * q + 1], acc1, 0, 0, 0);
+                    }
+                    // D[row = 4g + reg][col = cl]: four consecutive padded rows of candidate cl
+                    *(f32x4 *)&lds_c[cl * stride + t * 16 + 4 * g] = acc0;
+                    if (t + NP < ck.ntiles) *(f32x4 *)&lds_c[cl * stride + (t + NP) * 16 + 4 * g] = acc1;
+#pragma unroll
+                    for (int q = 0; q < KK / 2; q++) { fa[0][q] = na[0][q]; fa[1][q] = na[1][q]; }
+                    fm[0] = nm[0]; fm[1] = nm[1];
+                    t = tn;
+                }
+                MG_STAMP(2);
+            }
+            MG_STAMP(4);
+            mg_lds_barrier();
+            MG_STAMP(5);
+        }
+        MG_STAMP_DUMP;
+    } else {
+        // ================= wave 0: tables and root rows (f64 MFMA), one unit ahead =================
+        auto root_stage = [&](const mg_unit &un, int it) {   // tables -> tb[it%3], root rows -> rs[it&1]
+            const mg_chunk &ck = un.ck;
+            float4 *tw = (float4 *)(tb_base + (size_t)(it % 3) * MG_TB_BYTES);
+            int *tmo = (int *)(tw + MG_MAX_NT);
+            int *tmr = tmo + MG_MAX_NT;
+            double *tw64 = (double *)(tmr + MG_MAX_NT);
+            double *rs = (double *)(rs_base + (size_t)(it & 1) * rs_bytes);
+            float4 r_w = {0.f, 0.f, 0.f, 0.f};
+            int r_i0 = 0;
+            double r_w64[2] = {0.0, 0.0};
+            if (lane < ck.nT) { r_w = w32[ck.t0 + lane]; r_i0 = i0tab[ck.t0 + lane]; }
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (lane + 64 * e < ck.nT * 4) r_w64[e] = w64[4 * (size_t)ck.t0 + lane + 64 * e];
+            double s64frag[KK];
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                const int k = 4 * kk + g;
+                s64frag[kk] = (cl < un.ncand && k < L) ? mg_load_lat<LAT_F64>(lat, (un.b0 + cl) * a.ld + k) : 0.0;
+            }
+            // up to 3 root tiles (8 basis functions x 3 channels = 24 rows, rr = i*nroot + d), chains
+            // interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
+            f64x4 racc[3];
+            const double *rpp[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int tc = t < ck.nrt ? t : ck.nrt - 1;
+                rpp[t] = Erpack + ((size_t)(ck.rrt0 + tc) * KK) * 64 + lane;
+                const int row0 = (ck.rrt0 + tc) * 16;
+                racc[t][0] = meanroot[row0 + g];
+                racc[t][1] = meanroot[row0 + g + 4];
+                racc[t][2] = meanroot[row0 + g + 8];
+                racc[t][3] = meanroot[row0 + g + 12];
+            }
+            // k-steps in two halves so the fragments of one half (3 tiles) fit the register budget
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                double rp[3][KK / 2];
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int q = 0; q < KK / 2; q++) rp[t][q] = rpp[t][(h * (KK / 2) + q) * 64];
+                if (h == 0) {
+                    if (lane < ck.nT) {
+                        tw[lane] = r_w;
+                        tmo[lane] = (r_i0 - ck.imin) * Dp * 4;   // byte offset of the first tap row in the f32 image
+                        tmr[lane] = (r_i0 - ck.imin) * nroot;    // element offset in the float64 root image
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; e++)
+                        if (lane + 64 * e < ck.nT * 4) tw64[lane + 64 * e] = r_w64[e];
+                }
+#pragma unroll
+                for (int q = 0; q < KK / 2; q++)
+#pragma unroll
+                    for (int t = 0; t < 3; t++)
+                        racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q], s64frag[h * (KK / 2) + q], racc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int lr0 = (ck.rrt0 + t) * 16 + g - ck.imin * nroot;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int lr = lr0 + 4 * r;
+                    if (t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) rs[cl * root_stride + lr] = racc[t][r];
+                }
+            }
         };
-        int t = wave;
-        if (t < ck.ntiles) { load_tile(t, a0, m0); load_tile(t + NW, a1, m1); }
-        while (t < ck.ntiles) {
-            const int tn = t + 2 * NW;
-            if (tn < ck.ntiles) { load_tile(tn, n0, mn0); load_tile(tn + NW, n1, mn1); }
-            f32x4 acc0 = m0, acc1 = m1;
-#pragma unroll
-            for (int q = 0; q < KK / 2; q++) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].x, sfrag[2 * q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].x, sfrag[2 * q], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].y, sfrag[2 * q + 1], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].y, sfrag[2 * q + 1], acc1, 0, 0, 0);
+        MG_STAMP_DECL
+        mg_unit un = mg_unit_at(chunks, a, cur);   // unit 0
+        if (!(a.debug & 1)) root_stage(un, 0);
+        mg_lds_barrier();   // prologue barrier
+        for (int it = 0; it <= n_units; it++) {
+            MG_STAMP(0);
+            if (it + 1 < n_units) {
+                mg_cursor_next(cur, a.n_chunks);
+                un = mg_unit_at(chunks, a, cur);
+                if (!(a.debug & 1)) root_stage(un, it + 1);
             }
-            // D[row = 4g + reg][col = cl]: four consecutive padded rows of candidate cl
-            *(f32x4 *)&lds_c[cl * stride + t * 16 + 4 * g] = acc0;
-            if (t + NW < ck.ntiles) *(f32x4 *)&lds_c[cl * stride + (t + NW) * 16 + 4 * g] = acc1;
-#pragma unroll
-            for (int q = 0; q < KK / 2; q++) { a0[q] = n0[q]; a1[q] = n1[q]; }
-            m0 = mn0; m1 = mn1;
-            t = tn;
+            MG_STAMP(3);
+            MG_STAMP(4);
+            mg_lds_barrier();
+            MG_STAMP(5);
         }
-    }
-    // ---- stage 1b: root-translation rows in float64 (rows rr = i*nroot + d) ---------------
-    for (int t = wave; t < ck.nrt && !(a.debug & 1); t += MG_BLOCK / 64) {
-        const double *p = Erpack + ((size_t)(ck.rrt0 + t) * KK) * 64 + lane;
-        const int row0 = (ck.rrt0 + t) * 16;
-        // v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
-        f64x4 acc;
-        acc[0] = meanroot[row0 + g];
-        acc[1] = meanroot[row0 + g + 4];
-        acc[2] = meanroot[row0 + g + 8];
-        acc[3] = meanroot[row0 + g + 12];
-#pragma unroll
-        for (int kk = 0; kk < KK; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(p[kk * 64], s64frag[kk], acc, 0, 0, 0);
-        const int lr0 = row0 + g - ck.imin * nroot;   // local root row of reg 0
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int lr = lr0 + 4 * r;
-            if (lr >= 0 && lr < ck.wi * nroot) lds_root[cl * root_stride + lr] = acc[r];
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1c: root channels' spline taps in float64 -> float32 outputs in LDS -------------
-    {
-        const int n_items = ck.nT * MG_NCAND * nroot;
-        for (int it = tid; it < n_items; it += MG_BLOCK) {
-            const int c = it & 15;
-            const int rest = it >> 4;
-            const int fl = rest / nroot, d = rest - fl * nroot;
-            const double *wq = w64 + 4 * (size_t)(ck.t0 + fl);
-            const double *q = lds_root + c * root_stride + lds_m[fl] * nroot + d;
-            double v = wq[0] * q[0];
-            v = fma(wq[1], q[nroot], v);
-            v = fma(wq[2], q[2 * nroot], v);
-            v = fma(wq[3], q[3 * nroot], v);
-            lds_ro[(c * MG_MAX_NT + fl) * 4 + d] = (float)v;
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 2: quad-row sweep ----------------------------------------------------------------
-    if (a.debug & 2) return;
-    const int64_t TD = (int64_t)a.T * D;
-    const int nq = Dp >> 2;                       // quads per time sample
-    const int rpi = 64 / nq;                      // time samples per wave instruction
-    const int fsub = lane / nq, q4 = (lane - fsub * nq) * 4;
-    const bool lane_on = lane < rpi * nq;
-    const int col0 = ck.imin * Dp - ck.rt0 * 16;  // LDS column of (imin, d = 0)
-    const int nvalid = D - q4 < 4 ? D - q4 : 4;   // channels of this quad that exist (last quad of a row)
-    for (int c = wave; c < ncand; c += MG_BLOCK / 64) {
-        const float *cimg = lds_c + c * stride + col0 + q4;
-        float *orow = out + (size_t)(b0 + c) * TD + (size_t)ck.t0 * D + q4;
-        for (int f0 = 0; f0 < ck.nT; f0 += rpi) {
-            const int fl = f0 + fsub;
-            if (lane_on && fl < ck.nT) {
-                const float4 w = lds_w[fl];
-                const float *tp = cimg + lds_m[fl] * Dp;
-                const f32x4 t0 = *(const f32x4 *)tp;
-                const f32x4 t1 = *(const f32x4 *)(tp + Dp);
-                const f32x4 t2 = *(const f32x4 *)(tp + 2 * Dp);
-                const f32x4 t3 = *(const f32x4 *)(tp + 3 * Dp);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float x = w.x * t0[e];
-                    x = fmaf(w.y, t1[e], x);
-                    x = fmaf(w.z, t2[e], x);
-                    x = fmaf(w.w, t3[e], x);
-                    v[e] = x;
-                }
-                if (q4 == 0) {   // root channels come from the float64 path
-                    const f32x4 r = *(const f32x4 *)&lds_ro[(c * MG_MAX_NT + fl) * 4];
-#pragma unroll
-                    for (int e = 0; e < 3; e++)
-                        if (e < nroot) v[e] = r[e];
-                }
-                float *op = orow + (size_t)fl * D;
-                if (nvalid == 4) {
-                    *(f32x4u *)op = v;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 3; e++)
-                        if (e < nvalid) op[e] = v[e];
-                }
-            }
-        }
+        MG_STAMP_DUMP;
     }
 }
 
@@ -309,23 +531,23 @@ __global__ __launch_bounds__(256) void mg_spline_eval_kernel(const double *coeff
 // launchers
 // -----------------------------------------------------------------------------------------
 template <int KK>
-static int mg_launch_mfma_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, const mg_frames_args &a,
-                             bool lat_f64, int lds, int grid) {
+static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, const mg_frames_args &a,
+                           bool lat_f64, int buf_bytes, int lds, int grid) {
     hipStream_t st = p->ctx->stream;
     if (lat_f64)
-        hipLaunchKernelGGL((mg_frames_mfma_kernel<KK, true>), dim3(grid), dim3(MG_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_chunks, out, a);
+        hipLaunchKernelGGL((mg_frames_ws_kernel<KK, true>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_chunks, out, a, buf_bytes);
     else
-        hipLaunchKernelGGL((mg_frames_mfma_kernel<KK, false>), dim3(grid), dim3(MG_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_chunks, out, a);
+        hipLaunchKernelGGL((mg_frames_ws_kernel<KK, false>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_chunks, out, a, buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
 
 template <int KK>
 static int mg_set_attr_kk() {
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_mfma_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_mfma_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return MG_OK;
 }
 
@@ -344,31 +566,37 @@ int mg_setup_kernel_attributes(mg_context *) {
 
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out) {
     mg_frames_args a;
-    a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.L = p->L; a.nroot = p->nroot;
-    a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi;
+    a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
+    a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.pad = 0;
     {
         static const int dbg = getenv("MG_DEBUG_FLAGS") ? atoi(getenv("MG_DEBUG_FLAGS")) : 0;
         a.debug = dbg;
     }
-    if ((int64_t)g->T * p->D * MG_NCAND * 4 >= ((int64_t)1 << 31)) {
-        mg_set_error("mg_back_project_frames: n_times * n_dim too large for the MFMA path");
+    const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
+    const int64_t units = n_tiles * g->n_chunks;
+    if (n_tiles >= ((int64_t)1 << 27) || units >= ((int64_t)1 << 31)) {
+        mg_set_error("mg_back_project_frames: batch too large for one launch");
         return MG_ERR_UNSUPPORTED;
     }
-    int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
-    int64_t groups = (n_tiles + 7) / 8;
-    int64_t grid = groups * 8 * g->n_chunks;
-    if (grid > 0x7fffffff) { mg_set_error("mg_back_project_frames: batch too large for one launch"); return MG_ERR_UNSUPPORTED; }
     a.n_tiles = (int32_t)n_tiles;
     const bool lf = (ldt == MG_F64);
+    // two LDS buffers + three table sets + two float64 root images, one workgroup per CU
+    const int buf_bytes = (MG_NCAND * g->stride * 4 + MG_NCAND * MG_MAX_NT * 16 + 255) / 256 * 256;
+    const int lds = 2 * buf_bytes + 3 * MG_TB_BYTES + 2 * MG_NCAND * (g->max_wi * p->nroot + 1) * 8;
+    if (lds != g->lds_bytes || lds > 160 * 1024) {
+        mg_set_error("mg_back_project_frames: internal LDS sizing mismatch (%d vs %d)", lds, g->lds_bytes);
+        return MG_ERR_UNSUPPORTED;
+    }
+    const int grid = (int)std::min<int64_t>(units, p->ctx->n_cu);
     switch (p->KK) {
-        case 2: return mg_launch_mfma_kk<2>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
-        case 4: return mg_launch_mfma_kk<4>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
-        case 6: return mg_launch_mfma_kk<6>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
-        case 8: return mg_launch_mfma_kk<8>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
-        case 10: return mg_launch_mfma_kk<10>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
-        case 12: return mg_launch_mfma_kk<12>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
-        case 14: return mg_launch_mfma_kk<14>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
-        case 16: return mg_launch_mfma_kk<16>(p, g, lat, out, a, lf, g->lds_bytes, (int)grid);
+        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
         default: mg_set_error("mg_back_project_frames: MFMA path needs n_components <= 64"); return MG_ERR_UNSUPPORTED;
     }
 }

@@ -316,14 +316,13 @@ static int mg_round_stride(int nlocal) {
     return s;
 }
 
-// LDS of the MFMA kernel: coefficient image, float64 root image, float32 root outputs,
-// per-sample weight / first-tap tables.
+// LDS of the persistent kernel: two buffers (coefficient image + float32 root outputs),
+// three per-sample table sets, two float64 root images.
 static int mg_lds_bytes(const mg_primitive *p, int stride, int wi) {
-    int coef = MG_NCAND * stride * 4;
-    int root = MG_NCAND * (wi * p->nroot + 1) * 8;
-    int rout = MG_NCAND * MG_MAX_NT * 4 * 4;
-    int tabs = MG_MAX_NT * (16 + 4);
-    return coef + root + rout + tabs;
+    int buf = (MG_NCAND * stride * 4 + MG_NCAND * MG_MAX_NT * 16 + 255) / 256 * 256;
+    int tabs = 3 * (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32);
+    int root = 2 * MG_NCAND * (wi * p->nroot + 1) * 8;
+    return 2 * buf + tabs + root;
 }
 
 // Split the grid into chunks (runs of consecutive time samples) whose coefficient window
@@ -332,19 +331,16 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
     const int Dp = p->Dp;
     g->chunks.clear();
     g->mfma_ok = false;
-    if (p->KK == 0 || g->T == 0 || Dp > 256) return;
-    // window budget: three workgroups per CU (160 KiB LDS) when possible, else one
-    const int budget3 = 53 * 1024, budget1 = 156 * 1024;
+    if (p->KK == 0 || g->T == 0 || (p->D - p->nroot + 3) / 4 + 1 > 64) return;   // one row group must fit a wave
+    // widest window (<= 8 basis functions) whose double-buffered image fits one CU's 160 KiB of LDS
+    const int budget1 = 160 * 1024;
     auto fits = [&](int wi, int budget) {
         int nlocal = ((wi * Dp + 15) / 16 + 1) * 16;
         return mg_lds_bytes(p, mg_round_stride(nlocal), wi) <= budget;
     };
     int W = 0;
     for (int w = MG_MAX_WI; w >= 4; w--)
-        if (fits(w, budget3)) { W = w; break; }
-    if (W == 0)
-        for (int w = MG_MAX_WI; w >= 4; w--)
-            if (fits(w, budget1)) { W = w; break; }
+        if (fits(w, budget1)) { W = w; break; }
     if (W == 0) return;  // n_dim too large for the LDS-staged kernel
     int a = 0;
     int max_stride = 0, max_wi = 0;
@@ -475,7 +471,10 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
     p->NB = NB; p->D = D; p->L = L; p->F = d->n_canonical_frames; p->K = K; p->R = R;
     p->nroot = std::min(3, D);
     p->KK = (L <= 4 * MG_MAX_KK) ? (((L + 3) / 4 + 1) / 2) * 2 : 0;
-    p->Dp = (D + 3) & ~3;
+    // padded coefficient rows: column = d + cshift so that the first non-root channel sits on a
+    // 16-byte boundary (quads of channels start at d = nroot), pitch a multiple of 4
+    p->cshift = (4 - p->nroot) & 3;
+    p->Dp = (D + p->cshift + 3) & ~3;
     p->RT = (NB * p->Dp + 15) / 16;
     p->knots.assign(d->knots, d->knots + NB + 4);
     double tm[3] = {1.0, 1.0, 1.0};
@@ -511,7 +510,7 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
         {
             std::vector<float> m32((size_t)p->RT * 16, 0.0f);
             for (int i = 0; i < NB; i++)
-                for (int dd = 0; dd < D; dd++) m32[(size_t)i * p->Dp + dd] = (float)p->means_[(size_t)i * D + dd];
+                for (int dd = 0; dd < D; dd++) m32[(size_t)i * p->Dp + dd + p->cshift] = (float)p->means_[(size_t)i * D + dd];
             if (rc == MG_OK) rc = mg_upload(ctx, m32, &p->d_mean32);
         }
         if (rc == MG_OK && p->KK > 0) {
@@ -534,15 +533,15 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
         if (rc == MG_OK && p->KK > 0) {
             // MFMA A-operand fragments of v_mfma_f32_16x16x4_f32: lane l supplies
             // A[row = l & 15][k = 4*kk + (l >> 4)].  Rows are the padded coefficient rows
-            // r' = i*Dp + d (zero rows for d >= D).  Image [rt][kk/2][lane][2].
+            // r' = i*Dp + d + cshift (zero rows elsewhere).  Image [rt][kk/2][lane][2].
             const int KK = p->KK, Dp = p->Dp;
             std::vector<float> pack((size_t)p->RT * KK * 64, 0.0f);
             for (int rt = 0; rt < p->RT; rt++)
                 for (int kk = 0; kk < KK; kk++)
                     for (int lane = 0; lane < 64; lane++) {
                         int rp = rt * 16 + (lane & 15), k = 4 * kk + (lane >> 4);
-                        int i = rp / Dp, dd = rp - i * Dp;
-                        float v = (i < NB && dd < D && k < L) ? (float)p->Es[((size_t)i * D + dd) * L + k] : 0.0f;
+                        int i = rp / Dp, dd = rp - i * Dp - p->cshift;
+                        float v = (i < NB && dd >= 0 && dd < D && k < L) ? (float)p->Es[((size_t)i * D + dd) * L + k] : 0.0f;
                         pack[(((size_t)rt * (KK / 2) + kk / 2) * 64 + lane) * 2 + (kk & 1)] = v;
                     }
             rc = mg_upload(ctx, pack, &p->d_Epack);

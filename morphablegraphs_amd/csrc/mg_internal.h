@@ -99,7 +99,8 @@ struct mg_primitive {
     std::vector<double> knots;
     std::vector<double> gw, gm, gc, gp;  // weights (K), means (K,L), covars (K,L,L), prec chol (K,L,L)
     // device constants
-    int32_t Dp = 0;              // n_dim rounded up to a multiple of 4: row pitch of the padded coefficient rows
+    int32_t Dp = 0;              // row pitch of the padded coefficient rows (multiple of 4)
+    int32_t cshift = 0;          // column of channel d in a padded row is d + cshift
     float *d_Epack = nullptr;    // [RT][KK/2][64][2] MFMA A fragments, f32, padded rows r' = i*Dp + d
     float *d_Et32 = nullptr;     // [L][R] f32
     double *d_Et64 = nullptr;    // [L][R] f64
