@@ -296,6 +296,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         int cur_tile = -1;
         const float2 *ep = (const float2 *)Epack;
         constexpr int NP = MG_WS_NPW - 1;
+        if (a.debug & 256) __builtin_amdgcn_s_setprio(3);
         MG_STAMP_DECL
         mg_lds_barrier();   // prologue barrier
         for (int it = 0; it <= n_units; it++) {

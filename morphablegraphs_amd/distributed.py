@@ -1,0 +1,63 @@
+"""Candidate-batch sharding across the GPUs of one node.
+
+Candidates are independent units: rank r owns the contiguous block [r*B/N, (r+1)*B/N), the per-primitive
+constants are replicated, and the only exchange is one all-gather of the per-rank scores (RCCL over xGMI
+on GPUs, gloo in the CPU tests) followed by the reference's first-minimum argmin over the GLOBAL index order
+(reference motion_primitive_generator.py:251-257).  torch.distributed is plumbing; the scores come from the
+scorer callable (libmg_hip on a GPU box).
+"""
+import numpy as np
+
+
+def shard_range(n_total, rank, world_size):
+    """Contiguous block split; the first (n_total % world_size) ranks get one extra row."""
+    base, rem = divmod(int(n_total), int(world_size))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def first_min_argmin(values):
+    """First strict minimum; NaN never wins; (0, inf) when nothing wins."""
+    v = np.asarray(values, dtype=np.float64)
+    if v.size == 0:
+        return 0, float("inf")
+    w = np.where(np.isnan(v), np.inf, v)
+    i = int(np.argmin(w))          # np.argmin returns the first occurrence
+    if not np.isfinite(w[i]) and w[i] > 0:
+        return 0, float("inf")
+    return i, float(w[i])
+
+
+def all_gather_scores(local_scores, n_total, group=None):
+    """All-gather variable-length per-rank score blocks into the global (n_total,) order."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    t = local_scores if isinstance(local_scores, torch.Tensor) else torch.as_tensor(np.asarray(local_scores))
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    assert t.numel() == sizes[rank], "local block has %d scores, expected %d" % (t.numel(), sizes[rank])
+    m = max(sizes) if sizes else 0
+    padded = torch.full((m,), float("inf"), dtype=t.dtype, device=t.device)
+    padded[: t.numel()] = t
+    gathered = torch.empty((world * m,), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    parts = [gathered[r * m: r * m + sizes[r]] for r in range(world)]
+    return torch.cat(parts) if parts else gathered
+
+
+def sharded_best_candidate(samples, scorer, group=None):
+    """Every rank holds the same `samples` (n, L); each scores its block with `scorer(block) -> (len(block),)`,
+    the scores are all-gathered and every rank returns the same (best_index, min_error, all_scores)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = len(samples)
+    b, e = shard_range(n, rank, world)
+    local = scorer(samples[b:e])
+    if not isinstance(local, torch.Tensor):
+        local = torch.as_tensor(np.asarray(local, dtype=np.float64))
+    scores = all_gather_scores(local, n, group)
+    idx, val = first_min_argmin(scores.detach().cpu().numpy())
+    return idx, val, scores

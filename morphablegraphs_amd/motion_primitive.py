@@ -1,0 +1,184 @@
+"""MotionPrimitive duck type backed by libmg_hip.so.
+
+Mirror of reference morphablegraphs/motion_model/motion_primitive.py:41-380 for the
+``use_time_parameters=False`` path every scoring call site uses: same attribute names
+(``s_pca``, ``t_pca``, ``gaussian_mixture_model``, ``translation_maxima``,
+``n_canonical_frames`` ...), same methods and error behaviour, so
+``MotionPrimitiveModelWrapper.motion_primitive`` can be swapped without touching
+``motion_generator``.  Single-sample calls return float64 results from the float64 kernels;
+the ``*_batch`` methods are the hot path (float32 frames, MFMA kernel).
+"""
+import json
+
+import numpy as np
+
+from . import _capi
+from .gaussian_mixture import HipGaussianMixture
+from .motion_spline import HipMotionSpline
+
+_default_context = {}
+
+
+def get_context(device=0):
+    """One libmg_hip context per (process, device)."""
+    ctx = _default_context.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = _capi.Context(device)
+        _default_context[device] = ctx
+    return ctx
+
+
+class HipMotionPrimitive(object):
+    def __init__(self, filename=None, context=None, device=0):
+        self.filename = filename
+        self.name = ""
+        self.gaussian_mixture_model = None
+        self.s_pca = dict()
+        self.t_pca = dict()
+        self.n_canonical_frames = 0
+        self.translation_maxima = np.array([1.0, 1.0, 1.0])
+        self.smooth_time_parameters = False
+        self.has_time_parameters = True
+        self.has_semantic_parameters = False
+        self.animated_joints = []
+        self._ctx = context
+        self._device = device
+        self._prim = None
+        if self.filename is not None:
+            self._load(self.filename)
+
+    # ---- loading (reference motion_primitive.py:79-124) ------------------------------------
+    def _load(self, filename=None):
+        with open(filename, "r") as infile:
+            self._initialize_from_json(json.load(infile))
+
+    def _initialize_from_json(self, data):
+        if "name" in data:
+            self.name = data["name"]
+        if "semantic_label" in data:
+            self.has_semantic_parameters = True
+            self.semantic_labels = data["semantic_label"]
+        self.n_canonical_frames = data["n_canonical_frames"]
+        self.canonical_time_range = np.arange(0, self.n_canonical_frames)
+        if self._ctx is None:
+            self._ctx = get_context(self._device)
+        self._prim = _capi.Primitive(self._ctx, data)
+        self._init_gmm_from_json(data)
+        self._init_spatial_parameters_from_json(data)
+        if "eigen_vectors_time" in data:
+            self._init_time_parameters_from_json(data)
+            self.has_time_parameters = True
+        else:
+            self.has_time_parameters = False
+            self.t_pca = dict()
+            self.t_pca["n_components"] = 0
+        if "animated_joints" in data:
+            self.animated_joints = data["animated_joints"]
+
+    def _init_gmm_from_json(self, data):
+        self.gaussian_mixture_model = HipGaussianMixture(self._prim, data["gmm_weights"], data["gmm_means"],
+                                                         data["gmm_covars"])
+
+    def _init_spatial_parameters_from_json(self, data):
+        self.translation_maxima = np.array(data["translation_maxima"])
+        self.s_pca = dict()
+        self.s_pca["eigen_vectors"] = np.transpose(np.array(data["eigen_vectors_spatial"]))
+        self.s_pca["mean_vector"] = np.array(data["mean_spatial_vector"])
+        self.s_pca["n_basis"] = int(data["n_basis_spatial"])
+        self.s_pca["n_dim"] = int(data["n_dim_spatial"])
+        self.s_pca["n_components"] = len(self.s_pca["eigen_vectors"].T)
+        self.s_pca["knots"] = np.asarray(data["b_spline_knots_spatial"])
+
+    def _init_time_parameters_from_json(self, data):
+        # kept for attribute compatibility; the time-warp branch itself has no runnable oracle
+        # (the reference raises TypeError at motion_primitive.py:313-314 on numpy >= 1.18)
+        self.t_pca = dict()
+        self.t_pca["eigen_vectors"] = np.array(data["eigen_vectors_time"])
+        self.t_pca["mean_vector"] = np.array(data["mean_time_vector"])
+        self.t_pca["n_basis"] = int(data["n_basis_time"])
+        self.t_pca["n_dim"] = 1
+        self.t_pca["n_components"] = len(self.t_pca["eigen_vectors"].T)
+        self.t_pca["knots"] = np.asarray(data["b_spline_knots_time"])
+        self.t_pca["eigen_coefs"] = list(zip(*self.t_pca["eigen_vectors"]))
+
+    # ---- sampling (reference motion_primitive.py:182-204) -----------------------------------
+    def sample_low_dimensional_vector(self, n_samples=1):
+        assert self.gaussian_mixture_model is not None, "Motion primitive not initialized."
+        return self.gaussian_mixture_model.sample(n_samples)[0]
+
+    def sample(self, use_time_parameters=True):
+        return self.back_project(np.ravel(self.sample_low_dimensional_vector()), use_time_parameters)
+
+    # ---- back projection (reference motion_primitive.py:206-256) ---------------------------
+    def _strip_semantic_label(self, s):
+        semantic_annotation = None
+        if self.has_semantic_parameters:
+            semantic_label = s[-1]
+            for key, value in self.semantic_labels.items():
+                if int(np.round(semantic_label)) == value:
+                    semantic_annotation = key
+            if semantic_annotation is None:
+                raise ValueError('Unknown semantic label!')
+            s = np.delete(s, -1)
+        return s, semantic_annotation
+
+    def back_project(self, s, use_time_parameters=True, speed=1.0):
+        s = np.asarray(s, dtype=np.float64)
+        s, semantic_annotation = self._strip_semantic_label(s)
+        spatial_coeffs = self.back_project_spatial_coeffs(s[:self.s_pca["n_components"]])
+        if self.has_time_parameters and use_time_parameters:
+            raise NotImplementedError("time-warp back projection is outside the accelerated path: every scoring call "
+                                      "site passes use_time_parameters=False (SURVEY.md section 8c)")
+        time_function = np.linspace(0, self.n_canonical_frames, int(self.n_canonical_frames * (1.0 / speed)))
+        return HipMotionSpline(spatial_coeffs, time_function, self.s_pca["knots"], semantic_annotation,
+                               low_dimensional_parameters=s, primitive=self._prim)
+
+    def back_project_spatial_coeffs(self, alpha):
+        alpha = np.asarray(alpha, dtype=np.float64).reshape(1, -1)
+        return self._prim.back_project_coeffs(alpha, dtype=np.float64)[0]
+
+    def back_project_time_function(self, gamma, speed=1.0):
+        raise NotImplementedError("time-warp back projection is outside the accelerated path")
+
+    # ---- batched hot path ------------------------------------------------------------------------
+    def back_project_frames_batch(self, samples, times=None):
+        """(B, L) latents -> (B, F, D) float32 frames: back_project(s, False).get_motion_vector() for every row
+        in one launch (or .evaluate(times) when times is given)."""
+        S = np.asarray(samples)
+        S = S[:, :self.s_pca["n_components"] + (0 if not self.has_semantic_parameters else 0)]
+        if times is None:
+            return self._prim.back_project_frames(S)
+        g = self._prim.time_grid(times)
+        try:
+            return self._prim.back_project_frames(S, g)
+        finally:
+            g.close()
+
+    def back_project_spatial_coeffs_batch(self, samples, dtype=np.float64):
+        return self._prim.back_project_coeffs(np.asarray(samples)[:, :self.s_pca["n_components"]], dtype=dtype)
+
+    def score_samples_batch(self, samples, dtype=np.float64):
+        """log p(x) of every row under the primitive's mixture."""
+        return self._prim.gmm_log_prob(np.asarray(samples), dtype=dtype)
+
+    # ---- getters (reference motion_primitive.py:333-380) ---------------------------------------
+    def get_n_canonical_frames(self):
+        return self.n_canonical_frames
+
+    def get_n_spatial_components(self):
+        return self.s_pca["n_components"]
+
+    def get_n_time_components(self):
+        if "n_components" in self.t_pca.keys():
+            return self.t_pca["n_components"]
+        return 0
+
+    def get_spatial_jacobian(self):
+        return self.s_pca["eigen_vectors"].T
+
+    def get_animated_joints(self):
+        return self.animated_joints
+
+    def path_following_obj(self, target, alpha):
+        coeffs = self.back_project_spatial_coeffs(alpha)
+        return np.linalg.norm(target - coeffs[-1, :3])

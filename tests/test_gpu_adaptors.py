@@ -1,0 +1,171 @@
+"""GPU tests of the reference-shaped Python surface (HipMotionPrimitive / HipMotionSpline /
+HipGaussianMixture / wrapper / batched candidate scoring) against the golden vectors made by the
+reference's own code and against the oracle.  The call scripts read like the reference's callers."""
+import numpy as np
+import pytest
+
+from morphablegraphs_amd import (HipMotionPrimitive, HipMotionPrimitiveModelWrapper, _capi, synthetic)
+from morphablegraphs_amd.candidate_scoring import HipSampleFilter, evaluate_samples_using_constraints
+from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def pose_tol(ref):
+    return 1e-5 + 2.0 ** -24 * np.abs(ref)
+
+
+def _primitive(data):
+    p = HipMotionPrimitive(None)
+    p._initialize_from_json(data)
+    return p
+
+
+def test_reference_call_script_on_golden(golden_case):
+    """examples/run_construction.py load_model shape: load JSON -> sample(False) -> get_motion_vector()."""
+    name, data, g = golden_case
+    mp = _primitive(data)
+    scale = max(1.0, np.abs(g["frames"]).max())
+    # sampling consumes numpy's global stream exactly like sklearn's GaussianMixture.sample
+    np.random.seed(int(g["seed"]))
+    S = mp.sample_low_dimensional_vector(g["S"].shape[0])
+    np.testing.assert_allclose(S, g["S"], rtol=1e-12, atol=1e-12)
+    for b in range(len(S)):
+        spline = mp.back_project(g["S"][b], use_time_parameters=False)
+        np.testing.assert_array_equal(spline.time_function, g["time_function"])
+        np.testing.assert_array_equal(np.asarray(spline.knots), g["knots"])
+        np.testing.assert_allclose(spline.coeffs, g["coeffs"][b], rtol=0, atol=4e-12 * scale)
+        frames = spline.get_motion_vector()
+        assert frames.shape == g["frames"][b].shape and frames.dtype == np.float64
+        np.testing.assert_allclose(frames, g["frames"][b], rtol=0, atol=4e-12 * scale)
+        np.testing.assert_allclose(spline.evaluate(g["eval_times"]), g["evals"][b], rtol=0, atol=4e-12 * scale)
+    sp0 = mp.back_project(g["S"][0], False)
+    for i, t in enumerate(g["eval_times"]):
+        e = sp0.evaluate(float(t))
+        assert e.shape == (mp.s_pca["n_dim"],)
+        np.testing.assert_allclose(e, g["evals_scalar"][i], rtol=0, atol=4e-12 * scale)
+    assert mp.get_n_canonical_frames() == int(g["n_canonical_frames"])
+    assert mp.get_n_spatial_components() == int(g["n_spatial_components"])
+    assert mp.get_n_time_components() == 0 and not mp.has_time_parameters
+    # batched hot path against the same golden frames
+    fb = mp.back_project_frames_batch(g["S"])
+    assert fb.dtype == np.float32 and np.all(np.abs(fb - g["frames"]) <= pose_tol(g["frames"]))
+    np.testing.assert_allclose(mp.score_samples_batch(g["X"]), g["logp"], rtol=1e-9, atol=1e-7)
+
+
+def test_spline_coeffs_are_mutable_like_the_reference(golden_case):
+    """Callers overwrite spline.coeffs with aligned coefficients (motion_primitive_constraints.py:113);
+    evaluation must follow the current array."""
+    name, data, g = golden_case
+    mp = _primitive(data)
+    sp = mp.back_project(g["S"][0], False)
+    sp.coeffs = np.array(g["coeffs"][1])
+    scale = max(1.0, np.abs(g["frames"]).max())
+    np.testing.assert_allclose(sp.get_motion_vector(), g["frames"][1], rtol=0, atol=4e-12 * scale)
+    buffered = sp.get_buffered_motion_vector()
+    assert sp.get_buffered_motion_vector() is buffered
+    assert sp.get_domain() == (g["knots"][0], g["knots"][-1])
+    assert sp.n_pose_parameters == g["coeffs"].shape[2]
+
+
+def test_gaussian_mixture_surface(golden_case):
+    name, data, g = golden_case
+    gmm = _primitive(data).gaussian_mixture_model
+    np.testing.assert_allclose(gmm.score_samples(g["X"]), g["logp"], rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(gmm.score(g["X"]), float(g["score_mean"]), rtol=1e-9, atol=1e-7)
+    pc = g["precisions_cholesky"]
+    np.testing.assert_allclose(gmm.precisions_cholesky_, pc, rtol=1e-9, atol=1e-9 * np.abs(pc).max())
+    assert gmm.n_dims == g["X"].shape[1] and gmm.weights_.shape == (pc.shape[0],)
+    with pytest.raises(ValueError):
+        gmm.score(g["X"][0])              # 1-D input: sklearn raises ValueError too
+    X, y = gmm.sample(500, device=True, seed=3)
+    assert X.shape == (500, gmm.n_dims) and np.all(np.diff(y) >= 0)
+
+
+def test_wrapper_format_dispatch_and_getters():
+    data = synthetic.make_tiny_primitive(seed=1)                # translation_maxima [1,1,1]
+    w_legacy, w_v3 = HipMotionPrimitiveModelWrapper(), HipMotionPrimitiveModelWrapper()
+    w_legacy._initialize_from_json(None, data)
+    w_v3._initialize_from_json(None, synthetic.to_mgrd_v3_json(data))
+    assert not w_legacy.mgrd and not w_v3.mgrd
+    s = np.array([0.3, -0.2, 0.9])
+    fa = w_legacy.back_project(s, use_time_parameters=False).get_motion_vector()
+    fb = w_v3.back_project(s, use_time_parameters=False).get_motion_vector()
+    np.testing.assert_array_equal(fa, fb)
+    assert w_v3.get_n_canonical_frames() == 12 and w_v3.get_n_spatial_components() == 3
+    assert w_v3.get_n_time_components() == 0
+    assert w_v3.get_spatial_eigen_vectors().shape == (3, 7 * 7)
+    assert w_v3.sample_low_dimensional_vectors(5).shape == (5, 3)
+    assert w_v3.sample_low_dimensional_vector().shape == (1, 3)
+    assert w_v3.sample(False).get_motion_vector().shape == (12, 7)
+    assert w_v3.back_project_time_function(s) == list(range(12))
+    assert len(w_v3.get_animated_joints()) == 1
+    assert w_v3.get_gaussian_mixture_model().score_samples(s.reshape(1, -1)).shape == (1,)
+    static = HipMotionPrimitiveModelWrapper()
+    static._initialize_from_json(None, {"name": "idle", "spatial_coeffs": np.zeros((4, 7)).tolist(),
+                                        "knots": [0, 0, 0, 0, 3, 3, 3, 3], "n_canonical_frames": 4})
+    assert static.get_n_spatial_components() == 1 and static.sample_low_dimensional_vector() == [0]
+
+
+def test_semantic_label_and_time_parameter_errors():
+    data = synthetic.make_tiny_primitive()
+    data["semantic_label"] = {"left": 0, "right": 1}
+    mp = _primitive(data)
+    sp = mp.back_project(np.array([0.1, 0.2, 0.3, 1.0]), False)
+    assert sp.semantic_annotation == "right" and len(sp.low_dimensional_parameters) == 3
+    with pytest.raises(ValueError, match="Unknown semantic label"):
+        mp.back_project(np.array([0.1, 0.2, 0.3, 7.0]), False)
+    fresh = HipMotionPrimitive(None)
+    with pytest.raises(AssertionError):
+        fresh.sample_low_dimensional_vector()
+
+
+def test_batched_candidate_scoring_matches_the_reference_loop():
+    """evaluate_samples_using_constraints: per-sample loop of the reference vs one fused launch."""
+    data = synthetic.make_walk_primitive(seed=0)
+    mp = _primitive(data)
+    cp = c_oracle.COraclePrimitive(data)
+    np.random.seed(5)
+    samples = mp.sample_low_dimensional_vector(300)             # n_random_samples = 300 preset
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+            {"type": "direction", "t": 155.0, "weight": 1.0, "target": [0.5, 1.0]}]
+    nan = np.nan
+    cons_c = np.array([[0, 155.0, 1.0, 40.0, nan, -30.0, 0, 0], [1, 155.0, 1.0, 0.5, 1.0, 0.0, 0.0, 1.0]])
+    ref = cp.keyframe_errors_f64(samples, cons_c)
+    np.testing.assert_allclose(HipSampleFilter.score_samples(mp, samples, cons), ref, rtol=1e-10, atol=1e-9)
+
+    class Constraints(object):
+        constraints, min_error, evaluations = cons, None, 0
+
+    cobj = Constraints()
+    best, err = evaluate_samples_using_constraints(samples, mp, cobj, None)
+    best_idx, min_error = 0, np.inf
+    for i, e in enumerate(ref):                                   # motion_primitive_generator.py:251-257
+        if min_error > e:
+            min_error, best_idx = e, i
+    np.testing.assert_array_equal(best, samples[best_idx])
+    assert abs(err - min_error) <= 1e-9 and cobj.evaluations == 300 and cobj.min_error == err
+    # scoring through full frames agrees with the fused scorer (root position at the last canonical frame)
+    frames = mp.back_project_frames_batch(samples, times=[155.0])
+    d = np.sqrt((frames[:, 0, 0] - 40.0) ** 2 + (frames[:, 0, 2] + 30.0) ** 2)
+    pos_only = HipSampleFilter.score_samples(mp, samples, cons[:1])
+    np.testing.assert_allclose(d, pos_only, rtol=0, atol=2e-4)
+
+
+def test_graph_of_primitives_option_evaluation():
+    prims = synthetic.make_graph_primitives(4)
+    pset = HipPrimitiveSet(prims)
+    names = [p["name"] for p in prims]
+    cons = {n: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]}]
+            for n, p in zip(names, prims)}
+    best, results = pset.evaluate_options(names, cons, n_samples=256, rng_seed=11)
+    assert best in names and set(results) == set(names)
+    for n, p in zip(names, prims):
+        cp = c_oracle.COraclePrimitive(p)
+        np.random.seed(11)
+        S = pset.nodes[n].sample_low_dimensional_vector(256)
+        ref = cp.keyframe_errors_f64(S, np.array([[0, float(p["n_canonical_frames"] - 1), 1.0, 10.0, np.nan, 5.0, 0, 0]]))
+        assert abs(results[n][1] - ref.min()) <= 1e-9
+        np.testing.assert_array_equal(results[n][0], S[int(np.argmin(ref))])
+    assert best == names[int(np.argmin([results[n][1] for n in names]))]

@@ -1,0 +1,140 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol the header
+declares, sharding / argmin helpers, the sklearn-compatible sampler, format readers."""
+import io
+import json
+import os
+import re
+import zipfile
+
+import numpy as np
+import pytest
+
+from morphablegraphs_amd import _capi, distributed, model_io, synthetic
+from morphablegraphs_amd.candidate_scoring import constraints_to_device_form
+from morphablegraphs_amd.gaussian_mixture import sample_like_sklearn
+from morphablegraphs_amd.motion_primitive_wrapper import mgrd_json_to_legacy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mg_hip.h")).read()
+    declared = set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mg_primitive_desc", "mg_keyframe_constraint"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_capi.EXPORTED_SYMBOLS), declared ^ set(_capi.EXPORTED_SYMBOLS)
+    lib = _capi.load_library()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.mg_version().startswith(b"mg_hip")
+    assert lib.mg_status_string(-5) == b"covariance not positive definite"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_capi.MGError) as ei:
+        _capi.Context(0)
+    assert ei.value.status == -2
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "morphablegraphs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "libmg_oracle" not in src, f
+
+
+def test_shard_range_covers_everything_once():
+    for n in (0, 1, 7, 8, 4096, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            blocks = [distributed.shard_range(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            sizes = [e - b for b, e in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_first_min_argmin_matches_reference_rule():
+    f = distributed.first_min_argmin
+    assert f([3.0, 1.0, 1.0, 2.0]) == (1, 1.0)
+    assert f([np.nan, 2.0, np.nan, 2.0]) == (1, 2.0)
+    assert f([]) == (0, float("inf"))
+    assert f([np.inf, np.inf]) == (0, float("inf"))
+    assert f([np.nan]) == (0, float("inf"))
+    assert f([-np.inf, 0.0]) == (0, float("-inf"))
+
+
+def test_sample_like_sklearn_is_bit_compatible():
+    from sklearn.mixture import GaussianMixture
+    from sklearn.mixture._gaussian_mixture import _compute_precision_cholesky
+    data = synthetic.make_primitive(seed=3, n_components=6, n_frames=30, n_dim=11, n_gmm=3, dirichlet_weights=True)
+    w, m, c = np.array(data["gmm_weights"]), np.array(data["gmm_means"]), np.array(data["gmm_covars"])
+    gmm = GaussianMixture(n_components=3, covariance_type="full")
+    gmm.weights_, gmm.means_, gmm.covariances_ = w, m, c
+    gmm.precisions_cholesky_ = _compute_precision_cholesky(c, "full")
+    np.random.seed(123)
+    X_ref, y_ref = gmm.sample(50)
+    np.random.seed(123)
+    X, y = sample_like_sklearn(50, w, m, c)
+    np.testing.assert_array_equal(X, X_ref)
+    np.testing.assert_array_equal(y, y_ref)
+    with pytest.raises(ValueError):
+        sample_like_sklearn(0, w, m, c)
+
+
+def test_v3_json_maps_to_legacy_like_the_reference_wrapper():
+    data = synthetic.make_tiny_primitive()
+    v3 = synthetic.to_mgrd_v3_json(data)
+    legacy = mgrd_json_to_legacy(v3)
+    assert legacy["n_canonical_frames"] == data["n_canonical_frames"]
+    np.testing.assert_array_equal(legacy["translation_maxima"], [1, 1, 1])
+    assert legacy["eigen_vectors_spatial"] == data["eigen_vectors_spatial"]
+    assert "eigen_vectors_time" not in legacy
+
+
+def test_graph_zip_reader(tmp_path):
+    prims = synthetic.make_graph_primitives(3)
+    path = tmp_path / "graph.zip"
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("graph_definition.json", json.dumps({"nodes": {}}))
+        for i, p in enumerate(prims):
+            body = synthetic.to_mgrd_v3_json(p) if i % 2 else p
+            z.writestr("elementary_action_models/walk/%s_quaternion_mm.json" % p["name"], json.dumps(body))
+        z.writestr("elementary_action_models/walk/idle_quaternion_mm.json",
+                   json.dumps({"name": "idle", "spatial_coeffs": [[0.0]], "knots": [0, 0, 0, 0, 1, 1, 1, 1], "n_canonical_frames": 2}))
+    out = model_io.load_graph_zip(str(path))
+    assert sorted(k[1] for k in out) == sorted(p["name"] for p in prims)
+    assert all(k[0] == "walk" for k in out)
+    for p in prims:
+        assert out[("walk", p["name"])]["n_basis_spatial"] == p["n_basis_spatial"]
+
+
+def test_constraint_conversion_accepts_reference_shaped_objects():
+    class Pos(object):
+        canonical_keyframe, weight_factor, position, orientation, joint_name = 155, 2.0, [1.0, None, 3.0], None, "Hips"
+
+    class Dir(object):
+        canonical_keyframe, weight_factor = 77.5, 1.0
+        target_dir = np.array([0.0, 1.0])
+
+    class Pose(object):
+        canonical_keyframe, weight_factor = 1, 1.0
+
+    out = constraints_to_device_form([Pos(), Dir(), {"type": "position", "t": 0.0, "weight": 1.0, "target": [0, 0, 0]}], "Hips")
+    assert out[0] == {"type": "position", "t": 155.0, "weight": 2.0, "target": [1.0, None, 3.0]}
+    assert out[1]["type"] == "direction" and out[1]["ref_dir"] == (0.0, 0.0, 1.0)
+    with pytest.raises(NotImplementedError):
+        constraints_to_device_form([Pose()])
+
+
+def test_synthetic_models_follow_the_reference_layout():
+    d = synthetic.make_walk_primitive(seed=0)
+    assert (len(d["eigen_vectors_spatial"]), len(d["eigen_vectors_spatial"][0])) == (40, 31 * 79)
+    k = np.array(d["b_spline_knots_spatial"])
+    assert len(k) == 35 and np.all(k[:4] == 0) and np.all(k[-4:] == 155)
+    assert len(synthetic.make_graph_primitives(16)) == 16
