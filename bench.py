@@ -26,6 +26,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_summary.json")   # tools/prof_bench.sh + tools/summarize_prof.py
+
+
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units; FETCH_SIZE doubled as the
+    gfx950 correction for wide coalesced reads prescribes).  None when no summary is present."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            summ = json.load(f)
+        for name, c in summ.get("pmc", {}).items():
+            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def algorithmic_bytes(prim_shape, B):
@@ -149,8 +165,9 @@ def main():
             k_bytes = B * (4 * L + 4 * F * D) + 4 * (NB * D * L + NB * D + 4 * F)
             achieved = k_bytes / (avg_ms * 1e-3) / 1e9
             result["roofline"] = {
-                "bound": "hbm", "kernel": "mg_frames_mfma_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "bound": "hbm", "kernel": "mg_frames_ws_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": pmc_traffic_bytes("mg_frames_ws_kernel") if B == 8192 else None,
                 "avg_kernel_ms": avg_ms, "launches": frames_n, "algorithmic_bytes_per_launch": k_bytes,
                 "gmm_kernel_avg_ms": (gmm_ms / gmm_n) if gmm_n else None,
                 "step_algorithmic_bytes": bytes_launch,
@@ -158,14 +175,14 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_baseline
-            ref = cpu_baseline.reference_shaped_rate(data, S_host, budget_s=12.0)
+            ref = cpu_baseline.reference_shaped_rate(data, S_host, budget_s=12.0, max_candidates=1 << 30)
             cport = cpu_baseline.c_port_rate(data, S_host, budget_s=5.0)
             result["cpu_baseline"] = {
                 "value": ref["rate"], "unit": "samples/s", "cores": 1, "kind": "port",
-                "sample": "%d candidates of the same batch, reference-shaped per-candidate loop "
+                "sample": "%d candidates drawn cyclically from the same batch, reference-shaped per-candidate loop "
                           "(numpy dot + 79x scipy splev + sklearn score_samples), %.1f s" % (ref["n"], ref["seconds"]),
                 "c_port_value": cport["rate"],
-                "c_port_sample": "%d candidates, plain-C float64 oracle, 1 core, %.1f s" % (cport["n"], cport["seconds"]),
+                "c_port_sample": "%d candidates, plain-C float64 oracle (oracle/mg_oracle.c), 1 core, %.1f s" % (cport["n"], cport["seconds"]),
                 "host_cores_available": os.cpu_count(),
             }
         print(json.dumps(result))

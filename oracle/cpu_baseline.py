@@ -32,8 +32,8 @@ def reference_shaped_rate(data, S, budget_s=12.0, max_candidates=8192):
     n = 0
     t0 = time.perf_counter()
     checksum = 0.0
-    while n < min(len(S), max_candidates):
-        s = np.asarray(S[n], dtype=np.float64)
+    while n < max_candidates:
+        s = np.asarray(S[n % len(S)], dtype=np.float64)
         coefs = np.dot(E, s)
         coefs += mean
         coefs = coefs.reshape((nb, nd))
@@ -56,8 +56,8 @@ def c_port_rate(data, S, budget_s=6.0):
     S = np.ascontiguousarray(S, dtype=np.float64)
     n, chunk = 0, 64
     t0 = time.perf_counter()
-    while n < len(S):
-        part = S[n:n + chunk]
+    while True:
+        part = S[(n % len(S)):(n % len(S)) + chunk]
         cp.frames_f64(part)
         cp.log_prob_f64(part)
         n += len(part)
