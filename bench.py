@@ -76,17 +76,24 @@ def main():
         raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # == local_rank on an N-GPU node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N > 1 on a one-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = int(args.batch)
     data = synthetic.make_walk_primitive(seed=0)
     L, F, D, NB, K = 40, 156, 79, 31, 8
-    stream = torch.cuda.current_stream(dev)
-    ctx = _capi.Context(local_rank, stream=stream.cuda_stream)
+    # one explicit torch stream carries the HIP kernels (through the C-ABI context) and the RCCL all-gather
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = _capi.Context(dev_index, stream=stream.cuda_stream)
     prim = _capi.Primitive(ctx, data)
 
     # synthetic latents: sklearn-style GMM draw on the host (np.random.seed(rank)), cast to f32
@@ -97,13 +104,14 @@ def main():
     S = torch.from_numpy(S_host).to(dev)
     frames = torch.empty((B, F, D), dtype=torch.float32, device=dev)
     logp = torch.empty((B,), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * B,), dtype=torch.float32, device=dev) if world > 1 else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = torch.empty((world * B,), dtype=torch.float32, device=gdev) if world > 1 else None
 
     def step():
         prim.back_project_frames_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), path=_capi.MG_PATH_MFMA)
         prim.gmm_log_prob_dev(S.data_ptr(), np.float32, B, L, logp.data_ptr(), np.float32)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, logp)
+            dist.all_gather_into_tensor(gathered, logp if backend == "nccl" else logp.cpu())
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -125,9 +133,12 @@ def main():
     if not args.no_profile_events:
         ctx.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank holds the same global score vector: the graph-walk argmin needs no further exchange
+        from morphablegraphs_amd.distributed import first_min_argmin
+        best_idx, best_val = first_min_argmin((-gathered).float().cpu().numpy())   # most likely candidate
 
     frames_ms, frames_n = ctx.profile_get("frames")
     gmm_ms, gmm_n = ctx.profile_get("gmm_log_prob")
@@ -156,7 +167,7 @@ def main():
             "config": {"workload": "walk primitive L=40 F=156 D=79 NB=31 GMM k=8, batch=%d candidates/GPU "
                                    "(BASELINE.json configs[%d])" % (B, 1 if world == 1 else 3),
                        "candidates_per_gpu": B, "global_candidates": world * B,
-                       "collective": "all_gather(logp) per step" if world > 1 else "none",
+                       "collective": ("all_gather(logp) per step, backend %s" % backend) if world > 1 else "none",
                        "sharding": "contiguous candidate blocks, constants replicated"},
         }
         if frames_n > 0:
