@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmg_hip.so")
+LIB_PATH = os.environ.get("MG_HIP_LIB") or os.path.join(HERE, "csrc", "libmg_hip.so")
 
 MG_OK = 0
 MG_F32, MG_F64 = 0, 1

@@ -78,19 +78,19 @@ extern "C" int mg_debug_dump_stamps(void) {
 // in one-shot workgroups they run in lockstep and add up instead of overlapping.
 //
 //   producer wave 0    : unit it+1's per-sample tables -> tb[(it+1)%3]; unit it+1's root-translation
-//                        rows by v_mfma_f64_16x16x4_f64 (C-in = mean') -> rs[(it+1)&1]
+//                        rows by v_mfma_f64_16x16x4_f64 (C-in = mean') -> rs[(it+1)&1]; their spline taps by
+//                        a second f64 MFMA (banded weight matrix) -> float32 root outputs ro[(it+1)%3]
 //   producer waves 1-3 : unit it's window of padded coefficient rows by v_mfma_f32_16x16x4_f32
 //                        (A = E' fragments from L2, two tiles in flight + two prefetched; B = the
 //                        latent tile in registers; C-in = mean') -> buf[it&1].img [cand][i*Dp + d + cshift]
-//   consumer waves 4-11: their share of unit it's root taps (float64) -> buf[it&1].ro, then the
-//                        "quad-row" sweep of unit it-1: a wave owns two candidates; a lane owns 4
+//   consumer waves 4-11: the "quad-row" sweep of unit it-1: a wave owns two candidates; a lane owns 4
 //                        consecutive channels of one sample (4 ds_read_b128 taps, 16 FMAs, one
 //                        dwordx4 store), the last lane of each row group owns the root channels;
 //                        64/20 samples per wave instruction, so one store instruction writes ~1 KB
 //                        of consecutive bytes and the next continues where it ended.
 //   one raw s_barrier per unit with lgkmcnt(0) only: the consumers' stores stay in flight across it.
 //
-// LDS: buf[2] = image [16][stride] f32 + root outputs [16][MG_MAX_NT][4] f32; tb[3] = w32 [MG_MAX_NT]
+// LDS: buf[2] = image [16][stride] f32; ro[3] = root outputs [16][MG_MAX_NT][4] f32; tb[3] = w32 [MG_MAX_NT]
 // float4, image tap byte offsets [MG_MAX_NT] int, root image tap offsets [MG_MAX_NT] int, w64 [MG_MAX_NT][4]
 // double; rs[2] = float64 root image.
 // -----------------------------------------------------------------------------------------
@@ -98,6 +98,7 @@ extern "C" int mg_debug_dump_stamps(void) {
 #define MG_WS_NCW 8      // consumer waves, two candidates each
 #define MG_WS_BLOCK (64 * (MG_WS_NPW + MG_WS_NCW))
 #define MG_TB_BYTES (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32)
+#define MG_RO_BYTES (MG_NCAND * MG_MAX_NT * 16)
 
 __device__ __forceinline__ void mg_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -108,6 +109,7 @@ struct mg_unit {
     int64_t b0;
     int ncand;
     int tile;
+    int chunk;
 };
 struct mg_cursor {   // (tile, chunk) cursor over a workgroup's run of units: no division inside the unit loop
     int tile, chunk;
@@ -115,6 +117,7 @@ struct mg_cursor {   // (tile, chunk) cursor over a workgroup's run of units: no
 __device__ __forceinline__ mg_unit mg_unit_at(const mg_chunk *__restrict__ chunks, const mg_frames_args &a, const mg_cursor &c) {
     mg_unit r;
     r.tile = c.tile;
+    r.chunk = c.chunk;
     r.ck = chunks[c.chunk];
     r.b0 = (int64_t)c.tile * MG_NCAND;
     r.ncand = (int)((a.B - r.b0) < MG_NCAND ? (a.B - r.b0) : MG_NCAND);
@@ -166,16 +169,18 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const int32_t *__restrict__ i0tab,    // (T)
     const float4 *__restrict__ w32,       // (T)
     const double *__restrict__ w64,       // (T, 4)
+    const double *__restrict__ wtap,      // [n_chunks][2][2][64] banded tap weights as f64 MFMA A fragments
     const mg_chunk *__restrict__ chunks,
     float *__restrict__ out,              // (B,T,D)
-    const mg_frames_args a, const int buf_bytes) {
+    const mg_frames_args a, const int chunk_stride_unused, const int buf_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
     const int root_stride = a.max_wi * nroot + 1;
-    unsigned char *tb_base = smem + 2 * (size_t)buf_bytes;
+    unsigned char *ro_base = smem + 2 * (size_t)buf_bytes;            // root outputs, triple buffered
+    unsigned char *tb_base = ro_base + 3 * MG_RO_BYTES;
     unsigned char *rs_base = tb_base + 3 * MG_TB_BYTES;
     const int rs_bytes = MG_NCAND * root_stride * 8;
 
@@ -212,39 +217,12 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             if (it < n_units) {
                 un = mg_unit_at(chunks, a, cur);
                 mg_cursor_next(cur, a.n_chunks);
-                if (!(a.debug & 1)) {
-                    // root taps of unit it: round r (64 items: sample fl = r, channel slot d of 4, candidate c)
-                    // belongs to consumer r % 8; two rounds in flight
-                    const mg_chunk &ck = un.ck;
-                    const float4 *tw = (const float4 *)(tb_base + (size_t)(it % 3) * MG_TB_BYTES);
-                    const int *tmr = (const int *)(tw + MG_MAX_NT) + MG_MAX_NT;
-                    const double *tw64 = (const double *)(tmr + MG_MAX_NT);
-                    const double *rs = (const double *)(rs_base + (size_t)(it & 1) * rs_bytes);
-                    float *ro = (float *)(smem + (size_t)(it & 1) * buf_bytes) + (size_t)MG_NCAND * stride;
-                    const int c = lane & 15, d = (lane >> 4) & 3;
-                    const bool dok = d < nroot;
-                    const int ds = dok ? d : 0;
-                    for (int r0 = cj; r0 < ck.nT; r0 += 2 * MG_WS_NCW) {
-                        const int r1 = r0 + MG_WS_NCW;
-                        const bool ok1 = r1 < ck.nT;
-                        const int f1 = ok1 ? r1 : r0;
-                        const double *wa = tw64 + 4 * r0, *wb = tw64 + 4 * f1;
-                        const double *qa = rs + c * root_stride + tmr[r0] + ds;
-                        const double *qb = rs + c * root_stride + tmr[f1] + ds;
-                        double va = wa[0] * qa[0], vb = wb[0] * qb[0];
-                        va = fma(wa[1], qa[nroot], va);         vb = fma(wb[1], qb[nroot], vb);
-                        va = fma(wa[2], qa[2 * nroot], va);     vb = fma(wb[2], qb[2 * nroot], vb);
-                        va = fma(wa[3], qa[3 * nroot], va);     vb = fma(wb[3], qb[3 * nroot], vb);
-                        if (dok) ro[(c * MG_MAX_NT + r0) * 4 + d] = (float)va;
-                        if (dok && ok1) ro[(c * MG_MAX_NT + r1) * 4 + d] = (float)vb;
-                    }
-                }
             }
             MG_STAMP(1);
             if (it >= 1 && !(a.debug & 2) && cj < un_prev.ncand) {
                 const mg_chunk &ck = un_prev.ck;
                 const unsigned char *img = smem + (size_t)((it - 1) & 1) * buf_bytes;
-                const float *lds_ro = (const float *)img + (size_t)MG_NCAND * stride;
+                const float *lds_ro = (const float *)(ro_base + (size_t)((it - 1) % 3) * MG_RO_BYTES);
                 const float4 *lds_w = (const float4 *)(tb_base + (size_t)((it - 1) % 3) * MG_TB_BYTES);
                 const int *lds_mo = (const int *)(lds_w + MG_MAX_NT);
                 const int col0 = ck.imin * Dp - ck.rt0 * 16;
@@ -358,7 +336,24 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         }
         MG_STAMP_DUMP;
     } else {
-        // ================= wave 0: tables and root rows (f64 MFMA), one unit ahead =================
+        // ================= wave 0: tables, root rows and root taps (f64 MFMA), one unit ahead =================
+        // per-lane constants of the tap MFMA: B operand = rows[m = 4 ks + (l >> 4)][col = 16 ct + (l & 15)] with
+        // col = candidate * nroot + channel (48 columns = 3 tiles); D column = the same col
+        int tap_b_off[3][2], tap_o_off[3];
+        bool tap_b_ok[3][2];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+            const int col = ct * 16 + cl;
+            const bool colok = col < MG_NCAND * nroot;
+            const int cc = colok ? col / nroot : 0, cd = colok ? col - cc * nroot : 0;
+            tap_o_off[ct] = colok ? cc * MG_MAX_NT * 4 + cd : -1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int m = 4 * ks + g;
+                tap_b_ok[ct][ks] = colok && m < a.max_wi;
+                tap_b_off[ct][ks] = cc * root_stride + m * nroot + cd;
+            }
+        }
         auto root_stage = [&](const mg_unit &un, int it) {   // tables -> tb[it%3], root rows -> rs[it&1]
             const mg_chunk &ck = un.ck;
             float4 *tw = (float4 *)(tb_base + (size_t)(it % 3) * MG_TB_BYTES);
@@ -373,6 +368,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
 #pragma unroll
             for (int e = 0; e < 2; e++)
                 if (lane + 64 * e < ck.nT * 4) r_w64[e] = w64[4 * (size_t)ck.t0 + lane + 64 * e];
+            double r_wt[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) r_wt[e] = wtap[((size_t)un.chunk * 4 + e) * 64 + lane];
             double s64frag[KK];
 #pragma unroll
             for (int kk = 0; kk < KK; kk++) {
@@ -424,6 +422,37 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 for (int r = 0; r < 4; r++) {
                     const int lr = lr0 + 4 * r;
                     if (t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) rs[cl * root_stride + lr] = racc[t][r];
+                }
+            }
+            // root taps, again on the float64 matrix pipe: out[f][(c,d)] = sum_m W[f][m] * rows[m][(c,d)] with the
+            // banded W[f][m] = w[f][m - m0(f)] (0 outside the 4 taps) pre-packed per chunk as A fragments.  The zero
+            // products leave the accumulator untouched and the taps are met in ascending m, so the result is
+            // bit-identical to w0*c0, fma(w1,c1,.), fma(w2,c2,.), fma(w3,c3,.).  Same wave wrote rs: program order syncs.
+            float *ro = (float *)(ro_base + (size_t)(it % 3) * MG_RO_BYTES);
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++) {
+                if (ft * 16 < ck.nT) {
+                    f64x4 acc[3];
+                    double bv[3][2];
+#pragma unroll
+                    for (int ct = 0; ct < 3; ct++) {
+                        acc[ct] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) bv[ct][ks] = tap_b_ok[ct][ks] ? rs[tap_b_off[ct][ks]] : 0.0;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                        for (int ct = 0; ct < 3; ct++)
+                            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_wt[ft * 2 + ks], bv[ct][ks], acc[ct], 0, 0, 0);
+                    // D[row = f = 16 ft + (l >> 4) + 4 reg][col]
+#pragma unroll
+                    for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int fo = ft * 16 + g + 4 * r;
+                            if (tap_o_off[ct] >= 0 && fo < ck.nT) ro[tap_o_off[ct] + fo * 4] = (float)acc[ct][r];
+                        }
                 }
             }
         };
@@ -537,10 +566,10 @@ static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *l
     hipStream_t st = p->ctx->stream;
     if (lat_f64)
         hipLaunchKernelGGL((mg_frames_ws_kernel<KK, true>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_chunks, out, a, buf_bytes);
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
     else
         hipLaunchKernelGGL((mg_frames_ws_kernel<KK, false>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_chunks, out, a, buf_bytes);
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
@@ -582,8 +611,8 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     a.n_tiles = (int32_t)n_tiles;
     const bool lf = (ldt == MG_F64);
     // two LDS buffers + three table sets + two float64 root images, one workgroup per CU
-    const int buf_bytes = (MG_NCAND * g->stride * 4 + MG_NCAND * MG_MAX_NT * 16 + 255) / 256 * 256;
-    const int lds = 2 * buf_bytes + 3 * MG_TB_BYTES + 2 * MG_NCAND * (g->max_wi * p->nroot + 1) * 8;
+    const int buf_bytes = (MG_NCAND * g->stride * 4 + 255) / 256 * 256;
+    const int lds = 2 * buf_bytes + 3 * MG_RO_BYTES + 3 * MG_TB_BYTES + 2 * MG_NCAND * (g->max_wi * p->nroot + 1) * 8;
     if (lds != g->lds_bytes || lds > 160 * 1024) {
         mg_set_error("mg_back_project_frames: internal LDS sizing mismatch (%d vs %d)", lds, g->lds_bytes);
         return MG_ERR_UNSUPPORTED;

@@ -304,6 +304,8 @@ static void mg_free_grid_device(mg_time_grid *g) {
     if (g->d_i0) (void)hipFree(g->d_i0);
     if (g->d_w) (void)hipFree(g->d_w);
     if (g->d_w32) (void)hipFree(g->d_w32);
+    if (g->d_wtap) (void)hipFree(g->d_wtap);
+    g->d_wtap = nullptr;
     if (g->d_chunks) (void)hipFree(g->d_chunks);
     g->d_i0 = nullptr; g->d_w = nullptr; g->d_w32 = nullptr; g->d_chunks = nullptr;
 }
@@ -319,10 +321,11 @@ static int mg_round_stride(int nlocal) {
 // LDS of the persistent kernel: two buffers (coefficient image + float32 root outputs),
 // three per-sample table sets, two float64 root images.
 static int mg_lds_bytes(const mg_primitive *p, int stride, int wi) {
-    int buf = (MG_NCAND * stride * 4 + MG_NCAND * MG_MAX_NT * 16 + 255) / 256 * 256;
+    int buf = (MG_NCAND * stride * 4 + 255) / 256 * 256;
+    int rout = 3 * MG_NCAND * MG_MAX_NT * 16;
     int tabs = 3 * (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32);
     int root = 2 * MG_NCAND * (wi * p->nroot + 1) * 8;
-    return 2 * buf + tabs + root;
+    return 2 * buf + rout + tabs + root;
 }
 
 // Split the grid into chunks (runs of consecutive time samples) whose coefficient window
@@ -400,6 +403,22 @@ static int mg_grid_build(mg_primitive *p, mg_time_grid *g, const double *times, 
     if ((rc = mg_upload(p->ctx, g->w, &g->d_w)) != MG_OK) return rc;
     if ((rc = mg_upload(p->ctx, w32, &g->d_w32)) != MG_OK) return rc;
     if ((rc = mg_upload(p->ctx, g->chunks, &g->d_chunks)) != MG_OK) return rc;
+    {   // banded tap weights of every chunk as v_mfma_f64_16x16x4_f64 A fragments: lane l supplies
+        // W[f = 16 ft + (l & 15)][m = 4 ks + (l >> 4)],  W[f][m] = w[f][m - (i0[f] - imin)] inside the band
+        std::vector<double> wtap(std::max<size_t>(g->chunks.size(), 1) * 4 * 64, 0.0);
+        for (size_t c = 0; c < g->chunks.size(); c++) {
+            const mg_chunk &ck = g->chunks[c];
+            for (int ft = 0; ft < 2; ft++)
+                for (int ks = 0; ks < 2; ks++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        int f = ft * 16 + (lane & 15), m = 4 * ks + (lane >> 4);
+                        if (f >= ck.nT) continue;
+                        int j = m - (g->i0[ck.t0 + f] - ck.imin);
+                        if (j >= 0 && j < 4) wtap[((c * 2 + ft) * 2 + ks) * 64 + lane] = g->w[4 * (size_t)(ck.t0 + f) + j];
+                    }
+        }
+        if ((rc = mg_upload(p->ctx, wtap, &g->d_wtap)) != MG_OK) return rc;
+    }
     return MG_OK;
 }
 

@@ -79,6 +79,7 @@ struct mg_time_grid {
     int32_t *d_i0 = nullptr;
     double *d_w = nullptr;      // (T,4) float64 weights
     float *d_w32 = nullptr;     // (T,4) float32 weights
+    double *d_wtap = nullptr;   // [n_chunks][2][2][64] banded tap weights, f64 MFMA A fragments
     mg_chunk *d_chunks = nullptr;
     int32_t n_chunks = 0;
     int32_t stride = 0;      // floats per candidate in the LDS coefficient image
