@@ -26,6 +26,7 @@ int mg_hip_fail(hipError_t e, const char *what);
 struct mg_event_pair {
     hipEvent_t a, b;
     int slot;
+    bool ended;
 };
 
 struct mg_context {
