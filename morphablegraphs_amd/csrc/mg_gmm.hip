@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__r
                                                               const void *__restrict__ x, void *__restrict__ out,
                                                               const mg_gmm_mfma_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *lds_t = (double *)smem;   // [K][16]
+    double *lds_t = (double *)smem;          // [K][16] component terms
+    double *lds_e = lds_t + (size_t)a.K * 16;   // [K][16] exp(term - max)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, g = lane >> 4;
@@ -112,19 +113,36 @@ __global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__r
         if (cl < ncand && k < a.L) v = X_F64 ? ((const double *)x)[(b0 + cl) * a.ld + k] : (double)((const float *)x)[(b0 + cl) * a.ld + k];
         xf[kk] = v;
     }
+    constexpr int JTM = (KK + 3) / 4;   // column tiles of 16 for n_components <= 4 KK
     for (int k = wave; k < a.K; k += 4) {
-        double part[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int jt = 0; jt < a.JT; jt++) {
-            const double *pp = Ppack + (((size_t)k * a.JT + jt) * KK) * 64 + lane;
-            const double c0 = -mP[((size_t)k * a.JT + jt) * 16 + cl];
-            f64x4 acc = {c0, c0, c0, c0};
-            const int kmax = 4 * (jt + 1) < KK ? 4 * (jt + 1) : KK;   // P_k is upper triangular
+        // all B fragments of this component first (P_k is upper triangular: tile jt needs k-steps < 4 (jt + 1)),
+        // then the column tiles' accumulator chains interleaved
+        double pf[JTM][KK];
+        f64x4 acc[JTM];
+#pragma unroll
+        for (int jt = 0; jt < JTM; jt++) {
+            const int jtc = jt < a.JT ? jt : a.JT - 1;
+            const double *pp = Ppack + (((size_t)k * a.JT + jtc) * KK) * 64 + lane;
+            constexpr int dummy = 0;
+            (void)dummy;
 #pragma unroll
             for (int kk = 0; kk < KK; kk++)
-                if (kk < kmax) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], pp[kk * 64], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) part[r] = fma(acc[r], acc[r], part[r]);
+                if (kk < 4 * (jt + 1)) pf[jt][kk] = pp[kk * 64];
+            const double c0 = -mP[((size_t)k * a.JT + jtc) * 16 + cl];
+            acc[jt] = {c0, c0, c0, c0};
         }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+            for (int jt = 0; jt < JTM; jt++)
+                if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], pf[jt][kk], acc[jt], 0, 0, 0);
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jt = 0; jt < JTM; jt++)
+            if (jt < a.JT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) part[r] = fma(acc[jt][r], acc[jt][r], part[r]);
+            }
         // C/D layout: col = lane & 15, row (candidate) = (lane >> 4) + 4*reg: reduce over the 16 columns
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -142,6 +160,14 @@ __global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__r
         }
     }
     __syncthreads();
+    // log-sum-exp: the K exponentials of a candidate in parallel, summed in component order
+    for (int e = tid; e < a.K * 16; e += 256) {
+        const int c = e & 15;
+        double vmax = -INFINITY;
+        for (int k = 0; k < a.K; k++) vmax = fmax(vmax, lds_t[k * 16 + c]);
+        lds_e[e] = (vmax == -INFINITY) ? 0.0 : exp(lds_t[e] - vmax);
+    }
+    __syncthreads();
     if (tid < ncand) {
         double vmax = -INFINITY;
         for (int k = 0; k < a.K; k++) vmax = fmax(vmax, lds_t[k * 16 + tid]);
@@ -150,7 +176,7 @@ __global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__r
             r = -INFINITY;
         } else {
             double acc = 0.0;
-            for (int k = 0; k < a.K; k++) acc += exp(lds_t[k * 16 + tid] - vmax);
+            for (int k = 0; k < a.K; k++) acc += lds_e[k * 16 + tid];
             r = log(acc) + vmax;
         }
         if (OUT_F64) ((double *)out)[b0 + tid] = r;
@@ -164,7 +190,7 @@ static int mg_launch_gmm_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_
     a.B = B; a.ld = ld; a.K = p->K; a.L = p->L; a.JT = (p->L + 15) / 16;
     const int64_t grid = (B + 15) / 16;
     if (grid > 0x7fffffff) { mg_set_error("mg_gmm_log_prob: too many samples"); return MG_ERR_UNSUPPORTED; }
-    const size_t lds = (size_t)p->K * 16 * 8;
+    const size_t lds = (size_t)p->K * 16 * 8 * 2;
     hipStream_t st = p->ctx->stream;
     const bool xf = xdt == MG_F64, of = odt == MG_F64;
     if (xf && of) hipLaunchKernelGGL((mg_gmm_logp_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a);
@@ -176,7 +202,7 @@ static int mg_launch_gmm_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_
 }
 
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
-    if (p->d_gPpack && p->K * 16 * 8 <= 60 * 1024) {
+    if (p->d_gPpack && p->K * 16 * 16 <= 60 * 1024) {
         switch (p->KK) {
             case 2: return mg_launch_gmm_mfma_kk<2>(p, x, xdt, B, ld, out, odt);
             case 4: return mg_launch_gmm_mfma_kk<4>(p, x, xdt, B, ld, out, odt);
