@@ -77,9 +77,9 @@ extern "C" int mg_debug_dump_stamps(void) {
 // consumers only STORE; (2) the contraction is L2-latency bound and the sweep is HBM bound:
 // in one-shot workgroups they run in lockstep and add up instead of overlapping.
 //
-//   producer wave 0    : unit it+1's per-sample tables -> tb[(it+1)%3]; unit it+1's root-translation
-//                        rows by v_mfma_f64_16x16x4_f64 (C-in = mean') -> rs[(it+1)&1]; their spline taps by
-//                        a second f64 MFMA (banded weight matrix) -> float32 root outputs ro[(it+1)%3]
+//   producer wave 0    : unit it's per-sample tables -> tb[it&1]; unit it's root-translation rows by
+//                        v_mfma_f64_16x16x4_f64 (C-in = mean') -> rs; their spline taps by a second f64
+//                        MFMA (banded weight matrix) -> float32 root outputs ro[it&1]
 //   producer waves 1-3 : unit it's window of padded coefficient rows by v_mfma_f32_16x16x4_f32
 //                        (A = E' fragments from L2, two tiles in flight + two prefetched; B = the
 //                        latent tile in registers; C-in = mean') -> buf[it&1].img [cand][i*Dp + d + cshift]
@@ -90,9 +90,9 @@ extern "C" int mg_debug_dump_stamps(void) {
 //                        of consecutive bytes and the next continues where it ended.
 //   one raw s_barrier per unit with lgkmcnt(0) only: the consumers' stores stay in flight across it.
 //
-// LDS: buf[2] = image [16][stride] f32; ro[3] = root outputs [16][MG_MAX_NT][4] f32; tb[3] = w32 [MG_MAX_NT]
+// LDS: buf[2] = image [16][stride] f32; ro[2] = root outputs [16][MG_MAX_NT][4] f32; tb[2] = w32 [MG_MAX_NT]
 // float4, image tap byte offsets [MG_MAX_NT] int, root image tap offsets [MG_MAX_NT] int, w64 [MG_MAX_NT][4]
-// double; rs[2] = float64 root image.
+// double; rs = float64 root image.
 // -----------------------------------------------------------------------------------------
 #define MG_WS_NPW 4      // producer waves
 #define MG_WS_NCW 8      // consumer waves, two candidates each
@@ -179,10 +179,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
     const int root_stride = a.max_wi * nroot + 1;
-    unsigned char *ro_base = smem + 2 * (size_t)buf_bytes;            // root outputs, triple buffered
-    unsigned char *tb_base = ro_base + 3 * MG_RO_BYTES;
-    unsigned char *rs_base = tb_base + 3 * MG_TB_BYTES;
-    const int rs_bytes = MG_NCAND * root_stride * 8;
+    unsigned char *ro_base = smem + 2 * (size_t)buf_bytes;            // root outputs, double buffered
+    unsigned char *tb_base = ro_base + 2 * MG_RO_BYTES;               // per-sample tables, double buffered
+    unsigned char *rs_base = tb_base + 2 * MG_TB_BYTES;               // float64 root image (wave 0 only)
 
     const int64_t U = (int64_t)a.n_tiles * a.n_chunks;
     const int64_t u_begin = (int64_t)blockIdx.x * U / gridDim.x;
@@ -210,7 +209,6 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         const int lane_out = fsub * D + d0;               // float offset inside a row group
         mg_unit un_prev;
         MG_STAMP_DECL
-        mg_lds_barrier();   // prologue barrier (unit 0's tables and root rows)
         for (int it = 0; it <= n_units; it++) {
             MG_STAMP(0);
             mg_unit un;
@@ -222,8 +220,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             if (it >= 1 && !(a.debug & 2) && cj < un_prev.ncand) {
                 const mg_chunk &ck = un_prev.ck;
                 const unsigned char *img = smem + (size_t)((it - 1) & 1) * buf_bytes;
-                const float *lds_ro = (const float *)(ro_base + (size_t)((it - 1) % 3) * MG_RO_BYTES);
-                const float4 *lds_w = (const float4 *)(tb_base + (size_t)((it - 1) % 3) * MG_TB_BYTES);
+                const float *lds_ro = (const float *)(ro_base + (size_t)((it - 1) & 1) * MG_RO_BYTES);
+                const float4 *lds_w = (const float4 *)(tb_base + (size_t)((it - 1) & 1) * MG_TB_BYTES);
                 const int *lds_mo = (const int *)(lds_w + MG_MAX_NT);
                 const int col0 = ck.imin * Dp - ck.rt0 * 16;
                 const bool has1 = cj + MG_WS_NCW < un_prev.ncand;
@@ -276,7 +274,6 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         constexpr int NP = MG_WS_NPW - 1;
         if (a.debug & 256) __builtin_amdgcn_s_setprio(3);
         MG_STAMP_DECL
-        mg_lds_barrier();   // prologue barrier
         for (int it = 0; it <= n_units; it++) {
             MG_STAMP(0);
             if (it < n_units && !(a.debug & 1)) {
@@ -356,11 +353,11 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         }
         auto root_stage = [&](const mg_unit &un, int it) {   // tables -> tb[it%3], root rows -> rs[it&1]
             const mg_chunk &ck = un.ck;
-            float4 *tw = (float4 *)(tb_base + (size_t)(it % 3) * MG_TB_BYTES);
+            float4 *tw = (float4 *)(tb_base + (size_t)(it & 1) * MG_TB_BYTES);
             int *tmo = (int *)(tw + MG_MAX_NT);
             int *tmr = tmo + MG_MAX_NT;
             double *tw64 = (double *)(tmr + MG_MAX_NT);
-            double *rs = (double *)(rs_base + (size_t)(it & 1) * rs_bytes);
+            double *rs = (double *)rs_base;
             float4 r_w = {0.f, 0.f, 0.f, 0.f};
             int r_i0 = 0;
             double r_w64[2] = {0.0, 0.0};
@@ -428,7 +425,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             // banded W[f][m] = w[f][m - m0(f)] (0 outside the 4 taps) pre-packed per chunk as A fragments.  The zero
             // products leave the accumulator untouched and the taps are met in ascending m, so the result is
             // bit-identical to w0*c0, fma(w1,c1,.), fma(w2,c2,.), fma(w3,c3,.).  Same wave wrote rs: program order syncs.
-            float *ro = (float *)(ro_base + (size_t)(it % 3) * MG_RO_BYTES);
+            float *ro = (float *)(ro_base + (size_t)(it & 1) * MG_RO_BYTES);
 #pragma unroll
             for (int ft = 0; ft < 2; ft++) {
                 if (ft * 16 < ck.nT) {
@@ -457,15 +454,12 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             }
         };
         MG_STAMP_DECL
-        mg_unit un = mg_unit_at(chunks, a, cur);   // unit 0
-        if (!(a.debug & 1)) root_stage(un, 0);
-        mg_lds_barrier();   // prologue barrier
         for (int it = 0; it <= n_units; it++) {
             MG_STAMP(0);
-            if (it + 1 < n_units) {
+            if (it < n_units) {
+                const mg_unit un = mg_unit_at(chunks, a, cur);
                 mg_cursor_next(cur, a.n_chunks);
-                un = mg_unit_at(chunks, a, cur);
-                if (!(a.debug & 1)) root_stage(un, it + 1);
+                if (!(a.debug & 1)) root_stage(un, it);
             }
             MG_STAMP(3);
             MG_STAMP(4);
@@ -612,7 +606,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     const bool lf = (ldt == MG_F64);
     // two LDS buffers + three table sets + two float64 root images, one workgroup per CU
     const int buf_bytes = (MG_NCAND * g->stride * 4 + 255) / 256 * 256;
-    const int lds = 2 * buf_bytes + 3 * MG_RO_BYTES + 3 * MG_TB_BYTES + 2 * MG_NCAND * (g->max_wi * p->nroot + 1) * 8;
+    const int lds = 2 * buf_bytes + 2 * MG_RO_BYTES + 2 * MG_TB_BYTES + MG_NCAND * (g->max_wi * p->nroot + 1) * 8;
     if (lds != g->lds_bytes || lds > 160 * 1024) {
         mg_set_error("mg_back_project_frames: internal LDS sizing mismatch (%d vs %d)", lds, g->lds_bytes);
         return MG_ERR_UNSUPPORTED;

@@ -329,9 +329,9 @@ static int mg_round_stride(int nlocal) {
 // three per-sample table sets, two float64 root images.
 static int mg_lds_bytes(const mg_primitive *p, int stride, int wi) {
     int buf = (MG_NCAND * stride * 4 + 255) / 256 * 256;
-    int rout = 3 * MG_NCAND * MG_MAX_NT * 16;
-    int tabs = 3 * (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32);
-    int root = 2 * MG_NCAND * (wi * p->nroot + 1) * 8;
+    int rout = 2 * MG_NCAND * MG_MAX_NT * 16;
+    int tabs = 2 * (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32);
+    int root = MG_NCAND * (wi * p->nroot + 1) * 8;
     return 2 * buf + rout + tabs + root;
 }
 
