@@ -122,6 +122,26 @@ def test_frames_ragged_batches_bit_exact(ctx, B):
     prim.close()
 
 
+def test_frames_repeated_launches_are_bitwise_stable(ctx):
+    """The persistent kernel hands LDS buffers between producer and consumer waves: repeated launches over ragged
+    and full batches must reproduce the oracle bit for bit every time (guards the barrier protocol)."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(77)
+    for B in (1000, 4099):
+        S = rng.standard_normal((B, 40)).astype(np.float32)
+        model = cp.frames_f32model(S[:1000].astype(np.float64))
+        for rep in range(4):
+            got = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+            np.testing.assert_array_equal(_bits(got[:1000]), _bits(model), err_msg="B=%d rep=%d" % (B, rep))
+            if rep == 0:
+                first = got
+            else:
+                np.testing.assert_array_equal(_bits(got), _bits(first), err_msg="B=%d rep=%d" % (B, rep))
+    prim.close()
+
+
 def test_frames_leading_dimension_and_extra_columns(ctx):
     """back_project uses s[:n_components] (reference motion_primitive.py:229); extra time
     columns in the latent rows are ignored."""
