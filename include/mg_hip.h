@@ -115,8 +115,9 @@ int mg_memcpy_h2d(mg_context *ctx, void *dst_dev, const void *src, int64_t bytes
 int mg_memcpy_d2h(mg_context *ctx, void *dst, const void *src_dev, int64_t bytes);
 int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);
 
-/* Kernel timing with HIP events on the context's stream.  When enabled, each hot
- * kernel launch is bracketed by an event pair; totals are resolved on query.
+/* Kernel timing with HIP events on the context's stream.  enabled = n > 0 brackets every
+ * n-th launch of each slot with an event pair (n = 1: every launch; an event pair costs a few
+ * microseconds of stream time, so a timed region samples with n ~ 8); totals are resolved on query.
  * slot: 0 = back_project_frames, 1 = gmm_log_prob, 2 = score_constraints, 3 = argmin,
  *       4 = gmm_sample, 5 = spline_evaluate, 6 = fused step. */
 int mg_profile_enable(mg_context *ctx, int enabled);

@@ -201,7 +201,8 @@ class Context(object):
         return out
 
     def profile_enable(self, on=True):
-        _check(self.lib.mg_profile_enable(self.handle, 1 if on else 0))
+        """on: False/0 = off, True/1 = bracket every launch, n > 1 = bracket every n-th launch of a slot."""
+        _check(self.lib.mg_profile_enable(self.handle, int(on)))
 
     def profile_reset(self):
         _check(self.lib.mg_profile_reset(self.handle))

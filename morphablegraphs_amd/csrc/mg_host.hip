@@ -200,6 +200,7 @@ static hipEvent_t mg_get_event(mg_context *ctx) {
 }
 void mg_prof_begin(mg_context *ctx, int slot) {
     if (!ctx->profile) return;
+    if (ctx->prof_interval > 1 && (ctx->prof_seen[slot]++ % ctx->prof_interval) != 0) return;   // sampled bracketing
     if (ctx->pending.size() > 4096) (void)mg_prof_resolve(ctx);
     mg_event_pair p;
     p.a = mg_get_event(ctx);
@@ -237,6 +238,8 @@ extern "C" int mg_profile_enable(mg_context *ctx, int enabled) {
     MG_REQUIRE(ctx != nullptr, "mg_profile_enable: ctx is NULL");
     if (!enabled) (void)mg_prof_resolve(ctx);
     ctx->profile = enabled != 0;
+    ctx->prof_interval = enabled > 1 ? enabled : 1;
+    for (int i = 0; i < MG_PROFILE_SLOTS; i++) ctx->prof_seen[i] = 0;
     return MG_OK;
 }
 extern "C" int mg_profile_reset(mg_context *ctx) {
