@@ -435,7 +435,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     for (int ct = 0; ct < 3; ct++) {
                         acc[ct] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int ks = 0; ks < 2; ks++) bv[ct][ks] = tap_b_ok[ct][ks] ? rs[tap_b_off[ct][ks]] : 0.0;
+                        for (int ks = 0; ks < 2; ks++)   // rows at or beyond this chunk's window were never written: 0 * stale LDS could be NaN
+                            bv[ct][ks] = (tap_b_ok[ct][ks] && 4 * ks + g < ck.wi) ? rs[tap_b_off[ct][ks]] : 0.0;
                     }
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++)

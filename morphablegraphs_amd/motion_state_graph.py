@@ -7,8 +7,108 @@ Graph loading / transitions / control flow stay in the reference; only the scori
 import numpy as np
 
 from . import _capi
-from .candidate_scoring import constraints_to_device_form
+from .candidate_scoring import constraints_to_device_form, evaluate_samples_using_constraints
 from .motion_primitive import HipMotionPrimitive, get_context
+from .motion_primitive_wrapper import HipMotionPrimitiveModelWrapper
+
+NODE_TYPE_START = "start"
+NODE_TYPE_STANDARD = "standard"
+NODE_TYPE_END = "end"
+
+
+def arc_length_xz(root_positions):
+    """Length of the root path on the ground plane (x, z) -- what the reference gets from anim_utils'
+    extract_root_positions_from_frames + get_arc_length_from_points (motion_state_graph_node.py:222-224;
+    PARITY UNPINNED: anim_utils is not under /root/reference)."""
+    p = np.asarray(root_positions, dtype=np.float64)[..., [0, 2]]
+    return np.sqrt(((p[..., 1:, :] - p[..., :-1, :]) ** 2).sum(axis=-1)).sum(axis=-1)
+
+
+class HipMotionStateGraphNode(HipMotionPrimitiveModelWrapper):
+    """The hot-path call sites of MotionStateGraphNode (reference motion_model/motion_state_graph_node.py:45-275)
+    on top of the HIP-backed wrapper: step-length statistics, transition-model dispatch, best-sample search.
+    Edges / groups / cluster trees are plain host data exactly as in the reference."""
+
+    def __init__(self, motion_state_group=None, context=None, device=0):
+        super(HipMotionStateGraphNode, self).__init__(context=context, device=device)
+        self.motion_state_group = motion_state_group
+        self.outgoing_edges = dict()
+        self.node_type = NODE_TYPE_STANDARD
+        self.n_standard_transitions = 0
+        self.parameter_bb = None
+        self.cartesian_bb = None
+        self.velocity_data = None
+        self.average_step_length = 0
+        self.action_name = None
+        self.name = None
+        self.cluster_tree = None
+
+    def init_from_dict(self, action_name, desc):
+        self.name = desc["name"]
+        self.action_name = action_name
+        self._initialize_from_json(None, desc["mm"])
+        if "stats" in desc:
+            self.parameter_bb = desc["stats"]["pose_bb"]
+            self.cartesian_bb = desc["stats"]["cartesian_bb"]
+            self.velocity_data = desc["stats"]["pose_velocity"]
+
+    # ---- step length (motion_state_graph_node.py:183-230) ------------------------------------------
+    def update_motion_stats(self, n_samples=5, method="median"):
+        self.n_standard_transitions = len([e for e in self.outgoing_edges
+                                           if getattr(self.outgoing_edges[e], "transition_type", None) == NODE_TYPE_STANDARD])
+        sample_lengths = [self._get_random_sample_step_length() for _ in range(n_samples)]
+        if method == "average":
+            self.average_step_length = sum(sample_lengths) / n_samples
+        else:
+            self.average_step_length = np.median(sample_lengths)
+
+    def _get_random_sample_step_length(self, method="arc_length"):
+        current_parameters = np.ravel(self.sample_low_dimensional_vector())
+        return self.get_step_length_for_sample(current_parameters, method)
+
+    def get_step_length_for_sample(self, parameters, method="arc_length"):
+        quat_frames = self.back_project(parameters, use_time_parameters=False).get_motion_vector()
+        if method == "arc_length":
+            return float(arc_length_xz(quat_frames[:, :3]))
+        elif method == "distance":
+            return float(np.linalg.norm(quat_frames[-1][:3] - quat_frames[0][:3]))
+        raise NotImplementedError
+
+    def get_step_lengths_for_samples(self, samples, method="arc_length"):
+        """Batched form: one frames launch for all rows."""
+        frames = self.motion_primitive.back_project_frames_batch(np.asarray(samples))
+        if method == "arc_length":
+            return arc_length_xz(frames[:, :, :3])
+        elif method == "distance":
+            return np.linalg.norm(frames[:, -1, :3].astype(np.float64) - frames[:, 0, :3], axis=1)
+        raise NotImplementedError
+
+    # ---- transitions (motion_state_graph_node.py:232-272) -----------------------------------------
+    def has_transition_model(self, to_node_key):
+        return to_node_key in self.outgoing_edges and getattr(self.outgoing_edges[to_node_key], "transition_model", None) is not None
+
+    def predict_parameters(self, to_node_key, current_parameters):
+        gmm = self.outgoing_edges[to_node_key].transition_model.predict(current_parameters)
+        return np.ravel(gmm.sample()[0] if isinstance(gmm.sample(), tuple) else gmm.sample())
+
+    def predict_gmm(self, to_node_key, current_parameters):
+        edge = self.outgoing_edges.get(to_node_key)
+        if edge is not None and getattr(edge, "transition_model", None) is not None:
+            return edge.transition_model.predict(current_parameters)
+        return self.get_gaussian_mixture_model()
+
+    # ---- best-sample search (motion_state_graph_node.py:119-142) -------------------------------------
+    def search_best_sample(self, obj, data, n_candidates=2):
+        if self.cluster_tree is not None:
+            return self.cluster_tree.find_best_example_excluding_search_candidates(obj, data, n_candidates)
+        return np.inf, None
+
+    def search_best_sample_gpu(self, constraints, n_samples):
+        """Brute-force replacement of the cluster-tree search at GPU batch sizes: draw n_samples latents, score
+        them in one launch, return (error, parameters) like search_best_sample."""
+        samples = self.sample_low_dimensional_vectors(n_samples)
+        best, err = evaluate_samples_using_constraints(samples, self, constraints, None)
+        return err, best
 
 
 class HipPrimitiveSet(object):

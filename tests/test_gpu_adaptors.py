@@ -6,7 +6,7 @@ import pytest
 
 from morphablegraphs_amd import (HipMotionPrimitive, HipMotionPrimitiveModelWrapper, _capi, synthetic)
 from morphablegraphs_amd.candidate_scoring import HipSampleFilter, evaluate_samples_using_constraints
-from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
+from morphablegraphs_amd.motion_state_graph import HipMotionStateGraphNode, HipPrimitiveSet, arc_length_xz
 from oracle import c_oracle
 
 pytestmark = pytest.mark.gpu
@@ -169,3 +169,39 @@ def test_graph_of_primitives_option_evaluation():
         assert abs(results[n][1] - ref.min()) <= 1e-9
         np.testing.assert_array_equal(results[n][0], S[int(np.argmin(ref))])
     assert best == names[int(np.argmin([results[n][1] for n in names]))]
+
+
+def test_graph_node_call_sites():
+    """MotionStateGraphNode's hot-path call sites (motion_state_graph_node.py:183-272) on the HIP wrapper."""
+    data = synthetic.make_walk_primitive(seed=0)
+    cp = c_oracle.COraclePrimitive(data)
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "leftStance", "mm": data})
+    assert (node.action_name, node.name) == ("walk", "leftStance")
+    rng = np.random.default_rng(3)
+    S = rng.standard_normal((6, 40))
+    ref_frames = cp.frames_f64(S)
+    ref_len = arc_length_xz(ref_frames[:, :, :3])
+    for i in range(3):
+        assert abs(node.get_step_length_for_sample(S[i]) - ref_len[i]) <= 1e-9 * max(1.0, ref_len[i])
+        d = np.linalg.norm(ref_frames[i, -1, :3] - ref_frames[i, 0, :3])
+        assert abs(node.get_step_length_for_sample(S[i], "distance") - d) <= 1e-9 * max(1.0, d)
+    np.testing.assert_allclose(node.get_step_lengths_for_samples(S), ref_len, rtol=2e-6)
+    with pytest.raises(NotImplementedError):
+        node.get_step_length_for_sample(S[0], "other")
+    np.random.seed(9)
+    node.update_motion_stats(n_samples=5)
+    np.random.seed(9)
+    lens = [arc_length_xz(cp.frames_f64(node.sample_low_dimensional_vector())[0][:, :3]) for _ in range(5)]
+    assert abs(node.average_step_length - np.median(lens)) <= 1e-9 * np.median(lens)
+    assert node.n_standard_transitions == 0
+    assert node.predict_gmm(("walk", "rightStance"), S[0]) is node.get_gaussian_mixture_model()
+    assert not node.has_transition_model(("walk", "rightStance"))
+    assert node.search_best_sample(None, None) == (np.inf, None)
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [20.0, None, 10.0]}]
+    np.random.seed(4)
+    err, best = node.search_best_sample_gpu(cons, 512)
+    np.random.seed(4)
+    S2 = node.sample_low_dimensional_vectors(512)
+    ref = cp.keyframe_errors_f64(S2, np.array([[0, 155.0, 1.0, 20.0, np.nan, 10.0, 0, 0]]))
+    assert abs(err - ref.min()) <= 1e-9 and np.array_equal(best, S2[int(np.argmin(ref))])

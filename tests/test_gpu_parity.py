@@ -142,6 +142,26 @@ def test_frames_repeated_launches_are_bitwise_stable(ctx):
     prim.close()
 
 
+def test_short_last_window_ignores_stale_lds(ctx):
+    """The last chunk of the walk grid has a 6-row window; the root-tap MFMA must not pick up stale LDS (a previous
+    launch's bytes) from rows 6-7 of the float64 root image -- 0 * NaN would poison the root channels.  A launch with
+    NaN latents leaves NaN bit patterns in every CU's LDS; small launches whose workgroups START on the short chunk
+    must still be exact."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(5)
+    poison = np.full((4096, 40), np.nan, dtype=np.float32)
+    for B in (16, 40, 16):
+        S = rng.standard_normal((B, 40)).astype(np.float32)
+        model = cp.frames_f32model(S.astype(np.float64))
+        assert np.isnan(prim.back_project_frames(poison, path=_capi.MG_PATH_MFMA)).all()
+        got = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+        assert np.isfinite(got).all(), "stale LDS leaked into the output"
+        np.testing.assert_array_equal(_bits(got), _bits(model))
+    prim.close()
+
+
 def test_frames_leading_dimension_and_extra_columns(ctx):
     """back_project uses s[:n_components] (reference motion_primitive.py:229); extra time
     columns in the latent rows are ignored."""
