@@ -25,7 +25,7 @@ struct mg_frames_args {
     int64_t B, ld;
     int32_t T, D, Dp, cshift, L, nroot, n_chunks, n_tiles, stride, max_wi;
     int32_t debug;   // MG_DEBUG_FLAGS (bench ablations only): 1 = producers idle, 2 = consumers idle, 16 = phase timers
-    int32_t pad;
+    int32_t nbuf;    // LDS ring depth (2 or 3)
 };
 
 template <bool F64>
@@ -60,7 +60,7 @@ extern "C" int mg_debug_dump_stamps(void) {
     printf("  (0: loop top, 1: loads issued / root taps, 2: MFMA, 3: root staging, 4: consume / work end, 5: barrier wait)\n");
     for (int w = 0; w < 12; w++) {
         printf("wave %2d:", w);
-        for (int ph = 0; ph < 6; ph++) printf(" %9llu", h[w][ph]);
+        for (int ph = 0; ph < 8; ph++) printf(" %9llu", h[w][ph]);
         printf("\n");
     }
     return 0;
@@ -77,31 +77,61 @@ extern "C" int mg_debug_dump_stamps(void) {
 // consumers only STORE; (2) the contraction is L2-latency bound and the sweep is HBM bound:
 // in one-shot workgroups they run in lockstep and add up instead of overlapping.
 //
-//   producer wave 0    : unit it's per-sample tables -> tb[it&1]; unit it's root-translation rows by
+//   producer wave 0    : unit u's per-sample tables -> tb[slot]; unit u's root-translation rows by
 //                        v_mfma_f64_16x16x4_f64 (C-in = mean') -> rs; their spline taps by a second f64
-//                        MFMA (banded weight matrix) -> float32 root outputs ro[it&1]
-//   producer waves 1-3 : unit it's window of padded coefficient rows by v_mfma_f32_16x16x4_f32
+//                        MFMA (banded weight matrix) -> float32 root outputs ro[slot]
+//   producer waves 1-3 : unit u's window of padded coefficient rows by v_mfma_f32_16x16x4_f32
 //                        (A = E' fragments from L2, two tiles in flight + two prefetched; B = the
-//                        latent tile in registers; C-in = mean') -> buf[it&1].img [cand][i*Dp + d + cshift]
-//   consumer waves 4-11: the "quad-row" sweep of unit it-1: a wave owns two candidates; a lane owns 4
+//                        latent tile in registers; C-in = mean') -> buf[slot] [cand][i*Dp + d + cshift]
+//   consumer waves 4-11: the "quad-row" sweep of a finished unit: a wave owns two candidates; a lane owns 4
 //                        consecutive channels of one sample (4 ds_read_b128 taps, 16 FMAs, one
 //                        dwordx4 store), the last lane of each row group owns the root channels;
 //                        64/20 samples per wave instruction, so one store instruction writes ~1 KB
 //                        of consecutive bytes and the next continues where it ended.
-//   one raw s_barrier per unit with lgkmcnt(0) only: the consumers' stores stay in flight across it.
+//   No s_barrier in the unit loop: the slots form a ring of nbuf (3 when LDS allows, else 2) and the roles
+//   hand units over through per-wave progress counters in LDS (mg_publish / mg_wait_*), so a slow consumer
+//   wave delays only the recycling of its slot and the consumers' stores stay in flight throughout.
 //
-// LDS: buf[2] = image [16][stride] f32; ro[2] = root outputs [16][MG_MAX_NT][4] f32; tb[2] = w32 [MG_MAX_NT]
-// float4, image tap byte offsets [MG_MAX_NT] int, root image tap offsets [MG_MAX_NT] int, w64 [MG_MAX_NT][4]
-// double; rs = float64 root image.
+// LDS: buf[nbuf] = image [16][stride] f32; ro[nbuf] = root outputs [16][MG_MAX_NT][4] f32; tb[nbuf] = w32
+// [MG_MAX_NT] float4 + image tap byte offsets [MG_MAX_NT] int; rs = float64 root image; prog = 16 counters.
 // -----------------------------------------------------------------------------------------
 #define MG_WS_NPW 4      // producer waves
 #define MG_WS_NCW 8      // consumer waves, two candidates each
 #define MG_WS_BLOCK (64 * (MG_WS_NPW + MG_WS_NCW))
-#define MG_TB_BYTES (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32)
+#define MG_TB_BYTES (MG_MAX_NT * 16 + MG_MAX_NT * 4)
 #define MG_RO_BYTES (MG_NCAND * MG_MAX_NT * 16)
 
-__device__ __forceinline__ void mg_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Producer/consumer hand-off through per-wave progress counters in LDS (no s_barrier in the unit loop):
+// prog[w] = number of units wave w has finished.  A wave publishes after its own LDS traffic has completed
+// (lgkmcnt(0)); LDS serves one wave's requests in order, so whoever sees the counter sees the data.
+// (the counters are addressed through an explicit LDS pointer: a generic one becomes flat_load + vmcnt(0),
+// which would drain the consumers' stores at every unit)
+typedef __attribute__((address_space(3))) int mg_lds_int;
+typedef __attribute__((address_space(3))) i32x4 mg_lds_i32x4;
+__device__ __forceinline__ void mg_publish(mg_lds_int *prog, int wave, int lane, int done) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *(volatile mg_lds_int *)&prog[wave] = done;
+}
+__device__ __forceinline__ void mg_wait_producers(const mg_lds_int *prog, int target) {   // waves 0..3
+    for (;;) {
+        const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
+        const int m = min(min(v[0], v[1]), min(v[2], v[3]));
+        if (__builtin_amdgcn_readfirstlane(m) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void mg_wait_consumers(const mg_lds_int *prog, int target) {   // waves 4..11
+    for (;;) {
+        const i32x4 v = *(const volatile mg_lds_i32x4 *)(prog + 4);
+        const i32x4 x = *(const volatile mg_lds_i32x4 *)(prog + 8);
+        const int m = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(x[0], x[1]), min(x[2], x[3])));
+        if (__builtin_amdgcn_readfirstlane(m) >= target) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
 }
 
 struct mg_unit {
@@ -159,6 +189,59 @@ __device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {
     }
 }
 
+
+// One wave's share of a unit's float32 coefficient window: row tiles pw, pw + npw, pw + 2 npw, ... of the
+// window, each D = E'tile (16 x 4KK) . latent tile (4KK x 16) + mean' by KK chained v_mfma_f32_16x16x4_f32,
+// written as four consecutive padded rows per lane (conflict-free since stride = 4 mod 32).
+// Two tiles in flight, the next two prefetched unconditionally (clamped): a conditional prefetch makes the
+// compiler drain it with vmcnt(0) at the loop top.
+template <int KK>
+__device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, const float *__restrict__ mean32,
+                                               const mg_chunk &ck, float *lds_c, int stride, int pw, int npw,
+                                               const float (&sfrag)[KK], int lane, int cl, int g) {
+    float2 fa[2][KK / 2], na[2][KK / 2];
+    f32x4 fm[2], nm[2];
+    auto load_tile = [&](int t, float2(&fr)[KK / 2], f32x4 &cin) {
+        const int tc = t < ck.ntiles ? t : ck.ntiles - 1;   // clamp: redundant but in bounds
+        const float2 *p = ep + ((size_t)(ck.rt0 + tc) * (KK / 2)) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KK / 2; q++) fr[q] = p[q * 64];
+        cin = *(const f32x4 *)(mean32 + (size_t)(ck.rt0 + tc) * 16 + 4 * g);
+    };
+    int t = pw;
+    load_tile(t, fa[0], fm[0]);
+    load_tile(t + npw, fa[1], fm[1]);
+    while (t < ck.ntiles) {
+        const int tn = t + 2 * npw;
+        load_tile(tn, na[0], nm[0]);
+        load_tile(tn + npw, na[1], nm[1]);
+        f32x4 acc0 = fm[0], acc1 = fm[1];
+#pragma unroll
+        for (int q = 0; q < KK / 2; q++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q].x, sfrag[2 * q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][q].x, sfrag[2 * q], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q].y, sfrag[2 * q + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][q].y, sfrag[2 * q + 1], acc1, 0, 0, 0);
+        }
+        // D[row = 4g + reg][col = cl]: four consecutive padded rows of candidate cl
+        *(f32x4 *)&lds_c[cl * stride + t * 16 + 4 * g] = acc0;
+        if (t + npw < ck.ntiles) *(f32x4 *)&lds_c[cl * stride + (t + npw) * 16 + 4 * g] = acc1;
+#pragma unroll
+        for (int q = 0; q < KK / 2; q++) { fa[0][q] = na[0][q]; fa[1][q] = na[1][q]; }
+        fm[0] = nm[0]; fm[1] = nm[1];
+        t = tn;
+    }
+}
+
+template <int KK, bool LAT_F64>
+__device__ __forceinline__ void mg_load_sfrag(float (&sfrag)[KK], const void *lat, const mg_unit &un, int64_t ld, int L, int cl, int g) {
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        const int k = 4 * kk + g;
+        sfrag[kk] = (cl < un.ncand && k < L) ? (float)mg_load_lat<LAT_F64>(lat, (un.b0 + cl) * ld + k) : 0.0f;
+    }
+}
+
 template <int KK, bool LAT_F64>
 __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const float *__restrict__ Epack,      // [RT][KK/2][64][2]
@@ -168,7 +251,6 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const void *__restrict__ lat,         // (B, ld) f32 or f64
     const int32_t *__restrict__ i0tab,    // (T)
     const float4 *__restrict__ w32,       // (T)
-    const double *__restrict__ w64,       // (T, 4)
     const double *__restrict__ wtap,      // [n_chunks][2][2][64] banded tap weights as f64 MFMA A fragments
     const mg_chunk *__restrict__ chunks,
     float *__restrict__ out,              // (B,T,D)
@@ -179,9 +261,13 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
     const int root_stride = a.max_wi * nroot + 1;
-    unsigned char *ro_base = smem + 2 * (size_t)buf_bytes;            // root outputs, double buffered
-    unsigned char *tb_base = ro_base + 2 * MG_RO_BYTES;               // per-sample tables, double buffered
-    unsigned char *rs_base = tb_base + 2 * MG_TB_BYTES;               // float64 root image (wave 0 only)
+    const int nbuf = a.nbuf;
+    unsigned char *ro_base = smem + nbuf * (size_t)buf_bytes;         // root outputs, one per ring slot
+    unsigned char *tb_base = ro_base + nbuf * MG_RO_BYTES;            // per-sample tables, one per ring slot
+    unsigned char *rs_base = tb_base + nbuf * MG_TB_BYTES;            // float64 root image (wave 0 only)
+    mg_lds_int *prog = (mg_lds_int *)(rs_base + (size_t)MG_NCAND * root_stride * 8);   // 16 progress counters
+    if (tid < 16) prog[tid] = 0;
+    __syncthreads();
 
     const int64_t U = (int64_t)a.n_tiles * a.n_chunks;
     const int64_t u_begin = (int64_t)blockIdx.x * U / gridDim.x;
@@ -207,21 +293,19 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         const int dp4 = Dp * 4;
         const int lane_img = (d0 + a.cshift) * 4;         // byte offset of the lane's quad inside a basis row
         const int lane_out = fsub * D + d0;               // float offset inside a row group
-        mg_unit un_prev;
+        int slot = 0;
         MG_STAMP_DECL
-        for (int it = 0; it <= n_units; it++) {
+        for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
-            mg_unit un;
-            if (it < n_units) {
-                un = mg_unit_at(chunks, a, cur);
-                mg_cursor_next(cur, a.n_chunks);
-            }
+            const mg_unit un_prev = mg_unit_at(chunks, a, cur);
+            mg_cursor_next(cur, a.n_chunks);
+            mg_wait_producers(prog, u + 1);
             MG_STAMP(1);
-            if (it >= 1 && !(a.debug & 2) && cj < un_prev.ncand) {
+            if (!(a.debug & 2) && cj < un_prev.ncand) {
                 const mg_chunk &ck = un_prev.ck;
-                const unsigned char *img = smem + (size_t)((it - 1) & 1) * buf_bytes;
-                const float *lds_ro = (const float *)(ro_base + (size_t)((it - 1) & 1) * MG_RO_BYTES);
-                const float4 *lds_w = (const float4 *)(tb_base + (size_t)((it - 1) & 1) * MG_TB_BYTES);
+                const unsigned char *img = smem + (size_t)slot * buf_bytes;
+                const float *lds_ro = (const float *)(ro_base + (size_t)slot * MG_RO_BYTES);
+                const float4 *lds_w = (const float4 *)(tb_base + (size_t)slot * MG_TB_BYTES);
                 const int *lds_mo = (const int *)(lds_w + MG_MAX_NT);
                 const int col0 = ck.imin * Dp - ck.rt0 * 16;
                 const bool has1 = cj + MG_WS_NCW < un_prev.ncand;
@@ -258,9 +342,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     if (ob && has1) mg_store_n(pb1 + lane_out, v1b, nst);
                 }
             }
-            un_prev = un;
             MG_STAMP(4);
-            mg_lds_barrier();
+            mg_publish(prog, wave, lane, u + 1);
+            if (++slot == nbuf) slot = 0;
             MG_STAMP(5);
         }
         MG_STAMP_DUMP;
@@ -271,65 +355,27 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         for (int kk = 0; kk < KK; kk++) sfrag[kk] = 0.f;
         int cur_tile = -1;
         const float2 *ep = (const float2 *)Epack;
-        constexpr int NP = MG_WS_NPW - 1;
-        if (a.debug & 256) __builtin_amdgcn_s_setprio(3);
+        int slot = 0;
         MG_STAMP_DECL
-        for (int it = 0; it <= n_units; it++) {
+        for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
-            if (it < n_units && !(a.debug & 1)) {
-                const mg_unit un = mg_unit_at(chunks, a, cur);
-                mg_cursor_next(cur, a.n_chunks);
+            const mg_unit un = mg_unit_at(chunks, a, cur);
+            mg_cursor_next(cur, a.n_chunks);
+            if (u >= nbuf) mg_wait_consumers(prog, u - nbuf + 1);   // the slot's previous unit has been swept
+            MG_STAMP(5);
+            if (!(a.debug & 1)) {
                 const mg_chunk &ck = un.ck;
-                float *lds_c = (float *)(smem + (size_t)(it & 1) * buf_bytes);
+                float *lds_c = (float *)(smem + (size_t)slot * buf_bytes);
                 if (un.tile != cur_tile) {
                     cur_tile = un.tile;
-#pragma unroll
-                    for (int kk = 0; kk < KK; kk++) {
-                        const int k = 4 * kk + g;
-                        sfrag[kk] = (cl < un.ncand && k < L) ? (float)mg_load_lat<LAT_F64>(lat, (un.b0 + cl) * a.ld + k) : 0.0f;
-                    }
+                    mg_load_sfrag<KK, LAT_F64>(sfrag, lat, un, a.ld, L, cl, g);
                 }
-                // tile t belongs to wave 1 + t % 3; two tiles in flight, the next two prefetched
-                float2 fa[2][KK / 2], na[2][KK / 2];
-                f32x4 fm[2], nm[2];
-                auto load_tile = [&](int t, float2(&fr)[KK / 2], f32x4 &cin) {
-                    const int tc = t < ck.ntiles ? t : ck.ntiles - 1;   // clamp: redundant but in bounds
-                    const float2 *p = ep + ((size_t)(ck.rt0 + tc) * (KK / 2)) * 64 + lane;
-#pragma unroll
-                    for (int q = 0; q < KK / 2; q++) fr[q] = p[q * 64];
-                    cin = *(const f32x4 *)(mean32 + (size_t)(ck.rt0 + tc) * 16 + 4 * g);
-                };
-                int t = wave - 1;
-                load_tile(t, fa[0], fm[0]);
-                load_tile(t + NP, fa[1], fm[1]);
-                MG_STAMP(1);
-                while (t < ck.ntiles) {
-                    // unconditional (clamped) prefetch: the compiler can then count the younger loads and wait
-                    // with a counted vmcnt instead of draining the prefetch it has just issued
-                    const int tn = t + 2 * NP;
-                    load_tile(tn, na[0], nm[0]);
-                    load_tile(tn + NP, na[1], nm[1]);
-                    f32x4 acc0 = fm[0], acc1 = fm[1];
-#pragma unroll
-                    for (int q = 0; q < KK / 2; q++) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q].x, sfrag[2 * q], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][q].x, sfrag[2 * q], acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q].y, sfrag[2 * q + 1], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][q].y, sfrag[2 * q + 1], acc1, 0, 0, 0);
-                    }
-                    // D[row = 4g + reg][col = cl]: four consecutive padded rows of candidate cl
-                    *(f32x4 *)&lds_c[cl * stride + t * 16 + 4 * g] = acc0;
-                    if (t + NP < ck.ntiles) *(f32x4 *)&lds_c[cl * stride + (t + NP) * 16 + 4 * g] = acc1;
-#pragma unroll
-                    for (int q = 0; q < KK / 2; q++) { fa[0][q] = na[0][q]; fa[1][q] = na[1][q]; }
-                    fm[0] = nm[0]; fm[1] = nm[1];
-                    t = tn;
-                }
+                mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g);
                 MG_STAMP(2);
             }
+            mg_publish(prog, wave, lane, u + 1);
+            if (++slot == nbuf) slot = 0;
             MG_STAMP(4);
-            mg_lds_barrier();
-            MG_STAMP(5);
         }
         MG_STAMP_DUMP;
     } else {
@@ -351,20 +397,15 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 tap_b_off[ct][ks] = cc * root_stride + m * nroot + cd;
             }
         }
-        auto root_stage = [&](const mg_unit &un, int it) {   // tables -> tb[it%3], root rows -> rs[it&1]
+        MG_STAMP_DECL
+        auto root_stage = [&](const mg_unit &un, int slot) {   // tables -> tb[slot], root rows -> rs, root outputs -> ro[slot]
             const mg_chunk &ck = un.ck;
-            float4 *tw = (float4 *)(tb_base + (size_t)(it & 1) * MG_TB_BYTES);
+            float4 *tw = (float4 *)(tb_base + (size_t)slot * MG_TB_BYTES);
             int *tmo = (int *)(tw + MG_MAX_NT);
-            int *tmr = tmo + MG_MAX_NT;
-            double *tw64 = (double *)(tmr + MG_MAX_NT);
             double *rs = (double *)rs_base;
             float4 r_w = {0.f, 0.f, 0.f, 0.f};
             int r_i0 = 0;
-            double r_w64[2] = {0.0, 0.0};
             if (lane < ck.nT) { r_w = w32[ck.t0 + lane]; r_i0 = i0tab[ck.t0 + lane]; }
-#pragma unroll
-            for (int e = 0; e < 2; e++)
-                if (lane + 64 * e < ck.nT * 4) r_w64[e] = w64[4 * (size_t)ck.t0 + lane + 64 * e];
             double r_wt[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) r_wt[e] = wtap[((size_t)un.chunk * 4 + e) * 64 + lane];
@@ -374,6 +415,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 const int k = 4 * kk + g;
                 s64frag[kk] = (cl < un.ncand && k < L) ? mg_load_lat<LAT_F64>(lat, (un.b0 + cl) * a.ld + k) : 0.0;
             }
+            if (a.debug & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MG_STAMP(1); }
             // up to 3 root tiles (8 basis functions x 3 channels = 24 rows, rr = i*nroot + d), chains
             // interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
             f64x4 racc[3];
@@ -388,29 +430,28 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 racc[t][2] = meanroot[row0 + g + 8];
                 racc[t][3] = meanroot[row0 + g + 12];
             }
-            // k-steps in two halves so the fragments of one half (3 tiles) fit the register budget
+            // all fragments of the 3 tiles in one round of loads (one L2 round trip under store pressure costs
+            // thousands of cycles); only for many components in two halves to stay inside the register budget
+            constexpr int NH = KK <= 10 ? 1 : 2;
+            constexpr int KH = KK / NH;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                double rp[3][KK / 2];
+            for (int h = 0; h < NH; h++) {
+                double rp[3][KH];
 #pragma unroll
                 for (int t = 0; t < 3; t++)
 #pragma unroll
-                    for (int q = 0; q < KK / 2; q++) rp[t][q] = rpp[t][(h * (KK / 2) + q) * 64];
+                    for (int q = 0; q < KH; q++) rp[t][q] = rpp[t][(h * KH + q) * 64];
                 if (h == 0) {
                     if (lane < ck.nT) {
                         tw[lane] = r_w;
                         tmo[lane] = (r_i0 - ck.imin) * Dp * 4;   // byte offset of the first tap row in the f32 image
-                        tmr[lane] = (r_i0 - ck.imin) * nroot;    // element offset in the float64 root image
                     }
-#pragma unroll
-                    for (int e = 0; e < 2; e++)
-                        if (lane + 64 * e < ck.nT * 4) tw64[lane + 64 * e] = r_w64[e];
                 }
 #pragma unroll
-                for (int q = 0; q < KK / 2; q++)
+                for (int q = 0; q < KH; q++)
 #pragma unroll
                     for (int t = 0; t < 3; t++)
-                        racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q], s64frag[h * (KK / 2) + q], racc[t], 0, 0, 0);
+                        racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q], s64frag[h * KH + q], racc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 3; t++) {
@@ -421,11 +462,12 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     if (t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) rs[cl * root_stride + lr] = racc[t][r];
                 }
             }
+            if (a.debug & 32) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); MG_STAMP(2); }
             // root taps, again on the float64 matrix pipe: out[f][(c,d)] = sum_m W[f][m] * rows[m][(c,d)] with the
             // banded W[f][m] = w[f][m - m0(f)] (0 outside the 4 taps) pre-packed per chunk as A fragments.  The zero
             // products leave the accumulator untouched and the taps are met in ascending m, so the result is
             // bit-identical to w0*c0, fma(w1,c1,.), fma(w2,c2,.), fma(w3,c3,.).  Same wave wrote rs: program order syncs.
-            float *ro = (float *)(ro_base + (size_t)(it & 1) * MG_RO_BYTES);
+            float *ro = (float *)(ro_base + (size_t)slot * MG_RO_BYTES);
 #pragma unroll
             for (int ft = 0; ft < 2; ft++) {
                 if (ft * 16 < ck.nT) {
@@ -452,20 +494,21 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                             if (tap_o_off[ct] >= 0 && fo < ck.nT) ro[tap_o_off[ct] + fo * 4] = (float)acc[ct][r];
                         }
                 }
+                if ((a.debug & 32) && ft == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MG_STAMP(6); }
             }
         };
-        MG_STAMP_DECL
-        for (int it = 0; it <= n_units; it++) {
+        int slot = 0;
+        for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
-            if (it < n_units) {
-                const mg_unit un = mg_unit_at(chunks, a, cur);
-                mg_cursor_next(cur, a.n_chunks);
-                if (!(a.debug & 1)) root_stage(un, it);
-            }
-            MG_STAMP(3);
-            MG_STAMP(4);
-            mg_lds_barrier();
+            const mg_unit un = mg_unit_at(chunks, a, cur);
+            mg_cursor_next(cur, a.n_chunks);
+            if (u >= nbuf) mg_wait_consumers(prog, u - nbuf + 1);
             MG_STAMP(5);
+            if (!(a.debug & 1)) root_stage(un, slot);
+            MG_STAMP(3);
+            mg_publish(prog, wave, lane, u + 1);
+            if (++slot == nbuf) slot = 0;
+            MG_STAMP(4);
         }
         MG_STAMP_DUMP;
     }
@@ -561,10 +604,10 @@ static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *l
     hipStream_t st = p->ctx->stream;
     if (lat_f64)
         hipLaunchKernelGGL((mg_frames_ws_kernel<KK, true>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
     else
         hipLaunchKernelGGL((mg_frames_ws_kernel<KK, false>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_w, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
@@ -592,7 +635,7 @@ int mg_setup_kernel_attributes(mg_context *) {
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out) {
     mg_frames_args a;
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
-    a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.pad = 0;
+    a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.nbuf = g->nbuf;
     {
         static const int dbg = getenv("MG_DEBUG_FLAGS") ? atoi(getenv("MG_DEBUG_FLAGS")) : 0;
         a.debug = dbg;
@@ -605,9 +648,9 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     }
     a.n_tiles = (int32_t)n_tiles;
     const bool lf = (ldt == MG_F64);
-    // two LDS buffers + three table sets + two float64 root images, one workgroup per CU
+    // nbuf ring slots (image + root outputs + tables), the float64 root image, the progress counters
     const int buf_bytes = (MG_NCAND * g->stride * 4 + 255) / 256 * 256;
-    const int lds = 2 * buf_bytes + 2 * MG_RO_BYTES + 2 * MG_TB_BYTES + MG_NCAND * (g->max_wi * p->nroot + 1) * 8;
+    const int lds = g->nbuf * (buf_bytes + MG_RO_BYTES + MG_TB_BYTES) + MG_NCAND * (g->max_wi * p->nroot + 1) * 8 + 64;
     if (lds != g->lds_bytes || lds > 160 * 1024) {
         mg_set_error("mg_back_project_frames: internal LDS sizing mismatch (%d vs %d)", lds, g->lds_bytes);
         return MG_ERR_UNSUPPORTED;

@@ -330,12 +330,12 @@ static int mg_round_stride(int nlocal) {
 
 // LDS of the persistent kernel: two buffers (coefficient image + float32 root outputs),
 // three per-sample table sets, two float64 root images.
-static int mg_lds_bytes(const mg_primitive *p, int stride, int wi) {
+static int mg_lds_bytes(const mg_primitive *p, int stride, int wi, int nbuf = 2) {
     int buf = (MG_NCAND * stride * 4 + 255) / 256 * 256;
-    int rout = 2 * MG_NCAND * MG_MAX_NT * 16;
-    int tabs = 2 * (MG_MAX_NT * 16 + MG_MAX_NT * 4 + MG_MAX_NT * 4 + MG_MAX_NT * 32);
+    int rout = MG_NCAND * MG_MAX_NT * 16;
+    int tabs = MG_MAX_NT * 16 + MG_MAX_NT * 4;
     int root = MG_NCAND * (wi * p->nroot + 1) * 8;
-    return 2 * buf + rout + tabs + root;
+    return nbuf * (buf + rout + tabs) + root + 64;
 }
 
 // Split the grid into chunks (runs of consecutive time samples) whose coefficient window
@@ -384,7 +384,10 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
     }
     g->stride = max_stride;
     g->max_wi = max_wi;
-    g->lds_bytes = mg_lds_bytes(p, max_stride, max_wi);
+    // a third ring slot lets the producers run a full unit ahead of the slowest consumer wave
+    g->nbuf = mg_lds_bytes(p, max_stride, max_wi, 3) <= budget1 ? 3 : 2;
+    if (const char *e = getenv("MG_NBUF")) g->nbuf = (atoi(e) == 3 && g->nbuf == 3) ? 3 : 2;   // bench ablation only
+    g->lds_bytes = mg_lds_bytes(p, max_stride, max_wi, g->nbuf);
     g->n_chunks = (int32_t)g->chunks.size();
     g->mfma_ok = g->lds_bytes <= budget1;
 }

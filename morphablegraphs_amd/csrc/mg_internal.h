@@ -88,6 +88,7 @@ struct mg_time_grid {
     int32_t stride = 0;      // floats per candidate in the LDS coefficient image
     int32_t max_wi = 0;
     int32_t lds_bytes = 0;   // dynamic LDS of the MFMA kernel for this grid
+    int32_t nbuf = 2;        // LDS ring depth of the MFMA kernel (3 when it fits)
     bool mfma_ok = false;
 };
 
