@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8192, help="candidates per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-launch", action="store_true",
+                    help="frames kernel and log-likelihood kernel as two launches instead of the fused step kernel")
     ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-interval", type=int, default=8,
                     help="bracket every n-th launch of a kernel with a HIP event pair inside the timed region")
@@ -110,8 +112,12 @@ def main():
     gathered = torch.empty((world * B,), dtype=torch.float32, device=gdev) if world > 1 else None
 
     def step():
-        prim.back_project_frames_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), path=_capi.MG_PATH_MFMA)
-        prim.gmm_log_prob_dev(S.data_ptr(), np.float32, B, L, logp.data_ptr(), np.float32)
+        if args.two_launch:
+            prim.back_project_frames_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), path=_capi.MG_PATH_MFMA)
+            prim.gmm_log_prob_dev(S.data_ptr(), np.float32, B, L, logp.data_ptr(), np.float32)
+        else:
+            # mg_step_frames_and_logp: one launch, the mixture is scored inside the frames kernel
+            prim.step_frames_and_logp_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), logp.data_ptr())
         if world > 1:
             dist.all_gather_into_tensor(gathered, logp if backend == "nccl" else logp.cpu())
 
@@ -174,8 +180,9 @@ def main():
         }
         if frames_n > 0:
             avg_ms = frames_ms / frames_n
-            # the frames kernel's own algorithmic bytes: latents + frames (+ E, mean, basis)
-            k_bytes = B * (4 * L + 4 * F * D) + 4 * (NB * D * L + NB * D + 4 * F)
+            # algorithmic bytes of the dominant kernel.  Fused step kernel: the whole step (latents, frames, log p,
+            # E, mean, basis, mixture constants); stand-alone frames kernel: latents + frames (+ E, mean, basis)
+            k_bytes = (B * (4 * L + 4 * F * D) + 4 * (NB * D * L + NB * D + 4 * F)) if args.two_launch else bytes_launch
             achieved = k_bytes / (avg_ms * 1e-3) / 1e9
             result["roofline"] = {
                 "bound": "hbm", "kernel": "mg_frames_ws_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -183,6 +190,7 @@ def main():
                 "traffic": pmc_traffic_bytes("mg_frames_ws_kernel") if B == 8192 else None,
                 "avg_kernel_ms": avg_ms, "launches_timed": frames_n, "event_interval": max(1, args.event_interval),
                 "algorithmic_bytes_per_launch": k_bytes,
+                "launches_per_step": 2 if args.two_launch else 1,
                 "gmm_kernel_avg_ms": (gmm_ms / gmm_n) if gmm_n else None,
                 "step_algorithmic_bytes": bytes_launch,
                 "step_achieved_GBps": bytes_launch / (elapsed / args.steps) / 1e9,

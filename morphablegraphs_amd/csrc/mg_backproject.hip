@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "mg_internal.h"
+#include "mg_gmm_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -95,6 +96,7 @@ extern "C" int mg_debug_dump_stamps(void) {
 // LDS: buf[nbuf] = image [16][stride] f32; ro[nbuf] = root outputs [16][MG_MAX_NT][4] f32; tb[nbuf] = w32
 // [MG_MAX_NT] float4 + image tap byte offsets [MG_MAX_NT] int; rs = float64 root image; prog = 16 counters.
 // -----------------------------------------------------------------------------------------
+#define MG_FUSE_MAX_KK 10   // fused mixture scoring: k-steps (4 latent components each) that fit the register budget
 #define MG_WS_NPW 4      // producer waves
 #define MG_WS_NCW 8      // consumer waves, two candidates each
 #define MG_WS_BLOCK (64 * (MG_WS_NPW + MG_WS_NCW))
@@ -119,6 +121,14 @@ __device__ __forceinline__ void mg_wait_producers(const mg_lds_int *prog, int ta
         const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
         const int m = min(min(v[0], v[1]), min(v[2], v[3]));
         if (__builtin_amdgcn_readfirstlane(m) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void mg_wait_counter(const mg_lds_int *ctr, int target) {
+    for (;;) {
+        const int v = *(const volatile mg_lds_int *)ctr;
+        if (__builtin_amdgcn_readfirstlane(v) >= target) break;
         __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
@@ -235,14 +245,72 @@ __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, co
 
 template <int KK, bool LAT_F64>
 __device__ __forceinline__ void mg_load_sfrag(float (&sfrag)[KK], const void *lat, const mg_unit &un, int64_t ld, int L, int cl, int g) {
+    typename mg_gmm_xt<LAT_F64>::type x[KK];
+    mg_gmm_load_x<KK, LAT_F64>(x, lat, un.b0, un.ncand, ld, L, cl, g);
 #pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        const int k = 4 * kk + g;
-        sfrag[kk] = (cl < un.ncand && k < L) ? (float)mg_load_lat<LAT_F64>(lat, (un.b0 + cl) * ld + k) : 0.0f;
+    for (int kk = 0; kk < KK; kk++) sfrag[kk] = (float)x[kk];
+}
+
+
+// The fused step kernel's mixture scoring: log p(s_b) for this workgroup's share of the candidates (at most two
+// 16-candidate tiles: the launcher fuses only then), run by the four producer waves after their last unit, while
+// the sweep waves drain the ring.  (Measured alternatives, all slower: by the sweep waves while the pipeline
+// fills -- the float64 MFMAs delay the first unit; by the producers when the ring first fills, whole or one
+// component per unit -- the mixture constants are read once per launch, miss L2 behind the store stream and
+// each round trip stalls the producer long enough to starve the sweep.)
+//  * mg_fused_gmm_terms: wave pw takes components pw, pw + 4, ... of both tiles (terms -> LDS); the loads of
+//    a component and of both latent tiles are all issued before the first MFMA (two components per round do
+//    not fit the register budget).
+//  * mg_fused_gmm_finish: wave b (0, 1) finishes tile b (log-sum-exp -> logp) once gdone[0..3] say that all
+//    terms are written.
+template <int KK, bool LAT_F64>
+__device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const double *__restrict__ gPpack,
+                                                   const double *__restrict__ gmP, const double *__restrict__ gcst,
+                                                   const void *__restrict__ lat, int64_t B, int64_t ld, int L, int n_tiles,
+                                                   int gK, int gJT, int pw, int lane) {
+    const int cl = lane & 15, g = lane >> 4;
+    mg_lds_f64 *gterms = (mg_lds_f64 *)(prog + 32);   // [2][K*16]
+    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x;
+    const int64_t gt1 = ((int64_t)blockIdx.x + 1) * n_tiles / gridDim.x;
+    if (gt0 < gt1) {
+        const bool has_b = gt0 + 1 < gt1;
+        typename mg_gmm_xt<LAT_F64>::type xa[KK], xb[KK];
+        {
+            const int64_t ba = gt0 * MG_NCAND, bb = (has_b ? gt0 + 1 : gt0) * MG_NCAND;
+            const int na = (int)((B - ba) < MG_NCAND ? (B - ba) : MG_NCAND);
+            const int nb = (int)((B - bb) < MG_NCAND ? (B - bb) : MG_NCAND);
+            mg_gmm_load_x<KK, LAT_F64>(xa, lat, ba, na, ld, L, cl, g);
+            mg_gmm_load_x<KK, LAT_F64>(xb, lat, bb, nb, ld, L, cl, g);
+        }
+        for (int k = pw; k < gK; k += MG_WS_NPW) {
+            mg_gmm_frag<KK> f;
+            mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl);
+            mg_gmm_apply_component(f, k, gJT, xa, gterms, cl, g);
+            if (has_b) mg_gmm_apply_component(f, k, gJT, xb, gterms + gK * 16, cl, g);
+        }
+    }
+    mg_publish(prog + 16, pw, lane, 1);   // gdone[pw]
+}
+
+__device__ __forceinline__ void mg_fused_gmm_finish(mg_lds_int *prog, float *__restrict__ logp, int64_t B, int n_tiles, int gK,
+                                                    int pw, int lane) {
+    mg_lds_int *gdone = prog + 16;
+    mg_lds_f64 *gterms = (mg_lds_f64 *)(prog + 32);   // [2][K*16]
+    mg_lds_f64 *gexps = gterms + 2 * gK * 16;          // [2][K*16]
+    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x;
+    const int64_t gt1 = ((int64_t)blockIdx.x + 1) * n_tiles / gridDim.x;
+    if (pw < 2 && gt0 + pw < gt1) {
+        mg_wait_producers(gdone, 1);   // all four producer waves have written their components' terms
+        const mg_lds_f64 *terms = gterms + pw * gK * 16;
+        mg_lds_f64 *exps = gexps + pw * gK * 16;
+        for (int e = lane; e < gK * 16; e += 64) exps[e] = mg_gmm_exp_entry(terms, gK, e);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t b0 = (gt0 + pw) * MG_NCAND;
+        if (lane < MG_NCAND && b0 + lane < B) logp[b0 + lane] = (float)mg_gmm_logsumexp(terms, exps, gK, lane);
     }
 }
 
-template <int KK, bool LAT_F64>
+template <int KK, bool LAT_F64, bool FUSE_GMM>
 __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const float *__restrict__ Epack,      // [RT][KK/2][64][2]
     const float *__restrict__ mean32,     // [RT*16]
@@ -254,7 +322,11 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const double *__restrict__ wtap,      // [n_chunks][2][2][64] banded tap weights as f64 MFMA A fragments
     const mg_chunk *__restrict__ chunks,
     float *__restrict__ out,              // (B,T,D)
-    const mg_frames_args a, const int chunk_stride_unused, const int buf_bytes) {
+    const double *__restrict__ gPpack,    // FUSE_GMM: precision-Cholesky fragments [K][JT][KK][64]
+    const double *__restrict__ gmP,       // FUSE_GMM: mu_k P_k [K][JT*16]
+    const double *__restrict__ gcst,      // FUSE_GMM: per-component constants [K]
+    float *__restrict__ logp,             // FUSE_GMM: (B) log p(s_b)
+    const mg_frames_args a, const int gK, const int gJT, const int buf_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -265,8 +337,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     unsigned char *ro_base = smem + nbuf * (size_t)buf_bytes;         // root outputs, one per ring slot
     unsigned char *tb_base = ro_base + nbuf * MG_RO_BYTES;            // per-sample tables, one per ring slot
     unsigned char *rs_base = tb_base + nbuf * MG_TB_BYTES;            // float64 root image (wave 0 only)
-    mg_lds_int *prog = (mg_lds_int *)(rs_base + (size_t)MG_NCAND * root_stride * 8);   // 16 progress counters
-    if (tid < 16) prog[tid] = 0;
+    mg_lds_int *prog = (mg_lds_int *)(rs_base + (size_t)MG_NCAND * root_stride * 8);   // 32 counters: progress, GMM
+    if (tid < 32) prog[tid] = 0;
     __syncthreads();
 
     const int64_t U = (int64_t)a.n_tiles * a.n_chunks;
@@ -281,6 +353,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     if (wave >= MG_WS_NPW) {
         // ================= consumers =================
         const int cj = wave - MG_WS_NPW;                  // candidates cj and cj + 8
+        MG_STAMP_DECL
         const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
         const int gl = nql + 1;                           // + the root lane
         const int rpi = 64 / gl;                          // samples per wave instruction
@@ -294,7 +367,6 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         const int lane_img = (d0 + a.cshift) * 4;         // byte offset of the lane's quad inside a basis row
         const int lane_out = fsub * D + d0;               // float offset inside a row group
         int slot = 0;
-        MG_STAMP_DECL
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
             const mg_unit un_prev = mg_unit_at(chunks, a, cur);
@@ -368,7 +440,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 float *lds_c = (float *)(smem + (size_t)slot * buf_bytes);
                 if (un.tile != cur_tile) {
                     cur_tile = un.tile;
-                    mg_load_sfrag<KK, LAT_F64>(sfrag, lat, un, a.ld, L, cl, g);
+                    int g_op = g;   // opaque: keeps the (loop-invariant) clamped indices from being hoisted and spilled
+                    asm volatile("" : "+v"(g_op));
+                    mg_load_sfrag<KK, LAT_F64>(sfrag, lat, un, a.ld, L, cl, g_op);
                 }
                 mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g);
                 MG_STAMP(2);
@@ -409,12 +483,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             double r_wt[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) r_wt[e] = wtap[((size_t)un.chunk * 4 + e) * 64 + lane];
-            double s64frag[KK];
-#pragma unroll
-            for (int kk = 0; kk < KK; kk++) {
-                const int k = 4 * kk + g;
-                s64frag[kk] = (cl < un.ncand && k < L) ? mg_load_lat<LAT_F64>(lat, (un.b0 + cl) * a.ld + k) : 0.0;
-            }
+            typename mg_gmm_xt<LAT_F64>::type s64frag[KK];   // widened to float64 at the MFMA
+            mg_gmm_load_x<KK, LAT_F64>(s64frag, lat, un.b0, un.ncand, a.ld, L, cl, g);
             if (a.debug & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MG_STAMP(1); }
             // up to 3 root tiles (8 basis functions x 3 channels = 24 rows, rr = i*nroot + d), chains
             // interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
@@ -451,7 +521,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 for (int q = 0; q < KH; q++)
 #pragma unroll
                     for (int t = 0; t < 3; t++)
-                        racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q], s64frag[h * KH + q], racc[t], 0, 0, 0);
+                        racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q], (double)s64frag[h * KH + q], racc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 3; t++) {
@@ -511,6 +581,10 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             MG_STAMP(4);
         }
         MG_STAMP_DUMP;
+    }
+    if (FUSE_GMM && wave < MG_WS_NPW) {
+        mg_fused_gmm_terms<KK, LAT_F64>(prog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane);
+        if (wave < 2) mg_fused_gmm_finish(prog, logp, a.B, a.n_tiles, gK, wave, lane);
     }
 }
 
@@ -598,41 +672,71 @@ __global__ __launch_bounds__(256) void mg_spline_eval_kernel(const double *coeff
 // -----------------------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------------------
-template <int KK>
-static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, const mg_frames_args &a,
-                           bool lat_f64, int buf_bytes, int lds, int grid) {
-    hipStream_t st = p->ctx->stream;
-    if (lat_f64)
-        hipLaunchKernelGGL((mg_frames_ws_kernel<KK, true>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
-    else
-        hipLaunchKernelGGL((mg_frames_ws_kernel<KK, false>), dim3(grid), dim3(MG_WS_BLOCK), lds, st, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out, a, 0, buf_bytes);
+template <int KK, bool LAT_F64, bool FUSE>
+static int mg_launch_ws_inst(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
+                             int buf_bytes, int lds, int grid) {
+    hipLaunchKernelGGL((mg_frames_ws_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_WS_BLOCK), lds, p->ctx->stream, p->d_Epack, p->d_mean32,
+                       p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out,
+                       p->d_gPpack, p->d_gmPpad, p->d_gconst, logp, a, p->K, (p->L + 15) / 16, buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
 
 template <int KK>
+static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
+                           bool lat_f64, int buf_bytes, int lds, int grid) {
+    if (logp) {
+        // fused instances exist for <= 40 components: beyond that the mixture fragments no longer fit the
+        // register budget next to the sweep (mg_frames_can_fuse_gmm refuses, so this is never reached)
+        if constexpr (KK <= MG_FUSE_MAX_KK)
+            return lat_f64 ? mg_launch_ws_inst<KK, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid)
+                           : mg_launch_ws_inst<KK, false, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid);
+        mg_set_error("mg_step_frames_and_logp: no fused kernel for %d components", p->L);
+        return MG_ERR_UNSUPPORTED;
+    }
+    return lat_f64 ? mg_launch_ws_inst<KK, true, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid)
+                   : mg_launch_ws_inst<KK, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid);
+}
+
+template <int KK>
 static int mg_set_attr_kk() {
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if constexpr (KK <= MG_FUSE_MAX_KK) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     return MG_OK;
 }
 
 int mg_setup_kernel_attributes(mg_context *) {
     int rc;
+#ifndef MG_ONLY_KK10
     if ((rc = mg_set_attr_kk<2>()) != MG_OK) return rc;
     if ((rc = mg_set_attr_kk<4>()) != MG_OK) return rc;
     if ((rc = mg_set_attr_kk<6>()) != MG_OK) return rc;
     if ((rc = mg_set_attr_kk<8>()) != MG_OK) return rc;
+#endif
     if ((rc = mg_set_attr_kk<10>()) != MG_OK) return rc;
+#ifndef MG_ONLY_KK10
     if ((rc = mg_set_attr_kk<12>()) != MG_OK) return rc;
     if ((rc = mg_set_attr_kk<14>()) != MG_OK) return rc;
     if ((rc = mg_set_attr_kk<16>()) != MG_OK) return rc;
+#endif
     return MG_OK;
 }
 
-int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out) {
+// LDS of the fused mixture scoring: two term buffers and two exp buffers of [K][16] float64
+static int mg_fused_gmm_lds(const mg_primitive *p) { return 4 * p->K * 16 * 8; }
+
+bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B) {
+    const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
+    const int64_t grid = std::min<int64_t>(n_tiles * g->n_chunks, p->ctx->n_cu);
+    return g->mfma_ok && p->d_gPpack != nullptr && p->K <= 16 && p->KK <= MG_FUSE_MAX_KK && g->lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 &&
+           n_tiles <= 2 * grid;   // the fused scoring handles at most two 16-candidate tiles per workgroup
+}
+
+int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp) {
     mg_frames_args a;
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
     a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.nbuf = g->nbuf;
@@ -650,21 +754,26 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     const bool lf = (ldt == MG_F64);
     // nbuf ring slots (image + root outputs + tables), the float64 root image, the progress counters
     const int buf_bytes = (MG_NCAND * g->stride * 4 + 255) / 256 * 256;
-    const int lds = g->nbuf * (buf_bytes + MG_RO_BYTES + MG_TB_BYTES) + MG_NCAND * (g->max_wi * p->nroot + 1) * 8 + 64;
-    if (lds != g->lds_bytes || lds > 160 * 1024) {
+    int lds = g->nbuf * (buf_bytes + MG_RO_BYTES + MG_TB_BYTES) + MG_NCAND * (g->max_wi * p->nroot + 1) * 8 + 128;
+    if (lds != g->lds_bytes || lds > 160 * 1024 || (logp && !mg_frames_can_fuse_gmm(p, g, B))) {
         mg_set_error("mg_back_project_frames: internal LDS sizing mismatch (%d vs %d)", lds, g->lds_bytes);
         return MG_ERR_UNSUPPORTED;
     }
+    if (logp) lds += mg_fused_gmm_lds(p);
     const int grid = (int)std::min<int64_t>(units, p->ctx->n_cu);
     switch (p->KK) {
-        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
-        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
-        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
-        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
-        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
-        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
-        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
-        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, a, lf, buf_bytes, lds, grid);
+#ifndef MG_ONLY_KK10
+        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+#endif
+        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+#ifndef MG_ONLY_KK10
+        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+#endif
         default: mg_set_error("mg_back_project_frames: MFMA path needs n_components <= 64"); return MG_ERR_UNSUPPORTED;
     }
 }

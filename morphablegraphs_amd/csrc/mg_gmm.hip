@@ -5,6 +5,7 @@
 // (reference morphablegraphs/motion_model/motion_primitive.py:126-144; formula twin
 //  morphablegraphs/motion_model/extended_mgrd_mixture_model.py:60-108).
 #include "mg_internal.h"
+#include "mg_gmm_device.h"
 
 #define MG_GMM_CANDS 64    // candidates per workgroup: one per lane
 #define MG_GMM_WAVES 8     // waves per workgroup: components are dealt round-robin to waves
@@ -83,7 +84,6 @@ __global__ __launch_bounds__(MG_GMM_CANDS *MG_GMM_WAVES) void mg_gmm_logp_kernel
 // sums over the column tiles, and the Mahalanobis term is finished by a wavefront
 // (butterfly) reduction over the 16 lanes that share the candidate rows.
 // -----------------------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct mg_gmm_mfma_args {
     int64_t B, ld;
@@ -97,88 +97,26 @@ __global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__r
                                                               const void *__restrict__ x, void *__restrict__ out,
                                                               const mg_gmm_mfma_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *lds_t = (double *)smem;          // [K][16] component terms
-    double *lds_e = lds_t + (size_t)a.K * 16;   // [K][16] exp(term - max)
+    mg_lds_f64 *lds_t = (mg_lds_f64 *)smem;   // [K][16] component terms
+    mg_lds_f64 *lds_e = lds_t + a.K * 16;     // [K][16] exp(term - max)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, g = lane >> 4;
     const int64_t b0 = (int64_t)blockIdx.x * 16;
     const int ncand = (int)((a.B - b0) < 16 ? (a.B - b0) : 16);
-    // A fragments: lane l supplies A[row = l & 15 (candidate)][k = 4*kk + (l >> 4)]
-    double xf[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) {
-        const int k = 4 * kk + g;
-        double v = 0.0;
-        if (cl < ncand && k < a.L) v = X_F64 ? ((const double *)x)[(b0 + cl) * a.ld + k] : (double)((const float *)x)[(b0 + cl) * a.ld + k];
-        xf[kk] = v;
-    }
-    constexpr int JTM = (KK + 3) / 4;   // column tiles of 16 for n_components <= 4 KK
+    typename mg_gmm_xt<X_F64>::type xf[KK];
+    mg_gmm_load_x<KK, X_F64>(xf, x, b0, ncand, a.ld, a.L, cl, g);
     for (int k = wave; k < a.K; k += 4) {
-        // all B fragments of this component first (P_k is upper triangular: tile jt needs k-steps < 4 (jt + 1)),
-        // then the column tiles' accumulator chains interleaved
-        double pf[JTM][KK];
-        f64x4 acc[JTM];
-#pragma unroll
-        for (int jt = 0; jt < JTM; jt++) {
-            const int jtc = jt < a.JT ? jt : a.JT - 1;
-            const double *pp = Ppack + (((size_t)k * a.JT + jtc) * KK) * 64 + lane;
-            constexpr int dummy = 0;
-            (void)dummy;
-#pragma unroll
-            for (int kk = 0; kk < KK; kk++)
-                if (kk < 4 * (jt + 1)) pf[jt][kk] = pp[kk * 64];
-            const double c0 = -mP[((size_t)k * a.JT + jtc) * 16 + cl];
-            acc[jt] = {c0, c0, c0, c0};
-        }
-#pragma unroll
-        for (int kk = 0; kk < KK; kk++)
-#pragma unroll
-            for (int jt = 0; jt < JTM; jt++)
-                if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], pf[jt][kk], acc[jt], 0, 0, 0);
-        double part[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int jt = 0; jt < JTM; jt++)
-            if (jt < a.JT) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) part[r] = fma(acc[jt][r], acc[jt][r], part[r]);
-            }
-        // C/D layout: col = lane & 15, row (candidate) = (lane >> 4) + 4*reg: reduce over the 16 columns
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            double v = part[r];
-            v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
-            v += __shfl_xor(v, 4, 64);
-            v += __shfl_xor(v, 8, 64);
-            part[r] = v;
-        }
-        if (cl == 0) {
-            const double ck = cst[k];
-#pragma unroll
-            for (int r = 0; r < 4; r++) lds_t[k * 16 + g + 4 * r] = ck - 0.5 * part[r];
-        }
+        mg_gmm_frag<KK> f;
+        mg_gmm_load_component<KK>(f, Ppack, mP, cst, k, a.JT, lane, cl);
+        mg_gmm_apply_component(f, k, a.JT, xf, lds_t, cl, g);
     }
     __syncthreads();
     // log-sum-exp: the K exponentials of a candidate in parallel, summed in component order
-    for (int e = tid; e < a.K * 16; e += 256) {
-        const int c = e & 15;
-        double vmax = -INFINITY;
-        for (int k = 0; k < a.K; k++) vmax = fmax(vmax, lds_t[k * 16 + c]);
-        lds_e[e] = (vmax == -INFINITY) ? 0.0 : exp(lds_t[e] - vmax);
-    }
+    for (int e = tid; e < a.K * 16; e += 256) lds_e[e] = mg_gmm_exp_entry(lds_t, a.K, e);
     __syncthreads();
     if (tid < ncand) {
-        double vmax = -INFINITY;
-        for (int k = 0; k < a.K; k++) vmax = fmax(vmax, lds_t[k * 16 + tid]);
-        double r;
-        if (vmax == -INFINITY) {
-            r = -INFINITY;
-        } else {
-            double acc = 0.0;
-            for (int k = 0; k < a.K; k++) acc += lds_e[k * 16 + tid];
-            r = log(acc) + vmax;
-        }
+        const double r = mg_gmm_logsumexp(lds_t, lds_e, a.K, tid);
         if (OUT_F64) ((double *)out)[b0 + tid] = r;
         else ((float *)out)[b0 + tid] = (float)r;
     }

@@ -1,0 +1,126 @@
+// Device-side pieces of the MFMA log-likelihood, shared by the stand-alone kernel (mg_gmm.hip)
+// and by the fused step kernel (mg_backproject.hip) so that both produce the same bits.
+// log p(x) = logsumexp_k [ cst_k - 0.5 |x P_k - mu_k P_k|^2 ]   (sklearn score_samples; reference
+// morphablegraphs/motion_model/motion_primitive.py:126-144).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+typedef double mg_f64x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) double mg_lds_f64;   // explicit LDS pointers: ds_* ops, 32-bit addresses
+
+// A/B fragments of a 16-candidate latent tile for the 16x16x4 MFMAs: lane l supplies
+// element [candidate = l & 15][k = 4*kk + (l >> 4)], 0 outside the tile / the latent dimension.
+// Kept in the latents' own type (float32 latents cost half the registers) and widened at the use.
+//  * every load is unconditional on a clamped in-bounds address and the zero is a select: a load under a lane
+//    condition compiles to branch + load + wait, i.e. KK serialized memory round trips per fragment;
+//  * KK = ceil(L/4) rounded up to even, so only the last two k-steps can reach past L: the others are
+//    immediate offsets from one row pointer (one address register pair per tile).
+template <bool X_F64> struct mg_gmm_xt { typedef double type; };
+template <> struct mg_gmm_xt<false> { typedef float type; };
+
+template <int KK, bool X_F64>
+__device__ __forceinline__ void mg_gmm_load_x(typename mg_gmm_xt<X_F64>::type (&xf)[KK], const void *x, int64_t b0, int ncand,
+                                              int64_t ld, int L, int cl, int g) {
+    typedef typename mg_gmm_xt<X_F64>::type T;
+    const int c = cl < ncand ? cl : ncand - 1;
+    const bool rok = cl < ncand;
+    const T *row = (const T *)x + (b0 + c) * ld;
+    const T *rowg = row + g;
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        if (kk < KK - 2) {
+            const T v = rowg[4 * kk];
+            xf[kk] = rok ? v : (T)0;
+        } else {
+            const int k = 4 * kk + g;
+            const T v = row[k < L ? k : L - 1];
+            xf[kk] = (rok && k < L) ? v : (T)0;
+        }
+    }
+}
+
+// One mixture component held in registers: B fragments of P_k (upper triangular: column tile jt needs only
+// the k-steps < 4 (jt + 1)), C-in = -mu_k P_k, the component's constant.
+template <int KK>
+struct mg_gmm_frag {
+    static constexpr int JTM = (KK + 3) / 4;   // column tiles of 16 for n_components <= 4 KK
+    double pf[JTM][KK];
+    double c0[JTM];
+    double cst;
+};
+
+template <int KK>
+__device__ __forceinline__ void mg_gmm_load_component(mg_gmm_frag<KK> &f,
+                                                      const double *__restrict__ Ppack,  // [K][JT][KK][64]
+                                                      const double *__restrict__ mP,     // [K][JT*16]
+                                                      const double *__restrict__ cst,    // [K]
+                                                      int k, int JT, int lane, int cl) {
+    constexpr int JTM = mg_gmm_frag<KK>::JTM;
+#pragma unroll
+    for (int jt = 0; jt < JTM; jt++) {
+        const int jtc = jt < JT ? jt : JT - 1;
+        const double *pp = Ppack + (((size_t)k * JT + jtc) * KK) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++)
+            if (kk < 4 * (jt + 1)) f.pf[jt][kk] = pp[kk * 64];
+        f.c0[jt] = -mP[((size_t)k * JT + jtc) * 16 + cl];
+    }
+    f.cst = cst[k];
+}
+
+// The component applied to a 16-candidate latent tile by one wave:
+// terms[k*16 + cand] = cst_k - 0.5 |x P_k - mu_k P_k|^2, the column tiles' accumulator chains interleaved.
+template <int KK, typename T>
+__device__ __forceinline__ void mg_gmm_apply_component(const mg_gmm_frag<KK> &f, int k, int JT, const T (&xf)[KK],
+                                                       mg_lds_f64 *terms, int cl, int g) {
+    constexpr int JTM = mg_gmm_frag<KK>::JTM;
+    mg_f64x4 acc[JTM];
+#pragma unroll
+    for (int jt = 0; jt < JTM; jt++) acc[jt] = {f.c0[jt], f.c0[jt], f.c0[jt], f.c0[jt]};
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+        for (int jt = 0; jt < JTM; jt++)
+            if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[kk], f.pf[jt][kk], acc[jt], 0, 0, 0);
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int jt = 0; jt < JTM; jt++)
+        if (jt < JT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[r] = fma(acc[jt][r], acc[jt][r], part[r]);
+        }
+    // C/D layout: col = lane & 15, row (candidate) = (lane >> 4) + 4*reg: reduce over the 16 columns
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double v = part[r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        part[r] = v;
+    }
+    if (cl == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) terms[k * 16 + g + 4 * r] = f.cst - 0.5 * part[r];
+    }
+}
+
+// exp(term - max over the components of the same candidate) of entry e = k*16 + cand
+__device__ __forceinline__ double mg_gmm_exp_entry(const mg_lds_f64 *terms, int K, int e) {
+    const int c = e & 15;
+    double vmax = -INFINITY;
+    for (int k = 0; k < K; k++) vmax = fmax(vmax, terms[k * 16 + c]);
+    return (vmax == -INFINITY) ? 0.0 : exp(terms[e] - vmax);
+}
+
+// log-sum-exp of candidate c: the exponentials summed in component order
+__device__ __forceinline__ double mg_gmm_logsumexp(const mg_lds_f64 *terms, const mg_lds_f64 *exps, int K, int c) {
+    double vmax = -INFINITY;
+    for (int k = 0; k < K; k++) vmax = fmax(vmax, terms[k * 16 + c]);
+    if (vmax == -INFINITY) return -INFINITY;
+    double acc = 0.0;
+    for (int k = 0; k < K; k++) acc += exps[k * 16 + c];
+    return log(acc) + vmax;
+}

@@ -335,7 +335,7 @@ static int mg_lds_bytes(const mg_primitive *p, int stride, int wi, int nbuf = 2)
     int rout = MG_NCAND * MG_MAX_NT * 16;
     int tabs = MG_MAX_NT * 16 + MG_MAX_NT * 4;
     int root = MG_NCAND * (wi * p->nroot + 1) * 8;
-    return nbuf * (buf + rout + tabs) + root + 64;
+    return nbuf * (buf + rout + tabs) + root + 128;
 }
 
 // Split the grid into chunks (runs of consecutive time samples) whose coefficient window
@@ -735,7 +735,7 @@ extern "C" int mg_back_project_frames(mg_primitive *p, const mg_time_grid *g, co
         use_mfma = g->mfma_ok && B >= 8;
     }
     mg_prof_begin(p->ctx, 0);
-    rc = use_mfma ? mg_launch_frames_mfma(p, g, lat, dt, B, ld, out) : mg_launch_frames_direct(p, g, lat, dt, B, ld, out, false);
+    rc = use_mfma ? mg_launch_frames_mfma(p, g, lat, dt, B, ld, out, nullptr) : mg_launch_frames_direct(p, g, lat, dt, B, ld, out, false);
     mg_prof_end(p->ctx, 0);
     return rc;
 }
@@ -763,7 +763,7 @@ extern "C" int mg_back_project_coeffs(mg_primitive *p, const void *lat, int dt, 
     MG_REQUIRE(out != nullptr, "mg_back_project_coeffs: coeffs pointer is NULL");
     const mg_time_grid *g = p->coeff_grid;
     if (odt == MG_F64) return mg_launch_frames_direct(p, g, lat, dt, B, ld, out, true);
-    if (g->mfma_ok && B >= 8) return mg_launch_frames_mfma(p, g, lat, dt, B, ld, (float *)out);
+    if (g->mfma_ok && B >= 8) return mg_launch_frames_mfma(p, g, lat, dt, B, ld, (float *)out, nullptr);
     return mg_launch_frames_direct(p, g, lat, dt, B, ld, out, false);
 }
 
@@ -907,11 +907,23 @@ extern "C" int mg_argmin_first(mg_context *ctx, const void *v, int dt, int64_t n
 // slower: 150 vs 142 us per step -- its f64 MFMAs steal VALU issue from the store sweep.)
 extern "C" int mg_step_frames_and_logp(mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld,
                                        float *frames, float *logp) {
-    mg_context *ctx = p ? p->ctx : nullptr;
-    if (ctx) mg_prof_begin(ctx, 6);
-    int rc = mg_back_project_frames(p, nullptr, lat, dt, B, ld, frames, MG_PATH_AUTO);
+    int rc = mg_check_latents("mg_step_frames_and_logp", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    mg_context *ctx = p->ctx;
+    const mg_time_grid *g = p->canonical;
+    if (B >= 8 && g->T > 0 && frames && logp && mg_frames_can_fuse_gmm(p, g, B)) {
+        // one launch: the mixture is scored by the sweep waves while the pipeline of the frames kernel fills
+        mg_prof_begin(ctx, 6);
+        mg_prof_begin(ctx, 0);
+        rc = mg_launch_frames_mfma(p, g, lat, dt, B, ld, frames, logp);
+        mg_prof_end(ctx, 0);
+        mg_prof_end(ctx, 6);
+        return rc;
+    }
+    mg_prof_begin(ctx, 6);
+    rc = mg_back_project_frames(p, nullptr, lat, dt, B, ld, frames, MG_PATH_AUTO);
     if (rc == MG_OK) rc = mg_gmm_log_prob(p, lat, dt, B, ld, logp, MG_F32);
-    if (ctx) mg_prof_end(ctx, 6);
+    mg_prof_end(ctx, 6);
     return rc;
 }
 

@@ -142,6 +142,59 @@ def test_frames_repeated_launches_are_bitwise_stable(ctx):
     prim.close()
 
 
+def _fused_step(ctx, prim, S, F, D):
+    B, L = S.shape
+    d_S = ctx.upload(S)
+    d_frames = ctx.malloc(max(B * F * D * 4, 4))
+    d_logp = ctx.malloc(max(B * 4, 4))
+    prim.step_frames_and_logp_dev(d_S, S.dtype, B, L, d_frames, d_logp)
+    ctx.synchronize()
+    frames = ctx.download(d_frames, (B, F, D), np.float32)
+    logp = ctx.download(d_logp, (B,), np.float32)
+    for buf in (d_S, d_frames, d_logp):
+        buf.free()
+    return frames, logp
+
+
+@pytest.mark.parametrize("B", [8, 16, 17, 255, 1000, 4099])
+def test_fused_step_matches_separate_calls_bit_for_bit(ctx, B):
+    """mg_step_frames_and_logp scores the mixture inside the frames kernel (the sweep waves do it while the
+    pipeline fills): frames must equal the oracle's f32 model and log p must equal the stand-alone log-likelihood
+    kernel bit for bit, for float32 and float64 latents, ragged and multi-tile batches, twice in a row."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(1000 + B)
+    for dtype in (np.float32, np.float64):
+        S = rng.standard_normal((B, 40)).astype(dtype)
+        model = cp.frames_f32model(S.astype(np.float64))
+        lp_sep = prim.gmm_log_prob(S, dtype=np.float32)
+        ref = cp.log_prob_f64(S.astype(np.float64))
+        for rep in range(2):
+            frames, logp = _fused_step(ctx, prim, S, 156, 79)
+            np.testing.assert_array_equal(_bits(frames), _bits(model), err_msg="B=%d %s rep=%d" % (B, dtype, rep))
+            np.testing.assert_array_equal(_bits(logp), _bits(lp_sep), err_msg="B=%d %s rep=%d" % (B, dtype, rep))
+            np.testing.assert_allclose(logp, ref, rtol=3e-7, atol=1e-6)
+    prim.close()
+
+
+def test_fused_step_golden_shapes(ctx, golden_case):
+    """Every golden primitive through the step entry point (fused where the shape allows it, two launches
+    otherwise): frames against the reference within the north-star tolerance, log p against the reference."""
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    F, D = g["frames"].shape[1], g["frames"].shape[2]
+    for reps in (1, 5):   # 4 samples: two launches (direct path); 20 samples: one fused launch where supported
+        S = np.ascontiguousarray(np.tile(g["S"], (reps, 1)))
+        ref = np.tile(g["frames"], (reps, 1, 1))
+        ref_lp = np.tile(g["logp_S"], reps)
+        frames, logp = _fused_step(ctx, prim, S, F, D)
+        err = np.abs(frames.astype(np.float64) - ref)
+        assert np.all(err <= pose_tol(ref)), (name, reps, float((err / pose_tol(ref)).max()))
+        np.testing.assert_allclose(logp, ref_lp, rtol=3e-7, atol=1e-5 * max(1.0, float(np.abs(ref_lp).max())))
+    prim.close()
+
+
 def test_short_last_window_ignores_stale_lds(ctx):
     """The last chunk of the walk grid has a 6-row window; the root-tap MFMA must not pick up stale LDS (a previous
     launch's bytes) from rows 6-7 of the float64 root image -- 0 * NaN would poison the root channels.  A launch with

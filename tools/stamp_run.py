@@ -7,7 +7,11 @@ prim = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
 B = 8192
 S = ctx.upload(np.random.default_rng(0).standard_normal((B, 40)).astype(np.float32))
 out = ctx.malloc(B * 156 * 79 * 4)
+logp = ctx.malloc(B * 4)
 for _ in range(5):
-    prim.back_project_frames_dev(S, np.float32, B, 40, out, path=_capi.MG_PATH_MFMA)
+    if os.environ.get("FUSED"):
+        prim.step_frames_and_logp_dev(S, np.float32, B, 40, out, logp)
+    else:
+        prim.back_project_frames_dev(S, np.float32, B, 40, out, path=_capi.MG_PATH_MFMA)
 ctx.synchronize()
 _capi.load_library().mg_debug_dump_stamps()
