@@ -56,8 +56,8 @@ def algorithmic_bytes(prim_shape, B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=8192, help="candidates per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-launch", action="store_true",
