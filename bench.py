@@ -107,21 +107,40 @@ def main():
                                  np.array(data["gmm_covars"]), rs)[0].astype(np.float32)
     S = torch.from_numpy(S_host).to(dev)
     frames = torch.empty((B, F, D), dtype=torch.float32, device=dev)
-    logp = torch.empty((B,), dtype=torch.float32, device=dev)
+    # scores and gathered scores are double buffered: the all-gather of step i runs on RCCL's stream while the
+    # kernel of step i+1 runs on ours; step i+2 first waits (stream-side) for gather i to release its buffers
+    logps = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(2)]
+    logp = logps[0]
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = torch.empty((world * B,), dtype=torch.float32, device=gdev) if world > 1 else None
+    gathereds = [torch.empty((world * B,), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
+    gathered = gathereds[0] if world > 1 else None
+    works = [None, None]
+    step_no = [0]
 
     def step():
+        b = step_no[0] & 1
+        step_no[0] += 1
+        lp = logps[b]
+        if works[b] is not None:
+            works[b].wait()
+            works[b] = None
         if args.two_launch:
             prim.back_project_frames_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), path=_capi.MG_PATH_MFMA)
-            prim.gmm_log_prob_dev(S.data_ptr(), np.float32, B, L, logp.data_ptr(), np.float32)
+            prim.gmm_log_prob_dev(S.data_ptr(), np.float32, B, L, lp.data_ptr(), np.float32)
         else:
             # mg_step_frames_and_logp: one launch, the mixture is scored inside the frames kernel
-            prim.step_frames_and_logp_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), logp.data_ptr())
+            prim.step_frames_and_logp_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), lp.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, logp if backend == "nccl" else logp.cpu())
+            if backend == "nccl":
+                works[b] = dist.all_gather_into_tensor(gathereds[b], lp, async_op=True)
+            else:
+                dist.all_gather_into_tensor(gathereds[b], lp.cpu())
 
     def fence():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -175,7 +194,8 @@ def main():
             "config": {"workload": "walk primitive L=40 F=156 D=79 NB=31 GMM k=8, batch=%d candidates/GPU "
                                    "(BASELINE.json configs[%d])" % (B, 1 if world == 1 else 3),
                        "candidates_per_gpu": B, "global_candidates": world * B,
-                       "collective": ("all_gather(logp) per step, backend %s" % backend) if world > 1 else "none",
+                       "collective": ("all_gather(logp) every step (double-buffered: gather i overlaps the kernel of step i+1), "
+                                      "backend %s" % backend) if world > 1 else "none",
                        "sharding": "contiguous candidate blocks, constants replicated"},
         }
         if frames_n > 0:
