@@ -185,6 +185,12 @@ int mg_spline_evaluate(mg_primitive *prim, const mg_time_grid *grid, const doubl
 int mg_gmm_log_prob(mg_primitive *prim, const void *x_dev, int x_dtype, int64_t n_samples, int64_t ld,
                     void *logp_dev, int out_dtype);
 
+/* log_likelihood_jac (reference optimization/objective_functions.py:95-107, inlined again at :190-206):
+ * sum_k N_k(x) w_k Sigma_k^-1 (x - mu_k) / p(x) = -grad log p(x), float64; rows where the reference's
+ * denominator exp(score(x)) underflows to 0 are all ones, as there.  jac_dev (n_samples, n_components). */
+int mg_gmm_log_prob_jac(mg_primitive *prim, const void *x_dev, int x_dtype, int64_t n_samples, int64_t ld,
+                        double *jac_dev);
+
 /* GaussianMixture.sample on the device (reference motion_primitive.py:182-189):
  * Philox4x32-10 + Cholesky; rows grouped by component like sklearn, but NOT
  * bit-compatible with sklearn's Mersenne stream (validated distributionally).
@@ -203,6 +209,13 @@ void mg_constraint_set_destroy(mg_constraint_set *cs);
 int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
                          const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,
                          void *errors_dev, int out_dtype);
+
+/* MotionPrimitiveConstraints.get_residual_vector (reference motion_primitive_constraints.py:124-144) for the
+ * same root-joint keyframe constraints: residuals_dev (n_samples, n_constraints) float64 row-major, entry
+ * [b][c] = weight_c * error_c(sample b); feeds the batched forms of obj_spatial_error_residual_vector[_and_
+ * naturalness] (reference optimization/objective_functions.py:209-267). */
+int mg_score_constraint_residuals(mg_primitive *prim, const mg_constraint_set *cs, const void *latents_dev,
+                                  int latent_dtype, int64_t n_samples, int64_t ld, double *residuals_dev);
 
 /* The argmin rule of evaluate_samples_using_constraints
  * (reference motion_primitive_generator.py:251-257): FIRST strict minimum, NaN never
@@ -232,6 +245,10 @@ int mg_gmm_sample_host(mg_primitive *prim, int64_t n_samples, const int64_t *cou
                        void *x, int x_dtype, int64_t ld, int32_t *component);
 int mg_score_constraints_host(mg_primitive *prim, const mg_constraint_set *cs, const void *latents,
                               int latent_dtype, int64_t n_samples, int64_t ld, void *errors, int out_dtype);
+int mg_score_constraint_residuals_host(mg_primitive *prim, const mg_constraint_set *cs, const void *latents,
+                                       int latent_dtype, int64_t n_samples, int64_t ld, double *residuals);
+int mg_gmm_log_prob_jac_host(mg_primitive *prim, const void *x, int x_dtype, int64_t n_samples, int64_t ld,
+                             double *jac);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = [
     "mg_score_constraints", "mg_argmin_first", "mg_argmin_first_dev", "mg_step_frames_and_logp",
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
+    "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
+    "mg_gmm_log_prob_jac_host",
 ]
 
 
@@ -117,6 +119,10 @@ def load_library(path=None):
         "mg_gmm_log_prob_host": [vp, vp, i32, i64, i64, vp, i32],
         "mg_gmm_sample_host": [vp, i64, vp, u64, vp, i32, i64, vp],
         "mg_score_constraints_host": [vp, vp, vp, i32, i64, i64, vp, i32],
+        "mg_score_constraint_residuals": [vp, vp, vp, i32, i64, i64, vp],
+        "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
+        "mg_score_constraint_residuals_host": [vp, vp, vp, i32, i64, i64, vp],
+        "mg_gmm_log_prob_jac_host": [vp, vp, i32, i64, i64, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -455,6 +461,23 @@ class Primitive(object):
         _check(self.lib.mg_score_constraints_host(self.handle, cset.handle, S.ctypes.data_as(C.c_void_p), _dtype_code(S),
                                                   S.shape[0], S.shape[1], out.ctypes.data_as(C.c_void_p),
                                                   _dtype_code(out)))
+        return out
+
+    def score_constraint_residuals(self, cset, S):
+        """(n_samples, n_constraints) float64: weight_c * error_c per sample (get_residual_vector, batched)."""
+        S = _latents(S)
+        out = np.empty((S.shape[0], cset.n), dtype=np.float64)
+        _check(self.lib.mg_score_constraint_residuals_host(self.handle, cset.handle, S.ctypes.data_as(C.c_void_p),
+                                                           _dtype_code(S), S.shape[0], S.shape[1],
+                                                           out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def gmm_log_prob_jac(self, X):
+        """(n_samples, n_components) float64: the reference's log_likelihood_jac (= -grad log p) per row."""
+        X = _latents(X)
+        out = np.empty((X.shape[0], self.n_components), dtype=np.float64)
+        _check(self.lib.mg_gmm_log_prob_jac_host(self.handle, X.ctypes.data_as(C.c_void_p), _dtype_code(X), X.shape[0],
+                                                 X.shape[1], out.ctypes.data_as(C.c_void_p)))
         return out
 
     # ---- device-pointer entry points (no copies, asynchronous on the context stream) ----------

@@ -77,6 +77,108 @@ __global__ __launch_bounds__(MG_GMM_CANDS *MG_GMM_WAVES) void mg_gmm_logp_kernel
 }
 
 // -----------------------------------------------------------------------------------------
+// log_likelihood_jac (reference morphablegraphs/motion_generator/optimization/objective_functions.py:95-107):
+//   jac(s) = sum_k N(s | mu_k, Sigma_k) w_k Sigma_k^-1 (s - mu_k) / p(s)          (= -grad log p(s))
+// evaluated as sum_k r_k P_k y_k with y_k = (s - mu_k) P_k and r_k = exp(term_k - log p(s)), which is the same
+// ratio without the reference's separate underflow of numerator and denominator; where the reference's
+// denominator exp(score(s)) underflows to 0 it returns ones, and so does this kernel.
+// One workgroup = 16 candidates; y for all components in LDS; float64 throughout.
+// -----------------------------------------------------------------------------------------
+#define MG_JAC_CANDS 16
+template <bool X_F64>
+__global__ __launch_bounds__(256) void mg_gmm_jac_kernel(mg_gmm_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = a.L, K = a.K;
+    double *lds_x = (double *)smem;                             // [16][L]
+    double *lds_y = lds_x + MG_JAC_CANDS * L;                   // [K][16][L]
+    double *lds_t = lds_y + (size_t)K * MG_JAC_CANDS * L;       // [K][16] terms, then responsibilities
+    double *lds_lp = lds_t + K * MG_JAC_CANDS;                  // [16] log p
+    const int tid = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * MG_JAC_CANDS;
+    const int ncand = (int)((a.B - b0) < MG_JAC_CANDS ? (a.B - b0) : MG_JAC_CANDS);
+    for (int e = tid; e < MG_JAC_CANDS * L; e += 256) {
+        const int c = e / L, i = e - c * L;
+        double v = 0.0;
+        if (c < ncand) v = X_F64 ? ((const double *)a.x)[(b0 + c) * a.ld + i] : (double)((const float *)a.x)[(b0 + c) * a.ld + i];
+        lds_x[e] = v;
+    }
+    __syncthreads();
+    // y[k][c][j] = sum_{i <= j} x[c][i] P_k[i][j] - (mu_k P_k)[j]   (P_k upper triangular, column j contiguous)
+    for (int e = tid; e < K * MG_JAC_CANDS * L; e += 256) {
+        const int j = e % L, kc = e / L, c = kc % MG_JAC_CANDS, k = kc / MG_JAC_CANDS;
+        const double *col = a.P + ((size_t)k * L + j) * L;
+        const double *xr = lds_x + c * L;
+        double y = -a.mP[(size_t)k * L + j];
+        for (int i = 0; i <= j; i++) y = fma(xr[i], col[i], y);
+        lds_y[e] = y;
+    }
+    __syncthreads();
+    for (int e = tid; e < K * MG_JAC_CANDS; e += 256) {
+        const double *yr = lds_y + (size_t)e * L;
+        double maha = 0.0;
+        for (int j = 0; j < L; j++) maha = fma(yr[j], yr[j], maha);
+        lds_t[e] = a.cst[e / MG_JAC_CANDS] - 0.5 * maha;
+    }
+    __syncthreads();
+    if (tid < MG_JAC_CANDS) {
+        double vmax = -INFINITY;
+        for (int k = 0; k < K; k++) vmax = fmax(vmax, lds_t[k * MG_JAC_CANDS + tid]);
+        double lp = -INFINITY;
+        if (vmax != -INFINITY) {
+            double acc = 0.0;
+            for (int k = 0; k < K; k++) acc += exp(lds_t[k * MG_JAC_CANDS + tid] - vmax);
+            lp = log(acc) + vmax;
+        }
+        lds_lp[tid] = lp;
+    }
+    __syncthreads();
+    for (int e = tid; e < K * MG_JAC_CANDS; e += 256) {
+        const double lp = lds_lp[e % MG_JAC_CANDS];
+        lds_t[e] = (lp == -INFINITY) ? 0.0 : exp(lds_t[e] - lp);   // responsibility r_k
+    }
+    __syncthreads();
+    // jac[c][i] = sum_k r[k][c] sum_{j >= i} P_k[i][j] y[k][c][j]
+    for (int e = tid; e < MG_JAC_CANDS * L; e += 256) {
+        const int c = e / L, i = e - c * L;
+        if (c >= ncand) continue;
+        double g;
+        if (exp(lds_lp[c]) == 0.0) {
+            g = 1.0;   // the reference: denominator == 0 -> np.ones(s.shape)
+        } else {
+            g = 0.0;
+            for (int k = 0; k < K; k++) {
+                const double *yr = lds_y + ((size_t)k * MG_JAC_CANDS + c) * L;
+                const double *Pk = a.P + (size_t)k * L * L;
+                double z = 0.0;
+                for (int j = i; j < L; j++) z = fma(Pk[(size_t)j * L + i], yr[j], z);
+                g = fma(lds_t[k * MG_JAC_CANDS + c], z, g);
+            }
+        }
+        ((double *)a.out)[(b0 + c) * L + i] = g;
+    }
+}
+
+int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out) {
+    mg_gmm_args a;
+    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
+    const int64_t grid = (B + MG_JAC_CANDS - 1) / MG_JAC_CANDS;
+    const size_t lds = ((size_t)MG_JAC_CANDS * p->L * (1 + p->K) + (size_t)p->K * MG_JAC_CANDS + MG_JAC_CANDS) * 8;
+    if (lds > 150 * 1024 || grid > 0x7fffffff) {
+        mg_set_error("mg_gmm_log_prob_jac: n_components %d x n_gmm %d too large for the LDS-staged kernel", p->L, p->K);
+        return MG_ERR_UNSUPPORTED;
+    }
+    if (lds > 64 * 1024) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipStream_t st = p->ctx->stream;
+    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_jac_kernel<true>), dim3((int)grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((mg_gmm_jac_kernel<false>), dim3((int)grid), dim3(256), lds, st, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// -----------------------------------------------------------------------------------------
 // MFMA variant (n_components <= 64): one workgroup = 16 candidates, one wave = one mixture
 // component at a time.  Y = X P_k - mu_k P_k by v_mfma_f64_16x16x4_f64: A = the latent tile
 // (registers), B = precision-Cholesky fragments streamed from L2 (only the k-steps at or above

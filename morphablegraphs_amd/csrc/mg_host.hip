@@ -876,8 +876,33 @@ extern "C" int mg_score_constraints(mg_primitive *p, const mg_constraint_set *cs
     if (B == 0) return MG_OK;
     MG_REQUIRE(out != nullptr, "mg_score_constraints: output pointer is NULL");
     mg_prof_begin(p->ctx, 2);
-    rc = mg_launch_score(p, cs, lat, dt, B, ld, out, odt);
+    rc = mg_launch_score(p, cs, lat, dt, B, ld, out, odt, nullptr);
     mg_prof_end(p->ctx, 2);
+    return rc;
+}
+
+extern "C" int mg_score_constraint_residuals(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt,
+                                             int64_t B, int64_t ld, double *res) {
+    int rc = mg_check_latents("mg_score_constraint_residuals", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(cs && cs->prim == p, "mg_score_constraint_residuals: constraint set is NULL or belongs to another primitive");
+    if (B == 0 || cs->n == 0) return MG_OK;
+    MG_REQUIRE(res != nullptr, "mg_score_constraint_residuals: output pointer is NULL");
+    mg_prof_begin(p->ctx, 2);
+    rc = mg_launch_score(p, cs, lat, dt, B, ld, nullptr, MG_F64, res);
+    mg_prof_end(p->ctx, 2);
+    return rc;
+}
+
+extern "C" int mg_gmm_log_prob_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *jac) {
+    int rc = mg_check_latents("mg_gmm_log_prob_jac", p, x, xdt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(p->K > 0, "mg_gmm_log_prob_jac: primitive has no mixture");
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(jac != nullptr, "mg_gmm_log_prob_jac: output pointer is NULL");
+    mg_prof_begin(p->ctx, 1);
+    rc = mg_launch_gmm_jac(p, x, xdt, B, ld, jac);
+    mg_prof_end(p->ctx, 1);
     return rc;
 }
 
@@ -1022,6 +1047,26 @@ extern "C" int mg_gmm_sample_host(mg_primitive *p, int64_t n, const int64_t *cou
     (void)mg_device_free(p->ctx, dx);
     (void)mg_device_free(p->ctx, dc);
     return rc;
+}
+extern "C" int mg_score_constraint_residuals_host(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt,
+                                                  int64_t B, int64_t ld, double *res) {
+    int rc = mg_check_latents("mg_score_constraint_residuals_host", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(cs && cs->prim == p, "mg_score_constraint_residuals_host: constraint set is NULL or belongs to another primitive");
+    int64_t ob = B * (int64_t)cs->n * 8;
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, lat, B * ld * (int64_t)mg_dt_size(dt), ob)) != MG_OK) return rc;
+    if ((rc = mg_score_constraint_residuals(p, cs, io.d_in, dt, B, ld, (double *)io.d_out)) != MG_OK) return rc;
+    return io.finish(res, ob);
+}
+extern "C" int mg_gmm_log_prob_jac_host(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *jac) {
+    int rc = mg_check_latents("mg_gmm_log_prob_jac_host", p, x, xdt, B, ld);
+    if (rc != MG_OK) return rc;
+    int64_t ob = B * (int64_t)p->L * 8;
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, x, B * ld * (int64_t)mg_dt_size(xdt), ob)) != MG_OK) return rc;
+    if ((rc = mg_gmm_log_prob_jac(p, io.d_in, xdt, B, ld, (double *)io.d_out)) != MG_OK) return rc;
+    return io.finish(jac, ob);
 }
 extern "C" int mg_score_constraints_host(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt,
                                          int64_t B, int64_t ld, void *errors, int odt) {

@@ -11,7 +11,8 @@ struct mg_score_args {
     const double *bias;   // [n][nch]      mean frame at t_c
     const double *par;    // [n][8]        type, weight, target[3], ref_dir[3]
     const void *lat;
-    void *out;
+    void *out;            // (B) summed error, or NULL
+    double *res;          // (B, n) weighted residual of every constraint, or NULL
     int64_t B, ld;
     int32_t n, nch, L;
 };
@@ -61,7 +62,9 @@ __global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
                 double t = par[2 + i];
                 if (t == t) ds += (t - fr[i]) * (t - fr[i]);
             }
-            err += par[1] * sqrt(ds);
+            const double e = par[1] * sqrt(ds);
+            err += e;
+            if (a.res) a.res[(b0 + tid) * a.n + c] = e;
         } else {
             // heading = xz of (rotation of the root quaternion (w,x,y,z)) applied to ref_dir
             const double qw = fr[3], qx = fr[4], qy = fr[5], qz = fr[6];
@@ -75,15 +78,20 @@ __global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
             const double mx = px / mn, mz = pz / mn;
             double cosang = (tx * mx + tz * mz) / (sqrt(tx * tx + tz * tz) * sqrt(mx * mx + mz * mz));
             cosang = fmin(1.0, fmax(cosang, -1.0));
-            err += par[1] * fabs(acos(cosang) * (180.0 / M_PI));
+            const double e = par[1] * fabs(acos(cosang) * (180.0 / M_PI));
+            err += e;
+            if (a.res) a.res[(b0 + tid) * a.n + c] = e;
         }
     }
-    if (OUT_F64) ((double *)a.out)[b0 + tid] = err;
-    else ((float *)a.out)[b0 + tid] = (float)err;
+    if (a.out) {
+        if (OUT_F64) ((double *)a.out)[b0 + tid] = err;
+        else ((float *)a.out)[b0 + tid] = (float)err;
+    }
 }
 
-int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt) {
+int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res) {
     mg_score_args a;
+    a.res = res;
     a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
     size_t lds = (size_t)256 * (p->L + 1) * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_score_constraints: n_components %d too large", p->L); return MG_ERR_UNSUPPORTED; }

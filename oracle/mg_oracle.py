@@ -153,6 +153,28 @@ def gmm_log_prob(X, weights, means, prec_chol):
     return logsumexp_rows(gmm_component_log_prob(X, weights, means, prec_chol))
 
 
+def gmm_log_likelihood_jac(s, weights, means, covars, prec_chol):
+    """log_likelihood_jac restated line by line
+    (reference morphablegraphs/motion_generator/optimization/objective_functions.py:95-107; the same code is
+    inlined in obj_spatial_error_sum_and_naturalness_jac, :190-206):
+        numerator = sum_i exp(logN_i(s)) * w_i * inv(cov_i) @ (s - mean_i);  denominator = exp(score(s))
+        return numerator / denominator  if denominator != 0 else ones
+    i.e. MINUS the gradient of log p(s).  PARITY UNPINNED against the reference's own run: its module imports
+    anim_utils (absent) and reads pre-0.18 sklearn attribute names; pinned instead by the finite-difference
+    identity jac == -d/ds score_samples(s) on the golden mixtures (tests/test_oracle_golden.py)."""
+    s = np.asarray(s, dtype=np.float64)
+    K, L = means.shape
+    numerator = np.zeros(L)
+    for i in range(K):
+        y = (s - means[i]) @ prec_chol[i]
+        log_n = -0.5 * (L * math.log(2.0 * math.pi) + np.dot(y, y)) + np.sum(np.log(np.diagonal(prec_chol[i])))
+        numerator += np.exp(log_n) * weights[i] * np.dot(np.linalg.inv(covars[i]), (s - means[i]))
+    denominator = np.exp(gmm_log_prob(s[None, :], weights, means, prec_chol)[0])
+    if denominator != 0:
+        return numerator / denominator
+    return np.ones(s.shape)
+
+
 def gmm_sample(n_samples, weights, means, covars, rng):
     """sklearn GaussianMixture.sample restated (motion_primitive.py:189):
     counts = multinomial(n, w); rows grouped by component, not shuffled."""
@@ -271,6 +293,25 @@ class OraclePrimitive(object):
         return gmm_sample(n_samples, self.weights, self.means, self.covars, rng)[0]
 
     # motion_primitive_constraints.py:100-122 restricted to the FK-free constraints
+    def keyframe_residuals(self, S, constraints):
+        """MotionPrimitiveConstraints.get_residual_vector (motion_primitive_constraints.py:124-144) for root-joint
+        keyframe constraints: (n_samples, n_constraints), entry = weight_factor * error."""
+        S = np.atleast_2d(S)
+        out = np.zeros((S.shape[0], len(constraints)))
+        for b in range(S.shape[0]):
+            coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
+            for ci, c in enumerate(constraints):
+                frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
+                if c["type"] == "position":
+                    out[b, ci] = c["weight"] * point_distance(c["target"], frame[:3])
+                else:
+                    out[b, ci] = c["weight"] * direction_2d_error(c["target"], frame[3:7], c.get("ref_dir", (0, 0, 1)))
+        return out
+
+    def log_likelihood_jac(self, S):
+        S = np.atleast_2d(np.asarray(S, dtype=np.float64))
+        return np.array([gmm_log_likelihood_jac(s, self.weights, self.means, self.covars, self.prec_chol) for s in S])
+
     def keyframe_errors(self, S, constraints):
         """constraints: list of dicts {"type": "position"|"direction", "t": float,
         "weight": w, "target": [x|None,y|None,z|None] or [dx, dz]}.  Root joint only."""

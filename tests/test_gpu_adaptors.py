@@ -205,3 +205,65 @@ def test_graph_node_call_sites():
     S2 = node.sample_low_dimensional_vectors(512)
     ref = cp.keyframe_errors_f64(S2, np.array([[0, 155.0, 1.0, 20.0, np.nan, 10.0, 0, 0]]))
     assert abs(err - ref.min()) <= 1e-9 and np.array_equal(best, S2[int(np.argmin(ref))])
+
+
+def test_batched_objective_functions_match_the_reference_formulas():
+    """objective_functions.py:95-267 batched on the GPU against the oracle's line-by-line restatement: residual
+    vectors, error sums, naturalness term, analytic mixture Jacobian, forward-difference kinematic Jacobian."""
+    from morphablegraphs_amd import objective_functions as of
+    from oracle import mg_oracle as orc
+    data = synthetic.make_walk_primitive(seed=0)
+    mp = _primitive(data)
+    op = orc.OraclePrimitive(data)
+    np.random.seed(11)
+    S = mp.sample_low_dimensional_vector(40)
+    L = S.shape[1]
+    cons = [{"type": "position", "t": 155.0, "weight": 1.5, "target": [40.0, None, -30.0]},
+            {"type": "position", "t": 77.0, "weight": 1.0, "target": [20.0, 0.0, -15.0]},
+            {"type": "direction", "t": 155.0, "weight": 0.7, "target": [0.5, 1.0]}]
+
+    class Constraints(object):
+        constraints, min_error, evaluations = cons, None, 0
+
+    ref_res = op.keyframe_residuals(S, cons)
+    ref_lp = orc.gmm_log_prob(S, op.weights, op.means, op.prec_chol)
+    error_scale, quality_scale, init_error_sum = 2.0, 0.01, 3.0
+    c = Constraints()
+    data6 = (mp, c, None, error_scale, quality_scale, init_error_sum)
+
+    np.testing.assert_allclose(of.obj_spatial_error_sum(S, (mp, c, None)), ref_res.sum(axis=1), rtol=1e-10, atol=1e-9)
+    assert c.evaluations == 40 and abs(c.min_error - ref_res[-1].sum()) <= 1e-9
+    assert isinstance(of.obj_spatial_error_sum(S[3], (mp, c, None)), float)
+
+    got = of.obj_spatial_error_sum_and_naturalness(S, data6)
+    np.testing.assert_allclose(got, error_scale * ref_res.sum(axis=1) - ref_lp * quality_scale, rtol=1e-10, atol=1e-9)
+
+    rv = of.obj_spatial_error_residual_vector(S, data6)
+    assert rv.shape == (40, L)                                   # 3 residuals zero-padded to n_variables
+    np.testing.assert_allclose(rv[:, :3], ref_res / init_error_sum, rtol=1e-10, atol=1e-9)
+    assert not rv[:, 3:].any()
+    rvn = of.obj_spatial_error_residual_vector_and_naturalness(S, data6)
+    np.testing.assert_allclose(rvn[:, :3], (ref_res * error_scale - (ref_lp * quality_scale)[:, None]) / init_error_sum,
+                               rtol=1e-10, atol=1e-9)
+    assert not rvn[:, 3:].any() and of.obj_spatial_error_residual_vector_and_naturalness(S[0], data6).shape == (L,)
+
+    jac = of.log_likelihood_jac(S, mp)
+    np.testing.assert_allclose(jac, op.log_likelihood_jac(S), rtol=1e-8, atol=1e-9 * np.abs(jac).max())
+    far = op.means[0] + 1e4                                       # exp(score) underflows: ones, like the reference
+    np.testing.assert_array_equal(of.log_likelihood_jac(far, mp), np.ones(L))
+
+    # kinematic Jacobian: approx_fprime's forward differences, all n*(L+1) points in one launch
+    eps = 1e-7
+    kin = of.spatial_error_jac(S[:4], (mp, c, None), eps)
+    for b in range(4):
+        f0 = op.keyframe_errors(S[b], cons)[0]
+        for i in (0, 7, L - 1):
+            sp = S[b].copy()
+            sp[i] += eps
+            fd = (op.keyframe_errors(sp, cons)[0] - f0) / eps
+            assert abs(kin[b, i] - fd) <= 1e-4 * max(1.0, abs(fd)), (b, i, kin[b, i], fd)
+    full = of.obj_spatial_error_sum_and_naturalness_jac(S[:4], data6, eps)
+    np.testing.assert_allclose(full, jac[:4] * data6[-2] + kin * data6[-1], rtol=1e-12, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        of.obj_spatial_error_sum(S, (mp, c, np.zeros((2, 79))))
+    mp.close() if hasattr(mp, "close") else None

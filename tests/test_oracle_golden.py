@@ -80,3 +80,48 @@ def test_first_min_argmin_rule():
 def test_point_distance_ignores_none_axes():
     assert orc.point_distance([1.0, None, 3.0], [0.0, 100.0, 1.0]) == np.sqrt(1.0 + 4.0)
     assert orc.point_distance([None, None, None], [1.0, 2.0, 3.0]) == 0.0
+
+
+def test_log_likelihood_jac_is_minus_the_gradient_of_the_pinned_log_prob(golden_case):
+    """objective_functions.py:95-107 restated in the oracle.  The reference module cannot be imported (anim_utils),
+    so the restatement is pinned through the identity jac(s) == -d/ds log p(s), with log p pinned by the goldens
+    (test_precision_cholesky_and_log_prob): central differences of the oracle's own score_samples."""
+    name, data, g = golden_case
+    prim = orc.OraclePrimitive(data)
+    X = np.vstack([np.asarray(g["S"], dtype=np.float64), np.asarray(g["X"][:4], dtype=np.float64)])
+    jac = prim.log_likelihood_jac(X)
+    assert jac.shape == X.shape
+    scale = np.sqrt(np.array([np.diag(c) for c in prim.covars]).mean(axis=0))   # per-dimension step scale
+    checked = 0
+    for b in range(X.shape[0]):
+        if np.exp(orc.gmm_log_prob(X[b][None], prim.weights, prim.means, prim.prec_chol)[0]) == 0.0:
+            np.testing.assert_array_equal(jac[b], np.ones(X.shape[1]))   # the reference's underflow branch
+            continue
+        checked += 1
+        for i in range(X.shape[1]):
+            h = 1e-5 * scale[i]
+            xp, xm = X[b].copy(), X[b].copy()
+            xp[i] += h
+            xm[i] -= h
+            fd = -(orc.gmm_log_prob(xp[None], prim.weights, prim.means, prim.prec_chol)[0]
+                   - orc.gmm_log_prob(xm[None], prim.weights, prim.means, prim.prec_chol)[0]) / (2 * h)
+            assert abs(fd - jac[b, i]) <= 2e-6 * max(1.0, abs(jac[b, i]), abs(fd)), (name, b, i, fd, jac[b, i])
+    assert checked >= 2
+    # denominator underflow: exp(score) == 0 -> ones, like the reference
+    far = prim.means[0] + 1e4 * scale
+    np.testing.assert_array_equal(prim.log_likelihood_jac(far[None])[0], np.ones(X.shape[1]))
+
+
+def test_keyframe_residuals_sum_to_the_evaluate_error():
+    """get_residual_vector (motion_primitive_constraints.py:124-144) vs evaluate (:100-122): same terms."""
+    from morphablegraphs_amd import synthetic
+    data = synthetic.make_tiny_primitive(seed=3)
+    prim = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(0)
+    S = rng.standard_normal((5, prim.n_components))
+    t = float(prim.n_canonical_frames - 1)
+    cons = [{"type": "position", "t": t, "weight": 2.0, "target": [1.0, None, -2.0]},
+            {"type": "direction", "t": 0.5 * t, "weight": 0.5, "target": [0.3, 1.0]}]
+    res = prim.keyframe_residuals(S, cons)
+    assert res.shape == (5, 2)
+    np.testing.assert_allclose(res.sum(axis=1), prim.keyframe_errors(S, cons), rtol=1e-14)
