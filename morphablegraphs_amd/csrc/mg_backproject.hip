@@ -125,14 +125,6 @@ __device__ __forceinline__ void mg_wait_producers(const mg_lds_int *prog, int ta
     }
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void mg_wait_counter(const mg_lds_int *ctr, int target) {
-    for (;;) {
-        const int v = *(const volatile mg_lds_int *)ctr;
-        if (__builtin_amdgcn_readfirstlane(v) >= target) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-}
 __device__ __forceinline__ void mg_wait_consumers(const mg_lds_int *prog, int target) {   // waves 4..11
     for (;;) {
         const i32x4 v = *(const volatile mg_lds_i32x4 *)(prog + 4);
