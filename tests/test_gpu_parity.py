@@ -272,6 +272,16 @@ def test_full_size_properties(ctx):
     # log-likelihood at full size against the oracle
     lp = prim.gmm_log_prob(S, dtype=np.float64)
     np.testing.assert_allclose(lp, cp.log_prob_f64(S.astype(np.float64)), rtol=1e-10, atol=1e-8)
+    # the bench's step (one fused launch, two 16-candidate tiles per workgroup): identical to the separate kernels
+    Ff, lpf = _fused_step(ctx, prim, S, 156, 79)
+    np.testing.assert_array_equal(_bits(Ff), _bits(F))
+    np.testing.assert_array_equal(_bits(lpf), _bits(prim.gmm_log_prob(S, dtype=np.float32)))
+    # just above the fused limit (more than two tiles per workgroup): the entry point takes two launches, same bits
+    S2 = np.vstack([S, S[:48]])
+    Ff2, lpf2 = _fused_step(ctx, prim, S2, 156, 79)
+    np.testing.assert_array_equal(_bits(Ff2[:B]), _bits(F))
+    np.testing.assert_array_equal(_bits(Ff2[B:]), _bits(F[:48]))
+    np.testing.assert_array_equal(_bits(lpf2[:B]), _bits(lpf))
     prim.close()
 
 
