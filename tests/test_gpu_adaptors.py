@@ -267,3 +267,89 @@ def test_batched_objective_functions_match_the_reference_formulas():
     with pytest.raises(NotImplementedError):
         of.obj_spatial_error_sum(S, (mp, c, np.zeros((2, 79))))
     mp.close() if hasattr(mp, "close") else None
+
+
+def test_generator_sampling_modes_and_batched_local_optimization():
+    """MotionPrimitiveGenerator.generate_constrained_sample (motion_primitive_generator.py:126-162) on the HIP
+    back end: gpu_batch / random_discrete pick the reference loop's first minimum; cluster_tree_search returns the
+    exhaustive optimum of the tree's stored samples; the leastsq local optimization with the batched
+    finite-difference Jacobian lands where scipy's own lmdif lands on the oracle's (CPU, float64) objective."""
+    from scipy.optimize import leastsq
+    from morphablegraphs_amd.motion_primitive_generator import (HipMotionPrimitiveGenerator, SAMPLING_MODE_CLUSTER_TREE_SEARCH,
+                                                                 SAMPLING_MODE_RANDOM)
+    from morphablegraphs_amd.candidate_scoring import SAMPLING_MODE_GPU_BATCH
+    from oracle import mg_oracle as orc
+    data = synthetic.make_tiny_primitive(seed=3)
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "leftStance", "mm": data})
+    op = orc.OraclePrimitive(data)
+    t_end = float(op.n_canonical_frames - 1)
+    cons = [{"type": "position", "t": t_end, "weight": 1.0, "target": [0.8, None, -0.4]},
+            {"type": "position", "t": 0.5 * t_end, "weight": 1.0, "target": [0.4, None, -0.2]},
+            {"type": "direction", "t": t_end, "weight": 0.05, "target": [0.2, 1.0]}]
+
+    class Constraints(object):
+        def __init__(self):
+            self.constraints, self.min_error, self.evaluations = list(cons), None, 0
+            self.motion_primitive_name, self.use_local_optimization = "leftStance", False
+
+    cfg = {"n_random_samples": 200, "use_constraints": True, "use_transition_model": False, "use_local_coordinates": True,
+           "constrained_sampling_mode": SAMPLING_MODE_GPU_BATCH, "n_cluster_search_candidates": 2,
+           "local_optimization_settings": {"start_error_threshold": 0.0, "error_scale_factor": 1.0, "quality_scale_factor": 0.1,
+                                           "method": "leastsq", "max_iterations": 500, "verbose": False}}
+    gen = HipMotionPrimitiveGenerator({("walk", "leftStance"): node}, cfg, "walk")
+    picks = {}
+    for mode in (SAMPLING_MODE_GPU_BATCH, SAMPLING_MODE_RANDOM):
+        cfg["constrained_sampling_mode"] = mode
+        gen.set_algorithm_config(cfg)
+        c = Constraints()
+        np.random.seed(21)
+        picks[mode] = gen.generate_constrained_sample(node, c)
+        np.random.seed(21)
+        samples = node.sample_low_dimensional_vectors(200)
+        ref = op.keyframe_errors(samples, cons)
+        best_idx, min_error = orc.first_min_argmin(ref)                  # the reference's loop
+        np.testing.assert_array_equal(picks[mode], samples[best_idx])
+        assert abs(c.min_error - min_error) <= 1e-9 and c.evaluations == 200
+    np.testing.assert_array_equal(picks[SAMPLING_MODE_GPU_BATCH], picks[SAMPLING_MODE_RANDOM])
+
+    # cluster tree: brute force over the stored samples == find_best_example_exhaustive
+    class Tree(object):
+        pass
+    node.cluster_tree = Tree()
+    np.random.seed(5)
+    node.cluster_tree.data = node.sample_low_dimensional_vectors(500)
+    cfg["constrained_sampling_mode"] = SAMPLING_MODE_CLUSTER_TREE_SEARCH
+    gen.set_algorithm_config(cfg)
+    c = Constraints()
+    got = gen.generate_constrained_sample(node, c)
+    ref = op.keyframe_errors(node.cluster_tree.data, cons)
+    np.testing.assert_array_equal(got, node.cluster_tree.data[int(np.argmin(ref))])
+    assert abs(c.min_error - ref.min()) <= 1e-9
+
+    # local optimization: batched-Jacobian leastsq vs scipy's lmdif on the oracle objective
+    cfg["constrained_sampling_mode"] = SAMPLING_MODE_GPU_BATCH
+    gen.set_algorithm_config(cfg)
+    c = Constraints()
+    c.use_local_optimization = True
+    np.random.seed(21)
+    opt = gen.generate_constrained_sample(node, c)
+    start = picks[SAMPLING_MODE_GPU_BATCH]
+    L = start.shape[0]
+
+    def cpu_objective(s, init_error_sum):   # obj_spatial_error_residual_vector_and_naturalness, objective_functions.py:239-267
+        nll = -orc.gmm_log_prob(s[None], op.weights, op.means, op.prec_chol)[0] * 0.1
+        r = list(op.keyframe_residuals(s, cons)[0] * 1.0 + nll)
+        while len(r) < L:
+            r.append(0.0)
+        return np.array(r) / init_error_sum
+    init = max(abs(np.sum(cpu_objective(start, 1.0))), 1.0)
+    ref_opt = leastsq(cpu_objective, start, args=(init,), maxfev=500)[0]
+    f_opt, f_ref, f_start = (np.sum(cpu_objective(x, init) ** 2) for x in (opt, ref_opt, start))
+    assert f_opt < f_start
+    assert abs(f_opt - f_ref) <= 1e-6 * max(1.0, f_ref), (f_opt, f_ref)
+    np.testing.assert_allclose(opt, ref_opt, rtol=0, atol=1e-4 * max(1.0, np.abs(ref_opt).max()))
+    # one launch per Jacobian instead of L + 1 objective calls
+    assert gen.numerical_minimizer.n_launches < 200
+    spline, params = gen.generate_constrained_motion_spline(c, None)
+    assert spline.get_motion_vector().shape[1] == op.n_dim and params.shape == (L,)

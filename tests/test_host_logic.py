@@ -138,3 +138,34 @@ def test_synthetic_models_follow_the_reference_layout():
     k = np.array(d["b_spline_knots_spatial"])
     assert len(k) == 35 and np.all(k[:4] == 0) and np.all(k[-4:] == 155)
     assert len(synthetic.make_graph_primitives(16)) == 16
+
+
+def test_batched_jacobian_reproduces_minpack_forward_differences():
+    """HipLeastSquares hands scipy's leastsq a Dfun that evaluates MINPACK lmdif's own forward differences
+    (step sqrt(eps) * |x_j|) on one (L + 1)-row batch: on a plain NumPy objective it must land where leastsq's
+    built-in differencing lands (reference optimization/least_squares.py:47-50 calls it without Dfun)."""
+    from scipy.optimize import leastsq
+    from morphablegraphs_amd.motion_primitive_generator import HipLeastSquares
+    A = np.random.default_rng(0).standard_normal((7, 4))
+    target = np.array([0.3, -1.2, 0.7, 2.0, -0.4, 0.1, 0.9])
+
+    def objective(s, data):                                     # accepts (L,) or (n, L) like the batched objectives
+        s = np.asarray(s)
+        r = np.tanh(s @ A.T) - data
+        return r
+    opt = HipLeastSquares({"max_iterations": 500}, objective)
+    opt.set_objective_function_parameters(target)
+    x0 = np.array([0.1, 0.0, -0.2, 0.3])                         # contains a zero: the absolute-step branch
+    got = opt.run(x0)
+    ref = leastsq(lambda s: objective(s, target), x0, maxfev=500)[0]
+    # same Levenberg-Marquardt iteration up to the stopping test (lmder vs lmdif count evaluations differently)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5)
+    f = lambda x: float(np.sum(objective(x, target) ** 2))
+    assert abs(f(got) - f(ref)) <= 1e-10 * max(1.0, f(ref))
+    J = opt._jac(x0, target)
+    h = np.sqrt(np.finfo(float).eps) * np.where(x0 == 0.0, 1.0, np.abs(x0))
+    for j in range(4):
+        e = np.zeros(4)
+        e[j] = h[j]
+        np.testing.assert_allclose(J[:, j], (objective(x0 + e, target) - objective(x0, target)) / h[j], rtol=0, atol=1e-6)
+    assert J.shape == (7, 4)
