@@ -111,6 +111,125 @@ class HipMotionStateGraphNode(HipMotionPrimitiveModelWrapper):
         return err, best
 
 
+class HipMotionStateTransition(object):
+    """MotionStateTransition (reference motion_model/motion_state_transition.py): plain host data."""
+
+    def __init__(self, from_node_key, to_node_key, transition_type, transition_model=None):
+        self.from_node_key, self.to_node_key = from_node_key, to_node_key
+        self.transition_type, self.transition_model = transition_type, transition_model
+
+
+class _StoredSamples(object):
+    """What the brute-force search needs of a FeatureClusterTree: its stored samples."""
+
+    def __init__(self, data):
+        self.data = np.asarray(data, dtype=np.float64)
+
+
+NODE_TYPE_SINGLE = "single_primitive"
+NODE_TYPE_CYCLE_END = "cycle_end"
+NODE_TYPE_IDLE = "idle"
+
+
+class HipMotionStateGraph(object):
+    """All primitives of a motion state graph resident on one GPU (BASELINE.json config 3), built the way
+    MotionStateGraphLoader._build_from_zip_file does (reference motion_model/motion_state_graph_loader.py:184-242):
+    node groups from the "subgraphs" of the zip, node types from each action's meta information
+    (motion_state_group.py:46-62), transitions from the "transitions" table (loader :244-263, types :265-289),
+    the start node, cached or recomputed step statistics.  Skeleton, hand poses and PFNN data are not read."""
+
+    def __init__(self, context=None, device=0):
+        self.ctx = context or get_context(device)
+        self.nodes = {}
+        self.node_groups = {}
+        self.start_node = None
+        self.action_definitions = {}
+
+    def load_from_zip(self, path, recalculate_stats=False):
+        from .model_io import read_graph_zip
+        return self.build_from_graph_data(read_graph_zip(path), recalculate_stats)
+
+    def build_from_graph_data(self, graph_data, recalculate_stats=False):
+        for action_name, action_data in graph_data["subgraphs"].items():
+            group = {"name": action_data["name"], "info": action_data.get("info", {}), "nodes": []}
+            for mp_name, desc in action_data["nodes"].items():
+                if "spatial_coeffs" in desc["mm"]:
+                    continue   # static primitives carry no statistical model (motion_primitive_wrapper.py:61-66)
+                node = HipMotionStateGraphNode(group, context=self.ctx)
+                node.init_from_dict(action_data["name"], desc)
+                if "space_partition_json" in desc:
+                    node.cluster_tree = _StoredSamples(desc["space_partition_json"]["data"])
+                self.nodes[(action_data["name"], mp_name)] = node
+                group["nodes"].append(mp_name)
+            self._set_node_types(group)
+            self.node_groups[action_data["name"]] = group
+            idle = group["info"].get("idle_states", [])
+            if action_name == "walk" and len(idle) > 0:
+                self.start_node = (action_name, idle[0])
+        self._set_transitions_from_dict(graph_data.get("transitions", {}))
+        for group in self.node_groups.values():
+            stats = group["info"].get("stats", {})
+            for mp_name in group["nodes"]:
+                node = self.nodes[(group["name"], mp_name)]
+                if recalculate_stats or mp_name not in stats:
+                    node.update_motion_stats()
+                else:   # motion_state_group.py:88-99: cached values from meta_information.json
+                    node.average_step_length = stats[mp_name]["average_step_length"]
+                    node.n_standard_transitions = stats[mp_name]["n_standard_transitions"]
+        if "actionDefinitions" in graph_data:
+            self.action_definitions = graph_data["actionDefinitions"]
+        if "startNode" in graph_data:
+            start_node = list(graph_data["startNode"])
+            if start_node[1].startswith("walk"):
+                start_node[1] = start_node[1][5:]
+            self.start_node = tuple(start_node)
+        return self
+
+    def _set_node_types(self, group):
+        keys = [(group["name"], n) for n in group["nodes"]]
+        if len(keys) == 1:
+            self.nodes[keys[0]].node_type = NODE_TYPE_SINGLE
+            return
+        info = group["info"]
+        for field, node_type in (("start_states", NODE_TYPE_START), ("end_states", NODE_TYPE_END),
+                                 ("cycle_states", NODE_TYPE_CYCLE_END), ("idle_states", NODE_TYPE_IDLE)):
+            for k in info.get(field, []):
+                if (group["name"], k) in self.nodes:
+                    self.nodes[(group["name"], k)].node_type = node_type
+
+    def _get_transition_type(self, from_node_key, to_node_key):
+        t_type = "action_transition"
+        if to_node_key[0] == from_node_key[0]:
+            to_type = self.nodes[to_node_key].node_type
+            if self.nodes[from_node_key].node_type == NODE_TYPE_IDLE:
+                if to_type in (NODE_TYPE_START, NODE_TYPE_IDLE, NODE_TYPE_END):
+                    t_type = to_type
+            else:
+                t_type = to_type if to_type in (NODE_TYPE_STANDARD, NODE_TYPE_START, NODE_TYPE_CYCLE_END, NODE_TYPE_IDLE) else NODE_TYPE_END
+        return t_type
+
+    def _set_transitions_from_dict(self, transition_dict):
+        if len(transition_dict) == 0:
+            return
+        split_key = ":" if ":" in list(transition_dict.keys())[0] else "_"
+        for node_key in transition_dict:
+            from_node_key = tuple(node_key.split(split_key)[:2])
+            if from_node_key not in self.nodes:
+                continue
+            for to_key in transition_dict[node_key]:
+                to_node_key = tuple(to_key.split(split_key)[:2])
+                if to_node_key in self.nodes:
+                    self.nodes[from_node_key].outgoing_edges[to_node_key] = HipMotionStateTransition(
+                        from_node_key, to_node_key, self._get_transition_type(from_node_key, to_node_key), None)
+
+    def close(self):
+        for node in self.nodes.values():
+            prim = getattr(node.motion_primitive, "_prim", None)
+            if prim is not None:
+                prim.close()
+        self.nodes = {}
+
+
 class HipPrimitiveSet(object):
     def __init__(self, primitives_json, context=None, device=0):
         self.ctx = context or get_context(device)

@@ -111,3 +111,27 @@ def to_mgrd_v3_json(data):
         "tspm": {"knots": [0.0, 0.0, 0.0, 0.0, float(F - 1), float(F - 1), float(F - 1), float(F - 1)]},
         "gmm": {"covars": data["gmm_covars"], "means": data["gmm_means"], "weights": data["gmm_weights"]},
     }
+
+
+def write_graph_zip(path, actions, transitions=None, start_node=None, format_version=4.0, cluster_trees=None, stats=None):
+    """A graph zip in the reference's layout (utilities/zip_io.py:37-233): ``actions`` = {action: {"primitives":
+    {name: legacy or v3 dict}, "info": meta_information dict}}; ``cluster_trees`` = {(action, name): samples}."""
+    import json
+    import zipfile
+    graph_def = {"formatVersion": format_version, "transitions": transitions or {}}
+    if start_node is not None:
+        graph_def["startNode"] = list(start_node)
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("graph_definition.json", json.dumps(graph_def))
+        z.writestr("skeleton.json", json.dumps({"name": "synthetic", "animated_joints": []}))
+        for action, desc in actions.items():
+            base = "elementary_action_models/elementary_action_%s/" % action
+            info = dict(desc.get("info", {}))
+            if stats is not None and action in stats:
+                info["stats"] = stats[action]
+            z.writestr(base + "meta_information.json", json.dumps(info))
+            for name, mm in desc["primitives"].items():
+                z.writestr(base + "%s_%s_quaternion_mm.json" % (action, name), json.dumps(mm))
+                if cluster_trees and (action, name) in cluster_trees:
+                    tree = {"data": np.asarray(cluster_trees[(action, name)]).tolist(), "features": [], "options": {}, "root": {}}
+                    z.writestr(base + "%s_%s_quaternion_cluster_tree.json" % (action, name), json.dumps(tree))

@@ -353,3 +353,48 @@ def test_generator_sampling_modes_and_batched_local_optimization():
     assert gen.numerical_minimizer.n_launches < 200
     spline, params = gen.generate_constrained_motion_spline(c, None)
     assert spline.get_motion_vector().shape[1] == op.n_dim and params.shape == (L,)
+
+
+def test_motion_state_graph_from_zip(tmp_path):
+    """MotionStateGraphLoader._build_from_zip_file (reference motion_model/motion_state_graph_loader.py:184-242) on
+    the HIP back end: every statistical primitive of the zip resident on the GPU, node types from the meta
+    information, transitions and their types, the start node, cached vs recomputed step statistics, the stored
+    samples of a cluster tree for the brute-force search."""
+    from morphablegraphs_amd.motion_state_graph import HipMotionStateGraph, NODE_TYPE_START, NODE_TYPE_END
+    prims = synthetic.make_graph_primitives(4)
+    lists = [{k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in p.items()} for p in prims]
+    actions = {"walk": {"primitives": {"beginLeftStance": lists[0], "leftStance": synthetic.to_mgrd_v3_json(lists[1]),
+                                       "endRightStance": lists[2]},
+                        "info": {"start_states": ["beginLeftStance"], "end_states": ["endRightStance"]}},
+               "pick": {"primitives": {"reach": lists[3]}, "info": {}}}
+    transitions = {"walk_beginLeftStance": ["walk_leftStance"], "walk_leftStance": ["walk_leftStance", "walk_endRightStance"],
+                   "walk_endRightStance": ["pick_reach"]}
+    np.random.seed(9)
+    stored = HipMotionPrimitive(None)
+    stored._initialize_from_json(prims[1])
+    tree_samples = stored.sample_low_dimensional_vector(64)
+    path = str(tmp_path / "graph.zip")
+    stats = {"walk": {"beginLeftStance": {"average_step_length": 12.5, "n_standard_transitions": 1}}}
+    synthetic.write_graph_zip(path, actions, transitions=transitions, start_node=("walk", "walk_beginLeftStance"),
+                              cluster_trees={("walk", "leftStance"): tree_samples}, stats=stats)
+    graph = HipMotionStateGraph().load_from_zip(path)
+    assert sorted(graph.nodes) == [("pick", "reach"), ("walk", "beginLeftStance"), ("walk", "endRightStance"), ("walk", "leftStance")]
+    assert graph.start_node == ("walk", "beginLeftStance")                       # "walk_" prefix stripped, loader :236-240
+    assert graph.nodes[("walk", "beginLeftStance")].node_type == NODE_TYPE_START
+    assert graph.nodes[("walk", "endRightStance")].node_type == NODE_TYPE_END
+    assert graph.nodes[("pick", "reach")].node_type == "single_primitive"
+    edges = graph.nodes[("walk", "leftStance")].outgoing_edges
+    assert edges[("walk", "leftStance")].transition_type == "standard" and edges[("walk", "endRightStance")].transition_type == "end"
+    assert graph.nodes[("walk", "endRightStance")].outgoing_edges[("pick", "reach")].transition_type == "action_transition"
+    # cached statistics are taken, missing ones are computed from GPU back-projections
+    assert graph.nodes[("walk", "beginLeftStance")].average_step_length == 12.5
+    node = graph.nodes[("walk", "leftStance")]
+    assert node.average_step_length > 0 and node.n_standard_transitions == 1
+    # every node back-projects through its own primitive; v3 and legacy files give the same model
+    for (key, node), p in zip(sorted(graph.nodes.items()), [prims[3], prims[0], prims[2], prims[1]]):
+        s = np.zeros(node.get_n_spatial_components())
+        frames = node.back_project(s, use_time_parameters=False).get_motion_vector()
+        ref = c_oracle.COraclePrimitive(p).frames_f64(s[None])[0]
+        np.testing.assert_allclose(frames, ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(graph.nodes[("walk", "leftStance")].cluster_tree.data, tree_samples, rtol=0, atol=0)
+    graph.close()

@@ -97,21 +97,35 @@ def test_v3_json_maps_to_legacy_like_the_reference_wrapper():
     assert "eigen_vectors_time" not in legacy
 
 
+def _listify(d):
+    return {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in d.items()}
+
+
 def test_graph_zip_reader(tmp_path):
-    prims = synthetic.make_graph_primitives(3)
-    path = tmp_path / "graph.zip"
-    with zipfile.ZipFile(path, "w") as z:
-        z.writestr("graph_definition.json", json.dumps({"nodes": {}}))
-        for i, p in enumerate(prims):
-            body = synthetic.to_mgrd_v3_json(p) if i % 2 else p
-            z.writestr("elementary_action_models/walk/%s_quaternion_mm.json" % p["name"], json.dumps(body))
-        z.writestr("elementary_action_models/walk/idle_quaternion_mm.json",
-                   json.dumps({"name": "idle", "spatial_coeffs": [[0.0]], "knots": [0, 0, 0, 0, 1, 1, 1, 1], "n_canonical_frames": 2}))
-    out = model_io.load_graph_zip(str(path))
-    assert sorted(k[1] for k in out) == sorted(p["name"] for p in prims)
-    assert all(k[0] == "walk" for k in out)
-    for p in prims:
-        assert out[("walk", p["name"])]["n_basis_spatial"] == p["n_basis_spatial"]
+    """The zip layout and key derivation of ZipReader (reference utilities/zip_io.py:65-233):
+    elementary_action_models/elementary_action_<action>/<action>_<primitive>_quaternion_mm.json."""
+    prims = [_listify(p) for p in synthetic.make_graph_primitives(3)]
+    path = str(tmp_path / "graph.zip")
+    actions = {"walk": {"primitives": {"leftStance": prims[0], "rightStance": synthetic.to_mgrd_v3_json(prims[1]),
+                                       "idle": {"name": "idle", "spatial_coeffs": [[0.0]], "knots": [0, 0, 0, 0, 1, 1, 1, 1],
+                                                "n_canonical_frames": 2}},
+                        "info": {"start_states": ["leftStance"], "end_states": ["rightStance"], "idle_states": ["idle"]}},
+               "pick": {"primitives": {"reach": prims[2]}, "info": {"start_states": ["reach"], "end_states": ["reach"]}}}
+    stored = np.arange(12.0).reshape(3, 4)
+    synthetic.write_graph_zip(path, actions, transitions={"walk_leftStance": ["walk_rightStance", "pick_reach"]},
+                              start_node=("walk", "walk_leftStance"), cluster_trees={("walk", "leftStance"): stored})
+    data = model_io.read_graph_zip(path)
+    assert sorted(data["subgraphs"]) == ["pick", "walk"] and data["formatVersion"] == 4.0
+    walk = data["subgraphs"]["walk"]
+    assert walk["name"] == "walk" and sorted(walk["nodes"]) == ["idle", "leftStance", "rightStance"]
+    assert walk["nodes"]["leftStance"]["name"] == "walk_leftStance"            # zip_io.py:186-191
+    assert walk["info"]["idle_states"] == ["idle"]
+    np.testing.assert_array_equal(walk["nodes"]["leftStance"]["space_partition_json"]["data"], stored)
+    assert "space_partition_json" not in walk["nodes"]["rightStance"]
+    out = model_io.load_graph_zip(path)
+    assert sorted(out) == [("pick", "reach"), ("walk", "leftStance"), ("walk", "rightStance")]   # static idle skipped
+    assert out[("walk", "rightStance")]["n_basis_spatial"] == prims[1]["n_basis_spatial"]          # v3 -> legacy
+    assert out[("pick", "reach")]["n_canonical_frames"] == prims[2]["n_canonical_frames"]
 
 
 def test_constraint_conversion_accepts_reference_shaped_objects():
