@@ -69,6 +69,15 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if not os.path.exists(os.path.join(ROOT, "morphablegraphs_amd", "csrc", "libmg_hip.so")):
+        # git-ignored build product missing (fresh checkout): rank 0 of the node builds it, the others wait for the file
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            while not os.path.exists(os.path.join(ROOT, "oracle", "libmg_oracle.so")):   # built last
+                time.sleep(1.0)
+            time.sleep(2.0)
     from morphablegraphs_amd import _capi, synthetic
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

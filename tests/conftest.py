@@ -12,6 +12,11 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the built libraries are git-ignored: a fresh checkout builds them once (hipcc cross-compiles without a GPU)
+    libs = [os.path.join(ROOT, "morphablegraphs_amd", "csrc", "libmg_hip.so"), os.path.join(ROOT, "oracle", "libmg_oracle.so")]
+    if not all(os.path.exists(l) for l in libs):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def load_golden(name):
