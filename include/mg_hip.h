@@ -74,24 +74,42 @@ typedef struct mg_primitive_desc {
     const double *gmm_covars;    /* (K, L, L)                                         */
 } mg_primitive_desc;
 
-/* One keyframe constraint on the ROOT joint, the FK-free subset of
- * MotionPrimitiveConstraints.evaluate (reference
+/* One keyframe constraint, the subset of
+ * MotionPrimitiveConstraints.evaluate the fused scorer covers (reference
  * morphablegraphs/constraints/motion_primitive_constraints.py:100-122):
  *  MG_CONSTRAINT_POSITION  -> GlobalTransformConstraint._point_distance
  *      (reference .../keyframe_constraints/global_transform_constraint.py:135-143),
  *      target axes set to NaN are unconstrained (the reference's None);
  *  MG_CONSTRAINT_DIRECTION_2D -> Direction2DConstraint.evaluate_motion_spline
  *      (reference .../keyframe_constraints/direction_2d_constraint.py:42-52), heading =
- *      xz of the root quaternion applied to ref_dir, error in degrees. */
-enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1 };
+ *      xz of the root quaternion applied to ref_dir, error in degrees;
+ *  MG_CONSTRAINT_JOINT_POSITION -> the same _point_distance for ANY joint of a skeleton (hands, feet: the
+ *      keyframe position constraints of reference two_hand_constraint.py:51-93, pose_constraint.py:48-67 go
+ *      through Skeleton.nodes[joint].get_global_position): forward kinematics along the joint's chain,
+ *      p = t_root + sum_i R(q_j0 q_j1 .. q_j(i-1)) offset(j_i), quaternions (w,x,y,z) normalised like
+ *      transformations.quaternion_matrix does; needs a set made by mg_constraint_set_create_fk.
+ *      PARITY UNPINNED: the reference's FK lives in anim_utils (absent); pinned by an independent
+ *      rotation-matrix oracle and known-answer poses (tests). */
+enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1, MG_CONSTRAINT_JOINT_POSITION = 2 };
+#define MG_MAX_CHAIN 32
 typedef struct mg_keyframe_constraint {
     int32_t type;
-    int32_t reserved;
+    int32_t joint;              /* MG_CONSTRAINT_JOINT_POSITION: index into the skeleton's joints; else unused */
     double canonical_keyframe;  /* t; may be fractional (graph_walk_planner.py:203) */
     double weight_factor;
     double target[3];           /* position xyz (NaN = free) or direction (x, z, unused) */
     double ref_dir[3];          /* direction only: skeleton.aligning_root_dir, e.g. (0,0,1) */
 } mg_keyframe_constraint;
+
+/* The part of a skeleton forward kinematics needs (anim_utils Skeleton: nodes with parent / offset, and the
+ * pose-vector layout root translation [0:3] + one quaternion per animated joint). */
+typedef struct mg_skeleton_desc {
+    int32_t n_joints;
+    int32_t reserved;
+    const int32_t *parents;       /* (n_joints) parent index, -1 for the root (joint 0 must be the root) */
+    const double *offsets;        /* (n_joints, 3) offset from the parent in the parent's frame (root: ignored) */
+    const int32_t *quat_channel;  /* (n_joints) first pose channel of the joint's (w,x,y,z), -1 = not animated (identity) */
+} mg_skeleton_desc;
 
 /* ---- library / context ------------------------------------------------------ */
 const char *mg_version(void);
@@ -205,6 +223,9 @@ int mg_gmm_sample(mg_primitive *prim, int64_t n_samples, const int64_t *counts, 
  * alignment), float64 arithmetic, without materialising frames. */
 int mg_constraint_set_create(mg_primitive *prim, const mg_keyframe_constraint *cons, int32_t n,
                              mg_constraint_set **out);
+/* the same with a skeleton, which MG_CONSTRAINT_JOINT_POSITION constraints need (chains of <= MG_MAX_CHAIN joints) */
+int mg_constraint_set_create_fk(mg_primitive *prim, const mg_skeleton_desc *skeleton,
+                                const mg_keyframe_constraint *cons, int32_t n, mg_constraint_set **out);
 void mg_constraint_set_destroy(mg_constraint_set *cs);
 int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
                          const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MG_HIP_LIB") or os.path.join(HERE, "csrc", "libmg_hip
 MG_OK = 0
 MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
-MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D = 0, 1
+MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
                  "gmm_sample": 4, "spline_evaluate": 5, "step": 6}
 
@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
-    "mg_gmm_log_prob_jac_host",
+    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk",
 ]
 
 
@@ -55,8 +55,45 @@ class PrimitiveDesc(C.Structure):
 
 
 class KeyframeConstraint(C.Structure):
-    _fields_ = [("type", C.c_int32), ("reserved", C.c_int32), ("canonical_keyframe", C.c_double),
+    _fields_ = [("type", C.c_int32), ("joint", C.c_int32), ("canonical_keyframe", C.c_double),
                 ("weight_factor", C.c_double), ("target", C.c_double * 3), ("ref_dir", C.c_double * 3)]
+
+
+class SkeletonDesc(C.Structure):   # struct mg_skeleton_desc
+    _fields_ = [("n_joints", C.c_int32), ("reserved", C.c_int32), ("parents", C.c_void_p), ("offsets", C.c_void_p),
+                ("quat_channel", C.c_void_p)]
+
+
+class Skeleton(object):
+    """The part of an anim_utils Skeleton forward kinematics needs: joints = [(name, parent name or None,
+    (ox, oy, oz)), ...] with parents before children and the root first; animated_joints = names in pose-vector
+    order (root translation at [0:3], then one (w,x,y,z) quaternion per animated joint)."""
+
+    def __init__(self, joints, animated_joints):
+        self.names = [j[0] for j in joints]
+        index = {n: i for i, n in enumerate(self.names)}
+        if len(index) != len(self.names):
+            raise ValueError("duplicate joint names")
+        self.parents = np.array([-1 if j[1] is None else index[j[1]] for j in joints], dtype=np.int32)
+        self.offsets = np.ascontiguousarray([j[2] for j in joints], dtype=np.float64).reshape(len(joints), 3)
+        self.animated_joints = list(animated_joints)
+        chan = {n: 3 + 4 * i for i, n in enumerate(self.animated_joints)}
+        self.quat_channel = np.array([chan.get(n, -1) for n in self.names], dtype=np.int32)
+        if self.parents[0] != -1 or np.any(self.parents[1:] >= np.arange(1, len(joints))) or np.any(self.parents[1:] < 0):
+            raise ValueError("joint 0 must be the root and parents must precede their children")
+
+    def index(self, joint):
+        return int(joint) if isinstance(joint, (int, np.integer)) else self.names.index(joint)
+
+    def chain(self, joint):
+        out, j = [], self.index(joint)
+        while j >= 0:
+            out.insert(0, j)
+            j = int(self.parents[j])
+        return out
+
+    def desc(self):
+        return SkeletonDesc(len(self.names), 0, self.parents.ctypes.data, self.offsets.ctypes.data, self.quat_channel.ctypes.data)
 
 
 _lib = None
@@ -120,6 +157,7 @@ def load_library(path=None):
         "mg_gmm_sample_host": [vp, i64, vp, u64, vp, i32, i64, vp],
         "mg_score_constraints_host": [vp, vp, vp, i32, i64, i64, vp, i32],
         "mg_score_constraint_residuals": [vp, vp, vp, i32, i64, i64, vp],
+        "mg_constraint_set_create_fk": [vp, vp, vp, i32, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
         "mg_score_constraint_residuals_host": [vp, vp, vp, i32, i64, i64, vp],
         "mg_gmm_log_prob_jac_host": [vp, vp, i32, i64, i64, vp],
@@ -289,11 +327,13 @@ class TimeGrid(object):
 
 
 class ConstraintSet(object):
-    """constraints: list of dicts {"type": "position"|"direction", "t": float, "weight": float,
-    "target": [x|None, y|None, z|None] | [dx, dz], "ref_dir": (rx, ry, rz)}."""
+    """constraints: list of dicts {"type": "position"|"direction"|"joint_position", "t": float, "weight": float,
+    "target": [x|None, y|None, z|None] | [dx, dz], "ref_dir": (rx, ry, rz), "joint": name or index}; a
+    `skeleton` (Skeleton) is needed for "joint_position"."""
 
-    def __init__(self, prim, constraints):
+    def __init__(self, prim, constraints, skeleton=None):
         self.prim = prim
+        self.skeleton = skeleton
         n = len(constraints)
         arr = (KeyframeConstraint * max(n, 1))()
         for i, c in enumerate(constraints):
@@ -302,6 +342,14 @@ class ConstraintSet(object):
             k.weight_factor = float(c.get("weight", 1.0))
             if c["type"] == "position":
                 k.type = MG_CONSTRAINT_POSITION
+                for a in range(3):
+                    v = c["target"][a]
+                    k.target[a] = float("nan") if v is None else float(v)
+            elif c["type"] == "joint_position":
+                if skeleton is None:
+                    raise ValueError("joint_position constraints need a skeleton")
+                k.type = MG_CONSTRAINT_JOINT_POSITION
+                k.joint = skeleton.index(c["joint"])
                 for a in range(3):
                     v = c["target"][a]
                     k.target[a] = float("nan") if v is None else float(v)
@@ -314,7 +362,11 @@ class ConstraintSet(object):
             else:
                 raise ValueError("unknown constraint type %r" % (c["type"],))
         h = C.c_void_p()
-        _check(prim.lib.mg_constraint_set_create(prim.handle, C.cast(arr, C.c_void_p), n, C.byref(h)))
+        if skeleton is None:
+            _check(prim.lib.mg_constraint_set_create(prim.handle, C.cast(arr, C.c_void_p), n, C.byref(h)))
+        else:
+            d = skeleton.desc()
+            _check(prim.lib.mg_constraint_set_create_fk(prim.handle, C.byref(d), C.cast(arr, C.c_void_p), n, C.byref(h)))
         self.handle = h
         self.n = n
 

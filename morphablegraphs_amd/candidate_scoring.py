@@ -3,10 +3,11 @@ MotionPrimitiveGenerator.evaluate_samples_using_constraints
 (reference morphablegraphs/motion_generator/motion_primitive_generator.py:230-261), shaped after the
 MGRD precedent MGRDSampleFilter.score_samples (reference mgrd_sample_filter.py:63-75).
 
-Constraints covered by the fused kernel are the FK-free ones path following uses
-(locomotion_constraints_builder.py:82-117): root position at a canonical keyframe
-(GlobalTransformConstraint, position only, root joint) and 2-D heading
-(Direction2DConstraint).  Anything else raises -- there is no silent CPU fallback.
+Constraints covered by the fused kernel: the FK-free ones path following uses
+(locomotion_constraints_builder.py:82-117) -- root position at a canonical keyframe
+(GlobalTransformConstraint, position only, root joint) and 2-D heading (Direction2DConstraint) -- and, given
+a `_capi.Skeleton` (argument, or `hip_skeleton` attribute of the constraints object), the position of any
+other joint by forward kinematics (hands, feet).  Anything else raises -- there is no silent CPU fallback.
 """
 import numpy as np
 
@@ -32,8 +33,10 @@ def constraints_to_device_form(constraints, root_joint=None):
         elif getattr(c, "position", None) is not None and getattr(c, "orientation", None) is None:
             joint = getattr(c, "joint_name", root_joint)
             if root_joint is not None and joint != root_joint:
-                raise NotImplementedError("fused scoring covers the root joint only (FK lives in anim_utils); got %r" % joint)
-            out.append({"type": "position", "t": t, "weight": w, "target": list(c.position)})
+                # any other joint goes through the forward-kinematics constraint (needs a skeleton on the set)
+                out.append({"type": "joint_position", "t": t, "weight": w, "target": list(c.position), "joint": joint})
+            else:
+                out.append({"type": "position", "t": t, "weight": w, "target": list(c.position)})
         else:
             raise NotImplementedError("constraint %r is not covered by the fused GPU scorer" % (type(c).__name__,))
     return out
@@ -43,16 +46,16 @@ class HipSampleFilter(object):
     """score_samples(primitive, samples, constraints) -> errors[n], like MGRDSampleFilter."""
 
     @staticmethod
-    def score_samples(motion_primitive, samples, constraints, dtype=np.float64):
+    def score_samples(motion_primitive, samples, constraints, dtype=np.float64, skeleton=None):
         prim = motion_primitive._prim if hasattr(motion_primitive, "_prim") else motion_primitive
-        cset = _capi.ConstraintSet(prim, constraints_to_device_form(constraints))
+        cset = _capi.ConstraintSet(prim, constraints_to_device_form(constraints), skeleton)
         try:
             return prim.score_constraints(cset, np.asarray(samples), dtype=dtype)
         finally:
             cset.close()
 
 
-def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frames=None):
+def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frames=None, skeleton=None):
     """Drop-in for MotionPrimitiveGenerator.evaluate_samples_using_constraints in local-coordinate
     mode: returns (samples[best_idx], min_error) with the reference's first-minimum rule, and
     updates constraints.min_error / constraints.evaluations when those attributes exist."""
@@ -62,7 +65,8 @@ def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frame
     prim_obj = mp_node.motion_primitive if hasattr(mp_node, "motion_primitive") else mp_node
     prim = prim_obj._prim
     clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
-    cset = _capi.ConstraintSet(prim, constraints_to_device_form(clist))
+    skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
+    cset = _capi.ConstraintSet(prim, constraints_to_device_form(clist), skeleton)
     ctx = prim.ctx
     try:
         S = _capi._latents(samples)

@@ -819,33 +819,76 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
 }
 
 // ---- constraint sets ---------------------------------------------------------------------
-extern "C" int mg_constraint_set_create(mg_primitive *p, const mg_keyframe_constraint *cons, int32_t n, mg_constraint_set **out) {
+extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
+                                           int32_t n, mg_constraint_set **out) {
     MG_REQUIRE(p && out && n >= 0 && (n == 0 || cons), "mg_constraint_set_create: bad arguments");
     *out = nullptr;
     const int nch = std::min(7, p->D), L = p->L, D = p->D;
+    if (sk) {
+        MG_REQUIRE(sk->n_joints > 0 && sk->parents && sk->offsets && sk->quat_channel, "mg_constraint_set_create_fk: incomplete skeleton");
+        MG_REQUIRE(sk->parents[0] < 0, "mg_constraint_set_create_fk: joint 0 must be the root");
+        for (int j = 0; j < sk->n_joints; j++) {
+            MG_REQUIRE(sk->parents[j] < j, "mg_constraint_set_create_fk: joint %d: parents must precede their children", j);
+            MG_REQUIRE(sk->quat_channel[j] < 0 || sk->quat_channel[j] + 4 <= D,
+                       "mg_constraint_set_create_fk: joint %d: quaternion channel %d outside n_dim = %d", j, sk->quat_channel[j], D);
+        }
+    }
+    // chains (root first) and row counts
+    std::vector<std::vector<int>> chains(n);
+    std::vector<int32_t> woff(n + 1, 0), chain_len(n, 0);
     for (int c = 0; c < n; c++) {
-        MG_REQUIRE(cons[c].type == MG_CONSTRAINT_POSITION || cons[c].type == MG_CONSTRAINT_DIRECTION_2D,
-                   "mg_constraint_set_create: constraint %d has unknown type %d", c, cons[c].type);
+        const int type = cons[c].type;
+        MG_REQUIRE(type == MG_CONSTRAINT_POSITION || type == MG_CONSTRAINT_DIRECTION_2D || type == MG_CONSTRAINT_JOINT_POSITION,
+                   "mg_constraint_set_create: constraint %d has unknown type %d", c, type);
         MG_REQUIRE(std::isfinite(cons[c].canonical_keyframe), "mg_constraint_set_create: constraint %d keyframe not finite", c);
-        MG_REQUIRE(cons[c].type == MG_CONSTRAINT_POSITION ? D >= 3 : D >= 7,
+        MG_REQUIRE(type == MG_CONSTRAINT_POSITION ? D >= 3 : D >= 7,
                    "mg_constraint_set_create: constraint %d needs more pose channels than n_dim = %d", c, D);
+        int rows = nch;
+        if (type == MG_CONSTRAINT_JOINT_POSITION) {
+            MG_REQUIRE(sk != nullptr, "mg_constraint_set_create: constraint %d needs a skeleton (mg_constraint_set_create_fk)", c);
+            MG_REQUIRE(cons[c].joint >= 0 && cons[c].joint < sk->n_joints, "mg_constraint_set_create_fk: constraint %d: joint %d out of range", c, cons[c].joint);
+            for (int j = cons[c].joint; j >= 0; j = sk->parents[j]) chains[c].insert(chains[c].begin(), j);
+            const int m = (int)chains[c].size() - 1;   // joints below the root on the chain
+            MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain of %d joints exceeds %d", c, m, MG_MAX_CHAIN);
+            chain_len[c] = m;
+            rows = 3 + 4 * std::max(m, 1);
+        }
+        woff[c + 1] = woff[c] + rows;
     }
     mg_constraint_set *cs = new (std::nothrow) mg_constraint_set();
     if (!cs) return MG_ERR_OUT_OF_MEMORY;
     cs->prim = p; cs->n = n; cs->nch = nch;
-    std::vector<double> W((size_t)n * nch * L, 0.0), bias((size_t)n * nch, 0.0), par((size_t)n * 8, 0.0);
+    const size_t rows_total = (size_t)woff[n];
+    std::vector<double> W(std::max<size_t>(rows_total, 1) * L, 0.0), bias(std::max<size_t>(rows_total, 1), 0.0), par((size_t)std::max(n, 1) * 8, 0.0);
+    std::vector<double> choff((size_t)std::max(n, 1) * MG_MAX_CHAIN * 3, 0.0);
     for (int c = 0; c < n; c++) {
         int32_t i0; double w[4];
         mg_basis_row(p->knots.data(), (int)p->knots.size(), cons[c].canonical_keyframe, &i0, w);
-        for (int d = 0; d < nch; d++) {
+        auto fill_row = [&](size_t row, int d) {   // pose channel d at the keyframe as a (1 x L) matrix + bias
             double b = 0.0;
             for (int j = 0; j < 4; j++) b = b + w[j] * p->means_[(size_t)(i0 + j) * D + d];
-            bias[(size_t)c * nch + d] = b;
+            bias[row] = b;
             for (int k = 0; k < L; k++) {
                 double acc = 0.0;
                 for (int j = 0; j < 4; j++) acc = acc + w[j] * p->Es[((size_t)(i0 + j) * D + d) * L + k];
-                W[((size_t)c * nch + d) * L + k] = acc;
+                W[row * L + k] = acc;
             }
+        };
+        const size_t r0 = (size_t)woff[c];
+        if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION) {
+            for (int d = 0; d < 3; d++) fill_row(r0 + d, d);
+            const int m = chain_len[c];
+            for (int i = 0; i < std::max(m, 1); i++) {   // quaternions of chain joints 0 .. m-1 (the end joint's own does not move it)
+                const int ch = sk->quat_channel[chains[c][i]];
+                for (int e = 0; e < 4; e++) {
+                    if (ch >= 0) fill_row(r0 + 3 + 4 * i + e, ch + e);
+                    else bias[r0 + 3 + 4 * i + e] = (e == 0) ? 1.0 : 0.0;   // not animated: identity, zero matrix row
+                }
+            }
+            for (int i = 0; i < m; i++)
+                for (int e = 0; e < 3; e++) choff[((size_t)c * MG_MAX_CHAIN + i) * 3 + e] = sk->offsets[(size_t)chains[c][i + 1] * 3 + e];
+        } else {
+            for (int d = 0; d < nch; d++) fill_row(r0 + d, d);
         }
         double *q = &par[(size_t)c * 8];
         q[0] = (double)cons[c].type; q[1] = cons[c].weight_factor;
@@ -854,9 +897,15 @@ extern "C" int mg_constraint_set_create(mg_primitive *p, const mg_keyframe_const
     int rc = mg_upload(p->ctx, W, &cs->d_W);
     if (rc == MG_OK) rc = mg_upload(p->ctx, bias, &cs->d_bias);
     if (rc == MG_OK) rc = mg_upload(p->ctx, par, &cs->d_par);
+    if (rc == MG_OK) rc = mg_upload(p->ctx, woff, &cs->d_woff);
+    if (rc == MG_OK) { if (chain_len.empty()) chain_len.push_back(0); rc = mg_upload(p->ctx, chain_len, &cs->d_chain); }
+    if (rc == MG_OK) rc = mg_upload(p->ctx, choff, &cs->d_choff);
     if (rc != MG_OK) { mg_constraint_set_destroy(cs); return rc; }
     *out = cs;
     return MG_OK;
+}
+extern "C" int mg_constraint_set_create(mg_primitive *p, const mg_keyframe_constraint *cons, int32_t n, mg_constraint_set **out) {
+    return mg_constraint_set_create_fk(p, nullptr, cons, n, out);
 }
 extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
     if (!cs) return;
@@ -864,6 +913,9 @@ extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
     if (cs->d_W) (void)hipFree(cs->d_W);
     if (cs->d_bias) (void)hipFree(cs->d_bias);
     if (cs->d_par) (void)hipFree(cs->d_par);
+    if (cs->d_woff) (void)hipFree(cs->d_woff);
+    if (cs->d_chain) (void)hipFree(cs->d_chain);
+    if (cs->d_choff) (void)hipFree(cs->d_choff);
     delete cs;
 }
 

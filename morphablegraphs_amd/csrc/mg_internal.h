@@ -129,10 +129,13 @@ struct mg_primitive {
 struct mg_constraint_set {
     mg_primitive *prim = nullptr;
     int32_t n = 0;
-    int32_t nch = 0;            // channels evaluated per constraint (<= 7)
-    double *d_W = nullptr;      // [n][nch][L]
-    double *d_bias = nullptr;   // [n][nch]
+    int32_t nch = 0;            // pose channels of the primitive the root constraints may touch (<= 7)
+    double *d_W = nullptr;      // [rows][L]: fused keyframe matrices, rows of constraint c start at woff[c]
+    double *d_bias = nullptr;   // [rows]
     double *d_par = nullptr;    // [n][8]: type, weight, target[3], ref_dir[3]
+    int32_t *d_woff = nullptr;  // [n + 1] first row of every constraint
+    int32_t *d_chain = nullptr; // [n] FK chain length m (0 for root constraints)
+    double *d_choff = nullptr;  // [n][MG_MAX_CHAIN][3] offsets along the chain
 };
 
 // launchers (each validates nothing: the C-ABI entry points did)

@@ -7,9 +7,12 @@
 #include "mg_internal.h"
 
 struct mg_score_args {
-    const double *W;      // [n][nch][L]   sum_j w_j E'[(i0+j) D + d]
-    const double *bias;   // [n][nch]      mean frame at t_c
+    const double *W;      // [rows][L]     sum_j w_j E'[(i0+j) D + d]; constraint c owns rows woff[c] ..
+    const double *bias;   // [rows]        mean frame at t_c
     const double *par;    // [n][8]        type, weight, target[3], ref_dir[3]
+    const int32_t *woff;  // [n + 1]
+    const int32_t *chain; // [n]           FK chain length
+    const double *choff;  // [n][MG_MAX_CHAIN][3]
     const void *lat;
     void *out;            // (B) summed error, or NULL
     double *res;          // (B, n) weighted residual of every constraint, or NULL
@@ -43,16 +46,51 @@ __global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
         double fr[7];
 #pragma unroll
         for (int d = 0; d < 7; d++) fr[d] = 0.0;
+        const size_t r0 = (size_t)a.woff[c];
+        auto channel = [&](size_t row) {   // one pose channel of this candidate at the keyframe
+            const double *wr = a.W + row * L;
+            double acc = a.bias[row];
+            for (int k = 0; k < L; k++) acc = fma(wr[k], x[k], acc);
+            return acc;
+        };
+        if (type == MG_CONSTRAINT_JOINT_POSITION) {
+            // forward kinematics along the chain: p = t_root + sum_i R(q_0 .. q_(i-1)) offset_i, unit quaternions (w,x,y,z)
+            double p0 = channel(r0), p1 = channel(r0 + 1), p2 = channel(r0 + 2);
+            const int m = a.chain[c];
+            double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;   // accumulated global rotation of the parent
+            for (int i = 0; i < m; i++) {
+                double qw = channel(r0 + 3 + 4 * i), qx = channel(r0 + 4 + 4 * i), qy = channel(r0 + 5 + 4 * i), qz = channel(r0 + 6 + 4 * i);
+                const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+                qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+                const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+                const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+                aw = nw; ax = nx; ay = ny; az = nz;
+                const double *off = a.choff + ((size_t)c * MG_MAX_CHAIN + i) * 3;
+                const double ox = off[0], oy = off[1], oz = off[2];
+                // v' = v + 2 w (u x v) + 2 u x (u x v), u = (ax, ay, az)
+                const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
+                const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
+                p0 += ox + 2.0 * (aw * cx + dx);
+                p1 += oy + 2.0 * (aw * cy + dy);
+                p2 += oz + 2.0 * (aw * cz + dz);
+            }
+            const double pj[3] = {p0, p1, p2};
+            double ds = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double t = par[2 + i];
+                if (t == t) ds += (t - pj[i]) * (t - pj[i]);
+            }
+            const double e = par[1] * sqrt(ds);
+            err += e;
+            if (a.res) a.res[(b0 + tid) * a.n + c] = e;
+            continue;
+        }
         const int d_lo = (type == MG_CONSTRAINT_POSITION) ? 0 : 3;
         const int d_hi = (type == MG_CONSTRAINT_POSITION) ? 3 : 7;
 #pragma unroll
         for (int d = 0; d < 7; d++) {
-            if (d >= d_lo && d < d_hi && d < a.nch) {
-                const double *wr = a.W + ((size_t)c * a.nch + d) * L;
-                double acc = a.bias[(size_t)c * a.nch + d];
-                for (int k = 0; k < L; k++) acc = fma(wr[k], x[k], acc);
-                fr[d] = acc;
-            }
+            if (d >= d_lo && d < d_hi && d < a.nch) fr[d] = channel(r0 + d);
         }
         if (type == MG_CONSTRAINT_POSITION) {
             // _point_distance: axes whose target is NaN (the reference's None) are ignored
@@ -92,7 +130,7 @@ __global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res) {
     mg_score_args a;
     a.res = res;
-    a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
+    a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
     size_t lds = (size_t)256 * (p->L + 1) * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_score_constraints: n_components %d too large", p->L); return MG_ERR_UNSUPPORTED; }
     int64_t grid = (B + 255) / 256;

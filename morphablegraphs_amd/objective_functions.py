@@ -48,7 +48,7 @@ def _residuals(prim, mp_constraints, S):
     clist = constraints_to_device_form(_constraint_list(mp_constraints))
     if len(clist) == 0:
         return np.zeros((len(S), 0))
-    cset = _capi.ConstraintSet(prim, clist)
+    cset = _capi.ConstraintSet(prim, clist, getattr(mp_constraints, "hip_skeleton", None))
     try:
         return prim.score_constraint_residuals(cset, S)
     finally:

@@ -135,3 +135,26 @@ def write_graph_zip(path, actions, transitions=None, start_node=None, format_ver
                 if cluster_trees and (action, name) in cluster_trees:
                     tree = {"data": np.asarray(cluster_trees[(action, name)]).tolist(), "features": [], "options": {}, "root": {}}
                     z.writestr(base + "%s_%s_quaternion_cluster_tree.json" % (action, name), json.dumps(tree))
+
+
+def make_skeleton(n_animated=19):
+    """A humanoid with `n_animated` animated joints (pose vector 3 + 4 n: 79 channels for 19 joints, the layout
+    of the 'walk' primitive) plus non-animated end sites, in the shape anim_utils' skeleton.json gives:
+    (name, parent, offset) with parents before children, and the animated joints in pose-vector order."""
+    joints = [("Hips", None, (0.0, 0.0, 0.0)),
+              ("Spine", "Hips", (0.0, 10.0, 0.5)), ("Spine1", "Spine", (0.0, 12.0, 0.0)), ("Neck", "Spine1", (0.0, 14.0, 0.5)),
+              ("Head", "Neck", (0.0, 8.0, 1.0)), ("Head_EndSite", "Head", (0.0, 10.0, 0.0)),
+              ("LeftShoulder", "Spine1", (6.0, 11.0, 0.0)), ("LeftArm", "LeftShoulder", (9.0, 0.0, 0.0)),
+              ("LeftForeArm", "LeftArm", (27.0, 0.0, 0.0)), ("LeftHand", "LeftForeArm", (25.0, 0.0, 0.0)),
+              ("LeftHand_EndSite", "LeftHand", (8.0, 0.0, 0.0)),
+              ("RightShoulder", "Spine1", (-6.0, 11.0, 0.0)), ("RightArm", "RightShoulder", (-9.0, 0.0, 0.0)),
+              ("RightForeArm", "RightArm", (-27.0, 0.0, 0.0)), ("RightHand", "RightForeArm", (-25.0, 0.0, 0.0)),
+              ("RightHand_EndSite", "RightHand", (-8.0, 0.0, 0.0)),
+              ("LeftUpLeg", "Hips", (9.0, -2.0, 0.0)), ("LeftLeg", "LeftUpLeg", (0.0, -42.0, 0.0)),
+              ("LeftFoot", "LeftLeg", (0.0, -40.0, 0.0)), ("LeftToeBase", "LeftFoot", (0.0, -6.0, 12.0)),
+              ("RightUpLeg", "Hips", (-9.0, -2.0, 0.0)), ("RightLeg", "RightUpLeg", (0.0, -42.0, 0.0)),
+              ("RightFoot", "RightLeg", (0.0, -40.0, 0.0)), ("RightToeBase", "RightFoot", (0.0, -6.0, 12.0))]
+    animated = [j[0] for j in joints if not j[0].endswith("EndSite")]   # 21 candidates
+    if n_animated <= 19:                                                  # the toes are the first to go
+        animated = [n for n in animated if not n.endswith("ToeBase")]
+    return joints, animated[:n_animated]

@@ -232,6 +232,37 @@ def direction_2d_error(target_dir_xz, root_quat, ref_dir=(0.0, 0.0, 1.0)):
     return abs(math.degrees(math.acos(cos_angle)))
 
 
+def quaternion_matrix3(q):
+    """Rotation matrix of a (w, x, y, z) quaternion, normalising like transformations.quaternion_matrix
+    (which the reference's FK reaches through anim_utils): q *= sqrt(2 / dot(q, q)), outer products."""
+    q = np.asarray(q, dtype=np.float64)
+    n = np.dot(q, q)
+    q = q * math.sqrt(2.0 / n)
+    o = np.outer(q, q)
+    return np.array([[1.0 - o[2, 2] - o[3, 3], o[1, 2] - o[3, 0], o[1, 3] + o[2, 0]],
+                     [o[1, 2] + o[3, 0], 1.0 - o[1, 1] - o[3, 3], o[2, 3] - o[1, 0]],
+                     [o[1, 3] - o[2, 0], o[2, 3] + o[1, 0], 1.0 - o[1, 1] - o[2, 2]]])
+
+
+def joint_global_position(frame, joints, animated_joints, joint):
+    """SELF-DEFINED forward kinematics (the reference calls anim_utils' SkeletonNode.get_global_position, absent
+    here; PARITY UNPINNED): walk the chain root -> joint with 3x3 matrices, p += R_parent_global @ offset.
+    frame: root translation [0:3] then one (w,x,y,z) per animated joint; joints: [(name, parent, offset)]."""
+    by_name = {j[0]: j for j in joints}
+    chan = {n: 3 + 4 * i for i, n in enumerate(animated_joints)}
+    chain, n = [], joint
+    while n is not None:
+        chain.insert(0, n)
+        n = by_name[n][1]
+    p = np.array(frame[:3], dtype=np.float64)
+    R = np.eye(3)
+    for parent, child in zip(chain[:-1], chain[1:]):
+        if parent in chan:
+            R = R @ quaternion_matrix3(frame[chan[parent]:chan[parent] + 4])
+        p = p + R @ np.asarray(by_name[child][2], dtype=np.float64)
+    return p
+
+
 # --------------------------------------------------------------------------
 # the primitive
 # --------------------------------------------------------------------------
@@ -306,6 +337,17 @@ class OraclePrimitive(object):
                     out[b, ci] = c["weight"] * point_distance(c["target"], frame[:3])
                 else:
                     out[b, ci] = c["weight"] * direction_2d_error(c["target"], frame[3:7], c.get("ref_dir", (0, 0, 1)))
+        return out
+
+    def joint_position_residuals(self, S, constraints, joints, animated_joints):
+        """weight * _point_distance(target, FK position of the joint at the keyframe) per (sample, constraint)."""
+        S = np.atleast_2d(S)
+        out = np.zeros((S.shape[0], len(constraints)))
+        for b in range(S.shape[0]):
+            coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
+            for ci, c in enumerate(constraints):
+                frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
+                out[b, ci] = c["weight"] * point_distance(c["target"], joint_global_position(frame, joints, animated_joints, c["joint"]))
         return out
 
     def log_likelihood_jac(self, S):

@@ -353,3 +353,61 @@ def test_graph_of_primitives_shapes(ctx):
         np.testing.assert_allclose(prim.gmm_log_prob(S, dtype=np.float64), cp.log_prob_f64(S.astype(np.float64)),
                                    rtol=1e-10, atol=1e-8)
         prim.close()
+
+
+def test_joint_position_constraints_forward_kinematics(ctx):
+    """MG_CONSTRAINT_JOINT_POSITION: GlobalTransformConstraint._point_distance on the FK position of any joint
+    (reference two_hand_constraint.py:51-93 / pose_constraint.py:48-67 through anim_utils' get_global_position;
+    PARITY UNPINNED, anim_utils absent).  Pinned by (1) known-answer poses built into a primitive whose mean
+    curve is a chosen pose, (2) an independent rotation-matrix oracle on random candidates, (3) the residual
+    matrix / error sum identity, (4) the root joint agreeing with the FK-free position constraint."""
+    from oracle import mg_oracle as orc
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    assert 3 + 4 * len(animated) == 79 and sk.chain("LeftHand_EndSite")[0] == 0
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(4)
+    S = rng.standard_normal((50, 40))
+    cons = [{"type": "joint_position", "joint": "LeftHand_EndSite", "t": 155.0, "weight": 1.0, "target": [30.0, 90.0, -20.0]},
+            {"type": "joint_position", "joint": "RightFoot", "t": 40.5, "weight": 2.0, "target": [None, 0.0, None]},
+            {"type": "joint_position", "joint": "Head_EndSite", "t": 0.0, "weight": 0.5, "target": [0.0, 160.0, None]},
+            {"type": "joint_position", "joint": "Hips", "t": 77.0, "weight": 1.0, "target": [10.0, None, -5.0]},
+            {"type": "position", "t": 77.0, "weight": 1.0, "target": [10.0, None, -5.0]},
+            {"type": "direction", "t": 155.0, "weight": 0.3, "target": [0.2, 1.0]}]
+    cset = _capi.ConstraintSet(prim, cons, sk)
+    res = prim.score_constraint_residuals(cset, S)
+    ref = op.joint_position_residuals(S, cons[:4], joints, animated)
+    np.testing.assert_allclose(res[:, :4], ref, rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(res[:, 3], res[:, 4], rtol=1e-13, atol=1e-12)       # root joint == FK-free constraint
+    np.testing.assert_allclose(res[:, 4:], op.keyframe_residuals(S, cons[4:]), rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(prim.score_constraints(cset, S), res.sum(axis=1), rtol=1e-13, atol=1e-12)
+    cset.close()
+    with pytest.raises(ValueError):
+        _capi.ConstraintSet(prim, cons[:1])                                          # no skeleton
+    prim.close()
+
+    # known answers: a primitive whose every control point is one pose, zero variance -> FK of that pose
+    tiny = synthetic.make_primitive(seed=2, n_components=3, n_frames=12, n_basis=7, n_dim=79, n_gmm=2, name="tiny79")
+    nb = int(tiny["n_basis_spatial"])
+    pose = np.zeros(79)
+    pose[3::4][:19] = 1.0                                                            # identity quaternions
+    pose[:3] = [1.0, 2.0, 3.0]
+    half = np.sqrt(0.5)
+    for name, quat, expect in (("identity", None, [76.0, 35.0, 3.5]),                # sum of the offsets along the chain
+                               ("hips +90deg about y", (half, 0.0, half, 0.0), [1.5, 35.0, -72.0])):
+        p = pose.copy()
+        if quat is not None:
+            p[3:7] = quat
+        model = dict(tiny)
+        model["mean_spatial_vector"] = np.tile(p, nb)
+        model["eigen_vectors_spatial"] = np.zeros_like(np.asarray(tiny["eigen_vectors_spatial"], dtype=np.float64))
+        model["translation_maxima"] = np.ones(3)
+        pr = _capi.Primitive(ctx, model)
+        cs = _capi.ConstraintSet(pr, [{"type": "joint_position", "joint": "LeftHand_EndSite", "t": 1.0, "weight": 1.0,
+                                       "target": [0.0, 0.0, 0.0]}], sk)
+        d = pr.score_constraints(cs, np.zeros((3, pr.n_components)))
+        np.testing.assert_allclose(d, np.linalg.norm(expect), rtol=1e-12, err_msg=name)
+        cs.close()
+        pr.close()

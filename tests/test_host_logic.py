@@ -183,3 +183,19 @@ def test_batched_jacobian_reproduces_minpack_forward_differences():
         e[j] = h[j]
         np.testing.assert_allclose(J[:, j], (objective(x0 + e, target) - objective(x0, target)) / h[j], rtol=0, atol=1e-6)
     assert J.shape == (7, 4)
+
+
+def test_skeleton_description_for_the_c_abi():
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    assert sk.quat_channel[sk.index("Hips")] == 3 and sk.quat_channel[sk.index("LeftHand_EndSite")] == -1
+    assert [sk.names[j] for j in sk.chain("LeftHand")] == ["Hips", "Spine", "Spine1", "LeftShoulder", "LeftArm", "LeftForeArm", "LeftHand"]
+    d = sk.desc()
+    assert d.n_joints == len(joints) and d.parents and d.offsets and d.quat_channel
+    with pytest.raises(ValueError):
+        _capi.Skeleton([("A", "B", (0, 0, 0)), ("B", None, (0, 0, 0))], ["A"])    # child before parent
+    from morphablegraphs_amd.candidate_scoring import constraints_to_device_form as conv
+
+    class Hand(object):
+        canonical_keyframe, weight_factor, position, orientation, joint_name = 10, 1.0, [1.0, 2.0, 3.0], None, "LeftHand"
+    assert conv([Hand()], "Hips")[0] == {"type": "joint_position", "t": 10.0, "weight": 1.0, "target": [1.0, 2.0, 3.0], "joint": "LeftHand"}

@@ -125,3 +125,26 @@ def test_keyframe_residuals_sum_to_the_evaluate_error():
     res = prim.keyframe_residuals(S, cons)
     assert res.shape == (5, 2)
     np.testing.assert_allclose(res.sum(axis=1), prim.keyframe_errors(S, cons), rtol=1e-14)
+
+
+def test_forward_kinematics_oracle_known_answers():
+    """The self-defined FK oracle (anim_utils is absent): identity pose = sum of offsets along the chain;
+    a quarter turn of the root about y maps (x, z) -> (z, -x); rotating a mid-chain joint moves only what hangs
+    below it; quaternions need not be unit (normalised like transformations.quaternion_matrix)."""
+    from morphablegraphs_amd import synthetic
+    joints, animated = synthetic.make_skeleton()
+    frame = np.zeros(3 + 4 * len(animated))
+    frame[3::4] = 1.0
+    frame[:3] = [1.0, 2.0, 3.0]
+    np.testing.assert_allclose(orc.joint_global_position(frame, joints, animated, "LeftHand_EndSite"), [76.0, 35.0, 3.5], atol=1e-12)
+    np.testing.assert_allclose(orc.joint_global_position(frame, joints, animated, "Hips"), [1.0, 2.0, 3.0], atol=0)
+    f2 = frame.copy()
+    f2[3:7] = [3.0, 0.0, 3.0, 0.0]                                   # unnormalised quarter turn about y
+    np.testing.assert_allclose(orc.joint_global_position(f2, joints, animated, "LeftHand_EndSite"), [1.5, 35.0, -72.0], atol=1e-12)
+    f3 = frame.copy()
+    ch = 3 + 4 * animated.index("LeftArm")
+    f3[ch:ch + 4] = [np.sqrt(0.5), 0.0, 0.0, np.sqrt(0.5)]           # left arm a quarter turn about z: x -> y
+    np.testing.assert_allclose(orc.joint_global_position(f3, joints, animated, "LeftArm"),
+                               orc.joint_global_position(frame, joints, animated, "LeftArm"), atol=1e-12)
+    base = orc.joint_global_position(frame, joints, animated, "LeftArm")
+    np.testing.assert_allclose(orc.joint_global_position(f3, joints, animated, "LeftHand_EndSite"), base + [0.0, 60.0, 0.0], atol=1e-12)
