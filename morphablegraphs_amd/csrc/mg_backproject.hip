@@ -125,6 +125,15 @@ __device__ __forceinline__ void mg_wait_producers(const mg_lds_int *prog, int ta
     }
     asm volatile("" ::: "memory");
 }
+__device__ __forceinline__ void mg_wait_row_producers(const mg_lds_int *prog, int target) {   // waves 1..3
+    for (;;) {
+        const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
+        const int m = min(v[1], min(v[2], v[3]));
+        if (__builtin_amdgcn_readfirstlane(m) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void mg_wait_consumers(const mg_lds_int *prog, int target) {   // waves 4..11
     for (;;) {
         const i32x4 v = *(const volatile mg_lds_i32x4 *)(prog + 4);
@@ -199,7 +208,7 @@ __device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {
 // compiler drain it with vmcnt(0) at the loop top.
 template <int KK>
 __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, const float *__restrict__ mean32,
-                                               const mg_chunk &ck, float *lds_c, int stride, int pw, int npw,
+                                               const mg_chunk &ck, float *lds_c, int stride, int t_first, int pw, int npw,
                                                const float (&sfrag)[KK], int lane, int cl, int g) {
     float2 fa[2][KK / 2], na[2][KK / 2];
     f32x4 fm[2], nm[2];
@@ -210,7 +219,7 @@ __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, co
         for (int q = 0; q < KK / 2; q++) fr[q] = p[q * 64];
         cin = *(const f32x4 *)(mean32 + (size_t)(ck.rt0 + tc) * 16 + 4 * g);
     };
-    int t = pw;
+    int t = t_first + pw;   // tiles below t_first are carried over from the previous unit's window
     load_tile(t, fa[0], fm[0]);
     load_tile(t + npw, fa[1], fm[1]);
     while (t < ck.ntiles) {
@@ -436,8 +445,28 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     asm volatile("" : "+v"(g_op));
                     mg_load_sfrag<KK, LAT_F64>(sfrag, lat, un, a.ld, L, cl, g_op);
                 }
-                mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g);
+                // Consecutive chunks of a tile share basis functions (windows of 8 advance by 5): the row tiles this
+                // unit has in common with the previous one are copied from the previous slot (LDS -> LDS, the same
+                // bits) instead of being recomputed: 37 % fewer MFMAs and E' fragment loads, which is what slows
+                // the sweep waves down (matrix-pipe time on the shared SIMDs, L2 requests in the store path).
+                int n_ov = 0, src_shift = 0;
+                if (u > 0 && un.chunk > 0 && !(a.debug & 128)) {
+                    const mg_chunk pk = chunks[un.chunk - 1];
+                    n_ov = pk.rt0 + pk.ntiles - ck.rt0;
+                    n_ov = n_ov < 0 ? 0 : (n_ov > ck.ntiles ? ck.ntiles : n_ov);
+                    src_shift = ck.rt0 - pk.rt0;
+                }
+                // this slot was the copy source of unit u - nbuf + 1: every row producer must be past that unit
+                if (u >= 2) mg_wait_row_producers(prog, u - 1);
+                mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, n_ov, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g);
                 MG_STAMP(2);
+                if (n_ov > 0) {
+                    mg_wait_row_producers(prog, u);   // the previous unit's window is complete
+                    const float *lds_p = (const float *)(smem + (size_t)(slot == 0 ? nbuf - 1 : slot - 1) * buf_bytes);
+                    for (int t = wave - 1; t < n_ov; t += MG_WS_NPW - 1)
+                        *(f32x4 *)&lds_c[cl * stride + t * 16 + 4 * g] = *(const f32x4 *)&lds_p[cl * stride + (t + src_shift) * 16 + 4 * g];
+                }
+                MG_STAMP(3);
             }
             mg_publish(prog, wave, lane, u + 1);
             if (++slot == nbuf) slot = 0;
