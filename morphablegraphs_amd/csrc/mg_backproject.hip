@@ -58,7 +58,8 @@ extern "C" int mg_debug_dump_stamps(void) {
     unsigned long long h[16][8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(mg_dbg_stamps), sizeof(h)) != hipSuccess) return -1;
     printf("per-wave cycles summed over the units of workgroup 0; phase p = time from stamp p-1 to stamp p\n");
-    printf("  (0: loop top, 1: loads issued / root taps, 2: MFMA, 3: root staging, 4: consume / work end, 5: barrier wait)\n");
+    printf("  (0: loop top, 1: sweep: wait for producers, 2: row producers: tiles, 3: row producers: carried tiles / wave 0: root stage,\n"
+           "   4: sweep / publish, 5: producers: wait for a free slot; sweep: publish)\n");
     for (int w = 0; w < 12; w++) {
         printf("wave %2d:", w);
         for (int ph = 0; ph < 8; ph++) printf(" %9llu", h[w][ph]);
@@ -82,8 +83,9 @@ extern "C" int mg_debug_dump_stamps(void) {
 //                        v_mfma_f64_16x16x4_f64 (C-in = mean') -> rs; their spline taps by a second f64
 //                        MFMA (banded weight matrix) -> float32 root outputs ro[slot]
 //   producer waves 1-3 : unit u's window of padded coefficient rows by v_mfma_f32_16x16x4_f32
-//                        (A = E' fragments from L2, two tiles in flight + two prefetched; B = the
-//                        latent tile in registers; C-in = mean') -> buf[slot] [cand][i*Dp + d + cshift]
+//                        (A = E' fragments from L2, two tiles per round; B = the latent tile in
+//                        registers; C-in = mean') -> buf[slot] [cand][i*Dp + d + cshift]; the row tiles the
+//                        window shares with the previous chunk's are copied from the previous slot
 //   consumer waves 4-11: the "quad-row" sweep of a finished unit: a wave owns two candidates; a lane owns 4
 //                        consecutive channels of one sample (4 ds_read_b128 taps, 16 FMAs, one
 //                        dwordx4 store), the last lane of each row group owns the root channels;
@@ -92,9 +94,11 @@ extern "C" int mg_debug_dump_stamps(void) {
 //   No s_barrier in the unit loop: the slots form a ring of nbuf (3 when LDS allows, else 2) and the roles
 //   hand units over through per-wave progress counters in LDS (mg_publish / mg_wait_*), so a slow consumer
 //   wave delays only the recycling of its slot and the consumers' stores stay in flight throughout.
+//   FUSE_GMM: after their last unit the producer waves score the workgroup's candidates against the mixture.
 //
 // LDS: buf[nbuf] = image [16][stride] f32; ro[nbuf] = root outputs [16][MG_MAX_NT][4] f32; tb[nbuf] = w32
-// [MG_MAX_NT] float4 + image tap byte offsets [MG_MAX_NT] int; rs = float64 root image; prog = 16 counters.
+// [MG_MAX_NT] float4 + image tap byte offsets [MG_MAX_NT] int; rs = float64 root image; prog = 32 counters
+// (producer/consumer progress, mixture hand-off); FUSE_GMM: mixture terms and exponentials [2][K*16] f64 each.
 // -----------------------------------------------------------------------------------------
 #define MG_FUSE_MAX_KK 10   // fused mixture scoring: k-steps (4 latent components each) that fit the register budget
 #define MG_WS_NPW 4      // producer waves
@@ -204,8 +208,9 @@ __device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {
 // One wave's share of a unit's float32 coefficient window: row tiles pw, pw + npw, pw + 2 npw, ... of the
 // window, each D = E'tile (16 x 4KK) . latent tile (4KK x 16) + mean' by KK chained v_mfma_f32_16x16x4_f32,
 // written as four consecutive padded rows per lane (conflict-free since stride = 4 mod 32).
-// Two tiles in flight, the next two prefetched unconditionally (clamped): a conditional prefetch makes the
-// compiler drain it with vmcnt(0) at the loop top.
+// Two tiles per round, the next two requested unconditionally (clamped) before the MFMAs of the current two
+// issue: a conditional prefetch makes the compiler drain it with vmcnt(0) at the loop top.  (The compiler still
+// folds the two register sets into one, so a round costs one L2 round trip + its MFMAs)
 template <int KK>
 __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, const float *__restrict__ mean32,
                                                const mg_chunk &ck, float *lds_c, int stride, int t_first, int pw, int npw,
