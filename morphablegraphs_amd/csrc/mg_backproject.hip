@@ -457,9 +457,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 int n_ov = 0, src_shift = 0;
                 if (u > 0 && un.chunk > 0 && !(a.debug & 128)) {
                     const mg_chunk pk = chunks[un.chunk - 1];
-                    n_ov = pk.rt0 + pk.ntiles - ck.rt0;
-                    n_ov = n_ov < 0 ? 0 : (n_ov > ck.ntiles ? ck.ntiles : n_ov);
                     src_shift = ck.rt0 - pk.rt0;
+                    n_ov = pk.rt0 + pk.ntiles - ck.rt0;   // tiles [ck.rt0, pk.rt0 + pk.ntiles) exist in the previous slot
+                    n_ov = (n_ov < 0 || src_shift < 0) ? 0 : (n_ov > ck.ntiles ? ck.ntiles : n_ov);   // a grid may run backwards
                 }
                 // this slot was the copy source of unit u - nbuf + 1: every row producer must be past that unit
                 if (u >= 2) mg_wait_row_producers(prog, u - 1);

@@ -411,3 +411,24 @@ def test_joint_position_constraints_forward_kinematics(ctx):
         np.testing.assert_allclose(d, np.linalg.norm(expect), rtol=1e-12, err_msg=name)
         cs.close()
         pr.close()
+
+
+def test_time_grids_that_run_backwards_or_jump(ctx):
+    """Caller-defined time grids (MotionSpline.evaluate(t), reference motion_spline.py:89-92) need not be increasing:
+    the persistent kernel carries row tiles over between consecutive chunks only when the next window starts at or
+    after the previous one.  Descending, shuffled and repeated sample times on the MFMA path, bit for bit."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(8)
+    S = rng.standard_normal((40, 40)).astype(np.float32)
+    grids = {"descending": np.linspace(155.0, 0.0, 97), "shuffled": rng.permutation(np.linspace(0.0, 155.0, 120)),
+             "repeated": np.repeat(np.linspace(3.0, 150.0, 9), 11), "zigzag": np.concatenate([np.linspace(0, 155, 40), np.linspace(155, 0, 40)])}
+    for name, times in grids.items():
+        grid = _capi.TimeGrid(prim, times)
+        model = cp.frames_f32model(S.astype(np.float64), tp=times)
+        for path in (_capi.MG_PATH_MFMA, _capi.MG_PATH_DIRECT):
+            got = prim.back_project_frames(S, grid=grid, path=path)
+            np.testing.assert_array_equal(_bits(got), _bits(model), err_msg="%s path %d" % (name, path))
+        grid.close()
+    prim.close()
