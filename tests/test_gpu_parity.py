@@ -67,6 +67,13 @@ def test_frames_f64_and_coeffs_golden(ctx, golden_case):
     np.testing.assert_allclose(coeffs, g["coeffs"], rtol=0, atol=4e-12 * scale)
     c32 = prim.back_project_coeffs(g["S"], dtype=np.float32)
     assert np.all(np.abs(c32 - g["coeffs"]) <= pose_tol(g["coeffs"]))
+    # a batch large enough for the persistent kernel (identity "time grid" over the control points, carried-over
+    # tiles included): same bits as the small-batch direct kernel row by row, same tolerance against float64
+    S64 = np.tile(g["S"], (16, 1))
+    big = prim.back_project_coeffs(S64, dtype=np.float32)
+    np.testing.assert_array_equal(_bits(big), _bits(np.tile(c32, (16, 1, 1))), err_msg=name)
+    ref64 = prim.back_project_coeffs(S64)
+    assert np.all(np.abs(big - ref64) <= pose_tol(ref64))
     prim.close()
 
 
