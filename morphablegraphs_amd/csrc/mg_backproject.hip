@@ -461,8 +461,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     n_ov = pk.rt0 + pk.ntiles - ck.rt0;   // tiles [ck.rt0, pk.rt0 + pk.ntiles) exist in the previous slot
                     n_ov = (n_ov < 0 || src_shift < 0) ? 0 : (n_ov > ck.ntiles ? ck.ntiles : n_ov);   // a grid may run backwards
                 }
-                // this slot was the copy source of unit u - nbuf + 1: every row producer must be past that unit
-                if (u >= 2) mg_wait_row_producers(prog, u - 1);
+                // this slot held unit u - nbuf and was the copy source of unit u - nbuf + 1: every row producer must
+                // have finished that unit before the slot is overwritten (with two slots: a full meeting per unit)
+                if (u >= nbuf - 1) mg_wait_row_producers(prog, u - nbuf + 2);
                 mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, n_ov, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g);
                 MG_STAMP(2);
                 if (n_ov > 0) {

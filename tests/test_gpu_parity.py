@@ -439,3 +439,24 @@ def test_time_grids_that_run_backwards_or_jump(ctx):
             np.testing.assert_array_equal(_bits(got), _bits(model), err_msg="%s path %d" % (name, path))
         grid.close()
     prim.close()
+
+
+def test_two_slot_ring(ctx, monkeypatch):
+    """Shapes whose three LDS slots do not fit 160 KiB run a two-slot ring; MG_NBUF=2 forces it on 'walk' (the
+    planner reads it when a grid is built).  Carried-over tiles then need a full meeting of the row producers per
+    unit: ragged and multi-tile batches, the fused step, repeated launches, bit for bit."""
+    monkeypatch.setenv("MG_NBUF", "2")
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)          # canonical grid planned under MG_NBUF=2
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(12)
+    for B in (17, 1000, 4099):
+        S = rng.standard_normal((B, 40)).astype(np.float32)
+        model = cp.frames_f32model(S[:600].astype(np.float64))
+        for rep in range(3):
+            got = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+            np.testing.assert_array_equal(_bits(got[:600]), _bits(model), err_msg="B=%d rep=%d" % (B, rep))
+        frames, logp = _fused_step(ctx, prim, S, 156, 79)
+        np.testing.assert_array_equal(_bits(frames), _bits(got))
+        np.testing.assert_array_equal(_bits(logp), _bits(prim.gmm_log_prob(S, dtype=np.float32)))
+    prim.close()
