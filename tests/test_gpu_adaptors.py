@@ -398,3 +398,46 @@ def test_motion_state_graph_from_zip(tmp_path):
         np.testing.assert_allclose(frames, ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
     np.testing.assert_allclose(graph.nodes[("walk", "leftStance")].cluster_tree.data, tree_samples, rtol=0, atol=0)
     graph.close()
+
+
+def test_baseline_config_sizes_graph_walk_step_and_optimizer_batch():
+    """BASELINE.json configs[2] and [4] at their stated sizes, through size-independent checks: a graph-walk step over
+    the 16 primitives of a MotionStateGraph with 4096 candidates per option (winner and error of every option against
+    the C oracle's per-sample loop), and a 128k-candidate optimizer batch of the objective (a seeded subset against
+    the oracle, the rest through the identity objective = error_scale * sum(residuals) - quality_scale * log p)."""
+    from morphablegraphs_amd import objective_functions as of
+    prims = synthetic.make_graph_primitives(16)
+    pset = HipPrimitiveSet(prims)
+    names = [p["name"] for p in prims]
+    cons = {n: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]},
+                {"type": "direction", "t": 0.5 * float(p["n_canonical_frames"] - 1), "weight": 0.2, "target": [0.0, 1.0]}]
+            for n, p in zip(names, prims)}
+    best, results = pset.evaluate_options(names, cons, n_samples=4096, rng_seed=3)
+    for n, p in zip(names, prims):
+        cp = c_oracle.COraclePrimitive(p)
+        np.random.seed(3)
+        S = pset.nodes[n].sample_low_dimensional_vector(4096)
+        t = float(p["n_canonical_frames"] - 1)
+        ref = cp.keyframe_errors_f64(S, np.array([[0, t, 1.0, 10.0, np.nan, 5.0, 0, 0], [1, 0.5 * t, 0.2, 0.0, 1.0, 0.0, 0.0, 1.0]]))
+        idx = int(np.argmin(ref))
+        assert abs(results[n][1] - ref[idx]) <= 1e-9 * max(1.0, ref[idx])
+        np.testing.assert_array_equal(results[n][0], S[idx])
+    assert best == names[int(np.argmin([results[n][1] for n in names]))]
+
+    data = synthetic.make_walk_primitive(seed=0)
+    mp = _primitive(data)
+    cp = c_oracle.COraclePrimitive(data)
+    B = 128 * 1024
+    rng = np.random.default_rng(17)
+    S = (0.5 * rng.standard_normal((B, 40))).astype(np.float32)
+    wcons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+             {"type": "direction", "t": 155.0, "weight": 0.5, "target": [0.5, 1.0]}]
+    obj = of.obj_spatial_error_sum_and_naturalness(S, (mp, wcons, None, 2.0, 0.1, 1.0))
+    res = of.obj_spatial_error_residual_vector(S, (mp, wcons, None, 2.0, 0.1, 1.0))
+    lp = mp._prim.gmm_log_prob(S, dtype=np.float64)
+    assert obj.shape == (B,) and res.shape == (B, 40) and np.isfinite(obj).all()
+    np.testing.assert_allclose(obj, 2.0 * res[:, :2].sum(axis=1) - 0.1 * lp, rtol=1e-12, atol=1e-9)
+    idx = rng.choice(B, size=64, replace=False)
+    ref = cp.keyframe_errors_f64(S[idx].astype(np.float64), np.array([[0, 155.0, 1.0, 40.0, np.nan, -30.0, 0, 0], [1, 155.0, 0.5, 0.5, 1.0, 0.0, 0.0, 1.0]]))
+    np.testing.assert_allclose(res[idx, :2].sum(axis=1), ref, rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(lp[idx], cp.log_prob_f64(S[idx].astype(np.float64)), rtol=1e-10, atol=1e-8)
