@@ -20,27 +20,31 @@ struct mg_score_args {
     int32_t n, nch, L;
 };
 
-// lane-per-candidate; the latent tile is staged in LDS ([256][L+1] float64), the fused
-// keyframe matrices are wave-uniform (scalar loads).
+// One workgroup = 64 candidates (a lane each) x 4 waves that deal the constraints round-robin, so a batch of
+// 8192 fills 128 CUs x 4 SIMDs instead of 32 workgroups.  The latent tile is staged in LDS ([64][L+1] float64),
+// the fused keyframe matrices are wave-uniform (scalar loads); every weighted residual meets in LDS ([n][64])
+// and lane-owners sum them in constraint order (the order MotionPrimitiveConstraints.evaluate adds them in).
+#define MG_SC_CANDS 64
+#define MG_SC_WAVES 4
 template <bool LAT_F64, bool OUT_F64>
-__global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
+__global__ __launch_bounds__(MG_SC_CANDS *MG_SC_WAVES) void mg_score_kernel(mg_score_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = a.L, xs = L + 1;
-    double *lds_x = (double *)smem;
-    const int tid = threadIdx.x;
-    const int64_t b0 = (int64_t)blockIdx.x * 256;
-    const int ncand = (int)((a.B - b0) < 256 ? (a.B - b0) : 256);
-    for (int e = tid; e < 256 * L; e += 256) {
+    double *lds_x = (double *)smem;                       // [64][L+1]
+    double *lds_r = lds_x + MG_SC_CANDS * xs;             // [n][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b0 = (int64_t)blockIdx.x * MG_SC_CANDS;
+    const int ncand = (int)((a.B - b0) < MG_SC_CANDS ? (a.B - b0) : MG_SC_CANDS);
+    for (int e = tid; e < MG_SC_CANDS * L; e += MG_SC_CANDS * MG_SC_WAVES) {
         int c = e / L, i = e - c * L;
         double v = 0.0;
         if (c < ncand) v = LAT_F64 ? ((const double *)a.lat)[(b0 + c) * a.ld + i] : (double)((const float *)a.lat)[(b0 + c) * a.ld + i];
         lds_x[c * xs + i] = v;
     }
     __syncthreads();
-    if (tid >= ncand) return;
-    const double *x = lds_x + tid * xs;
-    double err = 0.0;
-    for (int c = 0; c < a.n; c++) {
+    const double *x = lds_x + lane * xs;
+    for (int c = wave; c < a.n; c += MG_SC_WAVES) {
         const double *par = a.par + (size_t)c * 8;
         const int type = (int)par[0];
         double fr[7];
@@ -81,9 +85,7 @@ __global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
                 double t = par[2 + i];
                 if (t == t) ds += (t - pj[i]) * (t - pj[i]);
             }
-            const double e = par[1] * sqrt(ds);
-            err += e;
-            if (a.res) a.res[(b0 + tid) * a.n + c] = e;
+            lds_r[c * MG_SC_CANDS + lane] = par[1] * sqrt(ds);
             continue;
         }
         const int d_lo = (type == MG_CONSTRAINT_POSITION) ? 0 : 3;
@@ -100,9 +102,7 @@ __global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
                 double t = par[2 + i];
                 if (t == t) ds += (t - fr[i]) * (t - fr[i]);
             }
-            const double e = par[1] * sqrt(ds);
-            err += e;
-            if (a.res) a.res[(b0 + tid) * a.n + c] = e;
+            lds_r[c * MG_SC_CANDS + lane] = par[1] * sqrt(ds);
         } else {
             // heading = xz of (rotation of the root quaternion (w,x,y,z)) applied to ref_dir
             const double qw = fr[3], qx = fr[4], qy = fr[5], qz = fr[6];
@@ -116,12 +116,18 @@ __global__ __launch_bounds__(256) void mg_score_kernel(mg_score_args a) {
             const double mx = px / mn, mz = pz / mn;
             double cosang = (tx * mx + tz * mz) / (sqrt(tx * tx + tz * tz) * sqrt(mx * mx + mz * mz));
             cosang = fmin(1.0, fmax(cosang, -1.0));
-            const double e = par[1] * fabs(acos(cosang) * (180.0 / M_PI));
-            err += e;
-            if (a.res) a.res[(b0 + tid) * a.n + c] = e;
+            lds_r[c * MG_SC_CANDS + lane] = par[1] * fabs(acos(cosang) * (180.0 / M_PI));
         }
     }
-    if (a.out) {
+    __syncthreads();
+    if (a.res)   // (n_samples, n) row-major: consecutive threads write consecutive constraints of a candidate
+        for (int e = tid; e < ncand * a.n; e += MG_SC_CANDS * MG_SC_WAVES) {
+            const int cand = e / a.n, c = e - cand * a.n;
+            a.res[(b0 + cand) * a.n + c] = lds_r[c * MG_SC_CANDS + cand];
+        }
+    if (a.out && tid < ncand) {
+        double err = 0.0;
+        for (int c = 0; c < a.n; c++) err += lds_r[c * MG_SC_CANDS + tid];
         if (OUT_F64) ((double *)a.out)[b0 + tid] = err;
         else ((float *)a.out)[b0 + tid] = (float)err;
     }
@@ -131,9 +137,9 @@ int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *la
     mg_score_args a;
     a.res = res;
     a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
-    size_t lds = (size_t)256 * (p->L + 1) * 8;
-    if (lds > 150 * 1024) { mg_set_error("mg_score_constraints: n_components %d too large", p->L); return MG_ERR_UNSUPPORTED; }
-    int64_t grid = (B + 255) / 256;
+    size_t lds = ((size_t)MG_SC_CANDS * (p->L + 1) + (size_t)std::max(cs->n, 1) * MG_SC_CANDS) * 8;
+    if (lds > 150 * 1024) { mg_set_error("mg_score_constraints: n_components %d x %d constraints too large for LDS", p->L, cs->n); return MG_ERR_UNSUPPORTED; }
+    int64_t grid = (B + MG_SC_CANDS - 1) / MG_SC_CANDS;
     if (grid > 0x7fffffff) { mg_set_error("mg_score_constraints: too many samples"); return MG_ERR_UNSUPPORTED; }
     hipStream_t st = p->ctx->stream;
     const bool lf = ldt == MG_F64, of = odt == MG_F64;
@@ -143,10 +149,10 @@ int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *la
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    if (lf && of) hipLaunchKernelGGL((mg_score_kernel<true, true>), dim3((int)grid), dim3(256), lds, st, a);
-    else if (lf) hipLaunchKernelGGL((mg_score_kernel<true, false>), dim3((int)grid), dim3(256), lds, st, a);
-    else if (of) hipLaunchKernelGGL((mg_score_kernel<false, true>), dim3((int)grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((mg_score_kernel<false, false>), dim3((int)grid), dim3(256), lds, st, a);
+    if (lf && of) hipLaunchKernelGGL((mg_score_kernel<true, true>), dim3((int)grid), dim3(MG_SC_CANDS * MG_SC_WAVES), lds, st, a);
+    else if (lf) hipLaunchKernelGGL((mg_score_kernel<true, false>), dim3((int)grid), dim3(MG_SC_CANDS * MG_SC_WAVES), lds, st, a);
+    else if (of) hipLaunchKernelGGL((mg_score_kernel<false, true>), dim3((int)grid), dim3(MG_SC_CANDS * MG_SC_WAVES), lds, st, a);
+    else hipLaunchKernelGGL((mg_score_kernel<false, false>), dim3((int)grid), dim3(MG_SC_CANDS * MG_SC_WAVES), lds, st, a);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
