@@ -85,14 +85,16 @@ __global__ __launch_bounds__(MG_GMM_CANDS *MG_GMM_WAVES) void mg_gmm_logp_kernel
 // One workgroup = 16 candidates; y for all components in LDS; float64 throughout.
 // -----------------------------------------------------------------------------------------
 #define MG_JAC_CANDS 16
+#define MG_JAC_ITEMS 4   // (candidate, dimension) outputs per thread: 16 L / 256 rounded up, L <= 64
 template <bool X_F64>
 __global__ __launch_bounds__(256) void mg_gmm_jac_kernel(mg_gmm_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int L = a.L, K = a.K;
+    const int L = a.L, K = a.K, ps = L + 1;
     double *lds_x = (double *)smem;                             // [16][L]
     double *lds_y = lds_x + MG_JAC_CANDS * L;                   // [K][16][L]
     double *lds_t = lds_y + (size_t)K * MG_JAC_CANDS * L;       // [K][16] terms, then responsibilities
     double *lds_lp = lds_t + K * MG_JAC_CANDS;                  // [16] log p
+    double *lds_P = lds_lp + MG_JAC_CANDS;                      // [L][L+1]: column j of P_k at j*(L+1), staged per component
     const int tid = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * MG_JAC_CANDS;
     const int ncand = (int)((a.B - b0) < MG_JAC_CANDS ? (a.B - b0) : MG_JAC_CANDS);
@@ -102,21 +104,32 @@ __global__ __launch_bounds__(256) void mg_gmm_jac_kernel(mg_gmm_args a) {
         if (c < ncand) v = X_F64 ? ((const double *)a.x)[(b0 + c) * a.ld + i] : (double)((const float *)a.x)[(b0 + c) * a.ld + i];
         lds_x[e] = v;
     }
-    __syncthreads();
-    // y[k][c][j] = sum_{i <= j} x[c][i] P_k[i][j] - (mu_k P_k)[j]   (P_k upper triangular, column j contiguous)
-    for (int e = tid; e < K * MG_JAC_CANDS * L; e += 256) {
-        const int j = e % L, kc = e / L, c = kc % MG_JAC_CANDS, k = kc / MG_JAC_CANDS;
-        const double *col = a.P + ((size_t)k * L + j) * L;
-        const double *xr = lds_x + c * L;
-        double y = -a.mP[(size_t)k * L + j];
-        for (int i = 0; i <= j; i++) y = fma(xr[i], col[i], y);
-        lds_y[e] = y;
+    auto stage_P = [&](int k) {   // coalesced copy of P_k (column j contiguous over i) into the padded LDS image
+        const double *Pk = a.P + (size_t)k * L * L;
+        for (int e = tid; e < L * L; e += 256) {
+            const int jj = e / L, ii = e - jj * L;
+            lds_P[jj * ps + ii] = Pk[e];
+        }
+    };
+    // pass 1: y[k][c][j] = sum_{i <= j} x[c][i] P_k[i][j] - (mu_k P_k)[j]   (P_k upper triangular)
+    for (int k = 0; k < K; k++) {
+        __syncthreads();
+        stage_P(k);
+        __syncthreads();
+        for (int e = tid; e < MG_JAC_CANDS * L; e += 256) {
+            const int c = e / L, jj = e - c * L;
+            const double *col = lds_P + jj * ps;
+            const double *xr = lds_x + c * L;
+            double y = -a.mP[(size_t)k * L + jj];
+            for (int i = 0; i <= jj; i++) y = fma(xr[i], col[i], y);
+            lds_y[((size_t)k * MG_JAC_CANDS + c) * L + jj] = y;
+        }
     }
     __syncthreads();
     for (int e = tid; e < K * MG_JAC_CANDS; e += 256) {
         const double *yr = lds_y + (size_t)e * L;
         double maha = 0.0;
-        for (int j = 0; j < L; j++) maha = fma(yr[j], yr[j], maha);
+        for (int jj = 0; jj < L; jj++) maha = fma(yr[jj], yr[jj], maha);
         lds_t[e] = a.cst[e / MG_JAC_CANDS] - 0.5 * maha;
     }
     __syncthreads();
@@ -136,25 +149,34 @@ __global__ __launch_bounds__(256) void mg_gmm_jac_kernel(mg_gmm_args a) {
         const double lp = lds_lp[e % MG_JAC_CANDS];
         lds_t[e] = (lp == -INFINITY) ? 0.0 : exp(lds_t[e] - lp);   // responsibility r_k
     }
-    __syncthreads();
-    // jac[c][i] = sum_k r[k][c] sum_{j >= i} P_k[i][j] y[k][c][j]
-    for (int e = tid; e < MG_JAC_CANDS * L; e += 256) {
-        const int c = e / L, i = e - c * L;
-        if (c >= ncand) continue;
-        double g;
-        if (exp(lds_lp[c]) == 0.0) {
-            g = 1.0;   // the reference: denominator == 0 -> np.ones(s.shape)
-        } else {
-            g = 0.0;
-            for (int k = 0; k < K; k++) {
+    // pass 2: jac[c][i] = sum_k r[k][c] sum_{j >= i} P_k[i][j] y[k][c][j], components in order
+    double g[MG_JAC_ITEMS];
+#pragma unroll
+    for (int q = 0; q < MG_JAC_ITEMS; q++) g[q] = 0.0;
+    for (int k = 0; k < K; k++) {
+        __syncthreads();
+        stage_P(k);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MG_JAC_ITEMS; q++) {
+            const int e = tid + 256 * q;
+            if (e < MG_JAC_CANDS * L) {
+                const int c = e / L, i = e - c * L;
                 const double *yr = lds_y + ((size_t)k * MG_JAC_CANDS + c) * L;
-                const double *Pk = a.P + (size_t)k * L * L;
                 double z = 0.0;
-                for (int j = i; j < L; j++) z = fma(Pk[(size_t)j * L + i], yr[j], z);
-                g = fma(lds_t[k * MG_JAC_CANDS + c], z, g);
+                for (int jj = i; jj < L; jj++) z = fma(lds_P[jj * ps + i], yr[jj], z);
+                g[q] = fma(lds_t[k * MG_JAC_CANDS + c], z, g[q]);
             }
         }
-        ((double *)a.out)[(b0 + c) * L + i] = g;
+    }
+#pragma unroll
+    for (int q = 0; q < MG_JAC_ITEMS; q++) {
+        const int e = tid + 256 * q;
+        if (e < MG_JAC_CANDS * L) {
+            const int c = e / L, i = e - c * L;
+            if (c < ncand)   // the reference: denominator exp(score) == 0 -> np.ones(s.shape)
+                ((double *)a.out)[(b0 + c) * L + i] = (exp(lds_lp[c]) == 0.0) ? 1.0 : g[q];
+        }
     }
 }
 
@@ -162,8 +184,8 @@ int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_
     mg_gmm_args a;
     a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
     const int64_t grid = (B + MG_JAC_CANDS - 1) / MG_JAC_CANDS;
-    const size_t lds = ((size_t)MG_JAC_CANDS * p->L * (1 + p->K) + (size_t)p->K * MG_JAC_CANDS + MG_JAC_CANDS) * 8;
-    if (lds > 150 * 1024 || grid > 0x7fffffff) {
+    const size_t lds = ((size_t)MG_JAC_CANDS * p->L * (1 + p->K) + (size_t)p->K * MG_JAC_CANDS + MG_JAC_CANDS + (size_t)p->L * (p->L + 1)) * 8;
+    if (lds > 150 * 1024 || grid > 0x7fffffff || MG_JAC_CANDS * p->L > 256 * MG_JAC_ITEMS) {
         mg_set_error("mg_gmm_log_prob_jac: n_components %d x n_gmm %d too large for the LDS-staged kernel", p->L, p->K);
         return MG_ERR_UNSUPPORTED;
     }
