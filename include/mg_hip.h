@@ -251,6 +251,11 @@ int mg_argmin_first_dev(mg_context *ctx, const void *values_dev, int dtype, int6
 int mg_step_frames_and_logp(mg_primitive *prim, const void *latents_dev, int latent_dtype,
                             int64_t n_samples, int64_t ld, float *frames_dev, float *logp_dev);
 
+/* evaluate_samples_using_constraints (reference motion_primitive_generator.py:230-261) in one call: score all
+ * candidates against the set, first-minimum argmin, result on the host (no allocation, one synchronisation). */
+int mg_best_candidate(mg_primitive *prim, const mg_constraint_set *cs, const void *latents_dev, int latent_dtype,
+                      int64_t n_samples, int64_t ld, int64_t *best_index, double *min_error);
+
 /* ---- host-pointer convenience variants (H2D, launch, D2H, synchronise) ---------------- */
 int mg_back_project_frames_host(mg_primitive *prim, const mg_time_grid *grid, const void *latents,
                                 int latent_dtype, int64_t n_samples, int64_t ld, float *frames, int path);
@@ -266,6 +271,8 @@ int mg_gmm_sample_host(mg_primitive *prim, int64_t n_samples, const int64_t *cou
                        void *x, int x_dtype, int64_t ld, int32_t *component);
 int mg_score_constraints_host(mg_primitive *prim, const mg_constraint_set *cs, const void *latents,
                               int latent_dtype, int64_t n_samples, int64_t ld, void *errors, int out_dtype);
+int mg_best_candidate_host(mg_primitive *prim, const mg_constraint_set *cs, const void *latents, int latent_dtype,
+                           int64_t n_samples, int64_t ld, int64_t *best_index, double *min_error);
 int mg_score_constraint_residuals_host(mg_primitive *prim, const mg_constraint_set *cs, const void *latents,
                                        int latent_dtype, int64_t n_samples, int64_t ld, double *residuals);
 int mg_gmm_log_prob_jac_host(mg_primitive *prim, const void *x, int x_dtype, int64_t n_samples, int64_t ld,

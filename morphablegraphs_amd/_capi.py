@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
-    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk",
+    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_best_candidate", "mg_best_candidate_host",
 ]
 
 
@@ -158,6 +158,8 @@ def load_library(path=None):
         "mg_score_constraints_host": [vp, vp, vp, i32, i64, i64, vp, i32],
         "mg_score_constraint_residuals": [vp, vp, vp, i32, i64, i64, vp],
         "mg_constraint_set_create_fk": [vp, vp, vp, i32, vp],
+        "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
+        "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
         "mg_score_constraint_residuals_host": [vp, vp, vp, i32, i64, i64, vp],
         "mg_gmm_log_prob_jac_host": [vp, vp, i32, i64, i64, vp],
@@ -515,6 +517,21 @@ class Primitive(object):
                                                   _dtype_code(out)))
         return out
 
+    def best_candidate(self, cset, S):
+        """(best_index, min_error) of the reference's candidate loop (first minimum) for host latents S."""
+        S = _latents(S)
+        idx, val = C.c_int64(), C.c_double()
+        _check(self.lib.mg_best_candidate_host(self.handle, cset.handle, S.ctypes.data_as(C.c_void_p), _dtype_code(S),
+                                               S.shape[0], S.shape[1], C.byref(idx), C.byref(val)))
+        return idx.value, val.value
+
+    def best_candidate_dev(self, cset, lat_dev, lat_dtype, n, ld):
+        lc = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        idx, val = C.c_int64(), C.c_double()
+        _check(self.lib.mg_best_candidate(self.handle, cset.handle, _dev_ptr(lat_dev), lc, int(n), int(ld),
+                                          C.byref(idx), C.byref(val)))
+        return idx.value, val.value
+
     def score_constraint_residuals(self, cset, S):
         """(n_samples, n_constraints) float64: weight_c * error_c per sample (get_residual_vector, batched)."""
         S = _latents(S)
@@ -542,6 +559,14 @@ class Primitive(object):
         xc = MG_F64 if np.dtype(x_dtype) == np.float64 else MG_F32
         oc = MG_F64 if np.dtype(out_dtype) == np.float64 else MG_F32
         _check(self.lib.mg_gmm_log_prob(self.handle, _dev_ptr(x_dev), xc, int(n), int(ld), _dev_ptr(out_dev), oc))
+
+    def gmm_sample_dev(self, counts, seed, x_dev, x_dtype, ld, component_dev=None):
+        """Device Philox sampler into device memory: rows grouped by component like sklearn's sample()."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        xc = MG_F64 if np.dtype(x_dtype) == np.float64 else MG_F32
+        comp = _dev_ptr(component_dev) if component_dev is not None else C.c_void_p(0)
+        _check(self.lib.mg_gmm_sample(self.handle, int(counts.sum()), counts.ctypes.data_as(C.c_void_p),
+                                      C.c_uint64(int(seed)), _dev_ptr(x_dev), xc, int(ld), comp))
 
     def score_constraints_dev(self, cset, lat_dev, lat_dtype, n, ld, out_dev, out_dtype=np.float64):
         lc = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32

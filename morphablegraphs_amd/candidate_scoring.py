@@ -42,6 +42,45 @@ def constraints_to_device_form(constraints, root_joint=None):
     return out
 
 
+_CSET_CACHE = []   # [(key, ConstraintSet)], most recent last: an optimizer calls the objective hundreds of times with
+_CSET_CACHE_SIZE = 8   # the same constraints, and building a set uploads its fused keyframe matrices
+
+
+def _constraint_key(prim, clist, skeleton):
+    def freeze(v):
+        if isinstance(v, dict):
+            return tuple(sorted((k, freeze(x)) for k, x in v.items()))
+        if isinstance(v, (list, tuple, np.ndarray)):
+            return tuple(freeze(x) for x in v)
+        return v
+    return (id(prim), prim.handle.value, id(skeleton), freeze(clist))
+
+
+def cached_constraint_set(prim, clist, skeleton=None):
+    """A device constraint set for these (device-form) constraints, reused across calls: a graph walk or an
+    optimizer evaluates the same constraints again and again, and building a set uploads its fused matrices."""
+    key = _constraint_key(prim, clist, skeleton)
+    for i in range(len(_CSET_CACHE) - 1, -1, -1):   # entries whose primitive has been closed meanwhile are dropped
+        if not (_CSET_CACHE[i][1].handle and _CSET_CACHE[i][1].prim.handle):
+            _CSET_CACHE.pop(i)
+    for i, (k, cs) in enumerate(_CSET_CACHE):
+        if k == key:
+            _CSET_CACHE.append(_CSET_CACHE.pop(i))
+            return cs
+    cs = _capi.ConstraintSet(prim, clist, skeleton)
+    _CSET_CACHE.append((key, cs))
+    while len(_CSET_CACHE) > _CSET_CACHE_SIZE:
+        _CSET_CACHE.pop(0)[1].close()
+    return cs
+
+
+def clear_constraint_cache():
+    """Drop the cached device constraint sets (call before closing a primitive they belong to)."""
+    while _CSET_CACHE:
+        _CSET_CACHE.pop()[1].close()
+
+
+
 class HipSampleFilter(object):
     """score_samples(primitive, samples, constraints) -> errors[n], like MGRDSampleFilter."""
 
@@ -66,20 +105,39 @@ def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frame
     prim = prim_obj._prim
     clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
     skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
-    cset = _capi.ConstraintSet(prim, constraints_to_device_form(clist), skeleton)
-    ctx = prim.ctx
-    try:
-        S = _capi._latents(samples)
-        d_s = ctx.upload(S)
-        d_e = ctx.malloc(max(len(S), 1) * 8)
-        prim.score_constraints_dev(cset, d_s, S.dtype, len(S), S.shape[1], d_e, np.float64)
-        best_idx, min_error = ctx.argmin_first(d_e, len(S), np.float64)
-        d_s.free()
-        d_e.free()
-    finally:
-        cset.close()
+    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton)
+    best_idx, min_error = prim.best_candidate(cset, samples)   # one upload, two launches, 16 bytes back
     if hasattr(constraints, "min_error"):
         constraints.min_error = min_error
     if hasattr(constraints, "evaluations"):
         constraints.evaluations += len(samples)
     return samples[best_idx], min_error
+
+
+def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleton=None, dtype=np.float32):
+    """The gpu_batch step without the host round trip: component counts from NumPy's global stream (the first
+    draw sklearn's GaussianMixture.sample makes), latents from the device Philox sampler (NOT sklearn's Mersenne
+    stream: distributional parity only), scoring and first-minimum argmin on the device; only the winning latent
+    vector comes back.  Returns (best_sample, min_error)."""
+    prim_obj = mp_node.motion_primitive if hasattr(mp_node, "motion_primitive") else mp_node
+    prim = prim_obj._prim
+    ctx = prim.ctx
+    clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
+    skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
+    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton)
+    L = prim.n_components
+    weights = np.asarray(prim_obj.gaussian_mixture_model.weights_, dtype=np.float64)
+    counts = np.random.multinomial(int(n_samples), weights / weights.sum()).astype(np.int64)
+    item = np.dtype(dtype).itemsize
+    d_x = ctx.malloc(max(int(n_samples), 1) * L * item)
+    try:
+        prim.gmm_sample_dev(counts, seed, d_x, dtype, L)
+        best_idx, min_error = prim.best_candidate_dev(cset, d_x, dtype, int(n_samples), L)
+        best = ctx.download(d_x.ptr.value + best_idx * L * item, (L,), dtype)
+    finally:
+        d_x.free()
+    if hasattr(constraints, "min_error"):
+        constraints.min_error = min_error
+    if hasattr(constraints, "evaluations"):
+        constraints.evaluations += int(n_samples)
+    return best.astype(np.float64), min_error

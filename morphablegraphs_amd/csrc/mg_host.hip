@@ -1131,3 +1131,36 @@ extern "C" int mg_score_constraints_host(mg_primitive *p, const mg_constraint_se
     if ((rc = mg_score_constraints(p, cs, io.d_in, dt, B, ld, io.d_out, odt)) != MG_OK) return rc;
     return io.finish(errors, ob);
 }
+
+// ---------------------------------------------------------------------------------------
+// evaluate_samples_using_constraints in one call (reference motion_primitive_generator.py:230-261):
+// score every candidate, first-minimum argmin, 16 bytes back -- no allocation, one synchronisation.
+// ---------------------------------------------------------------------------------------
+static int mg_best_candidate_impl(const char *who, mg_primitive *p, const mg_constraint_set *cs, const void *lat_dev, int dt,
+                                  int64_t B, int64_t ld, void *err_dev, int64_t *best, double *minv) {
+    MG_REQUIRE(cs && cs->prim == p, "%s: constraint set is NULL or belongs to another primitive", who);
+    if (B == 0) {
+        if (best) *best = 0;
+        if (minv) *minv = INFINITY;
+        return MG_OK;
+    }
+    int rc = mg_score_constraints(p, cs, lat_dev, dt, B, ld, err_dev, MG_F64);
+    if (rc != MG_OK) return rc;
+    return mg_argmin_first(p->ctx, err_dev, MG_F64, B, best, minv);
+}
+extern "C" int mg_best_candidate(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt, int64_t B,
+                                 int64_t ld, int64_t *best, double *minv) {
+    int rc = mg_check_latents("mg_best_candidate", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    void *err = nullptr;
+    if ((rc = mg_ctx_scratch(p->ctx, std::max<int64_t>(B, 1) * 8, &err)) != MG_OK) return rc;
+    return mg_best_candidate_impl("mg_best_candidate", p, cs, lat, dt, B, ld, err, best, minv);
+}
+extern "C" int mg_best_candidate_host(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt, int64_t B,
+                                      int64_t ld, int64_t *best, double *minv) {
+    int rc = mg_check_latents("mg_best_candidate_host", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    mg_host_io io;
+    if ((rc = io.stage(p->ctx, lat, B * ld * (int64_t)mg_dt_size(dt), std::max<int64_t>(B, 1) * 8)) != MG_OK) return rc;
+    return mg_best_candidate_impl("mg_best_candidate_host", p, cs, io.d_in, dt, B, ld, io.d_out, best, minv);
+}

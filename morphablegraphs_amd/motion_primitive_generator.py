@@ -13,7 +13,7 @@ import numpy as np
 from scipy.optimize import leastsq
 
 from . import objective_functions as of
-from .candidate_scoring import SAMPLING_MODE_GPU_BATCH, evaluate_samples_using_constraints
+from .candidate_scoring import SAMPLING_MODE_GPU_BATCH, evaluate_samples_using_constraints, sample_and_evaluate_on_device
 
 SAMPLING_MODE_RANDOM = "random_discrete"                  # motion_primitive_generator.py:42-44
 SAMPLING_MODE_CLUSTER_TREE_SEARCH = "cluster_tree_search"
@@ -87,6 +87,9 @@ class HipMotionPrimitiveGenerator(object):
         self.constrained_sampling_mode = algorithm_config.get("constrained_sampling_mode", SAMPLING_MODE_GPU_BATCH)
         self.n_cluster_search_candidates = int(algorithm_config.get("n_cluster_search_candidates", 2))
         self.use_local_coordinates = algorithm_config.get("use_local_coordinates", True)
+        # gpu_batch only: draw the candidates with the device sampler and keep them on the GPU (not sklearn's stream)
+        self.gpu_sampling = bool(algorithm_config.get("gpu_sampling", False))
+        self.gpu_sampling_seed = int(algorithm_config.get("gpu_sampling_seed", 0))
         if self._settings.get("method", "leastsq") != "leastsq":
             raise NotImplementedError("only the leastsq local optimizer is batched")
 
@@ -153,6 +156,11 @@ class HipMotionPrimitiveGenerator(object):
             gmm = self._predict_gmm(mp_constraints.motion_primitive_name, prev_mp_name, prev_parameters)
             samples = gmm.sample(self.n_random_samples)
             samples = samples[0] if isinstance(samples, tuple) else samples
+        elif self.gpu_sampling and self.constrained_sampling_mode == SAMPLING_MODE_GPU_BATCH:
+            self.gpu_sampling_seed += 1
+            best_sample, _ = sample_and_evaluate_on_device(graph_node, mp_constraints, self.n_random_samples,
+                                                           self.gpu_sampling_seed)
+            return best_sample
         else:
             samples = graph_node.sample_low_dimensional_vectors(self.n_random_samples)
         best_sample, _ = self.evaluate_samples_using_constraints(samples, graph_node, mp_constraints, prev_frames)

@@ -15,7 +15,7 @@ the aligning transform from anim_utils).  There is no CPU fallback.
 import numpy as np
 
 from . import _capi
-from .candidate_scoring import constraints_to_device_form
+from .candidate_scoring import constraints_to_device_form, cached_constraint_set
 
 
 def _prim_of(motion_primitive):
@@ -44,47 +44,11 @@ def _note(mp_constraints, min_error, n):
         mp_constraints.evaluations += n
 
 
-_CSET_CACHE = []   # [(key, ConstraintSet)], most recent last: an optimizer calls the objective hundreds of times with
-_CSET_CACHE_SIZE = 8   # the same constraints, and building a set uploads its fused keyframe matrices
-
-
-def _constraint_key(prim, clist, skeleton):
-    def freeze(v):
-        if isinstance(v, dict):
-            return tuple(sorted((k, freeze(x)) for k, x in v.items()))
-        if isinstance(v, (list, tuple, np.ndarray)):
-            return tuple(freeze(x) for x in v)
-        return v
-    return (id(prim), prim.handle.value, id(skeleton), freeze(clist))
-
-
-def _constraint_set(prim, clist, skeleton):
-    key = _constraint_key(prim, clist, skeleton)
-    for i in range(len(_CSET_CACHE) - 1, -1, -1):   # entries whose primitive has been closed meanwhile are dropped
-        if not (_CSET_CACHE[i][1].handle and _CSET_CACHE[i][1].prim.handle):
-            _CSET_CACHE.pop(i)
-    for i, (k, cs) in enumerate(_CSET_CACHE):
-        if k == key:
-            _CSET_CACHE.append(_CSET_CACHE.pop(i))
-            return cs
-    cs = _capi.ConstraintSet(prim, clist, skeleton)
-    _CSET_CACHE.append((key, cs))
-    while len(_CSET_CACHE) > _CSET_CACHE_SIZE:
-        _CSET_CACHE.pop(0)[1].close()
-    return cs
-
-
-def clear_constraint_cache():
-    """Drop the cached device constraint sets (call before closing a primitive they belong to)."""
-    while _CSET_CACHE:
-        _CSET_CACHE.pop()[1].close()
-
-
 def _residuals(prim, mp_constraints, S):
     clist = constraints_to_device_form(_constraint_list(mp_constraints))
     if len(clist) == 0:
         return np.zeros((len(S), 0))
-    cset = _constraint_set(prim, clist, getattr(mp_constraints, "hip_skeleton", None))
+    cset = cached_constraint_set(prim, clist, getattr(mp_constraints, "hip_skeleton", None))
     return prim.score_constraint_residuals(cset, S)
 
 

@@ -441,3 +441,42 @@ def test_baseline_config_sizes_graph_walk_step_and_optimizer_batch():
     ref = cp.keyframe_errors_f64(S[idx].astype(np.float64), np.array([[0, 155.0, 1.0, 40.0, np.nan, -30.0, 0, 0], [1, 155.0, 0.5, 0.5, 1.0, 0.0, 0.0, 1.0]]))
     np.testing.assert_allclose(res[idx, :2].sum(axis=1), ref, rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(lp[idx], cp.log_prob_f64(S[idx].astype(np.float64)), rtol=1e-10, atol=1e-8)
+
+
+def test_device_sampled_candidates_stay_on_the_gpu():
+    """gpu_batch with gpu_sampling: component counts from NumPy's stream, latents from the device Philox sampler,
+    score + first-minimum argmin on the device, only the winner read back.  The winner must be a row the sampler
+    produced for that seed, its error must be the minimum of the errors of all rows (oracle), and the generator
+    must route to this path."""
+    from morphablegraphs_amd.candidate_scoring import sample_and_evaluate_on_device, SAMPLING_MODE_GPU_BATCH
+    from morphablegraphs_amd.motion_primitive_generator import HipMotionPrimitiveGenerator
+    data = synthetic.make_walk_primitive(seed=0)
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "leftStance", "mm": data})
+    cp = c_oracle.COraclePrimitive(data)
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+            {"type": "direction", "t": 155.0, "weight": 1.0, "target": [0.5, 1.0]}]
+    n = 4096
+    np.random.seed(123)
+    best, err = sample_and_evaluate_on_device(node, cons, n, seed=77)
+    np.random.seed(123)
+    counts = np.random.multinomial(n, np.asarray(data["gmm_weights"]) / np.sum(data["gmm_weights"]))
+    X, comp = node.motion_primitive._prim.gmm_sample(counts, 77, dtype=np.float32)     # same seed, same rows
+    ref = cp.keyframe_errors_f64(X.astype(np.float64), np.array([[0, 155.0, 1.0, 40.0, np.nan, -30.0, 0, 0], [1, 155.0, 1.0, 0.5, 1.0, 0.0, 0.0, 1.0]]))
+    idx = int(np.argmin(ref))
+    np.testing.assert_array_equal(best.astype(np.float32), X[idx])
+    assert abs(err - ref[idx]) <= 1e-9 * max(1.0, ref[idx])
+
+    class Constraints(object):
+        def __init__(self):
+            self.constraints, self.min_error, self.evaluations = list(cons), None, 0
+            self.motion_primitive_name, self.use_local_optimization = "leftStance", False
+    cfg = {"n_random_samples": 512, "constrained_sampling_mode": SAMPLING_MODE_GPU_BATCH, "gpu_sampling": True, "gpu_sampling_seed": 5,
+           "local_optimization_settings": {"start_error_threshold": 0.0, "error_scale_factor": 1.0, "quality_scale_factor": 0.1,
+                                           "method": "leastsq", "max_iterations": 50}}
+    gen = HipMotionPrimitiveGenerator({("walk", "leftStance"): node}, cfg, "walk")
+    c = Constraints()
+    s1 = gen.generate_constrained_sample(node, c)
+    assert s1.shape == (40,) and c.evaluations == 512 and np.isfinite(c.min_error)
+    s2 = gen.generate_constrained_sample(node, c)
+    assert not np.array_equal(s1, s2)                      # the seed advances per call
