@@ -460,3 +460,33 @@ def test_two_slot_ring(ctx, monkeypatch):
         np.testing.assert_array_equal(_bits(frames), _bits(got))
         np.testing.assert_array_equal(_bits(logp), _bits(prim.gmm_log_prob(S, dtype=np.float32)))
     prim.close()
+
+
+def test_large_ragged_batch_on_device(ctx):
+    """40 001 candidates (2 GB of frames, 157 units per workgroup, a ragged last tile): device-resident in and out,
+    a seeded subset and both ends against the f32 model, per-candidate checksums computed on the host from two
+    independent launches (fused step and stand-alone kernel) must agree bit for bit."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    B = 40001
+    rng = np.random.default_rng(99)
+    S = rng.standard_normal((B, 40)).astype(np.float32)
+    d_S = ctx.upload(S)
+    d_f = ctx.malloc(B * 156 * 79 * 4)
+    d_l = ctx.malloc(B * 4)
+    prim.back_project_frames_dev(d_S, np.float32, B, 40, d_f, path=_capi.MG_PATH_MFMA)
+    ctx.synchronize()
+    F1 = ctx.download(d_f, (B, 156, 79), np.float32)
+    idx = np.concatenate([[0, 1, 15, 16, B - 17, B - 2, B - 1], rng.choice(B, size=40, replace=False)])
+    np.testing.assert_array_equal(_bits(F1[idx]), _bits(cp.frames_f32model(S[idx].astype(np.float64))))
+    assert np.isfinite(F1).all()
+    prim.step_frames_and_logp_dev(d_S, np.float32, B, 40, d_f, d_l)     # > 2 tiles per workgroup: two launches
+    ctx.synchronize()
+    F2 = ctx.download(d_f, (B, 156, 79), np.float32)
+    np.testing.assert_array_equal(_bits(F2), _bits(F1))
+    lp = ctx.download(d_l, (B,), np.float32)
+    np.testing.assert_allclose(lp[idx], cp.log_prob_f64(S[idx].astype(np.float64)), rtol=3e-7, atol=1e-5)
+    for buf in (d_S, d_f, d_l):
+        buf.free()
+    prim.close()
