@@ -85,7 +85,7 @@ __global__ __launch_bounds__(MG_GMM_CANDS *MG_GMM_WAVES) void mg_gmm_logp_kernel
 // One workgroup = 16 candidates; y for all components in LDS; float64 throughout.
 // -----------------------------------------------------------------------------------------
 #define MG_JAC_CANDS 16
-#define MG_JAC_ITEMS 4   // (candidate, dimension) outputs per thread: 16 L / 256 rounded up, L <= 64
+#define MG_JAC_ITEMS 8   // (candidate, dimension) outputs per thread: 16 L / 256 rounded up, L <= 128
 template <bool X_F64>
 __global__ __launch_bounds__(256) void mg_gmm_jac_kernel(mg_gmm_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -180,25 +180,6 @@ __global__ __launch_bounds__(256) void mg_gmm_jac_kernel(mg_gmm_args a) {
     }
 }
 
-int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out) {
-    mg_gmm_args a;
-    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
-    const int64_t grid = (B + MG_JAC_CANDS - 1) / MG_JAC_CANDS;
-    const size_t lds = ((size_t)MG_JAC_CANDS * p->L * (1 + p->K) + (size_t)p->K * MG_JAC_CANDS + MG_JAC_CANDS + (size_t)p->L * (p->L + 1)) * 8;
-    if (lds > 150 * 1024 || grid > 0x7fffffff || MG_JAC_CANDS * p->L > 256 * MG_JAC_ITEMS) {
-        mg_set_error("mg_gmm_log_prob_jac: n_components %d x n_gmm %d too large for the LDS-staged kernel", p->L, p->K);
-        return MG_ERR_UNSUPPORTED;
-    }
-    if (lds > 64 * 1024) {
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-    hipStream_t st = p->ctx->stream;
-    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_jac_kernel<true>), dim3((int)grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((mg_gmm_jac_kernel<false>), dim3((int)grid), dim3(256), lds, st, a);
-    MG_HIP_CHECK(hipGetLastError());
-    return MG_OK;
-}
 
 // -----------------------------------------------------------------------------------------
 // MFMA variant (n_components <= 64): one workgroup = 16 candidates, one wave = one mixture
@@ -379,6 +360,176 @@ int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, uin
     }
     if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_kernel<true>), dim3((int)grid), dim3(256), lds, p->ctx->stream, a);
     else hipLaunchKernelGGL((mg_gmm_sample_kernel<false>), dim3((int)grid), dim3(256), lds, p->ctx->stream, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// MFMA form of the same Jacobian for n_components <= 64: y_k = x P_k - mu_k P_k as in the log-likelihood kernel
+// (kept in LDS this time), responsibilities from the log-sum-exp, then z_k = y_k P_k^T by a second chain of
+// v_mfma_f64_16x16x4_f64 against the transposed fragments (P_k^T is lower triangular: column tile `it` needs only
+// the k-steps >= 4 it), jac = sum_k r_k z_k.  16 candidates per workgroup, one component per wave at a time; the
+// four waves' partial sums meet in LDS and are added in wave order.
+template <int KK, bool X_F64>
+__global__ __launch_bounds__(256) void mg_gmm_jac_mfma_kernel(const double *__restrict__ Ppack,    // [K][JT][KK][64]
+                                                             const double *__restrict__ PTpack,   // [K][JT][KK][64]
+                                                             const double *__restrict__ mP,       // [K][JT*16]
+                                                             const double *__restrict__ cst,      // [K]
+                                                             const void *__restrict__ x, double *__restrict__ out,
+                                                             const mg_gmm_mfma_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int JTM = (KK + 3) / 4;
+    constexpr int YS = JTM * 16 + 1;                       // padded row of y: [cand][j], j < 16 JTM (zero beyond L)
+    mg_lds_f64 *lds_y = (mg_lds_f64 *)smem;               // [K][16][YS]
+    mg_lds_f64 *lds_t = lds_y + a.K * 16 * YS;             // [K][16] terms, then responsibilities
+    mg_lds_f64 *lds_lp = lds_t + a.K * 16;                 // [16]
+    mg_lds_f64 *lds_g = lds_lp + 16;                       // [4 waves][16][JTM*16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, g = lane >> 4;
+    const int64_t b0 = (int64_t)blockIdx.x * 16;
+    const int ncand = (int)((a.B - b0) < 16 ? (a.B - b0) : 16);
+    typename mg_gmm_xt<X_F64>::type xf[KK];
+    mg_gmm_load_x<KK, X_F64>(xf, x, b0, ncand, a.ld, a.L, cl, g);
+    for (int k = wave; k < a.K; k += 4) {
+        mg_gmm_frag<KK> f;
+        mg_gmm_load_component<KK>(f, Ppack, mP, cst, k, a.JT, lane, cl);
+        mg_f64x4 acc[JTM];
+#pragma unroll
+        for (int jt = 0; jt < JTM; jt++) acc[jt] = {f.c0[jt], f.c0[jt], f.c0[jt], f.c0[jt]};
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+            for (int jt = 0; jt < JTM; jt++)
+                if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[kk], f.pf[jt][kk], acc[jt], 0, 0, 0);
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jt = 0; jt < JTM; jt++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // C layout: col j = 16 jt + cl, row (candidate) = g + 4 r; columns >= L are zero (zero fragments, zero C-in)
+                lds_y[(k * 16 + g + 4 * r) * YS + 16 * jt + cl] = acc[jt][r];
+                if (jt < a.JT) part[r] = fma(acc[jt][r], acc[jt][r], part[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = part[r];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            part[r] = v;
+        }
+        if (cl == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) lds_t[k * 16 + g + 4 * r] = f.cst - 0.5 * part[r];
+        }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        double vmax = -INFINITY;
+        for (int k = 0; k < a.K; k++) vmax = fmax(vmax, lds_t[k * 16 + tid]);
+        double lp = -INFINITY;
+        if (vmax != -INFINITY) {
+            double s = 0.0;
+            for (int k = 0; k < a.K; k++) s += exp(lds_t[k * 16 + tid] - vmax);
+            lp = log(s) + vmax;
+        }
+        lds_lp[tid] = lp;
+    }
+    __syncthreads();
+    for (int e = tid; e < a.K * 16; e += 256) {
+        const double lp = lds_lp[e & 15];
+        lds_t[e] = (lp == -INFINITY) ? 0.0 : exp(lds_t[e] - lp);   // responsibility r_k
+    }
+    __syncthreads();
+    // z_k = y_k P_k^T: A = y (lane: candidate cl, k-step element j = 4 kk + g), B = transposed fragments
+    mg_f64x4 gacc[JTM];
+#pragma unroll
+    for (int it = 0; it < JTM; it++) gacc[it] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = wave; k < a.K; k += 4) {
+        double ya[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) ya[kk] = lds_y[(k * 16 + cl) * YS + 4 * kk + g];
+        mg_f64x4 z[JTM];
+#pragma unroll
+        for (int it = 0; it < JTM; it++) {
+            const int itc = it < a.JT ? it : a.JT - 1;
+            const double *pp = PTpack + (((size_t)k * a.JT + itc) * KK) * 64 + lane;
+            z[it] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++)
+                if (kk >= 4 * it) z[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[kk], pp[kk * 64], z[it], 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < JTM; it++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) gacc[it][r] = fma(lds_t[k * 16 + g + 4 * r], z[it][r], gacc[it][r]);
+    }
+#pragma unroll
+    for (int it = 0; it < JTM; it++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds_g[(wave * 16 + g + 4 * r) * (JTM * 16) + 16 * it + cl] = gacc[it][r];
+    __syncthreads();
+    for (int e = tid; e < 16 * a.L; e += 256) {
+        const int c = e / a.L, i = e - c * a.L;
+        if (c >= ncand) continue;
+        double v = 0.0;
+        for (int w = 0; w < 4; w++) v += lds_g[(w * 16 + c) * (JTM * 16) + i];
+        out[(b0 + c) * a.L + i] = (exp(lds_lp[c]) == 0.0) ? 1.0 : v;   // the reference: denominator == 0 -> ones
+    }
+}
+
+template <int KK>
+static int mg_launch_gmm_jac_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out) {
+    mg_gmm_mfma_args a;
+    a.B = B; a.ld = ld; a.K = p->K; a.L = p->L; a.JT = (p->L + 15) / 16;
+    constexpr int JTM = (KK + 3) / 4;
+    const int64_t grid = (B + 15) / 16;
+    const size_t lds = ((size_t)p->K * 16 * (JTM * 16 + 1) + (size_t)p->K * 16 + 16 + (size_t)4 * 16 * JTM * 16) * 8;
+    if (lds > 150 * 1024 || grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_mfma_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_mfma_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipStream_t st = p->ctx->stream;
+    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_jac_mfma_kernel<KK, true>), dim3((int)grid), dim3(256), lds, st, p->d_gPpack, p->d_gPTpack, p->d_gmPpad, p->d_gconst, x, out, a);
+    else hipLaunchKernelGGL((mg_gmm_jac_mfma_kernel<KK, false>), dim3((int)grid), dim3(256), lds, st, p->d_gPpack, p->d_gPTpack, p->d_gmPpad, p->d_gconst, x, out, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out) {
+    if (p->d_gPTpack) {
+        int rc = MG_ERR_UNSUPPORTED;
+        switch (p->KK) {
+            case 2: rc = mg_launch_gmm_jac_mfma_kk<2>(p, x, xdt, B, ld, out); break;
+            case 4: rc = mg_launch_gmm_jac_mfma_kk<4>(p, x, xdt, B, ld, out); break;
+            case 6: rc = mg_launch_gmm_jac_mfma_kk<6>(p, x, xdt, B, ld, out); break;
+            case 8: rc = mg_launch_gmm_jac_mfma_kk<8>(p, x, xdt, B, ld, out); break;
+            case 10: rc = mg_launch_gmm_jac_mfma_kk<10>(p, x, xdt, B, ld, out); break;
+            case 12: rc = mg_launch_gmm_jac_mfma_kk<12>(p, x, xdt, B, ld, out); break;
+            case 14: rc = mg_launch_gmm_jac_mfma_kk<14>(p, x, xdt, B, ld, out); break;
+            case 16: rc = mg_launch_gmm_jac_mfma_kk<16>(p, x, xdt, B, ld, out); break;
+            default: break;
+        }
+        if (rc != MG_ERR_UNSUPPORTED) return rc;   // too many components for LDS: the VALU kernel below
+    }
+    mg_gmm_args a;
+    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
+    const int64_t grid = (B + MG_JAC_CANDS - 1) / MG_JAC_CANDS;
+    const size_t lds = ((size_t)MG_JAC_CANDS * p->L * (1 + p->K) + (size_t)p->K * MG_JAC_CANDS + MG_JAC_CANDS + (size_t)p->L * (p->L + 1)) * 8;
+    if (lds > 150 * 1024 || grid > 0x7fffffff || MG_JAC_CANDS * p->L > 256 * MG_JAC_ITEMS) {
+        mg_set_error("mg_gmm_log_prob_jac: n_components %d x n_gmm %d too large for the LDS-staged kernel", p->L, p->K);
+        return MG_ERR_UNSUPPORTED;
+    }
+    if (lds > 64 * 1024) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_jac_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    hipStream_t st = p->ctx->stream;
+    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_jac_kernel<true>), dim3((int)grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((mg_gmm_jac_kernel<false>), dim3((int)grid), dim3(256), lds, st, a);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

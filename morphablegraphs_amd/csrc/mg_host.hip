@@ -470,7 +470,7 @@ static void mg_primitive_free(mg_primitive *p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean,
-                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad};
+                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad, p->d_gPTpack};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (mg_time_grid *g : {p->canonical, p->coeff_grid})
@@ -639,7 +639,18 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                                 ppack[((((size_t)k * JT + jt) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * L * L + (size_t)i * L + j];
                         }
             }
+            // the transposed factor for z = y P_k^T (log_likelihood_jac): lane l supplies B[k = 4*kk + (l >> 4) (= j)][col = i]
+            std::vector<double> ptpack((size_t)K * JT * KK * 64, 0.0);
+            for (int k = 0; k < K; k++)
+                for (int it = 0; it < JT; it++)
+                    for (int kk = 0; kk < KK; kk++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            int j = 4 * kk + (lane >> 4), i = 16 * it + (lane & 15);
+                            if (i < L && j < L && i <= j)
+                                ptpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * L * L + (size_t)i * L + j];
+                        }
             if (rc == MG_OK) rc = mg_upload(ctx, ppack, &p->d_gPpack);
+            if (rc == MG_OK) rc = mg_upload(ctx, ptpack, &p->d_gPTpack);
             if (rc == MG_OK) rc = mg_upload(ctx, mpad, &p->d_gmPpad);
         }
         if (rc == MG_OK) rc = mg_upload(ctx, gP, &p->d_gP);

@@ -119,6 +119,7 @@ struct mg_primitive {
     double *d_gmPpad = nullptr;  // [K][JT*16]: mu_k . P_k, zero padded
     double *d_gP = nullptr;      // [K][L(j)][L(i)]: column j of P_k contiguous over i
     double *d_gmP = nullptr;     // [K][L]: mu_k . P_k
+    double *d_gPTpack = nullptr; // [K][JT][KK][64]: B fragments of P_k^T (Jacobian)
     double *d_gconst = nullptr;  // [K]: log w_k + sum log diag P_k - 0.5 L log 2pi
     double *d_gmean = nullptr;   // [K][L]
     double *d_gchol = nullptr;   // [K][L][L] lower Cholesky of covars (sampler)

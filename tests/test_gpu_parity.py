@@ -359,7 +359,36 @@ def test_graph_of_primitives_shapes(ctx):
         np.testing.assert_array_equal(_bits(got), _bits(cp.frames_f32model(S.astype(np.float64))))
         np.testing.assert_allclose(prim.gmm_log_prob(S, dtype=np.float64), cp.log_prob_f64(S.astype(np.float64)),
                                    rtol=1e-10, atol=1e-8)
+        from oracle import mg_oracle as orc
+        jac = prim.gmm_log_prob_jac(S[:12].astype(np.float64))
+        ref = orc.OraclePrimitive(data).log_likelihood_jac(S[:12].astype(np.float64))
+        np.testing.assert_allclose(jac, ref, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref).max()))
         prim.close()
+
+
+def test_more_than_64_latent_components_take_the_fallback_kernels(ctx):
+    """n_components > 64 is outside the MFMA kernels' k-step templates: frames go through the direct kernel,
+    log-likelihood and its Jacobian through the VALU kernels, the fused step through two launches; same contracts."""
+    from oracle import mg_oracle as orc
+    data = synthetic.make_primitive(seed=21, n_components=70, n_frames=30, n_basis=8, n_dim=15, n_gmm=3, name="wide")
+    prim = _capi.Primitive(ctx, data)
+    assert not prim.mfma_supported
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(2)
+    S = (0.3 * rng.standard_normal((70, 70))).astype(np.float32)
+    got = prim.back_project_frames(S)
+    np.testing.assert_array_equal(_bits(got), _bits(cp.frames_f32model(S.astype(np.float64))))
+    with pytest.raises(_capi.MGError):
+        prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+    lp = prim.gmm_log_prob(S, dtype=np.float64)
+    np.testing.assert_allclose(lp, cp.log_prob_f64(S.astype(np.float64)), rtol=1e-10, atol=1e-8)
+    jac = prim.gmm_log_prob_jac(S[:20].astype(np.float64))
+    ref = orc.OraclePrimitive(data).log_likelihood_jac(S[:20].astype(np.float64))
+    np.testing.assert_allclose(jac, ref, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    frames, logp = _fused_step(ctx, prim, S, 30, 15)
+    np.testing.assert_array_equal(_bits(frames), _bits(got))
+    np.testing.assert_allclose(logp, lp, rtol=3e-7, atol=1e-5)
+    prim.close()
 
 
 def test_joint_position_constraints_forward_kinematics(ctx):
