@@ -231,13 +231,51 @@ class HipMotionStateGraph(object):
 
 
 class HipPrimitiveSet(object):
-    def __init__(self, primitives_json, context=None, device=0):
+    """separate_streams: every primitive gets its own libmg_hip context, i.e. its own HIP stream, so that the small,
+    latency-bound launches of different options overlap on the GPU (evaluate_options_on_device)."""
+
+    def __init__(self, primitives_json, context=None, device=0, separate_streams=False):
         self.ctx = context or get_context(device)
         self.nodes = {}
+        self._buffers = {}
         for data in primitives_json:
-            p = HipMotionPrimitive(None, context=self.ctx)
+            ctx = _capi.Context(device) if separate_streams else self.ctx
+            p = HipMotionPrimitive(None, context=ctx)
             p._initialize_from_json(data)
             self.nodes[p.name] = p
+
+    def evaluate_options_on_device(self, options, constraints_per_option, n_samples, seed=0, dtype=np.float32):
+        """GraphWalkPlanner's option evaluation (reference graph_walk_planner.py:184-226) without host round trips:
+        for every option the component counts come from NumPy's stream, the candidates from the device sampler,
+        scoring and first-minimum argmin stay on the device; everything is enqueued for all options first (one
+        stream per option with separate_streams) and only then the 16-byte results and the winning latents are
+        read back.  Returns (best_option, {name: (best_sample, min_error)})."""
+        from .candidate_scoring import cached_constraint_set
+        pending = []
+        for k, name in enumerate(options):
+            node = self.nodes[name]
+            prim, ctx = node._prim, node._prim.ctx
+            L = prim.n_components
+            item = np.dtype(dtype).itemsize
+            key = (name, int(n_samples), np.dtype(dtype).str)
+            if key not in self._buffers:   # persistent per-option device buffers: no allocation inside a step
+                self._buffers[key] = (ctx.malloc(max(int(n_samples), 1) * L * item), ctx.malloc(max(int(n_samples), 1) * 8), ctx.malloc(16))
+            d_x, d_e, d_o = self._buffers[key]
+            cset = cached_constraint_set(prim, constraints_to_device_form(constraints_per_option[name]))
+            weights = np.asarray(node.gaussian_mixture_model.weights_, dtype=np.float64)
+            counts = np.random.multinomial(int(n_samples), weights / weights.sum()).astype(np.int64)
+            prim.gmm_sample_dev(counts, int(seed) + k, d_x, dtype, L)
+            prim.score_constraints_dev(cset, d_x, dtype, int(n_samples), L, d_e, np.float64)
+            _capi._check(prim.lib.mg_argmin_first_dev(ctx.handle, d_e.ptr, _capi.MG_F64, int(n_samples), d_o.ptr))
+            pending.append((name, ctx, d_x, d_o, L, item))
+        results = {}
+        for name, ctx, d_x, d_o, L, item in pending:
+            raw = ctx.download(d_o, (16,), np.uint8)       # {int64 index, float64 value}; synchronises this option's stream
+            idx, err = int(raw[:8].view(np.int64)[0]), float(raw[8:].view(np.float64)[0])
+            best = ctx.download(d_x.ptr.value + idx * L * item, (L,), dtype)
+            results[name] = (best.astype(np.float64), err)
+        errors = [results[n][1] for n in options]
+        return options[int(np.argmin(errors))], results
 
     def evaluate_options(self, options, constraints_per_option, n_samples, rng_seed=None):
         """options: node names; constraints_per_option: name -> constraint list.  Returns

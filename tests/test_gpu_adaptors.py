@@ -480,3 +480,31 @@ def test_device_sampled_candidates_stay_on_the_gpu():
     assert s1.shape == (40,) and c.evaluations == 512 and np.isfinite(c.min_error)
     s2 = gen.generate_constrained_sample(node, c)
     assert not np.array_equal(s1, s2)                      # the seed advances per call
+
+
+def test_graph_walk_step_on_device_with_one_stream_per_option():
+    """evaluate_options_on_device: every option's sampler / scorer / argmin enqueued on its own stream before any
+    result is read.  Same answer as the synchronous per-option path fed with the same device-sampled rows, and the
+    winner is the option with the smallest error (np.argmin over options, graph_walk_planner.py:191-192)."""
+    prims = synthetic.make_graph_primitives(6)
+    names = [p["name"] for p in prims]
+    cons = {n: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]}]
+            for n, p in zip(names, prims)}
+    for separate in (False, True):
+        pset = HipPrimitiveSet(prims, separate_streams=separate)
+        np.random.seed(31)
+        best, results = pset.evaluate_options_on_device(names, cons, n_samples=2048, seed=100)
+        np.random.seed(31)
+        for k, (n, p) in enumerate(zip(names, prims)):
+            cp = c_oracle.COraclePrimitive(p)
+            w = np.asarray(p["gmm_weights"], dtype=np.float64)
+            counts = np.random.multinomial(2048, w / w.sum())
+            X, _ = pset.nodes[n]._prim.gmm_sample(counts, 100 + k, dtype=np.float32)
+            ref = cp.keyframe_errors_f64(X.astype(np.float64), np.array([[0, float(p["n_canonical_frames"] - 1), 1.0, 10.0, np.nan, 5.0, 0, 0]]))
+            idx = int(np.argmin(ref))
+            np.testing.assert_array_equal(results[n][0].astype(np.float32), X[idx])
+            assert abs(results[n][1] - ref[idx]) <= 1e-9 * max(1.0, ref[idx])
+        assert best == names[int(np.argmin([results[n][1] for n in names]))]
+        # a second step reuses the per-option buffers
+        best2, results2 = pset.evaluate_options_on_device(names, cons, n_samples=2048, seed=200)
+        assert set(results2) == set(names)

@@ -33,3 +33,17 @@ for i in range(R):
     best, err = sample_and_evaluate_on_device(mp, cons, n, i)
 print("sample_and_evaluate_on_device(%d candidates): %.1f us per call (device sampler, scoring, argmin, winner back), min error %.6g"
       % (n, 1e6 * (time.perf_counter() - t0) / R, err))
+
+from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
+prims = synthetic.make_graph_primitives(16)
+names = [p["name"] for p in prims]
+pcons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]}] for nm, p in zip(names, prims)}
+for separate in (False, True):
+    pset = HipPrimitiveSet(prims, separate_streams=separate)
+    for i in range(3):
+        pset.evaluate_options_on_device(names, pcons, n, seed=i)
+    t0 = time.perf_counter()
+    for i in range(50):
+        pset.evaluate_options_on_device(names, pcons, n, seed=i)
+    print("graph-walk step, 16 options x %d device-sampled candidates, %s: %.1f us per step"
+          % (n, "one stream per option" if separate else "one stream", 1e6 * (time.perf_counter() - t0) / 50))
