@@ -911,6 +911,22 @@ extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_de
     if (rc == MG_OK) rc = mg_upload(p->ctx, woff, &cs->d_woff);
     if (rc == MG_OK) { if (chain_len.empty()) chain_len.push_back(0); rc = mg_upload(p->ctx, chain_len, &cs->d_chain); }
     if (rc == MG_OK) rc = mg_upload(p->ctx, choff, &cs->d_choff);
+    if (rc == MG_OK && p->KK > 0 && rows_total > 0) {
+        // B fragments of v_mfma_f64_16x16x4_f64 for channels = X . W^T: lane l supplies B[k = 4*kk + (l >> 4)][col = l & 15]
+        const int KK = p->KK, RT = (int)((rows_total + 15) / 16);
+        std::vector<double> wpack((size_t)RT * KK * 64, 0.0), bpad((size_t)RT * 16, 0.0);
+        for (size_t r = 0; r < rows_total; r++) bpad[r] = bias[r];
+        for (int rt = 0; rt < RT; rt++)
+            for (int kk = 0; kk < KK; kk++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int k = 4 * kk + (lane >> 4);
+                    const size_t row = (size_t)rt * 16 + (lane & 15);
+                    if (k < L && row < rows_total) wpack[((size_t)rt * KK + kk) * 64 + lane] = W[row * L + k];
+                }
+        cs->RT = RT;
+        rc = mg_upload(p->ctx, wpack, &cs->d_Wpack);
+        if (rc == MG_OK) rc = mg_upload(p->ctx, bpad, &cs->d_bpad);
+    }
     if (rc != MG_OK) { mg_constraint_set_destroy(cs); return rc; }
     *out = cs;
     return MG_OK;
@@ -927,6 +943,8 @@ extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
     if (cs->d_woff) (void)hipFree(cs->d_woff);
     if (cs->d_chain) (void)hipFree(cs->d_chain);
     if (cs->d_choff) (void)hipFree(cs->d_choff);
+    if (cs->d_Wpack) (void)hipFree(cs->d_Wpack);
+    if (cs->d_bpad) (void)hipFree(cs->d_bpad);
     delete cs;
 }
 

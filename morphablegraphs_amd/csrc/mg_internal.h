@@ -137,6 +137,9 @@ struct mg_constraint_set {
     int32_t *d_woff = nullptr;  // [n + 1] first row of every constraint
     int32_t *d_chain = nullptr; // [n] FK chain length m (0 for root constraints)
     double *d_choff = nullptr;  // [n][MG_MAX_CHAIN][3] offsets along the chain
+    double *d_Wpack = nullptr;  // [RT][KK][64] MFMA B fragments of W (n_components <= 64), RT = ceil(rows / 16)
+    double *d_bpad = nullptr;   // [RT*16] bias, zero padded
+    int32_t RT = 0;
 };
 
 // launchers (each validates nothing: the C-ABI entry points did)

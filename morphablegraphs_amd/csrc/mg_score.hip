@@ -5,6 +5,7 @@
 // MotionPrimitiveConstraints.evaluate (reference .../constraints/motion_primitive_constraints.py:100-122)
 // for root-joint position / 2-D direction constraints, and its first-minimum argmin.
 #include "mg_internal.h"
+#include "mg_gmm_device.h"
 
 struct mg_score_args {
     const double *W;      // [rows][L]     sum_j w_j E'[(i0+j) D + d]; constraint c owns rows woff[c] ..
@@ -20,10 +21,76 @@ struct mg_score_args {
     int32_t n, nch, L;
 };
 
-// One workgroup = 64 candidates (a lane each) x 4 waves that deal the constraints round-robin, so a batch of
-// 8192 fills 128 CUs x 4 SIMDs instead of 32 workgroups.  The latent tile is staged in LDS ([64][L+1] float64),
-// the fused keyframe matrices are wave-uniform (scalar loads); every weighted residual meets in LDS ([n][64])
-// and lane-owners sum them in constraint order (the order MotionPrimitiveConstraints.evaluate adds them in).
+// The weighted residual of constraint c for one candidate; `channel(row)` yields the candidate's pose channel of
+// that row of the fused keyframe matrices (rows of constraint c start at woff[c]).  Shared by the VALU kernel (a dot
+// product per channel) and the MFMA kernel (channels already in LDS), so both produce the same value.
+template <typename ChannelFn>
+__device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a, int c, ChannelFn channel) {
+    const double *par = a.par + (size_t)c * 8;
+    const int type = (int)par[0];
+    const int r0 = a.woff[c];
+    if (type == MG_CONSTRAINT_JOINT_POSITION) {
+        // forward kinematics along the chain: p = t_root + sum_i R(q_0 .. q_(i-1)) offset_i, unit quaternions (w,x,y,z)
+        double p0 = channel(r0), p1 = channel(r0 + 1), p2 = channel(r0 + 2);
+        const int m = a.chain[c];
+        double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;   // accumulated global rotation of the parent
+        for (int i = 0; i < m; i++) {
+            double qw = channel(r0 + 3 + 4 * i), qx = channel(r0 + 4 + 4 * i), qy = channel(r0 + 5 + 4 * i), qz = channel(r0 + 6 + 4 * i);
+            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+            const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+            const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+            aw = nw; ax = nx; ay = ny; az = nz;
+            const double *off = a.choff + ((size_t)c * MG_MAX_CHAIN + i) * 3;
+            const double ox = off[0], oy = off[1], oz = off[2];
+            // v' = v + 2 w (u x v) + 2 u x (u x v), u = (ax, ay, az)
+            const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
+            const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
+            p0 += ox + 2.0 * (aw * cx + dx);
+            p1 += oy + 2.0 * (aw * cy + dy);
+            p2 += oz + 2.0 * (aw * cz + dz);
+        }
+        const double pj[3] = {p0, p1, p2};
+        double ds = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double t = par[2 + i];
+            if (t == t) ds += (t - pj[i]) * (t - pj[i]);
+        }
+        return par[1] * sqrt(ds);
+    }
+    if (type == MG_CONSTRAINT_POSITION) {
+        // _point_distance: axes whose target is NaN (the reference's None) are ignored
+        double ds = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double t = par[2 + i];
+            if (t == t) {
+                const double v = channel(r0 + i);
+                ds += (t - v) * (t - v);
+            }
+        }
+        return par[1] * sqrt(ds);
+    }
+    // heading = xz of (rotation of the root quaternion (w,x,y,z)) applied to ref_dir
+    const double qw = channel(r0 + 3), qx = channel(r0 + 4), qy = channel(r0 + 5), qz = channel(r0 + 6);
+    const double nq = qw * qw + qx * qx + qy * qy + qz * qz, s2 = 2.0 / nq;
+    const double rx = par[5], ry = par[6], rz = par[7];
+    const double px = (1.0 - s2 * (qy * qy + qz * qz)) * rx + s2 * (qx * qy - qz * qw) * ry + s2 * (qx * qz + qy * qw) * rz;
+    const double pz = s2 * (qx * qz - qy * qw) * rx + s2 * (qy * qz + qx * qw) * ry + (1.0 - s2 * (qx * qx + qy * qy)) * rz;
+    const double tn = sqrt(par[2] * par[2] + par[3] * par[3]);
+    const double tx = par[2] / tn, tz = par[3] / tn;
+    const double mn = sqrt(px * px + pz * pz);
+    const double mx = px / mn, mz = pz / mn;
+    double cosang = (tx * mx + tz * mz) / (sqrt(tx * tx + tz * tz) * sqrt(mx * mx + mz * mz));
+    cosang = fmin(1.0, fmax(cosang, -1.0));
+    return par[1] * fabs(acos(cosang) * (180.0 / M_PI));
+}
+
+// VALU kernel (fallback for > 64 latent components): one workgroup = 64 candidates (a lane each) x 4 waves that deal
+// the constraints round-robin.  The latent tile is staged in LDS ([64][L+1] float64), the fused keyframe matrices are
+// wave-uniform (scalar loads); every weighted residual meets in LDS ([n][64]) and lane-owners sum them in constraint
+// order (the order MotionPrimitiveConstraints.evaluate adds them in).
 #define MG_SC_CANDS 64
 #define MG_SC_WAVES 4
 template <bool LAT_F64, bool OUT_F64>
@@ -45,79 +112,13 @@ __global__ __launch_bounds__(MG_SC_CANDS *MG_SC_WAVES) void mg_score_kernel(mg_s
     __syncthreads();
     const double *x = lds_x + lane * xs;
     for (int c = wave; c < a.n; c += MG_SC_WAVES) {
-        const double *par = a.par + (size_t)c * 8;
-        const int type = (int)par[0];
-        double fr[7];
-#pragma unroll
-        for (int d = 0; d < 7; d++) fr[d] = 0.0;
-        const size_t r0 = (size_t)a.woff[c];
-        auto channel = [&](size_t row) {   // one pose channel of this candidate at the keyframe
-            const double *wr = a.W + row * L;
+        auto channel = [&](int row) {   // one pose channel of this candidate at the keyframe: fma chain over k from the bias
+            const double *wr = a.W + (size_t)row * L;
             double acc = a.bias[row];
             for (int k = 0; k < L; k++) acc = fma(wr[k], x[k], acc);
             return acc;
         };
-        if (type == MG_CONSTRAINT_JOINT_POSITION) {
-            // forward kinematics along the chain: p = t_root + sum_i R(q_0 .. q_(i-1)) offset_i, unit quaternions (w,x,y,z)
-            double p0 = channel(r0), p1 = channel(r0 + 1), p2 = channel(r0 + 2);
-            const int m = a.chain[c];
-            double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;   // accumulated global rotation of the parent
-            for (int i = 0; i < m; i++) {
-                double qw = channel(r0 + 3 + 4 * i), qx = channel(r0 + 4 + 4 * i), qy = channel(r0 + 5 + 4 * i), qz = channel(r0 + 6 + 4 * i);
-                const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
-                qw *= inv; qx *= inv; qy *= inv; qz *= inv;
-                const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
-                const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
-                aw = nw; ax = nx; ay = ny; az = nz;
-                const double *off = a.choff + ((size_t)c * MG_MAX_CHAIN + i) * 3;
-                const double ox = off[0], oy = off[1], oz = off[2];
-                // v' = v + 2 w (u x v) + 2 u x (u x v), u = (ax, ay, az)
-                const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
-                const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
-                p0 += ox + 2.0 * (aw * cx + dx);
-                p1 += oy + 2.0 * (aw * cy + dy);
-                p2 += oz + 2.0 * (aw * cz + dz);
-            }
-            const double pj[3] = {p0, p1, p2};
-            double ds = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                double t = par[2 + i];
-                if (t == t) ds += (t - pj[i]) * (t - pj[i]);
-            }
-            lds_r[c * MG_SC_CANDS + lane] = par[1] * sqrt(ds);
-            continue;
-        }
-        const int d_lo = (type == MG_CONSTRAINT_POSITION) ? 0 : 3;
-        const int d_hi = (type == MG_CONSTRAINT_POSITION) ? 3 : 7;
-#pragma unroll
-        for (int d = 0; d < 7; d++) {
-            if (d >= d_lo && d < d_hi && d < a.nch) fr[d] = channel(r0 + d);
-        }
-        if (type == MG_CONSTRAINT_POSITION) {
-            // _point_distance: axes whose target is NaN (the reference's None) are ignored
-            double ds = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                double t = par[2 + i];
-                if (t == t) ds += (t - fr[i]) * (t - fr[i]);
-            }
-            lds_r[c * MG_SC_CANDS + lane] = par[1] * sqrt(ds);
-        } else {
-            // heading = xz of (rotation of the root quaternion (w,x,y,z)) applied to ref_dir
-            const double qw = fr[3], qx = fr[4], qy = fr[5], qz = fr[6];
-            const double nq = qw * qw + qx * qx + qy * qy + qz * qz, s2 = 2.0 / nq;
-            const double rx = par[5], ry = par[6], rz = par[7];
-            const double px = (1.0 - s2 * (qy * qy + qz * qz)) * rx + s2 * (qx * qy - qz * qw) * ry + s2 * (qx * qz + qy * qw) * rz;
-            const double pz = s2 * (qx * qz - qy * qw) * rx + s2 * (qy * qz + qx * qw) * ry + (1.0 - s2 * (qx * qx + qy * qy)) * rz;
-            const double tn = sqrt(par[2] * par[2] + par[3] * par[3]);
-            const double tx = par[2] / tn, tz = par[3] / tn;
-            const double mn = sqrt(px * px + pz * pz);
-            const double mx = px / mn, mz = pz / mn;
-            double cosang = (tx * mx + tz * mz) / (sqrt(tx * tx + tz * tz) * sqrt(mx * mx + mz * mz));
-            cosang = fmin(1.0, fmax(cosang, -1.0));
-            lds_r[c * MG_SC_CANDS + lane] = par[1] * fabs(acos(cosang) * (180.0 / M_PI));
-        }
+        lds_r[c * MG_SC_CANDS + lane] = mg_constraint_residual(a, c, channel);
     }
     __syncthreads();
     if (a.res)   // (n_samples, n) row-major: consecutive threads write consecutive constraints of a candidate
@@ -133,10 +134,98 @@ __global__ __launch_bounds__(MG_SC_CANDS *MG_SC_WAVES) void mg_score_kernel(mg_s
     }
 }
 
+// MFMA kernel (n_components <= 64): every pose channel the constraints need is one row of the fused keyframe
+// matrices, so all channels of 16 candidates are ONE small GEMM, X (16 x L) . W^T (L x rows) + bias, on the float64
+// matrix pipe: per 16-row tile KK chained v_mfma_f64_16x16x4_f64 with C-in = bias -- the same k-ordered fma chain
+// as the VALU kernel's dot products, hence the same bits.  A wave owns a 16-candidate tile: channels -> LDS
+// ([16][rows+1]), then its lanes take (candidate, constraint) pairs, compute the residuals (FK chains included)
+// from LDS, and lanes < 16 sum a candidate's residuals in constraint order.
+template <int KK, bool LAT_F64, bool OUT_F64>
+__global__ __launch_bounds__(256) void mg_score_mfma_kernel(mg_score_args a, const double *__restrict__ Wpack,   // [RT][KK][64]
+                                                           const double *__restrict__ bpad,                    // [RT*16]
+                                                           const int RT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, g = lane >> 4;
+    const int vs = RT * 16 + 1;                                          // padded channel row of a candidate
+    double *vals = (double *)smem + (size_t)wave * (16 * vs + a.n * 16);  // [16][vs]
+    double *resid = vals + 16 * vs;                                      // [n][16]
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (b0 >= a.B) return;                                               // no workgroup-wide barrier below
+    const int ncand = (int)((a.B - b0) < 16 ? (a.B - b0) : 16);
+    typename mg_gmm_xt<LAT_F64>::type xf[KK];
+    mg_gmm_load_x<KK, LAT_F64>(xf, a.lat, b0, ncand, a.ld, a.L, cl, g);
+    for (int rt = 0; rt < RT; rt++) {
+        const double *wp = Wpack + ((size_t)rt * KK) * 64 + lane;
+        const double c0 = bpad[rt * 16 + cl];
+        mg_f64x4 acc = {c0, c0, c0, c0};
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[kk], wp[kk * 64], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) vals[(g + 4 * r) * vs + rt * 16 + cl] = acc[r];   // C layout: col = row index, row = candidate
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its own LDS writes are visible to its reads in order
+    for (int e = lane; e < 16 * a.n; e += 64) {
+        const int cand = e & 15, c = e >> 4;
+        const double *v = vals + cand * vs;
+        resid[c * 16 + cand] = mg_constraint_residual(a, c, [&](int row) { return v[row]; });
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (a.res)
+        for (int e = lane; e < ncand * a.n; e += 64) {
+            const int cand = e / a.n, c = e - cand * a.n;
+            a.res[(b0 + cand) * a.n + c] = resid[c * 16 + cand];
+        }
+    if (a.out && lane < ncand) {
+        double err = 0.0;
+        for (int c = 0; c < a.n; c++) err += resid[c * 16 + lane];
+        if (OUT_F64) ((double *)a.out)[b0 + lane] = err;
+        else ((float *)a.out)[b0 + lane] = (float)err;
+    }
+}
+
+template <int KK>
+static int mg_launch_score_mfma_kk(mg_primitive *p, const mg_constraint_set *cs, const mg_score_args &a, bool lf, bool of) {
+    const size_t lds = (size_t)4 * (16 * (cs->RT * 16 + 1) + (size_t)std::max(cs->n, 1) * 16) * 8;
+    if (lds > 150 * 1024) return MG_ERR_UNSUPPORTED;
+    const int64_t grid = (a.B + 63) / 64;
+    if (grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
+    hipStream_t st = p->ctx->stream;
+    if (lds > 64 * 1024) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_mfma_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_mfma_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_mfma_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_mfma_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (lf && of) hipLaunchKernelGGL((mg_score_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+    else if (lf) hipLaunchKernelGGL((mg_score_mfma_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+    else if (of) hipLaunchKernelGGL((mg_score_mfma_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+    else hipLaunchKernelGGL((mg_score_mfma_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res) {
     mg_score_args a;
     a.res = res;
     a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
+    const bool lf0 = ldt == MG_F64, of0 = odt == MG_F64;
+    if (cs->d_Wpack && !getenv("MG_SCORE_VALU")) {   // MG_SCORE_VALU: tests force the fallback kernel
+        int rc = MG_ERR_UNSUPPORTED;
+        switch (p->KK) {
+            case 2: rc = mg_launch_score_mfma_kk<2>(p, cs, a, lf0, of0); break;
+            case 4: rc = mg_launch_score_mfma_kk<4>(p, cs, a, lf0, of0); break;
+            case 6: rc = mg_launch_score_mfma_kk<6>(p, cs, a, lf0, of0); break;
+            case 8: rc = mg_launch_score_mfma_kk<8>(p, cs, a, lf0, of0); break;
+            case 10: rc = mg_launch_score_mfma_kk<10>(p, cs, a, lf0, of0); break;
+            case 12: rc = mg_launch_score_mfma_kk<12>(p, cs, a, lf0, of0); break;
+            case 14: rc = mg_launch_score_mfma_kk<14>(p, cs, a, lf0, of0); break;
+            case 16: rc = mg_launch_score_mfma_kk<16>(p, cs, a, lf0, of0); break;
+            default: break;
+        }
+        if (rc != MG_ERR_UNSUPPORTED) return rc;
+    }
     size_t lds = ((size_t)MG_SC_CANDS * (p->L + 1) + (size_t)std::max(cs->n, 1) * MG_SC_CANDS) * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_score_constraints: n_components %d x %d constraints too large for LDS", p->L, cs->n); return MG_ERR_UNSUPPORTED; }
     int64_t grid = (B + MG_SC_CANDS - 1) / MG_SC_CANDS;

@@ -519,3 +519,32 @@ def test_large_ragged_batch_on_device(ctx):
     for buf in (d_S, d_f, d_l):
         buf.free()
     prim.close()
+
+
+def test_score_kernels_mfma_and_valu_agree_bit_for_bit(ctx, monkeypatch):
+    """The fused keyframe scorer has two kernels: channels = X . W^T on the f64 matrix pipe (n_components <= 64) and
+    a dot product per channel on the VALU (fallback).  Both run the same k-ordered fma chain from the bias and share
+    the residual code, so errors and residual matrices must be identical, ragged batches included."""
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+            {"type": "direction", "t": 155.0, "weight": 0.5, "target": [0.5, 1.0]},
+            {"type": "joint_position", "joint": "LeftHand_EndSite", "t": 100.25, "weight": 1.0, "target": [30.0, 90.0, -20.0]},
+            {"type": "joint_position", "joint": "RightFoot", "t": 40.5, "weight": 2.0, "target": [None, 0.0, None]},
+            {"type": "position", "t": 0.0, "weight": 0.1, "target": [0.0, 0.0, 0.0]}]
+    cset = _capi.ConstraintSet(prim, cons, sk)
+    rng = np.random.default_rng(6)
+    for B in (1, 15, 64, 65, 1000):
+        for dtype in (np.float32, np.float64):
+            S = rng.standard_normal((B, 40)).astype(dtype)
+            monkeypatch.delenv("MG_SCORE_VALU", raising=False)
+            e1, r1 = prim.score_constraints(cset, S), prim.score_constraint_residuals(cset, S)
+            monkeypatch.setenv("MG_SCORE_VALU", "1")
+            e2, r2 = prim.score_constraints(cset, S), prim.score_constraint_residuals(cset, S)
+            np.testing.assert_array_equal(e1.view(np.uint64), e2.view(np.uint64), err_msg="B=%d %s" % (B, dtype))
+            np.testing.assert_array_equal(r1.view(np.uint64), r2.view(np.uint64), err_msg="B=%d %s" % (B, dtype))
+            np.testing.assert_allclose(r1.sum(axis=1), e1, rtol=1e-13, atol=1e-12)
+    cset.close()
+    prim.close()
