@@ -313,13 +313,14 @@ struct mg_sample_args {
     int32_t K, L;
 };
 
+#define MG_SAMPLE_BLOCK 64   // one wave per workgroup: 8192 samples spread over 128 CUs (the kernel is latency bound)
 template <bool X_F64>
-__global__ __launch_bounds__(256) void mg_gmm_sample_kernel(mg_sample_args a) {
+__global__ __launch_bounds__(MG_SAMPLE_BLOCK) void mg_gmm_sample_kernel(mg_sample_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = a.L, zs = L + 1;
-    double *lds_z = (double *)smem;   // [256][L+1]
+    double *lds_z = (double *)smem;   // [MG_SAMPLE_BLOCK][L+1]
     const int tid = threadIdx.x;
-    const int64_t b = (int64_t)blockIdx.x * 256 + tid;
+    const int64_t b = (int64_t)blockIdx.x * MG_SAMPLE_BLOCK + tid;
     if (b < a.n) {
         double *z = lds_z + (size_t)tid * zs;
         for (int i = 0; i < L; i += 4) {
@@ -350,16 +351,16 @@ __global__ __launch_bounds__(256) void mg_gmm_sample_kernel(mg_sample_args a) {
 int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
     mg_sample_args a;
     a.chol = p->d_gchol; a.mean = p->d_gmean; a.cum = cum_dev; a.x = x; a.comp = comp; a.n = n; a.ld = ld; a.seed = seed; a.K = p->K; a.L = p->L;
-    size_t lds = (size_t)256 * (p->L + 1) * 8;
+    size_t lds = (size_t)MG_SAMPLE_BLOCK * (p->L + 1) * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_gmm_sample: n_components %d too large", p->L); return MG_ERR_UNSUPPORTED; }
-    int64_t grid = (n + 255) / 256;
+    int64_t grid = (n + MG_SAMPLE_BLOCK - 1) / MG_SAMPLE_BLOCK;
     if (grid > 0x7fffffff) { mg_set_error("mg_gmm_sample: too many samples"); return MG_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_kernel<true>), dim3((int)grid), dim3(256), lds, p->ctx->stream, a);
-    else hipLaunchKernelGGL((mg_gmm_sample_kernel<false>), dim3((int)grid), dim3(256), lds, p->ctx->stream, a);
+    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_kernel<true>), dim3((int)grid), dim3(MG_SAMPLE_BLOCK), lds, p->ctx->stream, a);
+    else hipLaunchKernelGGL((mg_gmm_sample_kernel<false>), dim3((int)grid), dim3(MG_SAMPLE_BLOCK), lds, p->ctx->stream, a);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
