@@ -348,7 +348,7 @@ __global__ __launch_bounds__(MG_SAMPLE_BLOCK) void mg_gmm_sample_kernel(mg_sampl
     }
 }
 
-int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
+int mg_launch_gmm_sample_valu(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
     mg_sample_args a;
     a.chol = p->d_gchol; a.mean = p->d_gmean; a.cum = cum_dev; a.x = x; a.comp = comp; a.n = n; a.ld = ld; a.seed = seed; a.K = p->K; a.L = p->L;
     size_t lds = (size_t)MG_SAMPLE_BLOCK * (p->L + 1) * 8;
@@ -533,4 +533,104 @@ int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_
     else hipLaunchKernelGGL((mg_gmm_jac_kernel<false>), dim3((int)grid), dim3(256), lds, st, a);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
+}
+
+
+// MFMA sampler (n_components <= 64): a wave owns 16 consecutive rows of ONE component (tiles never straddle
+// components: the host passes tile prefix sums).  The standard normals of the tile come from the same Philox
+// counters as in the VALU kernel (row, group of four) -> LDS; x = mu + z L^T is KK chained v_mfma_f64_16x16x4_f64 per
+// 16-column tile with C-in = mu and the lower-triangular factor's transposed fragments (k-steps beyond the diagonal
+// are skipped; zero entries inside the diagonal block add exact zeros), i.e. the VALU kernel's ascending fma chain:
+// same seed, same rows, same bits.
+template <int KK, bool X_F64>
+__global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *__restrict__ cpack,     // [K][JT][KK][64]
+                                                                const double *__restrict__ meanpad,   // [K][JT*16]
+                                                                const int64_t *__restrict__ cum,      // [K+1] rows, then [K+1] tiles
+                                                                void *__restrict__ x, int32_t *__restrict__ comp,
+                                                                const int64_t n_tiles, const int64_t ld, const uint64_t seed,
+                                                                const int K, const int L, const int JT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int JTM = (KK + 3) / 4;
+    constexpr int ZS = 4 * KK + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, g = lane >> 4;
+    mg_lds_f64 *zt = (mg_lds_f64 *)smem + wave * 16 * ZS;   // [16][ZS] standard normals of this wave's tile
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= n_tiles) return;
+    const int64_t *tcum = cum + K + 1;
+    int c = 0;
+    while (c + 1 < K && t >= tcum[c + 1]) c++;
+    const int64_t row0 = cum[c] + (t - tcum[c]) * 16;
+    const int nrow = (int)((cum[c + 1] - row0) < 16 ? (cum[c + 1] - row0) : 16);
+    for (int e = lane; e < 16 * KK; e += 64) {
+        const int r = e & 15, q = e >> 4;
+        const int64_t b = row0 + r;
+        uint32_t rr[4];
+        mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)q, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+        const double inv = 1.0 / 4294967296.0;
+        const double u0 = ((double)rr[0] + 1.0) * inv, u1 = (double)rr[1] * inv;
+        const double u2 = ((double)rr[2] + 1.0) * inv, u3 = (double)rr[3] * inv;
+        const double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
+        zt[r * ZS + 4 * q + 0] = m0 * cos(2.0 * M_PI * u1);
+        zt[r * ZS + 4 * q + 1] = m0 * sin(2.0 * M_PI * u1);
+        zt[r * ZS + 4 * q + 2] = m1 * cos(2.0 * M_PI * u3);
+        zt[r * ZS + 4 * q + 3] = m1 * sin(2.0 * M_PI * u3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double za[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) za[kk] = (4 * kk + g < L) ? zt[cl * ZS + 4 * kk + g] : 0.0;
+#pragma unroll
+    for (int it = 0; it < JTM; it++) {
+        if (it < JT) {
+            const double *cp = cpack + (((size_t)c * JT + it) * KK) * 64 + lane;
+            const double m = meanpad[((size_t)c * JT + it) * 16 + cl];
+            mg_f64x4 acc = {m, m, m, m};
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++)
+                if (kk < 4 * (it + 1)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[kk], cp[kk * 64], acc, 0, 0, 0);
+            const int i = 16 * it + cl;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = g + 4 * r;
+                if (row < nrow && i < L) {
+                    if (X_F64) ((double *)x)[(row0 + row) * ld + i] = acc[r];
+                    else ((float *)x)[(row0 + row) * ld + i] = (float)acc[r];
+                }
+            }
+        }
+    }
+    if (comp && lane < nrow) comp[row0 + lane] = c;
+}
+
+template <int KK>
+static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev, int64_t n_tiles, uint64_t seed, void *x, int xdt,
+                                        int64_t ld, int32_t *comp) {
+    const int64_t grid = (n_tiles + 3) / 4;
+    if (grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)4 * 16 * (4 * KK + 1) * 8;
+    hipStream_t st = p->ctx->stream;
+    const int JT = (p->L + 15) / 16;
+    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+    else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
+    if (p->d_gcholpack && !getenv("MG_SAMPLE_VALU")) {   // MG_SAMPLE_VALU: tests force the fallback kernel
+        switch (p->KK) {
+            case 2: return mg_launch_gmm_sample_mfma_kk<2>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 4: return mg_launch_gmm_sample_mfma_kk<4>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 6: return mg_launch_gmm_sample_mfma_kk<6>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 8: return mg_launch_gmm_sample_mfma_kk<8>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 10: return mg_launch_gmm_sample_mfma_kk<10>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 12: return mg_launch_gmm_sample_mfma_kk<12>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 14: return mg_launch_gmm_sample_mfma_kk<14>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 16: return mg_launch_gmm_sample_mfma_kk<16>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            default: break;
+        }
+    }
+    return mg_launch_gmm_sample_valu(p, n, cum_dev, seed, x, xdt, ld, comp);
 }

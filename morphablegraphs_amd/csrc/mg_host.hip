@@ -470,7 +470,7 @@ static void mg_primitive_free(mg_primitive *p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean,
-                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad, p->d_gPTpack};
+                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad, p->d_gPTpack, p->d_gcholpack, p->d_gmeanpad};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (mg_time_grid *g : {p->canonical, p->coeff_grid})
@@ -649,6 +649,20 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                             if (i < L && j < L && i <= j)
                                 ptpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * L * L + (size_t)i * L + j];
                         }
+            // sampler: x = mu + z L^T, lane l supplies B[k = 4*kk + (l >> 4) (= j)][col = i] = L_k[i][j] (lower triangular)
+            std::vector<double> cpack((size_t)K * JT * KK * 64, 0.0), meanpad((size_t)K * JT * 16, 0.0);
+            for (int k = 0; k < K; k++) {
+                for (int i = 0; i < L; i++) meanpad[(size_t)k * JT * 16 + i] = p->gm[(size_t)k * L + i];
+                for (int it = 0; it < JT; it++)
+                    for (int kk = 0; kk < KK; kk++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            int j = 4 * kk + (lane >> 4), i = 16 * it + (lane & 15);
+                            if (i < L && j < L && j <= i)
+                                cpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = chol[(size_t)k * L * L + (size_t)i * L + j];
+                        }
+            }
+            if (rc == MG_OK) rc = mg_upload(ctx, cpack, &p->d_gcholpack);
+            if (rc == MG_OK) rc = mg_upload(ctx, meanpad, &p->d_gmeanpad);
             if (rc == MG_OK) rc = mg_upload(ctx, ppack, &p->d_gPpack);
             if (rc == MG_OK) rc = mg_upload(ctx, ptpack, &p->d_gPTpack);
             if (rc == MG_OK) rc = mg_upload(ctx, mpad, &p->d_gmPpad);
@@ -810,10 +824,12 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
     MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_gmm_sample: bad dtype %d", xdt);
     MG_REQUIRE(counts != nullptr, "mg_gmm_sample: counts is NULL");
     MG_REQUIRE(ld >= p->L, "mg_gmm_sample: leading dimension %lld < n_components %d", (long long)ld, p->L);
-    std::vector<int64_t> cum(p->K + 1, 0);
+    // [0 .. K]: row prefix sums; [K+1 .. 2K+1]: prefix sums of 16-row tiles (a tile never straddles two components)
+    std::vector<int64_t> cum(2 * (size_t)p->K + 2, 0);
     for (int k = 0; k < p->K; k++) {
         MG_REQUIRE(counts[k] >= 0, "mg_gmm_sample: counts[%d] < 0", k);
         cum[k + 1] = cum[k] + counts[k];
+        cum[p->K + 1 + k + 1] = cum[p->K + 1 + k] + (counts[k] + 15) / 16;
     }
     MG_REQUIRE(cum[p->K] == n, "mg_gmm_sample: counts sum to %lld, expected %lld", (long long)cum[p->K], (long long)n);
     if (n == 0) return MG_OK;
@@ -824,7 +840,7 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
     MG_HIP_CHECK(hipMemcpyAsync(scr, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, p->ctx->stream));
     MG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));  // cum is a stack-lifetime host buffer
     mg_prof_begin(p->ctx, 4);
-    rc = mg_launch_gmm_sample(p, n, (const int64_t *)scr, seed, x, xdt, ld, comp);
+    rc = mg_launch_gmm_sample(p, n, (const int64_t *)scr, cum[2 * (size_t)p->K + 1], seed, x, xdt, ld, comp);
     mg_prof_end(p->ctx, 4);
     return rc;
 }

@@ -120,6 +120,8 @@ struct mg_primitive {
     double *d_gP = nullptr;      // [K][L(j)][L(i)]: column j of P_k contiguous over i
     double *d_gmP = nullptr;     // [K][L]: mu_k . P_k
     double *d_gPTpack = nullptr; // [K][JT][KK][64]: B fragments of P_k^T (Jacobian)
+    double *d_gcholpack = nullptr; // [K][JT][KK][64]: B fragments of chol_k^T (sampler)
+    double *d_gmeanpad = nullptr;  // [K][JT*16]: means, zero padded
     double *d_gconst = nullptr;  // [K]: log w_k + sum log diag P_k - 0.5 L log 2pi
     double *d_gmean = nullptr;   // [K][L]
     double *d_gchol = nullptr;   // [K][L][L] lower Cholesky of covars (sampler)
@@ -148,7 +150,7 @@ bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt);
-int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);

@@ -548,3 +548,24 @@ def test_score_kernels_mfma_and_valu_agree_bit_for_bit(ctx, monkeypatch):
             np.testing.assert_allclose(r1.sum(axis=1), e1, rtol=1e-13, atol=1e-12)
     cset.close()
     prim.close()
+
+
+def test_device_sampler_mfma_and_valu_produce_the_same_rows(ctx, monkeypatch):
+    """The device sampler has an MFMA kernel (16-row tiles inside one component, x = mu + z L^T on the f64 matrix
+    pipe) and a lane-per-row VALU kernel; both draw z from the same Philox counters (row, group of four) and run the
+    same ascending fma chain, so the same seed must give the same rows bit for bit -- ragged component counts
+    (tiles that end inside a component), empty components, float32 and float64 output."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    for counts in ([100, 0, 17, 1, 250, 16, 33, 95], [0, 0, 0, 0, 0, 0, 0, 5], [4096] + [0] * 7):
+        for dtype in (np.float64, np.float32):
+            monkeypatch.delenv("MG_SAMPLE_VALU", raising=False)
+            X1, c1 = prim.gmm_sample(counts, 1234, dtype=dtype)
+            monkeypatch.setenv("MG_SAMPLE_VALU", "1")
+            X2, c2 = prim.gmm_sample(counts, 1234, dtype=dtype)
+            view = np.uint64 if dtype == np.float64 else np.uint32
+            np.testing.assert_array_equal(X1.view(view), X2.view(view), err_msg=str(counts))
+            np.testing.assert_array_equal(c1, c2)
+            np.testing.assert_array_equal(c1, np.repeat(np.arange(8), counts))
+            assert np.isfinite(X1).all()
+    prim.close()
