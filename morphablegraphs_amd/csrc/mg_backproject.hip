@@ -159,11 +159,12 @@ struct mg_unit {
 struct mg_cursor {   // (tile, chunk) cursor over a workgroup's run of units: no division inside the unit loop
     int tile, chunk;
 };
-__device__ __forceinline__ mg_unit mg_unit_at(const mg_chunk *__restrict__ chunks, const mg_frames_args &a, const mg_cursor &c) {
+__device__ __forceinline__ mg_unit mg_unit_at(const mg_chunk *__restrict__ chunks, const mg_frames_args &a, const mg_cursor &c, int rot = 0) {
     mg_unit r;
     r.tile = c.tile;
-    r.chunk = c.chunk;
-    r.ck = chunks[c.chunk];
+    r.chunk = c.chunk + rot;
+    if (r.chunk >= a.n_chunks) r.chunk -= a.n_chunks;
+    r.ck = chunks[r.chunk];
     r.b0 = (int64_t)c.tile * MG_NCAND;
     r.ncand = (int)((a.B - r.b0) < MG_NCAND ? (a.B - r.b0) : MG_NCAND);
     return r;
@@ -354,6 +355,10 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     mg_cursor cur;
     cur.tile = (int)(u_begin / a.n_chunks);
     cur.chunk = (int)(u_begin - (int64_t)cur.tile * a.n_chunks);
+    // When this workgroup owns whole tiles it walks each tile's chunks starting at chunk (blockIdx mod n_chunks): the
+    // workgroups run nearly in lockstep, and without the rotation all 256 of them request the same E' rows from L2 at
+    // the same time, the cold first unit above all (-2 % kernel time; MG_DEBUG_FLAGS & 128 switches it off).
+    const int rot = (!(a.debug & 128) && cur.chunk == 0 && (n_units % a.n_chunks) == 0) ? (int)(blockIdx.x % a.n_chunks) : 0;
     const int cl = lane & 15, g = lane >> 4;
 
     if (wave >= MG_WS_NPW) {
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         int slot = 0;
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
-            const mg_unit un_prev = mg_unit_at(chunks, a, cur);
+            const mg_unit un_prev = mg_unit_at(chunks, a, cur, rot);
             mg_cursor_next(cur, a.n_chunks);
             mg_wait_producers(prog, u + 1);
             MG_STAMP(1);
@@ -432,12 +437,13 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) sfrag[kk] = 0.f;
         int cur_tile = -1;
+        int prev_tile = -1, prev_chunk = -1;
         const float2 *ep = (const float2 *)Epack;
         int slot = 0;
         MG_STAMP_DECL
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
-            const mg_unit un = mg_unit_at(chunks, a, cur);
+            const mg_unit un = mg_unit_at(chunks, a, cur, rot);
             mg_cursor_next(cur, a.n_chunks);
             if (u >= nbuf) mg_wait_consumers(prog, u - nbuf + 1);   // the slot's previous unit has been swept
             MG_STAMP(5);
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 // bits) instead of being recomputed: 37 % fewer MFMAs and E' fragment loads, which is what slows
                 // the sweep waves down (matrix-pipe time on the shared SIMDs, L2 requests in the store path).
                 int n_ov = 0, src_shift = 0;
-                if (u > 0 && un.chunk > 0 && !(a.debug & 128)) {
+                if (un.tile == prev_tile && un.chunk == prev_chunk + 1) {   // the previous unit was this tile's previous chunk
                     const mg_chunk pk = chunks[un.chunk - 1];
                     src_shift = ck.rt0 - pk.rt0;
                     n_ov = pk.rt0 + pk.ntiles - ck.rt0;   // tiles [ck.rt0, pk.rt0 + pk.ntiles) exist in the previous slot
@@ -474,6 +480,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 }
                 MG_STAMP(3);
             }
+            prev_tile = un.tile;
+            prev_chunk = un.chunk;
             mg_publish(prog, wave, lane, u + 1);
             if (++slot == nbuf) slot = 0;
             MG_STAMP(4);
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         int slot = 0;
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
-            const mg_unit un = mg_unit_at(chunks, a, cur);
+            const mg_unit un = mg_unit_at(chunks, a, cur, rot);
             mg_cursor_next(cur, a.n_chunks);
             if (u >= nbuf) mg_wait_consumers(prog, u - nbuf + 1);
             MG_STAMP(5);
