@@ -215,7 +215,7 @@ __device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {
 template <int KK>
 __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, const float *__restrict__ mean32,
                                                const mg_chunk &ck, float *lds_c, int stride, int t_first, int pw, int npw,
-                                               const float (&sfrag)[KK], int lane, int cl, int g) {
+                                               const float (&sfrag)[KK], int lane, int cl, int g, int rot = 0) {
     float2 fa[2][KK / 2], na[2][KK / 2];
     f32x4 fm[2], nm[2];
     auto load_tile = [&](int t, float2(&fr)[KK / 2], f32x4 &cin) {
@@ -225,11 +225,19 @@ __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, co
         for (int q = 0; q < KK / 2; q++) fr[q] = p[q * 64];
         cin = *(const f32x4 *)(mean32 + (size_t)(ck.rt0 + tc) * 16 + 4 * g);
     };
-    int t = t_first + pw;   // tiles below t_first are carried over from the previous unit's window
+    // rounds of two tiles; round r of this wave covers tiles t_first + pw + 2 npw r (+ npw); tiles below t_first are
+    // carried over from the previous unit's window.  The rounds are walked from a workgroup-specific start (rot):
+    // neighbouring workgroups then fetch different E' tiles at the same moment.
+    const int span = ck.ntiles - t_first - pw;
+    const int nrounds = span > 0 ? (span + 2 * npw - 1) / (2 * npw) : 0;
+    if (nrounds == 0) return;
+    int rr = rot % nrounds;
+    int t = t_first + pw + 2 * npw * rr;
     load_tile(t, fa[0], fm[0]);
     load_tile(t + npw, fa[1], fm[1]);
-    while (t < ck.ntiles) {
-        const int tn = t + 2 * npw;
+    for (int r = 0; r < nrounds; r++) {
+        if (++rr == nrounds) rr = 0;
+        const int tn = t_first + pw + 2 * npw * rr;
         load_tile(tn, na[0], nm[0]);
         load_tile(tn + npw, na[1], nm[1]);
         f32x4 acc0 = fm[0], acc1 = fm[1];
@@ -241,7 +249,7 @@ __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, co
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1][q].y, sfrag[2 * q + 1], acc1, 0, 0, 0);
         }
         // D[row = 4g + reg][col = cl]: four consecutive padded rows of candidate cl
-        *(f32x4 *)&lds_c[cl * stride + t * 16 + 4 * g] = acc0;
+        if (t < ck.ntiles) *(f32x4 *)&lds_c[cl * stride + t * 16 + 4 * g] = acc0;
         if (t + npw < ck.ntiles) *(f32x4 *)&lds_c[cl * stride + (t + npw) * 16 + 4 * g] = acc1;
 #pragma unroll
         for (int q = 0; q < KK / 2; q++) { fa[0][q] = na[0][q]; fa[1][q] = na[1][q]; }
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 // this slot held unit u - nbuf and was the copy source of unit u - nbuf + 1: every row producer must
                 // have finished that unit before the slot is overwritten (with two slots: a full meeting per unit)
                 if (u >= nbuf - 1) mg_wait_row_producers(prog, u - nbuf + 2);
-                mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, n_ov, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g);
+                mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, n_ov, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g, (a.debug & 256) ? 0 : (int)(blockIdx.x / a.n_chunks));
                 MG_STAMP(2);
                 if (n_ov > 0) {
                     mg_wait_row_producers(prog, u);   // the previous unit's window is complete
