@@ -199,3 +199,15 @@ def test_skeleton_description_for_the_c_abi():
     class Hand(object):
         canonical_keyframe, weight_factor, position, orientation, joint_name = 10, 1.0, [1.0, 2.0, 3.0], None, "LeftHand"
     assert conv([Hand()], "Hips")[0] == {"type": "joint_position", "t": 10.0, "weight": 1.0, "target": [1.0, 2.0, 3.0], "joint": "LeftHand"}
+
+
+def test_c_abi_header_is_plain_c(tmp_path):
+    """include/mg_hip.h is the drop-in boundary: it must compile as strict C99 (and as C++) without any HIP or
+    torch header, so that a cgo / JNI / ctypes binding can be generated from it."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mg_hip.h"\nint main(void) { mg_primitive_desc d; mg_keyframe_constraint c; mg_skeleton_desc s; '
+                   '(void)d; (void)c; (void)s; return MG_OK; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
