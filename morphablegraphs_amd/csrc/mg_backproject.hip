@@ -25,7 +25,8 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 struct mg_frames_args {
     int64_t B, ld;
     int32_t T, D, Dp, cshift, L, nroot, n_chunks, n_tiles, stride, max_wi;
-    int32_t debug;   // MG_DEBUG_FLAGS (bench ablations only): 1 = producers idle, 2 = consumers idle, 16 = phase timers
+    int32_t debug;   // MG_DEBUG_FLAGS (ablations and timers, never set in production): 1 = producers idle, 2 = sweep idle,
+                     // 16 = per-wave phase timers, 32 = wave-0 sub-phases (serialising), 128 = no chunk rotation, 256 = no tile-round rotation
     int32_t nbuf;    // LDS ring depth (2 or 3)
 };
 
