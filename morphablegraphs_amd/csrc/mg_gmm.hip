@@ -4,6 +4,8 @@
 // which is sklearn's GaussianMixture.score_samples as the reference builds it
 // (reference morphablegraphs/motion_model/motion_primitive.py:126-144; formula twin
 //  morphablegraphs/motion_model/extended_mgrd_mixture_model.py:60-108).
+#include <cstring>
+
 #include "mg_internal.h"
 #include "mg_gmm_device.h"
 
@@ -542,10 +544,16 @@ int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_
 // 16-column tile with C-in = mu and the lower-triangular factor's transposed fragments (k-steps beyond the diagonal
 // are skipped; zero entries inside the diagonal block add exact zeros), i.e. the VALU kernel's ascending fma chain:
 // same seed, same rows, same bits.
-template <int KK, bool X_F64>
+// row and tile prefix sums as a kernel argument (n_gmm <= 16): no upload, no synchronisation per call
+struct mg_cum_arg {
+    int64_t v[2 * (MG_SAMPLE_ARG_K + 1)];
+};
+
+template <int KK, bool X_F64, bool CUM_ARG>
 __global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *__restrict__ cpack,     // [K][JT][KK][64]
                                                                 const double *__restrict__ meanpad,   // [K][JT*16]
-                                                                const int64_t *__restrict__ cum,      // [K+1] rows, then [K+1] tiles
+                                                                const int64_t *__restrict__ cum_dev,  // [K+1] rows, then [K+1] tiles
+                                                                const mg_cum_arg cum_arg,
                                                                 void *__restrict__ x, int32_t *__restrict__ comp,
                                                                 const int64_t n_tiles, const int64_t ld, const uint64_t seed,
                                                                 const int K, const int L, const int JT) {
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *_
     mg_lds_f64 *zt = (mg_lds_f64 *)smem + wave * 16 * ZS;   // [16][ZS] standard normals of this wave's tile
     const int64_t t = (int64_t)blockIdx.x * 4 + wave;
     if (t >= n_tiles) return;
+    const int64_t *cum = CUM_ARG ? cum_arg.v : cum_dev;
     const int64_t *tcum = cum + K + 1;
     int c = 0;
     while (c + 1 < K && t >= tcum[c + 1]) c++;
@@ -605,32 +614,44 @@ __global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *_
 }
 
 template <int KK>
-static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev, int64_t n_tiles, uint64_t seed, void *x, int xdt,
-                                        int64_t ld, int32_t *comp) {
+static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed,
+                                        void *x, int xdt, int64_t ld, int32_t *comp) {
     const int64_t grid = (n_tiles + 3) / 4;
     if (grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
     const size_t lds = (size_t)4 * 16 * (4 * KK + 1) * 8;
     hipStream_t st = p->ctx->stream;
     const int JT = (p->L + 15) / 16;
-    if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
-    else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+    mg_cum_arg ca;
+    memset(&ca, 0, sizeof(ca));
+    if (cum_host) {
+        memcpy(ca.v, cum_host, sizeof(int64_t) * 2 * (p->K + 1));
+        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+    } else {
+        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+    }
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
 
-int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
-    if (p->d_gcholpack && !getenv("MG_SAMPLE_VALU")) {   // MG_SAMPLE_VALU: tests force the fallback kernel
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
+    if (p->d_gcholpack && (cum_host || cum_dev) && !getenv("MG_SAMPLE_VALU")) {   // MG_SAMPLE_VALU: tests force the fallback kernel
         switch (p->KK) {
-            case 2: return mg_launch_gmm_sample_mfma_kk<2>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
-            case 4: return mg_launch_gmm_sample_mfma_kk<4>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
-            case 6: return mg_launch_gmm_sample_mfma_kk<6>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
-            case 8: return mg_launch_gmm_sample_mfma_kk<8>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
-            case 10: return mg_launch_gmm_sample_mfma_kk<10>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
-            case 12: return mg_launch_gmm_sample_mfma_kk<12>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
-            case 14: return mg_launch_gmm_sample_mfma_kk<14>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
-            case 16: return mg_launch_gmm_sample_mfma_kk<16>(p, cum_dev, n_tiles, seed, x, xdt, ld, comp);
+            case 2: return mg_launch_gmm_sample_mfma_kk<2>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 4: return mg_launch_gmm_sample_mfma_kk<4>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 6: return mg_launch_gmm_sample_mfma_kk<6>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 8: return mg_launch_gmm_sample_mfma_kk<8>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 10: return mg_launch_gmm_sample_mfma_kk<10>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 12: return mg_launch_gmm_sample_mfma_kk<12>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 14: return mg_launch_gmm_sample_mfma_kk<14>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 16: return mg_launch_gmm_sample_mfma_kk<16>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
             default: break;
         }
     }
     return mg_launch_gmm_sample_valu(p, n, cum_dev, seed, x, xdt, ld, comp);
+}
+
+bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p) {
+    return p->d_gcholpack != nullptr && p->KK > 0 && p->K <= MG_SAMPLE_ARG_K && !getenv("MG_SAMPLE_VALU");
 }

@@ -834,13 +834,20 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
     MG_REQUIRE(cum[p->K] == n, "mg_gmm_sample: counts sum to %lld, expected %lld", (long long)cum[p->K], (long long)n);
     if (n == 0) return MG_OK;
     MG_REQUIRE(x != nullptr, "mg_gmm_sample: output pointer is NULL");
+    int rc;
+    if (mg_gmm_sample_takes_host_prefix(p)) {   // prefix sums travel as a kernel argument: nothing to upload or wait for
+        mg_prof_begin(p->ctx, 4);
+        rc = mg_launch_gmm_sample(p, n, nullptr, cum.data(), cum[2 * (size_t)p->K + 1], seed, x, xdt, ld, comp);
+        mg_prof_end(p->ctx, 4);
+        return rc;
+    }
     void *scr = nullptr;
-    int rc = mg_ctx_scratch(p->ctx, (int64_t)cum.size() * 8, &scr);
+    rc = mg_ctx_scratch(p->ctx, (int64_t)cum.size() * 8, &scr);
     if (rc != MG_OK) return rc;
     MG_HIP_CHECK(hipMemcpyAsync(scr, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, p->ctx->stream));
     MG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));  // cum is a stack-lifetime host buffer
     mg_prof_begin(p->ctx, 4);
-    rc = mg_launch_gmm_sample(p, n, (const int64_t *)scr, cum[2 * (size_t)p->K + 1], seed, x, xdt, ld, comp);
+    rc = mg_launch_gmm_sample(p, n, (const int64_t *)scr, nullptr, cum[2 * (size_t)p->K + 1], seed, x, xdt, ld, comp);
     mg_prof_end(p->ctx, 4);
     return rc;
 }

@@ -150,7 +150,9 @@ bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt);
-int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
+#define MG_SAMPLE_ARG_K 16   // mixtures up to this size pass their prefix sums to the sampler as a kernel argument
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
+bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p);
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
