@@ -256,6 +256,14 @@ int mg_step_frames_and_logp(mg_primitive *prim, const void *latents_dev, int lat
 int mg_best_candidate(mg_primitive *prim, const mg_constraint_set *cs, const void *latents_dev, int latent_dtype,
                       int64_t n_samples, int64_t ld, int64_t *best_index, double *min_error);
 
+/* One outgoing option of a planner step (reference graph_walk_planner.py:184-226), enqueued WITHOUT
+ * synchronisation: n candidates from the device sampler (counts per mixture component like mg_gmm_sample) into
+ * x_dev (n, ld), their errors into errors_dev (n) float64, and into result_dev the first-minimum
+ * {int64 index, float64 error} followed by the winning latent as float64[n_components].  Enqueue all options of a
+ * step, synchronise once, read the results. */
+int mg_option_step(mg_primitive *prim, const mg_constraint_set *cs, int64_t n_samples, const int64_t *counts,
+                   uint64_t seed, void *x_dev, int x_dtype, int64_t ld, double *errors_dev, void *result_dev);
+
 /* ---- host-pointer convenience variants (H2D, launch, D2H, synchronise) ---------------- */
 int mg_back_project_frames_host(mg_primitive *prim, const mg_time_grid *grid, const void *latents,
                                 int latent_dtype, int64_t n_samples, int64_t ld, float *frames, int path);

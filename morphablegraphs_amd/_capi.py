@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_best_candidate", "mg_best_candidate_host",
+    "mg_option_step",
 ]
 
 
@@ -160,6 +161,7 @@ def load_library(path=None):
         "mg_constraint_set_create_fk": [vp, vp, vp, i32, vp],
         "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
+        "mg_option_step": [vp, vp, i64, vp, u64, vp, i32, i64, vp, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
         "mg_score_constraint_residuals_host": [vp, vp, vp, i32, i64, i64, vp],
         "mg_gmm_log_prob_jac_host": [vp, vp, i32, i64, i64, vp],
@@ -317,7 +319,7 @@ class TimeGrid(object):
         return i0, w, t
 
     def close(self):
-        if self.owned and getattr(self, "handle", None) and self.prim.handle:
+        if self.owned and getattr(self, "handle", None) and self.prim.handle and self.prim.ctx.handle:
             self.prim.lib.mg_time_grid_destroy(self.handle)
         self.handle = None
 
@@ -373,7 +375,8 @@ class ConstraintSet(object):
         self.n = n
 
     def close(self):
-        if getattr(self, "handle", None) and self.prim.handle:
+        # the C object points at its primitive and context: never touch it after either of them has been destroyed
+        if getattr(self, "handle", None) and self.prim.handle and self.prim.ctx.handle:
             self.prim.lib.mg_constraint_set_destroy(self.handle)
         self.handle = None
 

@@ -43,7 +43,7 @@ def constraints_to_device_form(constraints, root_joint=None):
 
 
 _CSET_CACHE = []   # [(key, ConstraintSet)], most recent last: an optimizer calls the objective hundreds of times with
-_CSET_CACHE_SIZE = 8   # the same constraints, and building a set uploads its fused keyframe matrices
+_CSET_CACHE_SIZE = 64   # the same constraints, and building a set uploads its fused keyframe matrices
 
 
 def _constraint_key(prim, clist, skeleton):
@@ -61,7 +61,7 @@ def cached_constraint_set(prim, clist, skeleton=None):
     optimizer evaluates the same constraints again and again, and building a set uploads its fused matrices."""
     key = _constraint_key(prim, clist, skeleton)
     for i in range(len(_CSET_CACHE) - 1, -1, -1):   # entries whose primitive has been closed meanwhile are dropped
-        if not (_CSET_CACHE[i][1].handle and _CSET_CACHE[i][1].prim.handle):
+        if not (_CSET_CACHE[i][1].handle and _CSET_CACHE[i][1].prim.handle and _CSET_CACHE[i][1].prim.ctx.handle):
             _CSET_CACHE.pop(i)
     for i, (k, cs) in enumerate(_CSET_CACHE):
         if k == key:

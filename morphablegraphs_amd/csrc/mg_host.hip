@@ -1216,3 +1216,18 @@ extern "C" int mg_best_candidate_host(mg_primitive *p, const mg_constraint_set *
     if ((rc = io.stage(p->ctx, lat, B * ld * (int64_t)mg_dt_size(dt), std::max<int64_t>(B, 1) * 8)) != MG_OK) return rc;
     return mg_best_candidate_impl("mg_best_candidate_host", p, cs, io.d_in, dt, B, ld, io.d_out, best, minv);
 }
+
+// One option of a planner step, enqueued without synchronisation (reference graph_walk_planner.py:184-226 evaluates
+// the options one after the other): draw n candidates on the device, score them, first-minimum argmin, copy the
+// winner next to the result.  result_dev: {int64 index, float64 error, float64 latent[n_components]}.
+extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int64_t n, const int64_t *counts, uint64_t seed,
+                              void *x_dev, int xdt, int64_t ld, double *errors_dev, void *result_dev) {
+    MG_REQUIRE(p && cs && cs->prim == p, "mg_option_step: constraint set is NULL or belongs to another primitive");
+    MG_REQUIRE(n > 0 && x_dev && errors_dev && result_dev, "mg_option_step: bad arguments");
+    int rc = mg_gmm_sample(p, n, counts, seed, x_dev, xdt, ld, nullptr);
+    if (rc == MG_OK) rc = mg_score_constraints(p, cs, x_dev, xdt, n, ld, errors_dev, MG_F64);
+    if (rc == MG_OK) rc = mg_argmin_first_dev(p->ctx, errors_dev, MG_F64, n, result_dev);
+    if (rc == MG_OK) rc = mg_launch_gather_winner(p->ctx, x_dev, xdt, ld, p->L, result_dev);
+    return rc;
+}
+

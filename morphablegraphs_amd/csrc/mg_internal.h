@@ -154,6 +154,7 @@ int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64
 int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
 bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p);
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res);
+int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld, int L, void *result_dev);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
 int mg_setup_kernel_attributes(mg_context *ctx);

@@ -287,3 +287,18 @@ int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *ou
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
+
+// result = {int64 index, float64 error} written by the argmin kernel, followed by the winning latent row
+__global__ __launch_bounds__(64) void mg_gather_winner_kernel(const void *x, int x_f64, int64_t ld, int L, void *result) {
+    const int64_t idx = ((const int64_t *)result)[0];
+    double *row = (double *)((char *)result + 16);
+    for (int i = threadIdx.x; i < L; i += 64)
+        row[i] = x_f64 ? ((const double *)x)[idx * ld + i] : (double)((const float *)x)[idx * ld + i];
+}
+
+int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld, int L, void *result_dev) {
+    hipLaunchKernelGGL(mg_gather_winner_kernel, dim3(1), dim3(64), 0, ctx->stream, x, xdt == MG_F64 ? 1 : 0, ld, L, result_dev);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+

@@ -247,33 +247,34 @@ class HipPrimitiveSet(object):
     def evaluate_options_on_device(self, options, constraints_per_option, n_samples, seed=0, dtype=np.float32):
         """GraphWalkPlanner's option evaluation (reference graph_walk_planner.py:184-226) without host round trips:
         for every option the component counts come from NumPy's stream, the candidates from the device sampler,
-        scoring and first-minimum argmin stay on the device; everything is enqueued for all options first (one
-        stream per option with separate_streams) and only then the 16-byte results and the winning latents are
-        read back.  Returns (best_option, {name: (best_sample, min_error)})."""
+        scoring, first-minimum argmin and the copy of the winner stay on the device (mg_option_step, one call per
+        option, no synchronisation); only after all options are enqueued are the (16 + 8 L)-byte results read back.
+        Returns (best_option, {name: (best_sample, min_error)})."""
         from .candidate_scoring import cached_constraint_set
+        n = int(n_samples)
+        item = np.dtype(dtype).itemsize
+        code = _capi.MG_F64 if np.dtype(dtype) == np.float64 else _capi.MG_F32
         pending = []
         for k, name in enumerate(options):
             node = self.nodes[name]
             prim, ctx = node._prim, node._prim.ctx
             L = prim.n_components
-            item = np.dtype(dtype).itemsize
-            key = (name, int(n_samples), np.dtype(dtype).str)
-            if key not in self._buffers:   # persistent per-option device buffers: no allocation inside a step
-                self._buffers[key] = (ctx.malloc(max(int(n_samples), 1) * L * item), ctx.malloc(max(int(n_samples), 1) * 8), ctx.malloc(16))
-            d_x, d_e, d_o = self._buffers[key]
+            key = (name, n, np.dtype(dtype).str)
+            bufs = self._buffers.get(key)
+            if bufs is None:   # persistent per-option device buffers: no allocation inside a step
+                bufs = self._buffers[key] = (ctx.malloc(max(n, 1) * L * item), ctx.malloc(max(n, 1) * 8), ctx.malloc(16 + 8 * L))
+            d_x, d_e, d_r = bufs
             cset = cached_constraint_set(prim, constraints_to_device_form(constraints_per_option[name]))
-            weights = np.asarray(node.gaussian_mixture_model.weights_, dtype=np.float64)
-            counts = np.random.multinomial(int(n_samples), weights / weights.sum()).astype(np.int64)
-            prim.gmm_sample_dev(counts, int(seed) + k, d_x, dtype, L)
-            prim.score_constraints_dev(cset, d_x, dtype, int(n_samples), L, d_e, np.float64)
-            _capi._check(prim.lib.mg_argmin_first_dev(ctx.handle, d_e.ptr, _capi.MG_F64, int(n_samples), d_o.ptr))
-            pending.append((name, ctx, d_x, d_o, L, item))
+            weights = node.gaussian_mixture_model.weights_
+            counts = np.random.multinomial(n, weights / weights.sum()).astype(np.int64)
+            _capi._check(prim.lib.mg_option_step(prim.handle, cset.handle, n, counts.ctypes.data, int(seed) + k, d_x.ptr, code, L,
+                                                 d_e.ptr, d_r.ptr))
+            pending.append((name, ctx, d_r, L))
         results = {}
-        for name, ctx, d_x, d_o, L, item in pending:
-            raw = ctx.download(d_o, (16,), np.uint8)       # {int64 index, float64 value}; synchronises this option's stream
-            idx, err = int(raw[:8].view(np.int64)[0]), float(raw[8:].view(np.float64)[0])
-            best = ctx.download(d_x.ptr.value + idx * L * item, (L,), dtype)
-            results[name] = (best.astype(np.float64), err)
+        for name, ctx, d_r, L in pending:
+            raw = ctx.download(d_r, (16 + 8 * L,), np.uint8)       # synchronises this option's stream
+            idx, err = int(raw[:8].view(np.int64)[0]), float(raw[8:16].view(np.float64)[0])
+            results[name] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
         errors = [results[n][1] for n in options]
         return options[int(np.argmin(errors))], results
 
