@@ -122,6 +122,9 @@ const char *mg_status_string(int status);
 int mg_context_create(int device, void *stream, mg_context **out);
 void mg_context_destroy(mg_context *ctx);
 int mg_context_set_stream(mg_context *ctx, void *stream);
+/* The persistent frames kernel normally occupies every CU (one workgroup each, all of its LDS); leave n CUs free
+ * so that kernels on other streams -- RCCL's all-gather of the scores -- run beside it instead of behind it. */
+int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 int mg_context_synchronize(mg_context *ctx);
 /* name (256 bytes), CU count, total bytes of the context's device */
 int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *total_mem);

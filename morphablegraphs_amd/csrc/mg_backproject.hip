@@ -283,10 +283,10 @@ template <int KK, bool LAT_F64>
 __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const double *__restrict__ gPpack,
                                                    const double *__restrict__ gmP, const double *__restrict__ gcst,
                                                    const void *__restrict__ lat, int64_t B, int64_t ld, int L, int n_tiles,
-                                                   int gK, int gJT, int pw, int lane) {
+                                                   int gK, int gJT, int pw, int lane, int group) {
     const int cl = lane & 15, g = lane >> 4;
     mg_lds_f64 *gterms = (mg_lds_f64 *)(prog + 32);   // [2][K*16]
-    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x;
+    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x + 2 * group;   // this group's (at most two) tiles
     const int64_t gt1 = ((int64_t)blockIdx.x + 1) * n_tiles / gridDim.x;
     if (gt0 < gt1) {
         const bool has_b = gt0 + 1 < gt1;
@@ -305,18 +305,18 @@ __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const doubl
             if (has_b) mg_gmm_apply_component(f, k, gJT, xb, gterms + gK * 16, cl, g);
         }
     }
-    mg_publish(prog + 16, pw, lane, 1);   // gdone[pw]
+    mg_publish(prog + 16, pw, lane, group + 1);   // gdone[pw]
 }
 
 __device__ __forceinline__ void mg_fused_gmm_finish(mg_lds_int *prog, float *__restrict__ logp, int64_t B, int n_tiles, int gK,
-                                                    int pw, int lane) {
+                                                    int pw, int lane, int group) {
     mg_lds_int *gdone = prog + 16;
     mg_lds_f64 *gterms = (mg_lds_f64 *)(prog + 32);   // [2][K*16]
     mg_lds_f64 *gexps = gterms + 2 * gK * 16;          // [2][K*16]
-    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x;
+    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x + 2 * group;
     const int64_t gt1 = ((int64_t)blockIdx.x + 1) * n_tiles / gridDim.x;
     if (pw < 2 && gt0 + pw < gt1) {
-        mg_wait_producers(gdone, 1);   // all four producer waves have written their components' terms
+        mg_wait_producers(gdone, group + 1);   // all four producer waves have written their components' terms
         const mg_lds_f64 *terms = gterms + pw * gK * 16;
         mg_lds_f64 *exps = gexps + pw * gK * 16;
         for (int e = lane; e < gK * 16; e += 64) exps[e] = mg_gmm_exp_entry(terms, gK, e);
@@ -324,6 +324,7 @@ __device__ __forceinline__ void mg_fused_gmm_finish(mg_lds_int *prog, float *__r
         const int64_t b0 = (gt0 + pw) * MG_NCAND;
         if (lane < MG_NCAND && b0 + lane < B) logp[b0 + lane] = (float)mg_gmm_logsumexp(terms, exps, gK, lane);
     }
+    if (pw < 2) mg_publish(prog + 24, pw, lane, group + 1);   // gfin[pw]: the term buffer may be written again
 }
 
 template <int KK, bool LAT_F64, bool FUSE_GMM>
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     unsigned char *tb_base = ro_base + nbuf * MG_RO_BYTES;            // per-sample tables, one per ring slot
     unsigned char *rs_base = tb_base + nbuf * MG_TB_BYTES;            // float64 root image (wave 0 only)
     mg_lds_int *prog = (mg_lds_int *)(rs_base + (size_t)MG_NCAND * root_stride * 8);   // 32 counters: progress, GMM
-    if (tid < 32) prog[tid] = 0;
+    if (tid < 32) prog[tid] = (tid == 26 || tid == 27) ? 0x7fffffff : 0;   // 26, 27: padding of the gfin wait
     __syncthreads();
 
     const int64_t U = (int64_t)a.n_tiles * a.n_chunks;
@@ -627,8 +628,16 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         MG_STAMP_DUMP;
     }
     if (FUSE_GMM && wave < MG_WS_NPW) {
-        mg_fused_gmm_terms<KK, LAT_F64>(prog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane);
-        if (wave < 2) mg_fused_gmm_finish(prog, logp, a.B, a.n_tiles, gK, wave, lane);
+        // up to four tiles per workgroup, as two groups of two written out one after the other (a loop would let the
+        // compiler hoist the exp/log polynomial constants above the MFMA code and spill)
+        mg_fused_gmm_terms<KK, LAT_F64>(prog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
+        if (wave < 2) mg_fused_gmm_finish(prog, logp, a.B, a.n_tiles, gK, wave, lane, 0);
+        const int64_t my_tiles = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x - (int64_t)blockIdx.x * a.n_tiles / gridDim.x;
+        if (my_tiles > 2) {
+            mg_wait_producers(prog + 24, 1);   // gfin[0], gfin[1] (entries 2, 3 are preset): both term buffers are free again
+            mg_fused_gmm_terms<KK, LAT_F64>(prog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 1);
+            if (wave < 2) mg_fused_gmm_finish(prog, logp, a.B, a.n_tiles, gK, wave, lane, 1);
+        }
     }
 }
 
@@ -775,9 +784,9 @@ static int mg_fused_gmm_lds(const mg_primitive *p) { return 4 * p->K * 16 * 8; }
 
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
-    const int64_t grid = std::min<int64_t>(n_tiles * g->n_chunks, p->ctx->n_cu);
+    const int64_t grid = std::min<int64_t>(n_tiles * g->n_chunks, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
     return g->mfma_ok && p->d_gPpack != nullptr && p->K <= 16 && p->KK <= MG_FUSE_MAX_KK && g->lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 &&
-           n_tiles <= 2 * grid;   // the fused scoring handles at most two 16-candidate tiles per workgroup
+           (n_tiles + grid - 1) / grid <= 4;   // the fused scoring handles at most four 16-candidate tiles per workgroup
 }
 
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp) {
@@ -804,7 +813,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
         return MG_ERR_UNSUPPORTED;
     }
     if (logp) lds += mg_fused_gmm_lds(p);
-    const int grid = (int)std::min<int64_t>(units, p->ctx->n_cu);
+    const int grid = (int)std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
     switch (p->KK) {
 #ifndef MG_ONLY_KK10
         case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);

@@ -129,6 +129,11 @@ extern "C" int mg_context_synchronize(mg_context *ctx) {
     return MG_OK;
 }
 
+extern "C" int mg_context_set_reserved_cus(mg_context *ctx, int32_t n) {
+    MG_REQUIRE(ctx != nullptr && n >= 0, "mg_context_set_reserved_cus: bad arguments");
+    ctx->reserved_cus = std::min<int32_t>(n, ctx->n_cu - 1);
+    return MG_OK;
+}
 extern "C" int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *total_mem) {
     MG_REQUIRE(ctx != nullptr, "mg_context_device_info: ctx is NULL");
     if (name) { strncpy(name, ctx->name, 255); name[255] = 0; }

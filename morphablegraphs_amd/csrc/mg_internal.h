@@ -41,6 +41,7 @@ struct mg_context {
     bool profile = false;
     std::vector<mg_event_pair> pending;
     std::vector<hipEvent_t> free_events;
+    int reserved_cus = 0;                        // CUs the persistent kernel leaves free (e.g. for RCCL kernels)
     int prof_interval = 1;                       // bracket every n-th launch of a slot
     int64_t prof_seen[MG_PROFILE_SLOTS] = {0};
     double prof_ms[MG_PROFILE_SLOTS] = {0};

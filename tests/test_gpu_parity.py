@@ -283,7 +283,7 @@ def test_full_size_properties(ctx):
     Ff, lpf = _fused_step(ctx, prim, S, 156, 79)
     np.testing.assert_array_equal(_bits(Ff), _bits(F))
     np.testing.assert_array_equal(_bits(lpf), _bits(prim.gmm_log_prob(S, dtype=np.float32)))
-    # just above the fused limit (more than two tiles per workgroup): the entry point takes two launches, same bits
+    # more than two tiles per workgroup: the fused kernel scores a second group of tiles, same bits
     S2 = np.vstack([S, S[:48]])
     Ff2, lpf2 = _fused_step(ctx, prim, S2, 156, 79)
     np.testing.assert_array_equal(_bits(Ff2[:B]), _bits(F))
@@ -568,4 +568,29 @@ def test_device_sampler_mfma_and_valu_produce_the_same_rows(ctx, monkeypatch):
             np.testing.assert_array_equal(c1, c2)
             np.testing.assert_array_equal(c1, np.repeat(np.arange(8), counts))
             assert np.isfinite(X1).all()
+    prim.close()
+
+
+def test_fused_step_with_reserved_cus_and_up_to_four_tiles_per_workgroup(ctx):
+    """mg_context_set_reserved_cus leaves CUs free for kernels on other streams (RCCL's all-gather): the persistent
+    kernel then runs fewer, longer workgroups and the fused mixture scoring handles three or four 16-candidate tiles
+    per workgroup in two groups.  Frames and scores must not change by a bit; above four tiles the entry point takes
+    two launches."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(13)
+    n_cu = ctx.device_info()["n_cu"]
+    try:
+        for reserved, B in ((0, 12 * n_cu + 5), (0, 64 * n_cu), (8, 32 * n_cu), (8, 33 * n_cu + 7), (n_cu - 3, 200), (0, 70 * n_cu)):
+            ctx.set_reserved_cus(reserved)
+            S = rng.standard_normal((B, 40)).astype(np.float32)
+            frames, logp = _fused_step(ctx, prim, S, 156, 79)
+            idx = np.concatenate([[0, B - 1], rng.choice(B, size=24, replace=False)])
+            np.testing.assert_array_equal(_bits(frames[idx]), _bits(cp.frames_f32model(S[idx].astype(np.float64))),
+                                          err_msg="reserved=%d B=%d" % (reserved, B))
+            np.testing.assert_array_equal(_bits(logp), _bits(prim.gmm_log_prob(S, dtype=np.float32)), err_msg="reserved=%d B=%d" % (reserved, B))
+            np.testing.assert_array_equal(_bits(frames), _bits(prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)))
+    finally:
+        ctx.set_reserved_cus(0)
     prim.close()
