@@ -111,6 +111,23 @@ typedef struct mg_skeleton_desc {
     const int32_t *quat_channel;  /* (n_joints) first pose channel of the joint's (w,x,y,z), -1 = not animated (identity) */
 } mg_skeleton_desc;
 
+/* The 2-D alignment MotionPrimitiveConstraints.evaluate applies to every candidate outside local-coordinate mode
+ * (reference motion_primitive_constraints.py:110-114, objective_functions.py:35-37 ->
+ * anim_utils align_quaternion_frames_automatically): the candidate's control points are rotated about the y axis
+ * so that the heading of the aligning node in its FIRST control point equals the heading in the last frame of the
+ * previous motion, and translated in x and z so that its first root position lands on that frame's (y untouched);
+ * heading = xz of the node's global orientation applied to ref_dir.  Rotation and translation differ per candidate.
+ * The scorer never transforms control points: with c = h.b and s = h x b (h = previous heading, b = candidate
+ * heading, both unit) a position becomes (c x + s z + tx, y, -s x + c z + tz), a heading (c hx + s hz, -s hx + c hz).
+ * PARITY UNPINNED: anim_utils is absent; pinned by a 4x4-matrix oracle that does transform the control points. */
+typedef struct mg_alignment_desc {
+    int32_t joint;        /* skeleton.aligning_root_node as an index into the skeleton (0 = root, no skeleton needed) */
+    int32_t reserved;
+    double position[3];   /* root position of the previous motion's last frame (x and z are used) */
+    double heading[2];    /* (x, z) heading of the aligning node in that frame; normalised by the library */
+    double ref_dir[3];    /* skeleton.aligning_root_dir, e.g. (0,0,1) */
+} mg_alignment_desc;
+
 /* ---- library / context ------------------------------------------------------ */
 const char *mg_version(void);
 /* message of the last failed call on this thread */
@@ -229,6 +246,11 @@ int mg_constraint_set_create(mg_primitive *prim, const mg_keyframe_constraint *c
 /* the same with a skeleton, which MG_CONSTRAINT_JOINT_POSITION constraints need (chains of <= MG_MAX_CHAIN joints) */
 int mg_constraint_set_create_fk(mg_primitive *prim, const mg_skeleton_desc *skeleton,
                                 const mg_keyframe_constraint *cons, int32_t n, mg_constraint_set **out);
+/* global-coordinate mode: every candidate is aligned to the previous motion before its constraints are evaluated
+ * (alignment may be NULL = local mode; skeleton may be NULL when no constraint and no alignment needs a chain) */
+int mg_constraint_set_create_aligned(mg_primitive *prim, const mg_skeleton_desc *skeleton,
+                                     const mg_keyframe_constraint *cons, int32_t n,
+                                     const mg_alignment_desc *alignment, mg_constraint_set **out);
 void mg_constraint_set_destroy(mg_constraint_set *cs);
 int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
                          const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
-    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_best_candidate", "mg_best_candidate_host",
+    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_best_candidate", "mg_best_candidate_host",
     "mg_option_step",
 ]
 
@@ -63,6 +63,16 @@ class KeyframeConstraint(C.Structure):
 class SkeletonDesc(C.Structure):   # struct mg_skeleton_desc
     _fields_ = [("n_joints", C.c_int32), ("reserved", C.c_int32), ("parents", C.c_void_p), ("offsets", C.c_void_p),
                 ("quat_channel", C.c_void_p)]
+
+
+class AlignmentDesc(C.Structure):   # struct mg_alignment_desc
+    _fields_ = [("joint", C.c_int32), ("reserved", C.c_int32), ("position", C.c_double * 3), ("heading", C.c_double * 2),
+                ("ref_dir", C.c_double * 3)]
+
+
+def _quat_mul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
 
 
 class Skeleton(object):
@@ -92,6 +102,33 @@ class Skeleton(object):
             out.insert(0, j)
             j = int(self.parents[j])
         return out
+
+    def heading(self, frame, joint=0, ref_dir=(0.0, 0.0, 1.0)):
+        """Unit (x, z) of the joint's global orientation in `frame` applied to ref_dir: what anim_utils'
+        get_global_node_orientation_vector returns for one pose vector (host side, once per step: the previous
+        motion's last frame; the candidates' own headings are computed on the device)."""
+        frame = np.asarray(frame, dtype=np.float64)
+        q = np.array([1.0, 0.0, 0.0, 0.0])
+        for j in self.chain(joint):
+            ch = int(self.quat_channel[j])
+            if ch >= 0:
+                qj = frame[ch:ch + 4]
+                nq = np.linalg.norm(qj)
+                if not (np.isfinite(nq) and nq > 0.0):
+                    raise ValueError("quaternion of joint %r in the previous frame is zero or not finite" % (self.names[j],))
+                q = _quat_mul(q, qj / nq)
+        v = np.asarray(ref_dir, dtype=np.float64)
+        u = q[1:]
+        p = v + 2.0 * (q[0] * np.cross(u, v) + np.cross(u, np.cross(u, v)))
+        d = np.array([p[0], p[2]])
+        return d / np.linalg.norm(d)
+
+    def alignment_to(self, prev_frame, joint=0, ref_dir=(0.0, 0.0, 1.0)):
+        """The alignment record (ConstraintSet `alignment`) that attaches a candidate to a previous motion ending
+        in `prev_frame` (= prev_frames[-1] of motion_primitive_constraints.py:110-114)."""
+        prev_frame = np.asarray(prev_frame, dtype=np.float64)
+        return {"joint": self.index(joint), "position": [float(v) for v in prev_frame[:3]],
+                "heading": [float(v) for v in self.heading(prev_frame, joint, ref_dir)], "ref_dir": [float(v) for v in ref_dir]}
 
     def desc(self):
         return SkeletonDesc(len(self.names), 0, self.parents.ctypes.data, self.offsets.ctypes.data, self.quat_channel.ctypes.data)
@@ -160,6 +197,7 @@ def load_library(path=None):
         "mg_score_constraints_host": [vp, vp, vp, i32, i64, i64, vp, i32],
         "mg_score_constraint_residuals": [vp, vp, vp, i32, i64, i64, vp],
         "mg_constraint_set_create_fk": [vp, vp, vp, i32, vp],
+        "mg_constraint_set_create_aligned": [vp, vp, vp, i32, vp, vp],
         "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_option_step": [vp, vp, i64, vp, u64, vp, i32, i64, vp, vp],
@@ -338,11 +376,14 @@ class TimeGrid(object):
 class ConstraintSet(object):
     """constraints: list of dicts {"type": "position"|"direction"|"joint_position", "t": float, "weight": float,
     "target": [x|None, y|None, z|None] | [dx, dz], "ref_dir": (rx, ry, rz), "joint": name or index}; a
-    `skeleton` (Skeleton) is needed for "joint_position"."""
+    `skeleton` (Skeleton) is needed for "joint_position".  `alignment` = {"joint", "position", "heading",
+    "ref_dir"} (Skeleton.alignment_to) switches to global coordinates: every candidate is aligned to the previous
+    motion before its constraints are evaluated; without a skeleton the aligning node is the root joint."""
 
-    def __init__(self, prim, constraints, skeleton=None):
+    def __init__(self, prim, constraints, skeleton=None, alignment=None):
         self.prim = prim
         self.skeleton = skeleton
+        self.alignment = alignment
         n = len(constraints)
         arr = (KeyframeConstraint * max(n, 1))()
         for i, c in enumerate(constraints):
@@ -371,7 +412,17 @@ class ConstraintSet(object):
             else:
                 raise ValueError("unknown constraint type %r" % (c["type"],))
         h = C.c_void_p()
-        if skeleton is None:
+        if alignment is not None:
+            al = AlignmentDesc()
+            al.joint = int(alignment.get("joint", 0)) if skeleton is None else skeleton.index(alignment.get("joint", 0))
+            for a in range(3):
+                al.position[a] = float(alignment["position"][a])
+                al.ref_dir[a] = float(alignment.get("ref_dir", (0.0, 0.0, 1.0))[a])
+            al.heading[0], al.heading[1] = float(alignment["heading"][0]), float(alignment["heading"][1])
+            d = skeleton.desc() if skeleton is not None else None
+            _check(prim.lib.mg_constraint_set_create_aligned(prim.handle, C.byref(d) if d is not None else None,
+                                                             C.cast(arr, C.c_void_p), n, C.byref(al), C.byref(h)))
+        elif skeleton is None:
             _check(prim.lib.mg_constraint_set_create(prim.handle, C.cast(arr, C.c_void_p), n, C.byref(h)))
         else:
             d = skeleton.desc()

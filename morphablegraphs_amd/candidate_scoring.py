@@ -3,6 +3,10 @@ MotionPrimitiveGenerator.evaluate_samples_using_constraints
 (reference morphablegraphs/motion_generator/motion_primitive_generator.py:230-261), shaped after the
 MGRD precedent MGRDSampleFilter.score_samples (reference mgrd_sample_filter.py:63-75).
 
+Global coordinates (`prev_frames` given, constraints not `is_local`): every candidate is first aligned to the last
+previous frame as MotionPrimitiveConstraints.evaluate does (motion_primitive_constraints.py:110-114), on the device,
+per candidate (mg_alignment_desc); the planner always scores this way (graph_walk_planner.py:179 never localises).
+
 Constraints covered by the fused kernel: the FK-free ones path following uses
 (locomotion_constraints_builder.py:82-117) -- root position at a canonical keyframe
 (GlobalTransformConstraint, position only, root joint) and 2-D heading (Direction2DConstraint) -- and, given
@@ -46,20 +50,46 @@ _CSET_CACHE = []   # [(key, ConstraintSet)], most recent last: an optimizer call
 _CSET_CACHE_SIZE = 64   # the same constraints, and building a set uploads its fused keyframe matrices
 
 
-def _constraint_key(prim, clist, skeleton):
+_ROOT_ONLY = _capi.Skeleton([("root", None, (0.0, 0.0, 0.0))], ["root"])
+
+
+def alignment_from_prev_frames(prev_frames, constraints=None, skeleton=None):
+    """The alignment record for scoring in global coordinates, or None where the reference does not align:
+    `is_local` constraints (motion_primitive_constraints.py:111) or no previous frames.  The aligning node and its
+    reference direction come from the reference skeleton on the constraints (`skeleton.aligning_root_node`,
+    `.aligning_root_dir`) when there is one, else the root joint and (0, 0, 1)."""
+    if getattr(constraints, "is_local", False):
+        return None
+    if prev_frames is None:
+        if getattr(constraints, "start_pose", None) is not None and hasattr(constraints, "is_local"):
+            raise NotImplementedError("alignment to a start pose (objective_functions.py:38-47) is not on the device")
+        return None
+    last = np.asarray(prev_frames, dtype=np.float64)
+    last = last[-1] if last.ndim == 2 else last
+    ref_sk = getattr(constraints, "skeleton", None)
+    node = getattr(ref_sk, "aligning_root_node", None)
+    ref_dir = tuple(float(v) for v in getattr(ref_sk, "aligning_root_dir", (0.0, 0.0, 1.0)))
+    if skeleton is None:
+        if node is not None and node != getattr(ref_sk, "root", node):
+            raise NotImplementedError("aligning node %r is not the root joint: pass a _capi.Skeleton (hip_skeleton)" % (node,))
+        return _ROOT_ONLY.alignment_to(last, 0, ref_dir)
+    return skeleton.alignment_to(last, 0 if node is None else node, ref_dir)
+
+
+def _constraint_key(prim, clist, skeleton, alignment=None):
     def freeze(v):
         if isinstance(v, dict):
             return tuple(sorted((k, freeze(x)) for k, x in v.items()))
         if isinstance(v, (list, tuple, np.ndarray)):
             return tuple(freeze(x) for x in v)
         return v
-    return (id(prim), prim.handle.value, id(skeleton), freeze(clist))
+    return (id(prim), prim.handle.value, id(skeleton), freeze(clist), freeze(alignment) if alignment is not None else None)
 
 
-def cached_constraint_set(prim, clist, skeleton=None):
+def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
     """A device constraint set for these (device-form) constraints, reused across calls: a graph walk or an
     optimizer evaluates the same constraints again and again, and building a set uploads its fused matrices."""
-    key = _constraint_key(prim, clist, skeleton)
+    key = _constraint_key(prim, clist, skeleton, alignment)
     for i in range(len(_CSET_CACHE) - 1, -1, -1):   # entries whose primitive has been closed meanwhile are dropped
         if not (_CSET_CACHE[i][1].handle and _CSET_CACHE[i][1].prim.handle and _CSET_CACHE[i][1].prim.ctx.handle):
             _CSET_CACHE.pop(i)
@@ -67,7 +97,7 @@ def cached_constraint_set(prim, clist, skeleton=None):
         if k == key:
             _CSET_CACHE.append(_CSET_CACHE.pop(i))
             return cs
-    cs = _capi.ConstraintSet(prim, clist, skeleton)
+    cs = _capi.ConstraintSet(prim, clist, skeleton, alignment)
     _CSET_CACHE.append((key, cs))
     while len(_CSET_CACHE) > _CSET_CACHE_SIZE:
         _CSET_CACHE.pop(0)[1].close()
@@ -85,9 +115,11 @@ class HipSampleFilter(object):
     """score_samples(primitive, samples, constraints) -> errors[n], like MGRDSampleFilter."""
 
     @staticmethod
-    def score_samples(motion_primitive, samples, constraints, dtype=np.float64, skeleton=None):
+    def score_samples(motion_primitive, samples, constraints, dtype=np.float64, skeleton=None, prev_frames=None):
         prim = motion_primitive._prim if hasattr(motion_primitive, "_prim") else motion_primitive
-        cset = _capi.ConstraintSet(prim, constraints_to_device_form(constraints), skeleton)
+        clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
+        cset = _capi.ConstraintSet(prim, constraints_to_device_form(clist), skeleton,
+                                   alignment_from_prev_frames(prev_frames, constraints, skeleton))
         try:
             return prim.score_constraints(cset, np.asarray(samples), dtype=dtype)
         finally:
@@ -95,17 +127,17 @@ class HipSampleFilter(object):
 
 
 def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frames=None, skeleton=None):
-    """Drop-in for MotionPrimitiveGenerator.evaluate_samples_using_constraints in local-coordinate
-    mode: returns (samples[best_idx], min_error) with the reference's first-minimum rule, and
-    updates constraints.min_error / constraints.evaluations when those attributes exist."""
-    if prev_frames is not None:
-        raise NotImplementedError("global-coordinate scoring needs anim_utils' alignment; use use_local_coordinates")
+    """Drop-in for MotionPrimitiveGenerator.evaluate_samples_using_constraints: returns (samples[best_idx],
+    min_error) with the reference's first-minimum rule, and updates constraints.min_error / constraints.evaluations
+    when those attributes exist.  With `prev_frames` (and constraints that are not `is_local`) every candidate is
+    aligned to the previous motion first, like MotionPrimitiveConstraints.evaluate."""
     samples = np.asarray(samples)
     prim_obj = mp_node.motion_primitive if hasattr(mp_node, "motion_primitive") else mp_node
     prim = prim_obj._prim
     clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
     skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
-    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton)
+    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton,
+                                 alignment_from_prev_frames(prev_frames, constraints, skeleton))
     best_idx, min_error = prim.best_candidate(cset, samples)   # one upload, two launches, 16 bytes back
     if hasattr(constraints, "min_error"):
         constraints.min_error = min_error
@@ -114,7 +146,7 @@ def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frame
     return samples[best_idx], min_error
 
 
-def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleton=None, dtype=np.float32):
+def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleton=None, dtype=np.float32, prev_frames=None):
     """The gpu_batch step without the host round trip: component counts from NumPy's global stream (the first
     draw sklearn's GaussianMixture.sample makes), latents from the device Philox sampler (NOT sklearn's Mersenne
     stream: distributional parity only), scoring and first-minimum argmin on the device; only the winning latent
@@ -124,7 +156,8 @@ def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleto
     ctx = prim.ctx
     clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
     skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
-    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton)
+    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton,
+                                 alignment_from_prev_frames(prev_frames, constraints, skeleton))
     L = prim.n_components
     weights = np.asarray(prim_obj.gaussian_mixture_model.weights_, dtype=np.float64)
     counts = np.random.multinomial(int(n_samples), weights / weights.sum()).astype(np.int64)

@@ -858,8 +858,8 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
 }
 
 // ---- constraint sets ---------------------------------------------------------------------
-extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
-                                           int32_t n, mg_constraint_set **out) {
+extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
+                                                int32_t n, const mg_alignment_desc *al, mg_constraint_set **out) {
     MG_REQUIRE(p && out && n >= 0 && (n == 0 || cons), "mg_constraint_set_create: bad arguments");
     *out = nullptr;
     const int nch = std::min(7, p->D), L = p->L, D = p->D;
@@ -874,7 +874,19 @@ extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_de
     }
     // chains (root first) and row counts
     std::vector<std::vector<int>> chains(n);
-    std::vector<int32_t> woff(n + 1, 0), chain_len(n, 0);
+    std::vector<int32_t> woff(n + 2, 0), chain_len(n, 0);
+    std::vector<int> al_chain;   // root .. aligning node, every one of their quaternions turns the heading
+    if (al) {
+        MG_REQUIRE(D >= 7, "mg_constraint_set_create_aligned: alignment needs the root quaternion, n_dim = %d", D);
+        MG_REQUIRE(al->joint == 0 || (sk && al->joint > 0 && al->joint < sk->n_joints),
+                   "mg_constraint_set_create_aligned: aligning joint %d needs a skeleton that has it", al->joint);
+        const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
+        MG_REQUIRE(std::isfinite(hn) && hn > 0.0 && std::isfinite(al->position[0]) && std::isfinite(al->position[2]),
+                   "mg_constraint_set_create_aligned: previous heading / position not finite or zero");
+        if (al->joint == 0) al_chain.push_back(0);
+        else for (int j = al->joint; j >= 0; j = sk->parents[j]) al_chain.insert(al_chain.begin(), j);
+        MG_REQUIRE((int)al_chain.size() <= MG_MAX_CHAIN, "mg_constraint_set_create_aligned: chain of %d joints exceeds %d", (int)al_chain.size(), MG_MAX_CHAIN);
+    }
     for (int c = 0; c < n; c++) {
         const int type = cons[c].type;
         MG_REQUIRE(type == MG_CONSTRAINT_POSITION || type == MG_CONSTRAINT_DIRECTION_2D || type == MG_CONSTRAINT_JOINT_POSITION,
@@ -894,10 +906,11 @@ extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_de
         }
         woff[c + 1] = woff[c] + rows;
     }
+    woff[n + 1] = woff[n] + (al ? 3 + 4 * (int)al_chain.size() : 0);
     mg_constraint_set *cs = new (std::nothrow) mg_constraint_set();
     if (!cs) return MG_ERR_OUT_OF_MEMORY;
     cs->prim = p; cs->n = n; cs->nch = nch;
-    const size_t rows_total = (size_t)woff[n];
+    const size_t rows_total = (size_t)woff[n + 1];
     std::vector<double> W(std::max<size_t>(rows_total, 1) * L, 0.0), bias(std::max<size_t>(rows_total, 1), 0.0), par((size_t)std::max(n, 1) * 8, 0.0);
     std::vector<double> choff((size_t)std::max(n, 1) * MG_MAX_CHAIN * 3, 0.0);
     for (int c = 0; c < n; c++) {
@@ -933,7 +946,28 @@ extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_de
         q[0] = (double)cons[c].type; q[1] = cons[c].weight_factor;
         for (int i = 0; i < 3; i++) { q[2 + i] = cons[c].target[i]; q[5 + i] = cons[c].ref_dir[i]; }
     }
+    std::vector<double> align;
+    if (al) {
+        // the candidate's first control point (new_frames[0] of align_quaternion_frames_automatically): plain rows of E', mean'
+        const size_t r0 = (size_t)woff[n];
+        auto cp0_row = [&](size_t row, int d) {
+            bias[row] = p->means_[d];
+            for (int k = 0; k < L; k++) W[row * L + k] = p->Es[(size_t)d * L + k];
+        };
+        for (int d = 0; d < 3; d++) cp0_row(r0 + d, d);
+        for (size_t i = 0; i < al_chain.size(); i++) {
+            const int ch = sk ? sk->quat_channel[al_chain[i]] : 3;
+            for (int e = 0; e < 4; e++) {
+                if (ch >= 0) cp0_row(r0 + 3 + 4 * i + e, ch + e);
+                else bias[r0 + 3 + 4 * i + e] = (e == 0) ? 1.0 : 0.0;
+            }
+        }
+        const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
+        align = {(double)al_chain.size(), al->heading[0] / hn, al->heading[1] / hn, al->position[0], al->position[2],
+                 al->ref_dir[0], al->ref_dir[1], al->ref_dir[2]};
+    }
     int rc = mg_upload(p->ctx, W, &cs->d_W);
+    if (rc == MG_OK && al) rc = mg_upload(p->ctx, align, &cs->d_align);
     if (rc == MG_OK) rc = mg_upload(p->ctx, bias, &cs->d_bias);
     if (rc == MG_OK) rc = mg_upload(p->ctx, par, &cs->d_par);
     if (rc == MG_OK) rc = mg_upload(p->ctx, woff, &cs->d_woff);
@@ -959,8 +993,12 @@ extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_de
     *out = cs;
     return MG_OK;
 }
+extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
+                                           int32_t n, mg_constraint_set **out) {
+    return mg_constraint_set_create_aligned(p, sk, cons, n, nullptr, out);
+}
 extern "C" int mg_constraint_set_create(mg_primitive *p, const mg_keyframe_constraint *cons, int32_t n, mg_constraint_set **out) {
-    return mg_constraint_set_create_fk(p, nullptr, cons, n, out);
+    return mg_constraint_set_create_aligned(p, nullptr, cons, n, nullptr, out);
 }
 extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
     if (!cs) return;
@@ -973,6 +1011,7 @@ extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
     if (cs->d_choff) (void)hipFree(cs->d_choff);
     if (cs->d_Wpack) (void)hipFree(cs->d_Wpack);
     if (cs->d_bpad) (void)hipFree(cs->d_bpad);
+    if (cs->d_align) (void)hipFree(cs->d_align);
     delete cs;
 }
 

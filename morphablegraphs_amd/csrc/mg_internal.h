@@ -143,6 +143,8 @@ struct mg_constraint_set {
     double *d_Wpack = nullptr;  // [RT][KK][64] MFMA B fragments of W (n_components <= 64), RT = ceil(rows / 16)
     double *d_bpad = nullptr;   // [RT*16] bias, zero padded
     int32_t RT = 0;
+    double *d_align = nullptr;  // [8] chain length, previous heading (x, z), previous root (x, z), ref_dir; NULL = local mode;
+                                // its rows (first control point: root xyz, then the chain's quaternions) start at woff[n]
 };
 
 // launchers (each validates nothing: the C-ABI entry points did)

@@ -14,6 +14,7 @@ struct mg_score_args {
     const int32_t *woff;  // [n + 1]
     const int32_t *chain; // [n]           FK chain length
     const double *choff;  // [n][MG_MAX_CHAIN][3]
+    const double *align;  // [8] or NULL: chain length, previous heading (x,z), previous root (x,z), ref_dir; rows at woff[n]
     const void *lat;
     void *out;            // (B) summed error, or NULL
     double *res;          // (B, n) weighted residual of every constraint, or NULL
@@ -24,11 +25,45 @@ struct mg_score_args {
 // The weighted residual of constraint c for one candidate; `channel(row)` yields the candidate's pose channel of
 // that row of the fused keyframe matrices (rows of constraint c start at woff[c]).  Shared by the VALU kernel (a dot
 // product per channel) and the MFMA kernel (channels already in LDS), so both produce the same value.
+// The candidate's 2-D aligning transform (mg_alignment_desc): rotation about y by the angle between its own heading
+// in the first control point and the previous motion's, as (cos, sin) = (h . b, h x b), and the xz translation that
+// puts its first root position on the previous one.
+struct mg_align2d { double c, s, tx, tz; };
+template <typename ChannelFn>
+__device__ __forceinline__ mg_align2d mg_candidate_alignment(const mg_score_args &a, ChannelFn channel) {
+    const double *al = a.align;
+    const int r0 = a.woff[a.n], m = (int)al[0];
+    double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;   // global orientation of the aligning node
+    for (int i = 0; i < m; i++) {
+        double qw = channel(r0 + 3 + 4 * i), qx = channel(r0 + 4 + 4 * i), qy = channel(r0 + 5 + 4 * i), qz = channel(r0 + 6 + 4 * i);
+        const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+        const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+        const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+        aw = nw; ax = nx; ay = ny; az = nz;
+    }
+    const double rx = al[5], ry = al[6], rz = al[7];
+    const double cx = ay * rz - az * ry, cy = az * rx - ax * rz, cz = ax * ry - ay * rx;
+    const double dx = ay * cz - az * cy, dz = ax * cy - ay * cx;
+    double bx = rx + 2.0 * (aw * cx + dx), bz = rz + 2.0 * (aw * cz + dz);
+    const double bn = 1.0 / sqrt(bx * bx + bz * bz);
+    bx *= bn; bz *= bn;
+    mg_align2d t;
+    t.c = al[1] * bx + al[2] * bz;
+    t.s = al[1] * bz - al[2] * bx;
+    const double p0x = channel(r0), p0z = channel(r0 + 2);
+    t.tx = al[3] - (t.c * p0x + t.s * p0z);
+    t.tz = al[4] - (t.c * p0z - t.s * p0x);
+    return t;
+}
+
 template <typename ChannelFn>
 __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a, int c, ChannelFn channel) {
     const double *par = a.par + (size_t)c * 8;
     const int type = (int)par[0];
     const int r0 = a.woff[c];
+    mg_align2d al = {1.0, 0.0, 0.0, 0.0};
+    if (a.align) al = mg_candidate_alignment(a, channel);
     if (type == MG_CONSTRAINT_JOINT_POSITION) {
         // forward kinematics along the chain: p = t_root + sum_i R(q_0 .. q_(i-1)) offset_i, unit quaternions (w,x,y,z)
         double p0 = channel(r0), p1 = channel(r0 + 1), p2 = channel(r0 + 2);
@@ -50,7 +85,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
             p1 += oy + 2.0 * (aw * cy + dy);
             p2 += oz + 2.0 * (aw * cz + dz);
         }
-        const double pj[3] = {p0, p1, p2};
+        const double pj[3] = {al.c * p0 + al.s * p2 + al.tx, p1, al.c * p2 - al.s * p0 + al.tz};
         double ds = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -62,6 +97,16 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
     if (type == MG_CONSTRAINT_POSITION) {
         // _point_distance: axes whose target is NaN (the reference's None) are ignored
         double ds = 0.0;
+        if (a.align) {
+            const double x = channel(r0), z = channel(r0 + 2);
+            const double pj[3] = {al.c * x + al.s * z + al.tx, channel(r0 + 1), al.c * z - al.s * x + al.tz};
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double t = par[2 + i];
+                if (t == t) ds += (t - pj[i]) * (t - pj[i]);
+            }
+            return par[1] * sqrt(ds);
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             double t = par[2 + i];
@@ -76,8 +121,9 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
     const double qw = channel(r0 + 3), qx = channel(r0 + 4), qy = channel(r0 + 5), qz = channel(r0 + 6);
     const double nq = qw * qw + qx * qx + qy * qy + qz * qz, s2 = 2.0 / nq;
     const double rx = par[5], ry = par[6], rz = par[7];
-    const double px = (1.0 - s2 * (qy * qy + qz * qz)) * rx + s2 * (qx * qy - qz * qw) * ry + s2 * (qx * qz + qy * qw) * rz;
-    const double pz = s2 * (qx * qz - qy * qw) * rx + s2 * (qy * qz + qx * qw) * ry + (1.0 - s2 * (qx * qx + qy * qy)) * rz;
+    const double lx = (1.0 - s2 * (qy * qy + qz * qz)) * rx + s2 * (qx * qy - qz * qw) * ry + s2 * (qx * qz + qy * qw) * rz;
+    const double lz = s2 * (qx * qz - qy * qw) * rx + s2 * (qy * qz + qx * qw) * ry + (1.0 - s2 * (qx * qx + qy * qy)) * rz;
+    const double px = a.align ? al.c * lx + al.s * lz : lx, pz = a.align ? al.c * lz - al.s * lx : lz;
     const double tn = sqrt(par[2] * par[2] + par[3] * par[3]);
     const double tx = par[2] / tn, tz = par[3] / tn;
     const double mn = sqrt(px * px + pz * pz);
@@ -209,7 +255,7 @@ static int mg_launch_score_mfma_kk(mg_primitive *p, const mg_constraint_set *cs,
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res) {
     mg_score_args a;
     a.res = res;
-    a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
+    a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.align = cs->d_align; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
     const bool lf0 = ldt == MG_F64, of0 = odt == MG_F64;
     if (cs->d_Wpack && !getenv("MG_SCORE_VALU")) {   // MG_SCORE_VALU: tests force the fallback kernel
         int rc = MG_ERR_UNSUPPORTED;

@@ -5,9 +5,11 @@ replaced by a brute-force pass over the tree's stored samples, and the local opt
 (reference optimization/least_squares.py:35-64) with the finite-difference Jacobian of the residual vector
 evaluated in one launch per iteration instead of L + 1 objective calls.
 
-Method names, the `algorithm_config` keys and the `data` tuples are the reference's.  Constraint construction,
-graph walking and alignment stay in the reference: this class needs `use_local_coordinates` (root-joint keyframe
-constraints need no skeleton then) and raises NotImplementedError for anything the fused scorer does not cover.
+Method names, the `algorithm_config` keys and the `data` tuples are the reference's.  Constraint construction and
+graph walking stay in the reference.  With `use_local_coordinates` the constraints are localised first
+(transform_constraints_to_local_cos) and no alignment is needed; without it the previous frames travel to the
+scorer, which aligns every candidate to them on the device (candidate_scoring.alignment_from_prev_frames).
+Anything the fused scorer does not cover raises NotImplementedError.
 """
 import numpy as np
 from scipy.optimize import leastsq
@@ -112,13 +114,15 @@ class HipMotionPrimitiveGenerator(object):
     # ---- motion_primitive_generator.py:126-162 --------------------------------------------------------
     def generate_constrained_sample(self, graph_node, in_mp_constraints, prev_mp_name="", prev_frames=None,
                                     prev_parameters=None):
-        if not self.use_local_coordinates:
-            raise NotImplementedError("global coordinates need anim_utils' alignment; set use_local_coordinates")
-        prev_frames_copy = None
-        if hasattr(in_mp_constraints, "transform_constraints_to_local_cos"):
-            mp_constraints = in_mp_constraints.transform_constraints_to_local_cos()
+        if self.use_local_coordinates:
+            prev_frames_copy = None
+            if hasattr(in_mp_constraints, "transform_constraints_to_local_cos"):
+                mp_constraints = in_mp_constraints.transform_constraints_to_local_cos()
+            else:
+                mp_constraints = in_mp_constraints
         else:
             mp_constraints = in_mp_constraints
+            prev_frames_copy = prev_frames
         if self.constrained_sampling_mode == SAMPLING_MODE_RANDOM_SPLINE:
             raise NotImplementedError("random_spline scores through the proprietary mgrd package")
         elif self.constrained_sampling_mode == SAMPLING_MODE_CLUSTER_TREE_SEARCH and getattr(graph_node, "cluster_tree", None) is not None:
@@ -159,7 +163,7 @@ class HipMotionPrimitiveGenerator(object):
         elif self.gpu_sampling and self.constrained_sampling_mode == SAMPLING_MODE_GPU_BATCH:
             self.gpu_sampling_seed += 1
             best_sample, _ = sample_and_evaluate_on_device(graph_node, mp_constraints, self.n_random_samples,
-                                                           self.gpu_sampling_seed)
+                                                           self.gpu_sampling_seed, prev_frames=prev_frames)
             return best_sample
         else:
             samples = graph_node.sample_low_dimensional_vectors(self.n_random_samples)

@@ -244,13 +244,17 @@ class HipPrimitiveSet(object):
             p._initialize_from_json(data)
             self.nodes[p.name] = p
 
-    def evaluate_options_on_device(self, options, constraints_per_option, n_samples, seed=0, dtype=np.float32):
+    def evaluate_options_on_device(self, options, constraints_per_option, n_samples, seed=0, dtype=np.float32,
+                                   prev_frames=None, skeleton=None):
         """GraphWalkPlanner's option evaluation (reference graph_walk_planner.py:184-226) without host round trips:
         for every option the component counts come from NumPy's stream, the candidates from the device sampler,
         scoring, first-minimum argmin and the copy of the winner stay on the device (mg_option_step, one call per
         option, no synchronisation); only after all options are enqueued are the (16 + 8 L)-byte results read back.
+        With `prev_frames` every candidate is aligned to the last previous frame before scoring, which is how the
+        planner scores (its constraints stay global, graph_walk_planner.py:179; `skeleton`: a _capi.Skeleton when
+        the aligning node is not the root or joints other than the root are constrained).
         Returns (best_option, {name: (best_sample, min_error)})."""
-        from .candidate_scoring import cached_constraint_set
+        from .candidate_scoring import cached_constraint_set, alignment_from_prev_frames
         n = int(n_samples)
         item = np.dtype(dtype).itemsize
         code = _capi.MG_F64 if np.dtype(dtype) == np.float64 else _capi.MG_F32
@@ -264,7 +268,10 @@ class HipPrimitiveSet(object):
             if bufs is None:   # persistent per-option device buffers: no allocation inside a step
                 bufs = self._buffers[key] = (ctx.malloc(max(n, 1) * L * item), ctx.malloc(max(n, 1) * 8), ctx.malloc(16 + 8 * L))
             d_x, d_e, d_r = bufs
-            cset = cached_constraint_set(prim, constraints_to_device_form(constraints_per_option[name]))
+            cons = constraints_per_option[name]
+            clist = cons.constraints if hasattr(cons, "constraints") else cons
+            sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
+            cset = cached_constraint_set(prim, constraints_to_device_form(clist), sk, alignment_from_prev_frames(prev_frames, cons, sk))
             weights = node.gaussian_mixture_model.weights_
             counts = np.random.multinomial(n, weights / weights.sum()).astype(np.int64)
             _capi._check(prim.lib.mg_option_step(prim.handle, cset.handle, n, counts.ctypes.data, int(seed) + k, d_x.ptr, code, L,

@@ -1,6 +1,6 @@
 """Batched objective functions for the numerical optimizers: the GPU forms of
 reference morphablegraphs/motion_generator/optimization/objective_functions.py for root-joint keyframe
-constraints in local-coordinate mode (no alignment, so no anim_utils).
+constraints, in local coordinates or aligned to the previous motion on the device.
 
 Every function keeps the reference's name, `data` tuple layout and return scaling, but takes a whole batch of
 latent vectors (n, L) instead of one `s` and returns one row / value per sample, so that a finite-difference
@@ -9,13 +9,14 @@ reference least_squares.py:35-64) or a population of starting points is ONE laun
 gives the reference's shapes back.
 
 `data[0]` is the motion primitive (anything exposing the HIP primitive as `._prim` or `.motion_primitive._prim`),
-`data[1]` the constraint list (or an object with `.constraints`), `data[2]` must be None (prev_frames would need
-the aligning transform from anim_utils).  There is no CPU fallback.
+`data[1]` the constraint list (or an object with `.constraints`), `data[2]` the previous frames or None: with
+previous frames and constraints that are not `is_local` every sample is aligned to the previous motion on the device
+(candidate_scoring.alignment_from_prev_frames).  There is no CPU fallback.
 """
 import numpy as np
 
 from . import _capi
-from .candidate_scoring import constraints_to_device_form, cached_constraint_set
+from .candidate_scoring import constraints_to_device_form, cached_constraint_set, alignment_from_prev_frames
 
 
 def _prim_of(motion_primitive):
@@ -44,25 +45,20 @@ def _note(mp_constraints, min_error, n):
         mp_constraints.evaluations += n
 
 
-def _residuals(prim, mp_constraints, S):
+def _residuals(prim, mp_constraints, S, prev_frames=None):
     clist = constraints_to_device_form(_constraint_list(mp_constraints))
     if len(clist) == 0:
         return np.zeros((len(S), 0))
-    cset = cached_constraint_set(prim, clist, getattr(mp_constraints, "hip_skeleton", None))
+    skeleton = getattr(mp_constraints, "hip_skeleton", None)
+    cset = cached_constraint_set(prim, clist, skeleton, alignment_from_prev_frames(prev_frames, mp_constraints, skeleton))
     return prim.score_constraint_residuals(cset, S)
-
-
-def _check_prev(prev_frames):
-    if prev_frames is not None:
-        raise NotImplementedError("global-coordinate objectives need anim_utils' alignment; use local coordinates")
 
 
 def obj_spatial_error_sum(s, data):
     """objective_functions.py:141-159: MotionPrimitiveConstraints.evaluate per sample -> (n,) (float for 1-D s)."""
     motion_primitive, mp_constraints, prev_frames = data[:3]
-    _check_prev(prev_frames)
     S, single = _batch(s)
-    err = _residuals(_prim_of(motion_primitive), mp_constraints, S).sum(axis=1)
+    err = _residuals(_prim_of(motion_primitive), mp_constraints, S, prev_frames).sum(axis=1)
     _note(mp_constraints, float(err[-1]) if len(err) else 0.0, len(S))
     return float(err[0]) if single else err
 
@@ -79,10 +75,9 @@ def obj_spatial_error_sum_and_naturalness(s, data):
     (The reference function computes this value and then falls off its end without `return`, so scipy receives
     None there; the batched form returns the value it computes.)"""
     motion_primitive, mp_constraints, prev_frames, error_scale, quality_scale = data[0], data[1], data[2], data[-3], data[-2]
-    _check_prev(prev_frames)
     S, single = _batch(s)
     prim = _prim_of(motion_primitive)
-    spatial = _residuals(prim, mp_constraints, S).sum(axis=1)
+    spatial = _residuals(prim, mp_constraints, S, prev_frames).sum(axis=1)
     _note(mp_constraints, float(spatial[-1]) if len(spatial) else 0.0, len(S))
     err = error_scale * spatial + (-prim.gmm_log_prob(S.astype(np.float64))) * quality_scale
     return float(err[0]) if single else err
@@ -93,13 +88,12 @@ def spatial_error_jac(s, data, epsilon=1e-7):
     scipy approx_fprime's forward differences of obj_spatial_error_sum, (f(s + eps e_i) - f(s)) / eps, with all
     n * (L + 1) evaluations in one launch -> (n, L)."""
     motion_primitive, mp_constraints, prev_frames = data[:3]
-    _check_prev(prev_frames)
     S, single = _batch(s)
     S = np.asarray(S, dtype=np.float64)
     n, L = S.shape
     pert = np.repeat(S[:, None, :], L + 1, axis=1)           # (n, L+1, L): row 0 unperturbed
     pert[:, np.arange(1, L + 1), np.arange(L)] += epsilon
-    f = _residuals(_prim_of(motion_primitive), mp_constraints, pert.reshape(n * (L + 1), L)).sum(axis=1).reshape(n, L + 1)
+    f = _residuals(_prim_of(motion_primitive), mp_constraints, pert.reshape(n * (L + 1), L), prev_frames).sum(axis=1).reshape(n, L + 1)
     if hasattr(mp_constraints, "evaluations"):
         mp_constraints.evaluations += n * (L + 1)
     jac = (f[:, 1:] - f[:, :1]) / epsilon
@@ -126,9 +120,8 @@ def obj_spatial_error_residual_vector(s, data):
     """objective_functions.py:209-236: weighted residual of every constraint, zero-padded to n_variables columns,
     divided by init_error_sum -> (n, max(n_constraints, L))."""
     motion_primitive, mp_constraints, prev_frames, error_scale, quality_scale, init_error_sum = data
-    _check_prev(prev_frames)
     S, single = _batch(s)
-    res = _residuals(_prim_of(motion_primitive), mp_constraints, S)
+    res = _residuals(_prim_of(motion_primitive), mp_constraints, S, prev_frames)
     _note(mp_constraints, float(res[-1].sum()) if len(res) else 0.0, len(S))
     out = _pad(res, S.shape[1]) / init_error_sum
     return out[0] if single else out
@@ -138,11 +131,10 @@ def obj_spatial_error_residual_vector_and_naturalness(s, data):
     """objective_functions.py:239-267: (residual_i * error_scale - log p(s) * quality_scale), zero-padded to
     n_variables columns, divided by init_error_sum."""
     mp, mp_constraints, prev_frames, error_scale, quality_scale, init_error_sum = data
-    _check_prev(prev_frames)
     S, single = _batch(s)
     prim = _prim_of(mp)
     nll = -prim.gmm_log_prob(S.astype(np.float64)) * quality_scale
-    res = _residuals(prim, mp_constraints, S)
+    res = _residuals(prim, mp_constraints, S, prev_frames)
     _note(mp_constraints, float(res[-1].sum()) if len(res) else 0.0, len(S))
     out = _pad(res * error_scale + nll[:, None], S.shape[1]) / init_error_sum
     return out[0] if single else out

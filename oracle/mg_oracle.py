@@ -263,6 +263,61 @@ def joint_global_position(frame, joints, animated_joints, joint):
     return p
 
 
+def joint_global_orientation(frame, joints, animated_joints, joint):
+    """3x3 global orientation of `joint` (its own rotation included) by chaining rotation matrices root -> joint."""
+    by_name = {j[0]: j for j in joints}
+    chan = {n: 3 + 4 * i for i, n in enumerate(animated_joints)}
+    chain, n = [], joint
+    while n is not None:
+        chain.insert(0, n)
+        n = by_name[n][1]
+    R = np.eye(3)
+    for name in chain:
+        if name in chan:
+            R = R @ quaternion_matrix3(frame[chan[name]:chan[name] + 4])
+    return R
+
+
+def node_heading(frame, joints, animated_joints, joint, ref_dir=(0.0, 0.0, 1.0)):
+    """What anim_utils' get_global_node_orientation_vector is documented to return: unit (x, z) of the node's global
+    rotation applied to ref_dir (SELF-DEFINED, anim_utils absent)."""
+    p = joint_global_orientation(frame, joints, animated_joints, joint) @ np.asarray(ref_dir, dtype=np.float64)
+    d = np.array([p[0], p[2]])
+    return d / np.linalg.norm(d)
+
+
+def quaternion_multiply(a, b):
+    """Hamilton product of (w, x, y, z) quaternions (transformations.quaternion_multiply)."""
+    w0, x0, y0, z0 = a
+    w1, x1, y1, z1 = b
+    return np.array([w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1, w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1,
+                     w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1, w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1])
+
+
+def align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, joint, ref_dir=(0.0, 0.0, 1.0)):
+    """SELF-DEFINED restatement of what motion_primitive_constraints.py:110-114 asks of anim_utils'
+    align_quaternion_frames_automatically (absent here; PARITY UNPINNED), written the way that library works -- on
+    the control points, with a 4x4 matrix and a quaternion: angle between the aligning node's heading in the last
+    previous frame and in the FIRST control point, rotation about y by it, translation in x and z that puts the
+    first root position on the previous one; every control point's root position goes through the matrix and its
+    root quaternion is multiplied by the rotation from the left.  Returns a new (n_basis, D) array."""
+    coeffs = np.array(coeffs, dtype=np.float64)
+    ha = node_heading(prev_frame, joints, animated_joints, joint, ref_dir)
+    hb = node_heading(coeffs[0], joints, animated_joints, joint, ref_dir)
+    # a rotation about +y by phi turns the xz heading angle atan2(z, x) by -phi
+    phi = math.atan2(hb[1], hb[0]) - math.atan2(ha[1], ha[0])
+    q = np.array([math.cos(phi / 2.0), 0.0, math.sin(phi / 2.0), 0.0])
+    m = np.eye(4)
+    m[:3, :3] = quaternion_matrix3(q)
+    rotated_first = m @ np.array([coeffs[0][0], coeffs[0][1], coeffs[0][2], 1.0])
+    m[0, 3] = prev_frame[0] - rotated_first[0]
+    m[2, 3] = prev_frame[2] - rotated_first[2]
+    for cp in coeffs:
+        cp[:3] = (m @ np.array([cp[0], cp[1], cp[2], 1.0]))[:3]
+        cp[3:7] = quaternion_multiply(q, cp[3:7])
+    return coeffs
+
+
 # --------------------------------------------------------------------------
 # the primitive
 # --------------------------------------------------------------------------
@@ -348,6 +403,25 @@ class OraclePrimitive(object):
             for ci, c in enumerate(constraints):
                 frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
                 out[b, ci] = c["weight"] * point_distance(c["target"], joint_global_position(frame, joints, animated_joints, c["joint"]))
+        return out
+
+    def aligned_residuals(self, S, constraints, prev_frame, joints, animated_joints, align_joint, ref_dir=(0.0, 0.0, 1.0)):
+        """MotionPrimitiveConstraints.get_residual_vector outside local mode (motion_primitive_constraints.py:124-144):
+        back-project, align the control points to the previous motion, evaluate every constraint on the aligned
+        spline.  Constraint dicts as in keyframe_residuals, plus "joint_position"."""
+        S = np.atleast_2d(S)
+        out = np.zeros((S.shape[0], len(constraints)))
+        for b in range(S.shape[0]):
+            coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
+            coeffs = align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, align_joint, ref_dir)
+            for ci, c in enumerate(constraints):
+                frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
+                if c["type"] == "position":
+                    out[b, ci] = c["weight"] * point_distance(c["target"], frame[:3])
+                elif c["type"] == "joint_position":
+                    out[b, ci] = c["weight"] * point_distance(c["target"], joint_global_position(frame, joints, animated_joints, c["joint"]))
+                else:
+                    out[b, ci] = c["weight"] * direction_2d_error(c["target"], frame[3:7], c.get("ref_dir", (0, 0, 1)))
         return out
 
     def log_likelihood_jac(self, S):

@@ -264,7 +264,7 @@ def test_batched_objective_functions_match_the_reference_formulas():
             assert abs(kin[b, i] - fd) <= 1e-4 * max(1.0, abs(fd)), (b, i, kin[b, i], fd)
     full = of.obj_spatial_error_sum_and_naturalness_jac(S[:4], data6, eps)
     np.testing.assert_allclose(full, jac[:4] * data6[-2] + kin * data6[-1], rtol=1e-12, atol=1e-12)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):     # previous frames with a zero root quaternion have no heading to align to
         of.obj_spatial_error_sum(S, (mp, c, np.zeros((2, 79))))
     mp.close() if hasattr(mp, "close") else None
 
@@ -508,3 +508,88 @@ def test_graph_walk_step_on_device_with_one_stream_per_option():
         # a second step reuses the per-option buffers
         best2, results2 = pset.evaluate_options_on_device(names, cons, n_samples=2048, seed=200)
         assert set(results2) == set(names)
+
+
+def test_scoring_in_global_coordinates_through_the_adaptors():
+    """prev_frames given and constraints not `is_local`: evaluate_samples_using_constraints, the objective
+    functions, the generator without use_local_coordinates and the planner's option step all align every candidate
+    to the last previous frame first (reference motion_primitive_constraints.py:110-114; the planner never
+    localises, graph_walk_planner.py:179).  Checked against the oracle that transforms the control points, and
+    against the reference's other route to the same number: localising the constraint with the inverse aligning
+    transform (transform_constraints_to_local_cos, motion_primitive_constraints.py:268-291) and scoring locally."""
+    from oracle import mg_oracle as orc
+    from morphablegraphs_amd import objective_functions as of
+    from morphablegraphs_amd.motion_primitive_generator import HipMotionPrimitiveGenerator
+    joints, animated = synthetic.make_skeleton()
+    hip_sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "leftStance", "mm": data})
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(21)
+    prev_frames = op.back_project_frames(rng.standard_normal(40)).copy()
+    prev_frames[:, 0] += 300.0
+    prev_frames[:, 2] -= 150.0
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [340.0, None, -120.0]},
+            {"type": "direction", "t": 155.0, "weight": 0.2, "target": [1.0, 0.3]},
+            {"type": "joint_position", "joint": "RightHand", "t": 77.5, "weight": 0.5, "target": [320.0, 100.0, -140.0]}]
+
+    class RefSkeleton(object):
+        aligning_root_node, aligning_root_dir, root = "Hips", (0.0, 0.0, 1.0), "Hips"
+
+    class Constraints(object):
+        def __init__(self, clist, is_local=False):
+            self.constraints, self.min_error, self.evaluations = list(clist), None, 0
+            self.motion_primitive_name, self.use_local_optimization = "leftStance", False
+            self.is_local, self.skeleton, self.hip_skeleton, self.start_pose = is_local, RefSkeleton(), hip_sk, None
+
+    S = rng.standard_normal((300, 40))
+    ref = op.aligned_residuals(S, cons, prev_frames[-1], joints, animated, "Hips")
+    c = Constraints(cons)
+    best, err = evaluate_samples_using_constraints(S, node, c, prev_frames)
+    idx = int(np.argmin(ref.sum(axis=1)))
+    np.testing.assert_array_equal(best, S[idx])
+    assert abs(err - ref.sum(axis=1)[idx]) < 1e-7 and c.evaluations == 300 and c.min_error == err
+    np.testing.assert_allclose(of.obj_spatial_error_sum(S[:40], (node, c, prev_frames)), ref[:40].sum(axis=1), rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(of.obj_spatial_error_residual_vector(S[3], (node, c, prev_frames, 1.0, 1.0, 2.0))[:3], ref[3] / 2.0, rtol=1e-9, atol=1e-8)
+    # is_local constraints are never aligned, previous frames or not
+    loc = Constraints(cons, is_local=True)
+    np.testing.assert_allclose(of.obj_spatial_error_sum(S[:10], (node, loc, prev_frames)),
+                               of.obj_spatial_error_sum(S[:10], (node, loc, None)), rtol=0, atol=0)
+    # the other route: one candidate, its own aligning transform, the position target taken into its local frame
+    for b in (0, 7):
+        coeffs = op.back_project_spatial_coeffs(S[b])
+        aligned = orc.align_coeffs_to_previous_frame(coeffs, prev_frames[-1], joints, animated, "Hips")
+        # recover the 4x4 transform from two control points (rotation about y + xz translation)
+        d0, d1 = coeffs[8][[0, 2]] - coeffs[0][[0, 2]], aligned[8][[0, 2]] - aligned[0][[0, 2]]
+        phi = np.arctan2(d0[1], d0[0]) - np.arctan2(d1[1], d1[0])
+        m = np.eye(4)
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = np.cos(phi), np.sin(phi), -np.sin(phi), np.cos(phi)
+        m[[0, 2], 3] = aligned[0][[0, 2]] - (m[:3, :3] @ coeffs[0][:3])[[0, 2]]
+        tgt = np.linalg.inv(m) @ np.array([340.0, 0.0, -120.0, 1.0])
+        local = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [tgt[0], None, tgt[2]]}]
+        np.testing.assert_allclose(of.obj_spatial_error_sum(S[b], (node, local, None)), ref[b, 0], rtol=1e-8, atol=1e-7)
+    # the generator in global coordinates
+    cfg = {"n_random_samples": 256, "constrained_sampling_mode": "random_discrete", "use_local_coordinates": False,
+           "local_optimization_settings": {"start_error_threshold": 0.0, "error_scale_factor": 1.0, "quality_scale_factor": 0.1,
+                                           "method": "leastsq", "max_iterations": 50}}
+    gen = HipMotionPrimitiveGenerator({("walk", "leftStance"): node}, cfg, "walk")
+    c2 = Constraints(cons)
+    np.random.seed(9)
+    s = gen.generate_constrained_sample(node, c2, prev_frames=prev_frames)
+    np.random.seed(9)
+    X = node.sample_low_dimensional_vectors(256)
+    r2 = op.aligned_residuals(X, cons, prev_frames[-1], joints, animated, "Hips").sum(axis=1)
+    np.testing.assert_array_equal(s, X[int(np.argmin(r2))])
+    assert abs(c2.min_error - r2.min()) < 1e-7
+    # the planner's option step, aligned
+    pset = HipPrimitiveSet([data])
+    np.random.seed(4)
+    best_name, results = pset.evaluate_options_on_device([data["name"]], {data["name"]: Constraints(cons)}, 1024, seed=50,
+                                                         prev_frames=prev_frames)
+    np.random.seed(4)
+    w = np.asarray(data["gmm_weights"], dtype=np.float64)
+    Xd, _ = pset.nodes[data["name"]]._prim.gmm_sample(np.random.multinomial(1024, w / w.sum()), 50, dtype=np.float32)
+    r3 = op.aligned_residuals(Xd.astype(np.float64), cons, prev_frames[-1], joints, animated, "Hips").sum(axis=1)
+    np.testing.assert_array_equal(results[best_name][0].astype(np.float32), Xd[int(np.argmin(r3))])
+    assert abs(results[best_name][1] - r3.min()) < 1e-7

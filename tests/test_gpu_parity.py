@@ -594,3 +594,59 @@ def test_fused_step_with_reserved_cus_and_up_to_four_tiles_per_workgroup(ctx):
     finally:
         ctx.set_reserved_cus(0)
     prim.close()
+
+
+def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous_motion(ctx, monkeypatch):
+    """MotionPrimitiveConstraints.evaluate outside local mode (reference motion_primitive_constraints.py:110-114 ->
+    anim_utils align_quaternion_frames_automatically; PARITY UNPINNED, anim_utils absent): per candidate a rotation
+    about y and an xz translation attach its first control point to the previous motion's last frame, then the
+    constraints are evaluated.  The device never transforms control points (closed form on the evaluated
+    quantities); the oracle does, with a 4x4 matrix and a quaternion product like the library.  Also: known
+    answers (the aligned start sits on the previous root, the aligned start heading is the previous heading), the
+    MFMA and the VALU kernel agree, and alignment through a chain (aligning node != root)."""
+    from oracle import mg_oracle as orc
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(12)
+    S = rng.standard_normal((70, 40))
+    prev = op.back_project_frames(rng.standard_normal(40))[-1].copy()        # some last frame of a previous step
+    prev[:3] = [120.0, 90.0, -340.0]
+    prev[3:7] = [0.3, 0.1, 0.9, -0.2]                                        # not unit: normalised like quaternion_matrix
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [150.0, None, -300.0]},
+            {"type": "position", "t": 77.5, "weight": 0.5, "target": [130.0, 88.0, -320.0]},
+            {"type": "direction", "t": 155.0, "weight": 0.3, "target": [0.2, 1.0]},
+            {"type": "joint_position", "joint": "LeftHand_EndSite", "t": 100.0, "weight": 2.0, "target": [160.0, 120.0, -310.0]},
+            {"type": "joint_position", "joint": "Hips", "t": 0.0, "weight": 1.0, "target": [0.0, None, 0.0]}]
+    for node in ("Hips", "Spine1"):
+        al = sk.alignment_to(prev, node)
+        np.testing.assert_allclose(al["heading"], orc.node_heading(prev, joints, animated, node), rtol=1e-13, atol=1e-14)
+        cset = _capi.ConstraintSet(prim, cons, sk, alignment=al)
+        res = prim.score_constraint_residuals(cset, S)
+        ref = op.aligned_residuals(S, cons, prev, joints, animated, node)
+        np.testing.assert_allclose(res, ref, rtol=1e-9, atol=1e-8, err_msg=node)
+        np.testing.assert_allclose(prim.score_constraints(cset, S), res.sum(axis=1), rtol=1e-13, atol=1e-12)
+        # the aligned start: root xz of the first control point lands on the previous root -> |(prev_x, ., prev_z)|
+        np.testing.assert_allclose(res[:, 4], np.hypot(prev[0], prev[2]), rtol=1e-12)
+        monkeypatch.setenv("MG_SCORE_VALU", "1")
+        np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
+        monkeypatch.delenv("MG_SCORE_VALU")
+        best, err = prim.best_candidate(cset, S)
+        assert best == int(np.argmin(ref.sum(axis=1))) and abs(err - ref.sum(axis=1).min()) < 1e-7
+        cset.close()
+    # root alignment needs no skeleton; a heading constraint at t = 0 then reads the angle between the previous heading
+    # and its own target for every candidate alike
+    al = sk.alignment_to(prev, 0)
+    cset = _capi.ConstraintSet(prim, [{"type": "direction", "t": 0.0, "weight": 1.0, "target": [1.0, 0.0]}], None,
+                               alignment={"position": al["position"], "heading": al["heading"]})
+    h = np.asarray(al["heading"])
+    expect = abs(np.degrees(np.arccos(np.clip(h[0], -1.0, 1.0))))
+    np.testing.assert_allclose(prim.score_constraints(cset, S), expect, rtol=1e-9, atol=1e-9)
+    cset.close()
+    with pytest.raises(_capi.MGError):
+        _capi.ConstraintSet(prim, cons[:1], None, alignment={"joint": 3, "position": [0, 0, 0], "heading": [0, 1]})
+    with pytest.raises(_capi.MGError):
+        _capi.ConstraintSet(prim, cons[:1], None, alignment={"position": [0, 0, 0], "heading": [0, 0]})
+    prim.close()

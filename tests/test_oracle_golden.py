@@ -148,3 +148,39 @@ def test_forward_kinematics_oracle_known_answers():
                                orc.joint_global_position(frame, joints, animated, "LeftArm"), atol=1e-12)
     base = orc.joint_global_position(frame, joints, animated, "LeftArm")
     np.testing.assert_allclose(orc.joint_global_position(f3, joints, animated, "LeftHand_EndSite"), base + [0.0, 60.0, 0.0], atol=1e-12)
+
+
+def test_alignment_oracle_known_answers():
+    """The self-defined 2-D alignment oracle (anim_utils is absent): after aligning, the first control point's root
+    sits on the previous root in x and z (y untouched), the aligning node's heading in the first control point is
+    the previous heading, control points move rigidly, a motion that already continues the previous one is left
+    alone, and a quarter-turn case comes out as computed by hand."""
+    from morphablegraphs_amd import synthetic
+    joints, animated = synthetic.make_skeleton()
+    prim = orc.OraclePrimitive(synthetic.make_walk_primitive(seed=0))
+    rng = np.random.default_rng(3)
+    coeffs = prim.back_project_spatial_coeffs(rng.standard_normal(prim.n_components))
+    prev = prim.back_project_frames(rng.standard_normal(prim.n_components))[-1].copy()
+    prev[:3] = [40.0, 95.0, -12.0]
+    for node in ("Hips", "Spine1"):
+        out = orc.align_coeffs_to_previous_frame(coeffs, prev, joints, animated, node)
+        assert out is not coeffs and out.shape == coeffs.shape
+        np.testing.assert_allclose(out[0][[0, 2]], prev[[0, 2]], atol=1e-10)
+        np.testing.assert_allclose(out[:, 1], coeffs[:, 1], atol=0)
+        np.testing.assert_allclose(orc.node_heading(out[0], joints, animated, node), orc.node_heading(prev, joints, animated, node), atol=1e-12)
+        np.testing.assert_allclose(np.linalg.norm(out[5][:3] - out[20][:3]), np.linalg.norm(coeffs[5][:3] - coeffs[20][:3]), rtol=1e-12)
+        np.testing.assert_allclose(out[:, 7:], coeffs[:, 7:], atol=0)                     # only the root channels change
+        again = orc.align_coeffs_to_previous_frame(out, out[0], joints, animated, node)  # already attached: identity
+        np.testing.assert_allclose(again, out, atol=1e-9)
+    # by hand: previous motion ends at (10, 0, 20) heading +x; the candidate starts at (1, 5, 2) heading +z and walks
+    # 3 along +z -> aligned it starts at (10, 5, 20) and walks 3 along +x
+    ident = np.zeros(3 + 4 * len(animated))
+    ident[3::4] = 1.0
+    prev2 = ident.copy()
+    prev2[:3] = [10.0, 0.0, 20.0]
+    prev2[3:7] = [np.sqrt(0.5), 0.0, np.sqrt(0.5), 0.0]        # +90 deg about y: ref (0,0,1) -> (1,0,0)
+    walk = np.tile(ident, (4, 1))
+    walk[:, :3] = [[1.0, 5.0, 2.0], [1.0, 5.0, 3.0], [1.0, 5.0, 4.0], [1.0, 5.0, 5.0]]
+    out = orc.align_coeffs_to_previous_frame(walk, prev2, joints, animated, "Hips")
+    np.testing.assert_allclose(out[:, :3], [[10.0, 5.0, 20.0], [11.0, 5.0, 20.0], [12.0, 5.0, 20.0], [13.0, 5.0, 20.0]], atol=1e-12)
+    np.testing.assert_allclose(out[:, 3:7], np.tile(prev2[3:7], (4, 1)), atol=1e-12)
