@@ -89,16 +89,27 @@ typedef struct mg_primitive_desc {
  *      p = t_root + sum_i R(q_j0 q_j1 .. q_j(i-1)) offset(j_i), quaternions (w,x,y,z) normalised like
  *      transformations.quaternion_matrix does; needs a set made by mg_constraint_set_create_fk.
  *      PARITY UNPINNED: the reference's FK lives in anim_utils (absent); pinned by an independent
- *      rotation-matrix oracle and known-answer poses (tests). */
-enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1, MG_CONSTRAINT_JOINT_POSITION = 2 };
+ *      rotation-matrix oracle and known-answer poses (tests);
+ *  MG_CONSTRAINT_JOINT_MIDPOINT -> the first residual of TwoHandConstraint.get_residual_vector_frame
+ *      (reference two_hand_constraint.py:66-74): |target - (p(joint) + p(joint2)) / 2|, both by the same FK (the
+ *      other two residuals of that constraint are plain MG_CONSTRAINT_JOINT_POSITIONs);
+ *  MG_CONSTRAINT_JOINT_ORIENTATION -> GlobalTransformConstraint._quaternion_distance
+ *      (reference global_transform_constraint.py:109-121): the angle in RADIANS between the joint's global
+ *      orientation (its own quaternion included) applied to ref_dir and `target` = the wanted orientation applied to
+ *      ref_dir (the caller rotates; ref_dir = (0,0,1) is the reference's ORIGIN); arccos of the normalised dot
+ *      product (transformations.angle_between_vectors), clamped to [-1, 1]. */
+enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1, MG_CONSTRAINT_JOINT_POSITION = 2,
+       MG_CONSTRAINT_JOINT_MIDPOINT = 3, MG_CONSTRAINT_JOINT_ORIENTATION = 4 };
 #define MG_MAX_CHAIN 32
 typedef struct mg_keyframe_constraint {
     int32_t type;
-    int32_t joint;              /* MG_CONSTRAINT_JOINT_POSITION: index into the skeleton's joints; else unused */
+    int32_t joint;              /* MG_CONSTRAINT_JOINT_*: index into the skeleton's joints; else unused */
     double canonical_keyframe;  /* t; may be fractional (graph_walk_planner.py:203) */
     double weight_factor;
     double target[3];           /* position xyz (NaN = free) or direction (x, z, unused) */
-    double ref_dir[3];          /* direction only: skeleton.aligning_root_dir, e.g. (0,0,1) */
+    double ref_dir[3];          /* direction / orientation: the vector that is rotated, e.g. (0,0,1) */
+    int32_t joint2;             /* MG_CONSTRAINT_JOINT_MIDPOINT: the second joint; else unused */
+    int32_t reserved;
 } mg_keyframe_constraint;
 
 /* The part of a skeleton forward kinematics needs (anim_utils Skeleton: nodes with parent / offset, and the

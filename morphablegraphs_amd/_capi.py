@@ -18,6 +18,7 @@ MG_OK = 0
 MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
+MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION = 3, 4
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
                  "gmm_sample": 4, "spline_evaluate": 5, "step": 6}
 
@@ -57,7 +58,8 @@ class PrimitiveDesc(C.Structure):
 
 class KeyframeConstraint(C.Structure):
     _fields_ = [("type", C.c_int32), ("joint", C.c_int32), ("canonical_keyframe", C.c_double),
-                ("weight_factor", C.c_double), ("target", C.c_double * 3), ("ref_dir", C.c_double * 3)]
+                ("weight_factor", C.c_double), ("target", C.c_double * 3), ("ref_dir", C.c_double * 3),
+                ("joint2", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SkeletonDesc(C.Structure):   # struct mg_skeleton_desc
@@ -73,6 +75,15 @@ class AlignmentDesc(C.Structure):   # struct mg_alignment_desc
 def _quat_mul(a, b):
     return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
                      a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def rotate_by_quaternion(q, v):
+    """v rotated by the (w, x, y, z) quaternion q (normalised first)."""
+    q = np.asarray(q, dtype=np.float64)
+    q = q / np.linalg.norm(q)
+    v = np.asarray(v, dtype=np.float64)
+    u = q[1:]
+    return v + 2.0 * (q[0] * np.cross(u, v) + np.cross(u, np.cross(u, v)))
 
 
 class Skeleton(object):
@@ -374,9 +385,11 @@ class TimeGrid(object):
 
 
 class ConstraintSet(object):
-    """constraints: list of dicts {"type": "position"|"direction"|"joint_position", "t": float, "weight": float,
-    "target": [x|None, y|None, z|None] | [dx, dz], "ref_dir": (rx, ry, rz), "joint": name or index}; a
-    `skeleton` (Skeleton) is needed for "joint_position".  `alignment` = {"joint", "position", "heading",
+    """constraints: list of dicts {"type": "position"|"direction"|"joint_position"|"joint_midpoint"|
+    "joint_orientation", "t": float, "weight": float, "target": [x|None, y|None, z|None] | [dx, dz],
+    "ref_dir": (rx, ry, rz), "joint": name or index, "joint2": second joint of a midpoint, "orientation": wanted
+    global (w,x,y,z) of a joint_orientation (or "target": that orientation applied to ref_dir)}; a `skeleton`
+    (Skeleton) is needed for "joint_position", "joint_midpoint" and for orientations of joints other than the root.  `alignment` = {"joint", "position", "heading",
     "ref_dir"} (Skeleton.alignment_to) switches to global coordinates: every candidate is aligned to the previous
     motion before its constraints are evaluated; without a skeleton the aligning node is the root joint."""
 
@@ -403,6 +416,24 @@ class ConstraintSet(object):
                 for a in range(3):
                     v = c["target"][a]
                     k.target[a] = float("nan") if v is None else float(v)
+            elif c["type"] == "joint_midpoint":
+                if skeleton is None:
+                    raise ValueError("joint_midpoint constraints need a skeleton")
+                k.type = MG_CONSTRAINT_JOINT_MIDPOINT
+                k.joint, k.joint2 = skeleton.index(c["joint"]), skeleton.index(c["joint2"])
+                for a in range(3):
+                    v = c["target"][a]
+                    k.target[a] = float("nan") if v is None else float(v)
+            elif c["type"] == "joint_orientation":
+                k.type = MG_CONSTRAINT_JOINT_ORIENTATION
+                if skeleton is None and c.get("joint", 0) not in (0, None):
+                    raise ValueError("the orientation of joint %r needs a skeleton (only the root joint, 0, does not)" % (c["joint"],))
+                k.joint = 0 if skeleton is None else skeleton.index(c.get("joint", 0) or 0)
+                rd = c.get("ref_dir", (0.0, 0.0, 1.0))
+                tv = rotate_by_quaternion(c["orientation"], rd) if "orientation" in c else c["target"]
+                for a in range(3):
+                    k.ref_dir[a] = float(rd[a])
+                    k.target[a] = float(tv[a])
             elif c["type"] == "direction":
                 k.type = MG_CONSTRAINT_DIRECTION_2D
                 k.target[0], k.target[1], k.target[2] = float(c["target"][0]), float(c["target"][1]), 0.0

@@ -22,27 +22,68 @@ SAMPLING_MODE_GPU_BATCH = "gpu_batch"   # a 4th constrained_sampling_mode next t
 
 def constraints_to_device_form(constraints, root_joint=None):
     """Accepts either ready dicts {"type","t","weight","target"[,"ref_dir"]} or reference-shaped
-    constraint objects (attributes canonical_keyframe, weight_factor, and position / target_dir)."""
+    constraint objects: Direction2DConstraint (target_dir), GlobalTransformConstraint (position and / or
+    orientation of a joint), TwoHandConstraint (positions + joint_names).  One reference constraint may become
+    several device constraints; "group" numbers the reference constraint's residual entry they add up to (a
+    GlobalTransformConstraint is ONE residual = position error + orientation error, a TwoHandConstraint three,
+    two_hand_constraint.py:66-74), see `group_residuals`."""
     out = []
+    group = 0
     for c in constraints:
         if isinstance(c, dict):
             out.append(c)
+            group += 1
             continue
         t = float(c.canonical_keyframe)
         w = float(getattr(c, "weight_factor", 1.0))
         if hasattr(c, "target_dir"):
             rd = getattr(getattr(c, "skeleton", None), "aligning_root_dir", (0.0, 0.0, 1.0))
             out.append({"type": "direction", "t": t, "weight": w, "target": [float(c.target_dir[0]), float(c.target_dir[1])],
-                        "ref_dir": tuple(float(v) for v in rd)})
-        elif getattr(c, "position", None) is not None and getattr(c, "orientation", None) is None:
+                        "ref_dir": tuple(float(v) for v in rd), "group": group})
+            group += 1
+        elif hasattr(c, "positions") and hasattr(c, "joint_names"):          # TwoHandConstraint
+            p0, p1 = np.asarray(c.positions[0], dtype=np.float64), np.asarray(c.positions[1], dtype=np.float64)
+            center = p0 + 0.5 * (p1 - p0)
+            out.append({"type": "joint_midpoint", "t": t, "weight": w, "target": [float(v) for v in center],
+                        "joint": c.joint_names[0], "joint2": c.joint_names[1], "group": group})
+            out.append({"type": "joint_position", "t": t, "weight": w, "target": [float(v) for v in p0], "joint": c.joint_names[0],
+                        "group": group + 1})
+            out.append({"type": "joint_position", "t": t, "weight": w, "target": [float(v) for v in p1], "joint": c.joint_names[1],
+                        "group": group + 2})
+            group += 3
+        elif getattr(c, "position", None) is not None or getattr(c, "orientation", None) is not None:
             joint = getattr(c, "joint_name", root_joint)
-            if root_joint is not None and joint != root_joint:
-                # any other joint goes through the forward-kinematics constraint (needs a skeleton on the set)
-                out.append({"type": "joint_position", "t": t, "weight": w, "target": list(c.position), "joint": joint})
-            else:
-                out.append({"type": "position", "t": t, "weight": w, "target": list(c.position)})
+            root = root_joint if root_joint is not None else getattr(getattr(c, "skeleton", None), "root", None)
+            n_before = len(out)
+            if getattr(c, "position", None) is not None:
+                if root is not None and joint is not None and joint != root:
+                    # any other joint goes through the forward-kinematics constraint (needs a skeleton on the set)
+                    out.append({"type": "joint_position", "t": t, "weight": w, "target": list(c.position), "joint": joint, "group": group})
+                else:
+                    out.append({"type": "position", "t": t, "weight": w, "target": list(c.position), "group": group})
+            if getattr(c, "orientation", None) is not None:                  # (w, x, y, z), global_transform_constraint.py:53-58
+                out.append({"type": "joint_orientation", "t": t, "weight": w, "orientation": [float(v) for v in c.orientation],
+                            "joint": 0 if (joint is None or root is None or joint == root) else joint, "group": group})
+            group += 1 if len(out) > n_before else 0
         else:
             raise NotImplementedError("constraint %r is not covered by the fused GPU scorer" % (type(c).__name__,))
+    return out
+
+
+def group_residuals(clist, res):
+    """(n, len(clist)) device residuals -> one column per reference residual entry: columns of the same "group"
+    are summed (dicts without a group stand alone)."""
+    groups, next_free = [], 0
+    for c in clist:
+        g = c.get("group") if isinstance(c, dict) else None
+        groups.append(next_free if g is None else g)
+        next_free = max(next_free, groups[-1]) + 1
+    if len(set(groups)) == len(groups):
+        return res
+    order = sorted(set(groups))
+    out = np.zeros((res.shape[0], len(order)), dtype=res.dtype)
+    for col, g in enumerate(groups):
+        out[:, order.index(g)] += res[:, col]
     return out
 
 

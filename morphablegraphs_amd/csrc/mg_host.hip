@@ -873,7 +873,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
         }
     }
     // chains (root first) and row counts
-    std::vector<std::vector<int>> chains(n);
+    std::vector<std::vector<int>> chains(n), chains2(n);   // chains2: second joint of a midpoint constraint
     std::vector<int32_t> woff(n + 2, 0), chain_len(n, 0);
     std::vector<int> al_chain;   // root .. aligning node, every one of their quaternions turns the heading
     if (al) {
@@ -889,7 +889,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
     }
     for (int c = 0; c < n; c++) {
         const int type = cons[c].type;
-        MG_REQUIRE(type == MG_CONSTRAINT_POSITION || type == MG_CONSTRAINT_DIRECTION_2D || type == MG_CONSTRAINT_JOINT_POSITION,
+        MG_REQUIRE(type >= MG_CONSTRAINT_POSITION && type <= MG_CONSTRAINT_JOINT_ORIENTATION,
                    "mg_constraint_set_create: constraint %d has unknown type %d", c, type);
         MG_REQUIRE(std::isfinite(cons[c].canonical_keyframe), "mg_constraint_set_create: constraint %d keyframe not finite", c);
         MG_REQUIRE(type == MG_CONSTRAINT_POSITION ? D >= 3 : D >= 7,
@@ -903,6 +903,28 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
             MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain of %d joints exceeds %d", c, m, MG_MAX_CHAIN);
             chain_len[c] = m;
             rows = 3 + 4 * std::max(m, 1);
+        } else if (type == MG_CONSTRAINT_JOINT_MIDPOINT) {
+            MG_REQUIRE(sk != nullptr, "mg_constraint_set_create: constraint %d needs a skeleton (mg_constraint_set_create_fk)", c);
+            MG_REQUIRE(cons[c].joint >= 0 && cons[c].joint < sk->n_joints && cons[c].joint2 >= 0 && cons[c].joint2 < sk->n_joints,
+                       "mg_constraint_set_create_fk: constraint %d: joints %d, %d out of range", c, cons[c].joint, cons[c].joint2);
+            for (int j = cons[c].joint; j >= 0; j = sk->parents[j]) chains[c].insert(chains[c].begin(), j);
+            for (int j = cons[c].joint2; j >= 0; j = sk->parents[j]) chains2[c].insert(chains2[c].begin(), j);
+            const int m = (int)chains[c].size() - 1, m2 = (int)chains2[c].size() - 1;
+            MG_REQUIRE(m <= MG_MAX_CHAIN && m2 <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain exceeds %d joints", c, MG_MAX_CHAIN);
+            chain_len[c] = m | (m2 << 16);
+            rows = 3 + 4 * std::max(m, 1) + 4 * std::max(m2, 1);
+        } else if (type == MG_CONSTRAINT_JOINT_ORIENTATION) {
+            MG_REQUIRE(cons[c].joint == 0 || (sk && cons[c].joint > 0 && cons[c].joint < sk->n_joints),
+                       "mg_constraint_set_create_fk: constraint %d: joint %d needs a skeleton that has it", c, cons[c].joint);
+            if (cons[c].joint == 0) chains[c].push_back(0);
+            else for (int j = cons[c].joint; j >= 0; j = sk->parents[j]) chains[c].insert(chains[c].begin(), j);
+            const int m = (int)chains[c].size();       // every quaternion root .. joint turns the vector
+            MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain of %d joints exceeds %d", c, m, MG_MAX_CHAIN);
+            const double tn = std::sqrt(cons[c].target[0] * cons[c].target[0] + cons[c].target[1] * cons[c].target[1] + cons[c].target[2] * cons[c].target[2]);
+            const double rn = std::sqrt(cons[c].ref_dir[0] * cons[c].ref_dir[0] + cons[c].ref_dir[1] * cons[c].ref_dir[1] + cons[c].ref_dir[2] * cons[c].ref_dir[2]);
+            MG_REQUIRE(std::isfinite(tn) && tn > 0.0 && std::isfinite(rn) && rn > 0.0, "mg_constraint_set_create: constraint %d: zero target or reference vector", c);
+            chain_len[c] = m;
+            rows = 4 * m;
         }
         woff[c + 1] = woff[c] + rows;
     }
@@ -912,7 +934,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
     cs->prim = p; cs->n = n; cs->nch = nch;
     const size_t rows_total = (size_t)woff[n + 1];
     std::vector<double> W(std::max<size_t>(rows_total, 1) * L, 0.0), bias(std::max<size_t>(rows_total, 1), 0.0), par((size_t)std::max(n, 1) * 8, 0.0);
-    std::vector<double> choff((size_t)std::max(n, 1) * MG_MAX_CHAIN * 3, 0.0);
+    std::vector<double> choff((size_t)std::max(n, 1) * 2 * MG_MAX_CHAIN * 3, 0.0);
     for (int c = 0; c < n; c++) {
         int32_t i0; double w[4];
         mg_basis_row(p->knots.data(), (int)p->knots.size(), cons[c].canonical_keyframe, &i0, w);
@@ -927,18 +949,31 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
             }
         };
         const size_t r0 = (size_t)woff[c];
-        if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION) {
-            for (int d = 0; d < 3; d++) fill_row(r0 + d, d);
-            const int m = chain_len[c];
-            for (int i = 0; i < std::max(m, 1); i++) {   // quaternions of chain joints 0 .. m-1 (the end joint's own does not move it)
-                const int ch = sk->quat_channel[chains[c][i]];
+        auto fill_quats = [&](size_t row, const std::vector<int> &chain, int count) {   // (w,x,y,z) of chain[0 .. count-1]
+            for (int i = 0; i < count; i++) {
+                const int ch = sk ? sk->quat_channel[chain[i]] : 3;
                 for (int e = 0; e < 4; e++) {
-                    if (ch >= 0) fill_row(r0 + 3 + 4 * i + e, ch + e);
-                    else bias[r0 + 3 + 4 * i + e] = (e == 0) ? 1.0 : 0.0;   // not animated: identity, zero matrix row
+                    if (ch >= 0) fill_row(row + 4 * i + e, ch + e);
+                    else bias[row + 4 * i + e] = (e == 0) ? 1.0 : 0.0;   // not animated: identity, zero matrix row
                 }
             }
+        };
+        auto fill_offsets = [&](int which, const std::vector<int> &chain, int m) {
             for (int i = 0; i < m; i++)
-                for (int e = 0; e < 3; e++) choff[((size_t)c * MG_MAX_CHAIN + i) * 3 + e] = sk->offsets[(size_t)chains[c][i + 1] * 3 + e];
+                for (int e = 0; e < 3; e++) choff[(((size_t)c * 2 + which) * MG_MAX_CHAIN + i) * 3 + e] = sk->offsets[(size_t)chain[i + 1] * 3 + e];
+        };
+        if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION || cons[c].type == MG_CONSTRAINT_JOINT_MIDPOINT) {
+            for (int d = 0; d < 3; d++) fill_row(r0 + d, d);
+            const int m = chain_len[c] & 0xffff;
+            fill_quats(r0 + 3, chains[c], std::max(m, 1));   // joints 0 .. m-1 (the end joint's own rotation does not move it)
+            fill_offsets(0, chains[c], m);
+            if (cons[c].type == MG_CONSTRAINT_JOINT_MIDPOINT) {
+                const int m2 = chain_len[c] >> 16;
+                fill_quats(r0 + 3 + 4 * std::max(m, 1), chains2[c], std::max(m2, 1));
+                fill_offsets(1, chains2[c], m2);
+            }
+        } else if (cons[c].type == MG_CONSTRAINT_JOINT_ORIENTATION) {
+            fill_quats(r0, chains[c], chain_len[c]);
         } else {
             for (int d = 0; d < nch; d++) fill_row(r0 + d, d);
         }

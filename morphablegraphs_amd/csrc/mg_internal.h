@@ -138,8 +138,8 @@ struct mg_constraint_set {
     double *d_bias = nullptr;   // [rows]
     double *d_par = nullptr;    // [n][8]: type, weight, target[3], ref_dir[3]
     int32_t *d_woff = nullptr;  // [n + 1] first row of every constraint
-    int32_t *d_chain = nullptr; // [n] FK chain length m (0 for root constraints)
-    double *d_choff = nullptr;  // [n][MG_MAX_CHAIN][3] offsets along the chain
+    int32_t *d_chain = nullptr; // [n] FK chain length m (0 for root constraints); midpoint: m | m2 << 16
+    double *d_choff = nullptr;  // [n][2][MG_MAX_CHAIN][3] offsets along the chain (second chain: midpoint only)
     double *d_Wpack = nullptr;  // [RT][KK][64] MFMA B fragments of W (n_components <= 64), RT = ceil(rows / 16)
     double *d_bpad = nullptr;   // [RT*16] bias, zero padded
     int32_t RT = 0;

@@ -13,7 +13,7 @@ struct mg_score_args {
     const double *par;    // [n][8]        type, weight, target[3], ref_dir[3]
     const int32_t *woff;  // [n + 1]
     const int32_t *chain; // [n]           FK chain length
-    const double *choff;  // [n][MG_MAX_CHAIN][3]
+    const double *choff;  // [n][2][MG_MAX_CHAIN][3]
     const double *align;  // [8] or NULL: chain length, previous heading (x,z), previous root (x,z), ref_dir; rows at woff[n]
     const void *lat;
     void *out;            // (B) summed error, or NULL
@@ -25,6 +25,52 @@ struct mg_score_args {
 // The weighted residual of constraint c for one candidate; `channel(row)` yields the candidate's pose channel of
 // that row of the fused keyframe matrices (rows of constraint c start at woff[c]).  Shared by the VALU kernel (a dot
 // product per channel) and the MFMA kernel (channels already in LDS), so both produce the same value.
+// Product of the chain's m quaternions (rows r_q ..), each normalised like transformations.quaternion_matrix does.
+template <typename ChannelFn>
+__device__ __forceinline__ void mg_chain_orientation(ChannelFn channel, int r_q, int m, double (&q)[4]) {
+    double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;
+    for (int i = 0; i < m; i++) {
+        double qw = channel(r_q + 4 * i), qx = channel(r_q + 1 + 4 * i), qy = channel(r_q + 2 + 4 * i), qz = channel(r_q + 3 + 4 * i);
+        const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+        const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+        const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+        aw = nw; ax = nx; ay = ny; az = nz;
+    }
+    q[0] = aw; q[1] = ax; q[2] = ay; q[3] = az;
+}
+// v' = v + 2 w (u x v) + 2 u x (u x v) for a unit quaternion (w, u)
+__device__ __forceinline__ void mg_rotate(const double (&q)[4], double vx, double vy, double vz, double (&out)[3]) {
+    const double cx = q[2] * vz - q[3] * vy, cy = q[3] * vx - q[1] * vz, cz = q[1] * vy - q[2] * vx;
+    const double dx = q[2] * cz - q[3] * cy, dy = q[3] * cx - q[1] * cz, dz = q[1] * cy - q[2] * cx;
+    out[0] = vx + 2.0 * (q[0] * cx + dx);
+    out[1] = vy + 2.0 * (q[0] * cy + dy);
+    out[2] = vz + 2.0 * (q[0] * cz + dz);
+}
+// Forward kinematics: p = root translation (rows r_p ..) + sum_i R(q_0 .. q_i) offset_i over the chain's m links
+// (quaternion rows r_q .., offsets off[m][3]).
+template <typename ChannelFn>
+__device__ __forceinline__ void mg_fk_position(ChannelFn channel, int r_p, int r_q, int m, const double *off, double (&p)[3]) {
+    double p0 = channel(r_p), p1 = channel(r_p + 1), p2 = channel(r_p + 2);
+    double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;   // accumulated global rotation of the parent
+    for (int i = 0; i < m; i++) {
+        double qw = channel(r_q + 4 * i), qx = channel(r_q + 1 + 4 * i), qy = channel(r_q + 2 + 4 * i), qz = channel(r_q + 3 + 4 * i);
+        const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+        const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+        const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+        aw = nw; ax = nx; ay = ny; az = nz;
+        const double ox = off[3 * i], oy = off[3 * i + 1], oz = off[3 * i + 2];
+        // v' = v + 2 w (u x v) + 2 u x (u x v), u = (ax, ay, az)
+        const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
+        const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
+        p0 += ox + 2.0 * (aw * cx + dx);
+        p1 += oy + 2.0 * (aw * cy + dy);
+        p2 += oz + 2.0 * (aw * cz + dz);
+    }
+    p[0] = p0; p[1] = p1; p[2] = p2;
+}
+
 // The candidate's 2-D aligning transform (mg_alignment_desc): rotation about y by the angle between its own heading
 // in the first control point and the previous motion's, as (cos, sin) = (h . b, h x b), and the xz translation that
 // puts its first root position on the previous one.
@@ -64,28 +110,22 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
     const int r0 = a.woff[c];
     mg_align2d al = {1.0, 0.0, 0.0, 0.0};
     if (a.align) al = mg_candidate_alignment(a, channel);
-    if (type == MG_CONSTRAINT_JOINT_POSITION) {
+    if (type == MG_CONSTRAINT_JOINT_POSITION || type == MG_CONSTRAINT_JOINT_MIDPOINT) {
         // forward kinematics along the chain: p = t_root + sum_i R(q_0 .. q_(i-1)) offset_i, unit quaternions (w,x,y,z)
-        double p0 = channel(r0), p1 = channel(r0 + 1), p2 = channel(r0 + 2);
-        const int m = a.chain[c];
-        double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;   // accumulated global rotation of the parent
-        for (int i = 0; i < m; i++) {
-            double qw = channel(r0 + 3 + 4 * i), qx = channel(r0 + 4 + 4 * i), qy = channel(r0 + 5 + 4 * i), qz = channel(r0 + 6 + 4 * i);
-            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
-            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
-            const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
-            const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
-            aw = nw; ax = nx; ay = ny; az = nz;
-            const double *off = a.choff + ((size_t)c * MG_MAX_CHAIN + i) * 3;
-            const double ox = off[0], oy = off[1], oz = off[2];
-            // v' = v + 2 w (u x v) + 2 u x (u x v), u = (ax, ay, az)
-            const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
-            const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
-            p0 += ox + 2.0 * (aw * cx + dx);
-            p1 += oy + 2.0 * (aw * cy + dy);
-            p2 += oz + 2.0 * (aw * cz + dz);
+        const int m = a.chain[c] & 0xffff;
+        double pj[3];
+        mg_fk_position(channel, r0, r0 + 3, m, a.choff + (size_t)c * 2 * MG_MAX_CHAIN * 3, pj);
+        if (type == MG_CONSTRAINT_JOINT_MIDPOINT) {   // two_hand_constraint.py:71: centre of the two joints
+            double pk[3];
+            mg_fk_position(channel, r0, r0 + 3 + 4 * (m > 1 ? m : 1), a.chain[c] >> 16, a.choff + ((size_t)c * 2 + 1) * MG_MAX_CHAIN * 3, pk);
+#pragma unroll
+            for (int i = 0; i < 3; i++) pj[i] = pj[i] + 0.5 * (pk[i] - pj[i]);
         }
-        const double pj[3] = {al.c * p0 + al.s * p2 + al.tx, p1, al.c * p2 - al.s * p0 + al.tz};
+        if (a.align) {
+            const double x = pj[0], z = pj[2];
+            pj[0] = al.c * x + al.s * z + al.tx;
+            pj[2] = al.c * z - al.s * x + al.tz;
+        }
         double ds = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -93,6 +133,21 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
             if (t == t) ds += (t - pj[i]) * (t - pj[i]);
         }
         return par[1] * sqrt(ds);
+    }
+    if (type == MG_CONSTRAINT_JOINT_ORIENTATION) {
+        // global_transform_constraint.py:109-121: angle between the joint's global orientation applied to ref_dir and the target vector
+        double q[4];
+        mg_chain_orientation(channel, r0, a.chain[c], q);
+        double v[3];
+        mg_rotate(q, par[5], par[6], par[7], v);
+        if (a.align) {
+            const double x = v[0], z = v[2];
+            v[0] = al.c * x + al.s * z;
+            v[2] = al.c * z - al.s * x;
+        }
+        const double dot = (v[0] * par[2] + v[1] * par[3] + v[2] * par[4]) /
+                           (sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * sqrt(par[2] * par[2] + par[3] * par[3] + par[4] * par[4]));
+        return par[1] * acos(fmin(1.0, fmax(dot, -1.0)));
     }
     if (type == MG_CONSTRAINT_POSITION) {
         // _point_distance: axes whose target is NaN (the reference's None) are ignored

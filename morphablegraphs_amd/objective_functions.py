@@ -16,7 +16,7 @@ previous frames and constraints that are not `is_local` every sample is aligned 
 import numpy as np
 
 from . import _capi
-from .candidate_scoring import constraints_to_device_form, cached_constraint_set, alignment_from_prev_frames
+from .candidate_scoring import constraints_to_device_form, cached_constraint_set, alignment_from_prev_frames, group_residuals
 
 
 def _prim_of(motion_primitive):
@@ -51,7 +51,7 @@ def _residuals(prim, mp_constraints, S, prev_frames=None):
         return np.zeros((len(S), 0))
     skeleton = getattr(mp_constraints, "hip_skeleton", None)
     cset = cached_constraint_set(prim, clist, skeleton, alignment_from_prev_frames(prev_frames, mp_constraints, skeleton))
-    return prim.score_constraint_residuals(cset, S)
+    return group_residuals(clist, prim.score_constraint_residuals(cset, S))
 
 
 def obj_spatial_error_sum(s, data):

@@ -278,6 +278,29 @@ def joint_global_orientation(frame, joints, animated_joints, joint):
     return R
 
 
+def joint_orientation_error(frame, joints, animated_joints, joint, target_quat, ref_dir=(0.0, 0.0, 1.0)):
+    """GlobalTransformConstraint._quaternion_distance (global_transform_constraint.py:109-121): the joint's global
+    orientation and the wanted one both applied to the z axis (ORIGIN = [0,0,0,1] read as the pure quaternion of
+    (0,0,1)), then transformations.angle_between_vectors = arccos(v1 . v2 / (|v1| |v2|)) in radians.  SELF-DEFINED
+    for the anim_utils pieces (get_global_orientation_quaternion, quaternion_rotate_vector); the dot product is
+    clamped to [-1, 1] where the reference would return NaN by rounding."""
+    v1 = joint_global_orientation(frame, joints, animated_joints, joint) @ np.asarray(ref_dir, dtype=np.float64)
+    v2 = quaternion_matrix3(target_quat) @ np.asarray(ref_dir, dtype=np.float64)
+    d = float(np.dot(v1, v2) / (np.linalg.norm(v1) * np.linalg.norm(v2)))
+    return math.acos(min(1.0, max(d, -1.0)))
+
+
+def two_hand_residuals(frame, joints, animated_joints, joint_names, positions):
+    """TwoHandConstraint.get_residual_vector_frame (two_hand_constraint.py:66-74): distance of the hands' centre to
+    the targets' centre, left hand to its target, right hand to its target."""
+    left = joint_global_position(frame, joints, animated_joints, joint_names[0])
+    right = joint_global_position(frame, joints, animated_joints, joint_names[1])
+    p0, p1 = np.asarray(positions[0], dtype=np.float64), np.asarray(positions[1], dtype=np.float64)
+    delta = right - left
+    center = p0 + 0.5 * (p1 - p0)
+    return [float(np.linalg.norm(center - (left + 0.5 * delta))), float(np.linalg.norm(p0 - left)), float(np.linalg.norm(p1 - right))]
+
+
 def node_heading(frame, joints, animated_joints, joint, ref_dir=(0.0, 0.0, 1.0)):
     """What anim_utils' get_global_node_orientation_vector is documented to return: unit (x, z) of the node's global
     rotation applied to ref_dir (SELF-DEFINED, anim_utils absent)."""
@@ -316,6 +339,22 @@ def align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, 
         cp[:3] = (m @ np.array([cp[0], cp[1], cp[2], 1.0]))[:3]
         cp[3:7] = quaternion_multiply(q, cp[3:7])
     return coeffs
+
+
+def constraint_error_on_frame(c, frame, joints, animated_joints):
+    """One constraint dict evaluated on one (aligned or local) pose vector."""
+    kind = c["type"]
+    if kind == "position":
+        return point_distance(c["target"], frame[:3])
+    if kind == "joint_position":
+        return point_distance(c["target"], joint_global_position(frame, joints, animated_joints, c["joint"]))
+    if kind == "joint_midpoint":
+        mid = 0.5 * (joint_global_position(frame, joints, animated_joints, c["joint"]) +
+                     joint_global_position(frame, joints, animated_joints, c["joint2"]))
+        return point_distance(c["target"], mid)
+    if kind == "joint_orientation":
+        return joint_orientation_error(frame, joints, animated_joints, c["joint"], c["orientation"], c.get("ref_dir", (0.0, 0.0, 1.0)))
+    return direction_2d_error(c["target"], frame[3:7], c.get("ref_dir", (0, 0, 1)))
 
 
 # --------------------------------------------------------------------------
@@ -416,12 +455,18 @@ class OraclePrimitive(object):
             coeffs = align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, align_joint, ref_dir)
             for ci, c in enumerate(constraints):
                 frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
-                if c["type"] == "position":
-                    out[b, ci] = c["weight"] * point_distance(c["target"], frame[:3])
-                elif c["type"] == "joint_position":
-                    out[b, ci] = c["weight"] * point_distance(c["target"], joint_global_position(frame, joints, animated_joints, c["joint"]))
-                else:
-                    out[b, ci] = c["weight"] * direction_2d_error(c["target"], frame[3:7], c.get("ref_dir", (0, 0, 1)))
+                out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
+        return out
+
+    def skeleton_residuals(self, S, constraints, joints, animated_joints):
+        """Every constraint type of the device scorer in local coordinates: (n_samples, n_constraints)."""
+        S = np.atleast_2d(S)
+        out = np.zeros((S.shape[0], len(constraints)))
+        for b in range(S.shape[0]):
+            coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
+            for ci, c in enumerate(constraints):
+                frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
+                out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
         return out
 
     def log_likelihood_jac(self, S):

@@ -593,3 +593,51 @@ def test_scoring_in_global_coordinates_through_the_adaptors():
     r3 = op.aligned_residuals(Xd.astype(np.float64), cons, prev_frames[-1], joints, animated, "Hips").sum(axis=1)
     np.testing.assert_array_equal(results[best_name][0].astype(np.float32), Xd[int(np.argmin(r3))])
     assert abs(results[best_name][1] - r3.min()) < 1e-7
+
+
+def test_reference_shaped_hand_constraints_through_the_objectives():
+    """TwoHandConstraint and a GlobalTransformConstraint with position and orientation, handed over as the
+    reference's objects: the error sum and the residual vector keep the reference's entries (three for the two-hand
+    constraint, two_hand_constraint.py:66-74; ONE for position + orientation, global_transform_constraint.py:70-77)."""
+    from oracle import mg_oracle as orc
+    from morphablegraphs_amd import objective_functions as of
+    joints, animated = synthetic.make_skeleton()
+    hip_sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "leftStance", "mm": data})
+    op = orc.OraclePrimitive(data)
+
+    class RefSkeleton(object):
+        root, aligning_root_node, aligning_root_dir = "Hips", "Hips", (0.0, 0.0, 1.0)
+
+    class TwoHand(object):
+        canonical_keyframe, weight_factor, skeleton = 100, 0.5, RefSkeleton()
+        positions, orientations, joint_names = [[30.0, 95.0, 10.0], [-20.0, 99.0, 14.0]], [None, None], ["LeftHand", "RightHand"]
+
+    class HeadPose(object):
+        canonical_keyframe, weight_factor, skeleton, joint_name = 40, 2.0, RefSkeleton(), "Head"
+        position, orientation = [0.0, 160.0, None], [0.9, 0.1, -0.3, 0.2]
+
+    class Constraints(object):
+        def __init__(self):
+            self.constraints, self.min_error, self.evaluations = [TwoHand(), HeadPose()], None, 0
+            self.is_local, self.skeleton, self.hip_skeleton, self.start_pose = True, RefSkeleton(), hip_sk, None
+
+    S = np.random.default_rng(2).standard_normal((12, 40))
+    expect = np.zeros((12, 4))
+    for b in range(12):
+        coeffs = op.back_project_spatial_coeffs(S[b])
+        f1 = orc.spline_frames(op.knots, coeffs, [100.0])[0]
+        f2 = orc.spline_frames(op.knots, coeffs, [40.0])[0]
+        expect[b, :3] = 0.5 * np.asarray(orc.two_hand_residuals(f1, joints, animated, TwoHand.joint_names, TwoHand.positions))
+        expect[b, 3] = 2.0 * (orc.point_distance(HeadPose.position, orc.joint_global_position(f2, joints, animated, "Head")) +
+                              orc.joint_orientation_error(f2, joints, animated, "Head", HeadPose.orientation))
+    c = Constraints()
+    np.testing.assert_allclose(of.obj_spatial_error_sum(S, (node, c, None)), expect.sum(axis=1), rtol=1e-9, atol=1e-8)
+    res = of.obj_spatial_error_residual_vector(S, (node, c, None, 1.0, 1.0, 1.0))
+    assert res.shape == (12, 40)                                        # zero padded to n_variables columns
+    np.testing.assert_allclose(res[:, :4], expect, rtol=1e-9, atol=1e-8)
+    assert not res[:, 4:].any()
+    best, err = evaluate_samples_using_constraints(S, node, c)
+    np.testing.assert_array_equal(best, S[int(np.argmin(expect.sum(axis=1)))])

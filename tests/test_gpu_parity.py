@@ -650,3 +650,69 @@ def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous
     with pytest.raises(_capi.MGError):
         _capi.ConstraintSet(prim, cons[:1], None, alignment={"position": [0, 0, 0], "heading": [0, 0]})
     prim.close()
+
+
+def test_two_hand_midpoint_and_joint_orientation_constraints(ctx, monkeypatch):
+    """MG_CONSTRAINT_JOINT_MIDPOINT (first residual of TwoHandConstraint, reference two_hand_constraint.py:66-74) and
+    MG_CONSTRAINT_JOINT_ORIENTATION (GlobalTransformConstraint._quaternion_distance, global_transform_constraint.py:
+    109-121; radians) against the matrix oracle, in local coordinates and aligned to a previous motion, MFMA and VALU
+    kernels bit for bit, plus known answers on a constant-pose primitive."""
+    from oracle import mg_oracle as orc
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(15)
+    S = rng.standard_normal((60, 40))
+    cons = [{"type": "joint_midpoint", "joint": "LeftHand", "joint2": "RightHand", "t": 120.0, "weight": 1.5, "target": [5.0, 95.0, 20.0]},
+            {"type": "joint_position", "joint": "LeftHand", "t": 120.0, "weight": 1.5, "target": [35.0, 95.0, 20.0]},
+            {"type": "joint_position", "joint": "RightHand", "t": 120.0, "weight": 1.5, "target": [-25.0, 95.0, 20.0]},
+            {"type": "joint_orientation", "joint": "Head", "t": 33.25, "weight": 2.0, "orientation": [0.9, 0.1, -0.3, 0.2]},
+            {"type": "joint_orientation", "joint": "Hips", "t": 155.0, "weight": 1.0, "orientation": [0.7, 0.0, 0.7, 0.0]},
+            {"type": "joint_midpoint", "joint": "Hips", "joint2": "LeftToeBase" if "LeftToeBase" in sk.names else "LeftFoot", "t": 0.0,
+             "weight": 1.0, "target": [0.0, None, 0.0]}]
+    cset = _capi.ConstraintSet(prim, cons, sk)
+    res = prim.score_constraint_residuals(cset, S)
+    np.testing.assert_allclose(res, op.skeleton_residuals(S, cons, joints, animated), rtol=1e-9, atol=1e-8)
+    monkeypatch.setenv("MG_SCORE_VALU", "1")
+    np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
+    monkeypatch.delenv("MG_SCORE_VALU")
+    cset.close()
+    prev = op.back_project_frames(rng.standard_normal(40))[-1].copy()
+    prev[:3] = [-60.0, 90.0, 210.0]
+    cset = _capi.ConstraintSet(prim, cons, sk, alignment=sk.alignment_to(prev, "Hips"))
+    res_al = prim.score_constraint_residuals(cset, S)
+    np.testing.assert_allclose(res_al, op.aligned_residuals(S, cons, prev, joints, animated, "Hips"), rtol=1e-9, atol=1e-8)
+    assert np.abs(res_al - res).max() > 1.0                                       # the alignment does something
+    cset.close()
+    # the root's orientation needs no skeleton
+    cset = _capi.ConstraintSet(prim, [dict(cons[4], joint=0)])
+    np.testing.assert_allclose(prim.score_constraint_residuals(cset, S)[:, 0], res[:, 4], rtol=1e-13, atol=1e-13)
+    cset.close()
+    with pytest.raises(ValueError):
+        _capi.ConstraintSet(prim, [dict(cons[3], joint=3)])                        # a chain without a skeleton
+    with pytest.raises(ValueError):
+        _capi.ConstraintSet(prim, [cons[0]])
+    prim.close()
+
+    # known answers: every control point is the identity pose at (1, 2, 3)
+    tiny = synthetic.make_primitive(seed=2, n_components=3, n_frames=12, n_basis=7, n_dim=79, n_gmm=2, name="tiny79")
+    pose = np.zeros(79)
+    pose[3::4][:19] = 1.0
+    pose[:3] = [1.0, 2.0, 3.0]
+    model = dict(tiny)
+    model["mean_spatial_vector"] = np.tile(pose, int(tiny["n_basis_spatial"]))
+    model["eigen_vectors_spatial"] = np.zeros_like(np.asarray(tiny["eigen_vectors_spatial"], dtype=np.float64))
+    model["translation_maxima"] = np.ones(3)
+    pr = _capi.Primitive(ctx, model)
+    half = np.sqrt(0.5)
+    known = [({"type": "joint_midpoint", "joint": "LeftHand_EndSite", "joint2": "RightHand_EndSite", "t": 4.0, "weight": 1.0,
+               "target": [1.0, 35.0, 0.5]}, 3.0),
+             ({"type": "joint_orientation", "joint": "LeftHand", "t": 4.0, "weight": 1.0, "orientation": [half, 0.0, half, 0.0]}, np.pi / 2),
+             ({"type": "joint_orientation", "joint": "Hips", "t": 4.0, "weight": 2.0, "orientation": [1.0, 0.0, 0.0, 0.0]}, 0.0)]
+    for c, expect in known:
+        cs = _capi.ConstraintSet(pr, [c], sk)
+        np.testing.assert_allclose(pr.score_constraints(cs, np.zeros((2, pr.n_components))), expect, rtol=1e-12, atol=1e-12, err_msg=str(c))
+        cs.close()
+    pr.close()

@@ -184,3 +184,32 @@ def test_alignment_oracle_known_answers():
     out = orc.align_coeffs_to_previous_frame(walk, prev2, joints, animated, "Hips")
     np.testing.assert_allclose(out[:, :3], [[10.0, 5.0, 20.0], [11.0, 5.0, 20.0], [12.0, 5.0, 20.0], [13.0, 5.0, 20.0]], atol=1e-12)
     np.testing.assert_allclose(out[:, 3:7], np.tile(prev2[3:7], (4, 1)), atol=1e-12)
+
+
+def test_two_hand_and_orientation_oracle_known_answers():
+    """TwoHandConstraint residuals (reference two_hand_constraint.py:66-74) and the orientation distance
+    (global_transform_constraint.py:109-121) on poses whose answers are known by hand."""
+    from morphablegraphs_amd import synthetic
+    joints, animated = synthetic.make_skeleton()
+    frame = np.zeros(3 + 4 * len(animated))
+    frame[3::4] = 1.0
+    frame[:3] = [1.0, 2.0, 3.0]
+    left = orc.joint_global_position(frame, joints, animated, "LeftHand_EndSite")
+    right = orc.joint_global_position(frame, joints, animated, "RightHand_EndSite")
+    np.testing.assert_allclose(left, [76.0, 35.0, 3.5], atol=1e-12)
+    np.testing.assert_allclose(right, [-74.0, 35.0, 3.5], atol=1e-12)
+    res = orc.two_hand_residuals(frame, joints, animated, ["LeftHand_EndSite", "RightHand_EndSite"], [[76.0, 35.0, 0.5], [-74.0, 39.0, 3.5]])
+    np.testing.assert_allclose(res, [np.hypot(2.0, 1.5), 3.0, 4.0], atol=1e-12)
+    mid = {"type": "joint_midpoint", "joint": "LeftHand_EndSite", "joint2": "RightHand_EndSite", "target": [1.0, 35.0, 0.5]}
+    assert abs(orc.constraint_error_on_frame(mid, frame, joints, animated) - 3.0) < 1e-12
+    half = np.sqrt(0.5)
+    # identity pose against a wanted quarter turn about y: z axis vs x axis = pi / 2; against itself 0; a half turn about x = pi
+    assert abs(orc.joint_orientation_error(frame, joints, animated, "LeftHand", [half, 0.0, half, 0.0]) - np.pi / 2) < 1e-12
+    assert abs(orc.joint_orientation_error(frame, joints, animated, "LeftHand", [2.0, 0.0, 0.0, 0.0])) < 1e-12
+    assert abs(orc.joint_orientation_error(frame, joints, animated, "Hips", [0.0, 1.0, 0.0, 0.0]) - np.pi) < 1e-7
+    # the joint's OWN rotation counts, and so does every parent's: spine a quarter turn about y turns the hand's z axis to x
+    f2 = frame.copy()
+    ch = 3 + 4 * animated.index("Spine")
+    f2[ch:ch + 4] = [half, 0.0, half, 0.0]
+    assert abs(orc.joint_orientation_error(f2, joints, animated, "LeftHand", [half, 0.0, half, 0.0])) < 1e-12
+    assert abs(orc.joint_orientation_error(f2, joints, animated, "Hips", [half, 0.0, half, 0.0]) - np.pi / 2) < 1e-12
