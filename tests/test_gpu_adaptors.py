@@ -641,3 +641,54 @@ def test_reference_shaped_hand_constraints_through_the_objectives():
     assert not res[:, 4:].any()
     best, err = evaluate_samples_using_constraints(S, node, c)
     np.testing.assert_array_equal(best, S[int(np.argmin(expect.sum(axis=1)))])
+
+
+def test_cluster_tree_training_data_in_batches():
+    """The data-producing half of ClusterTreeBuilder (reference construction/cluster_tree_builder.py:159-192,
+    293-301): threshold filter, best-of-2n by the reference's heap slice, back projection at the integer canonical
+    frames -- each as one batched call, compared with the reference's per-sample loops run on the oracle."""
+    import heapq
+    from oracle import mg_oracle as orc
+    from morphablegraphs_amd.cluster_tree_sampling import HipClusterTreeSampler
+    data = synthetic.make_walk_primitive(seed=0)
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "leftStance", "mm": data})
+    op = orc.OraclePrimitive(data)
+    sampler = HipClusterTreeSampler(n_samples=300)
+
+    np.random.seed(5)
+    X = node.sample_low_dimensional_vectors(300)
+    ll = op.score_samples(X)
+    thr = float(np.median(ll))
+    np.random.seed(5)
+    got = sampler._get_samples_using_threshold(node, threshold=thr, max_iter_count=5)
+    np.random.seed(5)
+    expect, count, it = [], 0, 0
+    while count < 300 and it < 5:                               # the reference's loop, scores from the oracle
+        Xi = node.sample_low_dimensional_vectors(300)
+        for s, l in zip(Xi, op.score_samples(Xi)):
+            if l > thr:
+                expect.append(s)
+                count += 1
+        it += 1
+    assert it < 5 and got.shape == (len(expect), 40)
+    np.testing.assert_array_equal(got, np.asarray(expect))
+    assert sampler._get_samples_using_threshold(node, threshold=1e9, max_iter_count=2) is None
+
+    np.random.seed(6)
+    best = sampler._get_best_samples(node)
+    np.random.seed(6)
+    X2 = node.sample_low_dimensional_vectors(600)
+    heap = []
+    for idx, l in enumerate(op.score_samples(X2)):
+        heapq.heappush(heap, (-l, idx))
+    ref = X2[[i for _, i in heap[:300]]]
+    np.random.shuffle(ref)
+    np.testing.assert_array_equal(best, ref)
+
+    motions = sampler._back_project(node, X[:20])
+    assert motions.shape == (20, 156, 79) and motions.dtype == np.float64
+    ref_m = op.back_project_frames_batch(X[:20], time_points=np.arange(156.0))
+    np.testing.assert_allclose(motions, ref_m, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(ref_m).max()))
+    np.testing.assert_array_equal(sampler._extract_features(node, X), X[:, :40])
+    assert sampler.sample_data(node).shape == (300, 40)
