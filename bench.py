@@ -75,7 +75,10 @@ def main():
             import __graft_entry__
             __graft_entry__.build()
         else:
+            deadline = time.time() + 900.0
             while not os.path.exists(os.path.join(ROOT, "oracle", "libmg_oracle.so")):   # built last
+                if time.time() > deadline:
+                    raise SystemExit("libmg_hip.so was not built by local rank 0 within 15 minutes")
                 time.sleep(1.0)
             time.sleep(2.0)
     from morphablegraphs_amd import _capi, synthetic

@@ -733,8 +733,17 @@ extern "C" int mg_primitive_get_precisions_cholesky(const mg_primitive *p, doubl
 // ---------------------------------------------------------------------------------------
 // hot-path entry points (validation, then launch)
 // ---------------------------------------------------------------------------------------
+// A process may hold contexts on several devices: kernels and copies of a context must be issued with its device
+// current (a no-op compare in the usual one-process-per-GPU deployment).
+static int mg_use_device(const mg_context *ctx) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) MG_HIP_CHECK(hipSetDevice(ctx->device));
+    return MG_OK;
+}
+
 static int mg_check_latents(const char *fn, const mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld) {
     MG_REQUIRE(p != nullptr, "%s: primitive is NULL", fn);
+    { int rc = mg_use_device(p->ctx); if (rc != MG_OK) return rc; }
     MG_REQUIRE(B >= 0, "%s: n_samples = %lld < 0", fn, (long long)B);
     MG_REQUIRE(dt == MG_F32 || dt == MG_F64, "%s: latent dtype %d is neither MG_F32 nor MG_F64", fn, dt);
     MG_REQUIRE(B == 0 || lat != nullptr, "%s: latents pointer is NULL", fn);
@@ -803,6 +812,7 @@ extern "C" int mg_spline_evaluate(mg_primitive *p, const mg_time_grid *g, const 
     MG_REQUIRE(g->prim == p, "mg_spline_evaluate: grid belongs to another primitive");
     if (n == 0 || g->T == 0) return MG_OK;
     MG_REQUIRE(coeffs && out, "mg_spline_evaluate: NULL pointer");
+    { int rc = mg_use_device(p->ctx); if (rc != MG_OK) return rc; }
     mg_prof_begin(p->ctx, 5);
     int rc = mg_launch_spline_eval(p, g, coeffs, n, out);
     mg_prof_end(p->ctx, 5);
@@ -829,6 +839,7 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
     MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_gmm_sample: bad dtype %d", xdt);
     MG_REQUIRE(counts != nullptr, "mg_gmm_sample: counts is NULL");
     MG_REQUIRE(ld >= p->L, "mg_gmm_sample: leading dimension %lld < n_components %d", (long long)ld, p->L);
+    { int rc0 = mg_use_device(p->ctx); if (rc0 != MG_OK) return rc0; }
     // [0 .. K]: row prefix sums; [K+1 .. 2K+1]: prefix sums of 16-row tiles (a tile never straddles two components)
     std::vector<int64_t> cum(2 * (size_t)p->K + 2, 0);
     for (int k = 0; k < p->K; k++) {
@@ -1092,6 +1103,7 @@ extern "C" int mg_gmm_log_prob_jac(mg_primitive *p, const void *x, int xdt, int6
 extern "C" int mg_argmin_first_dev(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev) {
     MG_REQUIRE(ctx && out_dev && n >= 0 && (n == 0 || v), "mg_argmin_first_dev: bad arguments");
     MG_REQUIRE(dt == MG_F32 || dt == MG_F64, "mg_argmin_first_dev: bad dtype %d", dt);
+    { int rc0 = mg_use_device(ctx); if (rc0 != MG_OK) return rc0; }
     mg_prof_begin(ctx, 3);
     int rc = mg_launch_argmin(ctx, v, dt, n, out_dev);
     mg_prof_end(ctx, 3);
