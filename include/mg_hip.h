@@ -89,7 +89,12 @@ typedef struct mg_primitive_desc {
  *      p = t_root + sum_i R(q_j0 q_j1 .. q_j(i-1)) offset(j_i), quaternions (w,x,y,z) normalised like
  *      transformations.quaternion_matrix does; needs a set made by mg_constraint_set_create_fk.
  *      PARITY UNPINNED: the reference's FK lives in anim_utils (absent); pinned by an independent
- *      rotation-matrix oracle and known-answer poses (tests);
+ *      rotation-matrix oracle and known-answer poses (tests).  A non-zero ref_dir is a point given in the joint's
+ *      own frame: p + R_global(joint) ref_dir, RelativeTransformConstraint's `global_matrix . offset`
+ *      (reference relative_transform_constraint.py:46-50);
+ *  MG_CONSTRAINT_LOOK_AT -> LookAtConstraint.evaluate_frame (reference look_at_constraint.py:55-66): the angle
+ *      in RADIANS between the joint's global orientation applied to ref_dir (REFERENCE_VECTOR (0,0,1)) and the
+ *      direction from the joint's position to `target`;
  *  MG_CONSTRAINT_JOINT_MIDPOINT -> the first residual of TwoHandConstraint.get_residual_vector_frame
  *      (reference two_hand_constraint.py:66-74): |target - (p(joint) + p(joint2)) / 2|, both by the same FK (the
  *      other two residuals of that constraint are plain MG_CONSTRAINT_JOINT_POSITIONs);
@@ -99,7 +104,7 @@ typedef struct mg_primitive_desc {
  *      ref_dir (the caller rotates; ref_dir = (0,0,1) is the reference's ORIGIN); arccos of the normalised dot
  *      product (transformations.angle_between_vectors), clamped to [-1, 1]. */
 enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1, MG_CONSTRAINT_JOINT_POSITION = 2,
-       MG_CONSTRAINT_JOINT_MIDPOINT = 3, MG_CONSTRAINT_JOINT_ORIENTATION = 4 };
+       MG_CONSTRAINT_JOINT_MIDPOINT = 3, MG_CONSTRAINT_JOINT_ORIENTATION = 4, MG_CONSTRAINT_LOOK_AT = 5 };
 #define MG_MAX_CHAIN 32
 typedef struct mg_keyframe_constraint {
     int32_t type;

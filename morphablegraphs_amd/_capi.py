@@ -18,7 +18,7 @@ MG_OK = 0
 MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
-MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION = 3, 4
+MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT = 3, 4, 5
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
                  "gmm_sample": 4, "spline_evaluate": 5, "step": 6}
 
@@ -386,9 +386,10 @@ class TimeGrid(object):
 
 class ConstraintSet(object):
     """constraints: list of dicts {"type": "position"|"direction"|"joint_position"|"joint_midpoint"|
-    "joint_orientation", "t": float, "weight": float, "target": [x|None, y|None, z|None] | [dx, dz],
+    "joint_orientation"|"look_at", "t": float, "weight": float, "target": [x|None, y|None, z|None] | [dx, dz],
     "ref_dir": (rx, ry, rz), "joint": name or index, "joint2": second joint of a midpoint, "orientation": wanted
-    global (w,x,y,z) of a joint_orientation (or "target": that orientation applied to ref_dir)}; a `skeleton`
+    global (w,x,y,z) of a joint_orientation (or "target": that orientation applied to ref_dir), "offset": a point in
+    the joint's own frame instead of its origin (joint_position), "look_at": {"joint", "target" xyz}}; a `skeleton`
     (Skeleton) is needed for "joint_position", "joint_midpoint" and for orientations of joints other than the root.  `alignment` = {"joint", "position", "heading",
     "ref_dir"} (Skeleton.alignment_to) switches to global coordinates: every candidate is aligned to the previous
     motion before its constraints are evaluated; without a skeleton the aligning node is the root joint."""
@@ -416,6 +417,16 @@ class ConstraintSet(object):
                 for a in range(3):
                     v = c["target"][a]
                     k.target[a] = float("nan") if v is None else float(v)
+                    k.ref_dir[a] = float(c["offset"][a]) if c.get("offset") is not None else 0.0   # point in the joint's frame
+            elif c["type"] == "look_at":
+                if skeleton is None and c.get("joint", 0) not in (0, None):
+                    raise ValueError("look_at on joint %r needs a skeleton (only the root joint, 0, does not)" % (c["joint"],))
+                k.type = MG_CONSTRAINT_LOOK_AT
+                k.joint = 0 if skeleton is None else skeleton.index(c.get("joint", 0) or 0)
+                rd = c.get("ref_dir", (0.0, 0.0, 1.0))
+                for a in range(3):
+                    k.target[a] = float(c["target"][a])
+                    k.ref_dir[a] = float(rd[a])
             elif c["type"] == "joint_midpoint":
                 if skeleton is None:
                     raise ValueError("joint_midpoint constraints need a skeleton")

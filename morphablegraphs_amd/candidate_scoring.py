@@ -23,7 +23,8 @@ SAMPLING_MODE_GPU_BATCH = "gpu_batch"   # a 4th constrained_sampling_mode next t
 def constraints_to_device_form(constraints, root_joint=None):
     """Accepts either ready dicts {"type","t","weight","target"[,"ref_dir"]} or reference-shaped
     constraint objects: Direction2DConstraint (target_dir), GlobalTransformConstraint (position and / or
-    orientation of a joint), TwoHandConstraint (positions + joint_names).  One reference constraint may become
+    orientation of a joint), RelativeTransformConstraint (position of a point given in a joint's frame),
+    TwoHandConstraint (positions + joint_names), LookAtConstraint (target_position).  One reference constraint may become
     several device constraints; "group" numbers the reference constraint's residual entry they add up to (a
     GlobalTransformConstraint is ONE residual = position error + orientation error, a TwoHandConstraint three,
     two_hand_constraint.py:66-74), see `group_residuals`."""
@@ -51,6 +52,15 @@ def constraints_to_device_form(constraints, root_joint=None):
             out.append({"type": "joint_position", "t": t, "weight": w, "target": [float(v) for v in p1], "joint": c.joint_names[1],
                         "group": group + 2})
             group += 3
+        elif hasattr(c, "target_position") and not hasattr(c, "position"):      # LookAtConstraint (look_at_constraint.py:37-43)
+            head = getattr(getattr(c, "skeleton", None), "head_joint", getattr(c, "joint_name", "Head"))
+            out.append({"type": "look_at", "t": t, "weight": w, "target": [float(v) for v in c.target_position], "joint": head,
+                        "group": group})
+            group += 1
+        elif getattr(c, "offset", None) is not None and getattr(c, "position", None) is not None:   # RelativeTransformConstraint
+            out.append({"type": "joint_position", "t": t, "weight": w, "target": [float(v) for v in c.position],
+                        "joint": c.joint_name, "offset": [float(v) for v in list(c.offset)[:3]], "group": group})
+            group += 1
         elif getattr(c, "position", None) is not None or getattr(c, "orientation", None) is not None:
             joint = getattr(c, "joint_name", root_joint)
             root = root_joint if root_joint is not None else getattr(getattr(c, "skeleton", None), "root", None)

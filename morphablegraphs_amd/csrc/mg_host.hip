@@ -900,7 +900,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
     }
     for (int c = 0; c < n; c++) {
         const int type = cons[c].type;
-        MG_REQUIRE(type >= MG_CONSTRAINT_POSITION && type <= MG_CONSTRAINT_JOINT_ORIENTATION,
+        MG_REQUIRE(type >= MG_CONSTRAINT_POSITION && type <= MG_CONSTRAINT_LOOK_AT,
                    "mg_constraint_set_create: constraint %d has unknown type %d", c, type);
         MG_REQUIRE(std::isfinite(cons[c].canonical_keyframe), "mg_constraint_set_create: constraint %d keyframe not finite", c);
         MG_REQUIRE(type == MG_CONSTRAINT_POSITION ? D >= 3 : D >= 7,
@@ -910,10 +910,25 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
             MG_REQUIRE(sk != nullptr, "mg_constraint_set_create: constraint %d needs a skeleton (mg_constraint_set_create_fk)", c);
             MG_REQUIRE(cons[c].joint >= 0 && cons[c].joint < sk->n_joints, "mg_constraint_set_create_fk: constraint %d: joint %d out of range", c, cons[c].joint);
             for (int j = cons[c].joint; j >= 0; j = sk->parents[j]) chains[c].insert(chains[c].begin(), j);
-            const int m = (int)chains[c].size() - 1;   // joints below the root on the chain
+            int m = (int)chains[c].size() - 1;   // joints below the root on the chain
+            // a point given in the joint's own frame hangs below it like one more joint: the joint's own quaternion turns it
+            if (cons[c].ref_dir[0] != 0.0 || cons[c].ref_dir[1] != 0.0 || cons[c].ref_dir[2] != 0.0) m++;
             MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain of %d joints exceeds %d", c, m, MG_MAX_CHAIN);
             chain_len[c] = m;
             rows = 3 + 4 * std::max(m, 1);
+        } else if (type == MG_CONSTRAINT_LOOK_AT) {
+            MG_REQUIRE(cons[c].joint == 0 || (sk && cons[c].joint > 0 && cons[c].joint < sk->n_joints),
+                       "mg_constraint_set_create_fk: constraint %d: joint %d needs a skeleton that has it", c, cons[c].joint);
+            if (cons[c].joint == 0) chains[c].push_back(0);
+            else for (int j = cons[c].joint; j >= 0; j = sk->parents[j]) chains[c].insert(chains[c].begin(), j);
+            const int m = (int)chains[c].size();       // quaternions root .. joint; the first m - 1 place the joint
+            MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain of %d joints exceeds %d", c, m, MG_MAX_CHAIN);
+            const double rn = std::sqrt(cons[c].ref_dir[0] * cons[c].ref_dir[0] + cons[c].ref_dir[1] * cons[c].ref_dir[1] + cons[c].ref_dir[2] * cons[c].ref_dir[2]);
+            MG_REQUIRE(std::isfinite(rn) && rn > 0.0, "mg_constraint_set_create: constraint %d: zero reference vector", c);
+            MG_REQUIRE(std::isfinite(cons[c].target[0]) && std::isfinite(cons[c].target[1]) && std::isfinite(cons[c].target[2]),
+                       "mg_constraint_set_create: constraint %d: look-at target not finite", c);
+            chain_len[c] = m;
+            rows = 3 + 4 * m;
         } else if (type == MG_CONSTRAINT_JOINT_MIDPOINT) {
             MG_REQUIRE(sk != nullptr, "mg_constraint_set_create: constraint %d needs a skeleton (mg_constraint_set_create_fk)", c);
             MG_REQUIRE(cons[c].joint >= 0 && cons[c].joint < sk->n_joints && cons[c].joint2 >= 0 && cons[c].joint2 < sk->n_joints,
@@ -973,7 +988,18 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
             for (int i = 0; i < m; i++)
                 for (int e = 0; e < 3; e++) choff[(((size_t)c * 2 + which) * MG_MAX_CHAIN + i) * 3 + e] = sk->offsets[(size_t)chain[i + 1] * 3 + e];
         };
-        if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION || cons[c].type == MG_CONSTRAINT_JOINT_MIDPOINT) {
+        if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION && chain_len[c] == (int)chains[c].size()) {
+            // relative point: every quaternion root .. joint, the skeleton's offsets and the point itself as the last link
+            for (int d = 0; d < 3; d++) fill_row(r0 + d, d);
+            const int m = chain_len[c];
+            fill_quats(r0 + 3, chains[c], m);
+            fill_offsets(0, chains[c], m - 1);
+            for (int e = 0; e < 3; e++) choff[(((size_t)c * 2) * MG_MAX_CHAIN + (m - 1)) * 3 + e] = cons[c].ref_dir[e];
+        } else if (cons[c].type == MG_CONSTRAINT_LOOK_AT) {
+            for (int d = 0; d < 3; d++) fill_row(r0 + d, d);
+            fill_quats(r0 + 3, chains[c], chain_len[c]);
+            fill_offsets(0, chains[c], chain_len[c] - 1);
+        } else if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION || cons[c].type == MG_CONSTRAINT_JOINT_MIDPOINT) {
             for (int d = 0; d < 3; d++) fill_row(r0 + d, d);
             const int m = chain_len[c] & 0xffff;
             fill_quats(r0 + 3, chains[c], std::max(m, 1));   // joints 0 .. m-1 (the end joint's own rotation does not move it)

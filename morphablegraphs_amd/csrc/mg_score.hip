@@ -134,6 +134,24 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
         }
         return par[1] * sqrt(ds);
     }
+    if (type == MG_CONSTRAINT_LOOK_AT) {
+        // look_at_constraint.py:55-66: angle between where the joint looks and where the target is
+        const int m = a.chain[c];
+        double pj[3], q[4], v[3];
+        mg_fk_position(channel, r0, r0 + 3, m - 1, a.choff + (size_t)c * 2 * MG_MAX_CHAIN * 3, pj);
+        mg_chain_orientation(channel, r0 + 3, m, q);
+        mg_rotate(q, par[5], par[6], par[7], v);
+        if (a.align) {
+            const double x = pj[0], z = pj[2], vx = v[0], vz = v[2];
+            pj[0] = al.c * x + al.s * z + al.tx;
+            pj[2] = al.c * z - al.s * x + al.tz;
+            v[0] = al.c * vx + al.s * vz;
+            v[2] = al.c * vz - al.s * vx;
+        }
+        const double tx = par[2] - pj[0], ty = par[3] - pj[1], tz = par[4] - pj[2];
+        const double dot = (v[0] * tx + v[1] * ty + v[2] * tz) / (sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * sqrt(tx * tx + ty * ty + tz * tz));
+        return par[1] * acos(fmin(1.0, fmax(dot, -1.0)));
+    }
     if (type == MG_CONSTRAINT_JOINT_ORIENTATION) {
         // global_transform_constraint.py:109-121: angle between the joint's global orientation applied to ref_dir and the target vector
         double q[4];

@@ -347,7 +347,18 @@ def constraint_error_on_frame(c, frame, joints, animated_joints):
     if kind == "position":
         return point_distance(c["target"], frame[:3])
     if kind == "joint_position":
-        return point_distance(c["target"], joint_global_position(frame, joints, animated_joints, c["joint"]))
+        p = joint_global_position(frame, joints, animated_joints, c["joint"])
+        if c.get("offset") is not None:   # relative_transform_constraint.py:46-50: global matrix of the joint times the offset
+            p = p + joint_global_orientation(frame, joints, animated_joints, c["joint"]) @ np.asarray(c["offset"], dtype=np.float64)[:3]
+        return point_distance(c["target"], p)
+    if kind == "look_at":                 # look_at_constraint.py:55-66
+        head = joint_global_position(frame, joints, animated_joints, c["joint"])
+        to_target = np.asarray(c["target"], dtype=np.float64) - head
+        to_target = to_target / np.linalg.norm(to_target)
+        look = joint_global_orientation(frame, joints, animated_joints, c["joint"]) @ np.asarray(c.get("ref_dir", (0.0, 0.0, 1.0)), dtype=np.float64)
+        look = look / np.linalg.norm(look)
+        # |angle| of the rotation taking `look` to `to_target` (quaternion_from_vector_to_vector + rotation_from_matrix)
+        return math.acos(min(1.0, max(float(np.dot(look, to_target)), -1.0)))
     if kind == "joint_midpoint":
         mid = 0.5 * (joint_global_position(frame, joints, animated_joints, c["joint"]) +
                      joint_global_position(frame, joints, animated_joints, c["joint2"]))

@@ -716,3 +716,59 @@ def test_two_hand_midpoint_and_joint_orientation_constraints(ctx, monkeypatch):
         np.testing.assert_allclose(pr.score_constraints(cs, np.zeros((2, pr.n_components))), expect, rtol=1e-12, atol=1e-12, err_msg=str(c))
         cs.close()
     pr.close()
+
+
+def test_relative_point_and_look_at_constraints(ctx, monkeypatch):
+    """A point given in a joint's own frame (RelativeTransformConstraint, reference relative_transform_constraint.py:
+    46-50) and LookAtConstraint (look_at_constraint.py:55-66), local and aligned, against the matrix oracle, plus
+    answers known by hand on a constant identity pose."""
+    from oracle import mg_oracle as orc
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(19)
+    S = rng.standard_normal((50, 40))
+    cons = [{"type": "joint_position", "joint": "RightHand", "offset": [0.0, -3.0, 12.0], "t": 60.0, "weight": 1.0, "target": [-30.0, 90.0, 25.0]},
+            {"type": "joint_position", "joint": "Hips", "offset": [5.0, 0.0, 0.0], "t": 155.0, "weight": 0.5, "target": [10.0, None, 0.0]},
+            {"type": "look_at", "joint": "Head", "t": 100.5, "weight": 2.0, "target": [50.0, 150.0, 400.0]},
+            {"type": "look_at", "joint": "Hips", "t": 0.0, "weight": 1.0, "target": [-100.0, 0.0, 30.0]},
+            {"type": "joint_position", "joint": "RightHand", "t": 60.0, "weight": 1.0, "target": [-30.0, 90.0, 25.0]}]
+    cset = _capi.ConstraintSet(prim, cons, sk)
+    res = prim.score_constraint_residuals(cset, S)
+    np.testing.assert_allclose(res, op.skeleton_residuals(S, cons, joints, animated), rtol=1e-9, atol=1e-8)
+    assert np.abs(res[:, 0] - res[:, 4]).max() > 1.0                                  # the offset matters
+    monkeypatch.setenv("MG_SCORE_VALU", "1")
+    np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
+    monkeypatch.delenv("MG_SCORE_VALU")
+    cset.close()
+    prev = op.back_project_frames(rng.standard_normal(40))[-1].copy()
+    prev[:3] = [15.0, 90.0, -75.0]
+    cset = _capi.ConstraintSet(prim, cons, sk, alignment=sk.alignment_to(prev, "Hips"))
+    np.testing.assert_allclose(prim.score_constraint_residuals(cset, S), op.aligned_residuals(S, cons, prev, joints, animated, "Hips"),
+                               rtol=1e-9, atol=1e-8)
+    cset.close()
+    prim.close()
+
+    tiny = synthetic.make_primitive(seed=2, n_components=3, n_frames=12, n_basis=7, n_dim=79, n_gmm=2, name="tiny79")
+    pose = np.zeros(79)
+    pose[3::4][:19] = 1.0
+    pose[:3] = [1.0, 2.0, 3.0]
+    half = np.sqrt(0.5)
+    pose[3:7] = [half, 0.0, half, 0.0]                                                 # hips a quarter turn about y: z -> x, x -> -z
+    model = dict(tiny)
+    model["mean_spatial_vector"] = np.tile(pose, int(tiny["n_basis_spatial"]))
+    model["eigen_vectors_spatial"] = np.zeros_like(np.asarray(tiny["eigen_vectors_spatial"], dtype=np.float64))
+    model["translation_maxima"] = np.ones(3)
+    pr = _capi.Primitive(ctx, model)
+    known = [({"type": "joint_position", "joint": "Hips", "offset": [0.0, 0.0, 5.0], "t": 3.0, "weight": 1.0, "target": [6.0, 2.0, 3.0]}, 0.0),
+             ({"type": "joint_position", "joint": "Hips", "offset": [2.0, 0.0, 0.0], "t": 3.0, "weight": 1.0, "target": [1.0, 2.0, 3.0]}, 2.0),
+             ({"type": "look_at", "joint": "Hips", "t": 3.0, "weight": 1.0, "target": [11.0, 2.0, 3.0]}, 0.0),     # looks along +x
+             ({"type": "look_at", "joint": "Hips", "t": 3.0, "weight": 1.0, "target": [1.0, 2.0, 9.0]}, np.pi / 2),
+             ({"type": "look_at", "joint": "Head", "t": 3.0, "weight": 3.0, "target": [1.0 - 50.0, 2.0 + 44.0 + 0.0, 3.0]}, 3.0 * np.pi)]
+    for c, expect in known:
+        cs = _capi.ConstraintSet(pr, [c], sk)
+        np.testing.assert_allclose(pr.score_constraints(cs, np.zeros((2, pr.n_components))), expect, rtol=1e-12, atol=1e-7, err_msg=str(c))
+        cs.close()
+    pr.close()

@@ -159,6 +159,19 @@ def test_constraint_conversion_accepts_reference_shaped_objects():
         canonical_keyframe, weight_factor = 20, 0.5
         positions, orientations, joint_names = [[0.0, 0.0, 0.0], [2.0, 4.0, 6.0]], [None, None], ["LeftHand", "RightHand"]
 
+    class Relative(object):     # RelativeTransformConstraint: a point in the joint's frame (homogeneous offset)
+        canonical_keyframe, weight_factor, joint_name, skeleton = 30, 1.0, "RightHand", RefSkeleton()
+        position, orientation, offset = [4.0, 5.0, 6.0], None, [0.0, -3.0, 12.0, 1.0]
+
+    class LookAt(object):
+        canonical_keyframe, weight_factor, joint_name = 40, 1.0, "Head"
+        target_position = np.array([1.0, 2.0, 3.0])
+
+    out = constraints_to_device_form([Relative(), LookAt()])
+    assert out[0] == {"type": "joint_position", "t": 30.0, "weight": 1.0, "target": [4.0, 5.0, 6.0], "joint": "RightHand",
+                      "offset": [0.0, -3.0, 12.0], "group": 0}
+    assert out[1] == {"type": "look_at", "t": 40.0, "weight": 1.0, "target": [1.0, 2.0, 3.0], "joint": "Head", "group": 1}
+
     out = constraints_to_device_form([HandPose(), TwoHand(), Dir()])
     assert [c["type"] for c in out] == ["joint_position", "joint_orientation", "joint_midpoint", "joint_position", "joint_position", "direction"]
     assert [c["group"] for c in out] == [0, 0, 1, 2, 3, 4]
