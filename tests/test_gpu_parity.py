@@ -645,6 +645,21 @@ def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous
     expect = abs(np.degrees(np.arccos(np.clip(h[0], -1.0, 1.0))))
     np.testing.assert_allclose(prim.score_constraints(cset, S), expect, rtol=1e-9, atol=1e-9)
     cset.close()
+    # edges: no constraints at all (error 0 for every candidate), one candidate, a ragged batch, float32 latents
+    al = sk.alignment_to(prev, "Spine1")
+    cset = _capi.ConstraintSet(prim, [], sk, alignment=al)
+    np.testing.assert_array_equal(prim.score_constraints(cset, S[:5]), np.zeros(5))
+    assert prim.score_constraint_residuals(cset, S[:5]).shape == (5, 0)
+    cset.close()
+    cset = _capi.ConstraintSet(prim, cons, sk, alignment=al)
+    for n in (1, 17):
+        np.testing.assert_allclose(prim.score_constraint_residuals(cset, S[:n]), op.aligned_residuals(S[:n], cons, prev, joints, animated, "Spine1"),
+                                   rtol=1e-9, atol=1e-8)
+    S32 = S[:17].astype(np.float32)
+    np.testing.assert_allclose(prim.score_constraint_residuals(cset, S32), op.aligned_residuals(S32.astype(np.float64), cons, prev, joints, animated, "Spine1"),
+                               rtol=1e-9, atol=1e-8)
+    assert prim.score_constraints(cset, S[:0]).shape == (0,)
+    cset.close()
     with pytest.raises(_capi.MGError):
         _capi.ConstraintSet(prim, cons[:1], None, alignment={"joint": 3, "position": [0, 0, 0], "heading": [0, 1]})
     with pytest.raises(_capi.MGError):
