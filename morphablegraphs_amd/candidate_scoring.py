@@ -24,7 +24,7 @@ def constraints_to_device_form(constraints, root_joint=None):
     """Accepts either ready dicts {"type","t","weight","target"[,"ref_dir"]} or reference-shaped
     constraint objects: Direction2DConstraint (target_dir), GlobalTransformConstraint (position and / or
     orientation of a joint), RelativeTransformConstraint (position of a point given in a joint's frame),
-    TwoHandConstraint (positions + joint_names), LookAtConstraint (target_position).  One reference constraint may become
+    TwoHandConstraintSet (positions + joint_names), LookAtConstraint (target_position), FeetConstraint (left, right).  One reference constraint may become
     several device constraints; "group" numbers the reference constraint's residual entry they add up to (a
     GlobalTransformConstraint is ONE residual = position error + orientation error, a TwoHandConstraint three,
     two_hand_constraint.py:66-74), see `group_residuals`."""
@@ -52,6 +52,13 @@ def constraints_to_device_form(constraints, root_joint=None):
             out.append({"type": "joint_position", "t": t, "weight": w, "target": [float(v) for v in p1], "joint": c.joint_names[1],
                         "group": group + 2})
             group += 3
+        elif hasattr(c, "left") and hasattr(c, "right"):                          # FeetConstraint (feet_constraint.py:47-51)
+            # its residuals carry weight_factor already and MotionPrimitiveConstraints.evaluate multiplies once more;
+            # get_residual_vector_spline is the single entry [left + right]
+            for joint, target in (("LeftFoot", c.left), ("RightFoot", c.right)):
+                out.append({"type": "joint_position", "t": t, "weight": w * w, "target": [float(v) for v in target], "joint": joint,
+                            "group": group})
+            group += 1
         elif hasattr(c, "target_position") and not hasattr(c, "position"):      # LookAtConstraint (look_at_constraint.py:37-43)
             head = getattr(getattr(c, "skeleton", None), "head_joint", getattr(c, "joint_name", "Head"))
             out.append({"type": "look_at", "t": t, "weight": w, "target": [float(v) for v in c.target_position], "joint": head,

@@ -167,6 +167,13 @@ def test_constraint_conversion_accepts_reference_shaped_objects():
         canonical_keyframe, weight_factor, joint_name = 40, 1.0, "Head"
         target_position = np.array([1.0, 2.0, 3.0])
 
+    class Feet(object):         # FeetConstraint: weight applied inside AND by the caller, one residual entry
+        canonical_keyframe, weight_factor = 11, 2.0
+        left, right = np.array([1.0, 0.0, 2.0]), np.array([-1.0, 0.0, 2.0])
+
+    out = constraints_to_device_form([Feet()])
+    assert [(c["joint"], c["weight"], c["group"], c["target"]) for c in out] == [("LeftFoot", 4.0, 0, [1.0, 0.0, 2.0]), ("RightFoot", 4.0, 0, [-1.0, 0.0, 2.0])]
+
     out = constraints_to_device_form([Relative(), LookAt()])
     assert out[0] == {"type": "joint_position", "t": 30.0, "weight": 1.0, "target": [4.0, 5.0, 6.0], "joint": "RightHand",
                       "offset": [0.0, -3.0, 12.0], "group": 0}
