@@ -267,6 +267,14 @@ int mg_constraint_set_create_fk(mg_primitive *prim, const mg_skeleton_desc *skel
 int mg_constraint_set_create_aligned(mg_primitive *prim, const mg_skeleton_desc *skeleton,
                                      const mg_keyframe_constraint *cons, int32_t n,
                                      const mg_alignment_desc *alignment, mg_constraint_set **out);
+/* New targets, weights and reference vectors -- and a new previous frame for the alignment -- for a set whose
+ * STRUCTURE stays the same: the same types, joints, keyframes and relative points in the same order, alignment to
+ * the same joint (or none).  That is a planner's situation: every step it scores the same kind of constraints with
+ * new goals and a new previous motion (graph_walk_planner.py:155-214).  Stream ordered (launches scored before
+ * the call see the old values, later ones the new), one small launch, no allocation, no synchronisation;
+ * building a new set costs about 200 us, this a few.  MG_ERR_INVALID_ARGUMENT if the structure differs. */
+int mg_constraint_set_update(mg_constraint_set *cs, const mg_keyframe_constraint *cons, int32_t n,
+                             const mg_alignment_desc *alignment);
 void mg_constraint_set_destroy(mg_constraint_set *cs);
 int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
                          const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,

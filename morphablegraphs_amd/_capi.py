@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
-    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_best_candidate", "mg_best_candidate_host",
+    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
     "mg_option_step",
 ]
 
@@ -209,6 +209,7 @@ def load_library(path=None):
         "mg_score_constraint_residuals": [vp, vp, vp, i32, i64, i64, vp],
         "mg_constraint_set_create_fk": [vp, vp, vp, i32, vp],
         "mg_constraint_set_create_aligned": [vp, vp, vp, i32, vp, vp],
+        "mg_constraint_set_update": [vp, vp, i32, vp],
         "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_option_step": [vp, vp, i64, vp, u64, vp, i32, i64, vp, vp],
@@ -399,6 +400,43 @@ class ConstraintSet(object):
         self.skeleton = skeleton
         self.alignment = alignment
         n = len(constraints)
+        arr = self._marshal(constraints, skeleton)
+        h = C.c_void_p()
+        if alignment is not None:
+            al = self._marshal_alignment(alignment, skeleton)
+            d = skeleton.desc() if skeleton is not None else None
+            _check(prim.lib.mg_constraint_set_create_aligned(prim.handle, C.byref(d) if d is not None else None,
+                                                             C.cast(arr, C.c_void_p), n, C.byref(al), C.byref(h)))
+        elif skeleton is None:
+            _check(prim.lib.mg_constraint_set_create(prim.handle, C.cast(arr, C.c_void_p), n, C.byref(h)))
+        else:
+            d = skeleton.desc()
+            _check(prim.lib.mg_constraint_set_create_fk(prim.handle, C.byref(d), C.cast(arr, C.c_void_p), n, C.byref(h)))
+        self.handle = h
+        self.n = n
+
+    def update(self, constraints, alignment=None):
+        """New targets / weights / previous frame for the same STRUCTURE (types, joints, keyframes, relative points,
+        aligning joint): one small stream-ordered launch instead of a new set (mg_constraint_set_update)."""
+        arr = self._marshal(constraints, self.skeleton)
+        al = self._marshal_alignment(alignment, self.skeleton) if alignment is not None else None
+        _check(self.prim.lib.mg_constraint_set_update(self.handle, C.cast(arr, C.c_void_p), len(constraints),
+                                                      C.byref(al) if al is not None else None))
+        self.alignment = alignment
+
+    @staticmethod
+    def _marshal_alignment(alignment, skeleton):
+        al = AlignmentDesc()
+        al.joint = int(alignment.get("joint", 0)) if skeleton is None else skeleton.index(alignment.get("joint", 0))
+        for a in range(3):
+            al.position[a] = float(alignment["position"][a])
+            al.ref_dir[a] = float(alignment.get("ref_dir", (0.0, 0.0, 1.0))[a])
+        al.heading[0], al.heading[1] = float(alignment["heading"][0]), float(alignment["heading"][1])
+        return al
+
+    @staticmethod
+    def _marshal(constraints, skeleton):
+        n = len(constraints)
         arr = (KeyframeConstraint * max(n, 1))()
         for i, c in enumerate(constraints):
             k = arr[i]
@@ -453,24 +491,7 @@ class ConstraintSet(object):
                     k.ref_dir[a] = float(rd[a])
             else:
                 raise ValueError("unknown constraint type %r" % (c["type"],))
-        h = C.c_void_p()
-        if alignment is not None:
-            al = AlignmentDesc()
-            al.joint = int(alignment.get("joint", 0)) if skeleton is None else skeleton.index(alignment.get("joint", 0))
-            for a in range(3):
-                al.position[a] = float(alignment["position"][a])
-                al.ref_dir[a] = float(alignment.get("ref_dir", (0.0, 0.0, 1.0))[a])
-            al.heading[0], al.heading[1] = float(alignment["heading"][0]), float(alignment["heading"][1])
-            d = skeleton.desc() if skeleton is not None else None
-            _check(prim.lib.mg_constraint_set_create_aligned(prim.handle, C.byref(d) if d is not None else None,
-                                                             C.cast(arr, C.c_void_p), n, C.byref(al), C.byref(h)))
-        elif skeleton is None:
-            _check(prim.lib.mg_constraint_set_create(prim.handle, C.cast(arr, C.c_void_p), n, C.byref(h)))
-        else:
-            d = skeleton.desc()
-            _check(prim.lib.mg_constraint_set_create_fk(prim.handle, C.byref(d), C.cast(arr, C.c_void_p), n, C.byref(h)))
-        self.handle = h
-        self.n = n
+        return arr
 
     def close(self):
         # the C object points at its primitive and context: never touch it after either of them has been destroyed

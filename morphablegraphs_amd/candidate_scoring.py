@@ -134,28 +134,42 @@ def alignment_from_prev_frames(prev_frames, constraints=None, skeleton=None):
     return skeleton.alignment_to(last, 0 if node is None else node, ref_dir)
 
 
-def _constraint_key(prim, clist, skeleton, alignment=None):
-    def freeze(v):
-        if isinstance(v, dict):
-            return tuple(sorted((k, freeze(x)) for k, x in v.items()))
-        if isinstance(v, (list, tuple, np.ndarray)):
-            return tuple(freeze(x) for x in v)
-        return v
-    return (id(prim), prim.handle.value, id(skeleton), freeze(clist), freeze(alignment) if alignment is not None else None)
+def _freeze(v):
+    if isinstance(v, dict):
+        return tuple(sorted((k, _freeze(x)) for k, x in v.items()))
+    if isinstance(v, (list, tuple, np.ndarray)):
+        return tuple(_freeze(x) for x in v)
+    return v
+
+
+def _structure_key(prim, clist, skeleton, alignment=None):
+    """What a device set is built from and cannot change afterwards: per constraint its type, keyframe, joints and
+    relative point, plus the aligning joint.  Targets, weights, reference vectors and the previous frame are values
+    (ConstraintSet.update)."""
+    items = tuple((c["type"], float(c["t"]), _freeze(c.get("joint")), _freeze(c.get("joint2")), _freeze(c.get("offset")))
+                  for c in clist)
+    return (id(prim), prim.handle.value, id(skeleton), items, None if alignment is None else _freeze(alignment.get("joint", 0)))
 
 
 def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
-    """A device constraint set for these (device-form) constraints, reused across calls: a graph walk or an
-    optimizer evaluates the same constraints again and again, and building a set uploads its fused matrices."""
-    key = _constraint_key(prim, clist, skeleton, alignment)
+    """A device constraint set for these (device-form) constraints, reused across calls.  An optimizer evaluates the
+    same constraints again and again (same values: nothing to do); a planner scores the same KIND of constraints with
+    new goals and a new previous frame every step (same structure: the values are rewritten by one small launch,
+    ConstraintSet.update, instead of building a new set, which costs about 200 us)."""
+    key = _structure_key(prim, clist, skeleton, alignment)
+    values = (_freeze(clist), _freeze(alignment) if alignment is not None else None)
     for i in range(len(_CSET_CACHE) - 1, -1, -1):   # entries whose primitive has been closed meanwhile are dropped
         if not (_CSET_CACHE[i][1].handle and _CSET_CACHE[i][1].prim.handle and _CSET_CACHE[i][1].prim.ctx.handle):
             _CSET_CACHE.pop(i)
     for i, (k, cs) in enumerate(_CSET_CACHE):
         if k == key:
             _CSET_CACHE.append(_CSET_CACHE.pop(i))
+            if cs.cached_values != values:
+                cs.update(clist, alignment)
+                cs.cached_values = values
             return cs
     cs = _capi.ConstraintSet(prim, clist, skeleton, alignment)
+    cs.cached_values = values
     _CSET_CACHE.append((key, cs))
     while len(_CSET_CACHE) > _CSET_CACHE_SIZE:
         _CSET_CACHE.pop(0)[1].close()

@@ -1062,8 +1062,51 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
         if (rc == MG_OK) rc = mg_upload(p->ctx, bpad, &cs->d_bpad);
     }
     if (rc != MG_OK) { mg_constraint_set_destroy(cs); return rc; }
+    cs->structure.assign(cons, cons + n);
+    cs->align_joint = al ? al->joint : -1;
     *out = cs;
     return MG_OK;
+}
+
+extern "C" int mg_constraint_set_update(mg_constraint_set *cs, const mg_keyframe_constraint *cons, int32_t n, const mg_alignment_desc *al) {
+    MG_REQUIRE(cs && cs->prim && n >= 0 && (n == 0 || cons), "mg_constraint_set_update: bad arguments");
+    MG_REQUIRE(n == cs->n, "mg_constraint_set_update: %d constraints, the set was built for %d", n, cs->n);
+    MG_REQUIRE((al != nullptr) == (cs->d_align != nullptr) && (!al || al->joint == cs->align_joint),
+               "mg_constraint_set_update: the alignment (none / aligning joint) differs from the one the set was built with");
+    for (int c = 0; c < n; c++) {
+        const mg_keyframe_constraint &o = cs->structure[c], &v = cons[c];
+        bool same = o.type == v.type && o.canonical_keyframe == v.canonical_keyframe;
+        if (same && v.type >= MG_CONSTRAINT_JOINT_POSITION) same = o.joint == v.joint;
+        if (same && v.type == MG_CONSTRAINT_JOINT_MIDPOINT) same = o.joint2 == v.joint2;
+        if (same && v.type == MG_CONSTRAINT_JOINT_POSITION)   // a relative point is one more link of the chain, stored with the set
+            same = o.ref_dir[0] == v.ref_dir[0] && o.ref_dir[1] == v.ref_dir[1] && o.ref_dir[2] == v.ref_dir[2];
+        MG_REQUIRE(same, "mg_constraint_set_update: constraint %d differs in type, joint, keyframe or relative point", c);
+        if (v.type == MG_CONSTRAINT_JOINT_ORIENTATION || v.type == MG_CONSTRAINT_LOOK_AT) {
+            const double rn = v.ref_dir[0] * v.ref_dir[0] + v.ref_dir[1] * v.ref_dir[1] + v.ref_dir[2] * v.ref_dir[2];
+            const double tn = v.target[0] * v.target[0] + v.target[1] * v.target[1] + v.target[2] * v.target[2];
+            MG_REQUIRE(std::isfinite(rn) && rn > 0.0 && std::isfinite(tn) && (tn > 0.0 || v.type == MG_CONSTRAINT_LOOK_AT),
+                       "mg_constraint_set_update: constraint %d: zero or non-finite target / reference vector", c);
+        }
+    }
+    std::vector<double> values((size_t)n * 8 + 7, 0.0);   // par [n][8], then entries 1..7 of the alignment record
+    for (int c = 0; c < n; c++) {
+        double *q = &values[(size_t)c * 8];
+        q[0] = (double)cons[c].type; q[1] = cons[c].weight_factor;
+        for (int i = 0; i < 3; i++) { q[2 + i] = cons[c].target[i]; q[5 + i] = cons[c].ref_dir[i]; }
+    }
+    if (al) {
+        const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
+        MG_REQUIRE(std::isfinite(hn) && hn > 0.0 && std::isfinite(al->position[0]) && std::isfinite(al->position[2]),
+                   "mg_constraint_set_update: previous heading / position not finite or zero");
+        double *q = &values[(size_t)n * 8];
+        q[0] = al->heading[0] / hn; q[1] = al->heading[1] / hn; q[2] = al->position[0]; q[3] = al->position[2];
+        q[4] = al->ref_dir[0]; q[5] = al->ref_dir[1]; q[6] = al->ref_dir[2];
+    }
+    { int rc = mg_use_device(cs->prim->ctx); if (rc != MG_OK) return rc; }
+    // entry 0 of the alignment record, the chain length, is structure and stays
+    int rc = mg_launch_set_params(cs->prim->ctx, values.data(), n * 8, al ? 7 : 0, cs->d_par, al ? cs->d_align + 1 : nullptr);
+    if (rc == MG_OK) cs->structure.assign(cons, cons + n);
+    return rc;
 }
 extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
                                            int32_t n, mg_constraint_set **out) {

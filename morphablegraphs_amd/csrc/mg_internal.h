@@ -143,6 +143,8 @@ struct mg_constraint_set {
     double *d_Wpack = nullptr;  // [RT][KK][64] MFMA B fragments of W (n_components <= 64), RT = ceil(rows / 16)
     double *d_bpad = nullptr;   // [RT*16] bias, zero padded
     int32_t RT = 0;
+    std::vector<mg_keyframe_constraint> structure;   // what mg_constraint_set_update must find unchanged
+    int32_t align_joint = -1;   // -1: local mode
     double *d_align = nullptr;  // [8] chain length, previous heading (x, z), previous root (x, z), ref_dir; NULL = local mode;
                                 // its rows (first control point: root xyz, then the chain's quaternions) start at woff[n]
 };
@@ -156,6 +158,7 @@ int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64
 #define MG_SAMPLE_ARG_K 16   // mixtures up to this size pass their prefix sums to the sampler as a kernel argument
 int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
 bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p);
+int mg_launch_set_params(mg_context *ctx, const double *values, int n_par, int n_align, double *d_par, double *d_align);
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res);
 int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld, int L, void *result_dev);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);

@@ -5,6 +5,7 @@
 // MotionPrimitiveConstraints.evaluate (reference .../constraints/motion_primitive_constraints.py:100-122)
 // for root-joint position / 2-D direction constraints, and its first-minimum argmin.
 #include "mg_internal.h"
+#include <cstring>
 #include "mg_gmm_device.h"
 
 struct mg_score_args {
@@ -361,6 +362,29 @@ int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *la
     else if (lf) hipLaunchKernelGGL((mg_score_kernel<true, false>), dim3((int)grid), dim3(MG_SC_CANDS * MG_SC_WAVES), lds, st, a);
     else if (of) hipLaunchKernelGGL((mg_score_kernel<false, true>), dim3((int)grid), dim3(MG_SC_CANDS * MG_SC_WAVES), lds, st, a);
     else hipLaunchKernelGGL((mg_score_kernel<false, false>), dim3((int)grid), dim3(MG_SC_CANDS * MG_SC_WAVES), lds, st, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// New constraint parameters for an existing set (mg_constraint_set_update): the values travel as kernel arguments,
+// so the call needs neither a staging buffer that outlives it nor a synchronisation, and is ordered on the stream
+// between the launches that read the old values and those that read the new.
+#define MG_SET_PARAMS_MAX 496   // doubles; kernel arguments are limited to 4 KB
+struct mg_set_params_args { double v[MG_SET_PARAMS_MAX]; };
+__global__ __launch_bounds__(64) void mg_set_params_kernel(mg_set_params_args a, int n_par, int n_align, double *par, double *align) {
+    for (int i = threadIdx.x; i < n_par; i += 64) par[i] = a.v[i];
+    for (int i = threadIdx.x; i < n_align; i += 64) align[i] = a.v[n_par + i];
+}
+int mg_launch_set_params(mg_context *ctx, const double *values, int n_par, int n_align, double *d_par, double *d_align) {
+    if (n_par + n_align > MG_SET_PARAMS_MAX) {   // more than 60 constraints: plain copies behind a synchronisation
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (n_par) MG_HIP_CHECK(hipMemcpy(d_par, values, (size_t)n_par * 8, hipMemcpyHostToDevice));
+        if (n_align) MG_HIP_CHECK(hipMemcpy(d_align, values + n_par, (size_t)n_align * 8, hipMemcpyHostToDevice));
+        return MG_OK;
+    }
+    mg_set_params_args a;
+    memcpy(a.v, values, (size_t)(n_par + n_align) * 8);
+    hipLaunchKernelGGL(mg_set_params_kernel, dim3(1), dim3(64), 0, ctx->stream, a, n_par, n_align, d_par, d_align);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

@@ -787,3 +787,77 @@ def test_relative_point_and_look_at_constraints(ctx, monkeypatch):
         np.testing.assert_allclose(pr.score_constraints(cs, np.zeros((2, pr.n_components))), expect, rtol=1e-12, atol=1e-7, err_msg=str(c))
         cs.close()
     pr.close()
+
+
+def test_constraint_set_update_keeps_the_structure_and_swaps_the_values(ctx):
+    """mg_constraint_set_update: new targets / weights / previous frame for a set of the same structure, stream
+    ordered and without a new allocation.  Results must be those of a freshly built set, bit for bit; a launch
+    enqueued before the update keeps the old values; a different structure is refused; more than 60 constraints
+    take the copying path."""
+    from morphablegraphs_amd.candidate_scoring import cached_constraint_set, clear_constraint_cache
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    rng = np.random.default_rng(23)
+    S = rng.standard_normal((333, 40))
+    prev_a, prev_b = np.zeros(79), np.zeros(79)
+    prev_a[3::4][:19], prev_b[3::4][:19] = 1.0, 1.0
+    prev_a[:7] = [10.0, 90.0, 20.0, 0.9, 0.0, 0.4, 0.0]
+    prev_b[:7] = [-40.0, 91.0, 5.0, 0.3, 0.1, -0.9, 0.0]
+
+    def cons(k):
+        return [{"type": "position", "t": 155.0, "weight": 1.0 + k, "target": [40.0 + 7 * k, None, -30.0 - k]},
+                {"type": "direction", "t": 155.0, "weight": 0.5, "target": [0.5 + k, 1.0]},
+                {"type": "joint_position", "joint": "LeftHand", "t": 80.0, "weight": 1.0, "target": [30.0, 95.0 + k, 10.0]},
+                {"type": "joint_orientation", "joint": "Head", "t": 33.0, "weight": 2.0, "orientation": [0.9, 0.1 * k, -0.3, 0.2]},
+                {"type": "look_at", "joint": "Head", "t": 50.0, "weight": 1.0, "target": [50.0 * k, 150.0, 400.0]}]
+    fresh_a = _capi.ConstraintSet(prim, cons(0), sk, alignment=sk.alignment_to(prev_a, "Hips"))
+    fresh_b = _capi.ConstraintSet(prim, cons(1), sk, alignment=sk.alignment_to(prev_b, "Hips"))
+    ra, rb = prim.score_constraint_residuals(fresh_a, S), prim.score_constraint_residuals(fresh_b, S)
+    assert np.abs(ra - rb).max() > 1.0
+    cs = _capi.ConstraintSet(prim, cons(0), sk, alignment=sk.alignment_to(prev_a, "Hips"))
+    # enqueue a scoring with the old values, update, enqueue one with the new values, only then read both back
+    d_S, d_e0, d_e1 = ctx.upload(S), ctx.malloc(len(S) * 8), ctx.malloc(len(S) * 8)
+    prim.score_constraints_dev(cs, d_S, np.float64, len(S), 40, d_e0, np.float64)
+    cs.update(cons(1), sk.alignment_to(prev_b, "Hips"))
+    prim.score_constraints_dev(cs, d_S, np.float64, len(S), 40, d_e1, np.float64)
+    np.testing.assert_array_equal(ctx.download(d_e0, (len(S),), np.float64), prim.score_constraints(fresh_a, S))
+    np.testing.assert_array_equal(ctx.download(d_e1, (len(S),), np.float64), prim.score_constraints(fresh_b, S))
+    np.testing.assert_array_equal(prim.score_constraint_residuals(cs, S), rb)
+    cs.update(cons(0), sk.alignment_to(prev_a, "Hips"))
+    np.testing.assert_array_equal(prim.score_constraint_residuals(cs, S), ra)
+    for bad, al in ((cons(0)[:4], sk.alignment_to(prev_a, "Hips")),                                  # fewer constraints
+                    ([dict(cons(0)[0], t=154.0)] + cons(0)[1:], sk.alignment_to(prev_a, "Hips")),    # another keyframe
+                    (cons(0)[:2] + [dict(cons(0)[2], joint="RightHand")] + cons(0)[3:], sk.alignment_to(prev_a, "Hips")),
+                    (cons(0)[:2] + [dict(cons(0)[2], offset=[0.0, 1.0, 0.0])] + cons(0)[3:], sk.alignment_to(prev_a, "Hips")),
+                    (cons(0), None),                                                                 # alignment dropped
+                    (cons(0), sk.alignment_to(prev_a, "Spine"))):                                    # another aligning joint
+        with pytest.raises(_capi.MGError):
+            cs.update(bad, al)
+    np.testing.assert_array_equal(prim.score_constraint_residuals(cs, S), ra)                         # refused updates change nothing
+    for c in (cs, fresh_a, fresh_b):
+        c.close()
+
+    # the cache hands out ONE set per structure and rewrites its values
+    clear_constraint_cache()
+    c0 = cached_constraint_set(prim, cons(0), sk, sk.alignment_to(prev_a, "Hips"))
+    r0 = prim.score_constraint_residuals(c0, S)
+    c1 = cached_constraint_set(prim, cons(1), sk, sk.alignment_to(prev_b, "Hips"))
+    assert c1 is c0
+    np.testing.assert_array_equal(prim.score_constraint_residuals(c1, S), rb)
+    np.testing.assert_array_equal(r0, ra)
+    c2 = cached_constraint_set(prim, cons(1), sk, None)                                               # local mode: another structure
+    assert c2 is not c0
+    clear_constraint_cache()
+
+    # 70 constraints: the values no longer fit kernel arguments
+    many = [{"type": "position", "t": float(i), "weight": 1.0, "target": [float(i), None, 1.0]} for i in range(70)]
+    many2 = [dict(c, target=[c["target"][0] + 3.0, 2.0, None]) for c in many]
+    cs = _capi.ConstraintSet(prim, many)
+    cs.update(many2)
+    ref = _capi.ConstraintSet(prim, many2)
+    np.testing.assert_array_equal(prim.score_constraint_residuals(cs, S[:40]), prim.score_constraint_residuals(ref, S[:40]))
+    cs.close()
+    ref.close()
+    prim.close()
