@@ -158,6 +158,13 @@ int mg_context_set_stream(mg_context *ctx, void *stream);
 /* The persistent frames kernel normally occupies every CU (one workgroup each, all of its LDS); leave n CUs free
  * so that kernels on other streams -- RCCL's all-gather of the scores -- run beside it instead of behind it. */
 int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
+/* Between _begin and _end every device constant the library uploads for this context (primitives and their
+ * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
+ * (0 = 64 MiB) instead of one hipMalloc each; a block is released when the last array in it has been destroyed
+ * (or with the context).  mg_context_arena_bytes reports (reserved, used). */
+int mg_context_arena_begin(mg_context *ctx, int64_t block_bytes);
+int mg_context_arena_end(mg_context *ctx);
+int mg_context_arena_bytes(mg_context *ctx, int64_t *reserved, int64_t *used);
 int mg_context_synchronize(mg_context *ctx);
 /* name (256 bytes), CU count, total bytes of the context's device */
 int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *total_mem);

@@ -25,7 +25,7 @@ PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin
 # every symbol include/mg_hip.h declares (tests check the built library exports them all)
 EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
-    "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_synchronize",
+    "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
     "mg_context_device_info", "mg_device_malloc", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_get_precisions_cholesky",
@@ -173,6 +173,9 @@ def load_library(path=None):
         "mg_context_create": [i32, vp, C.POINTER(vp)],
         "mg_context_set_stream": [vp, vp],
         "mg_context_set_reserved_cus": [vp, i32],
+        "mg_context_arena_begin": [vp, i64],
+        "mg_context_arena_end": [vp],
+        "mg_context_arena_bytes": [vp, C.POINTER(i64), C.POINTER(i64)],
         "mg_context_synchronize": [vp],
         "mg_context_device_info": [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(i64)],
         "mg_device_malloc": [vp, i64, C.POINTER(vp)],
@@ -275,6 +278,18 @@ class Context(object):
     def set_reserved_cus(self, n):
         """Leave n CUs free of the persistent frames kernel (for RCCL kernels running beside it)."""
         _check(self.lib.mg_context_set_reserved_cus(self.handle, int(n)))
+
+    def arena_begin(self, block_bytes=0):
+        """Until arena_end(), device constants of new primitives come out of shared blocks (one graph, one arena)."""
+        _check(self.lib.mg_context_arena_begin(self.handle, int(block_bytes)))
+
+    def arena_end(self):
+        _check(self.lib.mg_context_arena_end(self.handle))
+
+    def arena_bytes(self):
+        r, u = C.c_int64(0), C.c_int64(0)
+        _check(self.lib.mg_context_arena_bytes(self.handle, C.byref(r), C.byref(u)))
+        return int(r.value), int(u.value)
 
     def synchronize(self):
         _check(self.lib.mg_context_synchronize(self.handle))

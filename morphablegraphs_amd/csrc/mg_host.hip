@@ -105,6 +105,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     for (auto &ev : ctx->free_events) (void)hipEventDestroy(ev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
+    for (auto &b : ctx->arena) (void)hipFree(b.base);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -121,6 +122,55 @@ extern "C" int mg_context_set_stream(mg_context *ctx, void *stream) {
         ctx->own_stream = true;
     }
     return MG_OK;
+}
+
+extern "C" int mg_context_arena_begin(mg_context *ctx, int64_t block_bytes) {
+    MG_REQUIRE(ctx != nullptr && block_bytes >= 0, "mg_context_arena_begin: bad arguments");
+    ctx->arena_block_bytes = block_bytes > 0 ? (size_t)block_bytes : ((size_t)64 << 20);
+    return MG_OK;
+}
+extern "C" int mg_context_arena_end(mg_context *ctx) {
+    MG_REQUIRE(ctx != nullptr, "mg_context_arena_end: ctx is NULL");
+    ctx->arena_block_bytes = 0;
+    return MG_OK;
+}
+extern "C" int mg_context_arena_bytes(mg_context *ctx, int64_t *reserved, int64_t *used) {
+    MG_REQUIRE(ctx != nullptr, "mg_context_arena_bytes: ctx is NULL");
+    int64_t r = 0, u = 0;
+    for (auto &b : ctx->arena) { r += (int64_t)b.bytes; u += (int64_t)b.used; }
+    if (reserved) *reserved = r;
+    if (used) *used = u;
+    return MG_OK;
+}
+static int mg_arena_alloc(mg_context *ctx, size_t bytes, void **out) {
+    const size_t need = (bytes + 255) / 256 * 256;   // every array starts on a 256-byte boundary
+    if (ctx->arena.empty() || ctx->arena.back().used + need > ctx->arena.back().bytes) {
+        mg_context::arena_block b;
+        b.bytes = std::max(ctx->arena_block_bytes, need);
+        b.used = 0;
+        b.live = 0;
+        MG_HIP_CHECK(hipMalloc((void **)&b.base, b.bytes));
+        ctx->arena.push_back(b);
+    }
+    *out = ctx->arena.back().base + ctx->arena.back().used;
+    ctx->arena.back().used += need;
+    ctx->arena.back().live++;
+    return MG_OK;
+}
+void mg_dev_free(mg_context *ctx, void *p) {
+    if (!p) return;
+    for (size_t i = 0; i < ctx->arena.size(); i++) {
+        mg_context::arena_block &b = ctx->arena[i];
+        if ((char *)p >= b.base && (char *)p < b.base + b.bytes) {
+            // the last array of a block that is no longer being filled takes the block with it
+            if (--b.live == 0 && !(ctx->arena_block_bytes > 0 && i + 1 == ctx->arena.size())) {
+                (void)hipFree(b.base);
+                ctx->arena.erase(ctx->arena.begin() + (long)i);
+            }
+            return;
+        }
+    }
+    (void)hipFree(p);
 }
 
 extern "C" int mg_context_synchronize(mg_context *ctx) {
@@ -307,7 +357,12 @@ template <typename T>
 static int mg_upload(mg_context *ctx, const std::vector<T> &h, T **d) {
     *d = nullptr;
     size_t bytes = std::max<size_t>(h.size() * sizeof(T), 16);
-    MG_HIP_CHECK(hipMalloc((void **)d, bytes));
+    if (ctx->arena_block_bytes > 0) {
+        int rc = mg_arena_alloc(ctx, bytes, (void **)d);
+        if (rc != MG_OK) return rc;
+    } else {
+        MG_HIP_CHECK(hipMalloc((void **)d, bytes));
+    }
     if (!h.empty()) MG_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return MG_OK;
 }
@@ -316,12 +371,13 @@ static int mg_upload(mg_context *ctx, const std::vector<T> &h, T **d) {
 // time grids
 // ---------------------------------------------------------------------------------------
 static void mg_free_grid_device(mg_time_grid *g) {
-    if (g->d_i0) (void)hipFree(g->d_i0);
-    if (g->d_w) (void)hipFree(g->d_w);
-    if (g->d_w32) (void)hipFree(g->d_w32);
-    if (g->d_wtap) (void)hipFree(g->d_wtap);
+    mg_context *ctx = g->prim->ctx;
+    mg_dev_free(ctx, g->d_i0);
+    mg_dev_free(ctx, g->d_w);
+    mg_dev_free(ctx, g->d_w32);
+    mg_dev_free(ctx, g->d_wtap);
     g->d_wtap = nullptr;
-    if (g->d_chunks) (void)hipFree(g->d_chunks);
+    mg_dev_free(ctx, g->d_chunks);
     g->d_i0 = nullptr; g->d_w = nullptr; g->d_w32 = nullptr; g->d_chunks = nullptr;
 }
 
@@ -476,8 +532,7 @@ static void mg_primitive_free(mg_primitive *p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean,
                     p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad, p->d_gPTpack, p->d_gcholpack, p->d_gmeanpad};
-    for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+    for (void *q : ptrs) mg_dev_free(p->ctx, q);
     for (mg_time_grid *g : {p->canonical, p->coeff_grid})
         if (g) { mg_free_grid_device(g); delete g; }
     delete p;
@@ -1118,15 +1173,15 @@ extern "C" int mg_constraint_set_create(mg_primitive *p, const mg_keyframe_const
 extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
     if (!cs) return;
     if (cs->prim) (void)hipStreamSynchronize(cs->prim->ctx->stream);
-    if (cs->d_W) (void)hipFree(cs->d_W);
-    if (cs->d_bias) (void)hipFree(cs->d_bias);
-    if (cs->d_par) (void)hipFree(cs->d_par);
-    if (cs->d_woff) (void)hipFree(cs->d_woff);
-    if (cs->d_chain) (void)hipFree(cs->d_chain);
-    if (cs->d_choff) (void)hipFree(cs->d_choff);
-    if (cs->d_Wpack) (void)hipFree(cs->d_Wpack);
-    if (cs->d_bpad) (void)hipFree(cs->d_bpad);
-    if (cs->d_align) (void)hipFree(cs->d_align);
+    mg_dev_free(cs->prim->ctx, cs->d_W);
+    mg_dev_free(cs->prim->ctx, cs->d_bias);
+    mg_dev_free(cs->prim->ctx, cs->d_par);
+    mg_dev_free(cs->prim->ctx, cs->d_woff);
+    mg_dev_free(cs->prim->ctx, cs->d_chain);
+    mg_dev_free(cs->prim->ctx, cs->d_choff);
+    mg_dev_free(cs->prim->ctx, cs->d_Wpack);
+    mg_dev_free(cs->prim->ctx, cs->d_bpad);
+    mg_dev_free(cs->prim->ctx, cs->d_align);
     delete cs;
 }
 

@@ -50,7 +50,12 @@ struct mg_context {
     void *scratch = nullptr;
     int64_t scratch_bytes = 0;
     void *argmin_out = nullptr;  // 16 bytes device
+    // device arena for long-lived constants (mg_context_arena_begin/_end): blocks are bump-allocated, freed with the context
+    struct arena_block { char *base; size_t bytes, used; int64_t live; };   // live: arrays handed out and not yet freed
+    std::vector<arena_block> arena;
+    size_t arena_block_bytes = 0;   // > 0 while an arena section is open
 };
+void mg_dev_free(mg_context *ctx, void *p);   // hipFree unless p lives in the context's arena
 
 int mg_ctx_scratch(mg_context *ctx, int64_t bytes, void **out);
 void mg_prof_begin(mg_context *ctx, int slot);

@@ -150,22 +150,12 @@ class HipMotionStateGraph(object):
         return self.build_from_graph_data(read_graph_zip(path), recalculate_stats)
 
     def build_from_graph_data(self, graph_data, recalculate_stats=False):
-        for action_name, action_data in graph_data["subgraphs"].items():
-            group = {"name": action_data["name"], "info": action_data.get("info", {}), "nodes": []}
-            for mp_name, desc in action_data["nodes"].items():
-                if "spatial_coeffs" in desc["mm"]:
-                    continue   # static primitives carry no statistical model (motion_primitive_wrapper.py:61-66)
-                node = HipMotionStateGraphNode(group, context=self.ctx)
-                node.init_from_dict(action_data["name"], desc)
-                if "space_partition_json" in desc:
-                    node.cluster_tree = _StoredSamples(desc["space_partition_json"]["data"])
-                self.nodes[(action_data["name"], mp_name)] = node
-                group["nodes"].append(mp_name)
-            self._set_node_types(group)
-            self.node_groups[action_data["name"]] = group
-            idle = group["info"].get("idle_states", [])
-            if action_name == "walk" and len(idle) > 0:
-                self.start_node = (action_name, idle[0])
+        # every primitive of the graph lives in one device arena (a few 64 MiB blocks instead of ~20 allocations each)
+        self.ctx.arena_begin()
+        try:
+            self._build_nodes(graph_data)
+        finally:
+            self.ctx.arena_end()
         self._set_transitions_from_dict(graph_data.get("transitions", {}))
         for group in self.node_groups.values():
             stats = group["info"].get("stats", {})
@@ -184,6 +174,24 @@ class HipMotionStateGraph(object):
                 start_node[1] = start_node[1][5:]
             self.start_node = tuple(start_node)
         return self
+
+    def _build_nodes(self, graph_data):
+        for action_name, action_data in graph_data["subgraphs"].items():
+            group = {"name": action_data["name"], "info": action_data.get("info", {}), "nodes": []}
+            for mp_name, desc in action_data["nodes"].items():
+                if "spatial_coeffs" in desc["mm"]:
+                    continue   # static primitives carry no statistical model (motion_primitive_wrapper.py:61-66)
+                node = HipMotionStateGraphNode(group, context=self.ctx)
+                node.init_from_dict(action_data["name"], desc)
+                if "space_partition_json" in desc:
+                    node.cluster_tree = _StoredSamples(desc["space_partition_json"]["data"])
+                self.nodes[(action_data["name"], mp_name)] = node
+                group["nodes"].append(mp_name)
+            self._set_node_types(group)
+            self.node_groups[action_data["name"]] = group
+            idle = group["info"].get("idle_states", [])
+            if action_name == "walk" and len(idle) > 0:
+                self.start_node = (action_name, idle[0])
 
     def _set_node_types(self, group):
         keys = [(group["name"], n) for n in group["nodes"]]

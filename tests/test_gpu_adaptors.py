@@ -692,3 +692,44 @@ def test_cluster_tree_training_data_in_batches():
     np.testing.assert_allclose(motions, ref_m, rtol=1e-11, atol=1e-11 * max(1.0, np.abs(ref_m).max()))
     np.testing.assert_array_equal(sampler._extract_features(node, X), X[:, :40])
     assert sampler.sample_data(node).shape == (300, 40)
+
+
+def test_graph_primitives_share_one_device_arena(tmp_path):
+    """A graph's primitives are bump-allocated from shared arena blocks (one device arena per
+    graph); results are those of separately allocated primitives, bit for bit, and a block is released when its
+    last primitive goes."""
+    prims = synthetic.make_graph_primitives(5)
+    ctx = _capi.Context(0)
+    assert ctx.arena_bytes() == (0, 0)
+    ctx.arena_begin(8 << 20)
+    inside = [_capi.Primitive(ctx, p) for p in prims]
+    ctx.arena_end()
+    reserved, used = ctx.arena_bytes()
+    assert reserved >= used > 0 and reserved % (8 << 20) == 0
+    outside = [_capi.Primitive(ctx, p) for p in prims]
+    assert ctx.arena_bytes() == (reserved, used)                       # closed: later primitives allocate on their own
+    rng = np.random.default_rng(0)
+    for a, b in zip(inside, outside):
+        S = rng.standard_normal((40, a.n_components)).astype(np.float32)
+        np.testing.assert_array_equal(a.back_project_frames(S).view(np.uint32), b.back_project_frames(S).view(np.uint32))
+        np.testing.assert_array_equal(a.gmm_log_prob(S), b.gmm_log_prob(S))
+        cs_a = _capi.ConstraintSet(a, [{"type": "position", "t": 3.0, "weight": 1.0, "target": [1.0, None, 2.0]}])
+        cs_b = _capi.ConstraintSet(b, [{"type": "position", "t": 3.0, "weight": 1.0, "target": [1.0, None, 2.0]}])
+        np.testing.assert_array_equal(a.score_constraints(cs_a, S), b.score_constraints(cs_b, S))
+        cs_a.close()
+        cs_b.close()
+    for p in inside + outside:
+        p.close()
+    assert ctx.arena_bytes() == (0, 0)                                  # every block went with its last primitive
+    ctx.close()
+    # the graph loader uses it
+    from morphablegraphs_amd.motion_state_graph import HipMotionStateGraph
+    path = str(tmp_path / "graph.zip")
+    lists = [{k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in p.items()} for p in prims[:3]]
+    synthetic.write_graph_zip(path, {"walk": {"primitives": {"a": lists[0], "b": lists[1], "c": lists[2]}, "info": {}}})
+    gctx = _capi.Context(0)
+    graph = HipMotionStateGraph(context=gctx).load_from_zip(path)
+    assert gctx.arena_bytes()[1] > 0 and len(graph.nodes) == 3
+    graph.close()
+    assert gctx.arena_bytes() == (0, 0)
+    gctx.close()
