@@ -227,6 +227,30 @@ def main():
                 "step_algorithmic_bytes": bytes_launch,
                 "step_achieved_GBps": bytes_launch / (elapsed / args.steps) / 1e9,
             }
+            smp = np.sort(ctx.profile_samples("frames"))
+            if len(smp) >= 10:   # spread of the event-bracketed launches (median, p10 / p90)
+                result["roofline"].update({"kernel_ms_p10": float(smp[int(0.10 * (len(smp) - 1))]),
+                                           "kernel_ms_p50": float(smp[int(0.50 * (len(smp) - 1))]),
+                                           "kernel_ms_p90": float(smp[int(0.90 * (len(smp) - 1))])})
+        if world == 1:
+            # what the boundary costs when it hands over host buffers (never part of `value`): median of 20 copies
+            def med_us(fn):
+                ts = []
+                for _ in range(20):
+                    torch.cuda.synchronize(dev)
+                    t = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize(dev)
+                    ts.append(time.perf_counter() - t)
+                return 1e6 * float(np.median(ts))
+            pin_S = torch.from_numpy(S_host).pin_memory()
+            pin_lp = torch.empty((B,), dtype=torch.float32).pin_memory()
+            pin_fr = torch.empty((F, D), dtype=torch.float32).pin_memory()
+            result["transfers_us"] = {
+                "h2d_latents": med_us(lambda: S.copy_(pin_S, non_blocking=True)), "h2d_latents_bytes": int(S_host.nbytes),
+                "d2h_scores": med_us(lambda: pin_lp.copy_(logp, non_blocking=True)), "d2h_scores_bytes": 4 * B,
+                "d2h_winner_frames": med_us(lambda: pin_fr.copy_(frames[B // 2], non_blocking=True)), "d2h_winner_frames_bytes": 4 * F * D,
+            }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_baseline
             ref = cpu_baseline.reference_shaped_rate(data, S_host, budget_s=12.0, max_candidates=1 << 30)

@@ -184,6 +184,9 @@ int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);
 int mg_profile_enable(mg_context *ctx, int enabled);
 int mg_profile_reset(mg_context *ctx);
 int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64_t *launches);
+/* the individual durations (ms) behind mg_profile_get, oldest first, at most `capacity` of them (the library
+ * keeps the first 65536 per slot); *n = how many were written */
+int mg_profile_get_samples(mg_context *ctx, int slot, float *out_ms, int64_t capacity, int64_t *n);
 
 /* ---- primitive -------------------------------------------------------------------
  * Replaces MotionPrimitive._initialize_from_json (reference motion_primitive.py:96-163):

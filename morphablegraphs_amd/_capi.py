@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
     "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
     "mg_context_device_info", "mg_device_malloc", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
-    "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get",
+    "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_get_precisions_cholesky",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
@@ -186,6 +186,7 @@ def load_library(path=None):
         "mg_profile_enable": [vp, i32],
         "mg_profile_reset": [vp],
         "mg_profile_get": [vp, i32, C.POINTER(dbl), C.POINTER(i64)],
+        "mg_profile_get_samples": [vp, i32, vp, i64, C.POINTER(i64)],
         "mg_primitive_create": [vp, C.POINTER(PrimitiveDesc), C.POINTER(vp)],
         "mg_primitive_info": [vp, C.POINTER(C.c_int32)],
         "mg_primitive_get_precisions_cholesky": [vp, vp],
@@ -329,6 +330,14 @@ class Context(object):
         ms, n = C.c_double(), C.c_int64()
         _check(self.lib.mg_profile_get(self.handle, PROFILE_SLOTS.get(slot, slot), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_samples(self, slot, capacity=65536):
+        """The individual event-bracketed durations (ms) of a slot, oldest first."""
+        out = np.empty(int(capacity), dtype=np.float32)
+        n = C.c_int64()
+        _check(self.lib.mg_profile_get_samples(self.handle, PROFILE_SLOTS.get(slot, slot), out.ctypes.data_as(C.c_void_p),
+                                               int(capacity), C.byref(n)))
+        return out[:n.value].copy()
 
     def argmin_first(self, values_dev, n, dtype=np.float32):
         idx, val = C.c_int64(), C.c_double()

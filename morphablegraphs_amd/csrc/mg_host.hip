@@ -282,6 +282,7 @@ int mg_prof_resolve(mg_context *ctx) {
         if (p.ended && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             ctx->prof_ms[p.slot] += (double)ms;
             ctx->prof_n[p.slot] += 1;
+            if (ctx->prof_samples[p.slot].size() < 65536) ctx->prof_samples[p.slot].push_back(ms);
         }
         ctx->free_events.push_back(p.a);
         ctx->free_events.push_back(p.b);
@@ -300,7 +301,7 @@ extern "C" int mg_profile_enable(mg_context *ctx, int enabled) {
 extern "C" int mg_profile_reset(mg_context *ctx) {
     MG_REQUIRE(ctx != nullptr, "mg_profile_reset: ctx is NULL");
     (void)mg_prof_resolve(ctx);
-    for (int i = 0; i < MG_PROFILE_SLOTS; i++) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+    for (int i = 0; i < MG_PROFILE_SLOTS; i++) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; ctx->prof_samples[i].clear(); }
     return MG_OK;
 }
 extern "C" int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64_t *launches) {
@@ -308,6 +309,16 @@ extern "C" int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64
     (void)mg_prof_resolve(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[slot];
     if (launches) *launches = ctx->prof_n[slot];
+    return MG_OK;
+}
+extern "C" int mg_profile_get_samples(mg_context *ctx, int slot, float *out_ms, int64_t capacity, int64_t *n) {
+    MG_REQUIRE(ctx && slot >= 0 && slot < MG_PROFILE_SLOTS && capacity >= 0 && (capacity == 0 || out_ms) && n,
+               "mg_profile_get_samples: bad arguments");
+    (void)mg_prof_resolve(ctx);
+    const std::vector<float> &v = ctx->prof_samples[slot];
+    const int64_t m = std::min<int64_t>(capacity, (int64_t)v.size());
+    for (int64_t i = 0; i < m; i++) out_ms[i] = v[(size_t)i];
+    *n = m;
     return MG_OK;
 }
 

@@ -46,6 +46,7 @@ struct mg_context {
     int64_t prof_seen[MG_PROFILE_SLOTS] = {0};
     double prof_ms[MG_PROFILE_SLOTS] = {0};
     int64_t prof_n[MG_PROFILE_SLOTS] = {0};
+    std::vector<float> prof_samples[MG_PROFILE_SLOTS];   // individual durations, first 65536 per slot
     // scratch for host convenience variants / argmin
     void *scratch = nullptr;
     int64_t scratch_bytes = 0;
