@@ -255,12 +255,16 @@ def main():
             from oracle import cpu_baseline
             ref = cpu_baseline.reference_shaped_rate(data, S_host, budget_s=12.0, max_candidates=1 << 30)
             cport = cpu_baseline.c_port_rate(data, S_host, budget_s=5.0)
+            vec = cpu_baseline.vectorised_rate(data, S_host, budget_s=5.0)
             result["cpu_baseline"] = {
                 "value": ref["rate"], "unit": "samples/s", "cores": 1, "kind": "port",
                 "sample": "%d candidates drawn cyclically from the same batch, reference-shaped per-candidate loop "
                           "(numpy dot + 79x scipy splev + sklearn score_samples), %.1f s" % (ref["n"], ref["seconds"]),
                 "c_port_value": cport["rate"],
                 "c_port_sample": "%d candidates, plain-C float64 oracle (oracle/mg_oracle.c), 1 core, %.1f s" % (cport["n"], cport["seconds"]),
+                "vectorised_value": vec["rate"], "vectorised_cores": vec["threads"],
+                "vectorised_sample": "%d candidates, float32 GEMM (coefficients) + batched basis GEMM (frames materialised) + "
+                                     "batched sklearn score_samples, %d BLAS threads, %.1f s" % (vec["n"], vec["threads"], vec["seconds"]),
                 "host_cores_available": os.cpu_count(),
             }
         print(json.dumps(result))

@@ -73,3 +73,34 @@ def test_c_keyframe_errors_equal_numpy_oracle():
     # type-1 rows carry the reference direction in columns 5..7
     cons_c[2, 5:8] = [0.0, 0.0, 1.0]
     np.testing.assert_allclose(cp.keyframe_errors_f64(S, cons_c), po.keyframe_errors(S, cons_py), rtol=1e-10, atol=1e-10)
+
+
+def test_cpu_baselines_compute_the_same_step():
+    """bench.py's cpu_baseline legs are valid computations of the step, not strawmen: the reference-shaped loop, the
+    C port and the vectorised GEMM form run on a small model and a short budget, and the vectorised form's frames /
+    log p(x) agree with the float64 oracle to float32 accuracy."""
+    import numpy as np
+    from morphablegraphs_amd import synthetic
+    from oracle import cpu_baseline, c_oracle, mg_oracle as orc
+    data = synthetic.make_walk_primitive(seed=0)
+    S = np.random.default_rng(0).standard_normal((64, 40)).astype(np.float32)
+    for fn in (cpu_baseline.reference_shaped_rate, cpu_baseline.c_port_rate, cpu_baseline.vectorised_rate):
+        r = fn(data, S, budget_s=0.3)
+        assert r["n"] > 0 and r["rate"] > 0 and r["seconds"] > 0
+    # the vectorised form, restated on 8 rows, against the oracle
+    op = orc.OraclePrimitive(data)
+    nb, nd, F = 31, 79, 156
+    Et = np.array(data["eigen_vectors_spatial"], dtype=np.float64)
+    mean = np.array(data["mean_spatial_vector"], dtype=np.float64)
+    tm = np.array(data["translation_maxima"], dtype=np.float64)
+    scale = np.ones(nb * nd)
+    for d in range(3):
+        scale[d::nd] = tm[d]
+    i0, w = orc.basis_rows(op.knots, np.linspace(0, F, F))
+    Bm = np.zeros((F, nb), dtype=np.float32)
+    for f in range(F):
+        Bm[f, i0[f]:i0[f] + 4] = w[f]
+    coeffs = (S[:8] @ (Et * scale).astype(np.float32) + (mean * scale).astype(np.float32)).reshape(8, nb, nd)
+    frames = np.matmul(Bm, coeffs)
+    ref = op.back_project_frames_batch(S[:8].astype(np.float64))
+    np.testing.assert_allclose(frames, ref, rtol=0, atol=2e-4 * max(1.0, np.abs(ref).max()))
