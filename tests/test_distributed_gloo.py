@@ -36,6 +36,9 @@ def _worker(rank, world, port, n, seed, out_dir):
     cons = np.array([[0, 29.0, 1.0, 10.0, nan, -20.0, 0, 0], [1, 29.0, 2.0, 0.3, -1.0, 0.0, 0.0, 1.0]])
     idx, val, scores = distributed.sharded_best_candidate(S, lambda blk: cp.keyframe_errors_f64(blk, cons))
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([idx, val]))
+    idx2, val2, none = distributed.sharded_best_candidate(S, lambda blk: cp.keyframe_errors_f64(blk, cons), exchange="minloc")
+    assert none is None
+    np.save(os.path.join(out_dir, "m%d.npy" % rank), np.array([idx2, val2]))
     if rank == 0:
         np.save(os.path.join(out_dir, "scores.npy"), scores.numpy())
         ref = cp.keyframe_errors_f64(S, cons)
@@ -59,3 +62,6 @@ def test_two_rank_sharded_argmin_equals_single_process(tmp_path):
             if ref[best] > e:
                 best = i
         assert int(r0[0]) == best and r0[1] == ref[best]
+        m0, m1 = np.load(d / "m0.npy"), np.load(d / "m1.npy")       # the 16-byte (index, value) exchange: same winner
+        np.testing.assert_array_equal(m0, r0)
+        np.testing.assert_array_equal(m1, r0)
