@@ -24,7 +24,7 @@ __device__ __forceinline__ void flat_run(float *out, size_t e0, size_t e1, int f
     }
 }
 
-__global__ __launch_bounds__(768) void k(float *out, int pattern, int order, int nwaves) {
+__global__ __launch_bounds__(768) void k(float *out, int pattern, int order, int nwaves, int reverse = 0) {
     extern __shared__ float dyn[];
     if (pattern < 0) dyn[threadIdx.x] = 1.f;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -35,8 +35,9 @@ __global__ __launch_bounds__(768) void k(float *out, int pattern, int order, int
     const bool on = lane < 60;
     const int d0 = 4 * ql, nst = ql == 19 ? 3 : 4;
     for (int s = 0; s < per; s++) {
-        const int u = order == 0 ? w * per + s : s * G + w;
+        int u = order == 0 ? w * per + s : s * G + w;
         if (u >= U) continue;
+        if (reverse) u = U - 1 - u;   // the whole walk backwards: what the previous launch wrote last is written first
         const int tile = u / NCH, chunk = u % NCH;
         auto piece = [&](int cand) { return ((size_t)(tile * 16 + cand) * T + chunk * NF) * D; };
         if (pattern == 0) {
@@ -110,6 +111,16 @@ int main() {
                     printf("all 16 candidates by %d waves, %s  lds %3dK  %6.1f us  %7.1f GB/s\n", nw, pattern == 4 ? "all in flight " : "two at a time", lds / 1024, ms * 1e3, N * 4 / 1e9 / (ms * 1e-3));
                     fflush(stdout);
                 }
+    // Infinity Cache (256 MB) as a write-back cache between launches: if every other launch walks the buffer backwards,
+    // the last ~256 MB of launch i are the first of launch i + 1 and may be overwritten in the cache
+    for (int rep = 0; rep < 3; rep++) {
+        int flip = 0;
+        float ms = timeit([&] { k<<<256, 768, 150 * 1024>>>(out, 0, 0, 8, 0); });
+        printf("today's sweep, same direction every launch        %6.1f us  %7.1f GB/s\n", ms * 1e3, N * 4 / 1e9 / (ms * 1e-3));
+        ms = timeit([&] { k<<<256, 768, 150 * 1024>>>(out, 0, 0, 8, flip); flip ^= 1; });
+        printf("today's sweep, direction alternates per launch    %6.1f us  %7.1f GB/s\n", ms * 1e3, N * 4 / 1e9 / (ms * 1e-3));
+        fflush(stdout);
+    }
     const char *pn[] = {"quad rows, wave = 2 candidates (today)", "waves share a candidate, one at a time", "waves share, two candidates at a time", "flat float4 runs, wave = 2 candidates"};
     for (int rep = 0; rep < 2; rep++)
         for (int pattern = 0; pattern < 4; pattern++)
