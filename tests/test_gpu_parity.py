@@ -1,5 +1,7 @@
 """GPU parity tests: HIP kernels (through the C-ABI in include/mg_hip.h) against the oracle
 and the golden vectors made by the reference's own code.  Run with -m gpu on an MI355X."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -861,3 +863,53 @@ def test_constraint_set_update_keeps_the_structure_and_swaps_the_values(ctx):
     cs.close()
     ref.close()
     prim.close()
+
+
+def test_c_abi_rejects_misuse_with_status_codes_not_crashes(ctx):
+    """Every entry point validates what it is given and answers with a negative status and a message
+    (mg_last_error), never a fault: NULL handles and pointers, unknown dtype / path codes, negative sizes, a time
+    grid or constraint set that belongs to another primitive, non-finite constraint data."""
+    lib = ctx.lib
+    vp = C.c_void_p
+    prim_a = _capi.Primitive(ctx, synthetic.make_tiny_primitive())
+    prim_b = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
+    S = np.zeros((4, 40), dtype=np.float32)
+    d_S, d_out = ctx.upload(S), ctx.malloc(4 * 156 * 79 * 4)
+    null = vp(0)
+
+    def bad(rc, what):
+        assert rc < 0, what
+        assert len(lib.mg_last_error()) > 0, what
+    bad(lib.mg_back_project_frames(null, null, d_S.ptr, 0, 4, 40, d_out.ptr, 0), "NULL primitive")
+    bad(lib.mg_back_project_frames(prim_b.handle, null, null, 0, 4, 40, d_out.ptr, 0), "NULL latents")
+    bad(lib.mg_back_project_frames(prim_b.handle, null, d_S.ptr, 7, 4, 40, d_out.ptr, 0), "unknown dtype")
+    bad(lib.mg_back_project_frames(prim_b.handle, null, d_S.ptr, 0, -1, 40, d_out.ptr, 0), "negative batch")
+    bad(lib.mg_back_project_frames(prim_b.handle, null, d_S.ptr, 0, 4, 39, d_out.ptr, 0), "ld < n_components")
+    bad(lib.mg_back_project_frames(prim_b.handle, null, d_S.ptr, 0, 4, 40, d_out.ptr, 9), "unknown path")
+    bad(lib.mg_back_project_frames(prim_b.handle, null, d_S.ptr, 0, 4, 40, null, 0), "NULL output")
+    bad(lib.mg_back_project_frames(prim_b.handle, prim_a.canonical_grid.handle, d_S.ptr, 0, 4, 40, d_out.ptr, 0), "foreign grid")
+    bad(lib.mg_gmm_log_prob(prim_b.handle, d_S.ptr, 0, 4, 40, null, 0), "NULL log p output")
+    bad(lib.mg_gmm_log_prob(prim_b.handle, d_S.ptr, 0, 4, 40, d_out.ptr, 5), "unknown output dtype")
+    bad(lib.mg_step_frames_and_logp(null, d_S.ptr, 0, 4, 40, d_out.ptr, d_out.ptr), "NULL primitive (fused step)")
+    cs_a = _capi.ConstraintSet(prim_a, [{"type": "position", "t": 1.0, "weight": 1.0, "target": [0.0, 0.0, 0.0]}])
+    bad(lib.mg_score_constraints(prim_b.handle, cs_a.handle, d_S.ptr, 0, 4, 40, d_out.ptr, 1), "foreign constraint set")
+    bad(lib.mg_score_constraints(prim_b.handle, null, d_S.ptr, 0, 4, 40, d_out.ptr, 1), "NULL constraint set")
+    bad(lib.mg_constraint_set_update(null, null, 0, null), "NULL set update")
+    bad(lib.mg_argmin_first_dev(ctx.handle, d_out.ptr, 3, 4, d_out.ptr), "argmin dtype")
+    bad(lib.mg_argmin_first_dev(ctx.handle, null, 0, 4, d_out.ptr), "argmin NULL values")
+    bad(lib.mg_context_set_reserved_cus(ctx.handle, -1), "negative reserved CUs")
+    bad(lib.mg_context_arena_begin(null, 0), "NULL context")
+    h = vp()
+    bad(lib.mg_time_grid_create(prim_b.handle, null, 5, C.byref(h)), "NULL times")
+    t = np.array([0.0, np.nan, 3.0])
+    bad(lib.mg_time_grid_create(prim_b.handle, t.ctypes.data_as(vp), 3, C.byref(h)), "NaN sample time")
+    for kw in ({"t": float("inf")}, {"type": "joint_orientation", "orientation": [1, 0, 0, 0], "ref_dir": (0.0, 0.0, 0.0)}):
+        c = {"type": "position", "t": 1.0, "weight": 1.0, "target": [0.0, 0.0, 0.0]}
+        c.update(kw)
+        with pytest.raises(_capi.MGError):
+            _capi.ConstraintSet(prim_b, [c])
+    # and the library still works afterwards
+    assert prim_b.back_project_frames(S).shape == (4, 156, 79)
+    cs_a.close()
+    prim_a.close()
+    prim_b.close()
