@@ -188,6 +188,18 @@ int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64_t *launche
  * keeps the first 65536 per slot); *n = how many were written */
 int mg_profile_get_samples(mg_context *ctx, int slot, float *out_ms, int64_t capacity, int64_t *n);
 
+/* ---- multi-GPU: one process per GPU, one context per process ----------------------------------------
+ * The only exchange on the path is the all-gather of per-rank scores.  RCCL is loaded on first use
+ * (dlopen of librccl.so.1 -- the copy a host framework already has in the process, if any), so single-GPU users
+ * carry no dependency.  mg_dist_unique_id on rank 0, the 128 bytes travel out of band (MPI, a file, a
+ * torch.distributed broadcast), then mg_dist_init on every rank; mg_dist_all_gather runs on the context's stream:
+ * gathered[r * count + i] = rank r's local[i].  (bench.py keeps torch.distributed's communicator: same library.) */
+#define MG_DIST_ID_BYTES 128
+int mg_dist_unique_id(void *id_out);
+int mg_dist_init(mg_context *ctx, int32_t rank, int32_t n_ranks, const void *id);
+int mg_dist_all_gather(mg_context *ctx, const void *local_dev, void *gathered_dev, int64_t count, int dtype);
+int mg_dist_finalize(mg_context *ctx);
+
 /* ---- primitive -------------------------------------------------------------------
  * Replaces MotionPrimitive._initialize_from_json (reference motion_primitive.py:96-163):
  * transposes/scales/packs the eigenvectors, computes precisions_cholesky_ in float64

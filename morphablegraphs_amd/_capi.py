@@ -26,6 +26,7 @@ PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin
 EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
     "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
+    "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
     "mg_context_device_info", "mg_device_malloc", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_get_precisions_cholesky",
@@ -176,6 +177,10 @@ def load_library(path=None):
         "mg_context_arena_begin": [vp, i64],
         "mg_context_arena_end": [vp],
         "mg_context_arena_bytes": [vp, C.POINTER(i64), C.POINTER(i64)],
+        "mg_dist_unique_id": [vp],
+        "mg_dist_init": [vp, i32, i32, vp],
+        "mg_dist_all_gather": [vp, vp, vp, i64, i32],
+        "mg_dist_finalize": [vp],
         "mg_context_synchronize": [vp],
         "mg_context_device_info": [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(i64)],
         "mg_device_malloc": [vp, i64, C.POINTER(vp)],
@@ -294,6 +299,24 @@ class Context(object):
 
     def synchronize(self):
         _check(self.lib.mg_context_synchronize(self.handle))
+
+    # ---- multi-GPU (RCCL loaded on first use; one process per GPU) ----------------------------------
+    def dist_unique_id(self):
+        """128 opaque bytes made on rank 0 and carried to the other ranks out of band."""
+        buf = C.create_string_buffer(128)
+        _check(self.lib.mg_dist_unique_id(buf))
+        return buf.raw
+
+    def dist_init(self, rank, n_ranks, unique_id):
+        _check(self.lib.mg_dist_init(self.handle, int(rank), int(n_ranks), C.c_char_p(bytes(unique_id))))
+
+    def dist_all_gather(self, local_dev, gathered_dev, count, dtype=np.float32):
+        """gathered[r * count + i] = rank r's local[i], on the context's stream."""
+        code = MG_F64 if np.dtype(dtype) == np.float64 else MG_F32
+        _check(self.lib.mg_dist_all_gather(self.handle, _dev_ptr(local_dev), _dev_ptr(gathered_dev), int(count), code))
+
+    def dist_finalize(self):
+        _check(self.lib.mg_dist_finalize(self.handle))
 
     def set_stream(self, stream):
         _check(self.lib.mg_context_set_stream(self.handle, C.c_void_p(stream) if stream else None))

@@ -9,6 +9,7 @@
 #include <new>
 
 #include "mg_internal.h"
+#include <dlfcn.h>
 
 // ---------------------------------------------------------------------------------------
 // errors
@@ -52,6 +53,41 @@ extern "C" const char *mg_status_string(int s) {
         }                                \
     } while (0)
 
+// ---------------------------------------------------------------------------------------
+// RCCL, loaded on first use
+// ---------------------------------------------------------------------------------------
+struct mg_nccl_id { char internal[MG_DIST_ID_BYTES]; };
+struct mg_rccl_api {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ mg_nccl_id, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static mg_rccl_api g_rccl;
+static int mg_rccl_load() {
+    if (g_rccl.lib) return MG_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { mg_set_error("mg_dist: librccl.so.1 cannot be loaded (%s)", dlerror()); return MG_ERR_UNSUPPORTED; }
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void **, int, mg_nccl_id, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        mg_set_error("mg_dist: librccl lacks an expected symbol");
+        dlclose(h);
+        return MG_ERR_UNSUPPORTED;
+    }
+    g_rccl.lib = h;
+    return MG_OK;
+}
+static int mg_rccl_fail(int rc, const char *what) {
+    mg_set_error("RCCL error %d (%s) in %s", rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?", what);
+    return MG_ERR_HIP;
+}
 // ---------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------
@@ -101,6 +137,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->rccl_comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(ctx->rccl_comm); ctx->rccl_comm = nullptr; }
     for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &ev : ctx->free_events) (void)hipEventDestroy(ev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -171,6 +208,47 @@ void mg_dev_free(mg_context *ctx, void *p) {
         }
     }
     (void)hipFree(p);
+}
+
+extern "C" int mg_dist_unique_id(void *id_out) {
+    MG_REQUIRE(id_out != nullptr, "mg_dist_unique_id: id_out is NULL");
+    int rc = mg_rccl_load();
+    if (rc != MG_OK) return rc;
+    int nrc = g_rccl.GetUniqueId(id_out);
+    return nrc == 0 ? MG_OK : mg_rccl_fail(nrc, "ncclGetUniqueId");
+}
+extern "C" int mg_dist_init(mg_context *ctx, int32_t rank, int32_t n_ranks, const void *id) {
+    MG_REQUIRE(ctx && id && n_ranks >= 1 && rank >= 0 && rank < n_ranks, "mg_dist_init: bad arguments");
+    MG_REQUIRE(ctx->rccl_comm == nullptr, "mg_dist_init: the context already has a communicator");
+    int rc = mg_rccl_load();
+    if (rc != MG_OK) return rc;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    mg_nccl_id uid;
+    memcpy(uid.internal, id, MG_DIST_ID_BYTES);
+    int nrc = g_rccl.CommInitRank(&ctx->rccl_comm, n_ranks, uid, rank);
+    if (nrc != 0) { ctx->rccl_comm = nullptr; return mg_rccl_fail(nrc, "ncclCommInitRank"); }
+    ctx->dist_rank = rank;
+    ctx->dist_ranks = n_ranks;
+    return MG_OK;
+}
+extern "C" int mg_dist_all_gather(mg_context *ctx, const void *local_dev, void *gathered_dev, int64_t count, int dtype) {
+    MG_REQUIRE(ctx && count >= 0 && (count == 0 || (local_dev && gathered_dev)), "mg_dist_all_gather: bad arguments");
+    MG_REQUIRE(dtype == MG_F32 || dtype == MG_F64, "mg_dist_all_gather: bad dtype %d", dtype);
+    MG_REQUIRE(ctx->rccl_comm != nullptr, "mg_dist_all_gather: mg_dist_init has not been called on this context");
+    if (count == 0) return MG_OK;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    int nrc = g_rccl.AllGather(local_dev, gathered_dev, (size_t)count, dtype == MG_F64 ? 8 /* ncclFloat64 */ : 7 /* ncclFloat32 */,
+                               ctx->rccl_comm, ctx->stream);
+    return nrc == 0 ? MG_OK : mg_rccl_fail(nrc, "ncclAllGather");
+}
+extern "C" int mg_dist_finalize(mg_context *ctx) {
+    MG_REQUIRE(ctx != nullptr, "mg_dist_finalize: ctx is NULL");
+    if (!ctx->rccl_comm) return MG_OK;
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int nrc = g_rccl.CommDestroy(ctx->rccl_comm);
+    ctx->rccl_comm = nullptr;
+    ctx->dist_rank = 0; ctx->dist_ranks = 1;
+    return nrc == 0 ? MG_OK : mg_rccl_fail(nrc, "ncclCommDestroy");
 }
 
 extern "C" int mg_context_synchronize(mg_context *ctx) {

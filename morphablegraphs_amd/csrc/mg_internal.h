@@ -55,6 +55,8 @@ struct mg_context {
     struct arena_block { char *base; size_t bytes, used; int64_t live; };   // live: arrays handed out and not yet freed
     std::vector<arena_block> arena;
     size_t arena_block_bytes = 0;   // > 0 while an arena section is open
+    void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
+    int dist_rank = 0, dist_ranks = 1;
 };
 void mg_dev_free(mg_context *ctx, void *p);   // hipFree unless p lives in the context's arena
 

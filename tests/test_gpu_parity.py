@@ -913,3 +913,25 @@ def test_c_abi_rejects_misuse_with_status_codes_not_crashes(ctx):
     cs_a.close()
     prim_a.close()
     prim_b.close()
+
+
+def test_rccl_entry_points_of_the_c_abi_on_one_rank():
+    """mg_dist_*: RCCL loaded on first use, a communicator of one rank on the context's device, the all-gather of
+    the scores on the context's stream (with one rank: gathered == local).  More ranks need more GPUs than the
+    test box has; the exchange logic above the collective is covered by the 2-rank gloo test."""
+    ctx = _capi.Context(0)
+    with pytest.raises(_capi.MGError):
+        ctx.dist_all_gather(ctx.malloc(16), ctx.malloc(16), 4)             # no communicator yet
+    uid = ctx.dist_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.dist_init(0, 1, uid)
+    with pytest.raises(_capi.MGError):
+        ctx.dist_init(0, 1, uid)                                           # one communicator per context
+    for dtype in (np.float32, np.float64):
+        local = np.random.default_rng(0).standard_normal(8192).astype(dtype)
+        d_l, d_g = ctx.upload(local), ctx.malloc(local.nbytes)
+        ctx.dist_all_gather(d_l, d_g, len(local), dtype)
+        np.testing.assert_array_equal(ctx.download(d_g, (len(local),), dtype), local)
+    ctx.dist_finalize()
+    ctx.dist_finalize()                                                    # idempotent
+    ctx.close()
