@@ -14,5 +14,6 @@ rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-form
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $out/pmc_sq1 -- python3 $B > $out/pmc_sq1.log 2>&1 || { echo sq1 failed; tail -5 $out/pmc_sq1.log; exit 1; }
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $out/pmc_sq2 -- python3 $B > $out/pmc_sq2.log 2>&1 || { echo sq2 failed; tail -5 $out/pmc_sq2.log; exit 1; }
 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_misc -- python3 $B > $out/pmc_misc.log 2>&1 || { echo misc failed; tail -5 $out/pmc_misc.log; exit 1; }
-find $out -name '*.csv' | head -40
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES --output-format csv -d $out/pmc_mfma -- python3 $B > $out/pmc_mfma.log 2>&1 || { echo mfma failed; tail -5 $out/pmc_mfma.log; exit 1; }
+find $out -name '*.csv' | tail -40
 du -sh $out
