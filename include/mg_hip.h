@@ -104,7 +104,8 @@ typedef struct mg_primitive_desc {
  *      ref_dir (the caller rotates; ref_dir = (0,0,1) is the reference's ORIGIN); arccos of the normalised dot
  *      product (transformations.angle_between_vectors), clamped to [-1, 1]. */
 enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1, MG_CONSTRAINT_JOINT_POSITION = 2,
-       MG_CONSTRAINT_JOINT_MIDPOINT = 3, MG_CONSTRAINT_JOINT_ORIENTATION = 4, MG_CONSTRAINT_LOOK_AT = 5 };
+       MG_CONSTRAINT_JOINT_MIDPOINT = 3, MG_CONSTRAINT_JOINT_ORIENTATION = 4, MG_CONSTRAINT_LOOK_AT = 5,
+       MG_CONSTRAINT_POSE = 6 /* mg_keyframe_constraint.joint = index into the mg_pose_constraint array */ };
 #define MG_MAX_CHAIN 32
 typedef struct mg_keyframe_constraint {
     int32_t type;
@@ -116,6 +117,24 @@ typedef struct mg_keyframe_constraint {
     int32_t joint2;             /* MG_CONSTRAINT_JOINT_MIDPOINT: the second joint; else unused */
     int32_t reserved;
 } mg_keyframe_constraint;
+
+/* Point-cloud pose constraint, PoseConstraint.evaluate_motion_spline (reference pose_constraint.py:48-67): the global
+ * positions of `joints` at the keyframe form a cloud b; it is fitted to the wanted cloud a (`points`) by the optimal
+ * weighted 2-D rigid transform (rotation about y, translation in x and z: the closed form of Kovar et al.'s "Motion
+ * Graphs", theta = atan2(sum w (ax bz - bx az) - (Sax Sbz - Sbx Saz) / Sw, sum w (ax bx + az bz) - (Sax Sbx + Saz Sbz) / Sw),
+ * S* = weighted sums) and the error is the MEAN distance between corresponding points after the fit, plus -- with
+ * has_velocity -- |velocity - (p_0(t + 1) - p_0(t))| of the first joint.  PARITY UNPINNED: the fit and the distance are
+ * anim_utils' align_point_clouds_2D / calculate_point_cloud_distance (absent); the fit is pinned by its optimality
+ * (tests perturb it), the rest by a NumPy oracle. */
+typedef struct mg_pose_constraint {
+    int32_t n_points;        /* <= MG_MAX_POSE_POINTS */
+    int32_t has_velocity;
+    const int32_t *joints;   /* (n_points) indices into the skeleton (the reference's node_names) */
+    const double *points;    /* (n_points, 3) the wanted cloud */
+    const double *weights;   /* (n_points) */
+    double velocity[3];
+} mg_pose_constraint;
+#define MG_MAX_POSE_POINTS 64
 
 /* The part of a skeleton forward kinematics needs (anim_utils Skeleton: nodes with parent / offset, and the
  * pose-vector layout root translation [0:3] + one quaternion per animated joint). */
@@ -297,6 +316,12 @@ int mg_constraint_set_create_aligned(mg_primitive *prim, const mg_skeleton_desc 
  * building a new set costs about 200 us, this a few.  MG_ERR_INVALID_ARGUMENT if the structure differs. */
 int mg_constraint_set_update(mg_constraint_set *cs, const mg_keyframe_constraint *cons, int32_t n,
                              const mg_alignment_desc *alignment);
+/* the general form: MG_CONSTRAINT_POSE entries of `cons` refer to poses[cons[c].joint]; keyframe and weight come
+ * from the mg_keyframe_constraint as for every other type.  (mg_constraint_set_update refuses sets with poses.) */
+int mg_constraint_set_create_full(mg_primitive *prim, const mg_skeleton_desc *skeleton,
+                                  const mg_keyframe_constraint *cons, int32_t n,
+                                  const mg_pose_constraint *poses, int32_t n_poses,
+                                  const mg_alignment_desc *alignment, mg_constraint_set **out);
 void mg_constraint_set_destroy(mg_constraint_set *cs);
 int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
                          const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,

@@ -18,7 +18,7 @@ MG_OK = 0
 MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
-MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT = 3, 4, 5
+MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
                  "gmm_sample": 4, "spline_evaluate": 5, "step": 6}
 
@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
-    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
+    "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
     "mg_option_step",
 ]
 
@@ -61,6 +61,11 @@ class KeyframeConstraint(C.Structure):
     _fields_ = [("type", C.c_int32), ("joint", C.c_int32), ("canonical_keyframe", C.c_double),
                 ("weight_factor", C.c_double), ("target", C.c_double * 3), ("ref_dir", C.c_double * 3),
                 ("joint2", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PoseConstraintDesc(C.Structure):   # struct mg_pose_constraint
+    _fields_ = [("n_points", C.c_int32), ("has_velocity", C.c_int32), ("joints", C.c_void_p), ("points", C.c_void_p),
+                ("weights", C.c_void_p), ("velocity", C.c_double * 3)]
 
 
 class SkeletonDesc(C.Structure):   # struct mg_skeleton_desc
@@ -219,6 +224,7 @@ def load_library(path=None):
         "mg_constraint_set_create_fk": [vp, vp, vp, i32, vp],
         "mg_constraint_set_create_aligned": [vp, vp, vp, i32, vp, vp],
         "mg_constraint_set_update": [vp, vp, i32, vp],
+        "mg_constraint_set_create_full": [vp, vp, vp, i32, vp, i32, vp, vp],
         "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_option_step": [vp, vp, i64, vp, u64, vp, i32, i64, vp, vp],
@@ -434,7 +440,7 @@ class TimeGrid(object):
 
 class ConstraintSet(object):
     """constraints: list of dicts {"type": "position"|"direction"|"joint_position"|"joint_midpoint"|
-    "joint_orientation"|"look_at", "t": float, "weight": float, "target": [x|None, y|None, z|None] | [dx, dz],
+    "joint_orientation"|"look_at"|"pose" ({"joints": names, "points": (N, 3), "weights": (N,), "velocity": xyz or None}), "t": float, "weight": float, "target": [x|None, y|None, z|None] | [dx, dz],
     "ref_dir": (rx, ry, rz), "joint": name or index, "joint2": second joint of a midpoint, "orientation": wanted
     global (w,x,y,z) of a joint_orientation (or "target": that orientation applied to ref_dir), "offset": a point in
     the joint's own frame instead of its origin (joint_position), "look_at": {"joint", "target" xyz}}; a `skeleton`
@@ -449,7 +455,26 @@ class ConstraintSet(object):
         n = len(constraints)
         arr = self._marshal(constraints, skeleton)
         h = C.c_void_p()
-        if alignment is not None:
+        poses = [c for c in constraints if c["type"] == "pose"]
+        if poses:
+            if skeleton is None:
+                raise ValueError("pose constraints need a skeleton")
+            keep = []                                    # arrays the descriptors point at
+            parr = (PoseConstraintDesc * len(poses))()
+            for i, c in enumerate(poses):
+                joints = np.ascontiguousarray([skeleton.index(j) for j in c["joints"]], dtype=np.int32)
+                pts = np.ascontiguousarray(c["points"], dtype=np.float64).reshape(len(joints), 3)
+                wts = np.ascontiguousarray(c.get("weights", np.ones(len(joints))), dtype=np.float64).reshape(len(joints))
+                keep += [joints, pts, wts]
+                parr[i].n_points, parr[i].has_velocity = len(joints), int(c.get("velocity") is not None)
+                parr[i].joints, parr[i].points, parr[i].weights = joints.ctypes.data, pts.ctypes.data, wts.ctypes.data
+                for a in range(3):
+                    parr[i].velocity[a] = float(c["velocity"][a]) if c.get("velocity") is not None else 0.0
+            al = self._marshal_alignment(alignment, skeleton) if alignment is not None else None
+            d = skeleton.desc()
+            _check(prim.lib.mg_constraint_set_create_full(prim.handle, C.byref(d), C.cast(arr, C.c_void_p), n, C.cast(parr, C.c_void_p),
+                                                          len(poses), C.byref(al) if al is not None else None, C.byref(h)))
+        elif alignment is not None:
             al = self._marshal_alignment(alignment, skeleton)
             d = skeleton.desc() if skeleton is not None else None
             _check(prim.lib.mg_constraint_set_create_aligned(prim.handle, C.byref(d) if d is not None else None,
@@ -530,6 +555,9 @@ class ConstraintSet(object):
                 for a in range(3):
                     k.ref_dir[a] = float(rd[a])
                     k.target[a] = float(tv[a])
+            elif c["type"] == "pose":
+                k.type = MG_CONSTRAINT_POSE
+                k.joint = sum(1 for q in constraints[:i] if q["type"] == "pose")   # index into the pose array
             elif c["type"] == "direction":
                 k.type = MG_CONSTRAINT_DIRECTION_2D
                 k.target[0], k.target[1], k.target[2] = float(c["target"][0]), float(c["target"][1]), 0.0

@@ -24,7 +24,8 @@ def constraints_to_device_form(constraints, root_joint=None):
     """Accepts either ready dicts {"type","t","weight","target"[,"ref_dir"]} or reference-shaped
     constraint objects: Direction2DConstraint (target_dir), GlobalTransformConstraint (position and / or
     orientation of a joint), RelativeTransformConstraint (position of a point given in a joint's frame),
-    TwoHandConstraintSet (positions + joint_names), LookAtConstraint (target_position), FeetConstraint (left, right).  One reference constraint may become
+    TwoHandConstraintSet (positions + joint_names), LookAtConstraint (target_position), FeetConstraint (left, right),
+    PoseConstraint (pose_constraint + node_names + weights [+ velocity_constraint]).  One reference constraint may become
     several device constraints; "group" numbers the reference constraint's residual entry they add up to (a
     GlobalTransformConstraint is ONE residual = position error + orientation error, a TwoHandConstraint three,
     two_hand_constraint.py:66-74), see `group_residuals`."""
@@ -52,6 +53,13 @@ def constraints_to_device_form(constraints, root_joint=None):
             out.append({"type": "joint_position", "t": t, "weight": w, "target": [float(v) for v in p1], "joint": c.joint_names[1],
                         "group": group + 2})
             group += 3
+        elif hasattr(c, "pose_constraint") and hasattr(c, "node_names"):          # PoseConstraint (pose_constraint.py:37-46)
+            vel = getattr(c, "velocity_constraint", None)
+            out.append({"type": "pose", "t": t, "weight": w, "joints": list(c.node_names),
+                        "points": [[float(v) for v in p] for p in c.pose_constraint],
+                        "weights": [float(v) for v in c.weights], "velocity": None if vel is None else [float(v) for v in vel],
+                        "group": group})
+            group += 1
         elif hasattr(c, "left") and hasattr(c, "right"):                          # FeetConstraint (feet_constraint.py:47-51)
             # its residuals carry weight_factor already and MotionPrimitiveConstraints.evaluate multiplies once more;
             # get_residual_vector_spline is the single entry [left + right]
@@ -146,8 +154,9 @@ def _structure_key(prim, clist, skeleton, alignment=None):
     """What a device set is built from and cannot change afterwards: per constraint its type, keyframe, joints and
     relative point, plus the aligning joint.  Targets, weights, reference vectors and the previous frame are values
     (ConstraintSet.update)."""
-    items = tuple((c["type"], float(c["t"]), _freeze(c.get("joint")), _freeze(c.get("joint2")), _freeze(c.get("offset")))
-                  for c in clist)
+    # (a pose constraint's cloud is part of the set's tables: all of it is structure)
+    items = tuple((c["type"], float(c["t"]), _freeze(c.get("joint")), _freeze(c.get("joint2")), _freeze(c.get("offset")),
+                   _freeze(c) if c["type"] == "pose" else None) for c in clist)
     return (id(prim), prim.handle.value, id(skeleton), items, None if alignment is None else _freeze(alignment.get("joint", 0)))
 
 

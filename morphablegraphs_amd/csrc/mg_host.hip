@@ -1013,10 +1013,21 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
 }
 
 // ---- constraint sets ---------------------------------------------------------------------
-extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
-                                                int32_t n, const mg_alignment_desc *al, mg_constraint_set **out) {
-    MG_REQUIRE(p && out && n >= 0 && (n == 0 || cons), "mg_constraint_set_create: bad arguments");
+extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
+                                             int32_t n, const mg_pose_constraint *poses, int32_t n_poses,
+                                             const mg_alignment_desc *al, mg_constraint_set **out) {
+    MG_REQUIRE(p && out && n >= 0 && (n == 0 || cons) && n_poses >= 0 && (n_poses == 0 || poses), "mg_constraint_set_create: bad arguments");
     *out = nullptr;
+    // animated joints of the skeleton in skeleton order: a pose block is root xyz + one quaternion per slot
+    std::vector<int> slot;
+    int n_slots = 0;
+    if (sk) {
+        slot.assign((size_t)std::max(sk->n_joints, 0), -1);
+        for (int j = 0; j < sk->n_joints; j++)
+            if (sk->quat_channel && sk->quat_channel[j] >= 0) slot[(size_t)j] = n_slots++;
+    }
+    std::vector<double> pose_tab;
+    std::vector<size_t> pose_off((size_t)std::max(n, 1), 0);
     const int nch = std::min(7, p->D), L = p->L, D = p->D;
     if (sk) {
         MG_REQUIRE(sk->n_joints > 0 && sk->parents && sk->offsets && sk->quat_channel, "mg_constraint_set_create_fk: incomplete skeleton");
@@ -1044,7 +1055,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
     }
     for (int c = 0; c < n; c++) {
         const int type = cons[c].type;
-        MG_REQUIRE(type >= MG_CONSTRAINT_POSITION && type <= MG_CONSTRAINT_LOOK_AT,
+        MG_REQUIRE(type >= MG_CONSTRAINT_POSITION && type <= MG_CONSTRAINT_POSE,
                    "mg_constraint_set_create: constraint %d has unknown type %d", c, type);
         MG_REQUIRE(std::isfinite(cons[c].canonical_keyframe), "mg_constraint_set_create: constraint %d keyframe not finite", c);
         MG_REQUIRE(type == MG_CONSTRAINT_POSITION ? D >= 3 : D >= 7,
@@ -1060,6 +1071,40 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
             MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain of %d joints exceeds %d", c, m, MG_MAX_CHAIN);
             chain_len[c] = m;
             rows = 3 + 4 * std::max(m, 1);
+        } else if (type == MG_CONSTRAINT_POSE) {
+            MG_REQUIRE(sk != nullptr, "mg_constraint_set_create: constraint %d (pose) needs a skeleton", c);
+            MG_REQUIRE(cons[c].joint >= 0 && cons[c].joint < n_poses, "mg_constraint_set_create: constraint %d refers to pose %d of %d", c, cons[c].joint, n_poses);
+            const mg_pose_constraint &pc = poses[cons[c].joint];
+            MG_REQUIRE(pc.n_points > 0 && pc.n_points <= MG_MAX_POSE_POINTS && pc.joints && pc.points && pc.weights,
+                       "mg_constraint_set_create: pose %d: 1..%d points with joints, points and weights", cons[c].joint, MG_MAX_POSE_POINTS);
+            double sw = 0.0;
+            for (int i = 0; i < pc.n_points; i++) {
+                MG_REQUIRE(pc.joints[i] >= 0 && pc.joints[i] < sk->n_joints, "mg_constraint_set_create: pose %d: joint %d out of range", cons[c].joint, pc.joints[i]);
+                MG_REQUIRE(std::isfinite(pc.weights[i]) && std::isfinite(pc.points[3 * i]) && std::isfinite(pc.points[3 * i + 1]) && std::isfinite(pc.points[3 * i + 2]),
+                           "mg_constraint_set_create: pose %d: point %d not finite", cons[c].joint, i);
+                sw += pc.weights[i];
+            }
+            MG_REQUIRE(sw != 0.0, "mg_constraint_set_create: pose %d: weights sum to zero", cons[c].joint);
+            const int block = 3 + 4 * n_slots;
+            pose_off[(size_t)c] = pose_tab.size();
+            pose_tab.resize(pose_tab.size() + MG_POSE_HDR + (size_t)pc.n_points * MG_POSE_REC, 0.0);
+            double *tb = &pose_tab[pose_off[(size_t)c]];
+            tb[0] = pc.n_points; tb[1] = pc.has_velocity ? 1.0 : 0.0; tb[2] = pc.velocity[0]; tb[3] = pc.velocity[1]; tb[4] = pc.velocity[2];
+            tb[5] = block;
+            for (int i = 0; i < pc.n_points; i++) {
+                double *rec = tb + MG_POSE_HDR + (size_t)i * MG_POSE_REC;
+                rec[0] = pc.points[3 * i]; rec[1] = pc.points[3 * i + 1]; rec[2] = pc.points[3 * i + 2]; rec[3] = pc.weights[i];
+                std::vector<int> ch;
+                for (int j = pc.joints[i]; j >= 0; j = sk->parents[j]) ch.insert(ch.begin(), j);
+                const int m = (int)ch.size() - 1;
+                MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create: pose %d: chain of %d joints exceeds %d", cons[c].joint, m, MG_MAX_CHAIN);
+                rec[4] = m;
+                for (int k = 0; k < m; k++) {   // link k: rotation of chain joint k, offset of chain joint k + 1
+                    rec[5 + 4 * k] = slot[(size_t)ch[(size_t)k]] >= 0 ? 3 + 4 * slot[(size_t)ch[(size_t)k]] : -1.0;
+                    for (int e = 0; e < 3; e++) rec[6 + 4 * k + e] = sk->offsets[(size_t)ch[(size_t)k + 1] * 3 + e];
+                }
+            }
+            rows = block * (pc.has_velocity ? 2 : 1);
         } else if (type == MG_CONSTRAINT_LOOK_AT) {
             MG_REQUIRE(cons[c].joint == 0 || (sk && cons[c].joint > 0 && cons[c].joint < sk->n_joints),
                        "mg_constraint_set_create_fk: constraint %d: joint %d needs a skeleton that has it", c, cons[c].joint);
@@ -1132,7 +1177,18 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
             for (int i = 0; i < m; i++)
                 for (int e = 0; e < 3; e++) choff[(((size_t)c * 2 + which) * MG_MAX_CHAIN + i) * 3 + e] = sk->offsets[(size_t)chain[i + 1] * 3 + e];
         };
-        if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION && chain_len[c] == (int)chains[c].size()) {
+        if (cons[c].type == MG_CONSTRAINT_POSE) {
+            const int block = 3 + 4 * n_slots;
+            const mg_pose_constraint &pc = poses[cons[c].joint];
+            for (int blk = 0; blk < (pc.has_velocity ? 2 : 1); blk++) {
+                if (blk == 1) mg_basis_row(p->knots.data(), (int)p->knots.size(), cons[c].canonical_keyframe + 1.0, &i0, w);   // frame2 = evaluate(t + 1)
+                const size_t rb = r0 + (size_t)blk * block;
+                for (int d = 0; d < 3; d++) fill_row(rb + d, d);
+                for (int j = 0; j < sk->n_joints; j++)
+                    if (slot[(size_t)j] >= 0)
+                        for (int e = 0; e < 4; e++) fill_row(rb + 3 + 4 * slot[(size_t)j] + e, sk->quat_channel[j] + e);
+            }
+        } else if (cons[c].type == MG_CONSTRAINT_JOINT_POSITION && chain_len[c] == (int)chains[c].size()) {
             // relative point: every quaternion root .. joint, the skeleton's offsets and the point itself as the last link
             for (int d = 0; d < 3; d++) fill_row(r0 + d, d);
             const int m = chain_len[c];
@@ -1161,6 +1217,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
         double *q = &par[(size_t)c * 8];
         q[0] = (double)cons[c].type; q[1] = cons[c].weight_factor;
         for (int i = 0; i < 3; i++) { q[2 + i] = cons[c].target[i]; q[5 + i] = cons[c].ref_dir[i]; }
+        if (cons[c].type == MG_CONSTRAINT_POSE) q[2] = (double)pose_off[(size_t)c];
     }
     std::vector<double> align;
     if (al) {
@@ -1184,6 +1241,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
     }
     int rc = mg_upload(p->ctx, W, &cs->d_W);
     if (rc == MG_OK && al) rc = mg_upload(p->ctx, align, &cs->d_align);
+    if (rc == MG_OK && !pose_tab.empty()) { rc = mg_upload(p->ctx, pose_tab, &cs->d_pose); cs->has_pose = true; }
     if (rc == MG_OK) rc = mg_upload(p->ctx, bias, &cs->d_bias);
     if (rc == MG_OK) rc = mg_upload(p->ctx, par, &cs->d_par);
     if (rc == MG_OK) rc = mg_upload(p->ctx, woff, &cs->d_woff);
@@ -1215,6 +1273,7 @@ extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skelet
 extern "C" int mg_constraint_set_update(mg_constraint_set *cs, const mg_keyframe_constraint *cons, int32_t n, const mg_alignment_desc *al) {
     MG_REQUIRE(cs && cs->prim && n >= 0 && (n == 0 || cons), "mg_constraint_set_update: bad arguments");
     MG_REQUIRE(n == cs->n, "mg_constraint_set_update: %d constraints, the set was built for %d", n, cs->n);
+    if (cs->has_pose) { mg_set_error("mg_constraint_set_update: sets with pose constraints are rebuilt, not updated"); return MG_ERR_UNSUPPORTED; }
     MG_REQUIRE((al != nullptr) == (cs->d_align != nullptr) && (!al || al->joint == cs->align_joint),
                "mg_constraint_set_update: the alignment (none / aligning joint) differs from the one the set was built with");
     for (int c = 0; c < n; c++) {
@@ -1252,6 +1311,10 @@ extern "C" int mg_constraint_set_update(mg_constraint_set *cs, const mg_keyframe
     if (rc == MG_OK) cs->structure.assign(cons, cons + n);
     return rc;
 }
+extern "C" int mg_constraint_set_create_aligned(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
+                                                int32_t n, const mg_alignment_desc *al, mg_constraint_set **out) {
+    return mg_constraint_set_create_full(p, sk, cons, n, nullptr, 0, al, out);
+}
 extern "C" int mg_constraint_set_create_fk(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
                                            int32_t n, mg_constraint_set **out) {
     return mg_constraint_set_create_aligned(p, sk, cons, n, nullptr, out);
@@ -1271,6 +1334,7 @@ extern "C" void mg_constraint_set_destroy(mg_constraint_set *cs) {
     mg_dev_free(cs->prim->ctx, cs->d_Wpack);
     mg_dev_free(cs->prim->ctx, cs->d_bpad);
     mg_dev_free(cs->prim->ctx, cs->d_align);
+    mg_dev_free(cs->prim->ctx, cs->d_pose);
     delete cs;
 }
 

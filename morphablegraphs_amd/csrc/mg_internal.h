@@ -153,9 +153,15 @@ struct mg_constraint_set {
     int32_t RT = 0;
     std::vector<mg_keyframe_constraint> structure;   // what mg_constraint_set_update must find unchanged
     int32_t align_joint = -1;   // -1: local mode
+    double *d_pose = nullptr;   // pose constraints' tables (MG_POSE_* layout), NULL if there are none
+    bool has_pose = false;
     double *d_align = nullptr;  // [8] chain length, previous heading (x, z), previous root (x, z), ref_dir; NULL = local mode;
                                 // its rows (first control point: root xyz, then the chain's quaternions) start at woff[n]
 };
+
+// Device table of one pose constraint inside d_pose (doubles): header, then one record per point
+#define MG_POSE_HDR 8                            // [0] n_points, [1] has_velocity, [2..4] velocity, [5] rows of one pose block
+#define MG_POSE_REC (5 + 4 * MG_MAX_CHAIN)       // target xyz, weight, chain length m, then m x (quaternion row or -1, offset xyz)
 
 // launchers (each validates nothing: the C-ABI entry points did)
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp);

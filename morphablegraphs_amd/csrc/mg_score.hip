@@ -15,6 +15,7 @@ struct mg_score_args {
     const int32_t *woff;  // [n + 1]
     const int32_t *chain; // [n]           FK chain length
     const double *choff;  // [n][2][MG_MAX_CHAIN][3]
+    const double *pose;   // pose constraints' tables (MG_POSE_HDR / MG_POSE_REC layout) or NULL
     const double *align;  // [8] or NULL: chain length, previous heading (x,z), previous root (x,z), ref_dir; rows at woff[n]
     const void *lat;
     void *out;            // (B) summed error, or NULL
@@ -63,6 +64,33 @@ __device__ __forceinline__ void mg_fk_position(ChannelFn channel, int r_p, int r
         aw = nw; ax = nx; ay = ny; az = nz;
         const double ox = off[3 * i], oy = off[3 * i + 1], oz = off[3 * i + 2];
         // v' = v + 2 w (u x v) + 2 u x (u x v), u = (ax, ay, az)
+        const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
+        const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
+        p0 += ox + 2.0 * (aw * cx + dx);
+        p1 += oy + 2.0 * (aw * cy + dy);
+        p2 += oz + 2.0 * (aw * cz + dz);
+    }
+    p[0] = p0; p[1] = p1; p[2] = p2;
+}
+
+// Forward kinematics through a pose table record: link k rotates by the quaternion at row r0 + rec[5 + 4k] (identity if
+// negative) and moves by the offset rec[6 + 4k ..]; rows of the pose block start at r0 (root xyz first).
+template <typename ChannelFn>
+__device__ __forceinline__ void mg_fk_position_table(ChannelFn channel, int r0, const double *rec, double (&p)[3]) {
+    double p0 = channel(r0), p1 = channel(r0 + 1), p2 = channel(r0 + 2);
+    double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;
+    const int m = (int)rec[4];
+    for (int k = 0; k < m; k++) {
+        const int qr = (int)rec[5 + 4 * k];
+        if (qr >= 0) {
+            double qw = channel(r0 + qr), qx = channel(r0 + qr + 1), qy = channel(r0 + qr + 2), qz = channel(r0 + qr + 3);
+            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+            const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+            const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+            aw = nw; ax = nx; ay = ny; az = nz;
+        }
+        const double ox = rec[6 + 4 * k], oy = rec[7 + 4 * k], oz = rec[8 + 4 * k];
         const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
         const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
         p0 += ox + 2.0 * (aw * cx + dx);
@@ -134,6 +162,47 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
             if (t == t) ds += (t - pj[i]) * (t - pj[i]);
         }
         return par[1] * sqrt(ds);
+    }
+    if (type == MG_CONSTRAINT_POSE) {
+        // pose_constraint.py:48-67: cloud of joint positions, optimal weighted 2-D fit onto the wanted cloud (Kovar et
+        // al.), mean distance after the fit, + the velocity term of the first joint
+        const double *tb = a.pose + (size_t)par[2];
+        const int N = (int)tb[0], block = (int)tb[5];
+        double sw = 0.0, sax = 0.0, saz = 0.0, sbx = 0.0, sbz = 0.0, num = 0.0, den = 0.0;
+        for (int i = 0; i < N; i++) {
+            const double *rec = tb + MG_POSE_HDR + (size_t)i * MG_POSE_REC;
+            double b[3];
+            mg_fk_position_table(channel, r0, rec, b);
+            if (a.align) { const double x = b[0], z = b[2]; b[0] = al.c * x + al.s * z + al.tx; b[2] = al.c * z - al.s * x + al.tz; }
+            const double w = rec[3];
+            num += w * (rec[0] * b[2] - b[0] * rec[2]);
+            den += w * (rec[0] * b[0] + rec[2] * b[2]);
+            sw += w; sax += w * rec[0]; saz += w * rec[2]; sbx += w * b[0]; sbz += w * b[2];
+        }
+        num -= (sax * sbz - sbx * saz) / sw;
+        den -= (sax * sbx + saz * sbz) / sw;
+        const double theta = atan2(num, den), ct = cos(theta), st = sin(theta);
+        const double x0 = (sax - sbx * ct - sbz * st) / sw, z0 = (saz + sbx * st - sbz * ct) / sw;
+        double dist = 0.0, first[3] = {0.0, 0.0, 0.0};
+        for (int i = 0; i < N; i++) {
+            const double *rec = tb + MG_POSE_HDR + (size_t)i * MG_POSE_REC;
+            double b[3];
+            mg_fk_position_table(channel, r0, rec, b);
+            if (a.align) { const double x = b[0], z = b[2]; b[0] = al.c * x + al.s * z + al.tx; b[2] = al.c * z - al.s * x + al.tz; }
+            if (i == 0) { first[0] = b[0]; first[1] = b[1]; first[2] = b[2]; }
+            const double bx = b[0] * ct + b[2] * st + x0, bz = b[2] * ct - b[0] * st + z0;
+            const double ex = rec[0] - bx, ey = rec[1] - b[1], ez = rec[2] - bz;
+            dist += sqrt(ex * ex + ey * ey + ez * ez);
+        }
+        double err = dist / (double)N;
+        if (tb[1] != 0.0) {
+            double nx[3];
+            mg_fk_position_table(channel, r0 + block, tb + MG_POSE_HDR, nx);   // the first joint one frame later
+            if (a.align) { const double x = nx[0], z = nx[2]; nx[0] = al.c * x + al.s * z + al.tx; nx[2] = al.c * z - al.s * x + al.tz; }
+            const double vx = tb[2] - (nx[0] - first[0]), vy = tb[3] - (nx[1] - first[1]), vz = tb[4] - (nx[2] - first[2]);
+            err += sqrt(vx * vx + vy * vy + vz * vz);
+        }
+        return par[1] * err;
     }
     if (type == MG_CONSTRAINT_LOOK_AT) {
         // look_at_constraint.py:55-66: angle between where the joint looks and where the target is
@@ -329,7 +398,7 @@ static int mg_launch_score_mfma_kk(mg_primitive *p, const mg_constraint_set *cs,
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res) {
     mg_score_args a;
     a.res = res;
-    a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.align = cs->d_align; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
+    a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.align = cs->d_align; a.pose = cs->d_pose; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
     const bool lf0 = ldt == MG_F64, of0 = odt == MG_F64;
     if (cs->d_Wpack && !getenv("MG_SCORE_VALU")) {   // MG_SCORE_VALU: tests force the fallback kernel
         int rc = MG_ERR_UNSUPPORTED;

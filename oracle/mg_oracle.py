@@ -341,6 +341,46 @@ def align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, 
     return coeffs
 
 
+def align_point_clouds_2d(a, b, weights):
+    """The optimal weighted 2-D rigid fit of cloud b onto cloud a (rotation about y by theta, then translation in x
+    and z): the closed form of Kovar, Gleicher, Pighin, "Motion Graphs" (2002), which the reference reaches through
+    anim_utils' align_point_clouds_2D (absent here; PARITY UNPINNED, optimality checked by the tests).
+    Returns theta, offset_x, offset_z with x' = x cos + z sin + ox, z' = -x sin + z cos + oz."""
+    a, b, w = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), np.asarray(weights, dtype=np.float64)
+    sw = w.sum()
+    sax, saz, sbx, sbz = (w * a[:, 0]).sum(), (w * a[:, 2]).sum(), (w * b[:, 0]).sum(), (w * b[:, 2]).sum()
+    num = (w * (a[:, 0] * b[:, 2] - b[:, 0] * a[:, 2])).sum() - (sax * sbz - sbx * saz) / sw
+    den = (w * (a[:, 0] * b[:, 0] + a[:, 2] * b[:, 2])).sum() - (sax * sbx + saz * sbz) / sw
+    theta = math.atan2(num, den)
+    ox = (sax - sbx * math.cos(theta) - sbz * math.sin(theta)) / sw
+    oz = (saz + sbx * math.sin(theta) - sbz * math.cos(theta)) / sw
+    return theta, ox, oz
+
+
+def transform_point_cloud(cloud, theta, ox, oz):
+    cloud = np.asarray(cloud, dtype=np.float64)
+    out = cloud.copy()
+    out[:, 0] = cloud[:, 0] * math.cos(theta) + cloud[:, 2] * math.sin(theta) + ox
+    out[:, 2] = -cloud[:, 0] * math.sin(theta) + cloud[:, 2] * math.cos(theta) + oz
+    return out
+
+
+def pose_constraint_error(c, frame1, frame2, joints, animated_joints):
+    """PoseConstraint.evaluate_motion_spline (pose_constraint.py:48-67): the cloud of the joints' global positions at
+    the keyframe, fitted in 2-D onto the wanted cloud, MEAN distance of corresponding points after the fit, plus
+    |velocity - (first joint at t + 1 - first joint at t)| when a velocity is constrained."""
+    cloud = np.array([joint_global_position(frame1, joints, animated_joints, j) for j in c["joints"]])
+    target = np.asarray(c["points"], dtype=np.float64)
+    w = np.asarray(c.get("weights", np.ones(len(cloud))), dtype=np.float64)
+    theta, ox, oz = align_point_clouds_2d(target, cloud, w)
+    fitted = transform_point_cloud(cloud, theta, ox, oz)
+    err = float(np.linalg.norm(target - fitted, axis=1).sum() / len(cloud))
+    if c.get("velocity") is not None:
+        nxt = joint_global_position(frame2, joints, animated_joints, c["joints"][0])
+        err += float(np.linalg.norm(np.asarray(c["velocity"], dtype=np.float64) - (nxt - cloud[0])))
+    return err
+
+
 def constraint_error_on_frame(c, frame, joints, animated_joints):
     """One constraint dict evaluated on one (aligned or local) pose vector."""
     kind = c["type"]
@@ -466,7 +506,11 @@ class OraclePrimitive(object):
             coeffs = align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, align_joint, ref_dir)
             for ci, c in enumerate(constraints):
                 frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
-                out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
+                if c["type"] == "pose":
+                    frame2 = spline_frames(self.knots, coeffs, [c["t"] + 1.0])[0]
+                    out[b, ci] = c["weight"] * pose_constraint_error(c, frame, frame2, joints, animated_joints)
+                else:
+                    out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
         return out
 
     def skeleton_residuals(self, S, constraints, joints, animated_joints):
@@ -477,7 +521,11 @@ class OraclePrimitive(object):
             coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
             for ci, c in enumerate(constraints):
                 frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
-                out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
+                if c["type"] == "pose":
+                    frame2 = spline_frames(self.knots, coeffs, [c["t"] + 1.0])[0]
+                    out[b, ci] = c["weight"] * pose_constraint_error(c, frame, frame2, joints, animated_joints)
+                else:
+                    out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
         return out
 
     def log_likelihood_jac(self, S):

@@ -935,3 +935,72 @@ def test_rccl_entry_points_of_the_c_abi_on_one_rank():
     ctx.dist_finalize()
     ctx.dist_finalize()                                                    # idempotent
     ctx.close()
+
+
+def test_point_cloud_pose_constraint(ctx, monkeypatch):
+    """MG_CONSTRAINT_POSE (PoseConstraint.evaluate_motion_spline, reference pose_constraint.py:48-67; the fit and the
+    distance are anim_utils', absent: PARITY UNPINNED): forward kinematics of every listed joint, the optimal weighted
+    2-D fit onto the wanted cloud, mean distance, velocity of the first joint -- against the NumPy oracle in local
+    and global coordinates, MFMA and VALU kernels bit for bit, mixed with other constraint types, and a known answer
+    (a wanted cloud that IS the pose, turned and shifted: error 0)."""
+    from oracle import mg_oracle as orc
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(29)
+    S = rng.standard_normal((40, 40))
+    names = ["Hips", "Spine1", "Head", "LeftArm", "LeftHand", "RightArm", "RightHand", "LeftLeg", "LeftFoot", "RightLeg", "RightFoot",
+             "LeftHand_EndSite", "Head_EndSite"]
+    ref_frame = op.back_project_frames(rng.standard_normal(40))[70]
+    wanted = np.array([orc.joint_global_position(ref_frame, joints, animated, j) for j in names]) + rng.standard_normal((len(names), 3))
+    weights = rng.uniform(0.5, 2.0, len(names))
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+            {"type": "pose", "t": 0.0, "weight": 0.7, "joints": names, "points": wanted, "weights": weights, "velocity": [0.3, 0.0, 1.2]},
+            {"type": "joint_position", "joint": "LeftHand", "t": 80.0, "weight": 1.0, "target": [30.0, 95.0, 10.0]},
+            {"type": "pose", "t": 155.0, "weight": 1.0, "joints": names[:5], "points": wanted[:5], "weights": weights[:5], "velocity": None}]
+    cset = _capi.ConstraintSet(prim, cons, sk)
+    res = prim.score_constraint_residuals(cset, S)
+    np.testing.assert_allclose(res, op.skeleton_residuals(S, cons, joints, animated), rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(prim.score_constraints(cset, S), res.sum(axis=1), rtol=1e-13, atol=1e-12)
+    monkeypatch.setenv("MG_SCORE_VALU", "1")
+    np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
+    monkeypatch.delenv("MG_SCORE_VALU")
+    with pytest.raises(_capi.MGError):
+        cset.update(cons)                                              # sets with poses are rebuilt, not updated
+    cset.close()
+    prev = op.back_project_frames(rng.standard_normal(40))[-1].copy()
+    prev[:3] = [-20.0, 90.0, 45.0]
+    cset = _capi.ConstraintSet(prim, cons, sk, alignment=sk.alignment_to(prev, "Hips"))
+    res_al = prim.score_constraint_residuals(cset, S)
+    np.testing.assert_allclose(res_al, op.aligned_residuals(S, cons, prev, joints, animated, "Hips"), rtol=1e-9, atol=1e-8)
+    # the fit absorbs the alignment: a pose error without a velocity term is the same in both coordinate systems
+    np.testing.assert_allclose(res_al[:, 3], res[:, 3], rtol=1e-9, atol=1e-9)
+    cset.close()
+    with pytest.raises(ValueError):
+        _capi.ConstraintSet(prim, cons[1:2])                           # no skeleton
+    with pytest.raises(_capi.MGError):
+        _capi.ConstraintSet(prim, [dict(cons[1], weights=np.zeros(len(names)))], sk)
+    prim.close()
+
+    tiny = synthetic.make_primitive(seed=2, n_components=3, n_frames=12, n_basis=7, n_dim=79, n_gmm=2, name="tiny79")
+    pose = np.zeros(79)
+    pose[3::4][:19] = 1.0
+    pose[:3] = [1.0, 2.0, 3.0]
+    model = dict(tiny)
+    model["mean_spatial_vector"] = np.tile(pose, int(tiny["n_basis_spatial"]))
+    model["eigen_vectors_spatial"] = np.zeros_like(np.asarray(tiny["eigen_vectors_spatial"], dtype=np.float64))
+    model["translation_maxima"] = np.ones(3)
+    pr = _capi.Primitive(ctx, model)
+    cloud = np.array([orc.joint_global_position(pose, joints, animated, j) for j in names])
+    turned = orc.transform_point_cloud(cloud, -0.9, 25.0, 4.0)
+    cs = _capi.ConstraintSet(pr, [{"type": "pose", "t": 5.0, "weight": 2.0, "joints": names, "points": turned, "weights": weights,
+                                   "velocity": [0.0, 0.0, 0.0]}], sk)
+    np.testing.assert_allclose(pr.score_constraints(cs, np.zeros((2, pr.n_components))), 0.0, atol=1e-9)
+    cs.close()
+    lifted = turned + [0.0, 3.0, 0.0]                                   # y is not fitted: every point 3 off -> mean distance 3
+    cs = _capi.ConstraintSet(pr, [{"type": "pose", "t": 5.0, "weight": 2.0, "joints": names, "points": lifted, "weights": weights}], sk)
+    np.testing.assert_allclose(pr.score_constraints(cs, np.zeros((2, pr.n_components))), 6.0, rtol=1e-10)
+    cs.close()
+    pr.close()

@@ -174,6 +174,14 @@ def test_constraint_conversion_accepts_reference_shaped_objects():
     out = constraints_to_device_form([Feet()])
     assert [(c["joint"], c["weight"], c["group"], c["target"]) for c in out] == [("LeftFoot", 4.0, 0, [1.0, 0.0, 2.0]), ("RightFoot", 4.0, 0, [-1.0, 0.0, 2.0])]
 
+    class Pose2(object):        # PoseConstraint: cloud, joints, weights, optional velocity of the first joint
+        canonical_keyframe, weight_factor = 0, 0.5
+        pose_constraint, node_names, weights, velocity_constraint = [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]], ["Hips", "Head"], [1.0, 2.0], None
+
+    out = constraints_to_device_form([Pose2()])
+    assert out == [{"type": "pose", "t": 0.0, "weight": 0.5, "joints": ["Hips", "Head"], "points": [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]],
+                    "weights": [1.0, 2.0], "velocity": None, "group": 0}]
+
     out = constraints_to_device_form([Relative(), LookAt()])
     assert out[0] == {"type": "joint_position", "t": 30.0, "weight": 1.0, "target": [4.0, 5.0, 6.0], "joint": "RightHand",
                       "offset": [0.0, -3.0, 12.0], "group": 0}

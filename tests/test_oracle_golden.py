@@ -213,3 +213,44 @@ def test_two_hand_and_orientation_oracle_known_answers():
     f2[ch:ch + 4] = [half, 0.0, half, 0.0]
     assert abs(orc.joint_orientation_error(f2, joints, animated, "LeftHand", [half, 0.0, half, 0.0])) < 1e-12
     assert abs(orc.joint_orientation_error(f2, joints, animated, "Hips", [half, 0.0, half, 0.0]) - np.pi / 2) < 1e-12
+
+
+def test_point_cloud_fit_is_optimal_and_recovers_a_known_transform():
+    """The 2-D point-cloud fit behind the pose constraint (Kovar et al.'s closed form; anim_utils'
+    align_point_clouds_2D is absent): it recovers a known rotation about y + xz translation exactly, and on clouds
+    that do not match no nearby (theta, ox, oz) has a smaller weighted squared distance."""
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((12, 3)) * [30.0, 50.0, 30.0]
+    w = rng.uniform(0.2, 2.0, 12)
+    th, tx, tz = 0.7, 12.0, -5.0
+    b = orc.transform_point_cloud(a, -th, 0.0, 0.0)                     # b = a turned back by th ...
+    b[:, 0] -= tx * np.cos(th) - tz * np.sin(th)                        # ... and moved so that the fit must undo both
+    b[:, 2] -= tx * np.sin(th) + tz * np.cos(th)
+    theta, ox, oz = orc.align_point_clouds_2d(a, b, w)
+    fitted = orc.transform_point_cloud(b, theta, ox, oz)
+    np.testing.assert_allclose(fitted, a, atol=1e-10)
+    assert abs(theta - th) < 1e-12
+
+    def sse(cloud_b, t, x, z):
+        f = orc.transform_point_cloud(cloud_b, t, x, z)
+        return float((w * ((a[:, 0] - f[:, 0]) ** 2 + (a[:, 2] - f[:, 2]) ** 2)).sum())
+    b2 = b + rng.standard_normal(b.shape) * 4.0                         # no exact fit any more
+    t0, x0, z0 = orc.align_point_clouds_2d(a, b2, w)
+    best = sse(b2, t0, x0, z0)
+    for dt, dx, dz in ((1e-3, 0, 0), (-1e-3, 0, 0), (0, 1e-2, 0), (0, -1e-2, 0), (0, 0, 1e-2), (0, 0, -1e-2), (0.3, 1.0, -2.0)):
+        assert sse(b2, t0 + dt, x0 + dx, z0 + dz) > best
+    # the pose error of a cloud that is the wanted one turned and shifted is zero; a velocity of the first joint is added
+    from morphablegraphs_amd import synthetic
+    joints, animated = synthetic.make_skeleton()
+    frame = np.zeros(3 + 4 * len(animated))
+    frame[3::4] = 1.0
+    frame[:3] = [1.0, 2.0, 3.0]
+    names = ["Hips", "LeftHand", "RightHand", "Head", "LeftFoot"]
+    cloud = np.array([orc.joint_global_position(frame, joints, animated, j) for j in names])
+    wanted = orc.transform_point_cloud(cloud, 1.1, 40.0, -7.0)
+    c = {"type": "pose", "joints": names, "points": wanted, "weights": [1.0, 2.0, 2.0, 0.5, 1.0], "velocity": None}
+    assert orc.pose_constraint_error(c, frame, frame, joints, animated) < 1e-10
+    frame2 = frame.copy()
+    frame2[:3] += [0.5, 0.0, 2.0]
+    c["velocity"] = [0.5, 0.0, 0.0]
+    assert abs(orc.pose_constraint_error(c, frame, frame2, joints, animated) - 2.0) < 1e-10
