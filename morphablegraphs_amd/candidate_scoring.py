@@ -164,7 +164,9 @@ def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
     """A device constraint set for these (device-form) constraints, reused across calls.  An optimizer evaluates the
     same constraints again and again (same values: nothing to do); a planner scores the same KIND of constraints with
     new goals and a new previous frame every step (same structure: the values are rewritten by one small launch,
-    ConstraintSet.update, instead of building a new set, which costs about 200 us)."""
+    ConstraintSet.update, instead of building a new set, which costs about 200 us).  The returned set is SHARED: use
+    it for the call at hand and ask again next time -- a later request with the same structure and other values
+    rewrites it in place (stream ordered, so launches already enqueued keep the values they were enqueued with)."""
     key = _structure_key(prim, clist, skeleton, alignment)
     values = (_freeze(clist), _freeze(alignment) if alignment is not None else None)
     for i in range(len(_CSET_CACHE) - 1, -1, -1):   # entries whose primitive has been closed meanwhile are dropped
