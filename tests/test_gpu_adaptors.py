@@ -733,3 +733,24 @@ def test_graph_primitives_share_one_device_arena(tmp_path):
     graph.close()
     assert gctx.arena_bytes() == (0, 0)
     gctx.close()
+
+
+def test_the_ctypes_stub_in_integration_md_runs_as_printed():
+    """INTEGRATION.md section 2 shows the binding a maintainer of the reference would add.  The code block is taken
+    from the document as it stands, pointed at the in-tree library, and must reproduce the adaptor's results."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# morphablegraphs/motion_model/hip_backend.py.*?)```", text, re.S).group(1)
+    lib = os.path.join(root, "morphablegraphs_amd", "csrc", "libmg_hip.so")
+    assert 'C.CDLL("libmg_hip.so")' in block
+    ns = {}
+    exec(compile(block.replace('C.CDLL("libmg_hip.so")', "C.CDLL(%r)" % lib), "INTEGRATION.md", "exec"), ns)
+    data = synthetic.make_walk_primitive(seed=0)
+    backend = ns["HipBackend"](data)
+    S = np.random.default_rng(0).standard_normal((20, 40)).astype(np.float32)
+    prim = HipMotionPrimitive(None)
+    prim._initialize_from_json(data)
+    np.testing.assert_array_equal(backend.frames(S).view(np.uint32), prim.back_project_frames_batch(S).view(np.uint32))
+    np.testing.assert_array_equal(backend.score_samples(S), prim.score_samples_batch(S.astype(np.float64)))
