@@ -505,12 +505,15 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
     for (int w = MG_MAX_WI; w >= 4; w--)
         if (fits(w, budget1)) { W = w; break; }
     if (W == 0) return;  // n_dim too large for the LDS-staged kernel
+    int max_nt = MG_MAX_NT;
+    if (const char *e = getenv("MG_CHUNK_W")) W = std::max(4, std::min(W, atoi(e)));            // bench ablations only
+    if (const char *e = getenv("MG_CHUNK_NT")) max_nt = std::max(1, std::min(MG_MAX_NT, atoi(e)));
     int a = 0;
     int max_stride = 0, max_wi = 0;
     while (a < g->T) {
         int imin = g->i0[a], imax = g->i0[a];
         int b = a + 1;
-        while (b < g->T && b - a < MG_MAX_NT) {
+        while (b < g->T && b - a < max_nt) {
             int lo = std::min(imin, g->i0[b]), hi = std::max(imax, g->i0[b]);
             if (hi - lo + 4 > W) break;
             imin = lo; imax = hi;
