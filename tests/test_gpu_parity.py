@@ -1004,3 +1004,35 @@ def test_point_cloud_pose_constraint(ctx, monkeypatch):
     np.testing.assert_allclose(pr.score_constraints(cs, np.zeros((2, pr.n_components))), 6.0, rtol=1e-10)
     cs.close()
     pr.close()
+
+
+def test_frames_beyond_four_gigabytes_of_output(ctx):
+    """262 144 candidates = 12.9 GB of frames: output offsets pass 2^32 bytes (candidate 87 127) and 2^33, the unit
+    index passes 2^16 tiles.  Spot rows around those boundaries and at the very end against the float32 contract
+    model, bit for bit, for the stand-alone kernel and the fused step (two-launch fallback at this size)."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    B, L, F, D = 262144, 40, 156, 79
+    rng = np.random.default_rng(31)
+    S = rng.standard_normal((B, L)).astype(np.float32)
+    d_S = ctx.upload(S)
+    d_f = ctx.malloc(B * F * D * 4)
+    d_l = ctx.malloc(B * 4)
+    spots = [0, 15, 16, 87126, 87127, 87128, 174254, 174255, 174256, 200000, B - 17, B - 16, B - 1]
+    model = cp.frames_f32model(S[spots].astype(np.float64))
+    for fused in (False, True):
+        _capi._check(ctx.lib.mg_memset(ctx.handle, d_f.ptr, 0xFF, B * F * D * 4))     # NaN pattern: stale rows cannot pass
+        if fused:
+            prim.step_frames_and_logp_dev(d_S, np.float32, B, L, d_f, d_l)
+        else:
+            prim.back_project_frames_dev(d_S, np.float32, B, L, d_f, path=_capi.MG_PATH_MFMA)
+        for k, b in enumerate(spots):
+            row = ctx.download(d_f.ptr.value + b * F * D * 4, (F, D), np.float32)
+            np.testing.assert_array_equal(_bits(row), _bits(model[k]), err_msg="candidate %d fused=%s" % (b, fused))
+    lp = ctx.download(d_l, (B,), np.float32)
+    ref = cp.log_prob_f64(S[spots].astype(np.float64))
+    np.testing.assert_allclose(lp[spots], ref, rtol=3e-7, atol=1e-5)
+    assert np.isfinite(lp).all()
+    d_f.free(); d_l.free(); d_S.free()
+    prim.close()
