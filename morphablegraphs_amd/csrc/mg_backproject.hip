@@ -24,7 +24,7 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 // scalars of one launch; the pointers are separate __restrict__ kernel parameters
 struct mg_frames_args {
     int64_t B, ld;
-    int32_t T, D, Dp, cshift, L, nroot, n_chunks, n_tiles, stride, max_wi;
+    int32_t T, D, Dp, cshift, L, nroot, n_chunks, n_tiles, stride, max_wi, max_nt;
     int32_t debug;   // MG_DEBUG_FLAGS (ablations and timers, never set in production): 1 = producers idle, 2 = sweep idle,
                      // 16 = per-wave phase timers, 32 = wave-0 sub-phases (serialising), 128 = no chunk rotation, 256 = no tile-round rotation
     int32_t nbuf;    // LDS ring depth (2 or 3)
@@ -97,16 +97,16 @@ extern "C" int mg_debug_dump_stamps(void) {
 //   wave delays only the recycling of its slot and the consumers' stores stay in flight throughout.
 //   FUSE_GMM: after their last unit the producer waves score the workgroup's candidates against the mixture.
 //
-// LDS: buf[nbuf] = image [16][stride] f32; ro[nbuf] = root outputs [16][MG_MAX_NT][4] f32; tb[nbuf] = w32
-// [MG_MAX_NT] float4 + image tap byte offsets [MG_MAX_NT] int; rs = float64 root image; prog = 32 counters
+// LDS: buf[nbuf] = image [16][stride] f32; ro[nbuf] = root outputs [16][max_nt][4] f32; tb[nbuf] = w32
+// [max_nt] float4 + image tap byte offsets [max_nt] int (max_nt = the grid's longest chunk, padded to 16); rs = float64 root image; prog = 32 counters
 // (producer/consumer progress, mixture hand-off); FUSE_GMM: mixture terms and exponentials [2][K*16] f64 each.
 // -----------------------------------------------------------------------------------------
 #define MG_FUSE_MAX_KK 10   // fused mixture scoring: k-steps (4 latent components each) that fit the register budget
 #define MG_WS_NPW 4      // producer waves
 #define MG_WS_NCW 8      // consumer waves, two candidates each
 #define MG_WS_BLOCK (64 * (MG_WS_NPW + MG_WS_NCW))
-#define MG_TB_BYTES (MG_MAX_NT * 16 + MG_MAX_NT * 4)
-#define MG_RO_BYTES (MG_NCAND * MG_MAX_NT * 16)
+#define MG_TB_BYTES_N(nt) ((nt) * 16 + (nt) * 4)      // nt = the grid's longest chunk, rounded up to 16 samples
+#define MG_RO_BYTES_N(nt) (MG_NCAND * (nt) * 16)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -351,6 +351,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
     const int root_stride = a.max_wi * nroot + 1;
     const int nbuf = a.nbuf;
+    const int max_nt = a.max_nt;
+    const int MG_RO_BYTES = MG_RO_BYTES_N(max_nt), MG_TB_BYTES = MG_TB_BYTES_N(max_nt);
     unsigned char *ro_base = smem + nbuf * (size_t)buf_bytes;         // root outputs, one per ring slot
     unsigned char *tb_base = ro_base + nbuf * MG_RO_BYTES;            // per-sample tables, one per ring slot
     unsigned char *rs_base = tb_base + nbuf * MG_TB_BYTES;            // float64 root image (wave 0 only)
@@ -399,13 +401,13 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 const unsigned char *img = smem + (size_t)slot * buf_bytes;
                 const float *lds_ro = (const float *)(ro_base + (size_t)slot * MG_RO_BYTES);
                 const float4 *lds_w = (const float4 *)(tb_base + (size_t)slot * MG_TB_BYTES);
-                const int *lds_mo = (const int *)(lds_w + MG_MAX_NT);
+                const int *lds_mo = (const int *)(lds_w + max_nt);
                 const int col0 = ck.imin * Dp - ck.rt0 * 16;
                 const bool has1 = cj + MG_WS_NCW < un_prev.ncand;
                 const int c1 = has1 ? cj + MG_WS_NCW : cj;
                 const unsigned char *img0 = img + (size_t)(cj * stride + col0) * 4 + lane_img;
                 const unsigned char *img1 = img + (size_t)(c1 * stride + col0) * 4 + lane_img;
-                const float *ro0 = lds_ro + cj * MG_MAX_NT * 4, *ro1 = lds_ro + c1 * MG_MAX_NT * 4;
+                const float *ro0 = lds_ro + cj * max_nt * 4, *ro1 = lds_ro + c1 * max_nt * 4;
                 float *or0 = out + (size_t)(un_prev.b0 + cj) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
                 float *or1 = out + (size_t)(un_prev.b0 + c1) * TD + (size_t)ck.t0 * D;
                 // two row groups x two candidates in flight per trip
@@ -501,16 +503,16 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         // ================= wave 0: tables, root rows and root taps (f64 MFMA), one unit ahead =================
         // per-lane constants of the tap MFMA: B operand = rows[m = 4 ks + (l >> 4)][col = 16 ct + (l & 15)] with
         // col = candidate * nroot + channel (48 columns = 3 tiles); D column = the same col
-        int tap_b_off[3][2], tap_o_off[3];
-        bool tap_b_ok[3][2];
+        int tap_b_off[3][MG_TAP_KS], tap_o_off[3];
+        bool tap_b_ok[3][MG_TAP_KS];
 #pragma unroll
         for (int ct = 0; ct < 3; ct++) {
             const int col = ct * 16 + cl;
             const bool colok = col < MG_NCAND * nroot;
             const int cc = colok ? col / nroot : 0, cd = colok ? col - cc * nroot : 0;
-            tap_o_off[ct] = colok ? cc * MG_MAX_NT * 4 + cd : -1;
+            tap_o_off[ct] = colok ? cc * max_nt * 4 + cd : -1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
+            for (int ks = 0; ks < MG_TAP_KS; ks++) {
                 const int m = 4 * ks + g;
                 tap_b_ok[ct][ks] = colok && m < a.max_wi;
                 tap_b_off[ct][ks] = cc * root_stride + m * nroot + cd;
@@ -520,14 +522,14 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         auto root_stage = [&](const mg_unit &un, int slot) {   // tables -> tb[slot], root rows -> rs, root outputs -> ro[slot]
             const mg_chunk &ck = un.ck;
             float4 *tw = (float4 *)(tb_base + (size_t)slot * MG_TB_BYTES);
-            int *tmo = (int *)(tw + MG_MAX_NT);
+            int *tmo = (int *)(tw + max_nt);
             double *rs = (double *)rs_base;
             float4 r_w = {0.f, 0.f, 0.f, 0.f};
             int r_i0 = 0;
             if (lane < ck.nT) { r_w = w32[ck.t0 + lane]; r_i0 = i0tab[ck.t0 + lane]; }
-            double r_wt[4];
+            double r_wt[MG_TAP_FT * MG_TAP_KS];
 #pragma unroll
-            for (int e = 0; e < 4; e++) r_wt[e] = wtap[((size_t)un.chunk * 4 + e) * 64 + lane];
+            for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) r_wt[e] = wtap[((size_t)un.chunk * (MG_TAP_FT * MG_TAP_KS) + e) * 64 + lane];
             typename mg_gmm_xt<LAT_F64>::type s64frag[KK];   // widened to float64 at the MFMA
             mg_gmm_load_x<KK, LAT_F64>(s64frag, lat, un.b0, un.ncand, a.ld, L, cl, g);
             if (a.debug & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MG_STAMP(1); }
@@ -584,22 +586,22 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             // bit-identical to w0*c0, fma(w1,c1,.), fma(w2,c2,.), fma(w3,c3,.).  Same wave wrote rs: program order syncs.
             float *ro = (float *)(ro_base + (size_t)slot * MG_RO_BYTES);
 #pragma unroll
-            for (int ft = 0; ft < 2; ft++) {
+            for (int ft = 0; ft < MG_TAP_FT; ft++) {
                 if (ft * 16 < ck.nT) {
                     f64x4 acc[3];
-                    double bv[3][2];
+                    double bv[3][MG_TAP_KS];
 #pragma unroll
                     for (int ct = 0; ct < 3; ct++) {
                         acc[ct] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int ks = 0; ks < 2; ks++)   // rows at or beyond this chunk's window were never written: 0 * stale LDS could be NaN
+                        for (int ks = 0; ks < MG_TAP_KS; ks++)   // rows at or beyond this chunk's window were never written: 0 * stale LDS could be NaN
                             bv[ct][ks] = (tap_b_ok[ct][ks] && 4 * ks + g < ck.wi) ? rs[tap_b_off[ct][ks]] : 0.0;
                     }
 #pragma unroll
-                    for (int ks = 0; ks < 2; ks++)
+                    for (int ks = 0; ks < MG_TAP_KS; ks++)
 #pragma unroll
                         for (int ct = 0; ct < 3; ct++)
-                            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_wt[ft * 2 + ks], bv[ct][ks], acc[ct], 0, 0, 0);
+                            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(r_wt[ft * MG_TAP_KS + ks], bv[ct][ks], acc[ct], 0, 0, 0);
                     // D[row = f = 16 ft + (l >> 4) + 4 reg][col]
 #pragma unroll
                     for (int ct = 0; ct < 3; ct++)
@@ -792,7 +794,7 @@ bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp) {
     mg_frames_args a;
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
-    a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.nbuf = g->nbuf;
+    a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.max_nt = g->max_nt; a.nbuf = g->nbuf;
     {
         static const int dbg = getenv("MG_DEBUG_FLAGS") ? atoi(getenv("MG_DEBUG_FLAGS")) : 0;
         a.debug = dbg;
@@ -807,7 +809,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     const bool lf = (ldt == MG_F64);
     // nbuf ring slots (image + root outputs + tables), the float64 root image, the progress counters
     const int buf_bytes = (MG_NCAND * g->stride * 4 + 255) / 256 * 256;
-    int lds = g->nbuf * (buf_bytes + MG_RO_BYTES + MG_TB_BYTES) + MG_NCAND * (g->max_wi * p->nroot + 1) * 8 + 128;
+    int lds = g->nbuf * (buf_bytes + MG_RO_BYTES_N(g->max_nt) + MG_TB_BYTES_N(g->max_nt)) + MG_NCAND * (g->max_wi * p->nroot + 1) * 8 + 128;
     if (lds != g->lds_bytes || lds > 160 * 1024 || (logp && !mg_frames_can_fuse_gmm(p, g, B))) {
         mg_set_error("mg_back_project_frames: internal LDS sizing mismatch (%d vs %d)", lds, g->lds_bytes);
         return MG_ERR_UNSUPPORTED;

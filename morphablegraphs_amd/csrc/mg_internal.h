@@ -66,8 +66,10 @@ void mg_prof_end(mg_context *ctx, int slot);
 int mg_prof_resolve(mg_context *ctx);
 
 // One chunk of a time grid handled by one workgroup of the MFMA kernel.
-#define MG_MAX_WI 8          // basis functions per chunk window
-#define MG_MAX_NT 32         // time samples per chunk
+#define MG_MAX_WI 11         // basis functions per chunk window (11 x 3 root rows still span <= 3 row tiles of 16)
+#define MG_MAX_NT 48         // time samples per chunk
+#define MG_TAP_KS ((MG_MAX_WI + 3) / 4)   // k-steps of the banded root-tap MFMA (4 basis functions each)
+#define MG_TAP_FT (MG_MAX_NT / 16)       // sample tiles of 16 of the root-tap MFMA
 struct mg_chunk {
     int32_t t0;        // first time index (chunks are runs of consecutive time indices)
     int32_t nT;        // number of time samples in the chunk, <= MG_MAX_NT
@@ -96,6 +98,7 @@ struct mg_time_grid {
     int32_t n_chunks = 0;
     int32_t stride = 0;      // floats per candidate in the LDS coefficient image
     int32_t max_wi = 0;
+    int32_t max_nt = 16;        // samples of the longest chunk, rounded up to 16: sizes the per-slot tables in LDS
     int32_t lds_bytes = 0;   // dynamic LDS of the MFMA kernel for this grid
     int32_t nbuf = 2;        // LDS ring depth of the MFMA kernel (3 when it fits)
     bool mfma_ok = false;
