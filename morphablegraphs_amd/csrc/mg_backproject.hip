@@ -468,7 +468,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     asm volatile("" : "+v"(g_op));
                     mg_load_sfrag<KK, LAT_F64>(sfrag, lat, un, a.ld, L, cl, g_op);
                 }
-                // Consecutive chunks of a tile share basis functions (windows of 8 advance by 5): the row tiles this
+                // Consecutive chunks of a tile share basis functions (for 'walk' windows of 10 advance by 7): the row tiles this
                 // unit has in common with the previous one are copied from the previous slot (LDS -> LDS, the same
                 // bits) instead of being recomputed: 37 % fewer MFMAs and E' fragment loads, which is what slows
                 // the sweep waves down (matrix-pipe time on the shared SIMDs, L2 requests in the store path).
