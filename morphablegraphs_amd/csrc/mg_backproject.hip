@@ -415,26 +415,41 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     const int fla = f0 + fsub, flb = fla + rpi;
                     const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
                     const int fa_ = fla < ck.nT ? fla : ck.nT - 1, fb_ = flb < ck.nT ? flb : ck.nT - 1;
-                    f32x4 v0a, v0b, v1a, v1b;
-                    if (!root_lane) {
-                        const float4 wa = lds_w[fa_], wb = lds_w[fb_];
-                        const int moa = lds_mo[fa_], mob = lds_mo[fb_];
-                        v0a = mg_quad_taps(img0 + moa, wa, dp4);
-                        v0b = mg_quad_taps(img0 + mob, wb, dp4);
-                        v1a = mg_quad_taps(img1 + moa, wa, dp4);
-                        v1b = mg_quad_taps(img1 + mob, wb, dp4);
-                    } else {
-                        v0a = *(const f32x4 *)&ro0[fa_ * 4];
-                        v0b = *(const f32x4 *)&ro0[fb_ * 4];
-                        v1a = *(const f32x4 *)&ro1[fa_ * 4];
-                        v1b = *(const f32x4 *)&ro1[fb_ * 4];
-                    }
                     float *pa0 = or0 + (size_t)f0 * D, *pa1 = or1 + (size_t)f0 * D;          // uniform
                     float *pb0 = pa0 + (size_t)rpi * D, *pb1 = pa1 + (size_t)rpi * D;
-                    if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
-                    if (ob) mg_store_n(pb0 + lane_out, v0b, nst);
-                    if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
-                    if (ob && has1) mg_store_n(pb1 + lane_out, v1b, nst);
+                    if (f0 + rpi < ck.nT || (a.debug & 2048)) {   // the usual trip: both row groups (flag 2048: always)
+                        f32x4 v0a, v0b, v1a, v1b;
+                        if (!root_lane) {
+                            const float4 wa = lds_w[fa_], wb = lds_w[fb_];
+                            const int moa = lds_mo[fa_], mob = lds_mo[fb_];
+                            v0a = mg_quad_taps(img0 + moa, wa, dp4);
+                            v0b = mg_quad_taps(img0 + mob, wb, dp4);
+                            v1a = mg_quad_taps(img1 + moa, wa, dp4);
+                            v1b = mg_quad_taps(img1 + mob, wb, dp4);
+                        } else {
+                            v0a = *(const f32x4 *)&ro0[fa_ * 4];
+                            v0b = *(const f32x4 *)&ro0[fb_ * 4];
+                            v1a = *(const f32x4 *)&ro1[fa_ * 4];
+                            v1b = *(const f32x4 *)&ro1[fb_ * 4];
+                        }
+                        if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
+                        if (ob) mg_store_n(pb0 + lane_out, v0b, nst);
+                        if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                        if (ob && has1) mg_store_n(pb1 + lane_out, v1b, nst);
+                    } else {                                     // the chunk's last rows fill one group only: half the work
+                        f32x4 v0a, v1a;
+                        if (!root_lane) {
+                            const float4 wa = lds_w[fa_];
+                            const int moa = lds_mo[fa_];
+                            v0a = mg_quad_taps(img0 + moa, wa, dp4);
+                            v1a = mg_quad_taps(img1 + moa, wa, dp4);
+                        } else {
+                            v0a = *(const f32x4 *)&ro0[fa_ * 4];
+                            v1a = *(const f32x4 *)&ro1[fa_ * 4];
+                        }
+                        if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
+                        if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                    }
                 }
             }
             MG_STAMP(4);
