@@ -192,6 +192,11 @@ __device__ __forceinline__ f32x4 mg_quad_taps(const unsigned char *tp, const flo
     return v;
 }
 
+// all active lanes store four floats at base (wave-uniform) + a 32-bit byte offset: one store instruction, no lane classes
+__device__ __forceinline__ void mg_store4_at(float *base, unsigned byte_off, const f32x4 &v) {
+    *(f32x4u *)((char *)base + byte_off) = v;
+}
+
 __device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {
     if (n == 4) {
         *(f32x4u *)op = v;
@@ -389,6 +394,12 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         const int dp4 = Dp * 4;
         const int lane_img = (d0 + a.cshift) * 4;         // byte offset of the lane's quad inside a basis row
         const int lane_out = fsub * D + d0;               // float offset inside a row group
+        // When every quad lane holds four floats and the root lane three (D = 79: 3 + 19 x 4), the root lane borrows the
+        // row's channel 3 from quad lane 0 (a cross-lane read) and ALL lanes store four floats with one instruction;
+        // the float written twice carries the same value.  Otherwise lanes store 4 / 3 / 2 / 1 floats by class.
+        const bool all4 = nroot == 3 && ((D - nroot) & 3) == 0 && !(a.debug & 8192);
+        const int q0_lane = (lane - nql) << 2;            // byte index of this row's quad lane 0 for ds_bpermute
+        const unsigned lane_out_b = (unsigned)lane_out * 4u;
         int slot = 0;
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
@@ -432,10 +443,22 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
                             v1b = *(const f32x4 *)&ro1[fb_ * 4];
                         }
-                        if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
-                        if (ob) mg_store_n(pb0 + lane_out, v0b, nst);
-                        if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
-                        if (ob && has1) mg_store_n(pb1 + lane_out, v1b, nst);
+                        if (all4) {
+                            const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
+                            const float b0b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0b[0])));
+                            const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
+                            const float b1b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1b[0])));
+                            if (root_lane) { v0a[3] = b0a; v0b[3] = b0b; v1a[3] = b1a; v1b[3] = b1b; }
+                            if (oa) mg_store4_at(pa0, lane_out_b, v0a);
+                            if (ob) mg_store4_at(pb0, lane_out_b, v0b);
+                            if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
+                            if (ob && has1) mg_store4_at(pb1, lane_out_b, v1b);
+                        } else {
+                            if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
+                            if (ob) mg_store_n(pb0 + lane_out, v0b, nst);
+                            if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                            if (ob && has1) mg_store_n(pb1 + lane_out, v1b, nst);
+                        }
                     } else {                                     // the chunk's last rows fill one group only: half the work
                         f32x4 v0a, v1a;
                         if (!root_lane) {
@@ -447,8 +470,16 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
                         }
-                        if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
-                        if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                        if (all4) {
+                            const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
+                            const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
+                            if (root_lane) { v0a[3] = b0a; v1a[3] = b1a; }
+                            if (oa) mg_store4_at(pa0, lane_out_b, v0a);
+                            if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
+                        } else {
+                            if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
+                            if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                        }
                     }
                 }
             }
