@@ -13,6 +13,8 @@ def main(d, out):
         for k, v in agg.items():
             v2 = v[len(v) // 10:]  # drop warm-up launches
             res["kernels"][k[:90]] = {"launches": len(v), "avg_us": sum(v2) / len(v2), "min_us": min(v), "max_us": max(v)}
+            if len(v) >= 2000:   # bench.py's timed region: its last 2000 launches (before them: placement probes, warm-up)
+                res["kernels"][k[:90]]["timed_region_avg_us"] = sum(v[-2000:]) / 2000.0
     for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         agg = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
