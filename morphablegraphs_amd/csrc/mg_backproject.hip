@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "mg_internal.h"
+#include <type_traits>
 #include "mg_gmm_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -174,7 +175,10 @@ __device__ __forceinline__ void mg_cursor_next(mg_cursor &c, int n_chunks) {
     if (++c.chunk == n_chunks) { c.chunk = 0; c.tile++; }
 }
 
-// 4 channels of one sample: taps are 4 consecutive basis rows of the image (byte pitch dp4)
+// 4 channels of one sample: taps are 4 consecutive basis rows of the image (byte pitch dp4).  DP4 > 0: the pitch is a
+// compile-time constant, the three row offsets become immediate offsets of the LDS reads (no address arithmetic).
+template <int DP4>
+__device__ __forceinline__ f32x4 mg_quad_taps_t(const unsigned char *tp, const float4 w, int dp4_rt);
 __device__ __forceinline__ f32x4 mg_quad_taps(const unsigned char *tp, const float4 w, int dp4) {
     const f32x4 t0 = *(const f32x4 *)tp;
     const f32x4 t1 = *(const f32x4 *)(tp + dp4);
@@ -190,6 +194,10 @@ __device__ __forceinline__ f32x4 mg_quad_taps(const unsigned char *tp, const flo
         v[e] = x;
     }
     return v;
+}
+template <int DP4>
+__device__ __forceinline__ f32x4 mg_quad_taps_t(const unsigned char *tp, const float4 w, int dp4_rt) {
+    return mg_quad_taps(tp, w, DP4 > 0 ? DP4 : dp4_rt);
 }
 
 // all active lanes store four floats at base (wave-uniform) + a 32-bit byte offset: one store instruction, no lane classes
@@ -421,7 +429,10 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 const float *ro0 = lds_ro + cj * max_nt * 4, *ro1 = lds_ro + c1 * max_nt * 4;
                 float *or0 = out + (size_t)(un_prev.b0 + cj) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
                 float *or1 = out + (size_t)(un_prev.b0 + c1) * TD + (size_t)ck.t0 * D;
-                // two row groups x two candidates in flight per trip
+                // two row groups x two candidates in flight per trip; the loop exists twice: with the usual row pitch
+                // (Dp = 80 floats) as a constant, and with a run-time pitch
+                auto sweep_rows = [&](auto pitch_tag) {
+                constexpr int DP4 = decltype(pitch_tag)::value;
                 for (int f0 = 0; f0 < ck.nT; f0 += 2 * rpi) {
                     const int fla = f0 + fsub, flb = fla + rpi;
                     const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
@@ -433,10 +444,10 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         if (!root_lane) {
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
-                            v0a = mg_quad_taps(img0 + moa, wa, dp4);
-                            v0b = mg_quad_taps(img0 + mob, wb, dp4);
-                            v1a = mg_quad_taps(img1 + moa, wa, dp4);
-                            v1b = mg_quad_taps(img1 + mob, wb, dp4);
+                            v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
+                            v0b = mg_quad_taps_t<DP4>(img0 + mob, wb, dp4);
+                            v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
+                            v1b = mg_quad_taps_t<DP4>(img1 + mob, wb, dp4);
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v0b = *(const f32x4 *)&ro0[fb_ * 4];
@@ -464,8 +475,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         if (!root_lane) {
                             const float4 wa = lds_w[fa_];
                             const int moa = lds_mo[fa_];
-                            v0a = mg_quad_taps(img0 + moa, wa, dp4);
-                            v1a = mg_quad_taps(img1 + moa, wa, dp4);
+                            v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
+                            v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
@@ -482,6 +493,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         }
                     }
                 }
+                };
+                if (dp4 == 320 && !(a.debug & 16384)) sweep_rows(std::integral_constant<int, 320>{});
+                else sweep_rows(std::integral_constant<int, 0>{});
             }
             MG_STAMP(4);
             mg_publish(prog, wave, lane, u + 1);
