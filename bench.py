@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-interval", type=int, default=8,
                     help="bracket every n-th launch of a kernel with a HIP event pair inside the timed region")
-    ap.add_argument("--output-candidates", type=int, default=6,
+    ap.add_argument("--output-candidates", type=int, default=8,
                     help="allocate this many output buffers and keep the one the kernel writes fastest (physical placement "
                          "of the 404 MB changes the step time by several percent); 1 = take the first allocation")
     args = ap.parse_args()
