@@ -8,7 +8,7 @@ prim = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
 B, L = 8192, 40
 S = ctx.upload(np.random.default_rng(0).standard_normal((B, L)).astype(np.float32))
 lp = ctx.malloc(B * 4)
-bufs = [ctx.malloc(B * 156 * 79 * 4 + (k * 4096 if len(sys.argv) > 1 else 0)) for k in range(6)]
+bufs = [ctx.malloc(B * 156 * 79 * 4) for k in range(8)]
 def run(buf, n=1500):
     for _ in range(100): prim.step_frames_and_logp_dev(S, np.float32, B, L, buf, lp)
     ctx.synchronize(); t0 = time.perf_counter()
