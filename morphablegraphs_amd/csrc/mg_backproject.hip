@@ -199,6 +199,30 @@ template <int DP4>
 __device__ __forceinline__ f32x4 mg_quad_taps_t(const unsigned char *tp, const float4 w, int dp4_rt) {
     return mg_quad_taps(tp, w, DP4 > 0 ? DP4 : dp4_rt);
 }
+// the same in two steps, so that a trip can request all of its 16 tap rows before the first FMA waits for any of them
+struct mg_tap_rows { f32x4 t0, t1, t2, t3; };
+template <int DP4>
+__device__ __forceinline__ mg_tap_rows mg_quad_load(const unsigned char *tp, int dp4_rt) {
+    const int dp4 = DP4 > 0 ? DP4 : dp4_rt;
+    mg_tap_rows r;
+    r.t0 = *(const f32x4 *)tp;
+    r.t1 = *(const f32x4 *)(tp + dp4);
+    r.t2 = *(const f32x4 *)(tp + 2 * dp4);
+    r.t3 = *(const f32x4 *)(tp + 3 * dp4);
+    return r;
+}
+__device__ __forceinline__ f32x4 mg_quad_fma(const mg_tap_rows &r, const float4 w) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float x = w.x * r.t0[e];
+        x = fmaf(w.y, r.t1[e], x);
+        x = fmaf(w.z, r.t2[e], x);
+        x = fmaf(w.w, r.t3[e], x);
+        v[e] = x;
+    }
+    return v;
+}
 
 // all active lanes store four floats at base (wave-uniform) + a 32-bit byte offset: one store instruction, no lane classes
 __device__ __forceinline__ void mg_store4_at(float *base, unsigned byte_off, const f32x4 &v) {
@@ -444,10 +468,20 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         if (!root_lane) {
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
-                            v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
-                            v0b = mg_quad_taps_t<DP4>(img0 + mob, wb, dp4);
-                            v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
-                            v1b = mg_quad_taps_t<DP4>(img1 + mob, wb, dp4);
+                            if (a.debug & 131072) {
+                                v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
+                                v0b = mg_quad_taps_t<DP4>(img0 + mob, wb, dp4);
+                                v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
+                                v1b = mg_quad_taps_t<DP4>(img1 + mob, wb, dp4);
+                            } else {   // all 16 tap rows are requested before the first FMA
+                                const mg_tap_rows r0a = mg_quad_load<DP4>(img0 + moa, dp4), r0b = mg_quad_load<DP4>(img0 + mob, dp4);
+                                const mg_tap_rows r1a = mg_quad_load<DP4>(img1 + moa, dp4), r1b = mg_quad_load<DP4>(img1 + mob, dp4);
+                                __builtin_amdgcn_sched_barrier(0);
+                                v0a = mg_quad_fma(r0a, wa);
+                                v0b = mg_quad_fma(r0b, wb);
+                                v1a = mg_quad_fma(r1a, wa);
+                                v1b = mg_quad_fma(r1b, wb);
+                            }
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v0b = *(const f32x4 *)&ro0[fb_ * 4];
@@ -856,7 +890,8 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
     a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.max_nt = g->max_nt; a.nbuf = g->nbuf;
     {
-        static const int dbg = getenv("MG_DEBUG_FLAGS") ? atoi(getenv("MG_DEBUG_FLAGS")) : 0;
+        const char *dbg_env = getenv("MG_DEBUG_FLAGS");   // read per launch: A/B tools switch it inside one process
+        const int dbg = dbg_env ? atoi(dbg_env) : 0;
         a.debug = dbg;
     }
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
