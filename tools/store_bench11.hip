@@ -11,6 +11,7 @@ constexpr int B = 8192, T = 156, D = 79, NF = 39, NCH = 4, NTILES = B / 16;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef f4 f4u __attribute__((aligned(4)));
 
+__device__ int g_rot = 0;   // 1: each workgroup walks a chunk's rows from its own starting row (de-synchronised offsets)
 __global__ __launch_bounds__(768) void k(float *out, int ntiles = NTILES) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave < 4) return;
@@ -22,9 +23,11 @@ __global__ __launch_bounds__(768) void k(float *out, int ntiles = NTILES) {
         const int u = w * per + s;
         if (u >= U) continue;
         const int tile = u / NCH, chunk = u % NCH;
-        for (int f0 = 0; f0 < NF; f0 += 3)
+        const int r0 = g_rot ? 3 * (int)((blockIdx.x * 5u + (unsigned)s * 3u) % 13u) : 0;
+        for (int fi = 0; fi < NF; fi += 3)
             for (int half = 0; half < 2; half++) {
                 const size_t cand = (size_t)tile * 16 + cj + 8 * half;
+                const int f0 = (fi + r0) % NF;
                 const int f = f0 + fsub;
                 if (on && f < NF) {
                     float *p = out + (cand * T + chunk * NF + f) * D + (ql == 19 ? 75 : 4 * ql);
@@ -54,6 +57,12 @@ int main() {
     std::vector<float *> plain;
     for (int i = 0; i < 6; i++) { float *p; CK(hipMalloc(&p, NB)); plain.push_back(p); printf(" %6.1f", timeit(p)); }
     printf("  us\n");
+    { int one = 1, zero = 0;
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_rot), &one, sizeof(int)));
+      printf("  rotated row order   :");
+      for (float *p : plain) printf(" %6.1f", timeit(p));
+      printf("  us\n");
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_rot), &zero, sizeof(int))); }
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
