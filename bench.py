@@ -124,14 +124,16 @@ def main():
     # Where the 404 MB of frames land in HBM changes the step time by ~7 % (two stable modes per buffer, 87 vs 94 us,
     # tools/placement_probe.py): before anything is timed, a few allocations are probed and the best one is kept.
     placement = {"candidates": max(1, args.output_candidates), "probe_us": [], "chosen": 0,
-                 "allocator": "mg_device_malloc (hipMalloc of the exact size; separate allocations of this size land in the "
-                              "fast placement far more often than slices of a larger pool)"}
+                 "allocator": "candidates 0, 1: mg_device_malloc (hipMalloc of the exact size); the others: "
+                              "mg_device_malloc_chunked (virtual-memory API, 8 MiB physical chunks)"}
 
     class _RawFrames(object):   # the library's own allocation, seen by torch without a copy
         def __init__(self, buf):
             self.buf = buf
             self.__cuda_array_interface__ = {"shape": (B, F, D), "typestr": "<f4", "data": (int(buf.ptr.value), False), "version": 2}
-    raws = [_RawFrames(ctx.malloc(B * F * D * 4)) for _ in range(placement["candidates"])]
+    # candidates 0 and 1: one exact-size hipMalloc each; the others: assembled from 8 MiB physical chunks (three of four of
+    # those land in the fast placement even on boxes where single allocations never do)
+    raws = [_RawFrames(ctx.malloc(B * F * D * 4, chunk_bytes=(8 << 20) if i >= 2 else 0)) for i in range(placement["candidates"])]
     if len(raws) > 1:
         probe_lp = torch.empty((B,), dtype=torch.float32, device=dev)
 

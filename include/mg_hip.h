@@ -191,6 +191,11 @@ int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *
 /* plain device memory helpers so a host language needs no HIP binding of its own */
 int mg_device_malloc(mg_context *ctx, int64_t bytes, void **out_dev);
 int mg_device_free(mg_context *ctx, void *ptr_dev);
+/* The same buffer assembled from separately created physical chunks (HIP virtual-memory API: one reserved address
+ * range, hipMemCreate per chunk_bytes, mapped back to back).  Where a large output lands physically decides between
+ * two speed classes of the frames kernel ("Placement"); buffers built from 8 MiB chunks hit the
+ * fast class more often than single allocations on boxes where those never do.  Freed with mg_device_free. */
+int mg_device_malloc_chunked(mg_context *ctx, int64_t bytes, int64_t chunk_bytes, void **out_dev);
 int mg_memcpy_h2d(mg_context *ctx, void *dst_dev, const void *src, int64_t bytes);
 int mg_memcpy_d2h(mg_context *ctx, void *dst, const void *src_dev, int64_t bytes);
 int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
     "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
     "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
-    "mg_context_device_info", "mg_device_malloc", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
+    "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_get_precisions_cholesky",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
@@ -179,6 +179,7 @@ def load_library(path=None):
         "mg_context_create": [i32, vp, C.POINTER(vp)],
         "mg_context_set_stream": [vp, vp],
         "mg_context_set_reserved_cus": [vp, i32],
+        "mg_device_malloc_chunked": [vp, i64, i64, C.POINTER(vp)],
         "mg_context_arena_begin": [vp, i64],
         "mg_context_arena_end": [vp],
         "mg_context_arena_bytes": [vp, C.POINTER(i64), C.POINTER(i64)],
@@ -333,8 +334,8 @@ class Context(object):
         _check(self.lib.mg_context_device_info(self.handle, name, C.byref(ncu), C.byref(mem)))
         return {"name": name.value.decode(), "n_cu": ncu.value, "total_mem": mem.value}
 
-    def malloc(self, nbytes):
-        return DeviceBuffer(self, nbytes)
+    def malloc(self, nbytes, chunk_bytes=0):
+        return DeviceBuffer(self, nbytes, chunk_bytes)
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
@@ -377,11 +378,15 @@ class Context(object):
 
 
 class DeviceBuffer(object):
-    def __init__(self, ctx, nbytes):
+    def __init__(self, ctx, nbytes, chunk_bytes=0):
+        """chunk_bytes > 0: assembled from separate physical chunks of that size (mg_device_malloc_chunked)."""
         self.ctx = ctx
         self.nbytes = int(nbytes)
         p = C.c_void_p()
-        _check(ctx.lib.mg_device_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        if chunk_bytes:
+            _check(ctx.lib.mg_device_malloc_chunked(ctx.handle, self.nbytes, int(chunk_bytes), C.byref(p)))
+        else:
+            _check(ctx.lib.mg_device_malloc(ctx.handle, self.nbytes, C.byref(p)))
         self.ptr = p
 
     @property

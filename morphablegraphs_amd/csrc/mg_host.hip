@@ -133,6 +133,7 @@ extern "C" int mg_context_create(int device, void *stream, mg_context **out) {
     return MG_OK;
 }
 
+static void mg_vmm_release(mg_context::vmm_alloc &v);
 extern "C" void mg_context_destroy(mg_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -143,6 +144,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
+    for (auto &v : ctx->vmm) mg_vmm_release(v);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -278,10 +280,67 @@ extern "C" int mg_device_malloc(mg_context *ctx, int64_t bytes, void **out_dev) 
     MG_HIP_CHECK(hipMalloc(out_dev, (size_t)bytes));
     return MG_OK;
 }
+static void mg_vmm_release(mg_context::vmm_alloc &v) {
+    if (v.va) {
+        (void)hipMemUnmap(v.va, v.total);
+        (void)hipMemAddressFree(v.va, v.total);
+    }
+    for (auto h : v.handles) (void)hipMemRelease(h);
+    v.handles.clear();
+    v.va = nullptr;
+}
+extern "C" int mg_device_malloc_chunked(mg_context *ctx, int64_t bytes, int64_t chunk_bytes, void **out_dev) {
+    MG_REQUIRE(ctx && out_dev && bytes > 0 && chunk_bytes > 0, "mg_device_malloc_chunked: bad arguments");
+    *out_dev = nullptr;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    size_t gran = 0;
+    MG_HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+    if (gran == 0) gran = 4096;
+    const size_t chunk = ((size_t)chunk_bytes + gran - 1) / gran * gran;
+    const size_t n = ((size_t)bytes + chunk - 1) / chunk;
+    mg_context::vmm_alloc v;
+    v.total = n * chunk; v.chunk = chunk; v.va = nullptr;
+    hipError_t e = hipMemAddressReserve(&v.va, v.total, 0, nullptr, 0);
+    if (e != hipSuccess) return mg_hip_fail(e, "hipMemAddressReserve");
+    size_t mapped = 0;
+    for (size_t i = 0; i < n && e == hipSuccess; i++) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, chunk, &prop, 0);
+        if (e != hipSuccess) break;
+        v.handles.push_back(h);
+        e = hipMemMap((char *)v.va + i * chunk, chunk, 0, h, 0);
+        if (e == hipSuccess) mapped += chunk;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(v.va, v.total, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        if (mapped) (void)hipMemUnmap(v.va, mapped);
+        (void)hipMemAddressFree(v.va, v.total);
+        for (auto h : v.handles) (void)hipMemRelease(h);
+        return mg_hip_fail(e, "mg_device_malloc_chunked (virtual-memory API)");
+    }
+    *out_dev = v.va;
+    ctx->vmm.push_back(std::move(v));
+    return MG_OK;
+}
 extern "C" int mg_device_free(mg_context *ctx, void *p) {
     MG_REQUIRE(ctx != nullptr, "mg_device_free: ctx is NULL");
     if (!p) return MG_OK;
     MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->vmm.size(); i++)
+        if (ctx->vmm[i].va == p) {
+            mg_vmm_release(ctx->vmm[i]);
+            ctx->vmm.erase(ctx->vmm.begin() + (long)i);
+            return MG_OK;
+        }
     MG_HIP_CHECK(hipFree(p));
     return MG_OK;
 }

@@ -55,6 +55,8 @@ struct mg_context {
     struct arena_block { char *base; size_t bytes, used; int64_t live; };   // live: arrays handed out and not yet freed
     std::vector<arena_block> arena;
     size_t arena_block_bytes = 0;   // > 0 while an arena section is open
+    struct vmm_alloc { void *va; size_t total, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+    std::vector<vmm_alloc> vmm;     // buffers from mg_device_malloc_chunked
     void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
     int dist_rank = 0, dist_ranks = 1;
 };

@@ -1036,3 +1036,24 @@ def test_frames_beyond_four_gigabytes_of_output(ctx):
     assert np.isfinite(lp).all()
     d_f.free(); d_l.free(); d_S.free()
     prim.close()
+
+
+def test_chunked_device_allocation(ctx):
+    """mg_device_malloc_chunked: a buffer assembled from separate physical chunks behaves like any other device
+    buffer -- the frames kernel writes the same bits into it, copies work across chunk boundaries, and
+    mg_device_free releases it."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    B = 300
+    S = np.random.default_rng(41).standard_normal((B, 40)).astype(np.float32)
+    ref = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+    d_S = ctx.upload(S)
+    for chunk in (1 << 20, 8 << 20):
+        buf = ctx.malloc(ref.nbytes, chunk_bytes=chunk)                # 14.8 MB: 15 chunks of 1 MiB / 2 of 8 MiB
+        prim.back_project_frames_dev(d_S, np.float32, B, 40, buf, path=_capi.MG_PATH_MFMA)
+        got = ctx.download(buf, ref.shape, np.float32)
+        np.testing.assert_array_equal(_bits(got), _bits(ref))
+        buf.free()
+    with pytest.raises(_capi.MGError):
+        ctx.malloc(0, chunk_bytes=1 << 20)
+    prim.close()
