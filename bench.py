@@ -125,15 +125,16 @@ def main():
     # tools/placement_probe.py): before anything is timed, a few allocations are probed and the best one is kept.
     placement = {"candidates": max(1, args.output_candidates), "probe_us": [], "chosen": 0,
                  "allocator": "candidates 0, 1: mg_device_malloc (hipMalloc of the exact size); the others: "
-                              "mg_device_malloc_chunked (virtual-memory API, 8 MiB physical chunks)"}
+                              "mg_device_malloc_chunked (virtual-memory API, 8 / 16 / 32 MiB physical chunks)"}
 
     class _RawFrames(object):   # the library's own allocation, seen by torch without a copy
         def __init__(self, buf):
             self.buf = buf
             self.__cuda_array_interface__ = {"shape": (B, F, D), "typestr": "<f4", "data": (int(buf.ptr.value), False), "version": 2}
-    # candidates 0 and 1: one exact-size hipMalloc each; the others: assembled from 8 MiB physical chunks (three of four of
+    # candidates 0 and 1: one exact-size hipMalloc each; the others: assembled from 8 / 16 / 32 MiB physical chunks (most of
     # those land in the fast placement even on boxes where single allocations never do)
-    raws = [_RawFrames(ctx.malloc(B * F * D * 4, chunk_bytes=(8 << 20) if i >= 2 else 0)) for i in range(placement["candidates"])]
+    chunk_of = lambda i: 0 if i < 2 else ((8 << 20), (16 << 20), (32 << 20))[(i - 2) % 3]
+    raws = [_RawFrames(ctx.malloc(B * F * D * 4, chunk_bytes=chunk_of(i))) for i in range(placement["candidates"])]
     if len(raws) > 1:
         probe_lp = torch.empty((B,), dtype=torch.float32, device=dev)
 
