@@ -439,33 +439,31 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             mg_cursor_next(cur, a.n_chunks);
             mg_wait_producers(prog, u + 1);
             MG_STAMP(1);
-            const mg_chunk &ck = un_prev.ck;
-            // candidates ca and ca + 8, rows [r_lo, r_hi) of the chunk
-            auto sweep_pair = [&](const int ca, const int r_lo, const int r_hi) {
-                if (ca >= un_prev.ncand || r_lo >= r_hi) return;
+            if (!(a.debug & 2) && cj < un_prev.ncand) {
+                const mg_chunk &ck = un_prev.ck;
                 const unsigned char *img = smem + (size_t)slot * buf_bytes;
                 const float *lds_ro = (const float *)(ro_base + (size_t)slot * MG_RO_BYTES);
                 const float4 *lds_w = (const float4 *)(tb_base + (size_t)slot * MG_TB_BYTES);
                 const int *lds_mo = (const int *)(lds_w + max_nt);
                 const int col0 = ck.imin * Dp - ck.rt0 * 16;
-                const bool has1 = ca + 8 < un_prev.ncand;
-                const int c1 = has1 ? ca + 8 : ca;
-                const unsigned char *img0 = img + (size_t)(ca * stride + col0) * 4 + lane_img;
+                const bool has1 = cj + MG_WS_NCW < un_prev.ncand;
+                const int c1 = has1 ? cj + MG_WS_NCW : cj;
+                const unsigned char *img0 = img + (size_t)(cj * stride + col0) * 4 + lane_img;
                 const unsigned char *img1 = img + (size_t)(c1 * stride + col0) * 4 + lane_img;
-                const float *ro0 = lds_ro + ca * max_nt * 4, *ro1 = lds_ro + c1 * max_nt * 4;
-                float *or0 = out + (size_t)(un_prev.b0 + ca) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
+                const float *ro0 = lds_ro + cj * max_nt * 4, *ro1 = lds_ro + c1 * max_nt * 4;
+                float *or0 = out + (size_t)(un_prev.b0 + cj) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
                 float *or1 = out + (size_t)(un_prev.b0 + c1) * TD + (size_t)ck.t0 * D;
                 // two row groups x two candidates in flight per trip; the loop exists twice: with the usual row pitch
                 // (Dp = 80 floats) as a constant, and with a run-time pitch
                 auto sweep_rows = [&](auto pitch_tag) {
                 constexpr int DP4 = decltype(pitch_tag)::value;
-                for (int f0 = r_lo; f0 < r_hi; f0 += 2 * rpi) {
+                for (int f0 = 0; f0 < ck.nT; f0 += 2 * rpi) {
                     const int fla = f0 + fsub, flb = fla + rpi;
-                    const bool oa = lane_on && fla < r_hi, ob = lane_on && flb < r_hi;
-                    const int fa_ = fla < r_hi ? fla : r_hi - 1, fb_ = flb < r_hi ? flb : r_hi - 1;
+                    const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
+                    const int fa_ = fla < ck.nT ? fla : ck.nT - 1, fb_ = flb < ck.nT ? flb : ck.nT - 1;
                     float *pa0 = or0 + (size_t)f0 * D, *pa1 = or1 + (size_t)f0 * D;          // uniform
                     float *pb0 = pa0 + (size_t)rpi * D, *pb1 = pa1 + (size_t)rpi * D;
-                    if (f0 + rpi < r_hi || (a.debug & 2048)) {   // the usual trip: both row groups (flag 2048: always)
+                    if (f0 + rpi < ck.nT || (a.debug & 2048)) {   // the usual trip: both row groups (flag 2048: always)
                         f32x4 v0a, v0b, v1a, v1b;
                         if (!root_lane) {
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
@@ -532,20 +530,6 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 };
                 if (dp4 == 320 && !(a.debug & 16384)) sweep_rows(std::integral_constant<int, 320>{});
                 else sweep_rows(std::integral_constant<int, 0>{});
-            };
-            if (!(a.debug & 2)) {
-                if (a.debug & 262144) {   // one wave = two candidates, all rows (until v9)
-                    sweep_pair(cj, 0, ck.nT);
-                } else {
-                    // The two sweep waves of a SIMD (cj and cj + 4) share four candidates and split their rows: the older
-                    // wave wins the issue arbiter and would otherwise idle a fifth of the time waiting for the younger
-                    // one's unit to end, so it takes the larger part (54 : 46 for 39 rows, a multiple of the row group).
-                    const int sp = cj & 3;
-                    const int split = (((ck.nT * 27 + 49) / 50 + rpi - 1) / rpi) * rpi;
-                    const int r_lo = cj < 4 ? 0 : (split < ck.nT ? split : ck.nT), r_hi = cj < 4 ? (split < ck.nT ? split : ck.nT) : ck.nT;
-                    sweep_pair(sp, r_lo, r_hi);
-                    sweep_pair(sp + 4, r_lo, r_hi);
-                }
             }
             MG_STAMP(4);
             mg_publish(prog, wave, lane, u + 1);
