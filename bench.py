@@ -134,7 +134,12 @@ def main():
     # candidates 0 and 1: one exact-size hipMalloc each; the others: assembled from 8 / 16 / 32 MiB physical chunks (most of
     # those land in the fast placement even on boxes where single allocations never do)
     chunk_of = lambda i: 0 if i < 2 else ((8 << 20), (16 << 20), (32 << 20))[(i - 2) % 3]
-    raws = [_RawFrames(ctx.malloc(B * F * D * 4, chunk_bytes=chunk_of(i))) for i in range(placement["candidates"])]
+    def alloc_candidate(i):
+        try:
+            return ctx.malloc(B * F * D * 4, chunk_bytes=chunk_of(i))
+        except _capi.MGError:                      # no virtual-memory API on this driver: a plain allocation instead
+            return ctx.malloc(B * F * D * 4)
+    raws = [_RawFrames(alloc_candidate(i)) for i in range(placement["candidates"])]
     if len(raws) > 1:
         probe_lp = torch.empty((B,), dtype=torch.float32, device=dev)
 
