@@ -177,6 +177,26 @@ int mg_context_set_stream(mg_context *ctx, void *stream);
 /* The persistent frames kernel normally occupies every CU (one workgroup each, all of its LDS); leave n CUs free
  * so that kernels on other streams -- RCCL's all-gather of the scores -- run beside it instead of behind it. */
 int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
+/* Test and tuning switches as explicit calls (the library reads no environment variable): value 0 restores the
+ * default.  They select between kernels with identical results or change the launch geometry of grids planned
+ * AFTER the call; tests use them to cover the fallback kernels.
+ *   MG_OPT_FORCE_VALU_SCORE   1 = constraint scoring on the VALU kernel even where the MFMA kernel applies
+ *   MG_OPT_FORCE_VALU_SAMPLE  1 = mixture sampling on the VALU kernel
+ *   MG_OPT_RING_SLOTS         2 = two LDS ring slots in the frames kernel even where three fit
+ *   MG_OPT_CHUNK_WINDOW       n = at most n basis functions per time-chunk window (4 .. 11)
+ *   MG_OPT_CHUNK_SAMPLES      n = at most n time samples per chunk (1 .. 48)
+ *   MG_OPT_FRAMES_KERNEL      which LDS-staged frames kernel the MFMA path launches: 0 / 1 = tile-major (units of one
+ *                             tile's consecutive chunks, rows shared by neighbouring chunks carried over), 2 =
+ *                             chunk-stationary (a workgroup keeps one chunk's eigenvector window in registers;
+ *                             MG_ERR_UNSUPPORTED where the window does not fit) -- identical results */
+#define MG_OPT_FORCE_VALU_SCORE 0
+#define MG_OPT_FORCE_VALU_SAMPLE 1
+#define MG_OPT_RING_SLOTS 2
+#define MG_OPT_CHUNK_WINDOW 3
+#define MG_OPT_CHUNK_SAMPLES 4
+#define MG_OPT_FRAMES_KERNEL 5
+#define MG_OPT_COUNT 6
+int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
  * (0 = 64 MiB) instead of one hipMalloc each; a block is released when the last array in it has been destroyed
@@ -196,6 +216,20 @@ int mg_device_free(mg_context *ctx, void *ptr_dev);
  * two speed classes of the frames kernel ("Placement"); buffers built from 8 MiB chunks hit the
  * fast class more often than single allocations on boxes where those never do.  Freed with mg_device_free. */
 int mg_device_malloc_chunked(mg_context *ctx, int64_t bytes, int64_t chunk_bytes, void **out_dev);
+/* A buffer for a large kernel OUTPUT (the (B, T, D) frames), placed where the frames kernel's store stream runs at
+ * the fill rate.  Which part of the card's memory an allocation lands in decides between two speed classes of that
+ * stream (thousands of concurrent ~1 KB-piece streams: 63 vs 79 us for 404 MB stand-alone, 10 % of the frames
+ * kernel; a plain fill does not see the difference), whole multi-gigabyte regions are of one class, and nothing a
+ * kernel can choose -- base offset, stride, unit order -- changes the class ("Placement").  So the
+ * library probes: it allocates a candidate, times the store pattern and a plain fill on it (about 1 ms), keeps the
+ * first candidate whose ratio is in the fast class, holds the rejected ones until then (so that the next candidate
+ * comes from other memory) and frees them.  max_candidates <= 0: a default budget (up to 192 candidates, never
+ * more than half of the free device memory); if no candidate is fast the best one is returned.  info (may be NULL):
+ * [0] candidates probed, [1] pattern time / fill time of the buffer returned, [2] its pattern time in us,
+ * [3] 1 if it is in the fast class.  The contents are undefined afterwards.  Freed with mg_device_free. */
+int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out_dev, double *info4);
+/* the probe alone, on any device buffer of at least 64 MiB: info4 as above ([0] = 1) */
+int mg_device_probe_placement(mg_context *ctx, void *buf_dev, int64_t bytes, double *info4);
 int mg_memcpy_h2d(mg_context *ctx, void *dst_dev, const void *src, int64_t bytes);
 int mg_memcpy_d2h(mg_context *ctx, void *dst, const void *src_dev, int64_t bytes);
 int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);

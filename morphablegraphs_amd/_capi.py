@@ -12,11 +12,14 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MG_HIP_LIB") or os.path.join(HERE, "csrc", "libmg_hip.so")
+LIB_PATH = os.path.join(HERE, "csrc", "libmg_hip.so")   # the product library; tools pass another build to load_library(path)
 
 MG_OK = 0
 MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
+MG_OPT_FORCE_VALU_SCORE, MG_OPT_FORCE_VALU_SAMPLE, MG_OPT_RING_SLOTS, MG_OPT_CHUNK_WINDOW, MG_OPT_CHUNK_SAMPLES = 0, 1, 2, 3, 4
+MG_OPT_FRAMES_KERNEL = 5   # 0 / 1 = tile-major (default), 2 = chunk-stationary
+MG_OPT_COUNT = 6
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
@@ -25,9 +28,9 @@ PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin
 # every symbol include/mg_hip.h declares (tests check the built library exports them all)
 EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
-    "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
+    "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_set_option", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
     "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
-    "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
+    "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_get_precisions_cholesky",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
@@ -179,6 +182,9 @@ def load_library(path=None):
         "mg_context_create": [i32, vp, C.POINTER(vp)],
         "mg_context_set_stream": [vp, vp],
         "mg_context_set_reserved_cus": [vp, i32],
+        "mg_context_set_option": [vp, i32, i32],
+        "mg_device_malloc_placed": [vp, i64, i32, C.POINTER(vp), C.POINTER(dbl)],
+        "mg_device_probe_placement": [vp, vp, i64, C.POINTER(dbl)],
         "mg_device_malloc_chunked": [vp, i64, i64, C.POINTER(vp)],
         "mg_context_arena_begin": [vp, i64],
         "mg_context_arena_end": [vp],
@@ -237,7 +243,7 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if path is None:
+    if path is None or _lib is None:   # an explicit path given before first use (a tool's diagnostic build) becomes the library
         _lib = lib
     return lib
 
@@ -270,8 +276,8 @@ def _latents(a):
 class Context(object):
     """One per (process, device).  stream: raw hipStream_t (int) or None."""
 
-    def __init__(self, device=0, stream=None):
-        self.lib = load_library()
+    def __init__(self, device=0, stream=None, lib=None):
+        self.lib = lib if lib is not None else load_library()   # lib: another build loaded with load_library(path) (tools)
         h = C.c_void_p()
         _check(self.lib.mg_context_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self.handle = h
@@ -291,6 +297,10 @@ class Context(object):
     def set_reserved_cus(self, n):
         """Leave n CUs free of the persistent frames kernel (for RCCL kernels running beside it)."""
         _check(self.lib.mg_context_set_reserved_cus(self.handle, int(n)))
+
+    def set_option(self, option, value):
+        """Test / tuning switches (MG_OPT_*): explicit calls, the library reads no environment variable."""
+        _check(self.lib.mg_context_set_option(self.handle, int(option), int(value)))
 
     def arena_begin(self, block_bytes=0):
         """Until arena_end(), device constants of new primitives come out of shared blocks (one graph, one arena)."""
@@ -337,6 +347,16 @@ class Context(object):
     def malloc(self, nbytes, chunk_bytes=0):
         return DeviceBuffer(self, nbytes, chunk_bytes)
 
+    def malloc_placed(self, nbytes, max_candidates=0):
+        """A buffer for a large kernel output in the part of the card's memory where the frames kernel's store stream
+        runs at the fill rate (mg_device_malloc_placed).  .placement = {"probed", "ratio", "pattern_us", "fast"}."""
+        return DeviceBuffer(self, nbytes, placed=True, max_candidates=max_candidates)
+
+    def probe_placement(self, buf, nbytes=None):
+        info = (C.c_double * 4)()
+        _check(self.lib.mg_device_probe_placement(self.handle, _dev_ptr(buf), int(nbytes if nbytes is not None else buf.nbytes), info))
+        return {"probed": int(info[0]), "ratio": float(info[1]), "pattern_us": float(info[2]), "fast": bool(info[3])}
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         buf = DeviceBuffer(self, arr.nbytes)
@@ -378,12 +398,18 @@ class Context(object):
 
 
 class DeviceBuffer(object):
-    def __init__(self, ctx, nbytes, chunk_bytes=0):
-        """chunk_bytes > 0: assembled from separate physical chunks of that size (mg_device_malloc_chunked)."""
+    def __init__(self, ctx, nbytes, chunk_bytes=0, placed=False, max_candidates=0):
+        """chunk_bytes > 0: assembled from separate physical chunks of that size (mg_device_malloc_chunked);
+        placed: probed for the fast placement class (mg_device_malloc_placed)."""
         self.ctx = ctx
         self.nbytes = int(nbytes)
+        self.placement = None
         p = C.c_void_p()
-        if chunk_bytes:
+        if placed:
+            info = (C.c_double * 4)()
+            _check(ctx.lib.mg_device_malloc_placed(ctx.handle, self.nbytes, int(max_candidates), C.byref(p), info))
+            self.placement = {"probed": int(info[0]), "ratio": float(info[1]), "pattern_us": float(info[2]), "fast": bool(info[3])}
+        elif chunk_bytes:
             _check(ctx.lib.mg_device_malloc_chunked(ctx.handle, self.nbytes, int(chunk_bytes), C.byref(p)))
         else:
             _check(ctx.lib.mg_device_malloc(ctx.handle, self.nbytes, C.byref(p)))

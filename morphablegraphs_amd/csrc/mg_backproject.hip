@@ -27,8 +27,10 @@ struct mg_frames_args {
     int64_t B, ld;
     int32_t T, D, Dp, cshift, L, nroot, n_chunks, n_tiles, stride, max_wi, max_nt;
     int32_t debug;   // MG_DEBUG_FLAGS (ablations and timers, never set in production): 1 = producers idle, 2 = sweep idle,
-                     // 16 = per-wave phase timers, 32 = wave-0 sub-phases (serialising), 128 = no chunk rotation, 256 = no tile-round rotation
+                     // 4 = sweep stores only, 16 = per-wave phase timers, 32 = wave-0 sub-phases (serialising), 64 = row producers without MFMAs,
+                     // 128 = no chunk rotation, 256 = no tile-round rotation, 512 = row producers without E' loads, 1024 = wave 0 idle
     int32_t nbuf;    // LDS ring depth (2 or 3)
+    int32_t max_tiles;   // row tiles of the widest chunk window (chunk-stationary kernel: sizes its mean' window in LDS)
 };
 
 template <bool F64>
@@ -37,11 +39,17 @@ __device__ __forceinline__ double mg_load_lat(const void *lat, int64_t idx) {
     return (double)((const float *)lat)[idx];
 }
 
+// Ablation switches and phase timers exist only in the diagnostic build (make libmg_hip_dbg.so, -DMG_DEBUG_BUILD):
+// the product kernel carries none of their branches and never reads the environment.
+#ifdef MG_DEBUG_BUILD
+#define MG_DBG(bits) (a.debug & (bits))
 // diagnostic phase timers (MG_DEBUG_FLAGS & 16): per-wave s_memtime deltas accumulated in
 // registers over all units and written once at kernel end (a store inside the loop would put
 // the producers' loads behind it in vmcnt order and distort what is being measured).
-__device__ unsigned long long mg_dbg_stamps[16][8];   // [wave][phase] of workgroup 0
-#define MG_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+__device__ unsigned long long mg_dbg_wg[1024][2];      // [workgroup][begin, end] in 100 MHz ticks (first sweep wave)
+__device__ unsigned long long mg_dbg_stamps[16][10];   // [wave][phase] of workgroup 0; [8] = shader cycles, [9] = 100 MHz ticks of the wave
+#define MG_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime(); \
+    const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
 #define MG_STAMP(ph)                                                     \
     do {                                                                 \
         if (a.debug & 16) {                                              \
@@ -52,12 +60,19 @@ __device__ unsigned long long mg_dbg_stamps[16][8];   // [wave][phase] of workgr
     } while (0)
 #define MG_STAMP_DUMP                                                    \
     do {                                                                 \
-        if ((a.debug & 16) && blockIdx.x == 0 && lane == 0)              \
+        if ((a.debug & 16) && blockIdx.x == 0 && lane == 0) {            \
             for (int ph_ = 0; ph_ < 8; ph_++) mg_dbg_stamps[wave][ph_] = st_acc[ph_]; \
+            mg_dbg_stamps[wave][8] = __builtin_amdgcn_s_memtime() - st_c0; \
+            mg_dbg_stamps[wave][9] = __builtin_amdgcn_s_memrealtime() - st_r0; \
+        }                                                                \
+        if ((a.debug & 16) && wave == 4 && lane == 0 && blockIdx.x < 1024) { \
+            mg_dbg_wg[blockIdx.x][0] = st_r0;                            \
+            mg_dbg_wg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                \
     } while (0)
 
 extern "C" int mg_debug_dump_stamps(void) {
-    unsigned long long h[16][8];
+    unsigned long long h[16][10];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(mg_dbg_stamps), sizeof(h)) != hipSuccess) return -1;
     printf("per-wave cycles summed over the units of workgroup 0; phase p = time from stamp p-1 to stamp p\n");
     printf("  (0: loop top, 1: sweep: wait for producers, 2: row producers: tiles, 3: row producers: carried tiles / wave 0: root stage,\n"
@@ -65,10 +80,28 @@ extern "C" int mg_debug_dump_stamps(void) {
     for (int w = 0; w < 12; w++) {
         printf("wave %2d:", w);
         for (int ph = 0; ph < 8; ph++) printf(" %9llu", h[w][ph]);
-        printf("\n");
+        printf("  | %9llu cycles in %.2f us = %.3f GHz\n", h[w][8], h[w][9] / 100.0, h[w][9] ? h[w][8] / (h[w][9] * 10.0) : 0.0);
     }
+    static unsigned long long wg[1024][2];
+    if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(mg_dbg_wg), sizeof(wg)) != hipSuccess) return -1;
+    unsigned long long t0 = ~0ull;
+    int n = 0;
+    for (int i = 0; i < 1024; i++) if (wg[i][1]) { n++; if (wg[i][0] < t0) t0 = wg[i][0]; }
+    printf("sweep wave 4 of every workgroup, us after the first one began: begin / end\n");
+    for (int i = 0; i < 1024; i++) {
+        if (!wg[i][1]) continue;
+        if (i % 8 == 0) printf("\n  wg %3d:", i);
+        printf(" %5.1f/%5.1f", (wg[i][0] - t0) / 100.0, (wg[i][1] - t0) / 100.0);
+    }
+    printf("\n");
     return 0;
 }
+#else
+#define MG_DBG(bits) 0
+#define MG_STAMP_DECL
+#define MG_STAMP(ph) do { } while (0)
+#define MG_STAMP_DUMP do { } while (0)
+#endif
 
 // -----------------------------------------------------------------------------------------
 // The hot-path kernel: persistent, wave-specialised.
@@ -253,12 +286,20 @@ __device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {
 template <int KK>
 __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, const float *__restrict__ mean32,
                                                const mg_chunk &ck, float *lds_c, int stride, int t_first, int pw, int npw,
-                                               const float (&sfrag)[KK], int lane, int cl, int g, int rot = 0) {
+                                               const float (&sfrag)[KK], int lane, int cl, int g, int rot = 0, int dbg = 0) {
     float2 fa[2][KK / 2], na[2][KK / 2];
     f32x4 fm[2], nm[2];
     auto load_tile = [&](int t, float2(&fr)[KK / 2], f32x4 &cin) {
         const int tc = t < ck.ntiles ? t : ck.ntiles - 1;   // clamp: redundant but in bounds
         const float2 *p = ep + ((size_t)(ck.rt0 + tc) * (KK / 2)) * 64 + lane;
+#ifdef MG_DEBUG_BUILD
+        if (dbg & 512) {   // ablation: no E' loads (with 32768 in the caller: on every other unit)
+#pragma unroll
+            for (int q = 0; q < KK / 2; q++) fr[q] = make_float2(0.5f, 0.25f);
+            cin = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+#endif
 #pragma unroll
         for (int q = 0; q < KK / 2; q++) fr[q] = p[q * 64];
         cin = *(const f32x4 *)(mean32 + (size_t)(ck.rt0 + tc) * 16 + 4 * g);
@@ -279,6 +320,12 @@ __device__ __forceinline__ void mg_produce_f32(const float2 *__restrict__ ep, co
         load_tile(tn, na[0], nm[0]);
         load_tile(tn + npw, na[1], nm[1]);
         f32x4 acc0 = fm[0], acc1 = fm[1];
+#ifdef MG_DEBUG_BUILD
+        if (dbg & 64) {   // ablation: no MFMAs (the loaded fragments stay live)
+#pragma unroll
+            for (int q = 0; q < KK / 2; q++) { asm volatile("" :: "v"(fa[0][q].x), "v"(fa[0][q].y), "v"(fa[1][q].x), "v"(fa[1][q].y)); }
+        } else
+#endif
 #pragma unroll
         for (int q = 0; q < KK / 2; q++) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0][q].x, sfrag[2 * q], acc0, 0, 0, 0);
@@ -407,7 +454,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     // When this workgroup owns whole tiles it walks each tile's chunks starting at chunk (blockIdx mod n_chunks): the
     // workgroups run nearly in lockstep, and without the rotation all 256 of them request the same E' rows from L2 at
     // the same time, the cold first unit above all (-2 % kernel time; MG_DEBUG_FLAGS & 128 switches it off).
-    const int rot = (!(a.debug & 128) && cur.chunk == 0 && (n_units % a.n_chunks) == 0) ? (int)(blockIdx.x % a.n_chunks) : 0;
+    const int rot = (!MG_DBG(128) && cur.chunk == 0 && (n_units % a.n_chunks) == 0) ? (int)(blockIdx.x % a.n_chunks) : 0;
     const int cl = lane & 15, g = lane >> 4;
 
     if (wave >= MG_WS_NPW) {
@@ -429,7 +476,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         // When every quad lane holds four floats and the root lane three (D = 79: 3 + 19 x 4), the root lane borrows the
         // row's channel 3 from quad lane 0 (a cross-lane read) and ALL lanes store four floats with one instruction;
         // the float written twice carries the same value.  Otherwise lanes store 4 / 3 / 2 / 1 floats by class.
-        const bool all4 = nroot == 3 && ((D - nroot) & 3) == 0 && !(a.debug & 8192);
+        const bool all4 = nroot == 3 && ((D - nroot) & 3) == 0 && !MG_DBG(8192);
         const int q0_lane = (lane - nql) << 2;            // byte index of this row's quad lane 0 for ds_bpermute
         const unsigned lane_out_b = (unsigned)lane_out * 4u;
         int slot = 0;
@@ -439,7 +486,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             mg_cursor_next(cur, a.n_chunks);
             mg_wait_producers(prog, u + 1);
             MG_STAMP(1);
-            if (!(a.debug & 2) && cj < un_prev.ncand) {
+            if (!MG_DBG(2) && cj < un_prev.ncand) {
                 const mg_chunk &ck = un_prev.ck;
                 const unsigned char *img = smem + (size_t)slot * buf_bytes;
                 const float *lds_ro = (const float *)(ro_base + (size_t)slot * MG_RO_BYTES);
@@ -463,12 +510,14 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     const int fa_ = fla < ck.nT ? fla : ck.nT - 1, fb_ = flb < ck.nT ? flb : ck.nT - 1;
                     float *pa0 = or0 + (size_t)f0 * D, *pa1 = or1 + (size_t)f0 * D;          // uniform
                     float *pb0 = pa0 + (size_t)rpi * D, *pb1 = pa1 + (size_t)rpi * D;
-                    if (f0 + rpi < ck.nT || (a.debug & 2048)) {   // the usual trip: both row groups (flag 2048: always)
+                    if (f0 + rpi < ck.nT || MG_DBG(2048)) {   // the usual trip: both row groups (flag 2048: always)
                         f32x4 v0a, v0b, v1a, v1b;
-                        if (!root_lane) {
+                        if (MG_DBG(4)) {   // ablation: stores only
+                            v0a = v0b = v1a = v1b = f32x4{1.f, 2.f, 3.f, 4.f};
+                        } else if (!root_lane) {
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
-                            if (a.debug & 131072) {
+                            if (MG_DBG(131072)) {
                                 v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
                                 v0b = mg_quad_taps_t<DP4>(img0 + mob, wb, dp4);
                                 v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
@@ -488,7 +537,12 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
                             v1b = *(const f32x4 *)&ro1[fb_ * 4];
                         }
-                        if (all4) {
+                        if (all4 && MG_DBG(4)) {
+                            if (oa) mg_store4_at(pa0, lane_out_b, v0a);
+                            if (ob) mg_store4_at(pb0, lane_out_b, v0b);
+                            if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
+                            if (ob && has1) mg_store4_at(pb1, lane_out_b, v1b);
+                        } else if (all4) {
                             const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
                             const float b0b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0b[0])));
                             const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
@@ -528,7 +582,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     }
                 }
                 };
-                if (dp4 == 320 && !(a.debug & 16384)) sweep_rows(std::integral_constant<int, 320>{});
+                if (dp4 == 320 && !MG_DBG(16384)) sweep_rows(std::integral_constant<int, 320>{});
                 else sweep_rows(std::integral_constant<int, 0>{});
             }
             MG_STAMP(4);
@@ -553,7 +607,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             mg_cursor_next(cur, a.n_chunks);
             if (u >= nbuf) mg_wait_consumers(prog, u - nbuf + 1);   // the slot's previous unit has been swept
             MG_STAMP(5);
-            if (!(a.debug & 1)) {
+            if (!MG_DBG(1)) {
                 const mg_chunk &ck = un.ck;
                 float *lds_c = (float *)(smem + (size_t)slot * buf_bytes);
                 if (un.tile != cur_tile) {
@@ -573,10 +627,12 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     n_ov = pk.rt0 + pk.ntiles - ck.rt0;   // tiles [ck.rt0, pk.rt0 + pk.ntiles) exist in the previous slot
                     n_ov = (n_ov < 0 || src_shift < 0) ? 0 : (n_ov > ck.ntiles ? ck.ntiles : n_ov);   // a grid may run backwards
                 }
+                if (MG_DBG(4096)) n_ov = 0;   // ablation: no carried-over tiles (every window computed in full)
                 // this slot held unit u - nbuf and was the copy source of unit u - nbuf + 1: every row producer must
                 // have finished that unit before the slot is overwritten (with two slots: a full meeting per unit)
                 if (u >= nbuf - 1) mg_wait_row_producers(prog, u - nbuf + 2);
-                mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, n_ov, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g, (a.debug & 256) ? 0 : (int)(blockIdx.x / a.n_chunks));
+                mg_produce_f32<KK>(ep, mean32, ck, lds_c, stride, n_ov, wave - 1, MG_WS_NPW - 1, sfrag, lane, cl, g, MG_DBG(256) ? 0 : (int)(blockIdx.x / a.n_chunks),
+                                   (MG_DBG(32768) && (u & 1)) ? (a.debug | 512) : a.debug);   // 32768: E' loads on every other unit only
                 MG_STAMP(2);
                 if (n_ov > 0) {
                     mg_wait_row_producers(prog, u);   // the previous unit's window is complete
@@ -626,7 +682,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) r_wt[e] = wtap[((size_t)un.chunk * (MG_TAP_FT * MG_TAP_KS) + e) * 64 + lane];
             typename mg_gmm_xt<LAT_F64>::type s64frag[KK];   // widened to float64 at the MFMA
             mg_gmm_load_x<KK, LAT_F64>(s64frag, lat, un.b0, un.ncand, a.ld, L, cl, g);
-            if (a.debug & 32) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MG_STAMP(1); }
+            if (MG_DBG(32)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MG_STAMP(1); }
             // up to 3 root tiles (8 basis functions x 3 channels = 24 rows, rr = i*nroot + d), chains
             // interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
             f64x4 racc[3];
@@ -673,7 +729,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     if (t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) rs[cl * root_stride + lr] = racc[t][r];
                 }
             }
-            if (a.debug & 32) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); MG_STAMP(2); }
+            if (MG_DBG(32)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); MG_STAMP(2); }
             // root taps, again on the float64 matrix pipe: out[f][(c,d)] = sum_m W[f][m] * rows[m][(c,d)] with the
             // banded W[f][m] = w[f][m - m0(f)] (0 outside the 4 taps) pre-packed per chunk as A fragments.  The zero
             // products leave the accumulator untouched and the taps are met in ascending m, so the result is
@@ -705,7 +761,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                             if (tap_o_off[ct] >= 0 && fo < ck.nT) ro[tap_o_off[ct] + fo * 4] = (float)acc[ct][r];
                         }
                 }
-                if ((a.debug & 32) && ft == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MG_STAMP(6); }
+                if (MG_DBG(32) && ft == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); MG_STAMP(6); }
             }
         };
         int slot = 0;
@@ -715,7 +771,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             mg_cursor_next(cur, a.n_chunks);
             if (u >= nbuf) mg_wait_consumers(prog, u - nbuf + 1);
             MG_STAMP(5);
-            if (!(a.debug & 1)) root_stage(un, slot);
+            if (!MG_DBG(1) && !MG_DBG(1024)) root_stage(un, slot);
             MG_STAMP(3);
             mg_publish(prog, wave, lane, u + 1);
             if (++slot == nbuf) slot = 0;
@@ -733,6 +789,498 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             mg_wait_producers(prog + 24, 1);   // gfin[0], gfin[1] (entries 2, 3 are preset): both term buffers are free again
             mg_fused_gmm_terms<KK, LAT_F64>(prog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 1);
             if (wave < 2) mg_fused_gmm_finish(prog, logp, a.B, a.n_tiles, gK, wave, lane, 1);
+        }
+    }
+}
+
+
+// -----------------------------------------------------------------------------------------
+// The chunk-stationary variant of the hot-path kernel, for batches of many tiles per CU.
+//
+// What the tile-major kernel above pays for besides its stores was measured with the diagnostic build's
+// ablations in the fast placement class (tools/ab.py; B = 8192, 'walk'): the E' fragment loads of the row
+// producers cost 9-13 us of 84-93 -- not as bytes (189 MB of L2 hits per launch) but because every activity
+// on the chip lowers the clock it holds: 2.05 GHz for the whole kernel, 2.32 GHz without those loads,
+// 2.15 GHz without the MFMAs (per-wave s_memtime / s_memrealtime).  So E' must not travel at all:
+//   * a workgroup works on ONE time chunk for its whole life (workgroup w: chunk w mod n_chunks) and walks
+//     a block of consecutive candidate tiles; its row producers load the chunk's whole window of E' fragments
+//     ONCE into registers (512-thread workgroups: 2 waves per SIMD, 256 VGPRs; 3 row producers x 17 row tiles
+//     x KK floats) and every unit is MFMAs on registers + LDS writes, no vector-memory read but the 2.5 KB of
+//     latents (prefetched a unit ahead);
+//   * consecutive units are different tiles, so no window rows carry over: each unit computes its full window
+//     (51 instead of 36 row tiles for 'walk': +42 % MFMAs, which cost less clock than the loads they replace;
+//     emulated with the ablation flags: 82.3 vs 93.3 us) and the LDS -> LDS copies disappear;
+//   * the per-sample tables, the tap weights and the root rows' float64 fragments are stationary as well
+//     (loaded once by wave 0), mean' sits in LDS as the MFMAs' C-in;
+//   * wave 0 = root producer, waves 1-3 = row producers, waves 4-7 = sweep, four candidates each (wave j:
+//     j, j + 4, j + 8, j + 12; a trip = two row groups x two candidate pairs = 8 store instructions, so the
+//     chip still writes 4096 streams); same ring of two LDS slots, same progress counters, same arithmetic:
+//     the results are bit-identical to the tile-major kernel's.
+// Store order: at any moment the 4 workgroups of a group write the 4 chunks of the same tile, groups are 8 tiles
+// apart (stand-alone replica of this order: 64-65 us against 62-64 us for the tile-major order, tools/chan_probe.hip
+// mode 3).
+// -----------------------------------------------------------------------------------------
+#define MG_CS_NPW 4      // producer waves (0: root + latents, 1-3: rows)
+#define MG_CS_NCW 8      // sweep waves, two candidates each; they also produce a few row tiles per unit
+#define MG_CS_NSP 4      // the first (oldest, fastest) sweep waves produce row tiles as well; the others only sweep
+#define MG_CS_BLOCK (64 * (MG_CS_NPW + MG_CS_NCW))
+template <int KK> struct mg_cs_cfg {
+    static constexpr int TPWP = 120 / KK < 17 ? 120 / KK : 17;   // row tiles a row producer keeps in registers (TPWP * KK VGPRs)
+    static constexpr int TPWS = 40 / KK < 5 ? (40 / KK > 0 ? 40 / KK : 1) : 5;   // row tiles a producing sweep wave keeps in registers
+    static constexpr int MAX_TILES = (MG_CS_NPW - 1) * TPWP + MG_CS_NSP * TPWS;
+};
+int mg_cs_max_tiles(int KK) {
+    switch (KK) {
+        case 2: return mg_cs_cfg<2>::MAX_TILES;   case 4: return mg_cs_cfg<4>::MAX_TILES;   case 6: return mg_cs_cfg<6>::MAX_TILES;
+        case 8: return mg_cs_cfg<8>::MAX_TILES;   case 10: return mg_cs_cfg<10>::MAX_TILES; case 12: return mg_cs_cfg<12>::MAX_TILES;
+        case 14: return mg_cs_cfg<14>::MAX_TILES; case 16: return mg_cs_cfg<16>::MAX_TILES; default: return 0;
+    }
+}
+
+// progress counters of the chunk-stationary kernel (LDS ints): [0..11] units produced by wave w (every wave produces
+// row tiles; wave 0 the root rows), [12] latent tiles staged by wave 0, [16..23] units swept by sweep wave 4 + i;
+// the mixture's hand-off uses [32..63]
+#define MG_CS_PROG_LAT 12
+#define MG_CS_PROG_SWEPT 16
+#define MG_CS_PROG_GMM 32
+#define MG_CS_PROG_INTS 64
+__device__ __forceinline__ void mg_cs_wait_produced(const mg_lds_int *prog, int target) {   // the eight producing waves
+    for (;;) {
+        const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
+        const i32x4 x = *(const volatile mg_lds_i32x4 *)(prog + 4);
+        const int m = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(x[0], x[1]), min(x[2], x[3])));
+        if (__builtin_amdgcn_readfirstlane(m) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void mg_cs_wait_swept(const mg_lds_int *prog, int target) {   // the eight sweep waves
+    for (;;) {
+        const i32x4 v = *(const volatile mg_lds_i32x4 *)(prog + MG_CS_PROG_SWEPT);
+        const i32x4 x = *(const volatile mg_lds_i32x4 *)(prog + MG_CS_PROG_SWEPT + 4);
+        const int m = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(x[0], x[1]), min(x[2], x[3])));
+        if (__builtin_amdgcn_readfirstlane(m) >= target) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void mg_cs_wait_latents(const mg_lds_int *prog, int target) {
+    for (;;) {
+        const int v = *(const volatile mg_lds_int *)(prog + MG_CS_PROG_LAT);
+        if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+// NT row tiles t = first + step * i (i < NT, t < ntiles) of a unit: D = E' tile . latent tile + mean', the E' fragments in
+// registers, the latent tile's B fragments and mean' (C-in) from LDS; chains of two tiles interleaved
+template <int KK, int NT>
+__device__ __forceinline__ void mg_cs_produce(const float (&ef)[NT][KK], const float *lds_lat, const float *lds_mean, float *lds_c,
+                                              int stride, int first, int step, int ntiles, int lane, int cl, int g) {
+    if (first >= ntiles) return;
+    float sfrag[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) sfrag[kk] = lds_lat[kk * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < NT; i += 2) {
+        const int t0 = first + step * i, t1 = t0 + step;
+        if (t0 < ntiles) {
+            const int i1 = (i + 1 < NT) ? i + 1 : i;
+            const bool on1 = (i + 1 < NT) && t1 < ntiles;
+            f32x4 acc0 = *(const f32x4 *)&lds_mean[t0 * 16 + 4 * g];
+            if (on1) {
+                f32x4 acc1 = *(const f32x4 *)&lds_mean[t1 * 16 + 4 * g];
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[i][kk], sfrag[kk], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[i1][kk], sfrag[kk], acc1, 0, 0, 0);
+                }
+                *(f32x4 *)&lds_c[cl * stride + t0 * 16 + 4 * g] = acc0;   // D[row = 4g + reg][col = cl]: four consecutive padded rows
+                *(f32x4 *)&lds_c[cl * stride + t1 * 16 + 4 * g] = acc1;
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[i][kk], sfrag[kk], acc0, 0, 0, 0);
+                *(f32x4 *)&lds_c[cl * stride + t0 * 16 + 4 * g] = acc0;
+            }
+        }
+    }
+}
+template <int KK, int NT>
+__device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const float2 *ep, const float *mean32, float *lds_mean,
+                                                     const mg_chunk &ck, int first, int step, int lane) {
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int t = first + step * i;
+        const int tc = t < ck.ntiles ? t : ck.ntiles - 1;   // clamp: redundant but in bounds
+        const float2 *p = ep + ((size_t)(ck.rt0 + tc) * (KK / 2)) * 64 + lane;
+#pragma unroll
+        for (int q2 = 0; q2 < KK / 2; q2++) {
+            const float2 v = p[q2 * 64];
+            ef[i][2 * q2] = v.x;
+            ef[i][2 * q2 + 1] = v.y;
+        }
+        if (t < ck.ntiles && lane < 16) lds_mean[t * 16 + lane] = mean32[(size_t)(ck.rt0 + t) * 16 + lane];
+    }
+}
+
+template <int KK, bool LAT_F64, bool FUSE_GMM>
+__global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
+    const float *__restrict__ Epack,      // [RT][KK/2][64][2]
+    const float *__restrict__ mean32,     // [RT*16]
+    const double *__restrict__ Erpack,    // [RRT][KK][64]
+    const double *__restrict__ meanroot,  // [RRT*16]
+    const void *__restrict__ lat,         // (B, ld) f32 or f64
+    const int32_t *__restrict__ i0tab,    // (T)
+    const float4 *__restrict__ w32,       // (T)
+    const double *__restrict__ wtap,      // [n_chunks][FT][KS][64]
+    const mg_chunk *__restrict__ chunks,
+    float *__restrict__ out,              // (B,T,D)
+    const double *__restrict__ gPpack, const double *__restrict__ gmP, const double *__restrict__ gcst,
+    float *__restrict__ logp,             // FUSE_GMM: (B) log p(s_b)
+    const mg_frames_args a, const int gK, const int gJT, const int buf_bytes) {
+    constexpr int TPWP = mg_cs_cfg<KK>::TPWP, TPWS = mg_cs_cfg<KK>::TPWS;
+    constexpr int NRP = MG_CS_NPW - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
+    const int root_stride = a.max_wi * nroot + 1;
+    const int max_nt = a.max_nt;
+    const int RO_BYTES = MG_RO_BYTES_N(max_nt), TB_BYTES = MG_TB_BYTES_N(max_nt);
+    unsigned char *ro_base = smem + 2 * (size_t)buf_bytes;             // root outputs, one per ring slot
+    unsigned char *tb_base = ro_base + 2 * RO_BYTES;                   // per-sample tables of THE chunk
+    unsigned char *rs_base = tb_base + TB_BYTES;                       // float64 root image (wave 0 only)
+    float *lds_mean = (float *)(rs_base + (size_t)MG_NCAND * root_stride * 8);   // mean' of the window's rows [max_tiles * 16]
+    double *lds_rwt = (double *)((unsigned char *)lds_mean + (size_t)a.max_tiles * 64);   // the chunk's banded tap weights [FT * KS][64]
+    float *lds_latb = (float *)(lds_rwt + MG_TAP_FT * MG_TAP_KS * 64);                   // latent tiles as MFMA B fragments [2][KK][64]
+    mg_lds_int *prog = (mg_lds_int *)(lds_latb + 2 * KK * 64);                           // MG_CS_PROG_INTS counters, then the mixture's buffers
+    if (tid < MG_CS_PROG_INTS) prog[tid] = (tid == MG_CS_PROG_GMM + 26 || tid == MG_CS_PROG_GMM + 27) ? 0x7fffffff : 0;
+
+    // workgroup w: chunk w mod n_chunks; the Q workgroups of a chunk share the tiles out in consecutive blocks
+    const int n_chunks = a.n_chunks;
+    const int c = (int)(blockIdx.x % (unsigned)n_chunks), q = (int)(blockIdx.x / (unsigned)n_chunks);
+    const int Q = ((int)gridDim.x - 1 - c) / n_chunks + 1;
+    const int t_begin = (int)((int64_t)q * a.n_tiles / Q), t_end = (int)((int64_t)(q + 1) * a.n_tiles / Q);
+    const int n_units = t_end - t_begin;
+    const mg_chunk ck = chunks[c];
+    const int cl = lane & 15, g = lane >> 4;
+    const int nt_p = ck.ntiles < NRP * TPWP ? ck.ntiles : NRP * TPWP;   // tiles [0, nt_p): row producers; [nt_p, ntiles): sweep waves
+    const float2 *ep = (const float2 *)Epack;
+
+    if (wave >= MG_CS_NPW) {
+        // ================= sweep waves: two candidates each + TPWS row tiles of the NEXT unit, produced at half time =================
+        const int cj = wave - MG_CS_NPW;                  // candidates cj and cj + 8
+        float ef[TPWS][KK];
+        const bool producing = cj < MG_CS_NSP;
+        mg_cs_load_fragments<KK, TPWS>(ef, ep, mean32, lds_mean, ck, producing ? nt_p + cj : ck.ntiles, MG_CS_NSP, lane);
+        const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
+        const int gl = nql + 1;                           // + the root lane
+        const int rpi = 64 / gl;                          // samples per wave instruction
+        const int fsub = lane / gl, ql = lane - fsub * gl;
+        const bool lane_on = lane < rpi * gl;
+        const bool root_lane = ql == nql;
+        const int d0 = root_lane ? 0 : nroot + 4 * ql;    // first channel of this lane
+        const int nst = root_lane ? nroot : (D - d0 < 4 ? D - d0 : 4);
+        const int64_t TD = (int64_t)a.T * D;
+        const int dp4 = Dp * 4;
+        const int lane_img = (d0 + a.cshift) * 4;         // byte offset of the lane's quad inside a basis row
+        const int lane_out = fsub * D + d0;               // float offset inside a row group
+        const bool all4 = nroot == 3 && ((D - nroot) & 3) == 0;   // every lane stores four floats (see the tile-major kernel)
+        const int q0_lane = (lane - nql) << 2;            // byte index of this row's quad lane 0 for ds_bpermute
+        const unsigned lane_out_b = (unsigned)lane_out * 4u;
+        const float4 *lds_w = (const float4 *)tb_base;
+        const int *lds_mo = (const int *)(lds_w + max_nt);
+        const int col0 = ck.imin * Dp - ck.rt0 * 16;
+        const int ntrips = (ck.nT + 2 * rpi - 1) / (2 * rpi);
+        const int f_half = ((ntrips + 1) / 2) * 2 * rpi;   // first sample of the second half of a unit's trips
+        __syncthreads();   // counters, tables, mean' window
+        MG_STAMP_DECL
+        if (n_units > 0 && producing) {   // this wave's tiles of the first unit
+            mg_cs_wait_latents(prog, 1);
+            mg_cs_produce<KK, TPWS>(ef, lds_latb, lds_mean, (float *)smem, stride, nt_p + cj, MG_CS_NSP, ck.ntiles, lane, cl, g);
+            mg_publish(prog, wave, lane, 1);
+        }
+        for (int u = 0; u < n_units; u++) {
+            MG_STAMP(0);
+            const int64_t b0 = (int64_t)(t_begin + u) * MG_NCAND;
+            const int ncand = (int)((a.B - b0) < MG_NCAND ? (a.B - b0) : MG_NCAND);
+            mg_cs_wait_produced(prog, u + 1);
+            MG_STAMP(1);
+            const int slot = u & 1;
+            const unsigned char *img = smem + (size_t)slot * buf_bytes;
+            const float *lds_ro = (const float *)(ro_base + (size_t)slot * RO_BYTES);
+            const bool has1 = cj + 8 < ncand;
+            const int c1 = has1 ? cj + 8 : cj;
+            const unsigned char *img0 = img + (size_t)(cj * stride + col0) * 4 + lane_img;
+            const unsigned char *img1 = img + (size_t)(c1 * stride + col0) * 4 + lane_img;
+            const float *ro0 = lds_ro + cj * max_nt * 4, *ro1 = lds_ro + c1 * max_nt * 4;
+            float *or0 = out + (size_t)(b0 + cj) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
+            float *or1 = out + (size_t)(b0 + c1) * TD + (size_t)ck.t0 * D;
+            auto sweep_rows = [&](auto pitch_tag, int f_first, int f_last) {
+                constexpr int DP4 = decltype(pitch_tag)::value;
+                for (int f0 = f_first; f0 < f_last; f0 += 2 * rpi) {
+                    const int fla = f0 + fsub, flb = fla + rpi;
+                    const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
+                    const int fa_ = fla < ck.nT ? fla : ck.nT - 1, fb_ = flb < ck.nT ? flb : ck.nT - 1;
+                    float *pa0 = or0 + (size_t)f0 * D, *pa1 = or1 + (size_t)f0 * D;          // uniform
+                    float *pb0 = pa0 + (size_t)rpi * D, *pb1 = pa1 + (size_t)rpi * D;
+                    if (f0 + rpi < ck.nT) {   // the usual trip: both row groups
+                        f32x4 v0a, v0b, v1a, v1b;
+                        if (MG_DBG(4)) {   // ablation: stores only
+                            v0a = v0b = v1a = v1b = f32x4{1.f, 2.f, 3.f, 4.f};
+                        } else if (!root_lane) {   // all 16 tap rows are requested before the first FMA
+                            const float4 wa = lds_w[fa_], wb = lds_w[fb_];
+                            const int moa = lds_mo[fa_], mob = lds_mo[fb_];
+                            const mg_tap_rows r0a = mg_quad_load<DP4>(img0 + moa, dp4), r0b = mg_quad_load<DP4>(img0 + mob, dp4);
+                            const mg_tap_rows r1a = mg_quad_load<DP4>(img1 + moa, dp4), r1b = mg_quad_load<DP4>(img1 + mob, dp4);
+                            __builtin_amdgcn_sched_barrier(0);
+                            v0a = mg_quad_fma(r0a, wa);
+                            v0b = mg_quad_fma(r0b, wb);
+                            v1a = mg_quad_fma(r1a, wa);
+                            v1b = mg_quad_fma(r1b, wb);
+                        } else {
+                            v0a = *(const f32x4 *)&ro0[fa_ * 4];
+                            v0b = *(const f32x4 *)&ro0[fb_ * 4];
+                            v1a = *(const f32x4 *)&ro1[fa_ * 4];
+                            v1b = *(const f32x4 *)&ro1[fb_ * 4];
+                        }
+                        if (all4 && MG_DBG(4)) {
+                            if (oa) mg_store4_at(pa0, lane_out_b, v0a);
+                            if (ob) mg_store4_at(pb0, lane_out_b, v0b);
+                            if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
+                            if (ob && has1) mg_store4_at(pb1, lane_out_b, v1b);
+                        } else if (all4) {
+                            const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
+                            const float b0b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0b[0])));
+                            const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
+                            const float b1b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1b[0])));
+                            if (root_lane) { v0a[3] = b0a; v0b[3] = b0b; v1a[3] = b1a; v1b[3] = b1b; }
+                            if (oa) mg_store4_at(pa0, lane_out_b, v0a);
+                            if (ob) mg_store4_at(pb0, lane_out_b, v0b);
+                            if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
+                            if (ob && has1) mg_store4_at(pb1, lane_out_b, v1b);
+                        } else {
+                            if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
+                            if (ob) mg_store_n(pb0 + lane_out, v0b, nst);
+                            if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                            if (ob && has1) mg_store_n(pb1 + lane_out, v1b, nst);
+                        }
+                    } else {                                     // the chunk's last rows fill one group only: half the work
+                        f32x4 v0a, v1a;
+                        if (!root_lane) {
+                            const float4 wa = lds_w[fa_];
+                            const int moa = lds_mo[fa_];
+                            v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
+                            v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
+                        } else {
+                            v0a = *(const f32x4 *)&ro0[fa_ * 4];
+                            v1a = *(const f32x4 *)&ro1[fa_ * 4];
+                        }
+                        if (all4) {
+                            const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
+                            const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
+                            if (root_lane) { v0a[3] = b0a; v1a[3] = b1a; }
+                            if (oa) mg_store4_at(pa0, lane_out_b, v0a);
+                            if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
+                        } else {
+                            if (oa) mg_store_n(pa0 + lane_out, v0a, nst);
+                            if (oa && has1) mg_store_n(pa1 + lane_out, v1a, nst);
+                        }
+                    }
+                }
+            };
+            const bool mine = cj < ncand && !MG_DBG(2);
+            if (mine) {
+                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, 0, f_half);
+                else sweep_rows(std::integral_constant<int, 0>{}, 0, f_half);
+            }
+            MG_STAMP(2);
+            if (u + 1 < n_units && producing) {
+                // half time: this wave's row tiles of the next unit, into the slot the unit before this one was swept from
+                mg_cs_wait_swept(prog, u);
+                mg_cs_wait_latents(prog, u + 2);
+                MG_STAMP(3);
+                mg_cs_produce<KK, TPWS>(ef, lds_latb + ((u + 1) & 1) * KK * 64, lds_mean, (float *)(smem + (size_t)((u + 1) & 1) * buf_bytes), stride,
+                                        nt_p + cj, MG_CS_NSP, ck.ntiles, lane, cl, g);
+                mg_publish(prog, wave, lane, u + 2);
+            }
+            if (mine) {
+                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, f_half, ck.nT);
+                else sweep_rows(std::integral_constant<int, 0>{}, f_half, ck.nT);
+            }
+            MG_STAMP(4);
+            mg_publish(prog + MG_CS_PROG_SWEPT, cj, lane, u + 1);
+            MG_STAMP(5);
+        }
+        MG_STAMP_DUMP;
+    } else if (wave != 0) {
+        // ================= row producers (waves 1..3): TPWP row tiles each, the fragments in registers =================
+        const int pw = wave - 1;
+        float ef[TPWP][KK];
+        mg_cs_load_fragments<KK, TPWP>(ef, ep, mean32, lds_mean, ck, pw, NRP, lane);
+        __syncthreads();   // counters, tables, mean' window
+        MG_STAMP_DECL
+        for (int u = 0; u < n_units; u++) {
+            MG_STAMP(0);
+            if (u >= 2) mg_cs_wait_swept(prog, u - 1);   // the slot's previous unit has been swept
+            mg_cs_wait_latents(prog, u + 1);
+            MG_STAMP(5);
+            if (!MG_DBG(1))
+                mg_cs_produce<KK, TPWP>(ef, lds_latb + (u & 1) * KK * 64, lds_mean, (float *)(smem + (size_t)(u & 1) * buf_bytes), stride, pw, NRP, nt_p,
+                                        lane, cl, g);
+            MG_STAMP(2);
+            mg_publish(prog, wave, lane, u + 1);
+            MG_STAMP(4);
+        }
+        MG_STAMP_DUMP;
+    } else {
+        // ================= wave 0: the chunk's tables (once); per unit the latent tile -> LDS, root rows and root taps (f64 MFMA) =================
+        {
+            float4 *tw = (float4 *)tb_base;
+            int *tmo = (int *)(tw + max_nt);
+            if (lane < ck.nT) {
+                tw[lane] = w32[ck.t0 + lane];
+                tmo[lane] = (i0tab[ck.t0 + lane] - ck.imin) * Dp * 4;   // byte offset of the first tap row in the f32 image
+            }
+        }
+        int tap_b_off[3][MG_TAP_KS], tap_o_off[3];
+        bool tap_b_ok[3][MG_TAP_KS];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+            const int col = ct * 16 + cl;
+            const bool colok = col < MG_NCAND * nroot;
+            const int cc = colok ? col / nroot : 0, cd = colok ? col - cc * nroot : 0;
+            tap_o_off[ct] = colok ? cc * max_nt * 4 + cd : -1;
+#pragma unroll
+            for (int ks = 0; ks < MG_TAP_KS; ks++) {
+                const int m = 4 * ks + g;
+                tap_b_ok[ct][ks] = colok && m < ck.wi;   // rows at or beyond the window were never written: 0 * stale LDS could be NaN
+                tap_b_off[ct][ks] = cc * root_stride + m * nroot + cd;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) lds_rwt[e * 64 + lane] = wtap[((size_t)c * (MG_TAP_FT * MG_TAP_KS) + e) * 64 + lane];
+        const double *rpp[3];
+        const double *rmp[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int tc = t < ck.nrt ? t : ck.nrt - 1;
+            rpp[t] = Erpack + ((size_t)(ck.rrt0 + tc) * KK) * 64 + lane;
+            rmp[t] = meanroot + (ck.rrt0 + tc) * 16 + g;
+        }
+        // the root rows' float64 fragments stay in registers as well where the budget allows (6 KK VGPRs)
+        constexpr bool RR = KK <= 10;
+        double rp_reg[3][RR ? KK : 1];
+        if (RR) {
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+#pragma unroll
+                for (int q2 = 0; q2 < KK; q2++) rp_reg[t][RR ? q2 : 0] = rpp[t][q2 * 64];
+        }
+        auto load_latents = [&](typename mg_gmm_xt<LAT_F64>::type (&x)[KK], int u) {
+            int t = t_begin + (u < n_units ? u : n_units - 1);    // clamped: the prefetch of the unit after the last one,
+            t = t < 0 ? 0 : (t >= a.n_tiles ? a.n_tiles - 1 : t);  // a workgroup without units
+            const int64_t b0 = (int64_t)t * MG_NCAND;
+            const int ncand = (int)((a.B - b0) < MG_NCAND ? (a.B - b0) : MG_NCAND);
+            mg_gmm_load_x<KK, LAT_F64>(x, lat, b0, ncand, a.ld, L, cl, g);
+        };
+        typename mg_gmm_xt<LAT_F64>::type s64frag[KK], s64next[KK];
+        load_latents(s64next, 0);
+        __syncthreads();   // counters, tables, mean' window
+        double *rs = (double *)rs_base;
+        MG_STAMP_DECL
+        for (int u = 0; u < n_units; u++) {
+            MG_STAMP(0);
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) s64frag[kk] = s64next[kk];
+            if (u >= 2) mg_cs_wait_swept(prog, u - 1);   // every wave is done with the slot's previous unit: image, root outputs, latent tile
+            MG_STAMP(5);
+            {   // the latent tile as float32 MFMA B fragments for all the other waves
+                float *lb = lds_latb + (u & 1) * KK * 64;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) lb[kk * 64 + lane] = (float)s64frag[kk];
+                mg_publish(prog, MG_CS_PROG_LAT, lane, u + 1);
+            }
+            load_latents(s64next, u + 1);   // a unit ahead
+            // up to 3 root tiles (rows rr = i*nroot + d), chains interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
+            f64x4 racc[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) racc[t] = f64x4{rmp[t][0], rmp[t][4], rmp[t][8], rmp[t][12]};
+            if (RR) {
+#pragma unroll
+                for (int q2 = 0; q2 < KK; q2++)
+#pragma unroll
+                    for (int t = 0; t < 3; t++)
+                        racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp_reg[t][RR ? q2 : 0], (double)s64frag[q2], racc[t], 0, 0, 0);
+            } else {
+                constexpr int KH = KK / 2;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    double rp[3][KH];
+#pragma unroll
+                    for (int t = 0; t < 3; t++)
+#pragma unroll
+                        for (int q2 = 0; q2 < KH; q2++) rp[t][q2] = rpp[t][(h * KH + q2) * 64];
+#pragma unroll
+                    for (int q2 = 0; q2 < KH; q2++)
+#pragma unroll
+                        for (int t = 0; t < 3; t++)
+                            racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q2], (double)s64frag[h * KH + q2], racc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int lr0 = (ck.rrt0 + t) * 16 + g - ck.imin * nroot;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int lr = lr0 + 4 * r;
+                    if (t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) rs[cl * root_stride + lr] = racc[t][r];
+                }
+            }
+            // root taps on the float64 matrix pipe against the chunk's banded weight matrix (see the tile-major kernel)
+            float *ro = (float *)(ro_base + (size_t)(u & 1) * RO_BYTES);
+#pragma unroll
+            for (int ft = 0; ft < MG_TAP_FT; ft++) {
+                if (ft * 16 < ck.nT) {
+                    f64x4 acc[3];
+                    double bv[3][MG_TAP_KS];
+#pragma unroll
+                    for (int ct = 0; ct < 3; ct++) {
+                        acc[ct] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int ks = 0; ks < MG_TAP_KS; ks++) bv[ct][ks] = tap_b_ok[ct][ks] ? rs[tap_b_off[ct][ks]] : 0.0;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < MG_TAP_KS; ks++)
+#pragma unroll
+                        for (int ct = 0; ct < 3; ct++)
+                            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_rwt[(ft * MG_TAP_KS + ks) * 64 + lane], bv[ct][ks], acc[ct], 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int fo = ft * 16 + g + 4 * r;
+                            if (tap_o_off[ct] >= 0 && fo < ck.nT) ro[tap_o_off[ct] + fo * 4] = (float)acc[ct][r];
+                        }
+                }
+            }
+            MG_STAMP(3);
+            mg_publish(prog, wave, lane, u + 1);
+            MG_STAMP(4);
+        }
+        MG_STAMP_DUMP;
+    }
+    if (FUSE_GMM && wave < MG_WS_NPW) {   // the mixture: the four producer waves, as in the tile-major kernel
+        mg_lds_int *gprog = prog + MG_CS_PROG_GMM;
+        mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
+        if (wave < 2) mg_fused_gmm_finish(gprog, logp, a.B, a.n_tiles, gK, wave, lane, 0);
+        const int64_t my_tiles = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x - (int64_t)blockIdx.x * a.n_tiles / gridDim.x;
+        if (my_tiles > 2) {
+            mg_wait_producers(gprog + 24, 1);   // gfin[0], gfin[1]: both term buffers are free again
+            mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 1);
+            if (wave < 2) mg_fused_gmm_finish(gprog, logp, a.B, a.n_tiles, gK, wave, lane, 1);
         }
     }
 }
@@ -823,37 +1371,46 @@ __global__ __launch_bounds__(256) void mg_spline_eval_kernel(const double *coeff
 // -----------------------------------------------------------------------------------------
 template <int KK, bool LAT_F64, bool FUSE>
 static int mg_launch_ws_inst(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
-                             int buf_bytes, int lds, int grid) {
-    hipLaunchKernelGGL((mg_frames_ws_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_WS_BLOCK), lds, p->ctx->stream, p->d_Epack, p->d_mean32,
-                       p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out,
-                       p->d_gPpack, p->d_gmPpad, p->d_gconst, logp, a, p->K, (p->L + 15) / 16, buf_bytes);
+                             int buf_bytes, int lds, int grid, bool cs) {
+    if (cs)
+        hipLaunchKernelGGL((mg_frames_cs_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_CS_BLOCK), lds, p->ctx->stream, p->d_Epack, p->d_mean32,
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out,
+                           p->d_gPpack, p->d_gmPpad, p->d_gconst, logp, a, p->K, (p->L + 15) / 16, buf_bytes);
+    else
+        hipLaunchKernelGGL((mg_frames_ws_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_WS_BLOCK), lds, p->ctx->stream, p->d_Epack, p->d_mean32,
+                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out,
+                           p->d_gPpack, p->d_gmPpad, p->d_gconst, logp, a, p->K, (p->L + 15) / 16, buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
 
 template <int KK>
 static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
-                           bool lat_f64, int buf_bytes, int lds, int grid) {
+                           bool lat_f64, int buf_bytes, int lds, int grid, bool cs) {
     if (logp) {
         // fused instances exist for <= 40 components: beyond that the mixture fragments no longer fit the
         // register budget next to the sweep (mg_frames_can_fuse_gmm refuses, so this is never reached)
         if constexpr (KK <= MG_FUSE_MAX_KK)
-            return lat_f64 ? mg_launch_ws_inst<KK, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid)
-                           : mg_launch_ws_inst<KK, false, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid);
+            return lat_f64 ? mg_launch_ws_inst<KK, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, cs)
+                           : mg_launch_ws_inst<KK, false, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, cs);
         mg_set_error("mg_step_frames_and_logp: no fused kernel for %d components", p->L);
         return MG_ERR_UNSUPPORTED;
     }
-    return lat_f64 ? mg_launch_ws_inst<KK, true, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid)
-                   : mg_launch_ws_inst<KK, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid);
+    return lat_f64 ? mg_launch_ws_inst<KK, true, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, cs)
+                   : mg_launch_ws_inst<KK, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, cs);
 }
 
 template <int KK>
 static int mg_set_attr_kk() {
     MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if constexpr (KK <= MG_FUSE_MAX_KK) {
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return MG_OK;
 }
@@ -889,11 +1446,10 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     mg_frames_args a;
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
     a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.max_nt = g->max_nt; a.nbuf = g->nbuf;
-    {
-        const char *dbg_env = getenv("MG_DEBUG_FLAGS");   // read per launch: A/B tools switch it inside one process
-        const int dbg = dbg_env ? atoi(dbg_env) : 0;
-        a.debug = dbg;
-    }
+    a.debug = 0;
+#ifdef MG_DEBUG_BUILD
+    if (const char *dbg_env = getenv("MG_DEBUG_FLAGS")) a.debug = atoi(dbg_env);   // read per launch: A/B tools switch it inside one process
+#endif
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t units = n_tiles * g->n_chunks;
     if (n_tiles >= ((int64_t)1 << 27) || units >= ((int64_t)1 << 31)) {
@@ -901,7 +1457,20 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
         return MG_ERR_UNSUPPORTED;
     }
     a.n_tiles = (int32_t)n_tiles;
+    a.max_tiles = g->max_tiles;
     const bool lf = (ldt == MG_F64);
+    const int grid0 = (int)std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
+    // which of the two LDS-staged kernels: the tile-major one unless MG_OPT_FRAMES_KERNEL asks for the chunk-stationary
+    // one (measured at B = 8192, 'walk', same box and buffer: 86.2 vs 87.3 us -- its producers are four times faster, but
+    // its longer prologue and the coupling of its sweep waves give the gain back; see the kernel's header)
+    const int want = p->ctx->opt[MG_OPT_FRAMES_KERNEL];
+    bool cs = g->cs_ok && grid0 >= g->n_chunks && (logp == nullptr || g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024);
+    if (want == 2 && !cs) {
+        mg_set_error("mg_back_project_frames: the chunk-stationary kernel does not cover this shape (window of %d row tiles, %d bytes of LDS)",
+                     g->max_tiles, g->cs_lds_bytes);
+        return MG_ERR_UNSUPPORTED;
+    }
+    if (want != 2) cs = false;
     // nbuf ring slots (image + root outputs + tables), the float64 root image, the progress counters
     const int buf_bytes = (MG_NCAND * g->stride * 4 + 255) / 256 * 256;
     int lds = g->nbuf * (buf_bytes + MG_RO_BYTES_N(g->max_nt) + MG_TB_BYTES_N(g->max_nt)) + MG_NCAND * (g->max_wi * p->nroot + 1) * 8 + 128;
@@ -909,20 +1478,21 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
         mg_set_error("mg_back_project_frames: internal LDS sizing mismatch (%d vs %d)", lds, g->lds_bytes);
         return MG_ERR_UNSUPPORTED;
     }
+    if (cs) lds = g->cs_lds_bytes;
     if (logp) lds += mg_fused_gmm_lds(p);
-    const int grid = (int)std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
+    const int grid = grid0;
     switch (p->KK) {
 #ifndef MG_ONLY_KK10
-        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
-        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
-        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
-        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
 #endif
-        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
 #ifndef MG_ONLY_KK10
-        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
-        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
-        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid);
+        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
 #endif
         default: mg_set_error("mg_back_project_frames: MFMA path needs n_components <= 64"); return MG_ERR_UNSUPPORTED;
     }

@@ -636,7 +636,7 @@ static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev,
 }
 
 int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
-    if (p->d_gcholpack && (cum_host || cum_dev) && !getenv("MG_SAMPLE_VALU")) {   // MG_SAMPLE_VALU: tests force the fallback kernel
+    if (p->d_gcholpack && (cum_host || cum_dev) && !p->ctx->opt[MG_OPT_FORCE_VALU_SAMPLE]) {
         switch (p->KK) {
             case 2: return mg_launch_gmm_sample_mfma_kk<2>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
             case 4: return mg_launch_gmm_sample_mfma_kk<4>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
@@ -653,5 +653,5 @@ int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, con
 }
 
 bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p) {
-    return p->d_gcholpack != nullptr && p->KK > 0 && p->K <= MG_SAMPLE_ARG_K && !getenv("MG_SAMPLE_VALU");
+    return p->d_gcholpack != nullptr && p->KK > 0 && p->K <= MG_SAMPLE_ARG_K && !p->ctx->opt[MG_OPT_FORCE_VALU_SAMPLE];
 }

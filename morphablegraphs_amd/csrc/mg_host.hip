@@ -264,6 +264,13 @@ extern "C" int mg_context_set_reserved_cus(mg_context *ctx, int32_t n) {
     ctx->reserved_cus = std::min<int32_t>(n, ctx->n_cu - 1);
     return MG_OK;
 }
+extern "C" int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value) {
+    MG_REQUIRE(ctx != nullptr, "mg_context_set_option: ctx is NULL");
+    MG_REQUIRE(option >= 0 && option < MG_OPT_COUNT, "mg_context_set_option: unknown option %d", option);
+    MG_REQUIRE(value >= 0, "mg_context_set_option: value %d < 0", value);
+    ctx->opt[option] = value;
+    return MG_OK;
+}
 extern "C" int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *total_mem) {
     MG_REQUIRE(ctx != nullptr, "mg_context_device_info: ctx is NULL");
     if (name) { strncpy(name, ctx->name, 255); name[255] = 0; }
@@ -561,7 +568,7 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
         return mg_lds_bytes(p, mg_round_stride(nlocal), wi) <= budget;
     };
     int max_nt = MG_MAX_NT;
-    if (const char *e = getenv("MG_CHUNK_NT")) max_nt = std::max(1, std::min(MG_MAX_NT, atoi(e)));   // bench ablation only
+    if (const int o = p->ctx->opt[MG_OPT_CHUNK_SAMPLES]) max_nt = std::max(1, std::min(MG_MAX_NT, o));
     auto count_chunks = [&](int w) {   // greedy split under a window of w basis functions
         int n = 0;
         for (int a0 = 0; a0 < g->T; n++) {
@@ -586,7 +593,7 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
         if (W == 0 || n <= best_n) { W = w; best_n = n; }
     }
     if (W == 0) return;  // n_dim too large for the LDS-staged kernel
-    if (const char *e = getenv("MG_CHUNK_W")) W = std::max(4, std::min(W, atoi(e)));            // bench ablation only
+    if (const int o = p->ctx->opt[MG_OPT_CHUNK_WINDOW]) W = std::max(4, std::min(W, o));
     // the chunk count of the greedy split, evened out
     const int n_greedy = count_chunks(W);
     int a = 0;
@@ -624,10 +631,20 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
     g->max_nt = (longest + 15) / 16 * 16;
     // a third ring slot lets the producers run a full unit ahead of the slowest consumer wave
     g->nbuf = mg_lds_bytes(p, max_stride, max_wi, 3, g->max_nt) <= budget1 ? 3 : 2;
-    if (const char *e = getenv("MG_NBUF")) g->nbuf = (atoi(e) == 3 && g->nbuf == 3) ? 3 : 2;   // bench ablation only
+    if (p->ctx->opt[MG_OPT_RING_SLOTS] == 2) g->nbuf = 2;
     g->lds_bytes = mg_lds_bytes(p, max_stride, max_wi, g->nbuf, g->max_nt);
     g->n_chunks = (int32_t)g->chunks.size();
     g->mfma_ok = g->lds_bytes <= budget1;
+    // the chunk-stationary kernel: two ring slots, ONE table set, the window's mean' rows; its row producers hold the
+    // window's eigenvector fragments in registers
+    g->max_tiles = 0;
+    for (const mg_chunk &c : g->chunks) g->max_tiles = std::max(g->max_tiles, c.ntiles);
+    {
+        const int buf = (MG_NCAND * max_stride * 4 + 255) / 256 * 256;
+        g->cs_lds_bytes = 2 * (buf + MG_NCAND * g->max_nt * 16) + g->max_nt * 20 + MG_NCAND * (max_wi * p->nroot + 1) * 8 + g->max_tiles * 64 +
+                          MG_TAP_FT * MG_TAP_KS * 64 * 8 + 2 * p->KK * 64 * 4 + 256;   // + tap weights, two latent tiles, 64 counters
+        g->cs_ok = g->mfma_ok && g->max_tiles <= mg_cs_max_tiles(p->KK) && g->cs_lds_bytes <= budget1;
+    }
 }
 
 static int mg_grid_build(mg_primitive *p, mg_time_grid *g, const double *times, int32_t T,

@@ -42,6 +42,7 @@ struct mg_context {
     std::vector<mg_event_pair> pending;
     std::vector<hipEvent_t> free_events;
     int reserved_cus = 0;                        // CUs the persistent kernel leaves free (e.g. for RCCL kernels)
+    int32_t opt[MG_OPT_COUNT] = {0};             // mg_context_set_option (test / tuning switches, 0 = default)
     int prof_interval = 1;                       // bracket every n-th launch of a slot
     int64_t prof_seen[MG_PROFILE_SLOTS] = {0};
     double prof_ms[MG_PROFILE_SLOTS] = {0};
@@ -104,6 +105,9 @@ struct mg_time_grid {
     int32_t lds_bytes = 0;   // dynamic LDS of the MFMA kernel for this grid
     int32_t nbuf = 2;        // LDS ring depth of the MFMA kernel (3 when it fits)
     bool mfma_ok = false;
+    int32_t max_tiles = 0;   // row tiles of the widest chunk window
+    int32_t cs_lds_bytes = 0;   // dynamic LDS of the chunk-stationary kernel (without the fused mixture's buffers)
+    bool cs_ok = false;      // the chunk-stationary kernel covers this grid (window fits the row producers' registers, LDS fits)
 };
 
 struct mg_primitive {
@@ -171,6 +175,7 @@ struct mg_constraint_set {
 // launchers (each validates nothing: the C-ABI entry points did)
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp);
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B);
+int mg_cs_max_tiles(int KK);   // row tiles of a chunk window the chunk-stationary kernel can hold in registers
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt);
@@ -183,6 +188,7 @@ int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld,
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
 int mg_setup_kernel_attributes(mg_context *ctx);
+int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us);   // mg_placement.hip
 
 // host-side float64 spline basis (FITPACK splev/fpbspl semantics)
 void mg_basis_row(const double *knots, int n_knots, double x, int32_t *i0, double *w4);

@@ -1,0 +1,144 @@
+// Placement of large kernel outputs (gfx950 / MI355X).
+//
+// The frames kernel writes B x 49 KB as thousands of concurrent streams of ~1 KB pieces.  Stand-alone that store
+// stream takes 63 us for 404 MB in some parts of the card's memory (the rate of a plain fill) and 79 us in others;
+// the frames kernel itself 85 vs 93-95 us.  What the class depends on was narrowed down with tools/chan_probe*.hip:
+//   * not the base offset inside physically contiguous memory (one 1 GiB virtual-memory chunk: 78-81 us at every
+//     2 MiB offset, and at +256 B ... +1 MiB), not the stride between the streams, not the order in which
+//     workgroups walk their units, not a time skew between workgroups, not cache carry-over between launches
+//     (two buffers written alternately keep their classes);
+//   * the physical region: of 160 buffers of 404 MB held at once, numbers 2-5, 28, 117, 126-138 and 141-159 were
+//     fast -- long runs of neighbours, i.e. multi-gigabyte regions of one class;
+//   * a plain fill runs at the same rate everywhere (59-61 us), so no simple kernel change can see or avoid it.
+// So the library probes for placement: mg_device_malloc_placed times the store pattern against a fill on each
+// candidate allocation and keeps the first fast one, holding the rejected candidates until then so that the next
+// one comes from other memory.
+#include <algorithm>
+#include <vector>
+
+#include "mg_internal.h"
+
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+typedef f32x4p f32x4pu __attribute__((aligned(4)));
+
+// the sweep's store stream for a dense (n_cand, 156, 79) float block: 8 storing waves per workgroup, a wave owns two
+// of a tile's 16 candidates, one instruction stores three 316-byte rows (952 consecutive bytes), 4 chunks of 39 rows
+#define MG_PP_T 156
+#define MG_PP_D 79
+#define MG_PP_NF 39
+#define MG_PP_NCH 4
+__global__ __launch_bounds__(512) void mg_placement_pattern_kernel(float *out, int ntiles) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int fsub = lane / 20, ql = lane % 20;
+    const bool on = lane < 60;
+    const int U = ntiles * MG_PP_NCH, per = (U + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int s = 0; s < per; s++) {
+        const int u = blockIdx.x * per + s;
+        if (u >= U) break;
+        const int tile = u / MG_PP_NCH, chunk = (u % MG_PP_NCH + blockIdx.x) % MG_PP_NCH;
+        for (int f0 = 0; f0 < MG_PP_NF; f0 += 3)
+            for (int half = 0; half < 2; half++) {
+                const size_t cand = (size_t)tile * 16 + wave + 8 * half;
+                const int f = f0 + fsub;
+                if (on && f < MG_PP_NF) {
+                    float *p = out + (cand * MG_PP_T + (size_t)(chunk * MG_PP_NF + f)) * MG_PP_D + (ql == 19 ? 75 : 4 * ql);
+                    const f32x4pu v = {0.f, 0.f, 0.f, 0.f};
+                    *(f32x4pu *)p = v;
+                }
+            }
+    }
+}
+__global__ __launch_bounds__(256) void mg_placement_fill_kernel(f32x4p *buf, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const f32x4p v = {0.f, 0.f, 0.f, 0.f}; buf[i] = v; }
+}
+
+#define MG_PLACED_MIN_BYTES ((int64_t)64 << 20)   // below this an output sits in the 256 MiB Infinity Cache anyway
+#define MG_PLACED_FAST_RATIO 1.15                  // measured: 1.04-1.06 in the fast class, 1.25-1.33 in the slow one
+
+int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us) {
+    const int64_t cand_bytes = (int64_t)MG_PP_T * MG_PP_D * 4;
+    const int ntiles = (int)std::min<int64_t>(bytes / (16 * cand_bytes), 1 << 20);
+    if (ntiles < 64) { *ratio = 1.0; *pattern_us = 0.0; return MG_OK; }
+    const size_t n4 = (size_t)ntiles * 16 * (size_t)cand_bytes / 16;
+    const int grid = std::min(ntiles * MG_PP_NCH, std::max(1, ctx->n_cu));
+    hipEvent_t ev[3];
+    for (auto &e : ev) MG_HIP_CHECK(hipEventCreate(&e));
+    hipStream_t st = ctx->stream;
+    const int warm = 2, reps = 6;
+    auto pattern = [&] { hipLaunchKernelGGL(mg_placement_pattern_kernel, dim3(grid), dim3(512), 0, st, (float *)buf, ntiles); };
+    auto fill = [&] { hipLaunchKernelGGL(mg_placement_fill_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (f32x4p *)buf, n4); };
+    for (int i = 0; i < warm; i++) { fill(); pattern(); }
+    hipError_t e = hipEventRecord(ev[0], st);
+    for (int i = 0; i < reps && e == hipSuccess; i++) fill();
+    if (e == hipSuccess) e = hipEventRecord(ev[1], st);
+    for (int i = 0; i < reps && e == hipSuccess; i++) pattern();
+    if (e == hipSuccess) e = hipEventRecord(ev[2], st);
+    if (e == hipSuccess) e = hipEventSynchronize(ev[2]);
+    float ms_fill = 0.f, ms_pat = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_fill, ev[0], ev[1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_pat, ev[1], ev[2]);
+    if (e == hipSuccess) e = hipGetLastError();
+    for (auto &x : ev) (void)hipEventDestroy(x);
+    if (e != hipSuccess) return mg_hip_fail(e, "mg_probe_placement");
+    *ratio = ms_fill > 0.f ? (double)ms_pat / (double)ms_fill : 1.0;
+    *pattern_us = 1e3 * (double)ms_pat / reps;
+    return MG_OK;
+}
+
+extern "C" int mg_device_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *info) {
+    if (!ctx || !buf || !info || bytes < MG_PLACED_MIN_BYTES) {
+        mg_set_error("mg_device_probe_placement: needs a context, a buffer of at least 64 MiB and info4");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    double ratio = 1.0, us = 0.0;
+    int rc = mg_probe_placement(ctx, buf, bytes, &ratio, &us);
+    if (rc != MG_OK) return rc;
+    info[0] = 1.0; info[1] = ratio; info[2] = us; info[3] = ratio <= MG_PLACED_FAST_RATIO ? 1.0 : 0.0;
+    return MG_OK;
+}
+
+extern "C" int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out_dev, double *info) {
+    if (!ctx || !out_dev || bytes < 0) {
+        mg_set_error("mg_device_malloc_placed: bad arguments");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    *out_dev = nullptr;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    if (info) { info[0] = 0.0; info[1] = 1.0; info[2] = 0.0; info[3] = 1.0; }
+    if (bytes < MG_PLACED_MIN_BYTES) return mg_device_malloc(ctx, bytes, out_dev);
+    size_t free_b = 0, total_b = 0;
+    MG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    int budget = max_candidates > 0 ? max_candidates : 192;
+    budget = (int)std::max<int64_t>(1, std::min<int64_t>(budget, (int64_t)(free_b / 2) / bytes));
+    std::vector<void *> held;
+    void *best = nullptr;
+    double best_ratio = 0.0, best_us = 0.0;
+    int probed = 0, rc = MG_OK;
+    for (int i = 0; i < budget; i++) {
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); break; }   // out of memory: settle for the best so far
+        double ratio = 1.0, us = 0.0;
+        rc = mg_probe_placement(ctx, p, bytes, &ratio, &us);
+        if (rc != MG_OK) { (void)hipFree(p); break; }
+        probed++;
+        if (!best || ratio < best_ratio) {
+            if (best) held.push_back(best);
+            best = p; best_ratio = ratio; best_us = us;
+        } else {
+            held.push_back(p);
+        }
+        if (best_ratio <= MG_PLACED_FAST_RATIO) break;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : held) (void)hipFree(p);
+    if (!best) {
+        if (rc != MG_OK) return rc;
+        mg_set_error("mg_device_malloc_placed: out of device memory (%lld bytes)", (long long)bytes);
+        return MG_ERR_OUT_OF_MEMORY;
+    }
+    *out_dev = best;
+    if (info) { info[0] = probed; info[1] = best_ratio; info[2] = best_us; info[3] = best_ratio <= MG_PLACED_FAST_RATIO ? 1.0 : 0.0; }
+    return MG_OK;
+}

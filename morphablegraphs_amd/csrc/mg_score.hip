@@ -400,7 +400,7 @@ int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *la
     a.res = res;
     a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.align = cs->d_align; a.pose = cs->d_pose; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
     const bool lf0 = ldt == MG_F64, of0 = odt == MG_F64;
-    if (cs->d_Wpack && !getenv("MG_SCORE_VALU")) {   // MG_SCORE_VALU: tests force the fallback kernel
+    if (cs->d_Wpack && !p->ctx->opt[MG_OPT_FORCE_VALU_SCORE]) {
         int rc = MG_ERR_UNSUPPORTED;
         switch (p->KK) {
             case 2: rc = mg_launch_score_mfma_kk<2>(p, cs, a, lf0, of0); break;

@@ -25,6 +25,17 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _default_options(request):
+    """Tests that switch a library option (mg_context_set_option) leave the shared context at its defaults."""
+    yield
+    if "ctx" in request.fixturenames:
+        c = request.getfixturevalue("ctx")
+        if c.handle:
+            for option in range(_capi.MG_OPT_COUNT):
+                c.set_option(option, 0)
+
+
 def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
@@ -472,13 +483,116 @@ def test_time_grids_that_run_backwards_or_jump(ctx):
     prim.close()
 
 
-def test_two_slot_ring(ctx, monkeypatch):
-    """Shapes whose three LDS slots do not fit 160 KiB run a two-slot ring; MG_NBUF=2 forces it on 'walk' (the
+def test_placed_output_buffer_and_options(ctx):
+    """mg_device_malloc_placed hands out a usable buffer with its probe record (small buffers are not probed);
+    mg_device_probe_placement reports the same quantities for any buffer; unknown options are refused."""
+    small = ctx.malloc_placed(1 << 20)
+    assert small.placement["probed"] == 0 and small.placement["fast"]
+    small.free()
+    nbytes = 2048 * 156 * 79 * 4          # 101 MB
+    buf = ctx.malloc_placed(nbytes, max_candidates=3)
+    pl = buf.placement
+    assert 1 <= pl["probed"] <= 3 and pl["ratio"] > 0.5 and pl["pattern_us"] > 1.0
+    again = ctx.probe_placement(buf)
+    assert again["probed"] == 1 and abs(again["ratio"] - pl["ratio"]) < 0.5
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    S = np.random.default_rng(3).standard_normal((2048, 40)).astype(np.float32)
+    d_S = ctx.upload(S)
+    prim.back_project_frames_dev(d_S, np.float32, 2048, 40, buf, path=_capi.MG_PATH_MFMA)
+    got = ctx.download(buf, (2048, 156, 79), np.float32)
+    np.testing.assert_array_equal(_bits(got), _bits(prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)))
+    for b in (d_S, buf):
+        b.free()
+    prim.close()
+    with pytest.raises(_capi.MGError):
+        ctx.set_option(99, 1)
+    with pytest.raises(_capi.MGError):
+        ctx.set_option(_capi.MG_OPT_RING_SLOTS, -1)
+
+
+def _set_frames_kernel(ctx, which):
+    ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, which)
+
+
+@pytest.mark.parametrize("B", [16, 17, 255, 1000, 4099, 8192 + 5])
+def test_chunk_stationary_kernel_is_bit_identical(ctx, B):
+    """The chunk-stationary frames kernel (a workgroup keeps ONE time chunk's eigenvector window in registers and
+    walks candidate tiles; chosen by itself for large batches) against the tile-major kernel and the oracle's f32
+    model: ragged last tiles, fewer tiles than workgroups of a chunk (idle workgroups), float32 and float64 latents,
+    stand-alone and inside the fused step, repeated launches -- bit for bit."""
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(7000 + B)
+    for dtype in (np.float32, np.float64):
+        S = rng.standard_normal((B, 40)).astype(dtype)
+        n_model = min(B, 400)
+        model = cp.frames_f32model(S[:n_model].astype(np.float64))
+        model_tail = cp.frames_f32model(S[-40:].astype(np.float64))
+        _set_frames_kernel(ctx, 1)
+        tm = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+        _set_frames_kernel(ctx, 2)
+        for rep in range(2):
+            cs = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+            np.testing.assert_array_equal(_bits(cs), _bits(tm), err_msg="B=%d %s rep %d" % (B, dtype, rep))
+        np.testing.assert_array_equal(_bits(cs[:n_model]), _bits(model))
+        np.testing.assert_array_equal(_bits(cs[-40:][-min(B, 40):]), _bits(model_tail[-min(B, 40):]))
+        frames, logp = _fused_step(ctx, prim, S, 156, 79)
+        np.testing.assert_array_equal(_bits(frames), _bits(tm), err_msg="fused B=%d %s" % (B, dtype))
+        np.testing.assert_array_equal(logp, prim.gmm_log_prob(S, dtype=np.float32))
+    prim.close()
+
+
+def test_chunk_stationary_kernel_on_the_golden_shapes_and_other_grids(ctx, golden_case):
+    """Every golden shape the chunk-stationary kernel covers (the others must say MG_ERR_UNSUPPORTED, never run
+    something else): canonical grid against the reference's frames, and evaluation grids with fractional, repeated,
+    backwards and out-of-range times (chunks of other lengths and windows) against the tile-major kernel."""
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    if not prim.mfma_supported:
+        prim.close()
+        pytest.skip("no LDS-staged kernel for this shape")
+    cp = c_oracle.COraclePrimitive(data)
+    rng = np.random.default_rng(11)
+    L = g["S"].shape[1]
+    S = np.concatenate([g["S"], rng.standard_normal((333, L))]).astype(np.float64)
+    _set_frames_kernel(ctx, 2)
+    try:
+        got = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+    except _capi.MGError as e:
+        assert e.status == -4, e          # MG_ERR_UNSUPPORTED
+        prim.close()
+        pytest.skip("window of %s does not fit the row producers' registers" % name)
+    np.testing.assert_array_equal(_bits(got), _bits(cp.frames_f32model(S)))
+    ref = g["frames"]
+    assert np.all(np.abs(got[:len(ref)].astype(np.float64) - ref) <= pose_tol(ref))
+    F = int(data["n_canonical_frames"])
+    grids = [np.linspace(0.0, F, 2 * F + 3), np.array([F - 1.0, 0.25, 0.25, F / 2.0, -3.0, F + 5.0, 1.0]),
+             np.linspace(F, 0.0, 77), np.array([0.5 * (F - 1)])]
+    for times in grids:
+        grid = prim.time_grid(times)
+        _set_frames_kernel(ctx, 1)
+        tm = prim.back_project_frames(S, grid=grid, path=_capi.MG_PATH_MFMA)
+        _set_frames_kernel(ctx, 2)
+        try:
+            cs = prim.back_project_frames(S, grid=grid, path=_capi.MG_PATH_MFMA)
+        except _capi.MGError as e:
+            assert e.status == -4, e
+            grid.close()
+            continue
+        np.testing.assert_array_equal(_bits(cs), _bits(tm), err_msg="%s grid of %d" % (name, len(times)))
+        grid.close()
+    prim.close()
+
+
+def test_two_slot_ring(ctx):
+    """Shapes whose three LDS slots do not fit 160 KiB run a two-slot ring; mg_context_set_option(MG_OPT_RING_SLOTS, 2) forces it on 'walk' (the
     planner reads it when a grid is built).  Carried-over tiles then need a full meeting of the row producers per
     unit: ragged and multi-tile batches, the fused step, repeated launches, bit for bit."""
-    monkeypatch.setenv("MG_NBUF", "2")
+    ctx.set_option(_capi.MG_OPT_RING_SLOTS, 2)
     data = synthetic.make_walk_primitive(seed=0)
-    prim = _capi.Primitive(ctx, data)          # canonical grid planned under MG_NBUF=2
+    prim = _capi.Primitive(ctx, data)          # canonical grid planned with two ring slots
     cp = c_oracle.COraclePrimitive(data)
     rng = np.random.default_rng(12)
     for B in (17, 1000, 4099):
@@ -523,7 +637,7 @@ def test_large_ragged_batch_on_device(ctx):
     prim.close()
 
 
-def test_score_kernels_mfma_and_valu_agree_bit_for_bit(ctx, monkeypatch):
+def test_score_kernels_mfma_and_valu_agree_bit_for_bit(ctx):
     """The fused keyframe scorer has two kernels: channels = X . W^T on the f64 matrix pipe (n_components <= 64) and
     a dot product per channel on the VALU (fallback).  Both run the same k-ordered fma chain from the bias and share
     the residual code, so errors and residual matrices must be identical, ragged batches included."""
@@ -541,9 +655,9 @@ def test_score_kernels_mfma_and_valu_agree_bit_for_bit(ctx, monkeypatch):
     for B in (1, 15, 64, 65, 1000):
         for dtype in (np.float32, np.float64):
             S = rng.standard_normal((B, 40)).astype(dtype)
-            monkeypatch.delenv("MG_SCORE_VALU", raising=False)
+            ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 0)
             e1, r1 = prim.score_constraints(cset, S), prim.score_constraint_residuals(cset, S)
-            monkeypatch.setenv("MG_SCORE_VALU", "1")
+            ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 1)
             e2, r2 = prim.score_constraints(cset, S), prim.score_constraint_residuals(cset, S)
             np.testing.assert_array_equal(e1.view(np.uint64), e2.view(np.uint64), err_msg="B=%d %s" % (B, dtype))
             np.testing.assert_array_equal(r1.view(np.uint64), r2.view(np.uint64), err_msg="B=%d %s" % (B, dtype))
@@ -552,7 +666,7 @@ def test_score_kernels_mfma_and_valu_agree_bit_for_bit(ctx, monkeypatch):
     prim.close()
 
 
-def test_device_sampler_mfma_and_valu_produce_the_same_rows(ctx, monkeypatch):
+def test_device_sampler_mfma_and_valu_produce_the_same_rows(ctx):
     """The device sampler has an MFMA kernel (16-row tiles inside one component, x = mu + z L^T on the f64 matrix
     pipe) and a lane-per-row VALU kernel; both draw z from the same Philox counters (row, group of four) and run the
     same ascending fma chain, so the same seed must give the same rows bit for bit -- ragged component counts
@@ -561,9 +675,9 @@ def test_device_sampler_mfma_and_valu_produce_the_same_rows(ctx, monkeypatch):
     prim = _capi.Primitive(ctx, data)
     for counts in ([100, 0, 17, 1, 250, 16, 33, 95], [0, 0, 0, 0, 0, 0, 0, 5], [4096] + [0] * 7):
         for dtype in (np.float64, np.float32):
-            monkeypatch.delenv("MG_SAMPLE_VALU", raising=False)
+            ctx.set_option(_capi.MG_OPT_FORCE_VALU_SAMPLE, 0)
             X1, c1 = prim.gmm_sample(counts, 1234, dtype=dtype)
-            monkeypatch.setenv("MG_SAMPLE_VALU", "1")
+            ctx.set_option(_capi.MG_OPT_FORCE_VALU_SAMPLE, 1)
             X2, c2 = prim.gmm_sample(counts, 1234, dtype=dtype)
             view = np.uint64 if dtype == np.float64 else np.uint32
             np.testing.assert_array_equal(X1.view(view), X2.view(view), err_msg=str(counts))
@@ -598,7 +712,7 @@ def test_fused_step_with_reserved_cus_and_up_to_four_tiles_per_workgroup(ctx):
     prim.close()
 
 
-def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous_motion(ctx, monkeypatch):
+def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous_motion(ctx):
     """MotionPrimitiveConstraints.evaluate outside local mode (reference motion_primitive_constraints.py:110-114 ->
     anim_utils align_quaternion_frames_automatically; PARITY UNPINNED, anim_utils absent): per candidate a rotation
     about y and an xz translation attach its first control point to the previous motion's last frame, then the
@@ -632,9 +746,9 @@ def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous
         np.testing.assert_allclose(prim.score_constraints(cset, S), res.sum(axis=1), rtol=1e-13, atol=1e-12)
         # the aligned start: root xz of the first control point lands on the previous root -> |(prev_x, ., prev_z)|
         np.testing.assert_allclose(res[:, 4], np.hypot(prev[0], prev[2]), rtol=1e-12)
-        monkeypatch.setenv("MG_SCORE_VALU", "1")
+        ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 1)
         np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
-        monkeypatch.delenv("MG_SCORE_VALU")
+        ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 0)
         best, err = prim.best_candidate(cset, S)
         assert best == int(np.argmin(ref.sum(axis=1))) and abs(err - ref.sum(axis=1).min()) < 1e-7
         cset.close()
@@ -669,7 +783,7 @@ def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous
     prim.close()
 
 
-def test_two_hand_midpoint_and_joint_orientation_constraints(ctx, monkeypatch):
+def test_two_hand_midpoint_and_joint_orientation_constraints(ctx):
     """MG_CONSTRAINT_JOINT_MIDPOINT (first residual of TwoHandConstraint, reference two_hand_constraint.py:66-74) and
     MG_CONSTRAINT_JOINT_ORIENTATION (GlobalTransformConstraint._quaternion_distance, global_transform_constraint.py:
     109-121; radians) against the matrix oracle, in local coordinates and aligned to a previous motion, MFMA and VALU
@@ -692,9 +806,9 @@ def test_two_hand_midpoint_and_joint_orientation_constraints(ctx, monkeypatch):
     cset = _capi.ConstraintSet(prim, cons, sk)
     res = prim.score_constraint_residuals(cset, S)
     np.testing.assert_allclose(res, op.skeleton_residuals(S, cons, joints, animated), rtol=1e-9, atol=1e-8)
-    monkeypatch.setenv("MG_SCORE_VALU", "1")
+    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 1)
     np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
-    monkeypatch.delenv("MG_SCORE_VALU")
+    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 0)
     cset.close()
     prev = op.back_project_frames(rng.standard_normal(40))[-1].copy()
     prev[:3] = [-60.0, 90.0, 210.0]
@@ -735,7 +849,7 @@ def test_two_hand_midpoint_and_joint_orientation_constraints(ctx, monkeypatch):
     pr.close()
 
 
-def test_relative_point_and_look_at_constraints(ctx, monkeypatch):
+def test_relative_point_and_look_at_constraints(ctx):
     """A point given in a joint's own frame (RelativeTransformConstraint, reference relative_transform_constraint.py:
     46-50) and LookAtConstraint (look_at_constraint.py:55-66), local and aligned, against the matrix oracle, plus
     answers known by hand on a constant identity pose."""
@@ -756,9 +870,9 @@ def test_relative_point_and_look_at_constraints(ctx, monkeypatch):
     res = prim.score_constraint_residuals(cset, S)
     np.testing.assert_allclose(res, op.skeleton_residuals(S, cons, joints, animated), rtol=1e-9, atol=1e-8)
     assert np.abs(res[:, 0] - res[:, 4]).max() > 1.0                                  # the offset matters
-    monkeypatch.setenv("MG_SCORE_VALU", "1")
+    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 1)
     np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
-    monkeypatch.delenv("MG_SCORE_VALU")
+    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 0)
     cset.close()
     prev = op.back_project_frames(rng.standard_normal(40))[-1].copy()
     prev[:3] = [15.0, 90.0, -75.0]
@@ -937,7 +1051,7 @@ def test_rccl_entry_points_of_the_c_abi_on_one_rank():
     ctx.close()
 
 
-def test_point_cloud_pose_constraint(ctx, monkeypatch):
+def test_point_cloud_pose_constraint(ctx):
     """MG_CONSTRAINT_POSE (PoseConstraint.evaluate_motion_spline, reference pose_constraint.py:48-67; the fit and the
     distance are anim_utils', absent: PARITY UNPINNED): forward kinematics of every listed joint, the optimal weighted
     2-D fit onto the wanted cloud, mean distance, velocity of the first joint -- against the NumPy oracle in local
@@ -964,9 +1078,9 @@ def test_point_cloud_pose_constraint(ctx, monkeypatch):
     res = prim.score_constraint_residuals(cset, S)
     np.testing.assert_allclose(res, op.skeleton_residuals(S, cons, joints, animated), rtol=1e-9, atol=1e-8)
     np.testing.assert_allclose(prim.score_constraints(cset, S), res.sum(axis=1), rtol=1e-13, atol=1e-12)
-    monkeypatch.setenv("MG_SCORE_VALU", "1")
+    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 1)
     np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
-    monkeypatch.delenv("MG_SCORE_VALU")
+    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 0)
     with pytest.raises(_capi.MGError):
         cset.update(cons)                                              # sets with poses are rebuilt, not updated
     cset.close()

@@ -1,17 +1,33 @@
-import ctypes, os, sys
+#!/usr/bin/env python3
+"""Per-wave phase timers of the persistent frames kernel (diagnostic build only):
+    make -C morphablegraphs_amd/csrc libmg_hip_dbg.so && python3 tools/stamp_run.py [flags ...]
+Each argument is a MG_DEBUG_FLAGS value (16 is added); STAMP_B = batch, FUSED=0 for the stand-alone frames kernel,
+PLAIN=1 for an unplaced output buffer."""
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from morphablegraphs_amd import _capi, synthetic
-ctx = _capi.Context(0)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from morphablegraphs_amd import _capi, synthetic   # noqa: E402
+
+lib = _capi.load_library(os.path.join(ROOT, "morphablegraphs_amd", "csrc", "libmg_hip_dbg.so"))
+ctx = _capi.Context(0, lib=lib)
 prim = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
 B = int(os.environ.get("STAMP_B", "8192"))
 S = ctx.upload(np.random.default_rng(0).standard_normal((B, 40)).astype(np.float32))
-out = ctx.malloc(B * 156 * 79 * 4)
+out = ctx.malloc(B * 156 * 79 * 4) if os.environ.get("PLAIN") else ctx.malloc_placed(B * 156 * 79 * 4)
+print("output:", out.placement)
 logp = ctx.malloc(B * 4)
-for _ in range(5):
-    if os.environ.get("FUSED"):
-        prim.step_frames_and_logp_dev(S, np.float32, B, 40, out, logp)
-    else:
-        prim.back_project_frames_dev(S, np.float32, B, 40, out, path=_capi.MG_PATH_MFMA)
-ctx.synchronize()
-_capi.load_library().mg_debug_dump_stamps()
+for flags in (sys.argv[1:] or ["0"]):
+    os.environ["MG_DEBUG_FLAGS"] = str(int(flags) | 16)
+    for _ in range(200):
+        if os.environ.get("FUSED", "1") != "0":
+            prim.step_frames_and_logp_dev(S, np.float32, B, 40, out, logp)
+        else:
+            prim.back_project_frames_dev(S, np.float32, B, 40, out, path=_capi.MG_PATH_MFMA)
+    ctx.synchronize()
+    print("==== MG_DEBUG_FLAGS = %s (+16)" % flags, flush=True)
+    lib.mg_debug_dump_stamps()
+    sys.stdout.flush()
