@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- motion-primitive samples scored + back-projected per second on MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic latent candidates
-already resident in HBM: back-projection to full frames (156 x 79 float32 per candidate)
-plus the GMM log-likelihood of the same candidates ('walk' primitive: L=40, F=156, K=8;
-BASELINE.json configs[1] per GPU).  With N > 1 ranks the candidate batch is sharded
-8192 per GPU (configs[3]) and every step ends with the RCCL all-gather of the scores.
+A "step" is one pass of the hot path over one batch of synthetic latent candidates already
+resident in HBM: back-projection to full frames (156 x 79 float32 per candidate) plus the GMM
+log-likelihood of the same candidates ('walk' primitive: L=40, F=156, K=8; BASELINE.json
+configs[1] per GPU).  With N > 1 ranks the candidate batch is sharded 8192 per GPU (configs[3])
+and every step ends with the RCCL all-gather of the scores.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config walk|graph|optimizer]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
-Prints ONE JSON line on rank 0.  PyTorch is plumbing only (device buffers, the stream,
-torch.distributed); every kernel is libmg_hip.so through the ctypes C-ABI.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (child
+processes, before anything touches a GPU) and forwards rank 0's JSON line.  One JSON line on rank 0.
+Everything on the device goes through libmg_hip.so (ctypes C-ABI): buffers, the stream, the kernels
+and -- by default -- the collective (mg_dist_*: RCCL loaded by the library, the unique id handed over
+through a file); `--collective torch` keeps torch.distributed's communicator for comparison.
+`--config graph` (BASELINE configs[2]: 16 primitives x 4096 candidates per planner step) and
+`--config optimizer` (configs[4] per iteration on one GPU: 131072 candidates, score only) are the
+other two single-GPU workloads, each with its own roofline.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,14 +33,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_summary.json")   # tools/prof_bench.sh + tools/summarize_prof.py
+HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+F64_MFMA_PEAK_TFLOPS = 78.6   # AMD's published MI355X float64 matrix figure (the guide has no float64 row)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_summary.json")   # tools/prof_bench.sh + tools/summarize_prof.py
+METRIC = "motion-primitive samples scored+back-projected/sec; fraction of HBM roofline"
+L, F, D, NB, K = 40, 156, 79, 31, 8
 
 
 def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units; FETCH_SIZE doubled as the
-    gfx950 correction for wide coalesced reads prescribes).  None when no summary is present."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units; FETCH_SIZE doubled as the gfx950
+    correction for wide coalesced reads prescribes).  None when no summary is present."""
     try:
         with open(PMC_SUMMARY) as f:
             summ = json.load(f)
@@ -44,214 +55,329 @@ def pmc_traffic_bytes(kernel_substr):
     return None
 
 
-def algorithmic_bytes(prim_shape, B):
-    """SURVEY.md §8(d): per candidate 4L (latent) + 4FD (frames) + 4 (log p);
-    per launch the constants E, mean, basis, GMM."""
-    L, F, D, NB, K = prim_shape
+def algorithmic_bytes(B):
+    """per candidate 4L (latent) + 4FD (frames) + 4 (log p); per launch the constants E, mean, basis, GMM."""
     per_cand = 4 * L + 4 * F * D + 4
     consts = 4 * (NB * D * L + NB * D + 4 * F + K * (L * L + L + 1))
     return per_cand, consts, per_cand * B + consts
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=8192, help="candidates per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-launch", action="store_true",
-                    help="frames kernel and log-likelihood kernel as two launches instead of the fused step kernel")
-    ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--event-interval", type=int, default=8,
-                    help="bracket every n-th launch of a kernel with a HIP event pair inside the timed region")
-    ap.add_argument("--output-candidates", type=int, default=8,
-                    help="allocate this many output buffers and keep the one the kernel writes fastest (physical placement "
-                         "of the 404 MB changes the step time by several percent); 1 = take the first allocation")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------
+# launching N ranks from one command line
+# ---------------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    """`python bench.py --gpus N` typed as is: N child processes (one rank per GPU), started before this process has
+    touched a GPU and never exec'ed into; rank 0's stdout is forwarded, the exit code is the worst child's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
-    import torch
-    import torch.distributed as dist
-    if not os.path.exists(os.path.join(ROOT, "morphablegraphs_amd", "csrc", "libmg_hip.so")):
-        # git-ignored build product missing (fresh checkout): rank 0 of the node builds it, the others wait for the file
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        else:
-            deadline = time.time() + 900.0
-            while not os.path.exists(os.path.join(ROOT, "oracle", "libmg_oracle.so")):   # built last
-                if time.time() > deadline:
-                    raise SystemExit("libmg_hip.so was not built by local rank 0 within 15 minutes")
-                time.sleep(1.0)
-            time.sleep(2.0)
+
+class FileRendezvous(object):
+    """How the 128-byte RCCL unique id (and, in a dry run, everything else) travels between the ranks of one node
+    without torch: files named after the launcher's pid and the master port, written with an atomic rename."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.base = os.path.join(tempfile.gettempdir(), "mg_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        self.seq = 0
+
+    def _path(self, tag, r):
+        return "%s.%s.%d" % (self.base, tag, r)
+
+    def put(self, tag, payload):
+        tmp = self._path(tag, self.rank) + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.rename(tmp, self._path(tag, self.rank))
+
+    def get(self, tag, r, timeout=300.0):
+        deadline = time.time() + timeout
+        p = self._path(tag, r)
+        while not os.path.exists(p):
+            if time.time() > deadline:
+                raise SystemExit("rank %d: timed out waiting for rank %d (%s)" % (self.rank, r, tag))
+            time.sleep(0.002)
+        with open(p, "rb") as f:
+            return f.read()
+
+    def all_gather(self, payload):
+        """every rank's bytes on every rank (used for the id hand-over and by the dry run)"""
+        tag = "ag%d" % self.seq
+        self.seq += 1
+        self.put(tag, payload)
+        got = [self.get(tag, r) for r in range(self.world)]
+        self.put(tag + "done", b"1")
+        if self.rank == 0:   # the files go once everybody has read them
+            for r in range(self.world):
+                self.get(tag + "done", r)
+            for r in range(self.world):
+                for t in (tag, tag + "done"):
+                    try:
+                        os.remove(self._path(t, r))
+                    except OSError:
+                        pass
+        return got
+
+
+def ensure_built():
+    if os.path.exists(os.path.join(ROOT, "morphablegraphs_amd", "csrc", "libmg_hip.so")):
+        return
+    # git-ignored build product missing (fresh checkout): local rank 0 builds it, the others wait for the file
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__
+        __graft_entry__.build()
+    else:
+        deadline = time.time() + 900.0
+        while not os.path.exists(os.path.join(ROOT, "oracle", "libmg_oracle.so")):   # built last
+            if time.time() > deadline:
+                raise SystemExit("libmg_hip.so was not built by local rank 0 within 15 minutes")
+            time.sleep(1.0)
+        time.sleep(2.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the headline workload: frames + log p of 8192 candidates per GPU
+# ---------------------------------------------------------------------------------------------------------
+def run_walk(args, rank, local_rank, world):
+    dry = args.dry_run
+    rdv = FileRendezvous(rank, world) if world > 1 else None
+    B = int(args.batch)
+    per_cand, consts, bytes_launch = algorithmic_bytes(B)
+    use_torch = world > 1 and args.collective == "torch"
+    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")   # "gloo": the torch collective on CPU tensors (rehearsal)
+    if dry:
+        # no GPU in this process: the launcher, the rendezvous, the timing protocol and the JSON contract are
+        # exercised with a stand-in step; `value` means nothing and the line says so
+        if use_torch:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        scores = np.full((B,), float(rank), dtype=np.float32)
+
+        def step():
+            time.sleep(2e-4)
+
+        def gather():
+            if use_torch:
+                out = torch.empty((world * B,), dtype=torch.float32)
+                dist.all_gather_into_tensor(out, torch.from_numpy(scores))
+                return out.numpy()
+            return np.concatenate([np.frombuffer(b, dtype=np.float32) for b in rdv.all_gather(scores.tobytes())])
+
+        def barrier():
+            if world > 1:
+                if use_torch:
+                    dist.barrier()
+                else:
+                    rdv.all_gather(b"b")
+
+        def max_over_ranks(x):
+            if world == 1:
+                return x
+            if use_torch:
+                t = torch.tensor([x], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            return max(float(np.frombuffer(b, dtype=np.float64)[0]) for b in rdv.all_gather(np.array([x]).tobytes()))
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        gathered = gather() if world > 1 else scores
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if world > 1:
+            assert gathered.shape == (world * B,) and all(gathered[r * B] == r for r in range(world))
+        if use_torch:
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": world * B * args.steps / elapsed, "unit": "samples/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "dry_run": True,
+                              "config": {"workload": "DRY RUN (no GPU): launcher, rendezvous and timing protocol only", "candidates_per_gpu": B,
+                                         "global_candidates": world * B, "collective": "file rendezvous" if not use_torch else "torch.distributed gloo"}}))
+        return 0
+
+    ensure_built()
     from morphablegraphs_amd import _capi, synthetic
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()   # == local_rank on an N-GPU node
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse N > 1 on a one-GPU box
-    if world > 1:
+    from morphablegraphs_amd.distributed import first_min_argmin
+    from morphablegraphs_amd.gaussian_mixture import sample_like_sklearn
+    data = synthetic.make_walk_primitive(seed=0)
+    torch = dist = None
+    if use_torch:
+        import torch
+        import torch.distributed as dist
+        n_dev = torch.cuda.device_count()
+    dev_index = local_rank   # one rank per GPU of the node
+    if use_torch:
+        torch.cuda.set_device(dev_index % n_dev)
+        stream = torch.cuda.Stream(device=dev_index % n_dev)
+        torch.cuda.set_stream(stream)
+        ctx = _capi.Context(dev_index % n_dev, stream=stream.cuda_stream)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index % n_dev))
         else:
             dist.init_process_group(backend)
-
-    B = int(args.batch)
-    data = synthetic.make_walk_primitive(seed=0)
-    L, F, D, NB, K = 40, 156, 79, 31, 8
-    # one explicit torch stream carries the HIP kernels (through the C-ABI context) and the RCCL all-gather
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx = _capi.Context(dev_index, stream=stream.cuda_stream)
+    else:
+        try:
+            ctx = _capi.Context(dev_index)
+        except _capi.MGError as e:
+            raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback (%s)" % e)
+        if world > 1:
+            uid = ctx.dist_unique_id() if rank == 0 else b""
+            uid = rdv.all_gather(uid)[0]
+            ctx.dist_init(rank, world, uid)
     prim = _capi.Primitive(ctx, data)
 
-    # synthetic latents: sklearn-style GMM draw on the host (np.random.seed(rank)), cast to f32
-    from morphablegraphs_amd.gaussian_mixture import sample_like_sklearn
+    # synthetic latents: sklearn-style GMM draw on the host (RandomState(rank)), cast to f32, resident in HBM
     rs = np.random.RandomState(rank)
     S_host = sample_like_sklearn(B, np.array(data["gmm_weights"]), np.array(data["gmm_means"]),
                                  np.array(data["gmm_covars"]), rs)[0].astype(np.float32)
-    S = torch.from_numpy(S_host).to(dev)
-    # Where the 404 MB of frames land in HBM changes the step time by ~7 % (two stable modes per buffer, 87 vs 94 us,
-    # tools/placement_probe.py): before anything is timed, a few allocations are probed and the best one is kept.
-    placement = {"candidates": max(1, args.output_candidates), "probe_us": [], "chosen": 0,
-                 "allocator": "candidates 0, 1: mg_device_malloc (hipMalloc of the exact size); the others: "
-                              "mg_device_malloc_chunked (virtual-memory API, 8 / 16 / 32 MiB physical chunks)"}
-
-    class _RawFrames(object):   # the library's own allocation, seen by torch without a copy
-        def __init__(self, buf):
-            self.buf = buf
-            self.__cuda_array_interface__ = {"shape": (B, F, D), "typestr": "<f4", "data": (int(buf.ptr.value), False), "version": 2}
-    # candidates 0 and 1: one exact-size hipMalloc each; the others: assembled from 8 / 16 / 32 MiB physical chunks (most of
-    # those land in the fast placement even on boxes where single allocations never do)
-    chunk_of = lambda i: 0 if i < 2 else ((8 << 20), (16 << 20), (32 << 20))[(i - 2) % 3]
-    def alloc_candidate(i):
-        try:
-            return ctx.malloc(B * F * D * 4, chunk_bytes=chunk_of(i))
-        except _capi.MGError:                      # no virtual-memory API on this driver: a plain allocation instead
-            return ctx.malloc(B * F * D * 4)
-    raws = [_RawFrames(alloc_candidate(i)) for i in range(placement["candidates"])]
-    if len(raws) > 1:
-        probe_lp = torch.empty((B,), dtype=torch.float32, device=dev)
-
-        def probe(raw, n):
-            torch.cuda.synchronize(dev)
-            t_probe = time.perf_counter()
-            for _ in range(n):
-                prim.step_frames_and_logp_dev(S.data_ptr(), np.float32, B, L, raw.buf.ptr.value, probe_lp.data_ptr())
-            torch.cuda.synchronize(dev)
-            return 1e6 * (time.perf_counter() - t_probe) / n
-        probe(raws[0], 400)                                    # clocks up before anything is compared
-        best = [min(probe(r, 150), probe(r, 150)) for r in raws]
-        placement["probe_us"] = [round(v, 2) for v in best]
-        placement["chosen"] = int(np.argmin(best))
-        del probe_lp
-    frames_raw = raws[placement["chosen"]]
-    for i, r in enumerate(raws):
-        if i != placement["chosen"]:
-            r.buf.free()
-    del raws
-    frames = torch.as_tensor(frames_raw, device=dev)
-    assert frames.data_ptr() == frames_raw.buf.ptr.value and tuple(frames.shape) == (B, F, D)
-    # scores and gathered scores are double buffered: the all-gather of step i runs on RCCL's stream while the
-    # kernel of step i+1 runs on ours; step i+2 first waits (stream-side) for gather i to release its buffers
-    logps = [torch.empty((B,), dtype=torch.float32, device=dev) for _ in range(2)]
-    logp = logps[0]
-    gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathereds = [torch.empty((world * B,), dtype=torch.float32, device=gdev) for _ in range(2)] if world > 1 else None
-    gathered = gathereds[0] if world > 1 else None
-    works = [None, None]
+    S = ctx.upload(S_host)
+    nbytes = B * F * D * 4
+    # the output comes from the library's allocator for large outputs: where 404 MB land in HBM decides between two
+    # speed classes of the kernel's store stream (DESIGN.md "Placement"); mg_device_malloc_placed probes for the fast one
+    t_alloc = time.perf_counter()
+    frames = ctx.malloc(nbytes) if args.output_alloc == "plain" else ctx.malloc_placed(nbytes)
+    alloc_s = time.perf_counter() - t_alloc
+    probe = ctx.probe_placement(frames)   # pattern and fill time on THIS buffer: the in-run achievable ceiling
+    fill_us = probe["pattern_us"] / probe["ratio"] if probe["ratio"] > 0 else None
+    logps = [ctx.malloc(B * 4) for _ in range(2)]
+    gathereds = [ctx.malloc(world * B * 4) for _ in range(2)] if world > 1 else None
+    if use_torch:
+        t_logps = [torch.empty((B,), dtype=torch.float32, device="cuda") for _ in range(2)]
+        gdev = "cuda" if backend == "nccl" else "cpu"
+        t_gath = [torch.empty((world * B,), dtype=torch.float32, device=gdev) for _ in range(2)]
+        works = [None, None]
+    scalar_dev = ctx.malloc(8)
+    scalars_dev = ctx.malloc(8 * max(world, 1))
     step_no = [0]
 
     def step():
         b = step_no[0] & 1
         step_no[0] += 1
-        lp = logps[b]
-        if works[b] is not None:
-            works[b].wait()
-            works[b] = None
-        if args.two_launch:
-            prim.back_project_frames_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), path=_capi.MG_PATH_MFMA)
-            prim.gmm_log_prob_dev(S.data_ptr(), np.float32, B, L, lp.data_ptr(), np.float32)
-        else:
-            # mg_step_frames_and_logp: one launch, the mixture is scored inside the frames kernel
-            prim.step_frames_and_logp_dev(S.data_ptr(), np.float32, B, L, frames.data_ptr(), lp.data_ptr())
-        if world > 1:
-            if backend == "nccl":
-                works[b] = dist.all_gather_into_tensor(gathereds[b], lp, async_op=True)
-            else:
-                dist.all_gather_into_tensor(gathereds[b], lp.cpu())
-
-    def fence():
-        for b in range(2):
+        if use_torch:
             if works[b] is not None:
                 works[b].wait()
                 works[b] = None
-        torch.cuda.synchronize(dev)
+            lp_ptr = t_logps[b].data_ptr()
+        else:
+            lp_ptr = logps[b].ptr.value
+        if args.two_launch:
+            prim.back_project_frames_dev(S, np.float32, B, L, frames, path=_capi.MG_PATH_MFMA)
+            prim.gmm_log_prob_dev(S, np.float32, B, L, lp_ptr, np.float32)
+        else:
+            # mg_step_frames_and_logp: one launch, the mixture is scored inside the frames kernel
+            prim.step_frames_and_logp_dev(S, np.float32, B, L, frames, lp_ptr)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            if use_torch:
+                if backend == "nccl":
+                    works[b] = dist.all_gather_into_tensor(t_gath[b], t_logps[b], async_op=True)
+                else:
+                    dist.all_gather_into_tensor(t_gath[b], t_logps[b].cpu())
+            else:
+                ctx.dist_all_gather(logps[b], gathereds[b], B, np.float32)   # RCCL on the kernels' stream, stream ordered
 
+    def sync():
+        if use_torch:
+            for b in range(2):
+                if works[b] is not None:
+                    works[b].wait()
+                    works[b] = None
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    def barrier():
+        sync()
+        if world > 1:
+            if use_torch:
+                dist.barrier()
+            else:
+                ctx.dist_all_gather(scalar_dev, scalars_dev, 1, np.float64)
+        sync()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        if use_torch:
+            t = torch.tensor([x], dtype=torch.float64, device=gdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        ctx.lib.mg_memcpy_h2d(ctx.handle, scalar_dev.ptr, np.array([x], dtype=np.float64).ctypes.data, 8)
+        ctx.dist_all_gather(scalar_dev, scalars_dev, 1, np.float64)
+        return float(ctx.download(scalars_dev, (world,), np.float64).max())
+
+    # the chip raises its clock over the first ~0.1 s of load (the same kernel takes 98 us in a cold 25-launch run and 85 us
+    # in steady state): an untimed ramp before the W warm-up steps, so that a short run measures the steady state too
+    for _ in range(args.ramp_steps):
+        step()
     for _ in range(args.warmup):
         step()
-    fence()
+    barrier()
+    # timing events ride on the kernel's own dispatch (hipExtLaunchKernel: no marker packets, the duration is the kernel's
+    # own); they still cost ~4 us of step time each, so a long run samples every 8th launch and a short one times them all
+    interval = max(1, args.event_interval) if args.event_interval else (1 if args.steps <= 64 else 8)
     if not args.no_profile_events:
         ctx.profile_reset()
-        ctx.profile_enable(max(1, args.event_interval))
+        ctx.profile_enable(interval)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    barrier()
     elapsed = time.perf_counter() - t0
     if not args.no_profile_events:
         ctx.profile_enable(False)
+    elapsed = max_over_ranks(elapsed)
+    last = (step_no[0] - 1) & 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         # every rank holds the same global score vector: the graph-walk argmin needs no further exchange
-        from morphablegraphs_amd.distributed import first_min_argmin
-        best_idx, best_val = first_min_argmin((-gathered).float().cpu().numpy())   # most likely candidate
-
+        g_host = t_gath[last].float().cpu().numpy() if use_torch else ctx.download(gathereds[last], (world * B,), np.float32)
+        best_idx, best_val = first_min_argmin(-g_host)   # most likely candidate
     frames_ms, frames_n = ctx.profile_get("frames")
     gmm_ms, gmm_n = ctx.profile_get("gmm_log_prob")
 
     # sanity: the timed work produced real output
-    chk = float(frames[B // 2, F - 1, :4].sum().item()) + float(logp[:8].sum().item())
-    if not np.isfinite(chk):
+    row = ctx.download(frames.ptr.value + (B // 2) * F * D * 4 + (F - 1) * D * 4, (4,), np.float32)
+    lp_host = t_logps[last].cpu().numpy()[:8] if use_torch else ctx.download(logps[last], (8,), np.float32)
+    if not np.isfinite(float(row.sum()) + float(lp_host.sum())):
         raise SystemExit("non-finite output")
 
+    rc = 0
     if rank == 0:
-        per_cand, consts, bytes_launch = algorithmic_bytes((L, F, D, NB, K), B)
         value = world * B * args.steps / elapsed
+        placement = {"allocator": "mg_device_malloc" if args.output_alloc == "plain" else "mg_device_malloc_placed (the library's allocator for large outputs: first candidate allocation in the fast placement class)",
+                     "candidates_probed": frames.placement["probed"] if frames.placement else 0, "alloc_seconds": round(alloc_s, 4),
+                     "pattern_over_fill": round(probe["ratio"], 4), "fast_class": probe["fast"]}
         result = {
-            "metric": "motion-primitive samples scored+back-projected/sec; fraction of HBM roofline",
-            "value": value,
-            "unit": "samples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
+            "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "walk primitive L=40 F=156 D=79 NB=31 GMM k=8, batch=%d candidates/GPU "
                                    "(BASELINE.json configs[%d])" % (B, 1 if world == 1 else 3),
                        "candidates_per_gpu": B, "global_candidates": world * B,
-                       "collective": ("all_gather(logp) every step (double-buffered: gather i overlaps the kernel of step i+1), "
-                                      "backend %s" % backend) if world > 1 else "none",
+                       "collective": ("all_gather(logp) every step, %s" % ("RCCL through mg_dist_all_gather on the kernels' stream" if not use_torch
+                                      else "torch.distributed %s (double-buffered, overlapped)" % backend)) if world > 1 else "none",
                        "sharding": "contiguous candidate blocks, constants replicated",
+                       "clock_ramp_steps": args.ramp_steps,
                        "output_placement": placement},
         }
         if frames_n > 0:
@@ -260,65 +386,284 @@ def main():
             # E, mean, basis, mixture constants); stand-alone frames kernel: latents + frames (+ E, mean, basis)
             k_bytes = (B * (4 * L + 4 * F * D) + 4 * (NB * D * L + NB * D + 4 * F)) if args.two_launch else bytes_launch
             achieved = k_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = pmc_traffic_bytes("mg_frames_ws_kernel") if B == 8192 else None
             result["roofline"] = {
                 "bound": "hbm", "kernel": "mg_frames_ws_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic_bytes("mg_frames_ws_kernel") if B == 8192 else None,
-                "avg_kernel_ms": avg_ms, "launches_timed": frames_n, "event_interval": max(1, args.event_interval),
-                "algorithmic_bytes_per_launch": k_bytes,
-                "launches_per_step": 2 if args.two_launch else 1,
+                "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/r02_summary.json), not measured in this run" if traffic else None,
+                "avg_kernel_ms": avg_ms, "launches_timed": frames_n, "event_interval": interval,
+                "algorithmic_bytes_per_launch": k_bytes, "launches_per_step": 2 if args.two_launch else 1,
                 "gmm_kernel_avg_ms": (gmm_ms / gmm_n) if gmm_n else None,
-                "step_algorithmic_bytes": bytes_launch,
-                "step_achieved_GBps": bytes_launch / (elapsed / args.steps) / 1e9,
+                "step_algorithmic_bytes": bytes_launch, "step_achieved_GBps": bytes_launch / (elapsed / args.steps) / 1e9,
             }
+            if fill_us:   # both denominators -- the spec peak and what a plain fill of the same buffer reaches in this run
+                ach_peak = nbytes / (fill_us * 1e-6) / 1e9
+                result["roofline"].update({"achievable_peak": ach_peak, "frac_of_achievable": achieved / ach_peak,
+                                           "achievable_peak_how": "plain float4 fill of the same %d-byte output buffer, %.1f us" % (nbytes, fill_us),
+                                           "store_stream_alone_us": probe["pattern_us"]})
             smp = np.sort(ctx.profile_samples("frames"))
             if len(smp) >= 10:   # spread of the event-bracketed launches (median, p10 / p90)
                 result["roofline"].update({"kernel_ms_p10": float(smp[int(0.10 * (len(smp) - 1))]),
                                            "kernel_ms_p50": float(smp[int(0.50 * (len(smp) - 1))]),
                                            "kernel_ms_p90": float(smp[int(0.90 * (len(smp) - 1))])})
         if world == 1:
+            def wall_us(n, out_buf):
+                for _ in range(20):
+                    prim.step_frames_and_logp_dev(S, np.float32, B, L, out_buf, logps[0])
+                ctx.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    prim.step_frames_and_logp_dev(S, np.float32, B, L, out_buf, logps[0])
+                ctx.synchronize()
+                return 1e6 * (time.perf_counter() - t) / n
+            if args.output_alloc != "plain":
+                # beside the headline: the same step on a buffer taken from plain hipMalloc, wherever that landed
+                plain = ctx.malloc(nbytes)
+                pp = ctx.probe_placement(plain)
+                result["config"]["output_placement"]["unplaced"] = {"allocator": "mg_device_malloc (one hipMalloc)", "step_us": round(wall_us(200, plain), 2),
+                                                                    "pattern_over_fill": round(pp["ratio"], 4), "fast_class": pp["fast"]}
+                plain.free()
             # what the boundary costs when it hands over host buffers (never part of `value`): median of 20 copies
             def med_us(fn):
                 ts = []
                 for _ in range(20):
-                    torch.cuda.synchronize(dev)
+                    ctx.synchronize()
                     t = time.perf_counter()
                     fn()
-                    torch.cuda.synchronize(dev)
                     ts.append(time.perf_counter() - t)
                 return 1e6 * float(np.median(ts))
-            pin_S = torch.from_numpy(S_host).pin_memory()
-            pin_lp = torch.empty((B,), dtype=torch.float32).pin_memory()
-            pin_fr = torch.empty((F, D), dtype=torch.float32).pin_memory()
+            lp_h = np.empty((B,), dtype=np.float32)
+            fr_h = np.empty((F, D), dtype=np.float32)
+            C = __import__("ctypes")
             result["transfers_us"] = {
-                "h2d_latents": med_us(lambda: S.copy_(pin_S, non_blocking=True)), "h2d_latents_bytes": int(S_host.nbytes),
-                "d2h_scores": med_us(lambda: pin_lp.copy_(logp, non_blocking=True)), "d2h_scores_bytes": 4 * B,
-                "d2h_winner_frames": med_us(lambda: pin_fr.copy_(frames[B // 2], non_blocking=True)), "d2h_winner_frames_bytes": 4 * F * D,
+                "h2d_latents": med_us(lambda: ctx.lib.mg_memcpy_h2d(ctx.handle, S.ptr, S_host.ctypes.data_as(C.c_void_p), S_host.nbytes)), "h2d_latents_bytes": int(S_host.nbytes),
+                "d2h_scores": med_us(lambda: ctx.lib.mg_memcpy_d2h(ctx.handle, lp_h.ctypes.data_as(C.c_void_p), logps[0].ptr, lp_h.nbytes)), "d2h_scores_bytes": 4 * B,
+                "d2h_winner_frames": med_us(lambda: ctx.lib.mg_memcpy_d2h(ctx.handle, fr_h.ctypes.data_as(C.c_void_p), C.c_void_p(frames.ptr.value + (B // 2) * F * D * 4), fr_h.nbytes)),
+                "d2h_winner_frames_bytes": 4 * F * D, "note": "pageable host memory, synchronous copies through the C-ABI",
             }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import cpu_baseline
-            ref = cpu_baseline.reference_shaped_rate(data, S_host, budget_s=12.0, max_candidates=1 << 30)
-            cport = cpu_baseline.c_port_rate(data, S_host, budget_s=5.0)
-            vec = cpu_baseline.vectorised_rate(data, S_host, budget_s=5.0)
-            result["cpu_baseline"] = {
-                "value": ref["rate"], "unit": "samples/s", "cores": 1, "kind": "port",
-                "sample": "%d candidates drawn cyclically from the same batch, reference-shaped per-candidate loop "
-                          "(numpy dot + 79x scipy splev + sklearn score_samples), %.1f s" % (ref["n"], ref["seconds"]),
-                "c_port_value": cport["rate"],
-                "c_port_sample": "%d candidates, plain-C float64 oracle (oracle/mg_oracle.c), 1 core, %.1f s" % (cport["n"], cport["seconds"]),
-                "vectorised_value": vec["rate"], "vectorised_cores": vec["threads"],
-                "vectorised_sample": "%d candidates, float32 GEMM (coefficients) + batched basis GEMM (frames materialised) + "
-                                     "batched sklearn score_samples, %d BLAS threads, %.1f s" % (vec["n"], vec["threads"], vec["seconds"]),
-                "host_cores_available": os.cpu_count(),
-            }
+            result["cpu_baseline"] = cpu_baseline_leg(data, S_host)
         print(json.dumps(result))
-    del frames
-    frames_raw.buf.free()
+    for buf in [S, frames, scalar_dev, scalars_dev] + logps + (gathereds or []):
+        buf.free()
+    prim.close()
+    if world > 1 and not use_torch:
+        ctx.dist_finalize()
+    ctx.close()
+    if use_torch:
+        dist.destroy_process_group()
+    return rc
+
+
+def _ref_worker(job):
+    data, S, budget = job
+    from oracle import cpu_baseline
+    return cpu_baseline.reference_shaped_rate(data, S, budget_s=budget, max_candidates=1 << 30)
+
+
+def cpu_baseline_leg(data, S_host):
+    """The reference-shaped per-candidate loop (numpy dot + 79 x scipy splev + sklearn score_samples) on one core and on
+    N processes over disjoint slices, the plain-C oracle, the vectorised form: ~35 s of CPU in all."""
+    from oracle import cpu_baseline
+    ref = cpu_baseline.reference_shaped_rate(data, S_host, budget_s=10.0, max_candidates=1 << 30)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nproc = max(1, min(avail, 32))
+    multi = None
+    if nproc > 1:
+        import multiprocessing as mp
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        for k in saved:
+            os.environ[k] = "1"      # one core per process, as the reference's parallel server runs (one process per core)
+        try:
+            with mp.get_context("spawn").Pool(nproc) as pool:
+                parts = np.array_split(S_host, nproc)
+                t0 = time.perf_counter()
+                res = pool.map(_ref_worker, [(data, p, 8.0) for p in parts])
+                wall = time.perf_counter() - t0
+            multi = {"rate": sum(r["n"] for r in res) / max(r["seconds"] for r in res), "n": sum(r["n"] for r in res),
+                     "seconds": max(r["seconds"] for r in res), "wall_with_startup": wall}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    cport = cpu_baseline.c_port_rate(data, S_host, budget_s=5.0)
+    vec = cpu_baseline.vectorised_rate(data, S_host, budget_s=5.0)
+    out = {
+        "value": ref["rate"], "unit": "samples/s", "cores": 1, "kind": "port",
+        "sample": "%d candidates drawn cyclically from the same batch, reference-shaped per-candidate loop "
+                  "(numpy dot + 79x scipy splev + sklearn score_samples), %.1f s" % (ref["n"], ref["seconds"]),
+        "c_port_value": cport["rate"],
+        "c_port_sample": "%d candidates, plain-C float64 oracle (oracle/mg_oracle.c), 1 core, %.1f s" % (cport["n"], cport["seconds"]),
+        "vectorised_value": vec["rate"], "vectorised_cores": vec["threads"],
+        "vectorised_sample": "%d candidates, float32 GEMM (coefficients) + batched basis GEMM (frames materialised) + "
+                             "batched sklearn score_samples, %d BLAS threads, %.1f s" % (vec["n"], vec["threads"], vec["seconds"]),
+        "host_cores_available": os.cpu_count(),
+    }
+    if multi:
+        out.update({"multi_process_value": multi["rate"], "multi_process_cores": nproc,
+                    "multi_process_sample": "the same reference-shaped loop in %d processes (one core each, disjoint candidate slices), %d candidates, %.1f s"
+                                            % (nproc, multi["n"], multi["seconds"])})
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: one planner step over the 16 options of a graph, 4096 candidates each
+# ---------------------------------------------------------------------------------------------------------
+def run_graph(args):
+    ensure_built()
+    from morphablegraphs_amd import synthetic
+    from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
+    n = int(args.batch) if args.batch != 8192 else 4096
+    prims = synthetic.make_graph_primitives(16)
+    names = [p["name"] for p in prims]
+    cons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]},
+                 {"type": "direction", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [0.5, 1.0]}] for nm, p in zip(names, prims)}
+    pset = HipPrimitiveSet(prims, separate_streams=False)
+    ctxs = list({id(pset.nodes[nm]._prim.ctx): pset.nodes[nm]._prim.ctx for nm in names}.values())
+    for i in range(args.warmup):
+        pset.evaluate_options_on_device(names, cons, n, seed=i)
+    for c in ctxs:
+        c.profile_reset()
+        c.profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        best, results = pset.evaluate_options_on_device(names, cons, n, seed=i)
+    elapsed = time.perf_counter() - t0
+    slots = {}
+    for c in ctxs:
+        c.profile_enable(False)
+        for slot in ("gmm_sample", "score_constraints", "argmin"):
+            ms, cnt = c.profile_get(slot)
+            a = slots.setdefault(slot, [0.0, 0])
+            a[0] += ms
+            a[1] += cnt
+    # flops of the dominant kernel (the scorer, float64 MFMA): X . W^T with 14 keyframe channel rows per candidate,
+    # per option its own L; the sampler's x = mu + z L^T is the other matrix product of a step
+    Ls = [int(np.shape(p["eigen_vectors_spatial"])[0]) for p in prims]
+    score_flop = sum(2 * 14 * l for l in Ls) * n
+    sample_flop = sum(2 * l * l for l in Ls) * n
+    score_ms = slots["score_constraints"][0] / max(1, slots["score_constraints"][1])
+    result = {
+        "metric": METRIC, "value": len(names) * n * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "graph-walk planner step: 16 synthetic primitives (L 12..40, F 40..160, K 1..8) x %d device-sampled candidates each, "
+                               "2 root keyframe constraints, winner per option read back (BASELINE.json configs[2]); score only, no frames written" % n,
+                   "options": len(names), "candidates_per_option": n, "launches_per_step": 4 * len(names)},
+        "roofline": {"bound": "mfma", "kernel": "mg_score_mfma_kernel (one per option)", "achieved": score_flop / len(names) / (score_ms * 1e-3) / 1e12 if score_ms else None,
+                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (score_flop / len(names) / (score_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS) if score_ms else None, "traffic": None,
+                     "avg_kernel_ms": score_ms, "launches_timed": slots["score_constraints"][1],
+                     "note": "4 launch-latency-bound kernels per option (sampler, scorer, argmin, winner copy), ~%d KB each: the step is bound by "
+                             "launch latency, not by the matrix pipe; step flops %.3g (scorer) + %.3g (sampler)" % (n * 40 * 4 // 1024, score_flop, sample_flop),
+                     "per_kernel_avg_us": {k: (1e3 * v[0] / v[1] if v[1] else None) for k, v in slots.items()}},
+    }
+    print(json.dumps(result))
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] per iteration on one GPU: 131072 candidates, objective only (no frames)
+# ---------------------------------------------------------------------------------------------------------
+def run_optimizer(args):
+    ensure_built()
+    from morphablegraphs_amd import _capi, synthetic
+    B = int(args.batch) if args.batch != 8192 else 131072
+    ctx = _capi.Context(0)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+            {"type": "direction", "t": 155.0, "weight": 1.0, "target": [0.5, 1.0]}]
+    cset = _capi.ConstraintSet(prim, cons)
+    rows = 14
+    flop = K * (2 * L * L + 2 * L) + 2 * rows * L          # mixture (dense x P_k, as sklearn does) + the keyframe channel rows
+    S = ctx.upload(np.random.default_rng(0).standard_normal((B, L)).astype(np.float32))
+    lp, err = ctx.malloc(B * 4), ctx.malloc(B * 8)
+
+    def step():
+        prim.gmm_log_prob_dev(S, np.float32, B, L, lp, np.float32)
+        prim.score_constraints_dev(cset, S, np.float32, B, L, err, np.float64)
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ctx.profile_reset()
+    ctx.profile_enable(1 if args.steps < 200 else 8)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    g_ms, g_n = ctx.profile_get("gmm_log_prob")
+    s_ms, s_n = ctx.profile_get("score_constraints")
+    gmm_flop = B * K * (2 * L * L + 2 * L)
+    g_avg = g_ms / max(1, g_n)
+    result = {
+        "metric": METRIC, "value": B * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "optimizer inner loop, score only: log p(x) + 2 root keyframe constraints of %d candidates per iteration on one GPU "
+                               "(BASELINE.json configs[4] is this per iteration over 8 GPUs); no frames written, %d bytes per candidate" % (B, 4 * L + 12),
+                   "candidates_per_iteration": B, "launches_per_step": 2, "flop_per_candidate": flop},
+        "roofline": {"bound": "mfma", "kernel": "mg_gmm_logp_mfma_kernel", "achieved": gmm_flop / (g_avg * 1e-3) / 1e12 if g_avg else None,
+                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (gmm_flop / (g_avg * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS) if g_avg else None,
+                     "traffic": None, "avg_kernel_ms": g_avg, "launches_timed": g_n,
+                     "score_kernel_avg_ms": s_ms / max(1, s_n), "step_achieved_TFLOPs": B * flop / (elapsed / args.steps) / 1e12,
+                     "step_frac": B * flop / (elapsed / args.steps) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                     "peak_note": "float64 matrix peak AMD publishes for MI355X; the microarchitecture guide lists no float64 MFMA row"},
+    }
+    print(json.dumps(result))
+    for b in (S, lp, err):
+        b.free()
+    cset.close()
     prim.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=8192, help="candidates per GPU")
+    ap.add_argument("--config", choices=("walk", "graph", "optimizer"), default="walk",
+                    help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-launch", action="store_true",
+                    help="frames kernel and log-likelihood kernel as two launches instead of the fused step kernel")
+    ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--event-interval", type=int, default=0,
+                    help="every n-th launch of the timed region carries HIP start/stop events attached to the dispatch "
+                         "(0: every launch up to 64 steps, else every 8th)")
+    ap.add_argument("--ramp-steps", type=int, default=1500,
+                    help="untimed steps before the warm-up that let the chip reach its steady clock (~0.13 s; reported in config)")
+    ap.add_argument("--output-alloc", choices=("placed", "plain"), default="placed",
+                    help="placed: the library's allocator for large outputs (mg_device_malloc_placed); plain: one hipMalloc")
+    ap.add_argument("--collective", choices=("mg", "torch"), default="mg",
+                    help="N > 1: mg = RCCL through the library's mg_dist_* entry points (no torch); torch = torch.distributed")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: exercise the launcher, the rendezvous and the JSON contract with a stand-in step (CPU tests)")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.config != "walk":
+        if world > 1:
+            raise SystemExit("--config %s is a single-GPU workload" % args.config)
+        return run_graph(args) if args.config == "graph" else run_optimizer(args)
+    return run_walk(args, rank, local_rank, world)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

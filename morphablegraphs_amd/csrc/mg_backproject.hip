@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "mg_internal.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include "mg_gmm_device.h"
 
@@ -1369,35 +1370,41 @@ __global__ __launch_bounds__(256) void mg_spline_eval_kernel(const double *coeff
 // -----------------------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------------------
+struct mg_launch_events { hipEvent_t start = nullptr, stop = nullptr; };   // both NULL: an ordinary launch
 template <int KK, bool LAT_F64, bool FUSE>
 static int mg_launch_ws_inst(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
-                             int buf_bytes, int lds, int grid, bool cs) {
+                             int buf_bytes, int lds, int grid, bool cs, const mg_launch_events &ev) {
+    // hipExtLaunchKernelGGL with NULL events is hipLaunchKernelGGL; with events the dispatch records its own begin and end
     if (cs)
-        hipLaunchKernelGGL((mg_frames_cs_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_CS_BLOCK), lds, p->ctx->stream, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out,
-                           p->d_gPpack, p->d_gmPpad, p->d_gconst, logp, a, p->K, (p->L + 15) / 16, buf_bytes);
+        hipExtLaunchKernelGGL((mg_frames_cs_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_CS_BLOCK), lds, p->ctx->stream, ev.start, ev.stop, 0,
+                              (const float *)p->d_Epack, (const float *)p->d_mean32, (const double *)p->d_Erpack, (const double *)p->d_meanroot, lat,
+                              (const int32_t *)g->d_i0, (const float4 *)g->d_w32, (const double *)g->d_wtap, (const mg_chunk *)g->d_chunks, out,
+                              (const double *)p->d_gPpack, (const double *)p->d_gmPpad, (const double *)p->d_gconst, logp, a, (int)p->K,
+                              (int)((p->L + 15) / 16), buf_bytes);
     else
-        hipLaunchKernelGGL((mg_frames_ws_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_WS_BLOCK), lds, p->ctx->stream, p->d_Epack, p->d_mean32,
-                           p->d_Erpack, p->d_meanroot, lat, g->d_i0, (const float4 *)g->d_w32, g->d_wtap, g->d_chunks, out,
-                           p->d_gPpack, p->d_gmPpad, p->d_gconst, logp, a, p->K, (p->L + 15) / 16, buf_bytes);
+        hipExtLaunchKernelGGL((mg_frames_ws_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_WS_BLOCK), lds, p->ctx->stream, ev.start, ev.stop, 0,
+                              (const float *)p->d_Epack, (const float *)p->d_mean32, (const double *)p->d_Erpack, (const double *)p->d_meanroot, lat,
+                              (const int32_t *)g->d_i0, (const float4 *)g->d_w32, (const double *)g->d_wtap, (const mg_chunk *)g->d_chunks, out,
+                              (const double *)p->d_gPpack, (const double *)p->d_gmPpad, (const double *)p->d_gconst, logp, a, (int)p->K,
+                              (int)((p->L + 15) / 16), buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
 
 template <int KK>
 static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
-                           bool lat_f64, int buf_bytes, int lds, int grid, bool cs) {
+                           bool lat_f64, int buf_bytes, int lds, int grid, bool cs, const mg_launch_events &ev) {
     if (logp) {
         // fused instances exist for <= 40 components: beyond that the mixture fragments no longer fit the
         // register budget next to the sweep (mg_frames_can_fuse_gmm refuses, so this is never reached)
         if constexpr (KK <= MG_FUSE_MAX_KK)
-            return lat_f64 ? mg_launch_ws_inst<KK, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, cs)
-                           : mg_launch_ws_inst<KK, false, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, cs);
+            return lat_f64 ? mg_launch_ws_inst<KK, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, cs, ev)
+                           : mg_launch_ws_inst<KK, false, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, cs, ev);
         mg_set_error("mg_step_frames_and_logp: no fused kernel for %d components", p->L);
         return MG_ERR_UNSUPPORTED;
     }
-    return lat_f64 ? mg_launch_ws_inst<KK, true, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, cs)
-                   : mg_launch_ws_inst<KK, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, cs);
+    return lat_f64 ? mg_launch_ws_inst<KK, true, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, cs, ev)
+                   : mg_launch_ws_inst<KK, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, cs, ev);
 }
 
 template <int KK>
@@ -1442,7 +1449,8 @@ bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_
            (n_tiles + grid - 1) / grid <= 4;   // the fused scoring handles at most four 16-candidate tiles per workgroup
 }
 
-int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp) {
+int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
+                          int prof_slot, int prof_slot2) {
     mg_frames_args a;
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
     a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.max_nt = g->max_nt; a.nbuf = g->nbuf;
@@ -1481,18 +1489,20 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     if (cs) lds = g->cs_lds_bytes;
     if (logp) lds += mg_fused_gmm_lds(p);
     const int grid = grid0;
+    mg_launch_events ev;
+    if (prof_slot >= 0) (void)mg_prof_kernel(p->ctx, prof_slot, prof_slot2, &ev.start, &ev.stop);
     switch (p->KK) {
 #ifndef MG_ONLY_KK10
-        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
-        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
-        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
-        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
+        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
+        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
+        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
 #endif
-        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
 #ifndef MG_ONLY_KK10
-        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
-        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
-        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs);
+        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
+        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
+        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, cs, ev);
 #endif
         default: mg_set_error("mg_back_project_frames: MFMA path needs n_components <= 64"); return MG_ERR_UNSUPPORTED;
     }

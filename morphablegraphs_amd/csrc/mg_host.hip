@@ -409,6 +409,21 @@ void mg_prof_begin(mg_context *ctx, int slot) {
     (void)hipEventRecord(p.a, ctx->stream);
     ctx->pending.push_back(p);
 }
+bool mg_prof_kernel(mg_context *ctx, int slot, int slot2, hipEvent_t *start, hipEvent_t *stop) {
+    if (!ctx->profile) return false;
+    if (ctx->prof_interval > 1 && (ctx->prof_seen[slot]++ % ctx->prof_interval) != 0) return false;
+    if (ctx->pending.size() > 4096) (void)mg_prof_resolve(ctx);
+    mg_event_pair p;
+    p.a = mg_get_event(ctx);
+    p.b = mg_get_event(ctx);
+    p.slot = slot;
+    p.slot2 = slot2;
+    p.ended = true;
+    ctx->pending.push_back(p);
+    *start = p.a;
+    *stop = p.b;
+    return true;
+}
 void mg_prof_end(mg_context *ctx, int slot) {
     if (!ctx->profile) return;
     for (size_t i = ctx->pending.size(); i-- > 0;) {   // brackets may nest (step > frames)
@@ -424,9 +439,12 @@ int mg_prof_resolve(mg_context *ctx) {
     for (auto &p : ctx->pending) {
         float ms = 0.f;
         if (p.ended && hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            ctx->prof_ms[p.slot] += (double)ms;
-            ctx->prof_n[p.slot] += 1;
-            if (ctx->prof_samples[p.slot].size() < 65536) ctx->prof_samples[p.slot].push_back(ms);
+            for (int sl : {p.slot, p.slot2}) {
+                if (sl < 0) continue;
+                ctx->prof_ms[sl] += (double)ms;
+                ctx->prof_n[sl] += 1;
+                if (ctx->prof_samples[sl].size() < 65536) ctx->prof_samples[sl].push_back(ms);
+            }
         }
         ctx->free_events.push_back(p.a);
         ctx->free_events.push_back(p.b);
@@ -1022,8 +1040,9 @@ extern "C" int mg_back_project_frames(mg_primitive *p, const mg_time_grid *g, co
     } else {
         use_mfma = g->mfma_ok && B >= 8;
     }
+    if (use_mfma) return mg_launch_frames_mfma(p, g, lat, dt, B, ld, out, nullptr, 0);   // timed by events attached to the launch
     mg_prof_begin(p->ctx, 0);
-    rc = use_mfma ? mg_launch_frames_mfma(p, g, lat, dt, B, ld, out, nullptr) : mg_launch_frames_direct(p, g, lat, dt, B, ld, out, false);
+    rc = mg_launch_frames_direct(p, g, lat, dt, B, ld, out, false);
     mg_prof_end(p->ctx, 0);
     return rc;
 }
@@ -1515,12 +1534,7 @@ extern "C" int mg_step_frames_and_logp(mg_primitive *p, const void *lat, int dt,
     const mg_time_grid *g = p->canonical;
     if (B >= 8 && g->T > 0 && frames && logp && mg_frames_can_fuse_gmm(p, g, B)) {
         // one launch: the mixture is scored by the sweep waves while the pipeline of the frames kernel fills
-        mg_prof_begin(ctx, 6);
-        mg_prof_begin(ctx, 0);
-        rc = mg_launch_frames_mfma(p, g, lat, dt, B, ld, frames, logp);
-        mg_prof_end(ctx, 0);
-        mg_prof_end(ctx, 6);
-        return rc;
+        return mg_launch_frames_mfma(p, g, lat, dt, B, ld, frames, logp, 0, 6);   // one kernel: slot "frames" and slot "step"
     }
     mg_prof_begin(ctx, 6);
     rc = mg_back_project_frames(p, nullptr, lat, dt, B, ld, frames, MG_PATH_AUTO);

@@ -27,6 +27,7 @@ struct mg_event_pair {
     hipEvent_t a, b;
     int slot;
     bool ended;
+    int slot2 = -1;   // the same duration counted into a second slot as well (the fused step: "frames" and "step")
 };
 
 struct mg_context {
@@ -65,6 +66,9 @@ void mg_dev_free(mg_context *ctx, void *p);   // hipFree unless p lives in the c
 
 int mg_ctx_scratch(mg_context *ctx, int64_t bytes, void **out);
 void mg_prof_begin(mg_context *ctx, int slot);
+// Events attached to ONE kernel launch (hipExtLaunchKernel start / stop events: the dispatch's own timestamps, no
+// marker packets between launches): true and two events if this launch of `slot` is to be timed, else false.
+bool mg_prof_kernel(mg_context *ctx, int slot, int slot2, hipEvent_t *start, hipEvent_t *stop);
 void mg_prof_end(mg_context *ctx, int slot);
 int mg_prof_resolve(mg_context *ctx);
 
@@ -173,7 +177,8 @@ struct mg_constraint_set {
 #define MG_POSE_REC (5 + 4 * MG_MAX_CHAIN)       // target xyz, weight, chain length m, then m x (quaternion row or -1, offset xyz)
 
 // launchers (each validates nothing: the C-ABI entry points did)
-int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp);
+int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
+                          int prof_slot = -1, int prof_slot2 = -1);   // prof_slot >= 0: the launch carries its own timing events
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B);
 int mg_cs_max_tiles(int KK);   // row tiles of a chunk window the chunk-stationary kernel can hold in registers
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);

@@ -3,8 +3,10 @@
 Candidates are independent units: rank r owns the contiguous block [r*B/N, (r+1)*B/N), the per-primitive
 constants are replicated, and the only exchange is one all-gather of the per-rank scores (RCCL over xGMI
 on GPUs, gloo in the CPU tests) followed by the reference's first-minimum argmin over the GLOBAL index order
-(reference motion_primitive_generator.py:251-257).  torch.distributed is plumbing; the scores come from the
-scorer callable (libmg_hip on a GPU box).
+(reference motion_primitive_generator.py:251-257).  Two carriers of the same exchange: torch.distributed (the
+*_scores / *_minloc / sharded_best_candidate functions; plumbing only) and, for hosts without torch, the library's
+own RCCL entry points (mg_all_gather_scores / mg_sharded_best_candidate over a _capi.Context after dist_init).
+The scores come from the scorer callable (libmg_hip on a GPU box).
 """
 import numpy as np
 
@@ -85,4 +87,37 @@ def sharded_best_candidate(samples, scorer, group=None, exchange="scores"):
         local = torch.as_tensor(np.asarray(local, dtype=np.float64))
     scores = all_gather_scores(local, n, group)
     idx, val = first_min_argmin(scores.detach().cpu().numpy())
+    return idx, val, scores
+
+
+def mg_all_gather_scores(ctx, local_scores, n_total, rank, world, dtype=np.float64):
+    """The all-gather of per-rank score blocks through mg_dist_all_gather (RCCL loaded by libmg_hip.so, communicator
+    made by ctx.dist_init): no torch anywhere.  Blocks of different lengths are padded with +inf to the longest."""
+    local = np.ascontiguousarray(local_scores, dtype=dtype)
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    assert local.size == sizes[rank], "local block has %d scores, expected %d" % (local.size, sizes[rank])
+    m = max(sizes) if sizes else 0
+    if m == 0:
+        return np.empty((0,), dtype=dtype)
+    padded = np.full((m,), np.inf, dtype=dtype)
+    padded[: local.size] = local
+    d_local = ctx.upload(padded)
+    d_all = ctx.malloc(world * m * padded.itemsize)
+    try:
+        ctx.dist_all_gather(d_local, d_all, m, dtype)
+        everyone = ctx.download(d_all, (world, m), dtype)     # synchronises the context's stream
+    finally:
+        d_local.free()
+        d_all.free()
+    return np.concatenate([everyone[r, : sizes[r]] for r in range(world)])
+
+
+def mg_sharded_best_candidate(ctx, samples, scorer, rank, world):
+    """sharded_best_candidate without torch: every rank scores its contiguous block with `scorer(block)` and the
+    blocks travel through mg_all_gather_scores; returns the same (best_index, min_error, all_scores) on every rank."""
+    n = len(samples)
+    b, e = shard_range(n, rank, world)
+    local = np.asarray(scorer(samples[b:e]), dtype=np.float64)
+    scores = mg_all_gather_scores(ctx, local, n, rank, world)
+    idx, val = first_min_argmin(scores)
     return idx, val, scores

@@ -1,0 +1,57 @@
+"""bench.py's N > 1 plumbing without a GPU (--dry-run): typed as `python bench.py --gpus 2` it must launch its own
+ranks and print exactly one JSON line; launched the driver's way (torch.distributed.run) it must read the ranks from
+the environment; both carriers of the collective (file rendezvous of the torch-free path, torch.distributed gloo)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def _run(cmd, env=None, timeout=240):
+    e = dict(os.environ)
+    e.update(env or {})
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    p = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return p.stdout.decode()
+
+
+@pytest.mark.parametrize("collective", ["mg", "torch"])
+def test_gpus_n_typed_as_is_launches_its_own_ranks(collective):
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run", "--batch", "64",
+                "--collective", collective], env={"MG_BENCH_BACKEND": "gloo"})
+    lines = _json_lines(out)
+    assert len(lines) == 1, out
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 1 and r["dry_run"] is True
+    assert r["config"]["global_candidates"] == 128 and r["scaling"] == "weak" and r["unit"] == "samples/s"
+    assert r["value"] > 0 and abs(r["ms_per_step"] * r["value"] / 1e3 - 128) < 1e-6
+
+
+def test_the_drivers_launch_form_reads_the_ranks_from_the_environment():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run", "--batch", "32"])
+    lines = _json_lines(out)
+    assert len(lines) == 1, out
+    assert lines[0]["n_gpus"] == 2 and lines[0]["config"]["global_candidates"] == 64
+
+
+def test_single_rank_dry_run_and_world_size_mismatch():
+    lines = _json_lines(_run([sys.executable, "bench.py", "--steps", "3", "--warmup", "0", "--dry-run"]))
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1
+    e = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"does not match WORLD_SIZE" in p.stderr

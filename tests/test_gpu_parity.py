@@ -1046,6 +1046,14 @@ def test_rccl_entry_points_of_the_c_abi_on_one_rank():
         d_l, d_g = ctx.upload(local), ctx.malloc(local.nbytes)
         ctx.dist_all_gather(d_l, d_g, len(local), dtype)
         np.testing.assert_array_equal(ctx.download(d_g, (len(local),), dtype), local)
+    # the torch-free sharded argmin on top of it (distributed.mg_sharded_best_candidate), one rank
+    from morphablegraphs_amd import distributed
+    S = np.random.default_rng(1).standard_normal((37, 8))
+    S[20] = S[3]
+    score = lambda blk: np.abs(blk).sum(axis=1)
+    idx, val, scores = distributed.mg_sharded_best_candidate(ctx, S, score, 0, 1)
+    np.testing.assert_array_equal(scores, score(S))
+    assert idx == int(np.argmin(score(S))) and val == score(S).min()
     ctx.dist_finalize()
     ctx.dist_finalize()                                                    # idempotent
     ctx.close()
