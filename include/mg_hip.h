@@ -70,8 +70,20 @@ typedef struct mg_primitive_desc {
     const double *translation_maxima; /* 3 values; NULL = [1,1,1] (v3 load path)      */
     const double *knots;         /* b_spline_knots_spatial (NB+4)                     */
     const double *gmm_weights;   /* (K)                                               */
-    const double *gmm_means;     /* (K, L)                                            */
-    const double *gmm_covars;    /* (K, L, L)                                         */
+    const double *gmm_means;     /* (K, Lg)                                           */
+    const double *gmm_covars;    /* (K, Lg, Lg)                                       */
+    /* The reference fits the mixture over the CONCATENATED (spatial, time) latents (reference
+     * construction/motion_model_constructor.py:424; motion_primitive.py:229-231 splits s[:n_s] / s[n_s:]):
+     * Lg = n_gmm_dims >= n_components, 0 = n_components.  Sampling, log p and its Jacobian work on all Lg columns;
+     * back projection and constraint scoring read the first n_components of every row. */
+    int32_t n_gmm_dims;
+    /* time model (reference motion_primitive.py:164-181, _init_time_parameters_from_json); 0 components = none */
+    int32_t n_time_components;   /* columns of eigen_vectors_time                      */
+    int32_t n_basis_time;        /* n_basis_time                                      */
+    int32_t reserved;
+    const double *eigen_vectors_time;  /* (n_basis_time, n_time_components) as the JSON holds it */
+    const double *mean_time_vector;    /* (n_basis_time)                               */
+    const double *knots_time;          /* b_spline_knots_time (n_basis_time + 4)       */
 } mg_primitive_desc;
 
 /* One keyframe constraint, the subset of
@@ -266,10 +278,22 @@ int mg_dist_finalize(mg_context *ctx);
 int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *desc, mg_primitive **out);
 void mg_primitive_destroy(mg_primitive *prim);
 /* out[8] = {n_basis, n_dim, n_components, n_canonical_frames, n_gmm, kk (MFMA k-steps),
- *           mfma_supported, reserved} */
+ *           mfma_supported, chunks of the canonical grid}; mg_primitive_info2: out[4] = {n_gmm_dims, n_time_components,
+ *           n_basis_time, kk of the mixture} */
 int mg_primitive_info(const mg_primitive *prim, int32_t *out8);
+int mg_primitive_info2(const mg_primitive *prim, int32_t *out4);
 /* (K, L, L) float64, upper triangular: sklearn's precisions_cholesky_ */
 int mg_primitive_get_precisions_cholesky(const mg_primitive *prim, double *out);
+
+/* MotionPrimitive._back_transform_gamma_to_canonical_time_function for a batch (reference motion_primitive.py:289-302):
+ * out[b][i] = sum_{j <= i} exp(mean_t(j) + sum_l phi_l(j) gamma[b][l]) - 1, i = 0 .. n_canonical_frames - 1, with the mean
+ * and the harmonics evaluated at the canonical frames by the FITPACK splev recurrence on the time knots (float64, host,
+ * once per primitive).  gamma: (B, ld), first n_time_components columns; out: (B, n_canonical_frames) float64.
+ * MG_ERR_INVALID_ARGUMENT if the primitive has no time model. */
+int mg_time_function_canonical(mg_primitive *prim, const void *gamma_dev, int gamma_dtype, int64_t n_samples, int64_t ld,
+                               double *out_dev);
+int mg_time_function_canonical_host(mg_primitive *prim, const void *gamma, int gamma_dtype, int64_t n_samples, int64_t ld,
+                                    double *out);
 
 /* ---- time grids ---------------------------------------------------------------------
  * A set of canonical times with its B-spline basis rows (FITPACK splev semantics,

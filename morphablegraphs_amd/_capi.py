@@ -32,7 +32,8 @@ EXPORTED_SYMBOLS = [
     "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
     "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
-    "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_get_precisions_cholesky",
+    "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_get_precisions_cholesky",
+    "mg_time_function_canonical", "mg_time_function_canonical_host",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
@@ -57,7 +58,9 @@ class PrimitiveDesc(C.Structure):
                 ("n_canonical_frames", C.c_int32), ("n_gmm", C.c_int32), ("eigen_is_transposed", C.c_int32),
                 ("eigen_vectors", C.c_void_p), ("mean_vector", C.c_void_p), ("translation_maxima", C.c_void_p),
                 ("knots", C.c_void_p), ("gmm_weights", C.c_void_p), ("gmm_means", C.c_void_p),
-                ("gmm_covars", C.c_void_p)]
+                ("gmm_covars", C.c_void_p), ("n_gmm_dims", C.c_int32), ("n_time_components", C.c_int32),
+                ("n_basis_time", C.c_int32), ("reserved", C.c_int32), ("eigen_vectors_time", C.c_void_p),
+                ("mean_time_vector", C.c_void_p), ("knots_time", C.c_void_p)]
 
 
 class KeyframeConstraint(C.Structure):
@@ -206,6 +209,9 @@ def load_library(path=None):
         "mg_profile_get_samples": [vp, i32, vp, i64, C.POINTER(i64)],
         "mg_primitive_create": [vp, C.POINTER(PrimitiveDesc), C.POINTER(vp)],
         "mg_primitive_info": [vp, C.POINTER(C.c_int32)],
+        "mg_primitive_info2": [vp, C.POINTER(C.c_int32)],
+        "mg_time_function_canonical": [vp, vp, i32, i64, i64, vp],
+        "mg_time_function_canonical_host": [vp, vp, i32, i64, i64, vp],
         "mg_primitive_get_precisions_cholesky": [vp, vp],
         "mg_time_grid_create": [vp, vp, C.c_int32, C.POINTER(vp)],
         "mg_time_grid_get_tables": [vp, vp, vp, vp],
@@ -640,14 +646,27 @@ class Primitive(object):
             gw = np.ascontiguousarray(np.asarray(data["gmm_weights"], dtype=np.float64))
             gm = np.ascontiguousarray(np.asarray(data["gmm_means"], dtype=np.float64))
             gc = np.ascontiguousarray(np.asarray(data["gmm_covars"], dtype=np.float64))
+            # the reference fits the mixture over the concatenated (spatial, time) latents: Lg >= L columns
             L = eig.shape[0]
-            if gm.shape != (len(gw), L) or gc.shape != (len(gw), L, L):
+            Lg = gm.shape[1] if gm.ndim == 2 else -1
+            if gm.ndim != 2 or gm.shape[0] != len(gw) or Lg < L or gc.shape != (len(gw), Lg, Lg):
                 raise ValueError("gmm_means/gmm_covars have the wrong shape")
             d.n_gmm = len(gw)
+            d.n_gmm_dims = Lg
             d.gmm_weights, d.gmm_means, d.gmm_covars = gw.ctypes.data, gm.ctypes.data, gc.ctypes.data
             keep += [gw, gm, gc]
         else:
             d.n_gmm = 0
+        if data.get("eigen_vectors_time") is not None:
+            et = np.ascontiguousarray(np.asarray(data["eigen_vectors_time"], dtype=np.float64))
+            mt = np.ascontiguousarray(np.asarray(data["mean_time_vector"], dtype=np.float64))
+            kt = np.ascontiguousarray(np.asarray(data["b_spline_knots_time"], dtype=np.float64))
+            nbt = int(data["n_basis_time"])
+            if et.ndim != 2 or et.shape[0] != nbt or mt.shape != (nbt,) or kt.shape != (nbt + 4,):
+                raise ValueError("eigen_vectors_time must be (n_basis_time, n_time_components); mean_time_vector (n_basis_time); knots (n_basis_time + 4)")
+            d.n_time_components, d.n_basis_time = et.shape[1], nbt
+            d.eigen_vectors_time, d.mean_time_vector, d.knots_time = et.ctypes.data, mt.ctypes.data, kt.ctypes.data
+            keep += [et, mt, kt]
         h = C.c_void_p()
         _check(self.lib.mg_primitive_create(ctx.handle, C.byref(d), C.byref(h)))
         self.handle = h
@@ -656,6 +675,9 @@ class Primitive(object):
         (self.n_basis, self.n_dim, self.n_components, self.n_canonical_frames, self.n_gmm,
          self.kk, mfma, self.n_chunks) = [int(v) for v in info]
         self.mfma_supported = bool(mfma)
+        info2 = (C.c_int32 * 4)()
+        _check(self.lib.mg_primitive_info2(self.handle, info2))
+        self.n_gmm_dims, self.n_time_components, self.n_basis_time, self.kk_gmm = [int(v) for v in info2]
         self.canonical_grid = TimeGrid(self, handle=C.c_void_p(self.lib.mg_primitive_canonical_grid(self.handle)))
 
     def close(self):
@@ -671,8 +693,17 @@ class Primitive(object):
 
     # ---- queries -----------------------------------------------------------------------
     def precisions_cholesky(self):
-        out = np.empty((self.n_gmm, self.n_components, self.n_components))
+        out = np.empty((self.n_gmm, self.n_gmm_dims, self.n_gmm_dims))
         _check(self.lib.mg_primitive_get_precisions_cholesky(self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def time_function_canonical(self, gamma):
+        """(B, n_time_components) time latents -> (B, n_canonical_frames) float64: the reference's
+        _back_transform_gamma_to_canonical_time_function (motion_primitive.py:289-302) for every row."""
+        G = _latents(gamma)
+        out = np.empty((G.shape[0], self.n_canonical_frames), dtype=np.float64)
+        _check(self.lib.mg_time_function_canonical_host(self.handle, G.ctypes.data_as(C.c_void_p), _dtype_code(G), G.shape[0], G.shape[1],
+                                                        out.ctypes.data_as(C.c_void_p)))
         return out
 
     def time_grid(self, times):
@@ -730,10 +761,10 @@ class Primitive(object):
     def gmm_sample(self, counts, seed, dtype=np.float64):
         counts = np.ascontiguousarray(counts, dtype=np.int64)
         n = int(counts.sum())
-        X = np.empty((n, self.n_components), dtype=dtype)
+        X = np.empty((n, self.n_gmm_dims), dtype=dtype)
         comp = np.empty(n, dtype=np.int32)
         _check(self.lib.mg_gmm_sample_host(self.handle, n, counts.ctypes.data_as(C.c_void_p), C.c_uint64(int(seed)),
-                                           X.ctypes.data_as(C.c_void_p), _dtype_code(X), self.n_components,
+                                           X.ctypes.data_as(C.c_void_p), _dtype_code(X), self.n_gmm_dims,
                                            comp.ctypes.data_as(C.c_void_p)))
         return X, comp
 
@@ -772,7 +803,7 @@ class Primitive(object):
     def gmm_log_prob_jac(self, X):
         """(n_samples, n_components) float64: the reference's log_likelihood_jac (= -grad log p) per row."""
         X = _latents(X)
-        out = np.empty((X.shape[0], self.n_components), dtype=np.float64)
+        out = np.empty((X.shape[0], self.n_gmm_dims), dtype=np.float64)
         _check(self.lib.mg_gmm_log_prob_jac_host(self.handle, X.ctypes.data_as(C.c_void_p), _dtype_code(X), X.shape[0],
                                                  X.shape[1], out.ctypes.data_as(C.c_void_p)))
         return out

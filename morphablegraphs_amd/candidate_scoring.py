@@ -241,7 +241,7 @@ def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleto
     skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
     cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton,
                                  alignment_from_prev_frames(prev_frames, constraints, skeleton))
-    L = prim.n_components
+    L = prim.n_gmm_dims          # the full sample (spatial + time latents); scoring reads its first n_components columns
     weights = np.asarray(prim_obj.gaussian_mixture_model.weights_, dtype=np.float64)
     counts = np.random.multinomial(int(n_samples), weights / weights.sum()).astype(np.int64)
     item = np.dtype(dtype).itemsize

@@ -1445,7 +1445,7 @@ static int mg_fused_gmm_lds(const mg_primitive *p) { return 4 * p->K * 16 * 8; }
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t grid = std::min<int64_t>(n_tiles * g->n_chunks, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
-    return g->mfma_ok && p->d_gPpack != nullptr && p->K <= 16 && p->KK <= MG_FUSE_MAX_KK && g->lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 &&
+    return g->mfma_ok && p->d_gPpack != nullptr && p->K <= 16 && p->KK <= MG_FUSE_MAX_KK && p->Lg == p->L &&   // fused: the mixture spans exactly the spatial latents g->lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 &&
            (n_tiles + grid - 1) / grid <= 4;   // the fused scoring handles at most four 16-candidate tiles per workgroup
 }
 

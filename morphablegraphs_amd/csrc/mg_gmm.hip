@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__r
 template <int KK>
 static int mg_launch_gmm_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
     mg_gmm_mfma_args a;
-    a.B = B; a.ld = ld; a.K = p->K; a.L = p->L; a.JT = (p->L + 15) / 16;
+    a.B = B; a.ld = ld; a.K = p->K; a.L = p->Lg; a.JT = (p->Lg + 15) / 16;
     const int64_t grid = (B + 15) / 16;
     if (grid > 0x7fffffff) { mg_set_error("mg_gmm_log_prob: too many samples"); return MG_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)p->K * 16 * 8 * 2;
@@ -248,7 +248,7 @@ static int mg_launch_gmm_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_
 
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
     if (p->d_gPpack && p->K * 16 * 16 <= 60 * 1024) {
-        switch (p->KK) {
+        switch (p->KKg) {
             case 2: return mg_launch_gmm_mfma_kk<2>(p, x, xdt, B, ld, out, odt);
             case 4: return mg_launch_gmm_mfma_kk<4>(p, x, xdt, B, ld, out, odt);
             case 6: return mg_launch_gmm_mfma_kk<6>(p, x, xdt, B, ld, out, odt);
@@ -261,11 +261,11 @@ int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64
         }
     }
     mg_gmm_args a;
-    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
+    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->Lg;
     int64_t grid = (B + MG_GMM_CANDS - 1) / MG_GMM_CANDS;
-    size_t lds = ((size_t)MG_GMM_CANDS * (p->L + 1) + (size_t)p->K * MG_GMM_CANDS) * 8;
+    size_t lds = ((size_t)MG_GMM_CANDS * (p->Lg + 1) + (size_t)p->K * MG_GMM_CANDS) * 8;
     if (lds > 150 * 1024 || grid > 0x7fffffff) {
-        mg_set_error("mg_gmm_log_prob: n_components %d / n_gmm %d too large for the LDS-staged kernel", p->L, p->K);
+        mg_set_error("mg_gmm_log_prob: n_components %d / n_gmm %d too large for the LDS-staged kernel", p->Lg, p->K);
         return MG_ERR_UNSUPPORTED;
     }
     dim3 blk(MG_GMM_CANDS * MG_GMM_WAVES);
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(MG_SAMPLE_BLOCK) void mg_gmm_sample_kernel(mg_sampl
 
 int mg_launch_gmm_sample_valu(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
     mg_sample_args a;
-    a.chol = p->d_gchol; a.mean = p->d_gmean; a.cum = cum_dev; a.x = x; a.comp = comp; a.n = n; a.ld = ld; a.seed = seed; a.K = p->K; a.L = p->L;
-    size_t lds = (size_t)MG_SAMPLE_BLOCK * (p->L + 1) * 8;
-    if (lds > 150 * 1024) { mg_set_error("mg_gmm_sample: n_components %d too large", p->L); return MG_ERR_UNSUPPORTED; }
+    a.chol = p->d_gchol; a.mean = p->d_gmean; a.cum = cum_dev; a.x = x; a.comp = comp; a.n = n; a.ld = ld; a.seed = seed; a.K = p->K; a.L = p->Lg;
+    size_t lds = (size_t)MG_SAMPLE_BLOCK * (p->Lg + 1) * 8;
+    if (lds > 150 * 1024) { mg_set_error("mg_gmm_sample: n_components %d too large", p->Lg); return MG_ERR_UNSUPPORTED; }
     int64_t grid = (n + MG_SAMPLE_BLOCK - 1) / MG_SAMPLE_BLOCK;
     if (grid > 0x7fffffff) { mg_set_error("mg_gmm_sample: too many samples"); return MG_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void mg_gmm_jac_mfma_kernel(const double *__re
 template <int KK>
 static int mg_launch_gmm_jac_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out) {
     mg_gmm_mfma_args a;
-    a.B = B; a.ld = ld; a.K = p->K; a.L = p->L; a.JT = (p->L + 15) / 16;
+    a.B = B; a.ld = ld; a.K = p->K; a.L = p->Lg; a.JT = (p->Lg + 15) / 16;
     constexpr int JTM = (KK + 3) / 4;
     const int64_t grid = (B + 15) / 16;
     const size_t lds = ((size_t)p->K * 16 * (JTM * 16 + 1) + (size_t)p->K * 16 + 16 + (size_t)4 * 16 * JTM * 16) * 8;
@@ -505,7 +505,7 @@ static int mg_launch_gmm_jac_mfma_kk(mg_primitive *p, const void *x, int xdt, in
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out) {
     if (p->d_gPTpack) {
         int rc = MG_ERR_UNSUPPORTED;
-        switch (p->KK) {
+        switch (p->KKg) {
             case 2: rc = mg_launch_gmm_jac_mfma_kk<2>(p, x, xdt, B, ld, out); break;
             case 4: rc = mg_launch_gmm_jac_mfma_kk<4>(p, x, xdt, B, ld, out); break;
             case 6: rc = mg_launch_gmm_jac_mfma_kk<6>(p, x, xdt, B, ld, out); break;
@@ -519,11 +519,11 @@ int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_
         if (rc != MG_ERR_UNSUPPORTED) return rc;   // too many components for LDS: the VALU kernel below
     }
     mg_gmm_args a;
-    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->L;
+    a.P = p->d_gP; a.mP = p->d_gmP; a.cst = p->d_gconst; a.x = x; a.out = out; a.B = B; a.ld = ld; a.K = p->K; a.L = p->Lg;
     const int64_t grid = (B + MG_JAC_CANDS - 1) / MG_JAC_CANDS;
-    const size_t lds = ((size_t)MG_JAC_CANDS * p->L * (1 + p->K) + (size_t)p->K * MG_JAC_CANDS + MG_JAC_CANDS + (size_t)p->L * (p->L + 1)) * 8;
-    if (lds > 150 * 1024 || grid > 0x7fffffff || MG_JAC_CANDS * p->L > 256 * MG_JAC_ITEMS) {
-        mg_set_error("mg_gmm_log_prob_jac: n_components %d x n_gmm %d too large for the LDS-staged kernel", p->L, p->K);
+    const size_t lds = ((size_t)MG_JAC_CANDS * p->Lg * (1 + p->K) + (size_t)p->K * MG_JAC_CANDS + MG_JAC_CANDS + (size_t)p->Lg * (p->Lg + 1)) * 8;
+    if (lds > 150 * 1024 || grid > 0x7fffffff || MG_JAC_CANDS * p->Lg > 256 * MG_JAC_ITEMS) {
+        mg_set_error("mg_gmm_log_prob_jac: n_components %d x n_gmm %d too large for the LDS-staged kernel", p->Lg, p->K);
         return MG_ERR_UNSUPPORTED;
     }
     if (lds > 64 * 1024) {
@@ -620,16 +620,16 @@ static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev,
     if (grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
     const size_t lds = (size_t)4 * 16 * (4 * KK + 1) * 8;
     hipStream_t st = p->ctx->stream;
-    const int JT = (p->L + 15) / 16;
+    const int JT = (p->Lg + 15) / 16;
     mg_cum_arg ca;
     memset(&ca, 0, sizeof(ca));
     if (cum_host) {
         memcpy(ca.v, cum_host, sizeof(int64_t) * 2 * (p->K + 1));
-        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
-        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
+        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
     } else {
-        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
-        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->L, JT);
+        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
+        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
     }
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
@@ -637,7 +637,7 @@ static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev,
 
 int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
     if (p->d_gcholpack && (cum_host || cum_dev) && !p->ctx->opt[MG_OPT_FORCE_VALU_SAMPLE]) {
-        switch (p->KK) {
+        switch (p->KKg) {
             case 2: return mg_launch_gmm_sample_mfma_kk<2>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
             case 4: return mg_launch_gmm_sample_mfma_kk<4>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
             case 6: return mg_launch_gmm_sample_mfma_kk<6>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
@@ -653,5 +653,36 @@ int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, con
 }
 
 bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p) {
-    return p->d_gcholpack != nullptr && p->KK > 0 && p->K <= MG_SAMPLE_ARG_K && !p->ctx->opt[MG_OPT_FORCE_VALU_SAMPLE];
+    return p->d_gcholpack != nullptr && p->KKg > 0 && p->K <= MG_SAMPLE_ARG_K && !p->ctx->opt[MG_OPT_FORCE_VALU_SAMPLE];
+}
+
+
+// MotionPrimitive._back_transform_gamma_to_canonical_time_function (reference motion_primitive.py:289-302): one thread per
+// sample walks the canonical frames, increment = exp(mean_t(i) + phi(i) . gamma) with the dot product as an ascending fma chain
+__global__ __launch_bounds__(128) void mg_time_function_kernel(const double *__restrict__ tphi, const double *__restrict__ tmean,
+                                                               const void *__restrict__ gamma, int gamma_f64, int64_t B, int64_t ld,
+                                                               int F, int Lt, double *__restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double g[16];
+    for (int l = 0; l < Lt && l < 16; l++)
+        g[l] = gamma_f64 ? ((const double *)gamma)[b * ld + l] : (double)((const float *)gamma)[b * ld + l];
+    double acc = 0.0;
+    for (int i = 0; i < F; i++) {
+        double e = tmean[i];
+        for (int l = 0; l < Lt; l++) {
+            const double gl = l < 16 ? g[l] : (gamma_f64 ? ((const double *)gamma)[b * ld + l] : (double)((const float *)gamma)[b * ld + l]);
+            e = fma(tphi[(size_t)i * Lt + l], gl, e);
+        }
+        acc += exp(e);
+        out[b * F + i] = acc - 1.0;
+    }
+}
+
+int mg_launch_time_function(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double *out) {
+    const int grid = (int)((B + 127) / 128);
+    hipLaunchKernelGGL(mg_time_function_kernel, dim3(grid), dim3(128), 0, p->ctx->stream, p->d_tphi, p->d_tmean, gamma, gdt == MG_F64 ? 1 : 0,
+                       B, ld, p->F, p->Lt, out);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
 }

@@ -743,7 +743,8 @@ static void mg_primitive_free(mg_primitive *p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean,
-                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad, p->d_gPTpack, p->d_gcholpack, p->d_gmeanpad};
+                    p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad, p->d_gPTpack, p->d_gcholpack, p->d_gmeanpad,
+                    p->d_tphi, p->d_tmean};
     for (void *q : ptrs) mg_dev_free(p->ctx, q);
     for (mg_time_grid *g : {p->canonical, p->coeff_grid})
         if (g) { mg_free_grid_device(g); delete g; }
@@ -764,6 +765,11 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                "mg_primitive_create: gmm arrays are required when n_gmm > 0");
     MG_REQUIRE((int64_t)d->n_basis * d->n_dim < (1 << 24), "mg_primitive_create: n_basis*n_dim too large");
     const int NB = d->n_basis, D = d->n_dim, L = d->n_components, K = d->n_gmm, R = NB * D;
+    const int Lg = d->n_gmm_dims > 0 ? d->n_gmm_dims : L;   // the mixture spans the spatial AND the time latents
+    MG_REQUIRE(Lg >= L, "mg_primitive_create: n_gmm_dims = %d < n_components = %d", Lg, L);
+    const int Lt = d->n_time_components, NBt = d->n_basis_time;
+    MG_REQUIRE(Lt >= 0 && (Lt == 0 || (NBt >= 4 && d->eigen_vectors_time && d->mean_time_vector && d->knots_time)),
+               "mg_primitive_create: a time model needs n_basis_time >= 4, eigen_vectors_time, mean_time_vector and knots_time");
     for (int i = 0; i + 1 < NB + 4; i++)
         MG_REQUIRE(d->knots[i] <= d->knots[i + 1] && std::isfinite(d->knots[i + 1]), "mg_primitive_create: knots must be finite and non-decreasing");
     MG_REQUIRE(d->knots[3] < d->knots[NB], "mg_primitive_create: knot vector has an empty domain");
@@ -775,6 +781,9 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
     p->NB = NB; p->D = D; p->L = L; p->F = d->n_canonical_frames; p->K = K; p->R = R;
     p->nroot = std::min(3, D);
     p->KK = (L <= 4 * MG_MAX_KK) ? (((L + 3) / 4 + 1) / 2) * 2 : 0;
+    p->Lg = Lg;
+    p->KKg = (Lg <= 4 * MG_MAX_KK) ? (((Lg + 3) / 4 + 1) / 2) * 2 : 0;
+    p->Lt = Lt; p->NBt = NBt;
     // padded coefficient rows: column = d + cshift so that the first non-root channel sits on a
     // 16-byte boundary (quads of channels start at d = nroot), pitch a multiple of 4
     p->cshift = (4 - p->nroot) & 3;
@@ -855,51 +864,51 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
 
     if (K > 0) {
         p->gw.assign(d->gmm_weights, d->gmm_weights + K);
-        p->gm.assign(d->gmm_means, d->gmm_means + (size_t)K * L);
-        p->gc.assign(d->gmm_covars, d->gmm_covars + (size_t)K * L * L);
-        p->gp.assign((size_t)K * L * L, 0.0);
-        std::vector<double> chol((size_t)K * L * L), inv((size_t)L * L);
-        std::vector<double> gP((size_t)K * L * L, 0.0), gmP((size_t)K * L), gconst(K);
+        p->gm.assign(d->gmm_means, d->gmm_means + (size_t)K * Lg);
+        p->gc.assign(d->gmm_covars, d->gmm_covars + (size_t)K * Lg * Lg);
+        p->gp.assign((size_t)K * Lg * Lg, 0.0);
+        std::vector<double> chol((size_t)K * Lg * Lg), inv((size_t)Lg * Lg);
+        std::vector<double> gP((size_t)K * Lg * Lg, 0.0), gmP((size_t)K * Lg), gconst(K);
         const double log2pi = std::log(2.0 * M_PI);
         for (int k = 0; k < K; k++) {
-            double *c = &chol[(size_t)k * L * L];
+            double *c = &chol[(size_t)k * Lg * Lg];
             if (!(p->gw[k] >= 0.0) || !std::isfinite(p->gw[k])) {
                 mg_set_error("mg_primitive_create: gmm_weights[%d] is negative or not finite", k);
                 mg_primitive_free(p);
                 return MG_ERR_INVALID_ARGUMENT;
             }
-            if (!mg_cholesky_lower(&p->gc[(size_t)k * L * L], L, c)) {
+            if (!mg_cholesky_lower(&p->gc[(size_t)k * Lg * Lg], Lg, c)) {
                 mg_set_error("mg_primitive_create: gmm_covars[%d] is not positive definite", k);
                 mg_primitive_free(p);
                 return MG_ERR_NOT_POSITIVE_DEFINITE;
             }
             // sklearn _compute_precision_cholesky: P = solve_triangular(chol, I, lower=True).T
             std::fill(inv.begin(), inv.end(), 0.0);
-            for (int col = 0; col < L; col++)
-                for (int r = col; r < L; r++) {
+            for (int col = 0; col < Lg; col++)
+                for (int r = col; r < Lg; r++) {
                     double s = (r == col) ? 1.0 : 0.0;
-                    for (int q = col; q < r; q++) s -= c[r * L + q] * inv[(size_t)q * L + col];
-                    inv[(size_t)r * L + col] = s / c[r * L + r];
+                    for (int q = col; q < r; q++) s -= c[r * Lg + q] * inv[(size_t)q * Lg + col];
+                    inv[(size_t)r * Lg + col] = s / c[r * Lg + r];
                 }
-            double *P = &p->gp[(size_t)k * L * L];
+            double *P = &p->gp[(size_t)k * Lg * Lg];
             double logdet = 0.0;
-            for (int i = 0; i < L; i++) {
-                for (int j = 0; j < L; j++) P[i * L + j] = inv[(size_t)j * L + i];
-                logdet += std::log(P[i * L + i]);
+            for (int i = 0; i < Lg; i++) {
+                for (int j = 0; j < Lg; j++) P[i * Lg + j] = inv[(size_t)j * Lg + i];
+                logdet += std::log(P[i * Lg + i]);
             }
-            for (int j = 0; j < L; j++) {
+            for (int j = 0; j < Lg; j++) {
                 double acc = 0.0;
                 for (int i = 0; i <= j; i++) {
-                    gP[((size_t)k * L + j) * L + i] = P[i * L + j];
-                    acc += p->gm[(size_t)k * L + i] * P[i * L + j];
+                    gP[((size_t)k * Lg + j) * Lg + i] = P[i * Lg + j];
+                    acc += p->gm[(size_t)k * Lg + i] * P[i * Lg + j];
                 }
-                gmP[(size_t)k * L + j] = acc;
+                gmP[(size_t)k * Lg + j] = acc;
             }
-            gconst[k] = std::log(p->gw[k]) + logdet - 0.5 * (double)L * log2pi;
+            gconst[k] = std::log(p->gw[k]) + logdet - 0.5 * (double)Lg * log2pi;
         }
-        if (p->KK > 0) {
+        if (p->KKg > 0) {
             // B fragments of v_mfma_f64_16x16x4_f64: lane l supplies B[k = 4*kk + (l >> 4)][col = l & 15]
-            const int KK = p->KK, JT = (L + 15) / 16;
+            const int KK = p->KKg, JT = (Lg + 15) / 16, L = Lg;   // inside this block L is the mixture's dimension
             std::vector<double> ppack((size_t)K * JT * KK * 64, 0.0), mpad((size_t)K * JT * 16, 0.0);
             for (int k = 0; k < K; k++) {
                 for (int j = 0; j < L; j++) mpad[(size_t)k * JT * 16 + j] = gmP[(size_t)k * L + j];
@@ -908,7 +917,7 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                         for (int lane = 0; lane < 64; lane++) {
                             int i = 4 * kk + (lane >> 4), j = 16 * jt + (lane & 15);
                             if (i < L && j < L && i <= j)
-                                ppack[((((size_t)k * JT + jt) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * L * L + (size_t)i * L + j];
+                                ppack[((((size_t)k * JT + jt) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * Lg * Lg + (size_t)i * L + j];
                         }
             }
             // the transposed factor for z = y P_k^T (log_likelihood_jac): lane l supplies B[k = 4*kk + (l >> 4) (= j)][col = i]
@@ -919,7 +928,7 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                         for (int lane = 0; lane < 64; lane++) {
                             int j = 4 * kk + (lane >> 4), i = 16 * it + (lane & 15);
                             if (i < L && j < L && i <= j)
-                                ptpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * L * L + (size_t)i * L + j];
+                                ptpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = p->gp[(size_t)k * Lg * Lg + (size_t)i * L + j];
                         }
             // sampler: x = mu + z L^T, lane l supplies B[k = 4*kk + (l >> 4) (= j)][col = i] = L_k[i][j] (lower triangular)
             std::vector<double> cpack((size_t)K * JT * KK * 64, 0.0), meanpad((size_t)K * JT * 16, 0.0);
@@ -930,7 +939,7 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                         for (int lane = 0; lane < 64; lane++) {
                             int j = 4 * kk + (lane >> 4), i = 16 * it + (lane & 15);
                             if (i < L && j < L && j <= i)
-                                cpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = chol[(size_t)k * L * L + (size_t)i * L + j];
+                                cpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = chol[(size_t)k * Lg * Lg + (size_t)i * L + j];
                         }
             }
             if (rc == MG_OK) rc = mg_upload(ctx, cpack, &p->d_gcholpack);
@@ -947,6 +956,34 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
         if (rc != MG_OK) { mg_primitive_free(p); return rc; }
     }
 
+    if (Lt > 0) {
+        // mean time spline and harmonics at the canonical frames 0 .. F-1 (reference motion_primitive.py:258-268,293-296:
+        // si.splev(canonical_time_range, (knots_t, coefficients, 3)); column l of eigen_vectors_time = coefficients of harmonic l)
+        const int F = p->F;
+        for (int i = 0; i + 1 < NBt + 4; i++)
+            if (!(d->knots_time[i] <= d->knots_time[i + 1]) || !std::isfinite(d->knots_time[i + 1])) {
+                mg_set_error("mg_primitive_create: knots_time must be finite and non-decreasing");
+                mg_primitive_free(p);
+                return MG_ERR_INVALID_ARGUMENT;
+            }
+        std::vector<double> tphi((size_t)F * Lt), tmean(F);
+        for (int f = 0; f < F; f++) {
+            int32_t i0;
+            double w[4];
+            mg_basis_row(d->knots_time, NBt + 4, (double)f, &i0, w);
+            double m = w[0] * d->mean_time_vector[i0];
+            for (int j = 1; j < 4; j++) m = std::fma(w[j], d->mean_time_vector[i0 + j], m);
+            tmean[f] = m;
+            for (int l = 0; l < Lt; l++) {
+                double v = w[0] * d->eigen_vectors_time[(size_t)i0 * Lt + l];
+                for (int j = 1; j < 4; j++) v = std::fma(w[j], d->eigen_vectors_time[(size_t)(i0 + j) * Lt + l], v);
+                tphi[(size_t)f * Lt + l] = v;
+            }
+        }
+        rc = mg_upload(ctx, tphi, &p->d_tphi);
+        if (rc == MG_OK) rc = mg_upload(ctx, tmean, &p->d_tmean);
+        if (rc != MG_OK) { mg_primitive_free(p); return rc; }
+    }
     {   // canonical grid: np.linspace(0, F, int(F * 1.0))  (reference motion_primitive.py:233)
         const int F = p->F;
         std::vector<double> t(F);
@@ -990,6 +1027,12 @@ extern "C" int mg_primitive_info(const mg_primitive *p, int32_t *o) {
     return MG_OK;
 }
 
+extern "C" int mg_primitive_info2(const mg_primitive *p, int32_t *o) {
+    MG_REQUIRE(p && o, "mg_primitive_info2: NULL argument");
+    o[0] = p->Lg; o[1] = p->Lt; o[2] = p->NBt; o[3] = p->KKg;
+    return MG_OK;
+}
+
 extern "C" int mg_primitive_get_precisions_cholesky(const mg_primitive *p, double *out) {
     MG_REQUIRE(p && out, "mg_primitive_get_precisions_cholesky: NULL argument");
     MG_REQUIRE(p->K > 0, "mg_primitive_get_precisions_cholesky: primitive has no mixture");
@@ -1008,6 +1051,14 @@ static int mg_use_device(const mg_context *ctx) {
     return MG_OK;
 }
 
+static int mg_check_latents(const char *fn, const mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld);
+// the mixture's entry points read all n_gmm_dims columns (spatial + time latents)
+static int mg_check_mixture_rows(const char *fn, const mg_primitive *p, const void *x, int dt, int64_t B, int64_t ld) {
+    int rc = mg_check_latents(fn, p, x, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(ld >= p->Lg, "%s: leading dimension %lld < n_gmm_dims %d", fn, (long long)ld, p->Lg);
+    return MG_OK;
+}
 static int mg_check_latents(const char *fn, const mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld) {
     MG_REQUIRE(p != nullptr, "%s: primitive is NULL", fn);
     { int rc = mg_use_device(p->ctx); if (rc != MG_OK) return rc; }
@@ -1088,7 +1139,7 @@ extern "C" int mg_spline_evaluate(mg_primitive *p, const mg_time_grid *g, const 
 }
 
 extern "C" int mg_gmm_log_prob(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
-    int rc = mg_check_latents("mg_gmm_log_prob", p, x, xdt, B, ld);
+    int rc = mg_check_mixture_rows("mg_gmm_log_prob", p, x, xdt, B, ld);
     if (rc != MG_OK) return rc;
     MG_REQUIRE(p->K > 0, "mg_gmm_log_prob: primitive has no mixture");
     MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_gmm_log_prob: bad output dtype %d", odt);
@@ -1100,13 +1151,24 @@ extern "C" int mg_gmm_log_prob(mg_primitive *p, const void *x, int xdt, int64_t 
     return rc;
 }
 
+extern "C" int mg_time_function_canonical(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double *out) {
+    MG_REQUIRE(p != nullptr, "mg_time_function_canonical: primitive is NULL");
+    MG_REQUIRE(p->Lt > 0, "mg_time_function_canonical: the primitive has no time model");
+    MG_REQUIRE(B >= 0 && (gdt == MG_F32 || gdt == MG_F64) && ld >= p->Lt, "mg_time_function_canonical: bad arguments (ld %lld, n_time_components %d)",
+               (long long)ld, p->Lt);
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(gamma && out, "mg_time_function_canonical: NULL pointer");
+    { int rc0 = mg_use_device(p->ctx); if (rc0 != MG_OK) return rc0; }
+    return mg_launch_time_function(p, gamma, gdt, B, ld, out);
+}
+
 extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, void *x, int xdt,
                              int64_t ld, int32_t *comp) {
     MG_REQUIRE(p != nullptr && n >= 0, "mg_gmm_sample: bad arguments");
     MG_REQUIRE(p->K > 0, "mg_gmm_sample: primitive has no mixture");
     MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_gmm_sample: bad dtype %d", xdt);
     MG_REQUIRE(counts != nullptr, "mg_gmm_sample: counts is NULL");
-    MG_REQUIRE(ld >= p->L, "mg_gmm_sample: leading dimension %lld < n_components %d", (long long)ld, p->L);
+    MG_REQUIRE(ld >= p->Lg, "mg_gmm_sample: leading dimension %lld < n_gmm_dims %d", (long long)ld, p->Lg);
     { int rc0 = mg_use_device(p->ctx); if (rc0 != MG_OK) return rc0; }
     // [0 .. K]: row prefix sums; [K+1 .. 2K+1]: prefix sums of 16-row tiles (a tile never straddles two components)
     std::vector<int64_t> cum(2 * (size_t)p->K + 2, 0);
@@ -1490,7 +1552,7 @@ extern "C" int mg_score_constraint_residuals(mg_primitive *p, const mg_constrain
 }
 
 extern "C" int mg_gmm_log_prob_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *jac) {
-    int rc = mg_check_latents("mg_gmm_log_prob_jac", p, x, xdt, B, ld);
+    int rc = mg_check_mixture_rows("mg_gmm_log_prob_jac", p, x, xdt, B, ld);
     if (rc != MG_OK) return rc;
     MG_REQUIRE(p->K > 0, "mg_gmm_log_prob_jac: primitive has no mixture");
     if (B == 0) return MG_OK;
@@ -1612,8 +1674,17 @@ extern "C" int mg_spline_evaluate_host(mg_primitive *p, const mg_time_grid *g, c
     if ((rc = mg_spline_evaluate(p, g, (const double *)io.d_in, n, (double *)io.d_out)) != MG_OK) return rc;
     return io.finish(frames, ob);
 }
+extern "C" int mg_time_function_canonical_host(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double *out) {
+    MG_REQUIRE(p != nullptr && B >= 0 && (gdt == MG_F32 || gdt == MG_F64), "mg_time_function_canonical_host: bad arguments");
+    int64_t ob = B * (int64_t)p->F * 8;
+    mg_host_io io;
+    int rc;
+    if ((rc = io.stage(p->ctx, gamma, B * ld * (int64_t)mg_dt_size(gdt), ob)) != MG_OK) return rc;
+    if ((rc = mg_time_function_canonical(p, io.d_in, gdt, B, ld, (double *)io.d_out)) != MG_OK) return rc;
+    return io.finish(out, ob);
+}
 extern "C" int mg_gmm_log_prob_host(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *logp, int odt) {
-    int rc = mg_check_latents("mg_gmm_log_prob_host", p, x, xdt, B, ld);
+    int rc = mg_check_mixture_rows("mg_gmm_log_prob_host", p, x, xdt, B, ld);
     if (rc != MG_OK) return rc;
     MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_gmm_log_prob_host: bad output dtype %d", odt);
     int64_t ob = B * (int64_t)mg_dt_size(odt);
@@ -1624,7 +1695,7 @@ extern "C" int mg_gmm_log_prob_host(mg_primitive *p, const void *x, int xdt, int
 }
 extern "C" int mg_gmm_sample_host(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, void *x, int xdt,
                                   int64_t ld, int32_t *comp) {
-    MG_REQUIRE(p != nullptr && n >= 0 && ld >= (p ? p->L : 0), "mg_gmm_sample_host: bad arguments");
+    MG_REQUIRE(p != nullptr && n >= 0 && ld >= (p ? p->Lg : 0), "mg_gmm_sample_host: bad arguments");
     MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_gmm_sample_host: bad dtype %d", xdt);
     int64_t xb = n * ld * (int64_t)mg_dt_size(xdt), cb = n * 4;
     void *dx = nullptr, *dc = nullptr;
@@ -1651,9 +1722,9 @@ extern "C" int mg_score_constraint_residuals_host(mg_primitive *p, const mg_cons
     return io.finish(res, ob);
 }
 extern "C" int mg_gmm_log_prob_jac_host(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *jac) {
-    int rc = mg_check_latents("mg_gmm_log_prob_jac_host", p, x, xdt, B, ld);
+    int rc = mg_check_mixture_rows("mg_gmm_log_prob_jac_host", p, x, xdt, B, ld);
     if (rc != MG_OK) return rc;
-    int64_t ob = B * (int64_t)p->L * 8;
+    int64_t ob = B * (int64_t)p->Lg * 8;
     mg_host_io io;
     if ((rc = io.stage(p->ctx, x, B * ld * (int64_t)mg_dt_size(xdt), ob)) != MG_OK) return rc;
     if ((rc = mg_gmm_log_prob_jac(p, io.d_in, xdt, B, ld, (double *)io.d_out)) != MG_OK) return rc;
@@ -1714,7 +1785,7 @@ extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int6
     int rc = mg_gmm_sample(p, n, counts, seed, x_dev, xdt, ld, nullptr);
     if (rc == MG_OK) rc = mg_score_constraints(p, cs, x_dev, xdt, n, ld, errors_dev, MG_F64);
     if (rc == MG_OK) rc = mg_argmin_first_dev(p->ctx, errors_dev, MG_F64, n, result_dev);
-    if (rc == MG_OK) rc = mg_launch_gather_winner(p->ctx, x_dev, xdt, ld, p->L, result_dev);
+    if (rc == MG_OK) rc = mg_launch_gather_winner(p->ctx, x_dev, xdt, ld, p->Lg, result_dev);   // the winner keeps its full width
     return rc;
 }
 

@@ -119,6 +119,11 @@ struct mg_primitive {
     int32_t NB = 0, D = 0, L = 0, F = 0, K = 0, R = 0;
     int32_t nroot = 0;  // min(3, D): channels computed in float64
     int32_t KK = 0;     // MFMA k-steps (even), 0 when L > 64
+    int32_t Lg = 0;     // dimension of the mixture (>= L: spatial + time latents)
+    int32_t KKg = 0;    // MFMA k-steps of the mixture kernels (even), 0 when Lg > 64
+    int32_t Lt = 0, NBt = 0;         // time model: components, basis functions
+    double *d_tphi = nullptr;        // [F][Lt]: harmonics at the canonical frames
+    double *d_tmean = nullptr;       // [F]: mean time spline at the canonical frames
     int32_t RT = 0;     // 16-row tiles of the padded-row space NB*Dp
     // host float64 copies (already scaled by translation_maxima)
     std::vector<double> Es;    // (R, L)
@@ -191,6 +196,7 @@ int mg_launch_set_params(mg_context *ctx, const double *values, int n_par, int n
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res);
 int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld, int L, void *result_dev);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);
+int mg_launch_time_function(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double *out);
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
 int mg_setup_kernel_attributes(mg_context *ctx);
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us);   // mg_placement.hip

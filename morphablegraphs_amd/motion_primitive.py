@@ -1,7 +1,6 @@
 """MotionPrimitive duck type backed by libmg_hip.so.
 
-Mirror of reference morphablegraphs/motion_model/motion_primitive.py:41-380 for the
-``use_time_parameters=False`` path every scoring call site uses: same attribute names
+Mirror of reference morphablegraphs/motion_model/motion_primitive.py:41-380: same attribute names
 (``s_pca``, ``t_pca``, ``gaussian_mixture_model``, ``translation_maxima``,
 ``n_canonical_frames`` ...), same methods and error behaviour, so
 ``MotionPrimitiveModelWrapper.motion_primitive`` can be swapped without touching
@@ -90,8 +89,7 @@ class HipMotionPrimitive(object):
         self.s_pca["knots"] = np.asarray(data["b_spline_knots_spatial"])
 
     def _init_time_parameters_from_json(self, data):
-        # kept for attribute compatibility; the time-warp branch itself has no runnable oracle
-        # (the reference raises TypeError at motion_primitive.py:313-314 on numpy >= 1.18)
+        # reference motion_primitive.py:164-181
         self.t_pca = dict()
         self.t_pca["eigen_vectors"] = np.array(data["eigen_vectors_time"])
         self.t_pca["mean_vector"] = np.array(data["mean_time_vector"])
@@ -127,9 +125,9 @@ class HipMotionPrimitive(object):
         s, semantic_annotation = self._strip_semantic_label(s)
         spatial_coeffs = self.back_project_spatial_coeffs(s[:self.s_pca["n_components"]])
         if self.has_time_parameters and use_time_parameters:
-            raise NotImplementedError("time-warp back projection is outside the accelerated path: every scoring call "
-                                      "site passes use_time_parameters=False (SURVEY.md section 8c)")
-        time_function = np.linspace(0, self.n_canonical_frames, int(self.n_canonical_frames * (1.0 / speed)))
+            time_function = self.back_project_time_function(s[self.s_pca["n_components"]:], speed)
+        else:
+            time_function = np.linspace(0, self.n_canonical_frames, int(self.n_canonical_frames * (1.0 / speed)))
         return HipMotionSpline(spatial_coeffs, time_function, self.s_pca["knots"], semantic_annotation,
                                low_dimensional_parameters=s, primitive=self._prim)
 
@@ -137,15 +135,56 @@ class HipMotionPrimitive(object):
         alpha = np.asarray(alpha, dtype=np.float64).reshape(1, -1)
         return self._prim.back_project_coeffs(alpha, dtype=np.float64)[0]
 
+    # ---- time warp (reference motion_primitive.py:258-331) -----------------------------------------------
+    def _mean_temporal(self):
+        """The mean time spline at the canonical frames (motion_primitive.py:258-266); host, scipy, as the reference."""
+        import scipy.interpolate as si
+        return si.splev(self.canonical_time_range, (self.t_pca["knots"], self.t_pca["mean_vector"], 3))
+
+    def _back_transform_gamma_to_canonical_time_function(self, gamma):
+        """t(t') at the canonical frames: cumulative sum of exp(mean + harmonics . gamma), minus 1
+        (motion_primitive.py:289-302), on the device; see also the *_batch variant."""
+        return self._prim.time_function_canonical(np.asarray(gamma, dtype=np.float64).reshape(1, -1))[0]
+
+    def back_transform_gamma_to_canonical_time_function_batch(self, gammas):
+        """(B, n_time_components) -> (B, n_canonical_frames) float64 in one launch."""
+        return self._prim.time_function_canonical(gammas)
+
+    def _invert_canonical_to_sample_time_function(self, canonical_time_function, speed=1.0):
+        """t'(t) from t(t') by an interpolating cubic spline through (t(t'), t') sampled at the integer sample times
+        (motion_primitive.py:304-319), with scipy's splrep / splev on the host exactly as the reference does.
+        PARITY UNPINNED for the sample count: the reference passes the FLOAT `num` to np.linspace, which raises
+        TypeError on every NumPy >= 1.18; this restatement truncates it with int() -- the value
+        NumPy < 1.18 silently used."""
+        import scipy.interpolate as si
+        x_sample = np.arange(self.n_canonical_frames)
+        sample_time_spline = si.splrep(canonical_time_function, x_sample, w=None, k=3)
+        num = int(np.round(canonical_time_function[-2]) * (1.0 / speed))
+        frames = np.linspace(1, stop=canonical_time_function[-2], num=num)
+        sample_time_function = si.splev(frames, sample_time_spline)
+        sample_time_function = np.insert(sample_time_function, 0, 0)
+        sample_time_function = np.insert(sample_time_function, len(sample_time_function), self.n_canonical_frames - 1)
+        return sample_time_function
+
+    def _smooth_time_function(self, time_function):
+        from scipy.signal import savgol_filter        # motion_primitive.py:321-331
+        return np.array(savgol_filter(time_function, 15, 3))
+
     def back_project_time_function(self, gamma, speed=1.0):
-        raise NotImplementedError("time-warp back projection is outside the accelerated path")
+        """The time-warp t'(t) of a sample (motion_primitive.py:268-287): canonical time function on the device,
+        its inversion on the host."""
+        canonical_time_function = self._back_transform_gamma_to_canonical_time_function(gamma)
+        sample_time_function = self._invert_canonical_to_sample_time_function(canonical_time_function, speed)
+        if self.smooth_time_parameters:
+            return self._smooth_time_function(sample_time_function)
+        return sample_time_function
 
     # ---- batched hot path ------------------------------------------------------------------------
     def back_project_frames_batch(self, samples, times=None):
         """(B, L) latents -> (B, F, D) float32 frames: back_project(s, False).get_motion_vector() for every row
         in one launch (or .evaluate(times) when times is given)."""
         S = np.asarray(samples)
-        S = S[:, :self.s_pca["n_components"] + (0 if not self.has_semantic_parameters else 0)]
+        S = S[:, :self.s_pca["n_components"]]
         if times is None:
             return self._prim.back_project_frames(S)
         g = self._prim.time_grid(times)

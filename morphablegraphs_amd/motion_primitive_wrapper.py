@@ -124,9 +124,19 @@ class HipMotionPrimitiveModelWrapper(object):
         return self.motion_primitive.back_project(s_vec, use_time_parameters, speed)
 
     def back_project_time_function(self, s_vec):
+        """reference motion_primitive_wrapper.py:233-249 (legacy branch): the canonical time function of the sample's time
+        latents, or the identity for a primitive without a time model."""
         if self.motion_primitive.has_time_parameters:
-            raise NotImplementedError("time-warp back projection is outside the accelerated path")
+            return self.motion_primitive._back_transform_gamma_to_canonical_time_function(
+                np.asarray(s_vec, dtype=np.float64)[self.get_n_spatial_components():])
         return list(range(0, self.motion_primitive.n_canonical_frames))
+
+    def back_project_time_functions(self, samples):
+        """The same for a batch of samples (n, n_spatial + n_time) in one launch: (n, n_canonical_frames)."""
+        samples = np.asarray(samples, dtype=np.float64)
+        if self.motion_primitive.has_time_parameters:
+            return self.motion_primitive.back_transform_gamma_to_canonical_time_function_batch(samples[:, self.get_n_spatial_components():])
+        return np.tile(np.arange(self.motion_primitive.n_canonical_frames, dtype=np.float64), (len(samples), 1))
 
     # ---- getters ---------------------------------------------------------------------------------
     def get_n_canonical_frames(self):

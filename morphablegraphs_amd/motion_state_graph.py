@@ -89,7 +89,8 @@ class HipMotionStateGraphNode(HipMotionPrimitiveModelWrapper):
 
     def predict_parameters(self, to_node_key, current_parameters):
         gmm = self.outgoing_edges[to_node_key].transition_model.predict(current_parameters)
-        return np.ravel(gmm.sample()[0] if isinstance(gmm.sample(), tuple) else gmm.sample())
+        s = gmm.sample()           # ONE draw, as motion_state_graph_node.py:252-253: every call consumes NumPy's global stream
+        return np.ravel(s[0] if isinstance(s, tuple) else s)
 
     def predict_gmm(self, to_node_key, current_parameters):
         edge = self.outgoing_edges.get(to_node_key)
@@ -270,7 +271,7 @@ class HipPrimitiveSet(object):
         for k, name in enumerate(options):
             node = self.nodes[name]
             prim, ctx = node._prim, node._prim.ctx
-            L = prim.n_components
+            L = prim.n_gmm_dims          # the winner comes back at full width (spatial + time latents)
             key = (name, n, np.dtype(dtype).str)
             bufs = self._buffers.get(key)
             if bufs is None:   # persistent per-option device buffers: no allocation inside a step

@@ -30,10 +30,14 @@ def cubic_b_spline_knots(n_basis, n_canonical_frames):
 
 def make_primitive(seed=0, n_components=40, n_frames=156, n_basis=None, n_dim=79, n_gmm=8,
                    translation_maxima=(1.0, 1.0, 1.0), root_scale=100.0, realistic=True,
-                   dirichlet_weights=False, name=None):
-    """Seeded synthetic primitive ("walk" sized by default: L=40, F=156, NB=31, D=79, K=8)."""
+                   dirichlet_weights=False, name=None, n_time_components=0, n_basis_time=None):
+    """Seeded synthetic primitive ("walk" sized by default: L=40, F=156, NB=31, D=79, K=8).
+    n_time_components > 0 adds the legacy time model (eigen_vectors_time (n_basis_time, n_t), mean_time_vector,
+    b_spline_knots_time: reference motion_primitive.py:164-181) and the mixture then spans all L + n_t latents, as
+    the reference's constructor fits it (construction/motion_model_constructor.py:424)."""
     rng = np.random.default_rng(seed)
     L, F, D, K = int(n_components), int(n_frames), int(n_dim), int(n_gmm)
+    Lt = int(n_time_components)
     NB = int(0.2 * F) if n_basis is None else int(n_basis)
     eigen = 0.05 * rng.standard_normal((L, NB * D))
     mean = rng.standard_normal(NB * D)
@@ -52,13 +56,23 @@ def make_primitive(seed=0, n_components=40, n_frames=156, n_basis=None, n_dim=79
         weights = rng.dirichlet(np.ones(K))
     else:
         weights = np.full(K, 1.0 / K)
-    means = rng.standard_normal((K, L))
-    covars = np.empty((K, L, L))
+    Lg = L + Lt
+    means = rng.standard_normal((K, Lg))
+    covars = np.empty((K, Lg, Lg))
     for k in range(K):
-        a = 0.3 * rng.standard_normal((L, L))
-        covars[k] = a @ a.T + 0.5 * np.eye(L)
+        a = 0.3 * rng.standard_normal((Lg, Lg))
+        covars[k] = a @ a.T + 0.5 * np.eye(Lg)
     n_joints = (D - LEN_ROOT) // LEN_QUAT
-    return {
+    time_model = {}
+    if Lt > 0:
+        trng = np.random.default_rng(seed + 10007)      # its own stream: models without a time part keep their values
+        NBt = int(n_basis_time) if n_basis_time is not None else max(4, int(0.1 * F))
+        # log of the time increments: around 0 (increments of one sample per canonical frame), harmonics of a few percent
+        time_model = {"eigen_vectors_time": (0.04 * trng.standard_normal((NBt, Lt))).tolist(),
+                      "mean_time_vector": (0.05 * trng.standard_normal(NBt)).tolist(),
+                      "n_basis_time": NBt,
+                      "b_spline_knots_time": cubic_b_spline_knots(NBt, F).tolist()}
+    out = {
         "name": name or ("synthetic_%d" % seed),
         "n_canonical_frames": F,
         "translation_maxima": [float(v) for v in translation_maxima],
@@ -72,6 +86,8 @@ def make_primitive(seed=0, n_components=40, n_frames=156, n_basis=None, n_dim=79
         "gmm_covars": covars.tolist(),
         "animated_joints": ["joint_%d" % j for j in range(n_joints)],
     }
+    out.update(time_model)
+    return out
 
 
 def make_walk_primitive(seed=0, **kw):

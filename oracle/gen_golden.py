@@ -81,6 +81,37 @@ def run_case(ref, name, data, n_samples, eval_times, seed, store_model, n_score=
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_time_case(ref, name, data, n_samples, seed):
+    """A model WITH the legacy time part: the mixture spans spatial + time latents (reference
+    motion_model_constructor.py:424), back_project(s, False) reads s[:n_s], and
+    _back_transform_gamma_to_canonical_time_function(s[n_s:]) runs (the inversion that follows it raises TypeError on
+    every NumPy >= 1.18: SURVEY.md section 8c, so back_project(s, True) has no vector)."""
+    mp = ref.MotionPrimitive(None)
+    mp._initialize_from_json(data)
+    assert mp.has_time_parameters
+    np.random.seed(seed)
+    S = mp.sample_low_dimensional_vector(n_samples)
+    n_s = mp.get_n_spatial_components()
+    splines = [mp.back_project(s, use_time_parameters=False) for s in S]
+    frames = np.stack([sp.get_motion_vector() for sp in splines])
+    ctf = np.stack([mp._back_transform_gamma_to_canonical_time_function(s[n_s:]) for s in S])
+    gmm = mp.gaussian_mixture_model
+    out = dict(S=S, frames=frames, canonical_time_functions=ctf, mean_temporal=mp._mean_temporal(), logp_S=gmm.score_samples(S),
+               precisions_cholesky=gmm.precisions_cholesky_, seed=np.int64(seed), digest=np.array(model_digest(data)),
+               n_canonical_frames=np.int64(mp.get_n_canonical_frames()), n_spatial_components=np.int64(n_s),
+               n_time_components=np.int64(mp.get_n_time_components()),
+               low_dimensional_parameters=np.asarray(splines[0].low_dimensional_parameters))
+    for key in ("eigen_vectors_spatial", "mean_spatial_vector", "b_spline_knots_spatial", "gmm_weights", "gmm_means", "gmm_covars",
+                "translation_maxima", "eigen_vectors_time", "mean_time_vector", "b_spline_knots_time"):
+        out["model_" + key] = np.asarray(data[key], dtype=np.float64)
+    out["model_n_basis"] = np.int64(data["n_basis_spatial"])
+    out["model_n_dim"] = np.int64(data["n_dim_spatial"])
+    out["model_n_basis_time"] = np.int64(data["n_basis_time"])
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref = import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -104,6 +135,10 @@ def main():
     odd = synthetic.make_primitive(seed=9, n_components=13, n_frames=47, n_dim=15, n_gmm=3, name="odd",
                                    translation_maxima=(2.0, 1.0, 3.0))
     run_case(ref, "odd_shape", odd, 6, [0.0, 23.0, 46.0, 47.0], 31, True, n_score=32)
+    # (vi) a model with the legacy time part: mixture over 12 spatial + 3 time latents
+    timed = synthetic.make_primitive(seed=13, n_components=12, n_frames=60, n_dim=15, n_gmm=3, name="timed",
+                                     n_time_components=3, n_basis_time=8)
+    run_time_case(ref, "time_model", timed, 9, 41)
 
 
 if __name__ == "__main__":

@@ -429,6 +429,32 @@ class OraclePrimitive(object):
         self.means = np.array(data["gmm_means"], dtype=np.float64)
         self.covars = np.array(data["gmm_covars"], dtype=np.float64)
         self.prec_chol = precision_cholesky(self.covars)
+        self.n_time_components = 0
+        if "eigen_vectors_time" in data:
+            self.init_time_model(data)
+
+    # motion_primitive.py:164-181, 258-266, 289-302 (the legacy time model; present when the model has 'eigen_vectors_time')
+    def init_time_model(self, data):
+        self.t_eigen_vectors = np.array(data["eigen_vectors_time"], dtype=np.float64)      # (n_basis_time, n_t): column l = harmonic l
+        self.t_mean_vector = np.array(data["mean_time_vector"], dtype=np.float64)
+        self.t_knots = np.asarray(data["b_spline_knots_time"], dtype=np.float64)
+        self.n_time_components = self.t_eigen_vectors.shape[1]
+
+    def mean_temporal(self):
+        """_mean_temporal: the mean time spline at the canonical frames 0 .. F-1."""
+        return splev(np.arange(self.n_canonical_frames, dtype=np.float64), self.t_knots, self.t_mean_vector)
+
+    def back_transform_gamma_to_canonical_time_function(self, gamma):
+        """_back_transform_gamma_to_canonical_time_function: t(t') = cumulative sum of exp(mean + harmonics . gamma), - 1."""
+        frames = np.arange(self.n_canonical_frames, dtype=np.float64)
+        mean_t = self.mean_temporal()
+        t_eigen_discrete = np.array([splev(frames, self.t_knots, self.t_eigen_vectors[:, l]) for l in range(self.n_time_components)]).T
+        gamma = np.asarray(gamma, dtype=np.float64)
+        out, acc = [], 0.0
+        for i in range(self.n_canonical_frames):
+            acc = acc + np.exp(mean_t[i] + np.dot(t_eigen_discrete[i], gamma))
+            out.append(acc)
+        return np.array(out) - 1.0
 
     # motion_primitive.py:236-256
     def back_project_spatial_coeffs(self, alpha):

@@ -34,6 +34,8 @@ def golden_model(name):
         data = {k[len("model_"):]: g[k] for k in g.files if k.startswith("model_")}
         data["n_basis_spatial"] = int(data.pop("n_basis"))
         data["n_dim_spatial"] = int(data.pop("n_dim"))
+        if "n_basis_time" in data:
+            data["n_basis_time"] = int(data["n_basis_time"])
         data["n_canonical_frames"] = int(g["n_canonical_frames"])
         data["name"] = name
     elif name == "walk_seed0":

@@ -754,3 +754,57 @@ def test_the_ctypes_stub_in_integration_md_runs_as_printed():
     prim._initialize_from_json(data)
     np.testing.assert_array_equal(backend.frames(S).view(np.uint32), prim.back_project_frames_batch(S).view(np.uint32))
     np.testing.assert_array_equal(backend.score_samples(S), prim.score_samples_batch(S.astype(np.float64)))
+
+
+def test_model_with_time_latents_end_to_end():
+    """A model whose mixture spans spatial AND time latents, as the reference's constructor writes it
+    (motion_model_constructor.py:424): loads, samples at full width on sklearn's stream, scores all columns,
+    back-projects from the spatial ones, and evaluates the time warp -- against vectors made by the reference."""
+    from conftest import golden_model
+    from morphablegraphs_amd.motion_primitive_wrapper import HipMotionPrimitiveModelWrapper
+    data, g = golden_model("time_model")
+    mp = HipMotionPrimitive(None)
+    mp._initialize_from_json(data)
+    n_s, n_t = int(g["n_spatial_components"]), int(g["n_time_components"])
+    assert mp.has_time_parameters and (mp.get_n_spatial_components(), mp.get_n_time_components()) == (n_s, n_t)
+    assert mp.gaussian_mixture_model.n_dims == n_s + n_t and mp._prim.n_gmm_dims == n_s + n_t
+    np.random.seed(int(g["seed"]))
+    S = mp.sample_low_dimensional_vector(len(g["S"]))
+    np.testing.assert_allclose(S, g["S"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mp.gaussian_mixture_model.score_samples(g["S"]), g["logp_S"], rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(mp.gaussian_mixture_model.precisions_cholesky_, g["precisions_cholesky"], rtol=1e-9, atol=1e-9)
+    scale = max(1.0, np.abs(g["frames"]).max())
+    for s, fr, ctf in zip(g["S"], g["frames"], g["canonical_time_functions"]):
+        spline = mp.back_project(s, use_time_parameters=False)
+        np.testing.assert_allclose(spline.get_motion_vector(), fr, rtol=0, atol=4e-12 * scale)
+        np.testing.assert_array_equal(spline.low_dimensional_parameters, s)
+        np.testing.assert_allclose(mp._back_transform_gamma_to_canonical_time_function(s[n_s:]), ctf, rtol=1e-12, atol=1e-11)
+    np.testing.assert_allclose(mp.back_transform_gamma_to_canonical_time_function_batch(g["S"][:, n_s:]), g["canonical_time_functions"],
+                               rtol=1e-12, atol=1e-11)
+    np.testing.assert_allclose(mp._mean_temporal(), g["mean_temporal"], rtol=0, atol=1e-13)
+    # float32 batch path reads the spatial columns of full-width rows
+    fb = mp.back_project_frames_batch(g["S"])
+    assert np.all(np.abs(fb - g["frames"]) <= 1e-5 + 2.0 ** -24 * np.abs(g["frames"]))
+    # the time warp itself (use_time_parameters=True): the reference raises TypeError there on every NumPy >= 1.18;
+    # the restatement with int(num) gives a monotone map from sample time to canonical time with the reference's end points
+    warped = mp.back_project(g["S"][0], use_time_parameters=True)
+    tf = np.asarray(warped.time_function)
+    assert tf[0] == 0 and tf[-1] == mp.n_canonical_frames - 1 and np.all(np.diff(tf[1:-1]) > 0)
+    assert warped.get_motion_vector().shape == (len(tf), mp.s_pca["n_dim"])
+    # the wrapper's time function of a sample = the canonical time function of its time latents (wrapper :233-249)
+    w = HipMotionPrimitiveModelWrapper()
+    w._initialize_from_json(None, data)
+    np.testing.assert_allclose(w.back_project_time_function(g["S"][2]), g["canonical_time_functions"][2], rtol=1e-12, atol=1e-11)
+    np.testing.assert_allclose(w.back_project_time_functions(g["S"]), g["canonical_time_functions"], rtol=1e-12, atol=1e-11)
+    # device sampler and the winner of a device-side option step come back at full width
+    X, comp = mp.gaussian_mixture_model.sample(4096, device=True, seed=5)
+    assert X.shape == (4096, n_s + n_t) and np.isfinite(X).all()
+    w0 = np.asarray(data["gmm_weights"])
+    mu = (w0[:, None] * np.asarray(data["gmm_means"])).sum(axis=0)
+    assert np.abs(X.mean(axis=0) - mu).max() < 0.15
+    from morphablegraphs_amd.candidate_scoring import sample_and_evaluate_on_device
+    cons = [{"type": "position", "t": float(mp.n_canonical_frames - 1), "weight": 1.0, "target": [10.0, None, 5.0]}]
+    best, err = sample_and_evaluate_on_device(mp, cons, 512, 3)
+    assert best.shape == (n_s + n_t,) and np.isfinite(err)
+    res = mp._prim.score_constraints(_capi.ConstraintSet(mp._prim, cons), best.reshape(1, -1))
+    assert abs(res[0] - err) < 1e-4 * max(1.0, abs(err))

@@ -254,3 +254,22 @@ def test_point_cloud_fit_is_optimal_and_recovers_a_known_transform():
     frame2[:3] += [0.5, 0.0, 2.0]
     c["velocity"] = [0.5, 0.0, 0.0]
     assert abs(orc.pose_constraint_error(c, frame, frame2, joints, animated) - 2.0) < 1e-10
+
+
+def test_time_model_fixture():
+    """The model with the legacy time part (reference motion_primitive.py:164-181): the mixture spans spatial + time
+    latents, back_project(s, False) reads s[:n_s], and the canonical time function of s[n_s:]
+    (_back_transform_gamma_to_canonical_time_function, :289-302) -- against vectors made by the reference itself."""
+    from conftest import golden_model
+    data, g = golden_model("time_model")
+    prim = orc.OraclePrimitive(data)
+    n_s, n_t = int(g["n_spatial_components"]), int(g["n_time_components"])
+    assert (prim.n_components, prim.n_time_components) == (n_s, n_t) and g["S"].shape[1] == n_s + n_t
+    np.testing.assert_allclose(prim.mean_temporal(), g["mean_temporal"], rtol=0, atol=1e-13)
+    for s, ctf, fr in zip(g["S"], g["canonical_time_functions"], g["frames"]):
+        np.testing.assert_allclose(prim.back_transform_gamma_to_canonical_time_function(s[n_s:]), ctf, rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(prim.back_project_frames(s), fr, rtol=0, atol=2e-12 * max(1.0, np.abs(fr).max()))
+    np.testing.assert_allclose(prim.score_samples(g["S"]), g["logp_S"], rtol=1e-9, atol=1e-7)
+    np.random.seed(int(g["seed"]))
+    np.testing.assert_allclose(prim.sample_low_dimensional_vector(len(g["S"])), g["S"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(g["low_dimensional_parameters"], g["S"][0])      # the spline keeps the full vector
