@@ -59,12 +59,16 @@ def read_graph_zip(path):
             parts = name.split("/")
             if not name.endswith(MORPHABLE_MODEL_FILE_ENDING):
                 continue
-            if len(parts) >= 3 and parts[0] == ELEMENTARY_ACTION_DIRECTORY:      # format >= 2
+            # the layout follows formatVersion, as ZipReader's path getters do (zip_io.py:215-233): >= 2.0 keeps the
+            # actions under elementary_action_models/, 1.x at the top level
+            if version >= 2.0:
+                if len(parts) != 3 or parts[0] != ELEMENTARY_ACTION_DIRECTORY:
+                    continue
                 structure_key, file_name, prefix = parts[1], parts[2], parts[0] + "/" + parts[1] + "/"
-            elif len(parts) == 2:                                                 # format 1
-                structure_key, file_name, prefix = parts[0], parts[1], parts[0] + "/"
             else:
-                continue
+                if len(parts) != 2:
+                    continue
+                structure_key, file_name, prefix = parts[0], parts[1], parts[0] + "/"
             action = _action_key(structure_key)
             group = subgraphs.setdefault(action, {"name": action, "nodes": {}})
             meta = prefix + "meta_information.json"
@@ -73,9 +77,12 @@ def read_graph_zip(path):
             motion_primitive_name = file_name[:-(len(MORPHABLE_MODEL_FILE_ENDING) + 1)]
             key, stem = _primitive_key(motion_primitive_name)
             node = {"name": stem, "mm": json.loads(z.read(name).decode("utf-8"))}
-            stats = prefix + stem + ".stats"
-            if stats in names:
-                node["stats"] = json.loads(z.read(stats).decode("utf-8"))
+            # the reference looks the statistics up at '<structure_key>/<stem>.stats' WITHOUT the elementary_action_models
+            # prefix, whatever the version (zip_io.py:196); the file next to the model is taken as a fallback
+            for stats in (structure_key + "/" + stem + ".stats", prefix + stem + ".stats"):
+                if stats in names:
+                    node["stats"] = json.loads(z.read(stats).decode("utf-8"))
+                    break
             tree = prefix + motion_primitive_name + "_cluster_tree.json"
             if version >= 4.0 and tree in names:
                 node["space_partition_json"] = json.loads(z.read(tree).decode("utf-8"))

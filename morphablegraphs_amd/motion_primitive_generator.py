@@ -23,10 +23,21 @@ SAMPLING_MODE_RANDOM_SPLINE = "random_spline"
 SPATIAL_CONSTRAINT_TYPE_KEYFRAME_POSE = "keyframe_pose"   # constraints/spatial_constraints/__init__.py
 
 
+class _EvaluationBudgetSpent(Exception):
+    pass
+
+
 class HipLeastSquares(object):
     """LeastSquares.run (reference optimization/least_squares.py:35-64): scipy's MINPACK Levenberg-Marquardt on
-    the residual-vector objective.  MINPACK's own forward-difference Jacobian (lmdif: step sqrt(eps) * |x_j|, or
-    sqrt(eps) where x_j == 0) is reproduced as `Dfun`, with its L + 1 objective evaluations batched into ONE launch."""
+    the residual-vector objective.  MINPACK's own forward-difference Jacobian (lmdif / fdjac2: step sqrt(eps) * |x_j|,
+    or sqrt(eps) where x_j == 0) is reproduced as `Dfun`, with its L objective evaluations batched into ONE launch.
+
+    `max_iterations` keeps the reference's meaning.  The reference calls leastsq WITHOUT Dfun (least_squares.py:50-53),
+    so MINPACK's lmdif charges the L evaluations of every finite-difference Jacobian against `maxfev`; with Dfun
+    MINPACK (lmder) would count plain function calls only and the same number would buy about L + 1 times as many
+    iterations.  The evaluations are therefore counted here the way lmdif counts them (1 per residual call, L per
+    Jacobian) and the run stops where the reference's stops: when the count reaches max_iterations, with the best
+    accepted point so far (Levenberg-Marquardt accepts a trial point exactly when it lowers the residual norm)."""
 
     def __init__(self, optimization_settings, objective=of.obj_spatial_error_residual_vector_and_naturalness):
         self.optimization_settings = optimization_settings
@@ -34,6 +45,7 @@ class HipLeastSquares(object):
         self._objective_function = objective
         self._error_func_params = None
         self.n_launches = 0
+        self.n_equivalent_evaluations = 0     # what lmdif's nfev would read
 
     def set_objective_function(self, obj):
         self._objective_function = obj
@@ -42,26 +54,51 @@ class HipLeastSquares(object):
         self._error_func_params = data
 
     def _func(self, s, data):
+        key = np.asarray(s, dtype=np.float64).tobytes()
+        if self._last_f is not None and self._last_f[0] == key:     # scipy checks the shapes with one call at x0, then MINPACK
+            return self._last_f[1]                                   # asks for the same point again: one evaluation
+        self.n_equivalent_evaluations += 1
         self.n_launches += 1
-        return self._objective_function(s, data)
+        r = np.asarray(self._objective_function(s, data), dtype=np.float64)
+        self._last_f = (key, r)
+        norm = float(np.dot(r, r))
+        if norm < self._best[0]:                # an accepted Levenberg-Marquardt step
+            self._best = (norm, np.array(s, dtype=np.float64))
+        # lmdif tests nfev >= maxfev only after a TRIAL point has been evaluated and accepted or rejected (never after
+        # the first residual call, never inside the Jacobian), so a run always completes the iteration it is in
+        if self.n_equivalent_evaluations > 1 and self.n_equivalent_evaluations >= self._budget:
+            raise _EvaluationBudgetSpent()
+        return r
 
     def _jac(self, s, data):
         s = np.asarray(s, dtype=np.float64)
+        key = s.tobytes()
+        if self._last_j is not None and self._last_j[0] == key:
+            return self._last_j[1]
         L = s.shape[0]
+        self.n_equivalent_evaluations += L      # fdjac2 evaluates the residuals at L displaced points
         h = np.sqrt(np.finfo(np.float64).eps) * np.abs(s)
         h[h == 0.0] = np.sqrt(np.finfo(np.float64).eps)
         pts = np.repeat(s[None, :], L + 1, axis=0)
         pts[np.arange(1, L + 1), np.arange(L)] += h
         self.n_launches += 1
         r = self._objective_function(pts, data)             # (L + 1, m) in one launch
-        return ((r[1:] - r[:1]) / h[:, None]).T              # (m, L)
+        J = ((r[1:] - r[:1]) / h[:, None]).T                 # (m, L)
+        self._last_j = (key, J)
+        return J
 
     def run(self, initial_guess):
         if self._objective_function is None or initial_guess is None:
             return initial_guess
+        x0 = np.asarray(initial_guess, dtype=np.float64)
+        self._budget = int(self.optimization_settings["max_iterations"])
+        self.n_equivalent_evaluations = 0
+        self._best = (np.inf, x0.copy())
+        self._last_f = self._last_j = None
         try:
-            result = leastsq(self._func, np.asarray(initial_guess, dtype=np.float64), args=(self._error_func_params,),
-                             Dfun=self._jac, maxfev=int(self.optimization_settings["max_iterations"]))
+            result = leastsq(self._func, x0, args=(self._error_func_params,), Dfun=self._jac, maxfev=max(1, self._budget))
+        except _EvaluationBudgetSpent:
+            return self._best[1]
         except ValueError:
             return initial_guess
         return result[0]

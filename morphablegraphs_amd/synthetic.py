@@ -129,9 +129,13 @@ def to_mgrd_v3_json(data):
     }
 
 
-def write_graph_zip(path, actions, transitions=None, start_node=None, format_version=4.0, cluster_trees=None, stats=None):
+def write_graph_zip(path, actions, transitions=None, start_node=None, format_version=4.0, cluster_trees=None, stats=None,
+                    node_stats=None, node_stats_prefixed=False):
     """A graph zip in the reference's layout (utilities/zip_io.py:37-233): ``actions`` = {action: {"primitives":
-    {name: legacy or v3 dict}, "info": meta_information dict}}; ``cluster_trees`` = {(action, name): samples}."""
+    {name: legacy or v3 dict}, "info": meta_information dict}}; ``cluster_trees`` = {(action, name): samples};
+    ``node_stats`` = {(action, name): dict} written as '<stem>.stats' where ZipReader looks for it
+    ('elementary_action_<action>/<stem>.stats', zip_io.py:196) or, with node_stats_prefixed, next to the model file;
+    format_version < 2 puts the actions at the top level (zip_io.py:215-233)."""
     import json
     import zipfile
     graph_def = {"formatVersion": format_version, "transitions": transitions or {}}
@@ -141,13 +145,16 @@ def write_graph_zip(path, actions, transitions=None, start_node=None, format_ver
         z.writestr("graph_definition.json", json.dumps(graph_def))
         z.writestr("skeleton.json", json.dumps({"name": "synthetic", "animated_joints": []}))
         for action, desc in actions.items():
-            base = "elementary_action_models/elementary_action_%s/" % action
+            base = ("elementary_action_models/" if format_version >= 2.0 else "") + "elementary_action_%s/" % action
             info = dict(desc.get("info", {}))
             if stats is not None and action in stats:
                 info["stats"] = stats[action]
             z.writestr(base + "meta_information.json", json.dumps(info))
             for name, mm in desc["primitives"].items():
                 z.writestr(base + "%s_%s_quaternion_mm.json" % (action, name), json.dumps(mm))
+                if node_stats and (action, name) in node_stats:
+                    where = base if node_stats_prefixed else "elementary_action_%s/" % action
+                    z.writestr(where + "%s_%s.stats" % (action, name), json.dumps(node_stats[(action, name)]))
                 if cluster_trees and (action, name) in cluster_trees:
                     tree = {"data": np.asarray(cluster_trees[(action, name)]).tolist(), "features": [], "options": {}, "root": {}}
                     z.writestr(base + "%s_%s_quaternion_cluster_tree.json" % (action, name), json.dumps(tree))

@@ -263,3 +263,66 @@ def test_c_abi_header_is_plain_c(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
+
+
+def test_local_optimizer_spends_the_references_evaluation_budget():
+    """HipLeastSquares hands MINPACK an analytic-looking Jacobian (the batched finite differences), so scipy runs lmder,
+    whose maxfev counts residual calls only; the reference runs leastsq WITHOUT Dfun (least_squares.py:50-53), where the L
+    evaluations of every finite-difference Jacobian count too.  Same max_iterations must mean the same stopping point:
+    the run is compared with scipy's Dfun-less leastsq on the same objective -- result and evaluation count."""
+    from scipy.optimize import leastsq
+    from morphablegraphs_amd.motion_primitive_generator import HipLeastSquares
+    rng = np.random.default_rng(5)
+    L, m = 7, 11
+    A = rng.standard_normal((m, L))
+    b = rng.standard_normal(m)
+
+    def objective(s, data):                              # works on one vector and on a batch, like the device objectives
+        s = np.asarray(s, dtype=np.float64)
+        r = np.tanh(s @ A.T) + 0.1 * (s ** 2) @ np.abs(A.T) - b
+        return r
+
+    x0 = 0.3 * rng.standard_normal(L)
+    for budget in (5, 9, 20, 33, 100, 2000):
+        calls = [0]
+
+        def counted(s):
+            calls[0] += 1
+            return objective(s, None)
+        ref = leastsq(counted, x0.copy(), maxfev=budget, full_output=True)
+        opt = HipLeastSquares({"max_iterations": budget, "verbose": False}, objective)
+        opt.set_objective_function_parameters(None)
+        got = opt.run(x0.copy())
+        ref_cost, got_cost = np.sum(objective(ref[0], None) ** 2), np.sum(objective(got, None) ** 2)
+        assert opt.n_equivalent_evaluations == ref[2]["nfev"], (budget, opt.n_equivalent_evaluations, ref[2]["nfev"])
+        # the same iterate, up to what the rounding of a batched residual evaluation does to a finite-difference Jacobian
+        np.testing.assert_allclose(got, ref[0], rtol=1e-3, atol=2e-4, err_msg="budget %d" % budget)
+        assert abs(got_cost - ref_cost) <= 1e-3 * max(1.0, ref_cost)
+    # far fewer launches than evaluations: every Jacobian is one launch
+    assert opt.n_launches < opt.n_equivalent_evaluations
+
+
+def test_graph_zip_reader_follows_format_version_and_the_references_stats_path(tmp_path):
+    """read_graph_zip = ZipReader.get_graph_data (reference utilities/zip_io.py:65-233): the layout comes from
+    formatVersion (not from the path depth), and '<stem>.stats' is looked up at 'elementary_action_<a>/<stem>.stats'
+    without the elementary_action_models prefix (zip_io.py:196); the prefixed location is only a fallback."""
+    from morphablegraphs_amd import model_io, synthetic
+    prim = synthetic.make_tiny_primitive(seed=2)
+    actions = {"walk": {"primitives": {"leftStance": prim}, "info": {"start_states": ["leftStance"]}}}
+    st = {"average_step_length": 7.25, "n_standard_transitions": 2}
+    for version, prefixed in ((4.0, False), (4.0, True), (2.0, False), (1.0, False)):
+        path = str(tmp_path / ("g_%s_%d.zip" % (version, prefixed)))
+        synthetic.write_graph_zip(path, actions, format_version=version, node_stats={("walk", "leftStance"): st},
+                                  node_stats_prefixed=prefixed)
+        data = model_io.read_graph_zip(path)
+        node = data["subgraphs"]["walk"]["nodes"]["leftStance"]
+        assert node["name"] == "walk_leftStance" and node["stats"] == st, (version, prefixed)
+        assert data["subgraphs"]["walk"]["info"] == {"start_states": ["leftStance"]}
+    # a version-4 zip read under the wrong assumption must not pick up top-level files as actions
+    import json
+    import zipfile
+    path = str(tmp_path / "mixed.zip")
+    synthetic.write_graph_zip(path, actions, format_version=4.0)
+    with zipfile.ZipFile(path, "a") as z:
+        z.writestr("elementary_action_run/run_fast_quaternion_mm.json", json.dumps(prim))
+    assert sorted(model_io.read_graph_zip(path)["subgraphs"]) == ["walk"]
