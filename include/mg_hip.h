@@ -166,7 +166,13 @@ typedef struct mg_skeleton_desc {
  * heading = xz of the node's global orientation applied to ref_dir.  Rotation and translation differ per candidate.
  * The scorer never transforms control points: with c = h.b and s = h x b (h = previous heading, b = candidate
  * heading, both unit) a position becomes (c x + s z + tx, y, -s x + c z + tz), a heading (c hx + s hz, -s hx + c hz).
- * PARITY UNPINNED: anim_utils is absent; pinned by a 4x4-matrix oracle that does transform the control points. */
+ * PARITY UNPINNED: anim_utils is absent; pinned by a 4x4-matrix oracle that does transform the control points.
+ * joint = MG_ALIGN_START_POSE is the other branch of the reference's align_quaternion_frames (objective_functions.py:38-47,
+ * taken for the first primitive of a walk, when there are no previous frames but a start pose): every candidate gets the
+ * SAME rotation about y, heading = (cos, sin) of the start orientation's y angle; its first root position lands on
+ * (position[0], ., position[2]) -- (0, 0) is what the reference's arithmetic produces, see candidate_scoring.py -- and every
+ * height is raised by position[1].  Start orientations with x or z angles are not covered. */
+#define MG_ALIGN_START_POSE (-1)
 typedef struct mg_alignment_desc {
     int32_t joint;        /* skeleton.aligning_root_node as an index into the skeleton (0 = root, no skeleton needed) */
     int32_t reserved;

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libmg_hip.so")   # the product library; t
 MG_OK = 0
 MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
+MG_ALIGN_START_POSE = -1   # mg_alignment_desc.joint: the start-pose branch of the reference's alignment
 MG_OPT_FORCE_VALU_SCORE, MG_OPT_FORCE_VALU_SAMPLE, MG_OPT_RING_SLOTS, MG_OPT_CHUNK_WINDOW, MG_OPT_CHUNK_SAMPLES = 0, 1, 2, 3, 4
 MG_OPT_FRAMES_KERNEL = 5   # 0 / 1 = tile-major (default), 2 = chunk-stationary
 MG_OPT_COUNT = 6
@@ -536,7 +537,8 @@ class ConstraintSet(object):
     @staticmethod
     def _marshal_alignment(alignment, skeleton):
         al = AlignmentDesc()
-        al.joint = int(alignment.get("joint", 0)) if skeleton is None else skeleton.index(alignment.get("joint", 0))
+        j = alignment.get("joint", 0)
+        al.joint = int(j) if (skeleton is None or j == MG_ALIGN_START_POSE) else skeleton.index(j)
         for a in range(3):
             al.position[a] = float(alignment["position"][a])
             al.ref_dir[a] = float(alignment.get("ref_dir", (0.0, 0.0, 1.0))[a])

@@ -127,8 +127,9 @@ def alignment_from_prev_frames(prev_frames, constraints=None, skeleton=None):
     if getattr(constraints, "is_local", False):
         return None
     if prev_frames is None:
-        if getattr(constraints, "start_pose", None) is not None and hasattr(constraints, "is_local"):
-            raise NotImplementedError("alignment to a start pose (objective_functions.py:38-47) is not on the device")
+        start_pose = getattr(constraints, "start_pose", None)
+        if start_pose is not None and hasattr(constraints, "is_local"):
+            return alignment_from_start_pose(start_pose)
         return None
     last = np.asarray(prev_frames, dtype=np.float64)
     last = last[-1] if last.ndim == 2 else last
@@ -140,6 +141,23 @@ def alignment_from_prev_frames(prev_frames, constraints=None, skeleton=None):
             raise NotImplementedError("aligning node %r is not the root joint: pass a _capi.Skeleton (hip_skeleton)" % (node,))
         return _ROOT_ONLY.alignment_to(last, 0, ref_dir)
     return skeleton.alignment_to(last, 0 if node is None else node, ref_dir)
+
+
+def alignment_from_start_pose(start_pose):
+    """The alignment record of the reference's start-pose branch (optimization/objective_functions.py:38-47): no previous
+    frames, so every candidate is rotated by the start orientation and its first root position is moved in x and z.
+    What the reference's arithmetic amounts to: `delta = start_pose["position"]` is the list inside the start pose, not a
+    copy; m . first_root already contains that position, so delta[0] -= t_pos[0] leaves -(R first_root)[0] (and rewrites
+    the start pose for the next call, where the same cancellation happens again): the first root position lands on
+    x = z = 0 whatever the start position says, and heights are raised by its y.  That is what the device does; the start
+    pose object is not touched.  get_transform_from_start_pose lives in anim_utils (absent, PARITY UNPINNED): Euler
+    angles in degrees, of which only a rotation about y is covered."""
+    orientation = [0.0 if v is None else float(v) for v in start_pose.get("orientation", (0.0, 0.0, 0.0))]
+    if orientation[0] != 0.0 or orientation[2] != 0.0:
+        raise NotImplementedError("start orientations with x or z angles are not aligned on the device")
+    theta = np.radians(orientation[1])
+    height = float(start_pose["position"][1])
+    return {"joint": _capi.MG_ALIGN_START_POSE, "position": (0.0, height, 0.0), "heading": (float(np.cos(theta)), float(np.sin(theta)))}
 
 
 def _freeze(v):

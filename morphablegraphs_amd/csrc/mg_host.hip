@@ -1230,12 +1230,13 @@ extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_
     std::vector<int> al_chain;   // root .. aligning node, every one of their quaternions turns the heading
     if (al) {
         MG_REQUIRE(D >= 7, "mg_constraint_set_create_aligned: alignment needs the root quaternion, n_dim = %d", D);
-        MG_REQUIRE(al->joint == 0 || (sk && al->joint > 0 && al->joint < sk->n_joints),
+        MG_REQUIRE(al->joint == MG_ALIGN_START_POSE || al->joint == 0 || (sk && al->joint > 0 && al->joint < sk->n_joints),
                    "mg_constraint_set_create_aligned: aligning joint %d needs a skeleton that has it", al->joint);
         const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
         MG_REQUIRE(std::isfinite(hn) && hn > 0.0 && std::isfinite(al->position[0]) && std::isfinite(al->position[2]),
                    "mg_constraint_set_create_aligned: previous heading / position not finite or zero");
-        if (al->joint == 0) al_chain.push_back(0);
+        if (al->joint == MG_ALIGN_START_POSE) { /* no chain: the rotation is given, not derived from a heading */ }
+        else if (al->joint == 0) al_chain.push_back(0);
         else for (int j = al->joint; j >= 0; j = sk->parents[j]) al_chain.insert(al_chain.begin(), j);
         MG_REQUIRE((int)al_chain.size() <= MG_MAX_CHAIN, "mg_constraint_set_create_aligned: chain of %d joints exceeds %d", (int)al_chain.size(), MG_MAX_CHAIN);
     }
@@ -1424,6 +1425,7 @@ extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_
         const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
         align = {(double)al_chain.size(), al->heading[0] / hn, al->heading[1] / hn, al->position[0], al->position[2],
                  al->ref_dir[0], al->ref_dir[1], al->ref_dir[2]};
+        if (al->joint == MG_ALIGN_START_POSE) { align[5] = al->position[1]; align[6] = align[7] = 0.0; }   // heights += position[1]
     }
     int rc = mg_upload(p->ctx, W, &cs->d_W);
     if (rc == MG_OK && al) rc = mg_upload(p->ctx, align, &cs->d_align);
@@ -1490,6 +1492,7 @@ extern "C" int mg_constraint_set_update(mg_constraint_set *cs, const mg_keyframe
         double *q = &values[(size_t)n * 8];
         q[0] = al->heading[0] / hn; q[1] = al->heading[1] / hn; q[2] = al->position[0]; q[3] = al->position[2];
         q[4] = al->ref_dir[0]; q[5] = al->ref_dir[1]; q[6] = al->ref_dir[2];
+        if (al->joint == MG_ALIGN_START_POSE) { q[4] = al->position[1]; q[5] = q[6] = 0.0; }
     }
     { int rc = mg_use_device(cs->prim->ctx); if (rc != MG_OK) return rc; }
     // entry 0 of the alignment record, the chain length, is structure and stays

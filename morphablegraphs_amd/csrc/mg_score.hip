@@ -103,11 +103,22 @@ __device__ __forceinline__ void mg_fk_position_table(ChannelFn channel, int r0, 
 // The candidate's 2-D aligning transform (mg_alignment_desc): rotation about y by the angle between its own heading
 // in the first control point and the previous motion's, as (cos, sin) = (h . b, h x b), and the xz translation that
 // puts its first root position on the previous one.
-struct mg_align2d { double c, s, tx, tz; };
+struct mg_align2d { double c, s, tx, tz, ty; };   // ty: the start-pose mode raises every position by the start height
 template <typename ChannelFn>
 __device__ __forceinline__ mg_align2d mg_candidate_alignment(const mg_score_args &a, ChannelFn channel) {
     const double *al = a.align;
     const int r0 = a.woff[a.n], m = (int)al[0];
+    if (m == 0) {
+        // start-pose mode (reference objective_functions.py:38-47): the SAME rotation about y for every candidate,
+        // (cos, sin) = al[1..2], the candidate's first root position moved to (al[3], ., al[4]), heights raised by al[5]
+        mg_align2d t;
+        t.c = al[1]; t.s = al[2];
+        const double p0x = channel(r0), p0z = channel(r0 + 2);
+        t.tx = al[3] - (t.c * p0x + t.s * p0z);
+        t.tz = al[4] - (t.c * p0z - t.s * p0x);
+        t.ty = al[5];
+        return t;
+    }
     double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;   // global orientation of the aligning node
     for (int i = 0; i < m; i++) {
         double qw = channel(r0 + 3 + 4 * i), qx = channel(r0 + 4 + 4 * i), qy = channel(r0 + 5 + 4 * i), qz = channel(r0 + 6 + 4 * i);
@@ -129,6 +140,7 @@ __device__ __forceinline__ mg_align2d mg_candidate_alignment(const mg_score_args
     const double p0x = channel(r0), p0z = channel(r0 + 2);
     t.tx = al[3] - (t.c * p0x + t.s * p0z);
     t.tz = al[4] - (t.c * p0z - t.s * p0x);
+    t.ty = 0.0;
     return t;
 }
 
@@ -137,7 +149,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
     const double *par = a.par + (size_t)c * 8;
     const int type = (int)par[0];
     const int r0 = a.woff[c];
-    mg_align2d al = {1.0, 0.0, 0.0, 0.0};
+    mg_align2d al = {1.0, 0.0, 0.0, 0.0, 0.0};
     if (a.align) al = mg_candidate_alignment(a, channel);
     if (type == MG_CONSTRAINT_JOINT_POSITION || type == MG_CONSTRAINT_JOINT_MIDPOINT) {
         // forward kinematics along the chain: p = t_root + sum_i R(q_0 .. q_(i-1)) offset_i, unit quaternions (w,x,y,z)
@@ -154,6 +166,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
             const double x = pj[0], z = pj[2];
             pj[0] = al.c * x + al.s * z + al.tx;
             pj[2] = al.c * z - al.s * x + al.tz;
+            pj[1] += al.ty;
         }
         double ds = 0.0;
 #pragma unroll
@@ -173,7 +186,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
             const double *rec = tb + MG_POSE_HDR + (size_t)i * MG_POSE_REC;
             double b[3];
             mg_fk_position_table(channel, r0, rec, b);
-            if (a.align) { const double x = b[0], z = b[2]; b[0] = al.c * x + al.s * z + al.tx; b[2] = al.c * z - al.s * x + al.tz; }
+            if (a.align) { const double x = b[0], z = b[2]; b[0] = al.c * x + al.s * z + al.tx; b[2] = al.c * z - al.s * x + al.tz; b[1] += al.ty; }
             const double w = rec[3];
             num += w * (rec[0] * b[2] - b[0] * rec[2]);
             den += w * (rec[0] * b[0] + rec[2] * b[2]);
@@ -188,7 +201,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
             const double *rec = tb + MG_POSE_HDR + (size_t)i * MG_POSE_REC;
             double b[3];
             mg_fk_position_table(channel, r0, rec, b);
-            if (a.align) { const double x = b[0], z = b[2]; b[0] = al.c * x + al.s * z + al.tx; b[2] = al.c * z - al.s * x + al.tz; }
+            if (a.align) { const double x = b[0], z = b[2]; b[0] = al.c * x + al.s * z + al.tx; b[2] = al.c * z - al.s * x + al.tz; b[1] += al.ty; }
             if (i == 0) { first[0] = b[0]; first[1] = b[1]; first[2] = b[2]; }
             const double bx = b[0] * ct + b[2] * st + x0, bz = b[2] * ct - b[0] * st + z0;
             const double ex = rec[0] - bx, ey = rec[1] - b[1], ez = rec[2] - bz;
@@ -198,7 +211,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
         if (tb[1] != 0.0) {
             double nx[3];
             mg_fk_position_table(channel, r0 + block, tb + MG_POSE_HDR, nx);   // the first joint one frame later
-            if (a.align) { const double x = nx[0], z = nx[2]; nx[0] = al.c * x + al.s * z + al.tx; nx[2] = al.c * z - al.s * x + al.tz; }
+            if (a.align) { const double x = nx[0], z = nx[2]; nx[0] = al.c * x + al.s * z + al.tx; nx[2] = al.c * z - al.s * x + al.tz; nx[1] += al.ty; }
             const double vx = tb[2] - (nx[0] - first[0]), vy = tb[3] - (nx[1] - first[1]), vz = tb[4] - (nx[2] - first[2]);
             err += sqrt(vx * vx + vy * vy + vz * vz);
         }
@@ -215,6 +228,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
             const double x = pj[0], z = pj[2], vx = v[0], vz = v[2];
             pj[0] = al.c * x + al.s * z + al.tx;
             pj[2] = al.c * z - al.s * x + al.tz;
+            pj[1] += al.ty;
             v[0] = al.c * vx + al.s * vz;
             v[2] = al.c * vz - al.s * vx;
         }
@@ -242,7 +256,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
         double ds = 0.0;
         if (a.align) {
             const double x = channel(r0), z = channel(r0 + 2);
-            const double pj[3] = {al.c * x + al.s * z + al.tx, channel(r0 + 1), al.c * z - al.s * x + al.tz};
+            const double pj[3] = {al.c * x + al.s * z + al.tx, channel(r0 + 1) + al.ty, al.c * z - al.s * x + al.tz};
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 double t = par[2 + i];

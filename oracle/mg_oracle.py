@@ -341,6 +341,33 @@ def align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, 
     return coeffs
 
 
+def align_coeffs_to_start_pose(coeffs, start_pose):
+    """The other branch of align_quaternion_frames (optimization/objective_functions.py:38-47), taken when there are no
+    previous frames but a start pose: m = get_transform_from_start_pose(start_pose) (anim_utils, absent: PARITY UNPINNED;
+    restated as the rotation by the start orientation's Euler angles in degrees plus the start position, here for
+    rotations about y only); t_pos = m . (first root position, 1); delta = start_pose["position"] -- the SAME list
+    object, so the two subtractions that follow also rewrite the start pose for the next call; m[:3, 3] = delta; every
+    control point goes through m (positions through the matrix, root quaternions multiplied by its rotation from the
+    left).  Returns a new (n_basis, D) array and mutates start_pose["position"] exactly as the reference does."""
+    coeffs = np.array(coeffs, dtype=np.float64)
+    rx, ry, rz = [math.radians(float(v)) for v in start_pose["orientation"]]
+    assert rx == 0.0 and rz == 0.0, "rotations about y only"
+    q = np.array([math.cos(ry / 2.0), 0.0, math.sin(ry / 2.0), 0.0])
+    m = np.eye(4)
+    m[:3, :3] = quaternion_matrix3(q)
+    m[:3, 3] = start_pose["position"]
+    first_frame_pos = coeffs[0][:3].tolist() + [1]
+    t_pos = np.dot(m, first_frame_pos)[:3]
+    delta = start_pose["position"]
+    delta[0] -= t_pos[0]
+    delta[2] -= t_pos[2]
+    m[:3, 3] = delta
+    for cp in coeffs:
+        cp[:3] = (m @ np.array([cp[0], cp[1], cp[2], 1.0]))[:3]
+        cp[3:7] = quaternion_multiply(q, cp[3:7])
+    return coeffs
+
+
 def align_point_clouds_2d(a, b, weights):
     """The optimal weighted 2-D rigid fit of cloud b onto cloud a (rotation about y by theta, then translation in x
     and z): the closed form of Kovar, Gleicher, Pighin, "Motion Graphs" (2002), which the reference reaches through
@@ -537,6 +564,20 @@ class OraclePrimitive(object):
                     out[b, ci] = c["weight"] * pose_constraint_error(c, frame, frame2, joints, animated_joints)
                 else:
                     out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
+        return out
+
+    def start_pose_residuals(self, S, constraints, start_pose, joints, animated_joints):
+        """The residuals of candidates aligned to a START POSE (no previous frames): (n_samples, n_constraints).  The
+        start pose is passed on from candidate to candidate as the reference's caller does (its position entry is
+        rewritten by every call, see align_coeffs_to_start_pose)."""
+        S = np.atleast_2d(S)
+        out = np.zeros((S.shape[0], len(constraints)))
+        for b in range(S.shape[0]):
+            coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
+            coeffs = align_coeffs_to_start_pose(coeffs, start_pose)
+            for ci, c in enumerate(constraints):
+                frame = spline_frames(self.knots, coeffs, [c["t"]])[0]
+                out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
         return out
 
     def skeleton_residuals(self, S, constraints, joints, animated_joints):

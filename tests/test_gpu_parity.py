@@ -783,6 +783,56 @@ def test_constraints_in_global_coordinates_align_every_candidate_to_the_previous
     prim.close()
 
 
+def test_start_pose_alignment_branch(ctx):
+    """The other branch of the reference's align_quaternion_frames (optimization/objective_functions.py:38-47): no previous
+    frames but a start pose.  Every candidate gets the same rotation about y; the reference's arithmetic (its `delta` IS
+    the start pose's position list) puts the first root position on x = z = 0 and raises heights by the start height, call
+    after call.  The oracle follows the reference's lines literally, mutation included, on the control points; the device
+    applies the closed form to the evaluated quantities.  PARITY UNPINNED (get_transform_from_start_pose is anim_utils')."""
+    from oracle import mg_oracle as orc
+    from morphablegraphs_amd.candidate_scoring import alignment_from_start_pose, alignment_from_prev_frames
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    op = orc.OraclePrimitive(data)
+    S = np.random.default_rng(21).standard_normal((40, 40))
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [30.0, None, -20.0]},
+            {"type": "position", "t": 0.0, "weight": 1.0, "target": [0.0, None, 0.0]},
+            {"type": "position", "t": 60.0, "weight": 0.5, "target": [10.0, 95.0, 5.0]},
+            {"type": "direction", "t": 155.0, "weight": 0.3, "target": [0.2, 1.0]},
+            {"type": "joint_position", "joint": "LeftHand_EndSite", "t": 100.0, "weight": 2.0, "target": [40.0, 120.0, -10.0]},
+            {"type": "joint_orientation", "joint": "Hips", "t": 20.0, "weight": 1.0, "orientation": [0.9, 0.1, 0.3, -0.2]}]
+    for angle in (0.0, 37.5, -110.0):
+        start_pose = {"position": [55.0, 7.5, -80.0], "orientation": [0.0, angle, 0.0]}
+        al = alignment_from_start_pose(start_pose)
+        assert start_pose["position"] == [55.0, 7.5, -80.0]                    # the device path leaves the caller's object alone
+        cset = _capi.ConstraintSet(prim, cons, sk, alignment=al)
+        res = prim.score_constraint_residuals(cset, S)
+        ref = op.start_pose_residuals(S, cons, {"position": [55.0, 7.5, -80.0], "orientation": [0.0, angle, 0.0]}, joints, animated)
+        np.testing.assert_allclose(res, ref, rtol=1e-9, atol=1e-8, err_msg=str(angle))
+        np.testing.assert_allclose(res[:, 1], 0.0, atol=1e-9)                   # the aligned start sits on x = z = 0
+        ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 1)
+        np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S), res)
+        ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 0)
+        # the values of a cached set are rewritten in place (another angle, another height)
+        al2 = alignment_from_start_pose({"position": [1.0, -3.0, 2.0], "orientation": [0.0, angle + 15.0, 0.0]})
+        cset.update(cons, alignment=al2)
+        ref2 = op.start_pose_residuals(S, cons, {"position": [1.0, -3.0, 2.0], "orientation": [0.0, angle + 15.0, 0.0]}, joints, animated)
+        np.testing.assert_allclose(prim.score_constraint_residuals(cset, S), ref2, rtol=1e-9, atol=1e-8)
+        cset.close()
+
+    class _C(object):                                                           # what MotionPrimitiveConstraints carries
+        is_local = False
+        start_pose = {"position": [5.0, 1.0, 5.0], "orientation": [0.0, 90.0, 0.0]}
+    rec = alignment_from_prev_frames(None, _C(), None)
+    assert rec["joint"] == _capi.MG_ALIGN_START_POSE and abs(rec["heading"][1] - 1.0) < 1e-12 and rec["position"] == (0.0, 1.0, 0.0)
+    _C.start_pose = {"position": [0.0, 0.0, 0.0], "orientation": [10.0, 0.0, 0.0]}
+    with pytest.raises(NotImplementedError):
+        alignment_from_prev_frames(None, _C(), None)
+    prim.close()
+
+
 def test_two_hand_midpoint_and_joint_orientation_constraints(ctx):
     """MG_CONSTRAINT_JOINT_MIDPOINT (first residual of TwoHandConstraint, reference two_hand_constraint.py:66-74) and
     MG_CONSTRAINT_JOINT_ORIENTATION (GlobalTransformConstraint._quaternion_distance, global_transform_constraint.py:
