@@ -313,6 +313,25 @@ int mg_time_grid_size(const mg_time_grid *grid);
 /* copies the grid's tables: i0 (T) int32, weights (T,4) float64, times (T) float64; any may be NULL */
 int mg_time_grid_get_tables(const mg_time_grid *grid, int32_t *i0, double *weights, double *times);
 
+/* ---- trajectory constraints -------------------------------------------------------------------------
+ * TrajectoryConstraint.evaluate_motion_spline / get_residual_vector for the ROOT joint (reference
+ * constraints/spatial_constraints/trajectory_constraint.py:79-121): per time sample of `grid` (NULL = the canonical grid,
+ * i.e. get_motion_vector()) the distance from the candidate's root position to the closest point of a Catmull-Rom spline
+ * through `control_points` (n_points x 3; reference splines/catmull_rom_spline.py:66-168) whose parameter is at or after
+ * the previous sample's, starting at min_u (= min_arc_length / full_arc_length); error = weight * average distance.
+ * errors_dev (B) float64: written, or added to with accumulate != 0 (the sum MotionPrimitiveConstraints.evaluate forms);
+ * residuals_dev: NULL or (B, T) float64 = weight * distance per sample.  alignment: NULL (local coordinates), the
+ * previous-frame record with the ROOT as aligning node, or a start-pose record.
+ * The reference searches with scipy's L-BFGS-B from the lower bound; here: grid walk (u = k / granularity) + parabolic
+ * refinement, deterministic (mg_trajectory.hip).  PARITY UNPINNED for the search (the reference function does not run on the
+ * installed NumPy); the spline itself is pinned by tests/golden/trajectory_spline.npz. */
+typedef struct mg_trajectory mg_trajectory;
+int mg_trajectory_create(mg_primitive *prim, const double *control_points, int32_t n_points, int32_t granularity, mg_trajectory **out);
+void mg_trajectory_destroy(mg_trajectory *trajectory);
+int mg_score_trajectory(mg_primitive *prim, const mg_trajectory *trajectory, const mg_time_grid *grid, const void *latents_dev,
+                        int latent_dtype, int64_t n_samples, int64_t ld, double min_u, double weight, const mg_alignment_desc *alignment,
+                        double *errors_dev, int accumulate, double *residuals_dev);
+
 /* ---- hot path, device pointers ------------------------------------------------------ */
 
 /* MotionPrimitive.back_project(s, False).get_motion_vector() for a batch

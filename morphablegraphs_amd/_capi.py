@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host",
+    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
@@ -178,7 +179,7 @@ def load_library(path=None):
     lib.mg_primitive_canonical_grid.restype = C.c_void_p
     lib.mg_primitive_canonical_grid.argtypes = [C.c_void_p]
     lib.mg_time_grid_size.argtypes = [C.c_void_p]
-    for name in ("mg_context_destroy", "mg_primitive_destroy", "mg_time_grid_destroy", "mg_constraint_set_destroy"):
+    for name in ("mg_context_destroy", "mg_primitive_destroy", "mg_time_grid_destroy", "mg_constraint_set_destroy", "mg_trajectory_destroy"):
         getattr(lib, name).restype = None
         getattr(lib, name).argtypes = [C.c_void_p]
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
@@ -212,6 +213,8 @@ def load_library(path=None):
         "mg_primitive_info": [vp, C.POINTER(C.c_int32)],
         "mg_primitive_info2": [vp, C.POINTER(C.c_int32)],
         "mg_time_function_canonical": [vp, vp, i32, i64, i64, vp],
+        "mg_trajectory_create": [vp, vp, i32, i32, C.POINTER(vp)],
+        "mg_score_trajectory": [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, i32, vp],
         "mg_time_function_canonical_host": [vp, vp, i32, i64, i64, vp],
         "mg_primitive_get_precisions_cholesky": [vp, vp],
         "mg_time_grid_create": [vp, vp, C.c_int32, C.POINTER(vp)],
@@ -620,6 +623,31 @@ class ConstraintSet(object):
             pass
 
 
+class Trajectory(object):
+    """A Catmull-Rom trajectory on the device for mg_score_trajectory: control_points (n, 3), the reference's
+    TrajectoryConstraint spline (trajectory_constraint.py:33-38); granularity = the step of the closest-point search."""
+
+    def __init__(self, prim, control_points, granularity=1000):
+        self.prim = prim
+        cp = np.ascontiguousarray(np.asarray(control_points, dtype=np.float64))
+        if cp.ndim != 2 or cp.shape[1] != 3:
+            raise ValueError("control_points must be (n, 3)")
+        h = C.c_void_p()
+        _check(prim.lib.mg_trajectory_create(prim.handle, cp.ctypes.data_as(C.c_void_p), cp.shape[0], int(granularity), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None) and self.prim.handle and self.prim.ctx.handle:
+            self.prim.lib.mg_trajectory_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Primitive(object):
     """Device-resident constants of one motion primitive, built from the reference's JSON dict."""
 
@@ -698,6 +726,31 @@ class Primitive(object):
         out = np.empty((self.n_gmm, self.n_gmm_dims, self.n_gmm_dims))
         _check(self.lib.mg_primitive_get_precisions_cholesky(self.handle, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def score_trajectory_dev(self, trajectory, lat_dev, lat_dtype, n, ld, errors_dev, min_u=0.0, weight=1.0, alignment=None,
+                             accumulate=False, residuals_dev=None, grid=None):
+        """mg_score_trajectory on device buffers: errors_dev (n) float64 written or added to."""
+        al = ConstraintSet._marshal_alignment(alignment, None) if alignment is not None else None
+        code = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        _check(self.lib.mg_score_trajectory(self.handle, trajectory.handle, self._grid_handle(grid), _dev_ptr(lat_dev), code, int(n), int(ld),
+                                            float(min_u), float(weight), C.byref(al) if al is not None else None, _dev_ptr(errors_dev),
+                                            1 if accumulate else 0, _dev_ptr(residuals_dev) if residuals_dev is not None else None))
+
+    def score_trajectory(self, trajectory, S, min_u=0.0, weight=1.0, alignment=None, residuals=False, grid=None):
+        """(n,) float64 errors = weight * average distance of the root path to the trajectory; with residuals=True also
+        the (n, T) per-sample residuals (TrajectoryConstraint.get_residual_vector times the weight)."""
+        S = _latents(S)
+        n, T = S.shape[0], self._grid_size(grid)
+        d_S, d_e = self.ctx.upload(S), self.ctx.malloc(max(n, 1) * 8)
+        d_r = self.ctx.malloc(max(n * T, 1) * 8) if residuals else None
+        try:
+            self.score_trajectory_dev(trajectory, d_S, S.dtype, n, S.shape[1], d_e, min_u, weight, alignment, False, d_r, grid)
+            err = self.ctx.download(d_e, (n,), np.float64)
+            return (err, self.ctx.download(d_r, (n, T), np.float64)) if residuals else err
+        finally:
+            for b in (d_S, d_e, d_r):
+                if b is not None:
+                    b.free()
 
     def time_function_canonical(self, gamma):
         """(B, n_time_components) time latents -> (B, n_canonical_frames) float64: the reference's

@@ -11,7 +11,10 @@ Constraints covered by the fused kernel: the FK-free ones path following uses
 (locomotion_constraints_builder.py:82-117) -- root position at a canonical keyframe
 (GlobalTransformConstraint, position only, root joint) and 2-D heading (Direction2DConstraint) -- and, given
 a `_capi.Skeleton` (argument, or `hip_skeleton` attribute of the constraints object), the position of any
-other joint by forward kinematics (hands, feet).  Anything else raises -- there is no silent CPU fallback.
+other joint by forward kinematics (hands, feet).  Trajectory constraints on the root joint
+(trajectory_constraint.py:79-121: the root path against a spline over ALL frames) run in their own kernel
+(mg_score_trajectory) and add to the same per-candidate error before the argmin.  Anything else raises -- there is no
+silent CPU fallback.
 """
 import numpy as np
 
@@ -34,6 +37,10 @@ def constraints_to_device_form(constraints, root_joint=None):
     for c in constraints:
         if isinstance(c, dict):
             out.append(c)
+            group += 1
+            continue
+        if getattr(c, "constraint_type", None) == "trajectory" or (hasattr(c, "min_arc_length") and hasattr(c, "full_arc_length")):
+            out.append(trajectory_to_device_form(c, root_joint, group))
             group += 1
             continue
         t = float(c.canonical_keyframe)
@@ -93,6 +100,59 @@ def constraints_to_device_form(constraints, root_joint=None):
         else:
             raise NotImplementedError("constraint %r is not covered by the fused GPU scorer" % (type(c).__name__,))
     return out
+
+
+def trajectory_to_device_form(c, root_joint=None, group=None):
+    """A reference TrajectoryConstraint (trajectory_constraint.py:33-52: an AnnotatedSpline over control points with
+    min_arc_length / full_arc_length, a joint and a weight) as the dict the device path takes.  Root joint and Catmull-Rom
+    splines only; collision-avoidance trajectories are scored differently in the reference and are not covered."""
+    if getattr(c, "is_collision_avoidance_constraint", False):
+        raise NotImplementedError("collision-avoidance trajectory constraints are not covered by the GPU scorer")
+    root = root_joint if root_joint is not None else getattr(getattr(c, "skeleton", None), "root", None)
+    joint = getattr(c, "joint_name", root)
+    if root is not None and joint is not None and joint != root:
+        raise NotImplementedError("trajectory constraint on joint %r: only the root joint's path is scored on the device" % (joint,))
+    spline = getattr(c, "spline", None)
+    padded = getattr(spline, "control_points", None)
+    if padded is None or not hasattr(spline, "_catmullrom_basematrix"):
+        raise NotImplementedError("trajectory constraint without a Catmull-Rom spline")
+    cps = [list(map(float, p)) for p in padded[1:-2]]          # the padding of catmull_rom_spline.py:66-71 undone
+    full = float(c.full_arc_length)
+    return {"type": "trajectory", "control_points": cps, "min_u": float(c.min_arc_length) / full if full > 0.0 else 0.0,
+            "weight": float(getattr(c, "weight_factor", 1.0)), "granularity": int(getattr(c, "granularity", 1000)), "group": group}
+
+
+def split_trajectories(clist):
+    """(keyframe constraints, trajectory constraints) of a device-form list."""
+    return [c for c in clist if c.get("type") != "trajectory"], [c for c in clist if c.get("type") == "trajectory"]
+
+
+_TRAJ_CACHE = []   # [(key, _capi.Trajectory)]: a planner scores against the same trajectory for a whole action
+
+
+def cached_trajectory(prim, c):
+    key = (id(prim), prim.handle.value, _freeze(c["control_points"]), int(c.get("granularity", 1000)))
+    for i, (k, t) in enumerate(_TRAJ_CACHE):
+        if k == key and t.handle:
+            _TRAJ_CACHE.append(_TRAJ_CACHE.pop(i))
+            return t
+    t = _capi.Trajectory(prim, c["control_points"], c.get("granularity", 1000))
+    _TRAJ_CACHE.append((key, t))
+    while len(_TRAJ_CACHE) > 16:
+        _TRAJ_CACHE.pop(0)[1].close()
+    return t
+
+
+def _errors_with_trajectories_dev(prim, keyframe_list, trajectory_list, skeleton, alignment, d_S, dtype, n, ld, d_err):
+    """sum of weighted constraint errors of n device-resident candidates into d_err (float64): the fused keyframe scorer,
+    then one mg_score_trajectory launch per trajectory constraint adding to the same buffer."""
+    if alignment is not None and trajectory_list and alignment.get("joint", 0) not in (0, _capi.MG_ALIGN_START_POSE):
+        raise NotImplementedError("trajectory constraints in global coordinates need the root joint as aligning node")
+    cset = cached_constraint_set(prim, keyframe_list, skeleton, alignment)
+    prim.score_constraints_dev(cset, d_S, dtype, n, ld, d_err, np.float64)
+    for c in trajectory_list:
+        prim.score_trajectory_dev(cached_trajectory(prim, c), d_S, dtype, n, ld, d_err, c.get("min_u", 0.0), c.get("weight", 1.0),
+                                  alignment, accumulate=True)
 
 
 def group_residuals(clist, res):
@@ -209,6 +269,8 @@ def clear_constraint_cache():
     """Drop the cached device constraint sets (call before closing a primitive they belong to)."""
     while _CSET_CACHE:
         _CSET_CACHE.pop()[1].close()
+    while _TRAJ_CACHE:
+        _TRAJ_CACHE.pop()[1].close()
 
 
 
@@ -219,8 +281,18 @@ class HipSampleFilter(object):
     def score_samples(motion_primitive, samples, constraints, dtype=np.float64, skeleton=None, prev_frames=None):
         prim = motion_primitive._prim if hasattr(motion_primitive, "_prim") else motion_primitive
         clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
-        cset = _capi.ConstraintSet(prim, constraints_to_device_form(clist), skeleton,
-                                   alignment_from_prev_frames(prev_frames, constraints, skeleton))
+        keyframes, trajectories = split_trajectories(constraints_to_device_form(clist))
+        alignment = alignment_from_prev_frames(prev_frames, constraints, skeleton)
+        if trajectories:
+            S = _capi._latents(samples)
+            d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(max(len(S), 1) * 8)
+            try:
+                _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_S, S.dtype, len(S), S.shape[1], d_e)
+                return prim.ctx.download(d_e, (len(S),), np.float64).astype(dtype)
+            finally:
+                d_S.free()
+                d_e.free()
+        cset = _capi.ConstraintSet(prim, keyframes, skeleton, alignment)
         try:
             return prim.score_constraints(cset, np.asarray(samples), dtype=dtype)
         finally:
@@ -237,9 +309,20 @@ def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frame
     prim = prim_obj._prim
     clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
     skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
-    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton,
-                                 alignment_from_prev_frames(prev_frames, constraints, skeleton))
-    best_idx, min_error = prim.best_candidate(cset, samples)   # one upload, two launches, 16 bytes back
+    keyframes, trajectories = split_trajectories(constraints_to_device_form(clist))
+    alignment = alignment_from_prev_frames(prev_frames, constraints, skeleton)
+    if trajectories:
+        S = _capi._latents(samples)
+        d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(max(len(S), 1) * 8)
+        try:
+            _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_S, S.dtype, len(S), S.shape[1], d_e)
+            best_idx, min_error = prim.ctx.argmin_first(d_e, len(S), np.float64)
+        finally:
+            d_S.free()
+            d_e.free()
+    else:
+        cset = cached_constraint_set(prim, keyframes, skeleton, alignment)
+        best_idx, min_error = prim.best_candidate(cset, samples)   # one upload, two launches, 16 bytes back
     if hasattr(constraints, "min_error"):
         constraints.min_error = min_error
     if hasattr(constraints, "evaluations"):
@@ -257,8 +340,9 @@ def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleto
     ctx = prim.ctx
     clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
     skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
-    cset = cached_constraint_set(prim, constraints_to_device_form(clist), skeleton,
-                                 alignment_from_prev_frames(prev_frames, constraints, skeleton))
+    keyframes, trajectories = split_trajectories(constraints_to_device_form(clist))
+    alignment = alignment_from_prev_frames(prev_frames, constraints, skeleton)
+    cset = cached_constraint_set(prim, keyframes, skeleton, alignment)
     L = prim.n_gmm_dims          # the full sample (spatial + time latents); scoring reads its first n_components columns
     weights = np.asarray(prim_obj.gaussian_mixture_model.weights_, dtype=np.float64)
     counts = np.random.multinomial(int(n_samples), weights / weights.sum()).astype(np.int64)
@@ -266,7 +350,15 @@ def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleto
     d_x = ctx.malloc(max(int(n_samples), 1) * L * item)
     try:
         prim.gmm_sample_dev(counts, seed, d_x, dtype, L)
-        best_idx, min_error = prim.best_candidate_dev(cset, d_x, dtype, int(n_samples), L)
+        if trajectories:
+            d_e = ctx.malloc(max(int(n_samples), 1) * 8)
+            try:
+                _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_x, dtype, int(n_samples), L, d_e)
+                best_idx, min_error = ctx.argmin_first(d_e, int(n_samples), np.float64)
+            finally:
+                d_e.free()
+        else:
+            best_idx, min_error = prim.best_candidate_dev(cset, d_x, dtype, int(n_samples), L)
         best = ctx.download(d_x.ptr.value + best_idx * L * item, (L,), dtype)
     finally:
         d_x.free()

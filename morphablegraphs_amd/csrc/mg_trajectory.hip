@@ -1,0 +1,267 @@
+// Trajectory constraints on the device (gfx950): TrajectoryConstraint.get_residual_vector / evaluate_motion_spline for
+// the ROOT joint (reference morphablegraphs/constraints/spatial_constraints/trajectory_constraint.py:79-121):
+// per frame of the motion the distance from the root position to the closest point of a Catmull-Rom spline
+// (splines/catmull_rom_spline.py:118-168) whose parameter is at or after the previous frame's; the constraint's error is
+// the average over the frames.  The reference finds that point with scipy's L-BFGS-B started at the lower bound
+// (splines/parameterized_spline.py:303-322; the function raises ValueError under NumPy >= 1.24, so PARITY UNPINNED);
+// here the search is deterministic: on the grid u_k = k / granularity walk forward from the bound while the distance
+// falls, then refine by the parabola through the three squared distances around the minimum (oracle:
+// oracle/mg_oracle.py closest_point_walk; the two agree to 2e-3 relative on paths that follow the spline).
+//
+// One thread per candidate (the search is a chain over the frames): the candidate's root coefficient rows
+// (n_basis x 3, float64 fma chains over the latents) are staged in LDS, every frame is four taps of them.
+// 172 + 8 bytes per candidate: arithmetic / latency bound, a scoring kernel beside mg_score_constraints.
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "mg_internal.h"
+
+struct mg_trajectory {
+    mg_primitive *prim = nullptr;
+    int32_t n_seg = 0, granularity = 1000, rows = 0;
+    double *d_poly = nullptr;    // [n_seg][4][3]: point(t) = ((A0 t + A1) t + A2) t + A3 on a segment; then the last control point [3]
+    double *d_E = nullptr;       // [rows][L]: root coefficient rows (i * 3 + d), then the first control point's root quaternion (4 rows)
+    double *d_mean = nullptr;    // [rows]
+};
+
+struct mg_traj_args {
+    const double *poly, *E, *mean;
+    const void *lat;
+    const int32_t *i0;
+    const double *w;
+    double *out, *res;
+    int64_t B, ld;
+    int32_t T, L, NB, n_seg, G, lat_f64, accumulate, align_mode;   // align_mode 0: none, 1: previous frame (root node), 2: start pose
+    double min_u, weight;
+    double al[7];   // heading (x, z) or (cos, sin); landing (x, z); ref_dir (3) or height
+};
+
+#define MG_TRAJ_BLOCK 64
+
+__device__ __forceinline__ void mg_traj_point(const double *__restrict__ poly, int n_seg, double u, double *p) {
+    const double scaled = n_seg * u;
+    int index = (int)floor(scaled);
+    index = index < n_seg ? index : n_seg;
+    if (index >= n_seg) {                       // past the last segment: the last control point
+        const double *q = poly + (size_t)n_seg * 12;
+        p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+        return;
+    }
+    const double t = scaled - index;
+    const double *A = poly + (size_t)index * 12;
+#pragma unroll
+    for (int d = 0; d < 3; d++) p[d] = ((A[d] * t + A[3 + d]) * t + A[6 + d]) * t + A[9 + d];
+}
+__device__ __forceinline__ double mg_traj_d2(const double *poly, int n_seg, double u, const double *q) {
+    double p[3];
+    mg_traj_point(poly, n_seg, u, p);
+    const double x = p[0] - q[0], y = p[1] - q[1], z = p[2] - q[2];
+    return x * x + y * y + z * z;
+}
+
+__global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_args a) {
+    extern __shared__ double lds[];                 // [L + rows][64]: the latents, then the root coefficient rows
+    const int tid = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * MG_TRAJ_BLOCK + tid;
+    const bool valid = b < a.B;
+    const int64_t bb = valid ? b : a.B - 1;
+    const int rows = a.NB * 3 + 4;
+    double *ls = lds, *lc = lds + (size_t)a.L * MG_TRAJ_BLOCK;
+    for (int k = 0; k < a.L; k++)
+        ls[k * MG_TRAJ_BLOCK + tid] = a.lat_f64 ? ((const double *)a.lat)[bb * a.ld + k] : (double)((const float *)a.lat)[bb * a.ld + k];
+    for (int r = 0; r < rows; r++) {
+        double acc = a.mean[r];
+        const double *e = a.E + (size_t)r * a.L;
+        for (int k = 0; k < a.L; k++) acc = fma(e[k], ls[k * MG_TRAJ_BLOCK + tid], acc);
+        lc[r * MG_TRAJ_BLOCK + tid] = acc;
+    }
+    // the candidate's aligning transform (mg_score.hip's closed form): rotation about y and an xz translation
+    double ac = 1.0, as = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
+    if (a.align_mode != 0) {
+        if (a.align_mode == 2) {
+            ac = a.al[0]; as = a.al[1]; ty = a.al[4];
+        } else {
+            double qw = lc[(a.NB * 3 + 0) * MG_TRAJ_BLOCK + tid], qx = lc[(a.NB * 3 + 1) * MG_TRAJ_BLOCK + tid];
+            double qy = lc[(a.NB * 3 + 2) * MG_TRAJ_BLOCK + tid], qz = lc[(a.NB * 3 + 3) * MG_TRAJ_BLOCK + tid];
+            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+            const double rx = a.al[4], ry = a.al[5], rz = a.al[6];
+            const double cx = qy * rz - qz * ry, cy = qz * rx - qx * rz, cz = qx * ry - qy * rx;
+            const double dx = qy * cz - qz * cy, dz = qx * cy - qy * cx;
+            double bx = rx + 2.0 * (qw * cx + dx), bz = rz + 2.0 * (qw * cz + dz);
+            const double bn = 1.0 / sqrt(bx * bx + bz * bz);
+            bx *= bn; bz *= bn;
+            ac = a.al[0] * bx + a.al[1] * bz;
+            as = a.al[0] * bz - a.al[1] * bx;
+        }
+        const double p0x = lc[0 * MG_TRAJ_BLOCK + tid], p0z = lc[2 * MG_TRAJ_BLOCK + tid];
+        tx = a.al[2] - (ac * p0x + as * p0z);
+        tz = a.al[3] - (ac * p0z - as * p0x);
+    }
+    const int G = a.G;
+    const double invG = 1.0 / (double)G;
+    double min_u = a.min_u, sum = 0.0;
+    for (int f = 0; f < a.T; f++) {
+        const int i0 = a.i0[f];
+        const double *w = a.w + 4 * (size_t)f;
+        double q[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double v = w[0] * lc[((i0 + 0) * 3 + d) * MG_TRAJ_BLOCK + tid];
+            v = fma(w[1], lc[((i0 + 1) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+            v = fma(w[2], lc[((i0 + 2) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+            v = fma(w[3], lc[((i0 + 3) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+            q[d] = v;
+        }
+        if (a.align_mode != 0) {
+            const double x = q[0], z = q[2];
+            q[0] = ac * x + as * z + tx;
+            q[2] = ac * z - as * x + tz;
+            q[1] += ty;
+        }
+        // closest point at or after min_u: grid walk + parabola (oracle closest_point_walk)
+        int k = (int)ceil(min_u * G - 1e-12);
+        k = k < G ? k : G;
+        double dk = mg_traj_d2(a.poly, a.n_seg, k * invG, q);
+        const double d_start = mg_traj_d2(a.poly, a.n_seg, min_u, q);
+        while (k < G) {
+            const double dn = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
+            if (dn >= dk) break;
+            k++;
+            dk = dn;
+        }
+        double u = k * invG;
+        if (k > 0 && k < G) {
+            const double da = mg_traj_d2(a.poly, a.n_seg, (k - 1) * invG, q), dc = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
+            const double den = da - 2.0 * dk + dc;
+            if (den > 0.0) u = (k + 0.5 * (da - dc) / den) * invG;
+        }
+        u = fmin(1.0, fmax(min_u, u));
+        double d2 = mg_traj_d2(a.poly, a.n_seg, u, q);
+        if (d_start <= d2) { u = min_u; d2 = d_start; }
+        const double dist = sqrt(d2);
+        sum += dist;
+        if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
+        min_u = u;
+    }
+    if (valid) {
+        const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
+        a.out[b] = a.accumulate ? a.out[b] + e : e;
+    }
+}
+
+template <typename T>
+static int mg_traj_upload(const std::vector<T> &h, T **d) {
+    *d = nullptr;
+    MG_HIP_CHECK(hipMalloc((void **)d, std::max<size_t>(h.size() * sizeof(T), 16)));
+    if (!h.empty()) MG_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MG_OK;
+}
+
+extern "C" void mg_trajectory_destroy(mg_trajectory *t) {
+    if (!t) return;
+    if (t->prim) { (void)hipSetDevice(t->prim->ctx->device); (void)hipStreamSynchronize(t->prim->ctx->stream); }
+    (void)hipFree(t->d_poly);
+    (void)hipFree(t->d_E);
+    (void)hipFree(t->d_mean);
+    delete t;
+}
+
+extern "C" int mg_trajectory_create(mg_primitive *p, const double *cp, int32_t n_points, int32_t granularity, mg_trajectory **out) {
+    if (!p || !cp || !out || n_points < 2 || granularity < 2 || p->D < 3) {
+        mg_set_error("mg_trajectory_create: needs a primitive with root channels, >= 2 control points (x, y, z) and a granularity >= 2");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    *out = nullptr;
+    for (int i = 0; i < 3 * n_points; i++)
+        if (!std::isfinite(cp[i])) { mg_set_error("mg_trajectory_create: control point %d is not finite", i / 3); return MG_ERR_INVALID_ARGUMENT; }
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    mg_trajectory *t = new (std::nothrow) mg_trajectory();
+    if (!t) return MG_ERR_OUT_OF_MEMORY;
+    t->prim = p;
+    t->n_seg = n_points - 1;
+    t->granularity = granularity;
+    // catmull_rom_spline.py:66-71: control points padded to [P0] + P + [Pn, Pn]; segment s (1-based) uses padded[s-1 .. s+2]
+    std::vector<double> pad((size_t)(n_points + 3) * 3);
+    for (int d = 0; d < 3; d++) {
+        pad[d] = cp[d];
+        for (int i = 0; i < n_points; i++) pad[(size_t)(i + 1) * 3 + d] = cp[(size_t)i * 3 + d];
+        pad[(size_t)(n_points + 1) * 3 + d] = pad[(size_t)(n_points + 2) * 3 + d] = cp[(size_t)(n_points - 1) * 3 + d];
+    }
+    static const double M[4][4] = {{-1.0, 3.0, -3.0, 1.0}, {2.0, -5.0, 4.0, -1.0}, {-1.0, 0.0, 1.0, 0.0}, {0.0, 2.0, 0.0, 0.0}};
+    std::vector<double> poly((size_t)t->n_seg * 12 + 3);
+    for (int s = 0; s < t->n_seg; s++)           // 0-based segment s = the reference's segment index s + 1
+        for (int r = 0; r < 4; r++)
+            for (int d = 0; d < 3; d++) {
+                double v = 0.0;
+                for (int j = 0; j < 4; j++) v += M[r][j] * pad[(size_t)(s + j) * 3 + d];
+                poly[(size_t)s * 12 + r * 3 + d] = 0.5 * v;
+            }
+    for (int d = 0; d < 3; d++) poly[(size_t)t->n_seg * 12 + d] = cp[(size_t)(n_points - 1) * 3 + d];
+    // root coefficient rows of the primitive (already scaled by translation_maxima), then the root quaternion of the first control point
+    const int NB = p->NB, D = p->D, L = p->L;
+    t->rows = NB * 3 + 4;
+    std::vector<double> E((size_t)t->rows * L, 0.0), mean(t->rows, 0.0);
+    for (int i = 0; i < NB; i++)
+        for (int d = 0; d < 3; d++) {
+            mean[(size_t)i * 3 + d] = p->means_[(size_t)i * D + d];
+            for (int k = 0; k < L; k++) E[((size_t)i * 3 + d) * L + k] = p->Es[((size_t)i * D + d) * L + k];
+        }
+    for (int e = 0; e < 4; e++) {
+        const size_t row = (size_t)NB * 3 + e;
+        if (D >= 7) {
+            mean[row] = p->means_[3 + e];
+            for (int k = 0; k < L; k++) E[row * L + k] = p->Es[(size_t)(3 + e) * L + k];
+        } else {
+            mean[row] = e == 0 ? 1.0 : 0.0;
+        }
+    }
+    int rc = mg_traj_upload(poly, &t->d_poly);
+    if (rc == MG_OK) rc = mg_traj_upload(E, &t->d_E);
+    if (rc == MG_OK) rc = mg_traj_upload(mean, &t->d_mean);
+    if (rc != MG_OK) { mg_trajectory_destroy(t); return rc; }
+    *out = t;
+    return MG_OK;
+}
+
+extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, const mg_time_grid *g, const void *lat, int dt, int64_t B,
+                                   int64_t ld, double min_u, double weight, const mg_alignment_desc *al, double *errors_dev,
+                                   int accumulate, double *residuals_dev) {
+    if (!p || !t || t->prim != p || B < 0 || (dt != MG_F32 && dt != MG_F64) || ld < p->L || !(min_u >= 0.0 && min_u <= 1.0) ||
+        !std::isfinite(weight)) {
+        mg_set_error("mg_score_trajectory: bad arguments (trajectory of another primitive, ld < n_components, min_u outside [0, 1] ...)");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    if (!g) g = p->canonical;
+    if (g->prim != p) { mg_set_error("mg_score_trajectory: grid belongs to another primitive"); return MG_ERR_INVALID_ARGUMENT; }
+    if (B == 0) return MG_OK;
+    if (!lat || !errors_dev) { mg_set_error("mg_score_trajectory: NULL pointer"); return MG_ERR_INVALID_ARGUMENT; }
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    mg_traj_args a;
+    a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = lat; a.i0 = g->d_i0; a.w = g->d_w; a.out = errors_dev; a.res = residuals_dev;
+    a.B = B; a.ld = ld; a.T = g->T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = dt == MG_F64 ? 1 : 0;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight;
+    a.align_mode = 0;
+    for (double &v : a.al) v = 0.0;
+    if (al) {
+        const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
+        if (!(hn > 0.0) || !std::isfinite(hn)) { mg_set_error("mg_score_trajectory: heading is zero or not finite"); return MG_ERR_INVALID_ARGUMENT; }
+        if (al->joint != 0 && al->joint != MG_ALIGN_START_POSE) {
+            mg_set_error("mg_score_trajectory: only the root joint or a start pose can be the aligning reference here (joint %d)", al->joint);
+            return MG_ERR_UNSUPPORTED;
+        }
+        a.align_mode = al->joint == MG_ALIGN_START_POSE ? 2 : 1;
+        a.al[0] = al->heading[0] / hn; a.al[1] = al->heading[1] / hn; a.al[2] = al->position[0]; a.al[3] = al->position[2];
+        if (a.align_mode == 2) a.al[4] = al->position[1];
+        else { a.al[4] = al->ref_dir[0]; a.al[5] = al->ref_dir[1]; a.al[6] = al->ref_dir[2]; }
+    }
+    const size_t lds = (size_t)(p->L + t->rows) * MG_TRAJ_BLOCK * 8;
+    if (lds > 150 * 1024) { mg_set_error("mg_score_trajectory: %d basis functions x %d components do not fit LDS", p->NB, p->L); return MG_ERR_UNSUPPORTED; }
+    if (lds > 48 * 1024) MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
+    hipLaunchKernelGGL(mg_trajectory_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}

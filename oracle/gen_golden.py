@@ -112,6 +112,31 @@ def run_time_case(ref, name, data, n_samples, seed):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_trajectory_spline_case(name):
+    """The spline under a TrajectoryConstraint (reference constraints/spatial_constraints/splines/{parameterized_spline,
+    catmull_rom_spline,arc_length_map}.py, which need only numpy / scipy / matplotlib): points at given parameters and the
+    arc length of the granularity-1000 table.  (find_closest_point_fast itself raises ValueError under the installed NumPy:
+    the closest-point search has no vector.)"""
+    pkg = types.ModuleType("mg_ref_splines")
+    pkg.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints/splines"]
+    sys.modules["mg_ref_splines"] = pkg
+    ps = importlib.import_module("mg_ref_splines.parameterized_spline")
+    rng = np.random.default_rng(77)
+    out = {}
+    for ci, n_points in enumerate((2, 5, 9)):
+        cps = np.cumsum(np.column_stack([rng.uniform(20, 60, n_points), np.zeros(n_points), rng.uniform(-40, 40, n_points)]), axis=0)
+        sp = ps.ParameterizedSpline(cps.tolist(), ps.SPLINE_TYPE_CATMULL_ROM)
+        us = np.concatenate([[0.0, 1.0, 0.5, 1.0 / 3.0], rng.uniform(0, 1, 40)])
+        out["control_points_%d" % ci] = cps
+        out["parameters_%d" % ci] = us
+        out["points_%d" % ci] = np.stack([np.asarray(sp.query_point_by_parameter(float(u)), dtype=np.float64) for u in us])
+        out["full_arc_length_%d" % ci] = np.float64(sp.full_arc_length)
+    out["n_cases"] = np.int64(3)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref = import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -139,6 +164,7 @@ def main():
     timed = synthetic.make_primitive(seed=13, n_components=12, n_frames=60, n_dim=15, n_gmm=3, name="timed",
                                      n_time_components=3, n_basis_time=8)
     run_time_case(ref, "time_model", timed, 9, 41)
+    run_trajectory_spline_case("trajectory_spline")
 
 
 if __name__ == "__main__":

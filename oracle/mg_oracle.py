@@ -368,6 +368,94 @@ def align_coeffs_to_start_pose(coeffs, start_pose):
     return coeffs
 
 
+# --------------------------------------------------------------------------
+# trajectory constraints (root path against a Catmull-Rom spline)
+# --------------------------------------------------------------------------
+_CATMULL_ROM_BASE = np.array([[-1.0, 3.0, -3.0, 1.0], [2.0, -5.0, 4.0, -1.0], [-1.0, 0.0, 1.0, 0.0], [0.0, 2.0, 0.0, 0.0]])
+
+
+def catmull_rom_point(control_points, u):
+    """CatmullRomSpline.query_point_by_parameter (constraints/spatial_constraints/splines/catmull_rom_spline.py:66-71,
+    118-168): the control points padded to [P0] + P + [Pn, Pn]; segment = min(floor(N u), N) + 1 with N = len(P) - 1,
+    local parameter = N u - floor; 0.5 * [t^3 t^2 t 1] . base . [P_(i-1) P_i P_(i+1) P_(i+2)]; past the last segment the
+    last control point.  PINNED by tests/golden/trajectory_spline.npz (points and arc length made by the reference)."""
+    P = [np.asarray(p, dtype=np.float64) for p in control_points]
+    n_seg = len(P) - 1
+    padded = [P[0]] + P + [P[-1], P[-1]]
+    scaled = n_seg * float(u)
+    index = min(int(math.floor(scaled)), n_seg)
+    t = scaled - index
+    seg = index + 1
+    if seg > n_seg:
+        return padded[-1].copy()
+    w = np.array([t ** 3, t ** 2, t, 1.0])
+    ctrl = np.stack([padded[seg - 1], padded[seg], padded[seg + 1], padded[seg + 2]])      # (4, dims)
+    return 0.5 * (w @ (_CATMULL_ROM_BASE @ ctrl))
+
+
+def catmull_rom_full_arc_length(control_points, granularity=1000):
+    """RelativeArcLengthMap._update_table (splines/arc_length_map.py:45-71): polyline length over granularity + 1 samples."""
+    pts = np.array([catmull_rom_point(control_points, k / float(granularity)) for k in range(granularity + 1)])
+    return float(np.sum(np.linalg.norm(pts[1:] - pts[:-1], axis=1)))
+
+
+def closest_point_from(control_points, point, min_u):
+    """ParameterizedSpline.find_closest_point_fast (splines/parameterized_spline.py:303-322): L-BFGS-B on the distance over
+    the spline parameter, bounds [min_u, 1], started AT min_u.  PARITY UNPINNED: the reference function raises ValueError
+    under the installed NumPy (its weight vector [x**3, x**2, x, 1] is ragged when scipy hands over x as a 1-element array),
+    so there is no vector of it; this is the same call with the parameter unwrapped to a float."""
+    from scipy.optimize import minimize
+    target = np.asarray(point, dtype=np.float64)
+
+    def dist(x):
+        return float(np.linalg.norm(catmull_rom_point(control_points, float(np.ravel(x)[0])) - target))
+    res = minimize(dist, np.array([float(min_u)]), method="L-BFGS-B", bounds=[(float(min_u), 1.0)])
+    u = float(res["x"][0])
+    return catmull_rom_point(control_points, u), u
+
+
+def trajectory_residuals(root_path, control_points, min_u=0.0):
+    """TrajectoryConstraint.get_residual_vector for the root joint (constraints/spatial_constraints/trajectory_constraint.py:
+    95-121): per frame the distance to the closest spline point at or after the previous frame's parameter."""
+    errors = np.empty(len(root_path))
+    for f, p in enumerate(root_path):
+        target, u = closest_point_from(control_points, p, min_u)
+        errors[f] = np.linalg.norm(np.asarray(p, dtype=np.float64) - target)
+        min_u = u
+    return errors
+
+
+def closest_point_walk(control_points, point, min_u, granularity=1000):
+    """The DEVICE's deterministic form of the same search (what mg_score_trajectory computes, restated): on the grid
+    u_k = k / granularity walk forward from the first grid point at or after min_u while the distance falls, then refine
+    the parameter by the parabola through the squared distances of the three grid points around the minimum (clamped to
+    [min_u, 1])."""
+    target = np.asarray(point, dtype=np.float64)
+    G = int(granularity)
+
+    def d2(u):
+        v = catmull_rom_point(control_points, u) - target
+        return float(v @ v)
+    k = min(G, int(math.ceil(min_u * G - 1e-12)))
+    dk = d2(k / G)
+    d_start = d2(min_u)
+    while k < G:
+        dn = d2((k + 1) / G)
+        if dn >= dk:
+            break
+        k, dk = k + 1, dn
+    u = k / G
+    if 0 < k < G:
+        a, b, c = d2((k - 1) / G), dk, d2((k + 1) / G)
+        den = a - 2.0 * b + c
+        if den > 0.0:
+            u = (k + 0.5 * (a - c) / den) / G
+    u = min(1.0, max(float(min_u), u))
+    if d_start <= d2(u):
+        u = float(min_u)
+    return catmull_rom_point(control_points, u), u
+
+
 def align_point_clouds_2d(a, b, weights):
     """The optimal weighted 2-D rigid fit of cloud b onto cloud a (rotation about y by theta, then translation in x
     and z): the closed form of Kovar, Gleicher, Pighin, "Motion Graphs" (2002), which the reference reaches through

@@ -808,3 +808,129 @@ def test_model_with_time_latents_end_to_end():
     assert best.shape == (n_s + n_t,) and np.isfinite(err)
     res = mp._prim.score_constraints(_capi.ConstraintSet(mp._prim, cons), best.reshape(1, -1))
     assert abs(res[0] - err) < 1e-4 * max(1.0, abs(err))
+
+
+def _path_following_model():
+    """The 'walk' shape with a root path a path-following constraint meets in practice: a gentle curve the candidates
+    vary around by a few units (the plain synthetic model's root coefficients are noise of amplitude 100)."""
+    data = synthetic.make_walk_primitive(seed=0)
+    NB, D = 31, 79
+    mean = np.array(data["mean_spatial_vector"]).reshape(NB, D)
+    eig = np.array(data["eigen_vectors_spatial"]).reshape(40, NB, D)
+    x = np.linspace(0.0, 1.0, NB)
+    mean[:, 0], mean[:, 1], mean[:, 2] = 160.0 * x, 90.0 + 2.0 * np.sin(6.0 * x), 40.0 * np.sin(2.0 * x)
+    eig[:, :, :3] *= 0.03
+    data["mean_spatial_vector"] = mean.reshape(-1).tolist()
+    data["eigen_vectors_spatial"] = eig.reshape(40, -1).tolist()
+    return data
+
+
+def test_trajectory_constraint_on_the_root_path():
+    """TrajectoryConstraint.get_residual_vector / evaluate_motion_spline for the root joint (reference
+    trajectory_constraint.py:79-121) in one launch per candidate batch: the device's deterministic closest-point search
+    against its restatement (oracle closest_point_walk, 1e-9) and against the reference's search restated (L-BFGS-B from
+    the lower bound, 2e-3: the reference function itself raises under the installed NumPy -- PARITY UNPINNED); the spline
+    under both is pinned by the reference's own vectors (tests/test_oracle_golden.py)."""
+    from oracle import mg_oracle as orc
+    data = _path_following_model()
+    mp = _primitive(data)
+    op = orc.OraclePrimitive(data)
+    prim = mp._prim
+    rng = np.random.default_rng(8)
+    S = rng.standard_normal((37, 40))
+    # a trajectory in the neighbourhood of the candidates' root paths: through points of one candidate's own path
+    path0 = op.back_project_frames(S[0])[:, :3]
+    cps = path0[::26].copy()
+    cps[:, 0] += np.linspace(0.0, 6.0, len(cps))
+    cps[:, 2] -= np.linspace(0.0, 4.0, len(cps))
+    traj = _capi.Trajectory(prim, cps, granularity=1000)
+    err, res = prim.score_trajectory(traj, S, min_u=0.0, weight=1.5, residuals=True)
+    assert res.shape == (37, 156) and err.shape == (37,)
+    np.testing.assert_allclose(err, res.mean(axis=1), rtol=1e-13)
+    for b in (0, 5, 36):
+        path = op.back_project_frames(S[b])[:, :3]
+        min_u, walk = 0.0, []
+        for p in path:
+            pt, min_u = orc.closest_point_walk(cps, p, min_u)
+            walk.append(np.linalg.norm(p - pt))
+        np.testing.assert_allclose(res[b], 1.5 * np.array(walk), rtol=1e-9, atol=1e-9)
+        ref = 1.5 * orc.trajectory_residuals(path, cps, 0.0)                 # the reference's search, restated
+        assert np.abs(res[b] - ref).max() <= 2e-3 * max(1.0, ref.max()), np.abs(res[b] - ref).max()
+    # a later start on the trajectory, float32 latents, another time grid (every second frame)
+    err2 = prim.score_trajectory(traj, S.astype(np.float32), min_u=0.4)
+    path = op.back_project_frames(S[3].astype(np.float32).astype(np.float64))[:, :3]
+    np.testing.assert_allclose(err2[3], orc.trajectory_residuals(path, cps, 0.4).mean(), rtol=2e-3)
+    grid = prim.time_grid(np.arange(0.0, 156.0, 2.0))
+    e3, r3 = prim.score_trajectory(traj, S[:4], residuals=True, grid=grid)
+    assert r3.shape == (4, 78)
+    grid.close()
+    # global coordinates: every candidate aligned to a previous frame (root as aligning node) or to a start pose first
+    prev = op.back_project_frames(rng.standard_normal(40))[-1].copy()
+    prev[:3] = [30.0, 88.0, -15.0]
+    joints, animated = synthetic.make_skeleton()
+    al = _capi.Skeleton(joints, animated).alignment_to(prev, 0)
+    e_al, r_al = prim.score_trajectory(traj, S[:6], alignment={"joint": 0, "position": al["position"], "heading": al["heading"]}, residuals=True)
+    for b in range(6):
+        coeffs = orc.align_coeffs_to_previous_frame(op.back_project_spatial_coeffs(S[b]), prev, joints, animated, "Hips")
+        path = orc.spline_frames(op.knots, coeffs, op.canonical_time_function())[:, :3]
+        min_u, walk = 0.0, []
+        for p in path:
+            pt, min_u = orc.closest_point_walk(cps, p, min_u)
+            walk.append(np.linalg.norm(p - pt))
+        np.testing.assert_allclose(r_al[b], walk, rtol=1e-8, atol=1e-8)
+    from morphablegraphs_amd.candidate_scoring import alignment_from_start_pose
+    sp = {"position": [3.0, 2.0, 1.0], "orientation": [0.0, 25.0, 0.0]}
+    e_sp, r_sp = prim.score_trajectory(traj, S[:3], alignment=alignment_from_start_pose(sp), residuals=True)
+    for b in range(3):
+        coeffs = orc.align_coeffs_to_start_pose(op.back_project_spatial_coeffs(S[b]), {"position": [3.0, 2.0, 1.0], "orientation": [0.0, 25.0, 0.0]})
+        path = orc.spline_frames(op.knots, coeffs, op.canonical_time_function())[:, :3]
+        min_u, walk = 0.0, []
+        for p in path:
+            pt, min_u = orc.closest_point_walk(cps, p, min_u)
+            walk.append(np.linalg.norm(p - pt))
+        np.testing.assert_allclose(r_sp[b], walk, rtol=1e-8, atol=1e-8)
+    traj.close()
+
+
+def test_candidate_loop_with_a_trajectory_constraint():
+    """evaluate_samples_using_constraints / HipSampleFilter / the device-sampling step with a trajectory constraint next to
+    keyframe constraints (the path-following mix): errors add up per candidate before the first-minimum argmin; a
+    reference-shaped TrajectoryConstraint object is converted (control points unpadded, min_u = min_arc_length / full)."""
+    from oracle import mg_oracle as orc
+    from morphablegraphs_amd.candidate_scoring import sample_and_evaluate_on_device, clear_constraint_cache
+    data = _path_following_model()
+    mp = _primitive(data)
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(9)
+    S = rng.standard_normal((64, 40))
+    cps = op.back_project_frames(S[7])[::31, :3].copy()
+
+    class _Spline(object):                                  # CatmullRomSpline's attributes (catmull_rom_spline.py:47-71)
+        _catmullrom_basematrix = None
+        control_points = [list(cps[0])] + [list(p) for p in cps] + [list(cps[-1]), list(cps[-1])]
+
+    class _Trajectory(object):                              # TrajectoryConstraint's (trajectory_constraint.py:33-52)
+        constraint_type = "trajectory"
+        joint_name = "Hips"
+        spline = _Spline()
+        weight_factor = 0.7
+        granularity = 1000
+        full_arc_length = orc.catmull_rom_full_arc_length(cps)
+        min_arc_length = 0.1 * full_arc_length
+        is_collision_avoidance_constraint = False
+    keyframe = {"type": "position", "t": 155.0, "weight": 1.0, "target": [float(cps[-1][0]), None, float(cps[-1][2])]}
+    cons = [keyframe, _Trajectory()]
+    errors = HipSampleFilter.score_samples(mp, S, cons)
+    kf = op.keyframe_errors(S, [keyframe])
+    for b in (0, 7, 63):
+        tr = 0.7 * orc.trajectory_residuals(op.back_project_frames(S[b])[:, :3], cps, 0.1).mean()
+        assert abs(errors[b] - (kf[b] + tr)) <= 2e-3 * max(1.0, kf[b] + tr)
+    best, err = evaluate_samples_using_constraints(S, mp, cons)
+    assert np.array_equal(best, S[int(np.argmin(errors))]) and abs(err - errors.min()) < 1e-9
+    b2, e2 = sample_and_evaluate_on_device(mp, cons, 256, 11)
+    assert b2.shape == (40,) and np.isfinite(e2) and e2 <= np.median(errors)
+    _Trajectory.joint_name = "LeftHand"
+    _Trajectory.skeleton = type("_Sk", (), {"root": "Hips"})()
+    with pytest.raises(NotImplementedError):
+        HipSampleFilter.score_samples(mp, S, cons)
+    clear_constraint_cache()

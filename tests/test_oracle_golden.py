@@ -273,3 +273,28 @@ def test_time_model_fixture():
     np.random.seed(int(g["seed"]))
     np.testing.assert_allclose(prim.sample_low_dimensional_vector(len(g["S"])), g["S"], rtol=1e-12, atol=1e-12)
     np.testing.assert_array_equal(g["low_dimensional_parameters"], g["S"][0])      # the spline keeps the full vector
+
+
+def test_trajectory_spline_against_the_reference():
+    """The Catmull-Rom spline under a trajectory constraint: points at parameters and the arc length of the
+    granularity-1000 table, against vectors made by the reference's own ParameterizedSpline; and the two closest-point
+    searches (the reference's L-BFGS-B call restated, the device's grid walk restated) against each other."""
+    from conftest import load_golden
+    g = load_golden("trajectory_spline")
+    for ci in range(int(g["n_cases"])):
+        cps = g["control_points_%d" % ci]
+        for u, pt in zip(g["parameters_%d" % ci], g["points_%d" % ci]):
+            np.testing.assert_allclose(orc.catmull_rom_point(cps, u), pt, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(orc.catmull_rom_full_arc_length(cps), float(g["full_arc_length_%d" % ci]), rtol=1e-12)
+    cps = g["control_points_1"]
+    rng = np.random.default_rng(4)
+    # a path that follows the spline loosely, as a root trajectory under a path-following constraint does
+    us = np.linspace(0.02, 0.9, 40)
+    path = np.array([orc.catmull_rom_point(cps, u) for u in us]) + rng.normal(0, 3.0, (40, 3)) * [1, 0, 1]
+    min_u_a = min_u_b = 0.0
+    for p in path:
+        pa, ua = orc.closest_point_from(cps, p, min_u_a)
+        pb, ub = orc.closest_point_walk(cps, p, min_u_b)
+        da, db = np.linalg.norm(p - pa), np.linalg.norm(p - pb)
+        assert abs(da - db) < 2e-3 * max(1.0, da), (ua, ub, da, db)
+        min_u_a, min_u_b = ua, ub
