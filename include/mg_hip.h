@@ -313,6 +313,13 @@ int mg_time_grid_size(const mg_time_grid *grid);
 /* copies the grid's tables: i0 (T) int32, weights (T,4) float64, times (T) float64; any may be NULL */
 int mg_time_grid_get_tables(const mg_time_grid *grid, int32_t *i0, double *weights, double *times);
 
+/* Global positions of joints[0 .. n_out) in every row of a (n_frames, n_dim) float64 frame block on the device, by forward
+ * kinematics along each joint's chain: out_dev (n_frames, n_out, 3).  What map_motions_to_euclidean_space asks of
+ * skeleton.nodes[j].get_global_position(frame) once per sample, frame and joint (reference space_partitioning/features.py:
+ * 133-153, under construction/cluster_tree_builder.py:266-301).  PARITY UNPINNED (anim_utils' FK), as for the constraints. */
+int mg_joint_positions(mg_context *ctx, const mg_skeleton_desc *skeleton, const int32_t *joints, int32_t n_out,
+                       const double *frames_dev, int64_t n_frames, int32_t n_dim, double *out_dev);
+
 /* ---- trajectory constraints -------------------------------------------------------------------------
  * TrajectoryConstraint.evaluate_motion_spline / get_residual_vector for the ROOT joint (reference
  * constraints/spatial_constraints/trajectory_constraint.py:79-121): per time sample of `grid` (NULL = the canonical grid,

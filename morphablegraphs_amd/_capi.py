@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host",
-    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory",
+    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_joint_positions",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
@@ -214,6 +214,7 @@ def load_library(path=None):
         "mg_primitive_info2": [vp, C.POINTER(C.c_int32)],
         "mg_time_function_canonical": [vp, vp, i32, i64, i64, vp],
         "mg_trajectory_create": [vp, vp, i32, i32, C.POINTER(vp)],
+        "mg_joint_positions": [vp, vp, vp, i32, vp, i64, i32, vp],
         "mg_score_trajectory": [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, i32, vp],
         "mg_time_function_canonical_host": [vp, vp, i32, i64, i64, vp],
         "mg_primitive_get_precisions_cholesky": [vp, vp],
@@ -398,6 +399,23 @@ class Context(object):
         _check(self.lib.mg_profile_get_samples(self.handle, PROFILE_SLOTS.get(slot, slot), out.ctypes.data_as(C.c_void_p),
                                                int(capacity), C.byref(n)))
         return out[:n.value].copy()
+
+    def joint_positions(self, skeleton, joints, frames):
+        """(N, D) float64 frames -> (N, len(joints), 3) global joint positions by forward kinematics (mg_joint_positions);
+        joints: names or indices of `skeleton` (a Skeleton)."""
+        F = np.ascontiguousarray(frames, dtype=np.float64)
+        if F.ndim != 2:
+            raise ValueError("frames must be (n_frames, n_dim)")
+        idx = np.ascontiguousarray([skeleton.index(j) for j in joints], dtype=np.int32)
+        out = np.empty((F.shape[0], len(idx), 3), dtype=np.float64)
+        d_f, d_o = self.upload(F), self.malloc(max(out.nbytes, 8))
+        try:
+            d = skeleton.desc()
+            _check(self.lib.mg_joint_positions(self.handle, C.byref(d), idx.ctypes.data_as(C.c_void_p), len(idx), d_f.ptr, F.shape[0], F.shape[1], d_o.ptr))
+            return self.download(d_o, out.shape, np.float64)
+        finally:
+            d_f.free()
+            d_o.free()
 
     def argmin_first(self, values_dev, n, dtype=np.float32):
         idx, val = C.c_int64(), C.c_double()

@@ -2,7 +2,10 @@
 159-192, 293-301) on the HIP back end: drawing the training samples of a space partitioning, filtering them by
 likelihood, and back-projecting them to frames for the feature maps.  The reference scores and back-projects one
 sample at a time (`gmm.score([s])[0]`, `spline.evaluate(frame_idx)` per frame); here each method is one batched
-call.  Clustering itself (k-means / KD tree construction, sklearn) is offline tooling and stays where it is.
+call.  The Euclidean feature map of the feature trees (features.py:125-153: global positions of a set of joints in
+every frame of every sample, then sklearn's PCA keeping 95 % of the variance) gets its positions from one forward-kinematics
+launch (mg_joint_positions).  Clustering itself (k-means / KD tree construction, sklearn) is offline tooling and stays
+where it is.
 
 Method names and results are the reference's; `motion_primitive` is a HipMotionPrimitiveModelWrapper or a
 HipMotionStateGraphNode.  There is no CPU fallback.
@@ -74,7 +77,33 @@ class HipClusterTreeSampler(object):
         finally:
             grid.close()
 
-    # cluster_tree_builder.py:266-291, the latent-feature branch (the Euclidean-PCA branch needs anim_utils' FK)
-    def _extract_features(self, motion_primitive, data):
-        n_spatial = motion_primitive.get_n_spatial_components()
-        return np.asarray(data)[:, :n_spatial]
+    # cluster_tree_builder.py:266-291
+    def _extract_features(self, motion_primitive, data, feature_type="latent", skeleton=None, joint_names=None, step=1):
+        """The features a FeatureClusterTree is built on: the spatial latents themselves, or (feature_type "euclidean_pca",
+        the reference's FEATURE_TYPE_EUCLIDEAN_PCA) the PCA projection of every sample's joint point cloud over its frames.
+        skeleton: a _capi.Skeleton; joint_names: the reference passes END_EFFECTORS2 and step = 1."""
+        if feature_type != "euclidean_pca":
+            n_spatial = motion_primitive.get_n_spatial_components()
+            return np.asarray(data)[:, :n_spatial]
+        motions = self._back_project(motion_primitive, data)
+        return self.map_motions_to_euclidean_pca(motion_primitive, motions, skeleton, joint_names, step)[0]
+
+    # space_partitioning/features.py:133-153
+    def map_motions_to_euclidean_space(self, motion_primitive, motions, skeleton, joint_names, step=4):
+        """(n, F * len(joint_names) * 3): per sample the global positions of `joint_names` in its frames, flattened.  As
+        in the reference a frame whose index is not a multiple of `step` REPEATS the cloud of the last one that is (its
+        `sample.append(frame)` sits outside the `if idx % step == 0`), so the vector always has F entries."""
+        prim_obj = motion_primitive.motion_primitive if hasattr(motion_primitive, "motion_primitive") else motion_primitive
+        ctx = prim_obj._prim.ctx
+        motions = np.asarray(motions, dtype=np.float64)
+        n, F, D = motions.shape
+        keep = np.arange(0, F, int(step))
+        pos = ctx.joint_positions(skeleton, joint_names, motions[:, keep, :].reshape(-1, D)).reshape(n, len(keep), -1)
+        return pos[:, np.arange(F) // int(step), :].reshape(n, -1)
+
+    # space_partitioning/features.py:125-130
+    def map_motions_to_euclidean_pca(self, motion_primitive, motions, skeleton, joint_names, step=4):
+        from sklearn.decomposition import PCA
+        point_clouds = self.map_motions_to_euclidean_space(motion_primitive, motions, skeleton, joint_names, step)
+        pca = PCA(n_components=0.95)
+        return pca.fit_transform(point_clouds), pca

@@ -1608,6 +1608,43 @@ extern "C" int mg_step_frames_and_logp(mg_primitive *p, const void *lat, int dt,
     return rc;
 }
 
+// Global positions of a list of joints in every frame of a (N, D) float64 frame block already on the device:
+// out (N, n_out, 3).  The data-producing half of the feature maps under the cluster-tree builder (reference
+// space_partitioning/features.py:133-153; construction/cluster_tree_builder.py:266-301).
+extern "C" int mg_joint_positions(mg_context *ctx, const mg_skeleton_desc *sk, const int32_t *joints, int32_t n_out,
+                                  const double *frames_dev, int64_t n_frames, int32_t n_dim, double *out_dev) {
+    MG_REQUIRE(ctx && sk && joints && n_out > 0 && n_frames >= 0 && n_dim >= 3, "mg_joint_positions: bad arguments");
+    MG_REQUIRE(sk->n_joints > 0 && sk->parents && sk->offsets && sk->quat_channel && sk->parents[0] < 0, "mg_joint_positions: incomplete skeleton");
+    std::vector<double> table((size_t)n_out * (1 + 4 * MG_MAX_CHAIN), 0.0);
+    for (int o = 0; o < n_out; o++) {
+        MG_REQUIRE(joints[o] >= 0 && joints[o] < sk->n_joints, "mg_joint_positions: joint %d out of range", joints[o]);
+        std::vector<int> ch;
+        for (int j = joints[o]; j >= 0; j = sk->parents[j]) {
+            MG_REQUIRE(sk->parents[j] < j, "mg_joint_positions: joint %d: parents must precede their children", j);
+            ch.insert(ch.begin(), j);
+        }
+        const int m = (int)ch.size() - 1;
+        MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_joint_positions: chain of %d joints exceeds %d", m, MG_MAX_CHAIN);
+        double *rec = &table[(size_t)o * (1 + 4 * MG_MAX_CHAIN)];
+        rec[0] = m;
+        for (int k = 0; k < m; k++) {   // link k: rotation of chain joint k, offset of chain joint k + 1
+            const int qc = sk->quat_channel[ch[(size_t)k]];
+            MG_REQUIRE(qc < 0 || qc + 4 <= n_dim, "mg_joint_positions: quaternion channel %d outside n_dim = %d", qc, n_dim);
+            rec[1 + 4 * k] = qc;
+            for (int e = 0; e < 3; e++) rec[2 + 4 * k + e] = sk->offsets[(size_t)ch[(size_t)k + 1] * 3 + e];
+        }
+    }
+    if (n_frames == 0) return MG_OK;
+    MG_REQUIRE(frames_dev && out_dev, "mg_joint_positions: NULL pointer");
+    { int rc0 = mg_use_device(ctx); if (rc0 != MG_OK) return rc0; }
+    void *scr = nullptr;
+    int rc = mg_ctx_scratch(ctx, (int64_t)table.size() * 8, &scr);
+    if (rc != MG_OK) return rc;
+    MG_HIP_CHECK(hipMemcpyAsync(scr, table.data(), table.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // table is a stack-lifetime host buffer
+    return mg_launch_joint_positions(ctx, frames_dev, (const double *)scr, n_frames, n_dim, n_out, out_dev);
+}
+
 // ---------------------------------------------------------------------------------------
 // host-pointer convenience variants
 // ---------------------------------------------------------------------------------------

@@ -528,3 +528,47 @@ int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld,
     return MG_OK;
 }
 
+
+
+// Global joint positions of whole frames by forward kinematics: out[n][j] = position of joints[j] in frame n (the inner loop
+// of map_motions_to_euclidean_space, reference space_partitioning/features.py:133-153, where anim_utils'
+// skeleton.nodes[j].get_global_position(frame) runs once per sample, frame and joint; PARITY UNPINNED like every FK here).
+// table: per output joint 1 + 4 * MG_MAX_CHAIN doubles = chain length m, then per link (quaternion channel or -1, offset xyz).
+__global__ __launch_bounds__(256) void mg_joint_positions_kernel(const double *__restrict__ frames, const double *__restrict__ table, int64_t N,
+                                                                 int D, int J, double *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * J) return;
+    const int64_t n = idx / J;
+    const int j = (int)(idx - n * J);
+    const double *f = frames + n * D;
+    const double *rec = table + (size_t)j * (1 + 4 * MG_MAX_CHAIN);
+    const int m = (int)rec[0];
+    double p0 = f[0], p1 = f[1], p2 = f[2];
+    double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;
+    for (int k = 0; k < m; k++) {
+        const int ch = (int)rec[1 + 4 * k];
+        if (ch >= 0) {
+            double qw = f[ch], qx = f[ch + 1], qy = f[ch + 2], qz = f[ch + 3];
+            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+            const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+            const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+            aw = nw; ax = nx; ay = ny; az = nz;
+        }
+        const double ox = rec[2 + 4 * k], oy = rec[3 + 4 * k], oz = rec[4 + 4 * k];
+        const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
+        const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
+        p0 += ox + 2.0 * (aw * cx + dx);
+        p1 += oy + 2.0 * (aw * cy + dy);
+        p2 += oz + 2.0 * (aw * cz + dz);
+    }
+    out[idx * 3] = p0; out[idx * 3 + 1] = p1; out[idx * 3 + 2] = p2;
+}
+
+int mg_launch_joint_positions(mg_context *ctx, const double *frames, const double *table, int64_t N, int D, int J, double *out) {
+    const int64_t total = N * J;
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(mg_joint_positions_kernel, dim3(grid), dim3(256), 0, ctx->stream, frames, table, N, D, J, out);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}

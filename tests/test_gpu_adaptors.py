@@ -934,3 +934,45 @@ def test_candidate_loop_with_a_trajectory_constraint():
     with pytest.raises(NotImplementedError):
         HipSampleFilter.score_samples(mp, S, cons)
     clear_constraint_cache()
+
+
+def test_euclidean_feature_map_of_the_cluster_tree_builder():
+    """The feature map under FeatureClusterTree construction (reference cluster_tree_builder.py:266-301 ->
+    space_partitioning/features.py:125-153): every sample back-projected at the integer canonical frames, the global
+    positions of a set of joints in every frame (one forward-kinematics launch instead of n x F x J Python calls), PCA on
+    the host.  Positions against the rotation-matrix oracle (FK is anim_utils': PARITY UNPINNED); the `step` quirk of the
+    reference (frames between multiples of step repeat the last computed cloud) reproduced."""
+    from oracle import mg_oracle as orc
+    from morphablegraphs_amd.cluster_tree_sampling import HipClusterTreeSampler
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    w = HipMotionPrimitiveModelWrapper()
+    w._initialize_from_json(None, data)
+    op = orc.OraclePrimitive(data)
+    sampler = HipClusterTreeSampler(n_samples=24)
+    np.random.seed(3)
+    S = sampler.sample_data(w)
+    motions = sampler._back_project(w, S)
+    assert motions.shape == (24, 156, 79)
+    names = ["LeftUpLeg", "RightHand", "LeftHand_EndSite", "RightFoot", "Hips"]
+    for step in (1, 4):
+        clouds = sampler.map_motions_to_euclidean_space(w, motions, sk, names, step=step)
+        assert clouds.shape == (24, 156 * len(names) * 3)
+        for b, f in ((0, 0), (5, 77), (23, 155), (7, 6)):
+            src = (f // step) * step                                   # the frame whose cloud the reference appends at f
+            frame = orc.spline_frames(op.knots, op.back_project_spatial_coeffs(S[b][:40]), [float(src)])[0]
+            expect = np.concatenate([orc.joint_global_position(frame, joints, animated, nm) for nm in names])
+            got = clouds[b].reshape(156, -1)[f]
+            np.testing.assert_allclose(got, expect, rtol=1e-9, atol=1e-8, err_msg="step %d sample %d frame %d" % (step, b, f))
+    feats = sampler._extract_features(w, S, feature_type="euclidean_pca", skeleton=sk, joint_names=names, step=1)
+    assert feats.shape[0] == 24 and 1 <= feats.shape[1] <= 24 and np.isfinite(feats).all()
+    np.testing.assert_array_equal(sampler._extract_features(w, S), S[:, :40])
+    # the raw entry point: known answer for the identity pose (every quaternion (1, 0, 0, 0)): offsets add up along the chain
+    frame = np.zeros((1, 79))
+    frame[0, :3] = [1.0, 2.0, 3.0]
+    frame[0, 3::4] = 1.0
+    pos = w.motion_primitive._prim.ctx.joint_positions(sk, ["LeftHand_EndSite", "Hips"], frame)
+    chain = sk.chain("LeftHand_EndSite")
+    np.testing.assert_allclose(pos[0, 0], [1.0, 2.0, 3.0] + sk.offsets[chain[1:]].sum(axis=0), atol=1e-12)
+    np.testing.assert_allclose(pos[0, 1], [1.0, 2.0, 3.0], atol=1e-12)
