@@ -247,6 +247,9 @@ def run_walk(args, rank, local_rank, world):
             uid = rdv.all_gather(uid)[0]
             ctx.dist_init(rank, world, uid)
     prim = _capi.Primitive(ctx, data)
+    if args.frames_kernel:
+        ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, args.frames_kernel)
+    kernel_name = prim.step_plan(B)["kernel"]
 
     # synthetic latents: sklearn-style GMM draw on the host (RandomState(rank)), cast to f32, resident in HBM
     rs = np.random.RandomState(rank)
@@ -386,9 +389,9 @@ def run_walk(args, rank, local_rank, world):
             # E, mean, basis, mixture constants); stand-alone frames kernel: latents + frames (+ E, mean, basis)
             k_bytes = (B * (4 * L + 4 * F * D) + 4 * (NB * D * L + NB * D + 4 * F)) if args.two_launch else bytes_launch
             achieved = k_bytes / (avg_ms * 1e-3) / 1e9
-            traffic = pmc_traffic_bytes("mg_frames_ws_kernel") if B == 8192 else None
+            traffic = pmc_traffic_bytes(kernel_name) if B == 8192 else None
             result["roofline"] = {
-                "bound": "hbm", "kernel": "mg_frames_ws_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/r02_summary.json), not measured in this run" if traffic else None,
                 "avg_kernel_ms": avg_ms, "launches_timed": frames_n, "event_interval": interval,
@@ -638,6 +641,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-launch", action="store_true",
                     help="frames kernel and log-likelihood kernel as two launches instead of the fused step kernel")
+    ap.add_argument("--frames-kernel", type=int, choices=(0, 1, 2), default=0,
+                    help="MG_OPT_FRAMES_KERNEL: 0 = the library's choice, 1 = tile-major, 2 = chunk-stationary (A/B runs)")
     ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-interval", type=int, default=0,
                     help="every n-th launch of the timed region carries HIP start/stop events attached to the dispatch "

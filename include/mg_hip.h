@@ -203,10 +203,11 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_RING_SLOTS         2 = two LDS ring slots in the frames kernel even where three fit
  *   MG_OPT_CHUNK_WINDOW       n = at most n basis functions per time-chunk window (4 .. 11)
  *   MG_OPT_CHUNK_SAMPLES      n = at most n time samples per chunk (1 .. 48)
- *   MG_OPT_FRAMES_KERNEL      which LDS-staged frames kernel the MFMA path launches: 0 / 1 = tile-major (units of one
- *                             tile's consecutive chunks, rows shared by neighbouring chunks carried over), 2 =
- *                             chunk-stationary (a workgroup keeps one chunk's eigenvector window in registers;
- *                             MG_ERR_UNSUPPORTED where the window does not fit) -- identical results */
+ *   MG_OPT_FRAMES_KERNEL      which LDS-staged frames kernel the MFMA path launches: 0 = by batch size (chunk-stationary
+ *                             from three units per workgroup on), 1 = tile-major (units of one tile's consecutive chunks,
+ *                             rows shared by neighbouring chunks carried over), 2 = chunk-stationary (a workgroup keeps one
+ *                             chunk's eigenvector window in registers; MG_ERR_UNSUPPORTED where the window does not fit)
+ *                             -- identical results */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
@@ -441,6 +442,12 @@ int mg_argmin_first_dev(mg_context *ctx, const void *values_dev, int dtype, int6
  * latent batch, enqueued back to back on the context's stream. */
 int mg_step_frames_and_logp(mg_primitive *prim, const void *latents_dev, int latent_dtype,
                             int64_t n_samples, int64_t ld, float *frames_dev, float *logp_dev);
+
+/* What mg_step_frames_and_logp would launch for n_samples candidates, without launching (for profiles and logs):
+ * plan[0] = frames kernel (0 = the plain VALU kernel, 1 = tile-major LDS-staged, 2 = chunk-stationary LDS-staged),
+ * plan[1] = 1 when log p(x) is scored inside the frames kernel (one launch per step), 0 when it is a second launch,
+ * plan[2] = workgroups, plan[3] = LDS bytes per workgroup. */
+int mg_step_plan(const mg_primitive *prim, int64_t n_samples, int32_t plan[4]);
 
 /* evaluate_samples_using_constraints (reference motion_primitive_generator.py:230-261) in one call: score all
  * candidates against the set, first-minimum argmin, result on the host (no allocation, one synchronisation). */

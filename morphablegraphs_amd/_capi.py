@@ -19,7 +19,7 @@ MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
 MG_ALIGN_START_POSE = -1   # mg_alignment_desc.joint: the start-pose branch of the reference's alignment
 MG_OPT_FORCE_VALU_SCORE, MG_OPT_FORCE_VALU_SAMPLE, MG_OPT_RING_SLOTS, MG_OPT_CHUNK_WINDOW, MG_OPT_CHUNK_SAMPLES = 0, 1, 2, 3, 4
-MG_OPT_FRAMES_KERNEL = 5   # 0 / 1 = tile-major (default), 2 = chunk-stationary
+MG_OPT_FRAMES_KERNEL = 5   # 0 = by batch size, 1 = tile-major, 2 = chunk-stationary
 MG_OPT_COUNT = 6
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
     "mg_gmm_log_prob", "mg_gmm_sample", "mg_constraint_set_create", "mg_constraint_set_destroy",
-    "mg_score_constraints", "mg_argmin_first", "mg_argmin_first_dev", "mg_step_frames_and_logp",
+    "mg_score_constraints", "mg_argmin_first", "mg_argmin_first_dev", "mg_step_frames_and_logp", "mg_step_plan",
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
@@ -231,6 +231,7 @@ def load_library(path=None):
         "mg_argmin_first": [vp, vp, i32, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_argmin_first_dev": [vp, vp, i32, i64, vp],
         "mg_step_frames_and_logp": [vp, vp, i32, i64, i64, vp, vp],
+        "mg_step_plan": [vp, i64, C.POINTER(C.c_int32)],
         "mg_back_project_frames_host": [vp, vp, vp, i32, i64, i64, vp, i32],
         "mg_back_project_frames_f64_host": [vp, vp, vp, i32, i64, i64, vp],
         "mg_back_project_coeffs_host": [vp, vp, i32, i64, i64, vp, i32],
@@ -905,6 +906,14 @@ class Primitive(object):
         oc = MG_F64 if np.dtype(out_dtype) == np.float64 else MG_F32
         _check(self.lib.mg_score_constraints(self.handle, cset.handle, _dev_ptr(lat_dev), lc, int(n), int(ld),
                                              _dev_ptr(out_dev), oc))
+
+    FRAMES_KERNEL_NAMES = ("mg_frames_direct_kernel", "mg_frames_ws_kernel", "mg_frames_cs_kernel")
+
+    def step_plan(self, n):
+        """What step_frames_and_logp_dev launches for n candidates: dict(kernel, fused, workgroups, lds_bytes)."""
+        plan = (C.c_int32 * 4)()
+        _check(self.lib.mg_step_plan(self.handle, int(n), plan))
+        return dict(kernel=self.FRAMES_KERNEL_NAMES[plan[0]], fused=bool(plan[1]), workgroups=int(plan[2]), lds_bytes=int(plan[3]))
 
     def step_frames_and_logp_dev(self, lat_dev, lat_dtype, n, ld, frames_dev, logp_dev):
         code = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32

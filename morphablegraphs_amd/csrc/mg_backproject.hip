@@ -908,8 +908,7 @@ __device__ __forceinline__ void mg_cs_produce(const float (&ef)[NT][KK], const f
     }
 }
 template <int KK, int NT>
-__device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const float2 *ep, const float *mean32, float *lds_mean,
-                                                     const mg_chunk &ck, int first, int step, int lane) {
+__device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const float2 *ep, const mg_chunk &ck, int first, int step, int lane) {
 #pragma unroll
     for (int i = 0; i < NT; i++) {
         const int t = first + step * i;
@@ -921,7 +920,6 @@ __device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const 
             ef[i][2 * q2] = v.x;
             ef[i][2 * q2 + 1] = v.y;
         }
-        if (t < ck.ntiles && lane < 16) lds_mean[t * 16 + lane] = mean32[(size_t)(ck.rt0 + t) * 16 + lane];
     }
 }
 
@@ -969,13 +967,13 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     const int cl = lane & 15, g = lane >> 4;
     const int nt_p = ck.ntiles < NRP * TPWP ? ck.ntiles : NRP * TPWP;   // tiles [0, nt_p): row producers; [nt_p, ntiles): sweep waves
     const float2 *ep = (const float2 *)Epack;
+    for (int e = tid; e < ck.ntiles * 16; e += MG_CS_BLOCK) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // mean' of the window's rows
 
     if (wave >= MG_CS_NPW) {
-        // ================= sweep waves: two candidates each + TPWS row tiles of the NEXT unit, produced at half time =================
+        // ================= sweep waves: two candidates each; the four oldest also produce TPWS row tiles of the NEXT unit =================
         const int cj = wave - MG_CS_NPW;                  // candidates cj and cj + 8
         float ef[TPWS][KK];
         const bool producing = cj < MG_CS_NSP;
-        mg_cs_load_fragments<KK, TPWS>(ef, ep, mean32, lds_mean, ck, producing ? nt_p + cj : ck.ntiles, MG_CS_NSP, lane);
         const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
         const int gl = nql + 1;                           // + the root lane
         const int rpi = 64 / gl;                          // samples per wave instruction
@@ -994,9 +992,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         const float4 *lds_w = (const float4 *)tb_base;
         const int *lds_mo = (const int *)(lds_w + max_nt);
         const int col0 = ck.imin * Dp - ck.rt0 * 16;
-        const int ntrips = (ck.nT + 2 * rpi - 1) / (2 * rpi);
-        const int f_half = ((ntrips + 1) / 2) * 2 * rpi;   // first sample of the second half of a unit's trips
         __syncthreads();   // counters, tables, mean' window
+        mg_cs_load_fragments<KK, TPWS>(ef, ep, ck, producing ? nt_p + cj : ck.ntiles, MG_CS_NSP, lane);
         MG_STAMP_DECL
         if (n_units > 0 && producing) {   // this wave's tiles of the first unit
             mg_cs_wait_latents(prog, 1);
@@ -1094,34 +1091,31 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             };
             const bool mine = cj < ncand && !MG_DBG(2);
             if (mine) {
-                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, 0, f_half);
-                else sweep_rows(std::integral_constant<int, 0>{}, 0, f_half);
+                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, 0, ck.nT);
+                else sweep_rows(std::integral_constant<int, 0>{}, 0, ck.nT);
             }
-            MG_STAMP(2);
+            MG_STAMP(4);
+            mg_publish(prog + MG_CS_PROG_SWEPT, cj, lane, u + 1);
+            MG_STAMP(5);
             if (u + 1 < n_units && producing) {
-                // half time: this wave's row tiles of the next unit, into the slot the unit before this one was swept from
+                // the producing sweep waves are the four oldest, which finish a unit first: its row tiles of the NEXT unit go
+                // into the slot the unit before this one was swept from (every sweep wave is past it by now, as a rule)
                 mg_cs_wait_swept(prog, u);
                 mg_cs_wait_latents(prog, u + 2);
                 MG_STAMP(3);
                 mg_cs_produce<KK, TPWS>(ef, lds_latb + ((u + 1) & 1) * KK * 64, lds_mean, (float *)(smem + (size_t)((u + 1) & 1) * buf_bytes), stride,
                                         nt_p + cj, MG_CS_NSP, ck.ntiles, lane, cl, g);
                 mg_publish(prog, wave, lane, u + 2);
+                MG_STAMP(2);
             }
-            if (mine) {
-                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, f_half, ck.nT);
-                else sweep_rows(std::integral_constant<int, 0>{}, f_half, ck.nT);
-            }
-            MG_STAMP(4);
-            mg_publish(prog + MG_CS_PROG_SWEPT, cj, lane, u + 1);
-            MG_STAMP(5);
         }
         MG_STAMP_DUMP;
     } else if (wave != 0) {
         // ================= row producers (waves 1..3): TPWP row tiles each, the fragments in registers =================
         const int pw = wave - 1;
         float ef[TPWP][KK];
-        mg_cs_load_fragments<KK, TPWP>(ef, ep, mean32, lds_mean, ck, pw, NRP, lane);
         __syncthreads();   // counters, tables, mean' window
+        mg_cs_load_fragments<KK, TPWP>(ef, ep, ck, pw, NRP, lane);   // in tile order: the first unit's MFMAs start as its first fragments land
         MG_STAMP_DECL
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
@@ -1205,6 +1199,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 mg_publish(prog, MG_CS_PROG_LAT, lane, u + 1);
             }
             load_latents(s64next, u + 1);   // a unit ahead
+            if (MG_DBG(1024)) { MG_STAMP(3); mg_publish(prog, wave, lane, u + 1); MG_STAMP(4); continue; }   // ablation: no root stage
             // up to 3 root tiles (rows rr = i*nroot + d), chains interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
             f64x4 racc[3];
 #pragma unroll
@@ -1445,8 +1440,31 @@ static int mg_fused_gmm_lds(const mg_primitive *p) { return 4 * p->K * 16 * 8; }
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t grid = std::min<int64_t>(n_tiles * g->n_chunks, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
-    return g->mfma_ok && p->d_gPpack != nullptr && p->K <= 16 && p->KK <= MG_FUSE_MAX_KK && p->Lg == p->L &&   // fused: the mixture spans exactly the spatial latents g->lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 &&
+    // fused: the mixture spans exactly the spatial latents
+    return g->mfma_ok && p->d_gPpack != nullptr && p->K <= 16 && p->KK <= MG_FUSE_MAX_KK && p->Lg == p->L &&
+           g->lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 &&
            (n_tiles + grid - 1) / grid <= 4;   // the fused scoring handles at most four 16-candidate tiles per workgroup
+}
+
+// Which of the two LDS-staged kernels a launch over B candidates uses (1 = tile-major, 2 = chunk-stationary; -1 = the
+// chunk-stationary one was asked for by option and does not cover the shape): the chunk-stationary one once every workgroup
+// gets at least three units out of the one-time load of its chunk's eigenvector window (B = 8192, 'walk', same box and
+// buffer, three boxes: 81.0 / 81.0 / 80.9 us per step against 83.3 / 83.7 / 82.9 for the tile-major kernel), the
+// tile-major one for smaller batches.
+int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused) {
+    const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
+    const int64_t units = n_tiles * g->n_chunks;
+    const int64_t grid0 = std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
+    const int want = p->ctx->opt[MG_OPT_FRAMES_KERNEL];
+    bool cs = g->cs_ok && grid0 >= g->n_chunks && (!fused || g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024);
+    if (want == 2 && !cs) return -1;
+    if (want == 1) cs = false;
+    else if (want == 0) cs = cs && units >= 3 * grid0;
+    return cs ? 2 : 1;
+}
+
+int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused) {
+    return (which == 2 ? g->cs_lds_bytes : g->lds_bytes) + (fused ? mg_fused_gmm_lds(p) : 0);
 }
 
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
@@ -1468,17 +1486,13 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     a.max_tiles = g->max_tiles;
     const bool lf = (ldt == MG_F64);
     const int grid0 = (int)std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
-    // which of the two LDS-staged kernels: the tile-major one unless MG_OPT_FRAMES_KERNEL asks for the chunk-stationary
-    // one (measured at B = 8192, 'walk', same box and buffer: 86.2 vs 87.3 us -- its producers are four times faster, but
-    // its longer prologue and the coupling of its sweep waves give the gain back; see the kernel's header)
-    const int want = p->ctx->opt[MG_OPT_FRAMES_KERNEL];
-    bool cs = g->cs_ok && grid0 >= g->n_chunks && (logp == nullptr || g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024);
-    if (want == 2 && !cs) {
+    const int which = mg_frames_kernel_choice(p, g, B, logp != nullptr);
+    if (which < 0) {
         mg_set_error("mg_back_project_frames: the chunk-stationary kernel does not cover this shape (window of %d row tiles, %d bytes of LDS)",
                      g->max_tiles, g->cs_lds_bytes);
         return MG_ERR_UNSUPPORTED;
     }
-    if (want != 2) cs = false;
+    const bool cs = which == 2;
     // nbuf ring slots (image + root outputs + tables), the float64 root image, the progress counters
     const int buf_bytes = (MG_NCAND * g->stride * 4 + 255) / 256 * 256;
     int lds = g->nbuf * (buf_bytes + MG_RO_BYTES_N(g->max_nt) + MG_TB_BYTES_N(g->max_nt)) + MG_NCAND * (g->max_wi * p->nroot + 1) * 8 + 128;

@@ -1608,6 +1608,25 @@ extern "C" int mg_step_frames_and_logp(mg_primitive *p, const void *lat, int dt,
     return rc;
 }
 
+extern "C" int mg_step_plan(const mg_primitive *p, int64_t B, int32_t *plan) {
+    MG_REQUIRE(p && plan && B >= 0, "mg_step_plan: bad arguments");
+    const mg_time_grid *g = p->canonical;
+    plan[0] = plan[1] = plan[2] = plan[3] = 0;
+    if (B == 0 || g->T == 0) return MG_OK;
+    const bool fused = B >= 8 && mg_frames_can_fuse_gmm(p, g, B);
+    if (!(g->mfma_ok && B >= 8)) {
+        plan[2] = (int32_t)std::min<int64_t>((B * (int64_t)g->T * p->D + 255) / 256, (int64_t)p->ctx->n_cu * 32);
+        return MG_OK;
+    }
+    const int which = mg_frames_kernel_choice(p, g, B, fused);
+    MG_REQUIRE(which > 0, "mg_step_plan: the chunk-stationary kernel does not cover this shape");
+    plan[0] = which;
+    plan[1] = fused ? 1 : 0;
+    plan[2] = (int32_t)std::min<int64_t>((B + MG_NCAND - 1) / MG_NCAND * g->n_chunks, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
+    plan[3] = mg_frames_lds_bytes(p, g, which, fused);
+    return MG_OK;
+}
+
 // Global positions of a list of joints in every frame of a (N, D) float64 frame block already on the device:
 // out (N, n_out, 3).  The data-producing half of the feature maps under the cluster-tree builder (reference
 // space_partitioning/features.py:133-153; construction/cluster_tree_builder.py:266-301).

@@ -185,6 +185,8 @@ struct mg_constraint_set {
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
                           int prof_slot = -1, int prof_slot2 = -1);   // prof_slot >= 0: the launch carries its own timing events
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B);
+int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused);
+int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused);
 int mg_cs_max_tiles(int KK);   // row tiles of a chunk window the chunk-stationary kernel can hold in registers
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);

@@ -2,7 +2,7 @@
 """Per-wave phase timers of the persistent frames kernel (diagnostic build only):
     make -C morphablegraphs_amd/csrc libmg_hip_dbg.so && python3 tools/stamp_run.py [flags ...]
 Each argument is a MG_DEBUG_FLAGS value (16 is added); STAMP_B = batch, FUSED=0 for the stand-alone frames kernel,
-PLAIN=1 for an unplaced output buffer."""
+PLAIN=1 for an unplaced output buffer, KERNEL=2 for the chunk-stationary kernel."""
 import os
 import sys
 
@@ -14,6 +14,7 @@ from morphablegraphs_amd import _capi, synthetic   # noqa: E402
 
 lib = _capi.load_library(os.path.join(ROOT, "morphablegraphs_amd", "csrc", "libmg_hip_dbg.so"))
 ctx = _capi.Context(0, lib=lib)
+ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, int(os.environ.get("KERNEL", "0")))   # 2: the chunk-stationary kernel
 prim = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
 B = int(os.environ.get("STAMP_B", "8192"))
 S = ctx.upload(np.random.default_rng(0).standard_normal((B, 40)).astype(np.float32))
