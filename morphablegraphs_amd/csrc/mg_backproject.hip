@@ -32,6 +32,9 @@ struct mg_frames_args {
                      // 128 = no chunk rotation, 256 = no tile-round rotation, 512 = row producers without E' loads, 1024 = wave 0 idle
     int32_t nbuf;    // LDS ring depth (2 or 3)
     int32_t max_tiles;   // row tiles of the widest chunk window (chunk-stationary kernel: sizes its mean' window in LDS)
+    int32_t cs_magic, cs_per, cs_rem;   // chunk-stationary kernel: workgroup w -> (chunk, block) without a division: q = (w * cs_magic) >> 20;
+                                        // cs_per tiles per workgroup of a chunk, the first cs_rem one more
+    mg_chunk ck[MG_ARG_CHUNKS];   // the first chunks' descriptors: read with the other arguments instead of a dependent trip to global memory
 };
 
 template <bool F64>
@@ -49,6 +52,15 @@ __device__ __forceinline__ double mg_load_lat(const void *lat, int64_t idx) {
 // the producers' loads behind it in vmcnt order and distort what is being measured).
 __device__ unsigned long long mg_dbg_wg[1024][2];      // [workgroup][begin, end] in 100 MHz ticks (first sweep wave)
 __device__ unsigned long long mg_dbg_stamps[16][10];   // [wave][phase] of workgroup 0; [8] = shader cycles, [9] = 100 MHz ticks of the wave
+__device__ unsigned long long mg_dbg_units[16][32][2];  // chunk-stationary kernel, workgroup 0: [wave][unit][work begins, work ends] in 100 MHz ticks
+#define MG_UNIT_STAMP(u_, k_)                                                                                          \
+    do {                                                                                                               \
+        if ((a.debug & 16) && blockIdx.x == 0 && lane == 0 && (u_) < 32) mg_dbg_units[wave][u_][k_] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define MG_SUB_STAMP(row_, u_, k_)                                                                                     \
+    do {                                                                                                               \
+        if ((a.debug & 16) && blockIdx.x == 0 && lane == 0 && (u_) < 32) mg_dbg_units[row_][u_][k_] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #define MG_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime(); \
     const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
 #define MG_STAMP(ph)                                                     \
@@ -86,8 +98,7 @@ extern "C" int mg_debug_dump_stamps(void) {
     static unsigned long long wg[1024][2];
     if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(mg_dbg_wg), sizeof(wg)) != hipSuccess) return -1;
     unsigned long long t0 = ~0ull;
-    int n = 0;
-    for (int i = 0; i < 1024; i++) if (wg[i][1]) { n++; if (wg[i][0] < t0) t0 = wg[i][0]; }
+    for (int i = 0; i < 1024; i++) if (wg[i][1] && wg[i][0] < t0) t0 = wg[i][0];
     printf("sweep wave 4 of every workgroup, us after the first one began: begin / end\n");
     for (int i = 0; i < 1024; i++) {
         if (!wg[i][1]) continue;
@@ -95,6 +106,20 @@ extern "C" int mg_debug_dump_stamps(void) {
         printf(" %5.1f/%5.1f", (wg[i][0] - t0) / 100.0, (wg[i][1] - t0) / 100.0);
     }
     printf("\n");
+    static unsigned long long un[16][32][2];
+    if (hipMemcpyFromSymbol(un, HIP_SYMBOL(mg_dbg_units), sizeof(un)) != hipSuccess) return -1;
+    unsigned long long u0 = ~0ull;
+    for (int w = 0; w < 16; w++) if (un[w][0][0] && un[w][0][0] < u0) u0 = un[w][0][0];   // row 14: kernel entry / barrier passed (wave 0)
+    if (u0 != ~0ull) {
+        printf("chunk-stationary kernel, workgroup 0: per unit, us after the first stamp: work begins / ends\n");
+        for (int w = 0; w < 16; w++) {   // rows 12..15: sub-phases of wave 0 (latents staged / root chains done, root image written / taps done)
+            printf("wave %2d:", w);
+            for (int u = 0; u < 32 && (w >= 14 ? u < 4 : un[w][u][1] != 0); u++) printf(" %5.1f/%5.1f", (un[w][u][0] - u0) / 100.0, (un[w][u][1] - u0) / 100.0);
+            printf("\n");
+        }
+    }
+    static unsigned long long zero[16][32][2];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_units), zero, sizeof(zero));
     return 0;
 }
 #else
@@ -102,6 +127,8 @@ extern "C" int mg_debug_dump_stamps(void) {
 #define MG_STAMP_DECL
 #define MG_STAMP(ph) do { } while (0)
 #define MG_STAMP_DUMP do { } while (0)
+#define MG_UNIT_STAMP(u_, k_) do { } while (0)
+#define MG_SUB_STAMP(row_, u_, k_) do { } while (0)
 #endif
 
 // -----------------------------------------------------------------------------------------
@@ -156,6 +183,9 @@ __device__ __forceinline__ void mg_publish(mg_lds_int *prog, int wave, int lane,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *(volatile mg_lds_int *)&prog[wave] = done;
 }
+// Workgroup barrier that orders LDS traffic only: vector-memory loads issued before it stay in flight across it
+// (__syncthreads() carries a fence that drains them).
+__device__ __forceinline__ void mg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void mg_wait_producers(const mg_lds_int *prog, int target) {   // waves 0..3
     for (;;) {
         const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
@@ -823,11 +853,14 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
 // -----------------------------------------------------------------------------------------
 #define MG_CS_NPW 4      // producer waves (0: root + latents, 1-3: rows)
 #define MG_CS_NCW 8      // sweep waves, two candidates each; they also produce a few row tiles per unit
-#define MG_CS_NSP 4      // the first (oldest, fastest) sweep waves produce row tiles as well; the others only sweep
+#ifndef MG_CS_NSP
+#define MG_CS_NSP 4      // how many of the sweep waves (the first ones, which sweep fastest) produce row tiles as well
+#endif
 #define MG_CS_BLOCK (64 * (MG_CS_NPW + MG_CS_NCW))
 template <int KK> struct mg_cs_cfg {
     static constexpr int TPWP = 120 / KK < 17 ? 120 / KK : 17;   // row tiles a row producer keeps in registers (TPWP * KK VGPRs)
-    static constexpr int TPWS = 40 / KK < 5 ? (40 / KK > 0 ? 40 / KK : 1) : 5;   // row tiles a producing sweep wave keeps in registers
+    static constexpr int TPWS_REGS = 160 / MG_CS_NSP;                            // VGPRs a producing sweep wave spends on fragments
+    static constexpr int TPWS = TPWS_REGS / KK < 5 ? (TPWS_REGS / KK > 0 ? TPWS_REGS / KK : 1) : 5;   // row tiles it keeps in registers
     static constexpr int MAX_TILES = (MG_CS_NPW - 1) * TPWP + MG_CS_NSP * TPWS;
 };
 int mg_cs_max_tiles(int KK) {
@@ -845,11 +878,15 @@ int mg_cs_max_tiles(int KK) {
 #define MG_CS_PROG_SWEPT 16
 #define MG_CS_PROG_GMM 32
 #define MG_CS_PROG_INTS 64
-__device__ __forceinline__ void mg_cs_wait_produced(const mg_lds_int *prog, int target) {   // the eight producing waves
+__device__ __forceinline__ void mg_cs_wait_produced(const mg_lds_int *prog, int target) {   // the producing waves: 0 .. 3 + MG_CS_NSP
     for (;;) {
         const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
         const i32x4 x = *(const volatile mg_lds_i32x4 *)(prog + 4);
-        const int m = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(x[0], x[1]), min(x[2], x[3])));
+        int m = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(x[0], x[1]), min(x[2], x[3])));
+        if (MG_CS_NSP > 4) {
+            const i32x4 y = *(const volatile mg_lds_i32x4 *)(prog + 8);
+            m = min(m, min(min(y[0], y[1]), min(y[2], y[3])));
+        }
         if (__builtin_amdgcn_readfirstlane(m) >= target) break;
         __builtin_amdgcn_s_sleep(1);
     }
@@ -944,6 +981,13 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave == 0) MG_SUB_STAMP(14, 0, 0);
+    // Kernel arguments: left alone, the compiler fetches each where a role first uses it -- a dependent trip to memory per
+    // 64-byte line of the argument block (wave 0 alone made eight in a row before it had issued its loads, 4.8 us after entry).
+    // Asking for all of them here makes that one trip; the later uses hit the scalar cache.
+    asm volatile("" ::"s"(Epack), "s"(mean32), "s"(Erpack), "s"(meanroot), "s"(lat), "s"(i0tab), "s"(w32), "s"(wtap), "s"(out), "s"(gPpack),
+                 "s"(gmP), "s"(gcst), "s"(logp), "s"(a.B), "s"(a.ld), "s"(a.T), "s"(a.L), "s"(a.n_chunks), "s"(a.stride), "s"(a.max_tiles),
+                 "s"(a.ck[1].t0), "s"(a.ck[3].t0), "s"(a.ck[5].t0), "s"(a.ck[7].t0), "s"(gK), "s"(gJT), "s"(buf_bytes));
     const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
     const int root_stride = a.max_wi * nroot + 1;
     const int max_nt = a.max_nt;
@@ -953,27 +997,50 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     unsigned char *rs_base = tb_base + TB_BYTES;                       // float64 root image (wave 0 only)
     float *lds_mean = (float *)(rs_base + (size_t)MG_NCAND * root_stride * 8);   // mean' of the window's rows [max_tiles * 16]
     double *lds_rwt = (double *)((unsigned char *)lds_mean + (size_t)a.max_tiles * 64);   // the chunk's banded tap weights [FT * KS][64]
-    float *lds_latb = (float *)(lds_rwt + MG_TAP_FT * MG_TAP_KS * 64);                   // latent tiles as MFMA B fragments [2][KK][64]
+    double *lds_rmean = lds_rwt + MG_TAP_FT * MG_TAP_KS * 64;                            // mean of the root rows as the root chains' C-in [3][4][4] (wave 0)
+    float *lds_latb = (float *)(lds_rmean + 64);                                         // latent tiles as MFMA B fragments [2][KK][64]
     mg_lds_int *prog = (mg_lds_int *)(lds_latb + 2 * KK * 64);                           // MG_CS_PROG_INTS counters, then the mixture's buffers
-    if (tid < MG_CS_PROG_INTS) prog[tid] = (tid == MG_CS_PROG_GMM + 26 || tid == MG_CS_PROG_GMM + 27) ? 0x7fffffff : 0;
+    if (tid < MG_CS_PROG_INTS)   // never-waited-for entries: the sweep waves that produce nothing, the padding of the mixture's hand-off
+        prog[tid] = ((tid >= MG_CS_NPW + MG_CS_NSP && tid < MG_CS_NPW + MG_CS_NCW) || tid == MG_CS_PROG_GMM + 26 || tid == MG_CS_PROG_GMM + 27) ? 0x7fffffff : 0;
 
-    // workgroup w: chunk w mod n_chunks; the Q workgroups of a chunk share the tiles out in consecutive blocks
+    // workgroup w: chunk w mod n_chunks; the gridDim / n_chunks workgroups of a chunk share the tiles out in consecutive blocks
+    // (the grid is a multiple of n_chunks; the quotient by multiplication, exact for w * n_chunks < 2^20)
     const int n_chunks = a.n_chunks;
-    const int c = (int)(blockIdx.x % (unsigned)n_chunks), q = (int)(blockIdx.x / (unsigned)n_chunks);
-    const int Q = ((int)gridDim.x - 1 - c) / n_chunks + 1;
-    const int t_begin = (int)((int64_t)q * a.n_tiles / Q), t_end = (int)((int64_t)(q + 1) * a.n_tiles / Q);
-    const int n_units = t_end - t_begin;
-    const mg_chunk ck = chunks[c];
+    const int q = (int)(((unsigned)blockIdx.x * (unsigned)a.cs_magic) >> 20), c = (int)blockIdx.x - q * n_chunks;
+    const int t_begin = q * a.cs_per + (q < a.cs_rem ? q : a.cs_rem);   // the first cs_rem workgroups of a chunk take one tile more
+    const int n_units = a.cs_per + (q < a.cs_rem ? 1 : 0);
+    const mg_chunk ck = a.ck[c];   // n_chunks <= MG_ARG_CHUNKS where this kernel is launched
     const int cl = lane & 15, g = lane >> 4;
     const int nt_p = ck.ntiles < NRP * TPWP ? ck.ntiles : NRP * TPWP;   // tiles [0, nt_p): row producers; [nt_p, ntiles): sweep waves
     const float2 *ep = (const float2 *)Epack;
-    for (int e = tid; e < ck.ntiles * 16; e += MG_CS_BLOCK) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // mean' of the window's rows
-
+    // Start-up: every role issues ALL its one-time loads first (mean' of the window's rows, then the role's fragments and
+    // tables), writes what the others need to LDS and meets them at a barrier that does not drain vector memory, so the
+    // fragment loads are still in flight behind it and nothing waits for more than it uses.
+    // Start-up order on the CU's one path to memory, which serves requests in the order they were issued: first what the
+    // first unit's root stage waits for (wave 0: latents, root fragments, tables -- 63 requests) and mean' of the window's rows
+    // (the sweep waves that produce nothing), THEN the 130 KB of row fragments.  Barrier A separates the two; barrier B follows the
+    // LDS writes.  Neither drains vector memory, so the fragments land while the first root stage is already running.
+    constexpr int MEAN_FIRST = MG_CS_NSP < MG_CS_NCW ? 64 * (MG_CS_NPW + MG_CS_NSP) : 64;   // (every sweep wave produces: all but wave 0 copy)
+    constexpr int MEAN_NTH = MG_CS_BLOCK - MEAN_FIRST;
+    const int n_mean = ck.ntiles * 16, e0 = tid - MEAN_FIRST;
+    float mv[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) mv[i] = (e0 >= 0 && e0 + i * MEAN_NTH < n_mean) ? mean32[(size_t)ck.rt0 * 16 + e0 + i * MEAN_NTH] : 0.f;
+    auto store_mean = [&]() {
+        if (e0 < 0) return;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            if (e0 + i * MEAN_NTH < n_mean) lds_mean[e0 + i * MEAN_NTH] = mv[i];
+        for (int e = e0 + 6 * MEAN_NTH; e < n_mean; e += MEAN_NTH) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // (windows beyond 6 * MEAN_NTH rows)
+    };
     if (wave >= MG_CS_NPW) {
         // ================= sweep waves: two candidates each; the four oldest also produce TPWS row tiles of the NEXT unit =================
         const int cj = wave - MG_CS_NPW;                  // candidates cj and cj + 8
         float ef[TPWS][KK];
         const bool producing = cj < MG_CS_NSP;
+        mg_lds_barrier();   // A
+        mg_cs_load_fragments<KK, TPWS>(ef, ep, ck, producing ? nt_p + cj : ck.ntiles, MG_CS_NSP, lane);   // in flight across barrier B
+        store_mean();
         const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
         const int gl = nql + 1;                           // + the root lane
         const int rpi = 64 / gl;                          // samples per wave instruction
@@ -992,8 +1059,9 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         const float4 *lds_w = (const float4 *)tb_base;
         const int *lds_mo = (const int *)(lds_w + max_nt);
         const int col0 = ck.imin * Dp - ck.rt0 * 16;
-        __syncthreads();   // counters, tables, mean' window
-        mg_cs_load_fragments<KK, TPWS>(ef, ep, ck, producing ? nt_p + cj : ck.ntiles, MG_CS_NSP, lane);
+        if (wave == 8) MG_SUB_STAMP(15, 2, 0);
+        if (wave == 4) MG_SUB_STAMP(15, 2, 1);
+        mg_lds_barrier();   // counters, tables, mean' window
         MG_STAMP_DECL
         if (n_units > 0 && producing) {   // this wave's tiles of the first unit
             mg_cs_wait_latents(prog, 1);
@@ -1006,6 +1074,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             const int ncand = (int)((a.B - b0) < MG_NCAND ? (a.B - b0) : MG_NCAND);
             mg_cs_wait_produced(prog, u + 1);
             MG_STAMP(1);
+            MG_UNIT_STAMP(u, 0);
             const int slot = u & 1;
             const unsigned char *img = smem + (size_t)slot * buf_bytes;
             const float *lds_ro = (const float *)(ro_base + (size_t)slot * RO_BYTES);
@@ -1095,6 +1164,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 else sweep_rows(std::integral_constant<int, 0>{}, 0, ck.nT);
             }
             MG_STAMP(4);
+            MG_UNIT_STAMP(u, 1);
             mg_publish(prog + MG_CS_PROG_SWEPT, cj, lane, u + 1);
             MG_STAMP(5);
             if (u + 1 < n_units && producing) {
@@ -1114,66 +1184,43 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         // ================= row producers (waves 1..3): TPWP row tiles each, the fragments in registers =================
         const int pw = wave - 1;
         float ef[TPWP][KK];
-        __syncthreads();   // counters, tables, mean' window
+        if (MG_CS_NSP == MG_CS_NCW) store_mean();
+        mg_lds_barrier();   // A
+        MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 0);
         mg_cs_load_fragments<KK, TPWP>(ef, ep, ck, pw, NRP, lane);   // in tile order: the first unit's MFMAs start as its first fragments land
+        if (MG_DBG(32)) {   // when do the fragments land?
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 1);
+        }
+        store_mean();
+        mg_lds_barrier();   // B: counters, tables, mean' window
         MG_STAMP_DECL
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
             if (u >= 2) mg_cs_wait_swept(prog, u - 1);   // the slot's previous unit has been swept
             mg_cs_wait_latents(prog, u + 1);
             MG_STAMP(5);
+            MG_UNIT_STAMP(u, 0);
             if (!MG_DBG(1))
                 mg_cs_produce<KK, TPWP>(ef, lds_latb + (u & 1) * KK * 64, lds_mean, (float *)(smem + (size_t)(u & 1) * buf_bytes), stride, pw, NRP, nt_p,
                                         lane, cl, g);
             MG_STAMP(2);
+            MG_UNIT_STAMP(u, 1);
             mg_publish(prog, wave, lane, u + 1);
             MG_STAMP(4);
+            if (MG_DBG(2048)) {   // experiment: what would streaming five more row tiles' fragments per unit from L2 cost?
+                for (int i = 0; i < 5; i++) {
+                    const int tc = min(nt_p + pw * 5 + i, ck.ntiles - 1);
+                    const float2 *pp = ep + ((size_t)(ck.rt0 + tc) * (KK / 2)) * 64 + lane;
+#pragma unroll
+                    for (int q2 = 0; q2 < KK / 2; q2++) { const float2 v = pp[q2 * 64]; asm volatile("" ::"v"(v.x), "v"(v.y)); }
+                }
+            }
         }
         MG_STAMP_DUMP;
     } else {
         // ================= wave 0: the chunk's tables (once); per unit the latent tile -> LDS, root rows and root taps (f64 MFMA) =================
-        {
-            float4 *tw = (float4 *)tb_base;
-            int *tmo = (int *)(tw + max_nt);
-            if (lane < ck.nT) {
-                tw[lane] = w32[ck.t0 + lane];
-                tmo[lane] = (i0tab[ck.t0 + lane] - ck.imin) * Dp * 4;   // byte offset of the first tap row in the f32 image
-            }
-        }
-        int tap_b_off[3][MG_TAP_KS], tap_o_off[3];
-        bool tap_b_ok[3][MG_TAP_KS];
-#pragma unroll
-        for (int ct = 0; ct < 3; ct++) {
-            const int col = ct * 16 + cl;
-            const bool colok = col < MG_NCAND * nroot;
-            const int cc = colok ? col / nroot : 0, cd = colok ? col - cc * nroot : 0;
-            tap_o_off[ct] = colok ? cc * max_nt * 4 + cd : -1;
-#pragma unroll
-            for (int ks = 0; ks < MG_TAP_KS; ks++) {
-                const int m = 4 * ks + g;
-                tap_b_ok[ct][ks] = colok && m < ck.wi;   // rows at or beyond the window were never written: 0 * stale LDS could be NaN
-                tap_b_off[ct][ks] = cc * root_stride + m * nroot + cd;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) lds_rwt[e * 64 + lane] = wtap[((size_t)c * (MG_TAP_FT * MG_TAP_KS) + e) * 64 + lane];
-        const double *rpp[3];
-        const double *rmp[3];
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int tc = t < ck.nrt ? t : ck.nrt - 1;
-            rpp[t] = Erpack + ((size_t)(ck.rrt0 + tc) * KK) * 64 + lane;
-            rmp[t] = meanroot + (ck.rrt0 + tc) * 16 + g;
-        }
-        // the root rows' float64 fragments stay in registers as well where the budget allows (6 KK VGPRs)
-        constexpr bool RR = KK <= 10;
-        double rp_reg[3][RR ? KK : 1];
-        if (RR) {
-#pragma unroll
-            for (int t = 0; t < 3; t++)
-#pragma unroll
-                for (int q2 = 0; q2 < KK; q2++) rp_reg[t][RR ? q2 : 0] = rpp[t][q2 * 64];
-        }
+        // every load first, the ones the first unit's root chains wait for at the head of the queue; the index arithmetic after them
         auto load_latents = [&](typename mg_gmm_xt<LAT_F64>::type (&x)[KK], int u) {
             int t = t_begin + (u < n_units ? u : n_units - 1);    // clamped: the prefetch of the unit after the last one,
             t = t < 0 ? 0 : (t >= a.n_tiles ? a.n_tiles - 1 : t);  // a workgroup without units
@@ -1183,8 +1230,82 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         };
         typename mg_gmm_xt<LAT_F64>::type s64frag[KK], s64next[KK];
         load_latents(s64next, 0);
-        __syncthreads();   // counters, tables, mean' window
+        const double *rpp[3];
+        double rm_v[3][4];   // mean of the root rows: the C-in of the root chains, parked in LDS
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int tc = t < ck.nrt ? t : ck.nrt - 1;
+            rpp[t] = Erpack + ((size_t)(ck.rrt0 + tc) * KK) * 64 + lane;
+        }
+        // the root rows' float64 fragments stay in registers as well where the budget allows (6 KK VGPRs)
+        constexpr bool RR = KK <= 10;
+        double rp_reg[3][RR ? KK : 1];
+        if (RR) {
+#pragma unroll
+            for (int q2 = 0; q2 < KK; q2++)
+#pragma unroll
+                for (int t = 0; t < 3; t++) rp_reg[t][RR ? q2 : 0] = rpp[t][q2 * 64];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int tc = t < ck.nrt ? t : ck.nrt - 1;
+            const double *rmp = meanroot + (ck.rrt0 + tc) * 16 + g;
+#pragma unroll
+            for (int r = 0; r < 4; r++) rm_v[t][r] = rmp[4 * r];
+        }
+        double wt_v[MG_TAP_FT * MG_TAP_KS];
+#pragma unroll
+        for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) wt_v[e] = wtap[((size_t)c * (MG_TAP_FT * MG_TAP_KS) + e) * 64 + lane];
+        const float4 tw_v = lane < ck.nT ? w32[ck.t0 + lane] : float4{0.f, 0.f, 0.f, 0.f};
+        const int ti_v = lane < ck.nT ? i0tab[ck.t0 + lane] : 0;
+        mg_lds_barrier();   // A
+        MG_SUB_STAMP(15, 1, 0);
+        // LDS offsets of the root stage, every access unconditional: what must not count reads a zero (lds_rmean[63]), what must
+        // not land goes to a spare slot (the padding double of a candidate's root image row; the fourth float of a root output)
         double *rs = (double *)rs_base;
+        const int rs_zero = (int)((lds_rmean + 63) - rs);
+        int tap_b_off[3][MG_TAP_KS], tap_o_off[3], rs_off[3][4];
+#pragma unroll
+        for (int ct = 0; ct < 3; ct++) {
+            const int col = ct * 16 + cl;
+            const bool colok = col < MG_NCAND * nroot;
+            const int cc = colok ? col / nroot : 0, cd = colok ? col - cc * nroot : 0;
+            tap_o_off[ct] = colok ? cc * max_nt * 4 + cd : 3;
+#pragma unroll
+            for (int ks = 0; ks < MG_TAP_KS; ks++) {
+                const int m = 4 * ks + g;   // rows at or beyond the window are never written: 0 * stale LDS could be NaN
+                tap_b_off[ct][ks] = (colok && m < ck.wi) ? cc * root_stride + m * nroot + cd : rs_zero;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int lr0 = (ck.rrt0 + t) * 16 + g - ck.imin * nroot;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int lr = lr0 + 4 * r;
+                rs_off[t][r] = cl * root_stride + ((t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) ? lr : a.max_wi * nroot);
+            }
+        }
+        {
+            float4 *tw = (float4 *)tb_base;
+            int *tmo = (int *)(tw + max_nt);
+            if (cl == 0) {   // one lane per row group g: [t][r][g]
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) lds_rmean[(t * 4 + r) * 4 + g] = rm_v[t][r];
+            }
+            if (lane == 63) lds_rmean[63] = 0.0;
+#pragma unroll
+            for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) lds_rwt[e * 64 + lane] = wt_v[e];
+            if (lane < ck.nT) {
+                tw[lane] = tw_v;
+                tmo[lane] = (ti_v - ck.imin) * Dp * 4;   // byte offset of the first tap row in the f32 image
+            }
+        }
+        MG_SUB_STAMP(15, 1, 1);
+        mg_lds_barrier();   // B: counters, tables, mean' window
+        MG_SUB_STAMP(14, 0, 1);
         MG_STAMP_DECL
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
@@ -1192,6 +1313,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             for (int kk = 0; kk < KK; kk++) s64frag[kk] = s64next[kk];
             if (u >= 2) mg_cs_wait_swept(prog, u - 1);   // every wave is done with the slot's previous unit: image, root outputs, latent tile
             MG_STAMP(5);
+            MG_UNIT_STAMP(u, 0);
             {   // the latent tile as float32 MFMA B fragments for all the other waves
                 float *lb = lds_latb + (u & 1) * KK * 64;
 #pragma unroll
@@ -1199,11 +1321,13 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 mg_publish(prog, MG_CS_PROG_LAT, lane, u + 1);
             }
             load_latents(s64next, u + 1);   // a unit ahead
+            MG_SUB_STAMP(12, u, 0);
             if (MG_DBG(1024)) { MG_STAMP(3); mg_publish(prog, wave, lane, u + 1); MG_STAMP(4); continue; }   // ablation: no root stage
             // up to 3 root tiles (rows rr = i*nroot + d), chains interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
             f64x4 racc[3];
 #pragma unroll
-            for (int t = 0; t < 3; t++) racc[t] = f64x4{rmp[t][0], rmp[t][4], rmp[t][8], rmp[t][12]};
+            for (int t = 0; t < 3; t++)
+                racc[t] = f64x4{lds_rmean[(t * 4 + 0) * 4 + g], lds_rmean[(t * 4 + 1) * 4 + g], lds_rmean[(t * 4 + 2) * 4 + g], lds_rmean[(t * 4 + 3) * 4 + g]};
             if (RR) {
 #pragma unroll
                 for (int q2 = 0; q2 < KK; q2++)
@@ -1226,28 +1350,25 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                             racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q2], (double)s64frag[h * KH + q2], racc[t], 0, 0, 0);
                 }
             }
+            MG_SUB_STAMP(12, u, 1);
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
-                const int lr0 = (ck.rrt0 + t) * 16 + g - ck.imin * nroot;
+            for (int t = 0; t < 3; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int lr = lr0 + 4 * r;
-                    if (t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) rs[cl * root_stride + lr] = racc[t][r];
-                }
-            }
+                for (int r = 0; r < 4; r++) rs[rs_off[t][r]] = racc[t][r];
             // root taps on the float64 matrix pipe against the chunk's banded weight matrix (see the tile-major kernel)
+            MG_SUB_STAMP(13, u, 0);
             float *ro = (float *)(ro_base + (size_t)(u & 1) * RO_BYTES);
+            double bv[3][MG_TAP_KS];
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++)
+#pragma unroll
+                for (int ks = 0; ks < MG_TAP_KS; ks++) bv[ct][ks] = rs[tap_b_off[ct][ks]];
 #pragma unroll
             for (int ft = 0; ft < MG_TAP_FT; ft++) {
-                if (ft * 16 < ck.nT) {
+                if (ft * 16 < ck.nT) {   // (rows of the last tile beyond the chunk land in the root outputs' padding: max_nt is a multiple of 16)
                     f64x4 acc[3];
-                    double bv[3][MG_TAP_KS];
 #pragma unroll
-                    for (int ct = 0; ct < 3; ct++) {
-                        acc[ct] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int ks = 0; ks < MG_TAP_KS; ks++) bv[ct][ks] = tap_b_ok[ct][ks] ? rs[tap_b_off[ct][ks]] : 0.0;
-                    }
+                    for (int ct = 0; ct < 3; ct++) acc[ct] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int ks = 0; ks < MG_TAP_KS; ks++)
 #pragma unroll
@@ -1256,13 +1377,12 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
 #pragma unroll
                     for (int ct = 0; ct < 3; ct++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int fo = ft * 16 + g + 4 * r;
-                            if (tap_o_off[ct] >= 0 && fo < ck.nT) ro[tap_o_off[ct] + fo * 4] = (float)acc[ct][r];
-                        }
+                        for (int r = 0; r < 4; r++) ro[tap_o_off[ct] + (ft * 16 + g + 4 * r) * 4] = (float)acc[ct][r];
                 }
             }
             MG_STAMP(3);
+            MG_UNIT_STAMP(u, 1);
+            MG_SUB_STAMP(13, u, 1);
             mg_publish(prog, wave, lane, u + 1);
             MG_STAMP(4);
         }
@@ -1455,12 +1575,19 @@ int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t units = n_tiles * g->n_chunks;
     const int64_t grid0 = std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
+    const int64_t grid_cs = grid0 / g->n_chunks * g->n_chunks;   // whole workgroups per chunk
     const int want = p->ctx->opt[MG_OPT_FRAMES_KERNEL];
-    bool cs = g->cs_ok && grid0 >= g->n_chunks && (!fused || g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024);
+    bool cs = g->cs_ok && grid_cs >= g->n_chunks && grid_cs <= 4096 &&
+              (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
     if (want == 2 && !cs) return -1;
     if (want == 1) cs = false;
     else if (want == 0) cs = cs && units >= 3 * grid0;
     return cs ? 2 : 1;
+}
+int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int which) {
+    const int64_t units = (B + MG_NCAND - 1) / MG_NCAND * g->n_chunks;
+    const int64_t grid0 = std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
+    return (int)(which == 2 ? grid0 / g->n_chunks * g->n_chunks : grid0);
 }
 
 int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused) {
@@ -1484,8 +1611,9 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     }
     a.n_tiles = (int32_t)n_tiles;
     a.max_tiles = g->max_tiles;
+    for (int i = 0; i < MG_ARG_CHUNKS; i++) a.ck[i] = i < g->n_chunks ? g->chunks[i] : mg_chunk{};
+    a.cs_magic = a.cs_per = a.cs_rem = 0;
     const bool lf = (ldt == MG_F64);
-    const int grid0 = (int)std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
     const int which = mg_frames_kernel_choice(p, g, B, logp != nullptr);
     if (which < 0) {
         mg_set_error("mg_back_project_frames: the chunk-stationary kernel does not cover this shape (window of %d row tiles, %d bytes of LDS)",
@@ -1502,7 +1630,13 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     }
     if (cs) lds = g->cs_lds_bytes;
     if (logp) lds += mg_fused_gmm_lds(p);
-    const int grid = grid0;
+    const int grid = mg_frames_grid(p, g, B, which);
+    if (cs) {
+        const int Q = grid / g->n_chunks;
+        a.cs_magic = (1 << 20) / g->n_chunks + 1;
+        a.cs_per = (int32_t)(n_tiles / Q);
+        a.cs_rem = (int32_t)(n_tiles % Q);
+    }
     mg_launch_events ev;
     if (prof_slot >= 0) (void)mg_prof_kernel(p->ctx, prof_slot, prof_slot2, &ev.start, &ev.stop);
     switch (p->KK) {

@@ -660,8 +660,8 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
     {
         const int buf = (MG_NCAND * max_stride * 4 + 255) / 256 * 256;
         g->cs_lds_bytes = 2 * (buf + MG_NCAND * g->max_nt * 16) + g->max_nt * 20 + MG_NCAND * (max_wi * p->nroot + 1) * 8 + g->max_tiles * 64 +
-                          MG_TAP_FT * MG_TAP_KS * 64 * 8 + 2 * p->KK * 64 * 4 + 256;   // + tap weights, two latent tiles, 64 counters
-        g->cs_ok = g->mfma_ok && g->max_tiles <= mg_cs_max_tiles(p->KK) && g->cs_lds_bytes <= budget1;
+                          MG_TAP_FT * MG_TAP_KS * 64 * 8 + 512 + 2 * p->KK * 64 * 4 + 256;   // + tap weights, root means, two latent tiles, 64 counters
+        g->cs_ok = g->mfma_ok && g->max_tiles <= mg_cs_max_tiles(p->KK) && g->cs_lds_bytes <= budget1 && (int)g->chunks.size() <= MG_ARG_CHUNKS;
     }
 }
 
@@ -1622,7 +1622,7 @@ extern "C" int mg_step_plan(const mg_primitive *p, int64_t B, int32_t *plan) {
     MG_REQUIRE(which > 0, "mg_step_plan: the chunk-stationary kernel does not cover this shape");
     plan[0] = which;
     plan[1] = fused ? 1 : 0;
-    plan[2] = (int32_t)std::min<int64_t>((B + MG_NCAND - 1) / MG_NCAND * g->n_chunks, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
+    plan[2] = mg_frames_grid(p, g, B, which);
     plan[3] = mg_frames_lds_bytes(p, g, which, fused);
     return MG_OK;
 }

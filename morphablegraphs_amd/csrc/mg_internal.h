@@ -77,6 +77,7 @@ int mg_prof_resolve(mg_context *ctx);
 #define MG_MAX_NT 48         // time samples per chunk
 #define MG_TAP_KS ((MG_MAX_WI + 3) / 4)   // k-steps of the banded root-tap MFMA (4 basis functions each)
 #define MG_TAP_FT (MG_MAX_NT / 16)       // sample tiles of 16 of the root-tap MFMA
+#define MG_ARG_CHUNKS 8   // chunk descriptors that travel in the frames kernels' arguments
 struct mg_chunk {
     int32_t t0;        // first time index (chunks are runs of consecutive time indices)
     int32_t nT;        // number of time samples in the chunk, <= MG_MAX_NT
@@ -187,6 +188,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B);
 int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused);
 int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused);
+int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int which);
 int mg_cs_max_tiles(int KK);   // row tiles of a chunk window the chunk-stationary kernel can hold in registers
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);

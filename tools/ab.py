@@ -3,8 +3,9 @@
 SAME output buffer, variants interleaved round by round (cdna_hip_programming.md, methodology rule 24).
 
     python3 tools/ab.py VARIANT [VARIANT ...] [--rounds 6] [--steps 300] [--plain] [--two-launch]
-    VARIANT = path/to/lib.so[:debug_flags[:kernel]]   kernel: 0 = by batch size, 1 = tile-major, 2 = chunk-stationary
-              e.g.  morphablegraphs_amd/csrc/libmg_hip.so  build/lib_x.so::1  dbg.so:1  dbg.so:512:2
+    VARIANT = path/to/lib.so[:debug_flags[:kernel[:window[:arena_MiB]]]]   kernel: 0 = by batch size, 1 = tile-major, 2 = chunk-stationary;
+              window: MG_OPT_CHUNK_WINDOW (basis functions per time chunk, 0 = the planner's choice)
+              e.g.  morphablegraphs_amd/csrc/libmg_hip.so  build/lib_x.so::1  dbg.so:1  dbg.so:512:2  lib.so::2:7
 
 The output buffer comes from mg_device_malloc_placed of the first variant's library (--plain: mg_device_malloc).
 Prints per variant the median / min step time over the rounds and the spread."""
@@ -34,10 +35,19 @@ var = []
 for v in args.variants:
     parts = v.split(":")
     path, flags, kern = os.path.abspath(parts[0]), (parts[1] if len(parts) > 1 else ""), int(parts[2]) if len(parts) > 2 and parts[2] else 0
+    window = int(parts[3]) if len(parts) > 3 and parts[3] else 0
+    arena = int(parts[4]) if len(parts) > 4 and parts[4] else 0   # MiB per arena block for the primitive's constants (0: one hipMalloc each)
+    path = (path, window, arena)
     if path not in libs:
-        lib = _capi.load_library(path)
+        lib = _capi.load_library(path[0])
         ctx = _capi.Context(0, lib=lib)
+        ctx.set_option(_capi.MG_OPT_CHUNK_WINDOW, window)   # read when the primitive's canonical grid is planned
+        if arena:
+            ctx.arena_begin(arena << 20)
         libs[path] = (lib, ctx, _capi.Primitive(ctx, data))
+        if arena:
+            ctx.arena_end()
+        print(v, libs[path][2].step_plan(B), flush=True)
     var.append((v, path, flags, kern))
 ctx0 = libs[var[0][1]][1]
 S = ctx0.upload(np.random.default_rng(0).standard_normal((B, L)).astype(np.float32))
@@ -71,6 +81,23 @@ for r in range(args.rounds + 1):
         ctx.synchronize()
         if r > 0:   # round 0 warms the clocks
             times[name].append(1e6 * (time.perf_counter() - t0) / args.steps)
+ref = None
+for name, path, flags, kern in var:   # every variant must write the same bytes as the first one
+    lib, ctx, prim = libs[path]
+    ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, kern)
+    if flags:
+        continue                       # ablations change the results by design
+    os.environ.pop("MG_DEBUG_FLAGS", None)
+    ctx0.lib.mg_memset(ctx0.handle, out.ptr, 0xff, B * F * D * 4)
+    ctx0.synchronize()
+    run(prim, 1)
+    ctx.synchronize()
+    got = (ctx0.download(out, (B * F * D,), np.float32), ctx0.download(lp, (B,), np.float32))
+    if ref is None:
+        ref = got
+    else:
+        print("%-60s frames %s  log p %s" % (name, "identical" if np.array_equal(ref[0], got[0], equal_nan=True) else "DIFFER",
+                                             "identical" if np.array_equal(ref[1], got[1], equal_nan=True) else "DIFFER"))
 for name, _, _, _ in var:
     t = np.array(times[name])
     print("%-60s median %.2f  min %.2f  max %.2f us" % (name, np.median(t), t.min(), t.max()))

@@ -29,6 +29,16 @@ for flags in (sys.argv[1:] or ["0"]):
         else:
             prim.back_project_frames_dev(S, np.float32, B, 40, out, path=_capi.MG_PATH_MFMA)
     ctx.synchronize()
-    print("==== MG_DEBUG_FLAGS = %s (+16)" % flags, flush=True)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(50):
+        if os.environ.get("FUSED", "1") != "0":
+            prim.step_frames_and_logp_dev(S, np.float32, B, 40, out, logp)
+        else:
+            prim.back_project_frames_dev(S, np.float32, B, 40, out, path=_capi.MG_PATH_MFMA)
+    ctx.synchronize()
+    ms, n = ctx.profile_get("frames")
+    ctx.profile_enable(False)
+    print("==== MG_DEBUG_FLAGS = %s (+16): kernel %.2f us by its dispatch's own events (%d launches)" % (flags, 1e3 * ms / max(n, 1), n), flush=True)
     lib.mg_debug_dump_stamps()
     sys.stdout.flush()
