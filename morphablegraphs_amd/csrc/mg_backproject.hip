@@ -876,6 +876,7 @@ int mg_cs_max_tiles(int KK) {
 // the mixture's hand-off uses [32..63]
 #define MG_CS_PROG_LAT 12
 #define MG_CS_PROG_SWEPT 16
+#define MG_CS_PROG_MEAN 24   // [24..27]: mean' of the window's rows copied by sweep wave 4 + MG_CS_NSP + i
 #define MG_CS_PROG_GMM 32
 #define MG_CS_PROG_INTS 64
 __device__ __forceinline__ void mg_cs_wait_produced(const mg_lds_int *prog, int target) {   // the producing waves: 0 .. 3 + MG_CS_NSP
@@ -899,6 +900,14 @@ __device__ __forceinline__ void mg_cs_wait_swept(const mg_lds_int *prog, int tar
         const int m = min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(x[0], x[1]), min(x[2], x[3])));
         if (__builtin_amdgcn_readfirstlane(m) >= target) break;
         __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void mg_cs_wait_mean(const mg_lds_int *prog) {   // the (at most four) copying sweep waves
+    for (;;) {
+        const i32x4 v = *(const volatile mg_lds_i32x4 *)(prog + MG_CS_PROG_MEAN);
+        if (__builtin_amdgcn_readfirstlane(min(min(v[0], v[1]), min(v[2], v[3]))) >= 1) break;
+        __builtin_amdgcn_s_sleep(1);
     }
     asm volatile("" ::: "memory");
 }
@@ -1001,7 +1010,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     float *lds_latb = (float *)(lds_rmean + 64);                                         // latent tiles as MFMA B fragments [2][KK][64]
     mg_lds_int *prog = (mg_lds_int *)(lds_latb + 2 * KK * 64);                           // MG_CS_PROG_INTS counters, then the mixture's buffers
     if (tid < MG_CS_PROG_INTS)   // never-waited-for entries: the sweep waves that produce nothing, the padding of the mixture's hand-off
-        prog[tid] = ((tid >= MG_CS_NPW + MG_CS_NSP && tid < MG_CS_NPW + MG_CS_NCW) || tid == MG_CS_PROG_GMM + 26 || tid == MG_CS_PROG_GMM + 27) ? 0x7fffffff : 0;
+        prog[tid] = ((tid >= MG_CS_NPW + MG_CS_NSP && tid < MG_CS_NPW + MG_CS_NCW) || (tid >= MG_CS_PROG_MEAN + (MG_CS_NCW - MG_CS_NSP) && tid < MG_CS_PROG_MEAN + 4) ||
+                     tid == MG_CS_PROG_GMM + 26 || tid == MG_CS_PROG_GMM + 27) ? 0x7fffffff : 0;
 
     // workgroup w: chunk w mod n_chunks; the gridDim / n_chunks workgroups of a chunk share the tiles out in consecutive blocks
     // (the grid is a multiple of n_chunks; the quotient by multiplication, exact for w * n_chunks < 2^20)
@@ -1013,34 +1023,40 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     const int cl = lane & 15, g = lane >> 4;
     const int nt_p = ck.ntiles < NRP * TPWP ? ck.ntiles : NRP * TPWP;   // tiles [0, nt_p): row producers; [nt_p, ntiles): sweep waves
     const float2 *ep = (const float2 *)Epack;
-    // Start-up: every role issues ALL its one-time loads first (mean' of the window's rows, then the role's fragments and
-    // tables), writes what the others need to LDS and meets them at a barrier that does not drain vector memory, so the
-    // fragment loads are still in flight behind it and nothing waits for more than it uses.
-    // Start-up order on the CU's one path to memory, which serves requests in the order they were issued: first what the
-    // first unit's root stage waits for (wave 0: latents, root fragments, tables -- 63 requests) and mean' of the window's rows
-    // (the sweep waves that produce nothing), THEN the 130 KB of row fragments.  Barrier A separates the two; barrier B follows the
-    // LDS writes.  Neither drains vector memory, so the fragments land while the first root stage is already running.
-    constexpr int MEAN_FIRST = MG_CS_NSP < MG_CS_NCW ? 64 * (MG_CS_NPW + MG_CS_NSP) : 64;   // (every sweep wave produces: all but wave 0 copy)
-    constexpr int MEAN_NTH = MG_CS_BLOCK - MEAN_FIRST;
-    const int n_mean = ck.ntiles * 16, e0 = tid - MEAN_FIRST;
-    float mv[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) mv[i] = (e0 >= 0 && e0 + i * MEAN_NTH < n_mean) ? mean32[(size_t)ck.rt0 * 16 + e0 + i * MEAN_NTH] : 0.f;
-    auto store_mean = [&]() {
-        if (e0 < 0) return;
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-            if (e0 + i * MEAN_NTH < n_mean) lds_mean[e0 + i * MEAN_NTH] = mv[i];
-        for (int e = e0 + 6 * MEAN_NTH; e < n_mean; e += MEAN_NTH) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // (windows beyond 6 * MEAN_NTH rows)
-    };
+    // Start-up.  The CU's one path to memory serves requests in the order they were issued, so first goes what the first unit's
+    // root stage waits for (wave 0: latents, root fragments, tables -- 63 requests) and mean' of the window's rows (the sweep
+    // waves that produce nothing), THEN the 130 KB of row fragments: one barrier, which does not drain vector memory, separates
+    // the two and publishes the zeroed counters.  Everything after it is data flow through those counters: the tables are in
+    // LDS before wave 0 publishes its first unit, mean' before its copiers raise their flags, and the row producers start their
+    // first MFMAs as the first fragments land while the root stage of the first unit is already running.
+    static_assert(MG_CS_NSP < MG_CS_NCW && MG_CS_NCW - MG_CS_NSP <= 4, "the (at most four) sweep waves that produce nothing copy mean'");
     if (wave >= MG_CS_NPW) {
         // ================= sweep waves: two candidates each; the four oldest also produce TPWS row tiles of the NEXT unit =================
         const int cj = wave - MG_CS_NPW;                  // candidates cj and cj + 8
         float ef[TPWS][KK];
         const bool producing = cj < MG_CS_NSP;
-        mg_lds_barrier();   // A
-        mg_cs_load_fragments<KK, TPWS>(ef, ep, ck, producing ? nt_p + cj : ck.ntiles, MG_CS_NSP, lane);   // in flight across barrier B
-        store_mean();
+        // the waves that produce nothing copy mean' of the window's rows: unconditional loads at clamped indices (a predicated load
+        // drags a wait for everything in flight behind it), all in flight before the first LDS write
+        constexpr int MEAN_NTH = 64 * (MG_CS_NCW - MG_CS_NSP);
+        const int n_mean = ck.ntiles * 16, e0 = tid - 64 * (MG_CS_NPW + MG_CS_NSP);
+        float mv[6];
+        if (!producing) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const int e = e0 + i * MEAN_NTH;
+                mv[i] = mean32[(size_t)ck.rt0 * 16 + (e < n_mean ? e : n_mean - 1)];
+            }
+        }
+        mg_lds_barrier();
+        if (producing) {
+            mg_cs_load_fragments<KK, TPWS>(ef, ep, ck, nt_p + cj, MG_CS_NSP, lane);   // in flight across barrier B
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (e0 + i * MEAN_NTH < n_mean) lds_mean[e0 + i * MEAN_NTH] = mv[i];
+            for (int e = e0 + 6 * MEAN_NTH; e < n_mean; e += MEAN_NTH) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // (windows beyond 6 * MEAN_NTH rows)
+            mg_publish(prog + MG_CS_PROG_MEAN, cj - MG_CS_NSP, lane, 1);
+        }
         const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
         const int gl = nql + 1;                           // + the root lane
         const int rpi = 64 / gl;                          // samples per wave instruction
@@ -1061,9 +1077,9 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         const int col0 = ck.imin * Dp - ck.rt0 * 16;
         if (wave == 8) MG_SUB_STAMP(15, 2, 0);
         if (wave == 4) MG_SUB_STAMP(15, 2, 1);
-        mg_lds_barrier();   // counters, tables, mean' window
         MG_STAMP_DECL
         if (n_units > 0 && producing) {   // this wave's tiles of the first unit
+            mg_cs_wait_mean(prog);
             mg_cs_wait_latents(prog, 1);
             mg_cs_produce<KK, TPWS>(ef, lds_latb, lds_mean, (float *)smem, stride, nt_p + cj, MG_CS_NSP, ck.ntiles, lane, cl, g);
             mg_publish(prog, wave, lane, 1);
@@ -1184,16 +1200,14 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         // ================= row producers (waves 1..3): TPWP row tiles each, the fragments in registers =================
         const int pw = wave - 1;
         float ef[TPWP][KK];
-        if (MG_CS_NSP == MG_CS_NCW) store_mean();
-        mg_lds_barrier();   // A
+        mg_lds_barrier();
         MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 0);
         mg_cs_load_fragments<KK, TPWP>(ef, ep, ck, pw, NRP, lane);   // in tile order: the first unit's MFMAs start as its first fragments land
         if (MG_DBG(32)) {   // when do the fragments land?
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 1);
         }
-        store_mean();
-        mg_lds_barrier();   // B: counters, tables, mean' window
+        mg_cs_wait_mean(prog);
         MG_STAMP_DECL
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
@@ -1230,6 +1244,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         };
         typename mg_gmm_xt<LAT_F64>::type s64frag[KK], s64next[KK];
         load_latents(s64next, 0);
+        asm volatile("" ::: "memory");   // keep this issue order: results return in it
         const double *rpp[3];
         double rm_v[3][4];   // mean of the root rows: the C-in of the root chains, parked in LDS
 #pragma unroll
@@ -1246,6 +1261,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
 #pragma unroll
                 for (int t = 0; t < 3; t++) rp_reg[t][RR ? q2 : 0] = rpp[t][q2 * 64];
         }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int tc = t < ck.nrt ? t : ck.nrt - 1;
@@ -1256,9 +1272,10 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         double wt_v[MG_TAP_FT * MG_TAP_KS];
 #pragma unroll
         for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) wt_v[e] = wtap[((size_t)c * (MG_TAP_FT * MG_TAP_KS) + e) * 64 + lane];
-        const float4 tw_v = lane < ck.nT ? w32[ck.t0 + lane] : float4{0.f, 0.f, 0.f, 0.f};
-        const int ti_v = lane < ck.nT ? i0tab[ck.t0 + lane] : 0;
-        mg_lds_barrier();   // A
+        const int tl = lane < ck.nT ? lane : ck.nT - 1;   // clamped, unconditional (see mv above)
+        const float4 tw_v = w32[ck.t0 + tl];
+        const int ti_v = i0tab[ck.t0 + tl];
+        mg_lds_barrier();
         MG_SUB_STAMP(15, 1, 0);
         // LDS offsets of the root stage, every access unconditional: what must not count reads a zero (lds_rmean[63]), what must
         // not land goes to a spare slot (the padding double of a candidate's root image row; the fourth float of a root output)
@@ -1286,28 +1303,24 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 rs_off[t][r] = cl * root_stride + ((t < ck.nrt && lr >= 0 && lr < ck.wi * nroot) ? lr : a.max_wi * nroot);
             }
         }
-        {
+        auto park_tables = [&]() {   // the loads issued last, written when the first unit's root chains no longer wait behind them
             float4 *tw = (float4 *)tb_base;
             int *tmo = (int *)(tw + max_nt);
-            if (cl == 0) {   // one lane per row group g: [t][r][g]
-#pragma unroll
-                for (int t = 0; t < 3; t++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) lds_rmean[(t * 4 + r) * 4 + g] = rm_v[t][r];
-            }
-            if (lane == 63) lds_rmean[63] = 0.0;
 #pragma unroll
             for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) lds_rwt[e * 64 + lane] = wt_v[e];
             if (lane < ck.nT) {
                 tw[lane] = tw_v;
                 tmo[lane] = (ti_v - ck.imin) * Dp * 4;   // byte offset of the first tap row in the f32 image
             }
-        }
+        };
+        if (lane == 63) lds_rmean[63] = 0.0;
         MG_SUB_STAMP(15, 1, 1);
-        mg_lds_barrier();   // B: counters, tables, mean' window
         MG_SUB_STAMP(14, 0, 1);
         MG_STAMP_DECL
-        for (int u = 0; u < n_units; u++) {
+        // one unit of the root stage; the first one is peeled (FIRST) so that what only it uses -- the one-time loads still in
+        // registers -- is dead in the loop over the others
+        auto root_unit = [&](const int u, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             MG_STAMP(0);
 #pragma unroll
             for (int kk = 0; kk < KK; kk++) s64frag[kk] = s64next[kk];
@@ -1320,14 +1333,29 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 for (int kk = 0; kk < KK; kk++) lb[kk * 64 + lane] = (float)s64frag[kk];
                 mg_publish(prog, MG_CS_PROG_LAT, lane, u + 1);
             }
-            load_latents(s64next, u + 1);   // a unit ahead
+            // the next unit's latents, a unit ahead -- but not yet in the first unit: the request would queue behind the row
+            // fragments still being issued and hold this wave up; there it goes out after the root stage
+            if (!FIRST) load_latents(s64next, u + 1);
             MG_SUB_STAMP(12, u, 0);
-            if (MG_DBG(1024)) { MG_STAMP(3); mg_publish(prog, wave, lane, u + 1); MG_STAMP(4); continue; }   // ablation: no root stage
+            if (MG_DBG(1024)) {   // ablation: no root stage
+                if (FIRST) { park_tables(); load_latents(s64next, 1); }
+                MG_STAMP(3); mg_publish(prog, wave, lane, u + 1); MG_STAMP(4);
+                return;
+            }
             // up to 3 root tiles (rows rr = i*nroot + d), chains interleaved; v_mfma_f64_16x16x4_f64 C/D: col = lane & 15, row = (lane >> 4) + 4*reg
             f64x4 racc[3];
 #pragma unroll
-            for (int t = 0; t < 3; t++)
-                racc[t] = f64x4{lds_rmean[(t * 4 + 0) * 4 + g], lds_rmean[(t * 4 + 1) * 4 + g], lds_rmean[(t * 4 + 2) * 4 + g], lds_rmean[(t * 4 + 3) * 4 + g]};
+            for (int t = 0; t < 3; t++) {
+                if (FIRST) {   // straight from the registers they were loaded into; parked in LDS for the later units
+                    racc[t] = f64x4{rm_v[t][0], rm_v[t][1], rm_v[t][2], rm_v[t][3]};
+                    if (cl == 0) {   // one lane per row group g: [t][r][g]
+#pragma unroll
+                        for (int r = 0; r < 4; r++) lds_rmean[(t * 4 + r) * 4 + g] = rm_v[t][r];
+                    }
+                } else {
+                    racc[t] = f64x4{lds_rmean[(t * 4 + 0) * 4 + g], lds_rmean[(t * 4 + 1) * 4 + g], lds_rmean[(t * 4 + 2) * 4 + g], lds_rmean[(t * 4 + 3) * 4 + g]};
+                }
+            }
             if (RR) {
 #pragma unroll
                 for (int q2 = 0; q2 < KK; q2++)
@@ -1355,6 +1383,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             for (int t = 0; t < 3; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) rs[rs_off[t][r]] = racc[t][r];
+            if (FIRST) park_tables();
             // root taps on the float64 matrix pipe against the chunk's banded weight matrix (see the tile-major kernel)
             MG_SUB_STAMP(13, u, 0);
             float *ro = (float *)(ro_base + (size_t)(u & 1) * RO_BYTES);
@@ -1384,8 +1413,11 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             MG_UNIT_STAMP(u, 1);
             MG_SUB_STAMP(13, u, 1);
             mg_publish(prog, wave, lane, u + 1);
+            if (FIRST) load_latents(s64next, 1);
             MG_STAMP(4);
-        }
+        };
+        if (n_units > 0) root_unit(0, std::true_type{});
+        for (int u = 1; u < n_units; u++) root_unit(u, std::false_type{});
         MG_STAMP_DUMP;
     }
     if (FUSE_GMM && wave < MG_WS_NPW) {   // the mixture: the four producer waves, as in the tile-major kernel
