@@ -394,7 +394,8 @@ static hipEvent_t mg_get_event(mg_context *ctx) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    // timing only: no system-scope fence (cache write-back and invalidation) when the event completes
+    (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
     return e;
 }
 void mg_prof_begin(mg_context *ctx, int slot) {
