@@ -826,27 +826,32 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
 
 
 // -----------------------------------------------------------------------------------------
-// The chunk-stationary variant of the hot-path kernel, for batches of many tiles per CU.
+// The chunk-stationary variant of the hot-path kernel, for batches of many tiles per CU (the default from three
+// units per workgroup on; DESIGN.md section 4.1 has the measurements behind every statement here).
 //
-// What the tile-major kernel above pays for besides its stores was measured with the diagnostic build's
-// ablations in the fast placement class (tools/ab.py; B = 8192, 'walk'): the E' fragment loads of the row
-// producers cost 9-13 us of 84-93 -- not as bytes (189 MB of L2 hits per launch) but because every activity
-// on the chip lowers the clock it holds: 2.05 GHz for the whole kernel, 2.32 GHz without those loads,
-// 2.15 GHz without the MFMAs (per-wave s_memtime / s_memrealtime).  So E' must not travel at all:
-//   * a workgroup works on ONE time chunk for its whole life (workgroup w: chunk w mod n_chunks) and walks
-//     a block of consecutive candidate tiles; its row producers load the chunk's whole window of E' fragments
-//     ONCE into registers (512-thread workgroups: 2 waves per SIMD, 256 VGPRs; 3 row producers x 17 row tiles
-//     x KK floats) and every unit is MFMAs on registers + LDS writes, no vector-memory read but the 2.5 KB of
-//     latents (prefetched a unit ahead);
-//   * consecutive units are different tiles, so no window rows carry over: each unit computes its full window
-//     (51 instead of 36 row tiles for 'walk': +42 % MFMAs, which cost less clock than the loads they replace;
-//     emulated with the ablation flags: 82.3 vs 93.3 us) and the LDS -> LDS copies disappear;
-//   * the per-sample tables, the tap weights and the root rows' float64 fragments are stationary as well
-//     (loaded once by wave 0), mean' sits in LDS as the MFMAs' C-in;
-//   * wave 0 = root producer, waves 1-3 = row producers, waves 4-7 = sweep, four candidates each (wave j:
-//     j, j + 4, j + 8, j + 12; a trip = two row groups x two candidate pairs = 8 store instructions, so the
-//     chip still writes 4096 streams); same ring of two LDS slots, same progress counters, same arithmetic:
-//     the results are bit-identical to the tile-major kernel's.
+// The tile-major kernel above ended with its row producers 88 % busy and the sweep waiting for them; 9-13 us of its
+// 84-93 went on the E' fragment loads of the unit loop -- 189 MB of L2 hits per launch that travel through the same L2
+// and the same per-CU memory pipe as 400 MB of stores (streaming just five more tiles per unit into THIS kernel's row
+// producers costs 18 us: MG_DEBUG_FLAGS & 2048).  So E' must not travel at all inside the loop:
+//   * a workgroup works on ONE time chunk for its whole life (workgroup w: chunk w mod n_chunks) and walks a block of
+//     consecutive candidate tiles; the chunk's whole window of E' fragments is loaded ONCE into registers: 768-thread
+//     workgroups, 3 waves per SIMD, 168 VGPRs -- three row producers x TPWP (12) row tiles x KK floats, the four oldest
+//     sweep waves TPWS (4) tiles each -- and every unit is MFMAs on registers + LDS writes, no vector-memory read but the
+//     2.5 KB of latents (prefetched a unit ahead);
+//   * consecutive units are different tiles, so no window rows carry over: each unit computes its full window (51
+//     instead of 36 row tiles for 'walk': +42 % MFMAs, cheaper than the loads they replace) and the LDS -> LDS copies
+//     disappear;
+//   * the per-sample tables, the tap weights and the root rows' float64 fragments are stationary as well (loaded once
+//     by wave 0), mean' sits in LDS as the MFMAs' C-in;
+//   * wave 0 = root producer, waves 1-3 = row producers, waves 4-11 = sweep, two candidates each exactly as in the
+//     tile-major kernel; waves 4-7 -- the older ones, which win the arbiter and finish a unit first -- produce their
+//     tiles of the NEXT unit after each sweep (all eight doing so turns the hand-over into a barrier: +4 us); same ring
+//     of two LDS slots, same kind of progress counters, same arithmetic: bit-identical results.
+// Start-up (the first store leaves ~7 us after kernel entry; 11.4 before the points below): all kernel arguments
+// requested in one batch; chunk descriptors in the arguments; no division in the workgroup mapping; every one-time load
+// unconditional (clamped index) and scoped to the role that uses it; ONE barrier, which does not drain vector memory,
+// between the requests the first root stage waits for and the 130 KB of row fragments; readiness of mean' and of the
+// tables handed over through flags; the first root unit peeled from the loop.
 // Store order: at any moment the 4 workgroups of a group write the 4 chunks of the same tile, groups are 8 tiles
 // apart (stand-alone replica of this order: 64-65 us against 62-64 us for the tile-major order, tools/chan_probe.hip
 // mode 3).
