@@ -207,14 +207,17 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *                             from three units per workgroup on), 1 = tile-major (units of one tile's consecutive chunks,
  *                             rows shared by neighbouring chunks carried over), 2 = chunk-stationary (a workgroup keeps one
  *                             chunk's eigenvector window in registers; MG_ERR_UNSUPPORTED where the window does not fit)
- *                             -- identical results */
+ *                             -- identical results 
+ *   MG_OPT_PLACED_FAST_PCT    mg_device_malloc_placed: pattern / fill ratio (in percent) up to which a candidate counts as
+ *                             fast (0 = 115); tests lower it to walk through both recipes */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
 #define MG_OPT_CHUNK_WINDOW 3
 #define MG_OPT_CHUNK_SAMPLES 4
 #define MG_OPT_FRAMES_KERNEL 5
-#define MG_OPT_COUNT 6
+#define MG_OPT_PLACED_FAST_PCT 6
+#define MG_OPT_COUNT 7
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
@@ -243,7 +246,9 @@ int mg_device_malloc_chunked(mg_context *ctx, int64_t bytes, int64_t chunk_bytes
  * library probes: it allocates a candidate, times the store pattern and a plain fill on it (about 1 ms), keeps the
  * first candidate whose ratio is in the fast class, holds the rejected ones until then (so that the next candidate
  * comes from other memory) and frees them.  max_candidates <= 0: a default budget (up to 192 candidates, never
- * more than half of the free device memory); if no candidate is fast the best one is returned.  info (may be NULL):
+ * more than half of the free device memory); where none of them is fast (and max_candidates != 1) twelve more are
+ * assembled from physical chunks of 8 / 32 / 2 MiB through the virtual-memory API -- on some boxes those do better --
+ * and the best candidate of all is returned.  info (may be NULL):
  * [0] candidates probed, [1] pattern time / fill time of the buffer returned, [2] its pattern time in us,
  * [3] 1 if it is in the fast class.  The contents are undefined afterwards.  Freed with mg_device_free. */
 int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out_dev, double *info4);

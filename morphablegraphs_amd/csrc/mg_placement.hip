@@ -112,6 +112,7 @@ extern "C" int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t m
     MG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     int budget = max_candidates > 0 ? max_candidates : 192;
     budget = (int)std::max<int64_t>(1, std::min<int64_t>(budget, (int64_t)(free_b / 2) / bytes));
+    const double fast_ratio = ctx->opt[MG_OPT_PLACED_FAST_PCT] > 0 ? ctx->opt[MG_OPT_PLACED_FAST_PCT] / 100.0 : MG_PLACED_FAST_RATIO;
     std::vector<void *> held;
     void *best = nullptr;
     double best_ratio = 0.0, best_us = 0.0;
@@ -129,16 +130,39 @@ extern "C" int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t m
         } else {
             held.push_back(p);
         }
-        if (best_ratio <= MG_PLACED_FAST_RATIO) break;
+        if (best_ratio <= fast_ratio) break;
     }
     (void)hipStreamSynchronize(ctx->stream);
+    // Second recipe, where no plain allocation was fast (some boxes): buffers assembled from physical chunks through the
+    // virtual-memory API.  Round 1 measured them 5-8 % faster than plain allocations on such a box (not on every one).
+    std::vector<void *> held_vmm;
+    bool best_is_vmm = false;
+    if (best && best_ratio > fast_ratio && rc == MG_OK && max_candidates != 1) {
+        static const int64_t chunk_mib[3] = {8, 32, 2};
+        for (int c = 0; c < 3 && best_ratio > fast_ratio; c++)
+            for (int i = 0; i < 4 && best_ratio > fast_ratio; i++) {
+                void *p = nullptr;
+                if (mg_device_malloc_chunked(ctx, bytes, chunk_mib[c] << 20, &p) != MG_OK) { (void)hipGetLastError(); c = 3; break; }
+                double ratio = 1.0, us = 0.0;
+                if (mg_probe_placement(ctx, p, bytes, &ratio, &us) != MG_OK) { (void)mg_device_free(ctx, p); c = 3; break; }
+                probed++;
+                if (ratio < best_ratio) {
+                    if (best_is_vmm) held_vmm.push_back(best); else held.push_back(best);
+                    best = p; best_ratio = ratio; best_us = us; best_is_vmm = true;
+                } else {
+                    held_vmm.push_back(p);
+                }
+            }
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     for (void *p : held) (void)hipFree(p);
+    for (void *p : held_vmm) (void)mg_device_free(ctx, p);
     if (!best) {
         if (rc != MG_OK) return rc;
         mg_set_error("mg_device_malloc_placed: out of device memory (%lld bytes)", (long long)bytes);
         return MG_ERR_OUT_OF_MEMORY;
     }
     *out_dev = best;
-    if (info) { info[0] = probed; info[1] = best_ratio; info[2] = best_us; info[3] = best_ratio <= MG_PLACED_FAST_RATIO ? 1.0 : 0.0; }
+    if (info) { info[0] = probed; info[1] = best_ratio; info[2] = best_us; info[3] = best_ratio <= fast_ratio ? 1.0 : 0.0; }
     return MG_OK;
 }

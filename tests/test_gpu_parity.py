@@ -511,6 +511,30 @@ def test_placed_output_buffer_and_options(ctx):
         ctx.set_option(_capi.MG_OPT_RING_SLOTS, -1)
 
 
+def test_placed_allocator_walks_both_recipes_when_nothing_is_fast(ctx):
+    """With an acceptance ratio no buffer can meet, mg_device_malloc_placed probes its plain candidates, then the
+    twelve assembled from physical chunks by the virtual-memory API, and returns the best of all of them: a buffer
+    that works like any other and is released by mg_device_free whichever recipe it came from."""
+    nbytes = 2048 * 156 * 79 * 4
+    ctx.set_option(_capi.MG_OPT_PLACED_FAST_PCT, 50)
+    try:
+        buf = ctx.malloc_placed(nbytes, max_candidates=2)
+    finally:
+        ctx.set_option(_capi.MG_OPT_PLACED_FAST_PCT, 0)
+    pl = buf.placement
+    assert pl["probed"] in (2, 14) and not pl["fast"] and pl["ratio"] > 0.5   # 2: a box without the virtual-memory API
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    S = np.random.default_rng(4).standard_normal((2048, 40)).astype(np.float32)
+    d_S = ctx.upload(S)
+    prim.back_project_frames_dev(d_S, np.float32, 2048, 40, buf, path=_capi.MG_PATH_MFMA)
+    got = ctx.download(buf, (2048, 156, 79), np.float32)
+    np.testing.assert_array_equal(_bits(got), _bits(prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)))
+    for b in (d_S, buf):
+        b.free()
+    prim.close()
+
+
 def _set_frames_kernel(ctx, which):
     ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, which)
 
