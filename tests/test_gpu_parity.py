@@ -610,6 +610,26 @@ def test_chunk_stationary_kernel_on_the_golden_shapes_and_other_grids(ctx, golde
     prim.close()
 
 
+def test_step_plan_names_what_a_step_launches(ctx):
+    """mg_step_plan: small batches on the tile-major kernel, from three units per workgroup on the chunk-stationary one
+    (whole workgroups per chunk), log p(x) inside the frames kernel for 'walk'; the option overrides the choice; a
+    mixture over spatial AND time latents is scored by a second launch."""
+    prim = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
+    small, large = prim.step_plan(256), prim.step_plan(8192)
+    assert small["kernel"] == "mg_frames_ws_kernel" and small["fused"]
+    assert large["kernel"] == "mg_frames_cs_kernel" and large["fused"] and large["workgroups"] % 4 == 0
+    assert 0 < large["lds_bytes"] <= 160 * 1024
+    _set_frames_kernel(ctx, 1)
+    assert prim.step_plan(8192)["kernel"] == "mg_frames_ws_kernel"
+    _set_frames_kernel(ctx, 0)
+    assert prim.step_plan(4)["kernel"] == "mg_frames_direct_kernel"
+    prim.close()
+    timed = _capi.Primitive(ctx, synthetic.make_primitive(seed=13, n_components=12, n_frames=60, n_dim=15, n_gmm=3, name="timed",
+                                                          n_time_components=3, n_basis_time=8))
+    assert not timed.step_plan(4096)["fused"]
+    timed.close()
+
+
 def test_two_slot_ring(ctx):
     """Shapes whose three LDS slots do not fit 160 KiB run a two-slot ring; mg_context_set_option(MG_OPT_RING_SLOTS, 2) forces it on 'walk' (the
     planner reads it when a grid is built).  Carried-over tiles then need a full meeting of the row producers per
