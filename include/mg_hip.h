@@ -467,6 +467,15 @@ int mg_best_candidate(mg_primitive *prim, const mg_constraint_set *cs, const voi
 int mg_option_step(mg_primitive *prim, const mg_constraint_set *cs, int64_t n_samples, const int64_t *counts,
                    uint64_t seed, void *x_dev, int x_dtype, int64_t ld, double *errors_dev, void *result_dev);
 
+/* ALL outgoing options of a planner step (reference graph_walk_planner.py:184-226: the loop over `options`) in one call:
+ * mg_option_step for option k with prims[k], csets[k], counts[k], seeds[k], x_dev[k] (n, ld[k]), errors_dev[k]; result
+ * record k at results_dev + k * result_stride bytes (result_stride >= 16 + 8 * n_gmm_dims of every option, a multiple
+ * of 8).  All primitives must live in one context.  results_host != NULL: the n_options * result_stride bytes are
+ * copied back and the stream is synchronised once -- one round trip for the whole step. */
+int mg_options_step(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n_samples,
+                    const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int x_dtype, const int64_t *ld,
+                    double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host);
+
 /* ---- host-pointer convenience variants (H2D, launch, D2H, synchronise) ---------------- */
 int mg_back_project_frames_host(mg_primitive *prim, const mg_time_grid *grid, const void *latents,
                                 int latent_dtype, int64_t n_samples, int64_t ld, float *frames, int path);

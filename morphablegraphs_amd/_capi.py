@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
-    "mg_option_step",
+    "mg_option_step", "mg_options_step",
 ]
 
 
@@ -248,6 +248,7 @@ def load_library(path=None):
         "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_option_step": [vp, vp, i64, vp, u64, vp, i32, i64, vp, vp],
+        "mg_options_step": [i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
         "mg_score_constraint_residuals_host": [vp, vp, vp, i32, i64, i64, vp],
         "mg_gmm_log_prob_jac_host": [vp, vp, i32, i64, i64, vp],

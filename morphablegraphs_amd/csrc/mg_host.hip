@@ -1844,8 +1844,35 @@ extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int6
     MG_REQUIRE(n > 0 && x_dev && errors_dev && result_dev, "mg_option_step: bad arguments");
     int rc = mg_gmm_sample(p, n, counts, seed, x_dev, xdt, ld, nullptr);
     if (rc == MG_OK) rc = mg_score_constraints(p, cs, x_dev, xdt, n, ld, errors_dev, MG_F64);
-    if (rc == MG_OK) rc = mg_argmin_first_dev(p->ctx, errors_dev, MG_F64, n, result_dev);
-    if (rc == MG_OK) rc = mg_launch_gather_winner(p->ctx, x_dev, xdt, ld, p->Lg, result_dev);   // the winner keeps its full width
+    if (rc == MG_OK) {   // first minimum and the copy of the winner (at its full width) in one launch
+        mg_prof_begin(p->ctx, 3);
+        rc = mg_launch_argmin_gather(p->ctx, errors_dev, MG_F64, n, result_dev, x_dev, xdt, ld, p->Lg);
+        mg_prof_end(p->ctx, 3);
+    }
     return rc;
+}
+
+// All outgoing options of a planner step in one call: mg_option_step for each (the primitives share one context, so
+// one stream), their result records side by side in results_dev (record k at k * result_stride bytes), then -- if
+// results_host is given -- ONE copy back and ONE synchronisation for the whole step.
+extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
+                               const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
+                               double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host) {
+    MG_REQUIRE(n_options > 0 && prims && csets && counts && seeds && x_dev && ld && errors_dev && results_dev, "mg_options_step: bad arguments");
+    mg_context *ctx = prims[0] ? prims[0]->ctx : nullptr;
+    for (int k = 0; k < n_options; k++) {
+        MG_REQUIRE(prims[k] && prims[k]->ctx == ctx, "mg_options_step: option %d is NULL or lives in another context", k);
+        MG_REQUIRE(result_stride >= 16 + 8 * (int64_t)prims[k]->Lg && result_stride % 8 == 0, "mg_options_step: result_stride %lld too small for option %d",
+                   (long long)result_stride, k);
+    }
+    for (int k = 0; k < n_options; k++) {
+        int rc = mg_option_step(prims[k], csets[k], n, counts[k], seeds[k], x_dev[k], xdt, ld[k], errors_dev[k], (char *)results_dev + k * result_stride);
+        if (rc != MG_OK) return rc;
+    }
+    if (results_host) {
+        MG_HIP_CHECK(hipMemcpyAsync(results_host, results_dev, (size_t)(n_options * result_stride), hipMemcpyDeviceToHost, ctx->stream));
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return MG_OK;
 }
 

@@ -522,6 +522,46 @@ __global__ __launch_bounds__(64) void mg_gather_winner_kernel(const void *x, int
         row[i] = x_f64 ? ((const double *)x)[idx * ld + i] : (double)((const float *)x)[idx * ld + i];
 }
 
+// the two in one launch (a planner step is a chain of small launches: every one saved counts)
+template <bool F64>
+__global__ __launch_bounds__(1024) void mg_argmin_gather_kernel(const void *vals, int64_t n, void *out, const void *x, int x_f64, int64_t ld, int L) {
+    __shared__ double sv[16];
+    __shared__ int64_t si[16];
+    __shared__ int64_t winner;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double best = INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t i = tid; i < n; i += 1024) {
+        double v = F64 ? ((const double *)vals)[i] : (double)((const float *)vals)[i];
+        if (v < best) { best = v; bi = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_down(best, off, 64);
+        long long oi = __shfl_down((long long)bi, off, 64);
+        mg_min_combine(best, bi, ov, (int64_t)oi);
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) mg_min_combine(best, bi, sv[w], si[w]);
+        if (bi == INT64_MAX) { bi = 0; best = INFINITY; }
+        ((int64_t *)out)[0] = bi;
+        ((double *)out)[1] = best;
+        winner = bi;
+    }
+    __syncthreads();
+    const int64_t idx = winner;
+    double *row = (double *)((char *)out + 16);
+    for (int i = tid; i < L; i += 1024)
+        row[i] = x_f64 ? ((const double *)x)[idx * ld + i] : (double)((const float *)x)[idx * ld + i];
+}
+int mg_launch_argmin_gather(mg_context *ctx, const void *v, int dt, int64_t n, void *result_dev, const void *x, int xdt, int64_t ld, int L) {
+    if (dt == MG_F64) hipLaunchKernelGGL((mg_argmin_gather_kernel<true>), dim3(1), dim3(1024), 0, ctx->stream, v, n, result_dev, x, xdt == MG_F64 ? 1 : 0, ld, L);
+    else hipLaunchKernelGGL((mg_argmin_gather_kernel<false>), dim3(1), dim3(1024), 0, ctx->stream, v, n, result_dev, x, xdt == MG_F64 ? 1 : 0, ld, L);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
 int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld, int L, void *result_dev) {
     hipLaunchKernelGGL(mg_gather_winner_kernel, dim3(1), dim3(64), 0, ctx->stream, x, xdt == MG_F64 ? 1 : 0, ld, L, result_dev);
     MG_HIP_CHECK(hipGetLastError());

@@ -257,17 +257,19 @@ class HipPrimitiveSet(object):
                                    prev_frames=None, skeleton=None):
         """GraphWalkPlanner's option evaluation (reference graph_walk_planner.py:184-226) without host round trips:
         for every option the component counts come from NumPy's stream, the candidates from the device sampler,
-        scoring, first-minimum argmin and the copy of the winner stay on the device (mg_option_step, one call per
-        option, no synchronisation); only after all options are enqueued are the (16 + 8 L)-byte results read back.
+        scoring, first-minimum argmin and the copy of the winner stay on the device (mg_options_step: one C call enqueues
+        every option without synchronisation and reads all (16 + 8 L)-byte result records back in one copy; with a
+        context per primitive: mg_option_step per option, then one read-back each).
         With `prev_frames` every candidate is aligned to the last previous frame before scoring, which is how the
         planner scores (its constraints stay global, graph_walk_planner.py:179; `skeleton`: a _capi.Skeleton when
         the aligning node is not the root or joints other than the root are constrained).
         Returns (best_option, {name: (best_sample, min_error)})."""
         from .candidate_scoring import cached_constraint_set, alignment_from_prev_frames
+        import ctypes as C
         n = int(n_samples)
         item = np.dtype(dtype).itemsize
         code = _capi.MG_F64 if np.dtype(dtype) == np.float64 else _capi.MG_F32
-        pending = []
+        steps = []
         for k, name in enumerate(options):
             node = self.nodes[name]
             prim, ctx = node._prim, node._prim.ctx
@@ -283,14 +285,41 @@ class HipPrimitiveSet(object):
             cset = cached_constraint_set(prim, constraints_to_device_form(clist), sk, alignment_from_prev_frames(prev_frames, cons, sk))
             weights = node.gaussian_mixture_model.weights_
             counts = np.random.multinomial(n, weights / weights.sum()).astype(np.int64)
-            _capi._check(prim.lib.mg_option_step(prim.handle, cset.handle, n, counts.ctypes.data, int(seed) + k, d_x.ptr, code, L,
-                                                 d_e.ptr, d_r.ptr))
-            pending.append((name, ctx, d_r, L))
+            steps.append((name, prim, ctx, cset, counts, d_x, d_e, d_r, L))
         results = {}
-        for name, ctx, d_r, L in pending:
-            raw = ctx.download(d_r, (16 + 8 * L,), np.uint8)       # synchronises this option's stream
-            idx, err = int(raw[:8].view(np.int64)[0]), float(raw[8:16].view(np.float64)[0])
-            results[name] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
+        one_context = all(st[2] is steps[0][2] for st in steps)
+        if one_context and steps:
+            # one C call and ONE read-back for the whole step (mg_options_step): the result records side by side
+            ctx = steps[0][2]
+            m = len(steps)
+            stride = 16 + 8 * max(st[8] for st in steps)
+            key = ("step", m, stride)
+            shared = self._buffers.get(key)
+            if shared is None:
+                shared = self._buffers[key] = ctx.malloc(m * stride)
+            vp = C.c_void_p
+            prims = (vp * m)(*[st[1].handle for st in steps])
+            csets = (vp * m)(*[st[3].handle for st in steps])
+            cnts = (vp * m)(*[st[4].ctypes.data for st in steps])
+            seeds = (C.c_uint64 * m)(*[int(seed) + k for k in range(m)])
+            xs = (vp * m)(*[_capi._dev_ptr(st[5]).value for st in steps])
+            lds = (C.c_int64 * m)(*[st[8] for st in steps])
+            errs = (vp * m)(*[_capi._dev_ptr(st[6]).value for st in steps])
+            host = np.empty(m * stride, dtype=np.uint8)
+            _capi._check(steps[0][1].lib.mg_options_step(m, prims, csets, n, cnts, seeds, xs, code, lds, errs, shared.ptr, stride,
+                                                         host.ctypes.data_as(vp)))
+            for k, st in enumerate(steps):
+                raw = host[k * stride:k * stride + 16 + 8 * st[8]]
+                err = float(raw[8:16].view(np.float64)[0])
+                results[st[0]] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
+        else:
+            for k, (name, prim, ctx, cset, counts, d_x, d_e, d_r, L) in enumerate(steps):
+                _capi._check(prim.lib.mg_option_step(prim.handle, cset.handle, n, counts.ctypes.data, int(seed) + k, d_x.ptr, code, L,
+                                                     d_e.ptr, d_r.ptr))
+            for name, prim, ctx, cset, counts, d_x, d_e, d_r, L in steps:
+                raw = ctx.download(d_r, (16 + 8 * L,), np.uint8)       # synchronises this option's stream
+                err = float(raw[8:16].view(np.float64)[0])
+                results[name] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
         errors = [results[n][1] for n in options]
         return options[int(np.argmin(errors))], results
 
