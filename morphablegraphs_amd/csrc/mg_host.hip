@@ -141,6 +141,8 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     if (ctx->rccl_comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(ctx->rccl_comm); ctx->rccl_comm = nullptr; }
     for (auto &p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &ev : ctx->free_events) (void)hipEventDestroy(ev);
+    for (auto &st : ctx->side) if (st) (void)hipStreamDestroy(st);
+    for (auto &e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
@@ -1865,10 +1867,31 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
         MG_REQUIRE(result_stride >= 16 + 8 * (int64_t)prims[k]->Lg && result_stride % 8 == 0, "mg_options_step: result_stride %lld too small for option %d",
                    (long long)result_stride, k);
     }
-    for (int k = 0; k < n_options; k++) {
-        int rc = mg_option_step(prims[k], csets[k], n, counts[k], seeds[k], x_dev[k], xdt, ld[k], errors_dev[k], (char *)results_dev + k * result_stride);
-        if (rc != MG_OK) return rc;
+    // the options are independent chains of three small, launch-latency-bound kernels: four chains run side by side on
+    // streams of the context's own (forked from and joined to its stream with events, so the call keeps stream semantics)
+    const int S = n_options >= 4 ? 4 : 1;
+    if (S > 1 && !ctx->side[0]) {
+        for (auto &st : ctx->side) MG_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto &e : ctx->side_ev) MG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    hipStream_t main_stream = ctx->stream;
+    if (S > 1) {
+        MG_HIP_CHECK(hipEventRecord(ctx->side_ev[4], main_stream));
+        for (int i = 0; i < S; i++) MG_HIP_CHECK(hipStreamWaitEvent(ctx->side[i], ctx->side_ev[4], 0));
+    }
+    int rc = MG_OK;
+    for (int k = 0; k < n_options && rc == MG_OK; k++) {
+        if (S > 1) ctx->stream = ctx->side[k % S];
+        rc = mg_option_step(prims[k], csets[k], n, counts[k], seeds[k], x_dev[k], xdt, ld[k], errors_dev[k], (char *)results_dev + k * result_stride);
+    }
+    ctx->stream = main_stream;
+    if (S > 1) {   // join even after an error: nothing may still be running behind the caller's back
+        for (int i = 0; i < S; i++) {
+            (void)hipEventRecord(ctx->side_ev[i], ctx->side[i]);
+            (void)hipStreamWaitEvent(main_stream, ctx->side_ev[i], 0);
+        }
+    }
+    if (rc != MG_OK) return rc;
     if (results_host) {
         MG_HIP_CHECK(hipMemcpyAsync(results_host, results_dev, (size_t)(n_options * result_stride), hipMemcpyDeviceToHost, ctx->stream));
         MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));

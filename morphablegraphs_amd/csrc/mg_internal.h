@@ -59,6 +59,8 @@ struct mg_context {
     size_t arena_block_bytes = 0;   // > 0 while an arena section is open
     struct vmm_alloc { void *va; size_t total, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
     std::vector<vmm_alloc> vmm;     // buffers from mg_device_malloc_chunked
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // mg_options_step: the options of a step are independent chains of small
+    hipEvent_t side_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // launches; four of them run side by side ([4]: the fork)
     void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
     int dist_rank = 0, dist_ranks = 1;
 };
