@@ -113,48 +113,48 @@ extern "C" int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t m
     int budget = max_candidates > 0 ? max_candidates : 192;
     budget = (int)std::max<int64_t>(1, std::min<int64_t>(budget, (int64_t)(free_b / 2) / bytes));
     const double fast_ratio = ctx->opt[MG_OPT_PLACED_FAST_PCT] > 0 ? ctx->opt[MG_OPT_PLACED_FAST_PCT] / 100.0 : MG_PLACED_FAST_RATIO;
-    std::vector<void *> held;
+    std::vector<void *> held, held_vmm;
     void *best = nullptr;
+    bool best_is_vmm = false;
     double best_ratio = 0.0, best_us = 0.0;
     int probed = 0, rc = MG_OK;
-    for (int i = 0; i < budget; i++) {
-        void *p = nullptr;
-        if (hipMalloc(&p, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); break; }   // out of memory: settle for the best so far
+    auto consider = [&](void *p, bool vmm) -> bool {   // probe p, keep the better of (best, p), hold the other; false: stop
         double ratio = 1.0, us = 0.0;
         rc = mg_probe_placement(ctx, p, bytes, &ratio, &us);
-        if (rc != MG_OK) { (void)hipFree(p); break; }
+        if (rc != MG_OK) { if (vmm) (void)mg_device_free(ctx, p); else (void)hipFree(p); return false; }
         probed++;
         if (!best || ratio < best_ratio) {
-            if (best) held.push_back(best);
-            best = p; best_ratio = ratio; best_us = us;
+            if (best) (best_is_vmm ? held_vmm : held).push_back(best);
+            best = p; best_ratio = ratio; best_us = us; best_is_vmm = vmm;
         } else {
-            held.push_back(p);
+            (vmm ? held_vmm : held).push_back(p);
         }
-        if (best_ratio <= fast_ratio) break;
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    // Second recipe, where no plain allocation was fast (some boxes): buffers assembled from physical chunks through the
-    // virtual-memory API.  Round 1 measured them 5-8 % faster than plain allocations on such a box (not on every one).
-    std::vector<void *> held_vmm;
-    bool best_is_vmm = false;
+        return best_ratio > fast_ratio;
+    };
+    auto plain = [&](int count) {
+        for (int i = 0; i < count; i++) {
+            void *p = nullptr;
+            if (hipMalloc(&p, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); return; }   // out of memory: settle for the best so far
+            if (!consider(p, false)) return;
+        }
+    };
+    // Two recipes.  Plain allocations first (on most boxes the second or third is fast); where sixteen of them were not, twelve
+    // buffers assembled from physical chunks through the virtual-memory API (on some boxes only those are fast: 202 probes
+    // in one measured run, the first fast one a chunked buffer), then the rest of the plain budget.
+    const int first = std::min(budget, 16);
+    plain(first);
     if (best && best_ratio > fast_ratio && rc == MG_OK && max_candidates != 1) {
         static const int64_t chunk_mib[3] = {8, 32, 2};
-        for (int c = 0; c < 3 && best_ratio > fast_ratio; c++)
-            for (int i = 0; i < 4 && best_ratio > fast_ratio; i++) {
+        bool go = true;
+        for (int c = 0; c < 3 && go; c++)
+            for (int i = 0; i < 4 && go; i++) {
                 void *p = nullptr;
-                if (mg_device_malloc_chunked(ctx, bytes, chunk_mib[c] << 20, &p) != MG_OK) { (void)hipGetLastError(); c = 3; break; }
-                double ratio = 1.0, us = 0.0;
-                if (mg_probe_placement(ctx, p, bytes, &ratio, &us) != MG_OK) { (void)mg_device_free(ctx, p); c = 3; break; }
-                probed++;
-                if (ratio < best_ratio) {
-                    if (best_is_vmm) held_vmm.push_back(best); else held.push_back(best);
-                    best = p; best_ratio = ratio; best_us = us; best_is_vmm = true;
-                } else {
-                    held_vmm.push_back(p);
-                }
+                if (mg_device_malloc_chunked(ctx, bytes, chunk_mib[c] << 20, &p) != MG_OK) { (void)hipGetLastError(); go = false; break; }
+                go = consider(p, true);
             }
-        (void)hipStreamSynchronize(ctx->stream);
+        if (rc == MG_OK && best_ratio > fast_ratio) plain(budget - first);
     }
+    (void)hipStreamSynchronize(ctx->stream);
     for (void *p : held) (void)hipFree(p);
     for (void *p : held_vmm) (void)mg_device_free(ctx, p);
     if (!best) {
