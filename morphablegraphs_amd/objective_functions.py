@@ -16,7 +16,8 @@ previous frames and constraints that are not `is_local` every sample is aligned 
 import numpy as np
 
 from . import _capi
-from .candidate_scoring import constraints_to_device_form, cached_constraint_set, alignment_from_prev_frames, group_residuals
+from .candidate_scoring import (constraints_to_device_form, cached_constraint_set, alignment_from_prev_frames, group_residuals,
+                                split_trajectories, cached_trajectory)
 
 
 def _prim_of(motion_primitive):
@@ -45,20 +46,40 @@ def _note(mp_constraints, min_error, n):
         mp_constraints.evaluations += n
 
 
-def _residuals(prim, mp_constraints, S, prev_frames=None):
+def _residuals(prim, mp_constraints, S, prev_frames=None, sums=False):
+    """(n, n_columns) weighted residuals like MotionPrimitiveConstraints.get_residual_vector
+    (motion_primitive_constraints.py:124-144): one column per keyframe residual, then -- the optimizers are invariant to
+    the order -- one column per canonical frame for every trajectory constraint (trajectory_constraint.py:91-115).
+    sums=True: (n,) what MotionPrimitiveConstraints.evaluate adds up (:100-122) -- a keyframe constraint's weighted
+    error, a trajectory constraint's weighted AVERAGE distance (:79-86)."""
     clist = constraints_to_device_form(_constraint_list(mp_constraints))
     if len(clist) == 0:
-        return np.zeros((len(S), 0))
+        return np.zeros(len(S)) if sums else np.zeros((len(S), 0))
     skeleton = getattr(mp_constraints, "hip_skeleton", None)
-    cset = cached_constraint_set(prim, clist, skeleton, alignment_from_prev_frames(prev_frames, mp_constraints, skeleton))
-    return group_residuals(clist, prim.score_constraint_residuals(cset, S))
+    alignment = alignment_from_prev_frames(prev_frames, mp_constraints, skeleton)
+    keyframes, trajectories = split_trajectories(clist)
+    if trajectories and alignment is not None and alignment.get("joint", 0) not in (0, _capi.MG_ALIGN_START_POSE):
+        raise NotImplementedError("trajectory constraints in global coordinates need the root joint as aligning node")
+    blocks, total = [], np.zeros(len(S))
+    if keyframes:
+        cset = cached_constraint_set(prim, keyframes, skeleton, alignment)
+        res = group_residuals(keyframes, prim.score_constraint_residuals(cset, S))
+        blocks.append(res)
+        total = total + res.sum(axis=1)
+    for c in trajectories:
+        err, res = prim.score_trajectory(cached_trajectory(prim, c), S, c.get("min_u", 0.0), c.get("weight", 1.0), alignment, residuals=True)
+        blocks.append(res)
+        total = total + err
+    if sums:
+        return total
+    return np.hstack(blocks) if blocks else np.zeros((len(S), 0))
 
 
 def obj_spatial_error_sum(s, data):
     """objective_functions.py:141-159: MotionPrimitiveConstraints.evaluate per sample -> (n,) (float for 1-D s)."""
     motion_primitive, mp_constraints, prev_frames = data[:3]
     S, single = _batch(s)
-    err = _residuals(_prim_of(motion_primitive), mp_constraints, S, prev_frames).sum(axis=1)
+    err = _residuals(_prim_of(motion_primitive), mp_constraints, S, prev_frames, sums=True)
     _note(mp_constraints, float(err[-1]) if len(err) else 0.0, len(S))
     return float(err[0]) if single else err
 
@@ -77,7 +98,7 @@ def obj_spatial_error_sum_and_naturalness(s, data):
     motion_primitive, mp_constraints, prev_frames, error_scale, quality_scale = data[0], data[1], data[2], data[-3], data[-2]
     S, single = _batch(s)
     prim = _prim_of(motion_primitive)
-    spatial = _residuals(prim, mp_constraints, S, prev_frames).sum(axis=1)
+    spatial = _residuals(prim, mp_constraints, S, prev_frames, sums=True)
     _note(mp_constraints, float(spatial[-1]) if len(spatial) else 0.0, len(S))
     err = error_scale * spatial + (-prim.gmm_log_prob(S.astype(np.float64))) * quality_scale
     return float(err[0]) if single else err
@@ -93,7 +114,7 @@ def spatial_error_jac(s, data, epsilon=1e-7):
     n, L = S.shape
     pert = np.repeat(S[:, None, :], L + 1, axis=1)           # (n, L+1, L): row 0 unperturbed
     pert[:, np.arange(1, L + 1), np.arange(L)] += epsilon
-    f = _residuals(_prim_of(motion_primitive), mp_constraints, pert.reshape(n * (L + 1), L), prev_frames).sum(axis=1).reshape(n, L + 1)
+    f = _residuals(_prim_of(motion_primitive), mp_constraints, pert.reshape(n * (L + 1), L), prev_frames, sums=True).reshape(n, L + 1)
     if hasattr(mp_constraints, "evaluations"):
         mp_constraints.evaluations += n * (L + 1)
     jac = (f[:, 1:] - f[:, :1]) / epsilon

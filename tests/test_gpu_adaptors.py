@@ -936,6 +936,54 @@ def test_candidate_loop_with_a_trajectory_constraint():
     clear_constraint_cache()
 
 
+def test_objective_functions_with_a_trajectory_constraint():
+    """The batched objectives with a trajectory constraint in the list: obj_spatial_error_sum adds its weighted AVERAGE
+    distance (MotionPrimitiveConstraints.evaluate -> evaluate_motion_spline, trajectory_constraint.py:79-86), the
+    residual-vector objectives get its per-frame weighted distances as further columns
+    (get_residual_vector_spline, :88-115) after the keyframe columns, zero padding and init_error_sum as for keyframes."""
+    from oracle import mg_oracle as orc
+    from morphablegraphs_amd import objective_functions as of
+    from morphablegraphs_amd.candidate_scoring import clear_constraint_cache
+    data = _path_following_model()
+    mp = _primitive(data)
+    op = orc.OraclePrimitive(data)
+    rng = np.random.default_rng(10)
+    S = rng.standard_normal((9, 40))
+    cps = op.back_project_frames(S[2])[::31, :3].copy()
+    keyframe = {"type": "position", "t": 155.0, "weight": 2.0, "target": [float(cps[-1][0]), None, float(cps[-1][2])]}
+    traj = {"type": "trajectory", "control_points": cps, "min_u": 0.0, "weight": 0.5}
+    class Constraints(object):                               # MotionPrimitiveConstraints' attributes the objectives touch
+        constraints = [keyframe, traj]
+        is_local = True
+        min_error = 0.0
+        evaluations = 0
+    cons = Constraints()
+    kf = op.keyframe_errors(S, [keyframe])
+    walks = []
+    for b in range(len(S)):
+        min_u, walk = 0.0, []
+        for p in op.back_project_frames(S[b])[:, :3]:
+            pt, min_u = orc.closest_point_walk(cps, p, min_u)
+            walk.append(np.linalg.norm(p - pt))
+        walks.append(0.5 * np.array(walk))
+    walks = np.array(walks)
+    err = of.obj_spatial_error_sum(S, (mp, cons, None))
+    np.testing.assert_allclose(err, kf + walks.mean(axis=1), rtol=1e-8)
+    assert cons.evaluations == len(S) and abs(cons.min_error - err[-1]) < 1e-12
+    res = of.obj_spatial_error_residual_vector(S, (mp, cons, None, 1.0, 1.0, 4.0))
+    assert res.shape == (9, 1 + 156)
+    np.testing.assert_allclose(res[:, 0], kf / 4.0, rtol=1e-8)
+    np.testing.assert_allclose(res[:, 1:], walks / 4.0, rtol=1e-8, atol=1e-9)
+    one = of.obj_spatial_error_residual_vector(S[4], (mp, cons, None, 1.0, 1.0, 4.0))
+    np.testing.assert_array_equal(one, res[4])
+    nat = of.obj_spatial_error_residual_vector_and_naturalness(S, (mp, cons, None, 3.0, 0.25, 2.0))
+    nll = -mp.gaussian_mixture_model.score_samples(S) * 0.25
+    np.testing.assert_allclose(nat[:, 1:], (walks * 3.0 + nll[:, None]) / 2.0, rtol=1e-8, atol=1e-9)
+    jac = of.spatial_error_jac(S[:2], (mp, cons, None))
+    assert jac.shape == (2, 40) and np.all(np.isfinite(jac))
+    clear_constraint_cache()
+
+
 def test_euclidean_feature_map_of_the_cluster_tree_builder():
     """The feature map under FeatureClusterTree construction (reference cluster_tree_builder.py:266-301 ->
     space_partitioning/features.py:125-153): every sample back-projected at the integer canonical frames, the global
