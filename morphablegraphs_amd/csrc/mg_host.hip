@@ -1854,6 +1854,13 @@ extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int6
     return rc;
 }
 
+static int mg_ctx_side_streams(mg_context *ctx) {
+    if (ctx->side[0]) return MG_OK;
+    for (auto &st : ctx->side) MG_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &e : ctx->side_ev) MG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return MG_OK;
+}
+
 // All outgoing options of a planner step in one call: mg_option_step for each (the primitives share one context, so
 // one stream), their result records side by side in results_dev (record k at k * result_stride bytes), then -- if
 // results_host is given -- ONE copy back and ONE synchronisation for the whole step.
@@ -1870,9 +1877,9 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
     // the options are independent chains of three small, launch-latency-bound kernels: four chains run side by side on
     // streams of the context's own (forked from and joined to its stream with events, so the call keeps stream semantics)
     const int S = n_options >= 4 ? 4 : 1;
-    if (S > 1 && !ctx->side[0]) {
-        for (auto &st : ctx->side) MG_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        for (auto &e : ctx->side_ev) MG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (S > 1) {
+        int rcs = mg_ctx_side_streams(ctx);
+        if (rcs != MG_OK) return rcs;
     }
     hipStream_t main_stream = ctx->stream;
     if (S > 1) {
