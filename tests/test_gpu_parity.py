@@ -1116,8 +1116,31 @@ def test_c_abi_rejects_misuse_with_status_codes_not_crashes(ctx):
         c.update(kw)
         with pytest.raises(_capi.MGError):
             _capi.ConstraintSet(prim_b, [c])
+    # round-2 entry points
+    i4, d4 = (C.c_int32 * 4)(), (C.c_double * 4)()
+    bad(lib.mg_step_plan(null, 8192, i4), "NULL primitive (step plan)")
+    bad(lib.mg_step_plan(prim_b.handle, -1, i4), "negative batch (step plan)")
+    bad(lib.mg_context_set_option(ctx.handle, _capi.MG_OPT_COUNT, 1), "unknown option")
+    bad(lib.mg_device_probe_placement(ctx.handle, d_out.ptr, 4 * 156 * 79 * 4, d4), "probe of a small buffer")
+    bad(lib.mg_device_malloc_placed(null, 1 << 28, 0, C.byref(h), d4), "NULL context (placed malloc)")
+    bad(lib.mg_time_function_canonical(prim_b.handle, d_S.ptr, 0, 4, 40, d_out.ptr), "time function of a primitive without a time model")
+    bad(lib.mg_joint_positions(ctx.handle, null, null, 1, d_out.ptr, 4, 79, d_out.ptr), "NULL skeleton")
+    cps = np.zeros((1, 3))
+    bad(lib.mg_trajectory_create(prim_b.handle, cps.ctypes.data_as(vp), 1, 1000, C.byref(h)), "trajectory of one control point")
+    cps = np.array([[0.0, 0.0, 0.0], [np.nan, 0.0, 1.0]])
+    bad(lib.mg_trajectory_create(prim_b.handle, cps.ctypes.data_as(vp), 2, 1000, C.byref(h)), "NaN control point")
+    bad(lib.mg_score_trajectory(prim_b.handle, null, null, d_S.ptr, 0, 4, 40, 0.0, 1.0, null, d_out.ptr, 0, null), "NULL trajectory")
+    cs_b = _capi.ConstraintSet(prim_b, [{"type": "position", "t": 1.0, "weight": 1.0, "target": [0.0, 0.0, 0.0]}])
+    one = lambda v: (vp * 1)(v)   # noqa: E731
+    cnt = np.array([4, 0, 0, 0, 0, 0, 0, 0], dtype=np.int64)
+    seeds, lds = (C.c_uint64 * 1)(1), (C.c_int64 * 1)(40)
+    ok_args = (1, one(prim_b.handle), one(cs_b.handle), 4, one(cnt.ctypes.data), seeds, one(d_S.ptr.value), 0, lds, one(d_out.ptr.value), d_out.ptr)
+    bad(lib.mg_options_step(*ok_args, 16 + 8 * 40 - 8, null), "result stride too small")
+    bad(lib.mg_options_step(0, *ok_args[1:], 16 + 8 * 40, null), "no options")
+    bad(lib.mg_options_step(1, one(None), *ok_args[2:], 16 + 8 * 40, null), "NULL option")
     # and the library still works afterwards
     assert prim_b.back_project_frames(S).shape == (4, 156, 79)
+    cs_b.close()
     cs_a.close()
     prim_a.close()
     prim_b.close()
