@@ -245,8 +245,8 @@ int mg_device_malloc_chunked(mg_context *ctx, int64_t bytes, int64_t chunk_bytes
  * kernel can choose -- base offset, stride, unit order -- changes the class ("Placement").  So the
  * library probes: it allocates a candidate, times the store pattern and a plain fill on it (about 1 ms), keeps the
  * first candidate whose ratio is in the fast class, holds the rejected ones until then (so that the next candidate
- * comes from other memory) and frees them.  max_candidates <= 0: a default budget (up to 512 candidates, never
- * more than three quarters of the free device memory; ~1.5 ms per candidate); where the first sixteen are not fast (and max_candidates != 1) twelve are
+ * comes from other memory) and frees them.  max_candidates <= 0: a default budget (up to 768 candidates, never
+ * more than nine tenths of the free device memory; ~1.5 ms per candidate); where the first sixteen are not fast (and max_candidates != 1) twelve are
  * assembled from physical chunks of 8 / 32 / 2 MiB through the virtual-memory API -- on some boxes only those are fast --
  * before the rest of the budget; if nothing is fast the best candidate of all is returned.  info (may be NULL):
  * [0] candidates probed, [1] pattern time / fill time of the buffer returned, [2] its pattern time in us,

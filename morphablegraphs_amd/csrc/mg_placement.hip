@@ -110,10 +110,11 @@ extern "C" int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t m
     if (bytes < MG_PLACED_MIN_BYTES) return mg_device_malloc(ctx, bytes, out_dev);
     size_t free_b = 0, total_b = 0;
     MG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    // default budget: up to 512 candidates in three quarters of the free memory (a probe takes ~1.5 ms; on the boxes where fast
-    // regions are rare the first fast candidate has been the 13th, the 22nd, the 202nd)
-    int budget = max_candidates > 0 ? max_candidates : 512;
-    budget = (int)std::max<int64_t>(1, std::min<int64_t>(budget, (int64_t)(free_b / 4 * 3) / bytes));
+    // default budget: up to 768 candidates in nine tenths of the free memory, i.e. a scan of nearly the whole card when it
+    // has to be (a probe takes ~1.5 ms; on the boxes where fast regions are rare the first fast candidate has been the 13th,
+    // the 22nd, the 202nd)
+    int budget = max_candidates > 0 ? max_candidates : 768;
+    budget = (int)std::max<int64_t>(1, std::min<int64_t>(budget, (int64_t)(free_b / 10 * 9) / bytes));
     const double fast_ratio = ctx->opt[MG_OPT_PLACED_FAST_PCT] > 0 ? ctx->opt[MG_OPT_PLACED_FAST_PCT] / 100.0 : MG_PLACED_FAST_RATIO;
     std::vector<void *> held, held_vmm;
     void *best = nullptr;
