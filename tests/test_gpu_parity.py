@@ -630,6 +630,33 @@ def test_step_plan_names_what_a_step_launches(ctx):
     timed.close()
 
 
+def test_large_batches_of_every_golden_shape_take_the_same_bits_through_either_kernel(ctx, golden_case):
+    """At a batch size where the library picks the chunk-stationary kernel by itself (other numbers of latent components:
+    other template instances, other register budgets, other chunk plans): frames and fused log p(x) of 6000 + 3
+    candidates, library's choice against the tile-major kernel forced, the first rows against the oracle's f32 model."""
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    if not prim.mfma_supported:
+        prim.close()
+        pytest.skip("no LDS-staged kernel for this shape")
+    cp = c_oracle.COraclePrimitive(data)
+    L = g["S"].shape[1]
+    F, D = int(data["n_canonical_frames"]), int(data["n_dim_spatial"])
+    S = np.random.default_rng(17).standard_normal((6003, L)).astype(np.float32)
+    plan = prim.step_plan(len(S))
+    _set_frames_kernel(ctx, 0)
+    auto = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+    _set_frames_kernel(ctx, 1)
+    tm = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+    np.testing.assert_array_equal(_bits(auto), _bits(tm), err_msg="%s (%s)" % (name, plan["kernel"]))
+    np.testing.assert_array_equal(_bits(auto[:200]), _bits(cp.frames_f32model(S[:200].astype(np.float64))))
+    _set_frames_kernel(ctx, 0)
+    frames, logp = _fused_step(ctx, prim, S, F, D)
+    np.testing.assert_array_equal(_bits(frames), _bits(tm))
+    np.testing.assert_array_equal(_bits(logp), _bits(prim.gmm_log_prob(S, dtype=np.float32)))
+    prim.close()
+
+
 def test_two_slot_ring(ctx):
     """Shapes whose three LDS slots do not fit 160 KiB run a two-slot ring; mg_context_set_option(MG_OPT_RING_SLOTS, 2) forces it on 'walk' (the
     planner reads it when a grid is built).  Carried-over tiles then need a full meeting of the row producers per
