@@ -204,7 +204,7 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_CHUNK_WINDOW       n = at most n basis functions per time-chunk window (4 .. 11)
  *   MG_OPT_CHUNK_SAMPLES      n = at most n time samples per chunk (1 .. 48)
  *   MG_OPT_FRAMES_KERNEL      which LDS-staged frames kernel the MFMA path launches: 0 = by batch size (chunk-stationary
- *                             from three units per workgroup on), 1 = tile-major (units of one tile's consecutive chunks,
+ *                             from two units per workgroup on), 1 = tile-major (units of one tile's consecutive chunks,
  *                             rows shared by neighbouring chunks carried over), 2 = chunk-stationary (a workgroup keeps one
  *                             chunk's eigenvector window in registers; MG_ERR_UNSUPPORTED where the window does not fit)
  *                             -- identical results 

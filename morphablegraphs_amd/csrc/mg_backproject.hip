@@ -826,7 +826,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
 
 
 // -----------------------------------------------------------------------------------------
-// The chunk-stationary variant of the hot-path kernel, for batches of many tiles per CU (the default from three
+// The chunk-stationary variant of the hot-path kernel, for batches of many tiles per CU (the default from two
 // units per workgroup on; DESIGN.md section 4.1 has the measurements behind every statement here).
 //
 // The tile-major kernel above ended with its row producers 88 % busy and the sweep waiting for them; 9-13 us of its
@@ -1608,9 +1608,9 @@ bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_
 
 // Which of the two LDS-staged kernels a launch over B candidates uses (1 = tile-major, 2 = chunk-stationary; -1 = the
 // chunk-stationary one was asked for by option and does not cover the shape): the chunk-stationary one once every workgroup
-// gets at least three units out of the one-time load of its chunk's eigenvector window (B = 8192, 'walk', same box and
-// buffer, three boxes: 81.0 / 81.0 / 80.9 us per step against 83.3 / 83.7 / 82.9 for the tile-major kernel), the
-// tile-major one for smaller batches.
+// gets at least two units out of the one-time load of its chunk's eigenvector window ('walk', same box and buffer, us per
+// step, tile-major / chunk-stationary: B = 1024 18.9 / 18.9, 2048 26.6 / 25.7, 4096 45.4 / 43.8, 6144 65.0 / 61.8,
+// 8192 83.3 / 81.0 before the start-up work and 87.4 / 81-83 after it), the tile-major one for smaller batches.
 int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t units = n_tiles * g->n_chunks;
@@ -1621,7 +1621,7 @@ int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_
               (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
     if (want == 2 && !cs) return -1;
     if (want == 1) cs = false;
-    else if (want == 0) cs = cs && units >= 3 * grid0;
+    else if (want == 0) cs = cs && units >= 2 * grid0;
     return cs ? 2 : 1;
 }
 int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int which) {

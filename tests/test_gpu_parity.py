@@ -611,7 +611,7 @@ def test_chunk_stationary_kernel_on_the_golden_shapes_and_other_grids(ctx, golde
 
 
 def test_step_plan_names_what_a_step_launches(ctx):
-    """mg_step_plan: small batches on the tile-major kernel, from three units per workgroup on the chunk-stationary one
+    """mg_step_plan: small batches on the tile-major kernel, from two units per workgroup on the chunk-stationary one
     (whole workgroups per chunk), log p(x) inside the frames kernel for 'walk'; the option overrides the choice; a
     mixture over spatial AND time latents is scored by a second launch."""
     prim = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
