@@ -209,7 +209,9 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *                             chunk's eigenvector window in registers; MG_ERR_UNSUPPORTED where the window does not fit)
  *                             -- identical results 
  *   MG_OPT_PLACED_FAST_PCT    mg_device_malloc_placed: pattern / fill ratio (in percent) up to which a candidate counts as
- *                             fast (0 = 115); tests lower it to walk through both recipes */
+ *                             fast (0 = 115); tests lower it to walk through both recipes
+ *   MG_OPT_OPTIONS_STEP       mg_options_step: 0 = one launch for the whole step where every option allows it, 1 = always one
+ *                             chain of launches per option (identical results; tests compare the two) */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
@@ -217,7 +219,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_CHUNK_SAMPLES 4
 #define MG_OPT_FRAMES_KERNEL 5
 #define MG_OPT_PLACED_FAST_PCT 6
-#define MG_OPT_COUNT 7
+#define MG_OPT_OPTIONS_STEP 7
+#define MG_OPT_COUNT 8
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
@@ -262,7 +265,7 @@ int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);
  * n-th launch of each slot with an event pair (n = 1: every launch; an event pair costs a few
  * microseconds of stream time, so a timed region samples with n ~ 8); totals are resolved on query.
  * slot: 0 = back_project_frames, 1 = gmm_log_prob, 2 = score_constraints, 3 = argmin,
- *       4 = gmm_sample, 5 = spline_evaluate, 6 = fused step. */
+ *       4 = gmm_sample, 5 = spline_evaluate, 6 = fused step, 7 = a planner step in one launch (mg_options_step). */
 int mg_profile_enable(mg_context *ctx, int enabled);
 int mg_profile_reset(mg_context *ctx);
 int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64_t *launches);

@@ -124,3 +124,19 @@ __device__ __forceinline__ double mg_gmm_logsumexp(const mg_lds_f64 *terms, cons
     for (int k = 0; k < K; k++) acc += exps[k * 16 + c];
     return log(acc) + vmax;
 }
+
+// Philox4x32-10 (the device sampler's counter-based generator): counter (c0..c3), key (k0, k1) -> four 32-bit draws
+__device__ __forceinline__ void mg_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1, uint32_t *out) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+        uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+

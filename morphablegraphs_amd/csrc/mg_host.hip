@@ -128,6 +128,7 @@ extern "C" int mg_context_create(int device, void *stream, mg_context **out) {
     e = hipMalloc(&ctx->argmin_out, 16);
     if (e != hipSuccess) { mg_context_destroy(ctx); return mg_hip_fail(e, "hipMalloc"); }
     int rc = mg_setup_kernel_attributes(ctx);
+    if (rc == MG_OK) rc = mg_options_fused_attributes();
     if (rc != MG_OK) { mg_context_destroy(ctx); return rc; }
     *out = ctx;
     return MG_OK;
@@ -145,6 +146,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     for (auto &e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
+    for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials}) if (q) (void)hipFree(q);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
     for (auto &v : ctx->vmm) mg_vmm_release(v);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1874,9 +1876,38 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
         MG_REQUIRE(result_stride >= 16 + 8 * (int64_t)prims[k]->Lg && result_stride % 8 == 0, "mg_options_step: result_stride %lld too small for option %d",
                    (long long)result_stride, k);
     }
-    // the options are independent chains of three small, launch-latency-bound kernels: four chains run side by side on
-    // streams of the context's own (forked from and joined to its stream with events, so the call keeps stream semantics)
-    const int S = n_options >= 4 ? 4 : 1;
+    { int rc0 = mg_use_device(ctx); if (rc0 != MG_OK) return rc0; }
+    for (int k = 0; k < n_options; k++) {
+        MG_REQUIRE(csets[k] && csets[k]->prim == prims[k], "mg_options_step: constraint set %d is NULL or belongs to another primitive", k);
+        MG_REQUIRE(n > 0 && counts[k] && x_dev[k] && errors_dev[k] && ld[k] >= prims[k]->Lg, "mg_options_step: bad arguments for option %d", k);
+    }
+    MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_options_step: bad dtype %d", xdt);
+    // One launch for the whole step where every option runs on the matrix-pipe sampler and scorer (mg_options.hip);
+    // more than MG_FUSED_MAX_OPTIONS options go in groups.
+    {
+        bool fused = true;
+        for (int k0 = 0; k0 < n_options && fused; k0 += 24) fused = mg_options_can_fuse(std::min(24, n_options - k0), prims + k0, csets + k0, n);
+        if (fused) {
+            for (int k0 = 0; k0 < n_options; k0 += 24) {
+                int rcf = mg_launch_options_fused(std::min(24, n_options - k0), prims + k0, csets + k0, n, counts + k0, seeds + k0, x_dev + k0, xdt, ld + k0,
+                                                  errors_dev + k0, (char *)results_dev + (size_t)k0 * result_stride, result_stride);
+                if (rcf != MG_OK) return rcf;
+            }
+            if (results_host) {
+                MG_HIP_CHECK(hipMemcpyAsync(results_host, results_dev, (size_t)(n_options * result_stride), hipMemcpyDeviceToHost, ctx->stream));
+                MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            }
+            return MG_OK;
+        }
+    }
+    // Otherwise the options are independent chains of three small, launch-latency-bound kernels: four chains run side by side
+    // on streams of the context's own (forked from and joined to its stream with events, so the call keeps stream semantics)
+    // -- unless an option's sampler stages its prefix sums in the context's ONE scratch buffer (more than MG_SAMPLE_ARG_K
+    // components, more than 64 mixture dimensions, or the VALU sampler forced): chains on different streams would overwrite
+    // that buffer under each other, so those steps stay on one stream.
+    bool shared_scratch = false;
+    for (int k = 0; k < n_options; k++) shared_scratch = shared_scratch || !mg_gmm_sample_takes_host_prefix(prims[k]);
+    const int S = (n_options >= 4 && !shared_scratch) ? 4 : 1;
     if (S > 1) {
         int rcs = mg_ctx_side_streams(ctx);
         if (rcs != MG_OK) return rcs;

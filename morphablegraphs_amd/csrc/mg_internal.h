@@ -61,6 +61,12 @@ struct mg_context {
     std::vector<vmm_alloc> vmm;     // buffers from mg_device_malloc_chunked
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // mg_options_step: the options of a step are independent chains of small
     hipEvent_t side_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // launches; four of them run side by side ([4]: the fork)
+    // mg_options_step as one launch (mg_options.hip): the per-option constants on the device and their host copy, the
+    // per-option arrival counters and one {value, index} partial per workgroup
+    void *fused_tab_dev = nullptr;
+    std::vector<unsigned char> fused_tab_host;
+    void *fused_counters = nullptr, *fused_partials = nullptr;
+    int fused_partials_n = 0;
     void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
     int dist_rank = 0, dist_ranks = 1;
 };
@@ -207,6 +213,11 @@ int mg_launch_time_function(mg_primitive *p, const void *gamma, int gdt, int64_t
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
 int mg_launch_joint_positions(mg_context *ctx, const double *frames, const double *table, int64_t N, int D, int J, double *out);
 int mg_setup_kernel_attributes(mg_context *ctx);
+int mg_options_fused_attributes();   // mg_options.hip
+bool mg_options_can_fuse(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n);
+int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
+                            const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
+                            double *const *errors_dev, void *results_dev, int64_t result_stride);
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us);   // mg_placement.hip
 
 // host-side float64 spline basis (FITPACK splev/fpbspl semantics)

@@ -1,0 +1,298 @@
+// One launch per planner step (gfx950 / MI355X).
+//
+// GraphWalkPlanner evaluates every outgoing option of a node the same way (reference
+// morphablegraphs/motion_generator/graph_walk_planner.py:184-226): draw n candidates from the option's mixture, score
+// them against the step's constraints, keep the first minimum.  Option by option that is three launch-latency-bound
+// kernels each (sampler, scorer, argmin + winner copy): 48 launches for a 16-option step, the GPU idle most of the time.
+// mg_options_fused_kernel does the whole step in ONE launch:
+//   * the workgroups are dealt over the options (option k owns workgroups wg0[k] .. wg0[k+1]); a wave owns one 16-row tile
+//     of ONE mixture component, exactly the tiles of mg_gmm_sample_mfma_kernel (same Philox counters, same f64 MFMA chain:
+//     the candidates are the same bits), keeps the tile in LDS and scores it right there with the arithmetic of
+//     mg_score_mfma_kernel (channels by f64 MFMA with C-in = bias, residuals by mg_constraint_residual, summed in
+//     constraint order: the errors are the same bits);
+//   * first minimum: lanes -> wave (shuffles) -> workgroup (LDS) -> one partial {value, index} per workgroup in global
+//     memory; the workgroup whose arrival is the last of its option (agent-scope release / counter / acquire) reduces the
+//     option's partials, writes {index, error} and copies the winning latent behind them.  (value, index) pairs are
+//     combined with a total order -- smaller value, then smaller index, NaN and +inf never win -- so the order of the
+//     combination does not matter and the result is the one mg_argmin_gather_kernel finds.
+// Per-step values (seeds, rows per component) travel in the kernel arguments; the per-option constants (fragment and
+// constraint tables, buffers) sit in a small device table that is rewritten only when an option's pointers change.
+#include <algorithm>
+#include <cstring>
+
+#include "mg_internal.h"
+#include "mg_gmm_device.h"
+#include "mg_score_device.h"
+
+#define MG_FUSED_MAX_OPTIONS 24
+
+struct mg_fused_static {          // one option: what stays the same from step to step
+    const double *cpack;          // sampler: [K][JT][KKg][64] fragments of chol^T
+    const double *meanpad;        //          [K][JT*16]
+    const double *Wpack;          // scorer:  [RT][KK][64]
+    const double *bpad;           //          [RT*16]
+    mg_score_args sa;             // constraint tables; sa.out = errors (n) float64, sa.B = n, sa.ld = ld of x
+    void *x;                      // (n, ld) candidates, written
+    void *result;                 // {int64 index, float64 error, float64 latent[Lg]}
+    int32_t K, Lg, KKg, KK, JT, RT;
+};
+
+struct mg_fused_dyn {             // one step: what changes every time (kernel argument)
+    uint64_t seed[MG_FUSED_MAX_OPTIONS];
+    int32_t counts[MG_FUSED_MAX_OPTIONS][MG_SAMPLE_ARG_K];
+    int32_t wg0[MG_FUSED_MAX_OPTIONS + 1];
+};
+
+struct mg_fused_partial { double v; int64_t i; };
+
+template <bool X_F64>
+__global__ __launch_bounds__(256) void mg_options_fused_kernel(const mg_fused_static *__restrict__ tab, const mg_fused_dyn dyn,
+                                                              const int n_options, const int wave_doubles,
+                                                              mg_fused_partial *__restrict__ partials, int32_t *__restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, g = lane >> 4;
+    const int wg = blockIdx.x;
+    int k = 0;
+    while (k + 1 < n_options && wg >= dyn.wg0[k + 1]) k++;
+    const mg_fused_static &o = tab[k];
+    const int K = o.K, Lg = o.Lg, KKg = o.KKg, KK = o.KK, JT = o.JT, RT = o.RT, L = o.sa.L, n = o.sa.n;
+    const int64_t ld = o.sa.ld;
+    const int ZS = 4 * KKg + 1, vs = RT * 16 + 1;
+    double *zt = (double *)smem + (size_t)wave * wave_doubles;   // [16][ZS] standard normals, then the candidates of the tile
+    double *vals = zt + 16 * ZS;                                  // [16][vs] pose channels of the tile
+    double *resid = vals + 16 * vs;                               // [n][16]
+
+    // this wave's tile: rows [row0, row0 + nrow) of component c (rows grouped by component, tiles never straddle two)
+    const int64_t t = (int64_t)(wg - dyn.wg0[k]) * 4 + wave;
+    int c = 0;
+    int64_t row_c = 0, tile_c = 0, rows_next, tiles_next;
+    for (;;) {
+        const int cnt = dyn.counts[k][c];
+        rows_next = row_c + cnt;
+        tiles_next = tile_c + (cnt + 15) / 16;
+        if (c + 1 < K && t >= tiles_next) { c++; row_c = rows_next; tile_c = tiles_next; }
+        else break;
+    }
+    const bool active = t < tiles_next;
+    double best = INFINITY;
+    int64_t bi = INT64_MAX;
+    if (active) {
+        const int64_t row0 = row_c + (t - tile_c) * 16;
+        const int nrow = (int)((rows_next - row0) < 16 ? (rows_next - row0) : 16);
+        const uint64_t seed = dyn.seed[k];
+        for (int e = lane; e < 16 * KKg; e += 64) {
+            const int r = e & 15, q = e >> 4;
+            const int64_t b = row0 + r;
+            uint32_t rr[4];
+            mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)q, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+            const double inv = 1.0 / 4294967296.0;
+            const double u0 = ((double)rr[0] + 1.0) * inv, u1 = (double)rr[1] * inv;
+            const double u2 = ((double)rr[2] + 1.0) * inv, u3 = (double)rr[3] * inv;
+            const double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
+            zt[r * ZS + 4 * q + 0] = m0 * cos(2.0 * M_PI * u1);
+            zt[r * ZS + 4 * q + 1] = m0 * sin(2.0 * M_PI * u1);
+            zt[r * ZS + 4 * q + 2] = m1 * cos(2.0 * M_PI * u3);
+            zt[r * ZS + 4 * q + 3] = m1 * sin(2.0 * M_PI * u3);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double za[MG_MAX_KK];
+#pragma unroll
+        for (int kk = 0; kk < MG_MAX_KK; kk++) za[kk] = (kk < KKg && 4 * kk + g < Lg) ? zt[cl * ZS + 4 * kk + g] : 0.0;
+        // x = mu + z L^T; the tile goes to memory in the caller's type and stays in LDS, rounded the same way, for the scorer
+#pragma unroll
+        for (int it = 0; it < MG_MAX_KK / 4; it++) {
+            if (it < JT) {
+                const double *cp = o.cpack + (((size_t)c * JT + it) * KKg) * 64 + lane;
+                const double m = o.meanpad[((size_t)c * JT + it) * 16 + cl];
+                mg_f64x4 acc = {m, m, m, m};
+#pragma unroll
+                for (int kk = 0; kk < MG_MAX_KK; kk++)
+                    if (kk < KKg && kk < 4 * (it + 1)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[kk], cp[kk * 64], acc, 0, 0, 0);
+                const int i = 16 * it + cl;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = g + 4 * r;
+                    if (i < Lg) {
+                        const double xv = X_F64 ? acc[r] : (double)(float)acc[r];
+                        zt[row * ZS + i] = xv;
+                        if (row < nrow) {
+                            if (X_F64) ((double *)o.x)[(row0 + row) * ld + i] = acc[r];
+                            else ((float *)o.x)[(row0 + row) * ld + i] = (float)acc[r];
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // pose channels of the tile: X (16 x L) . W^T + bias on the f64 matrix pipe
+        double xf[MG_MAX_KK];
+#pragma unroll
+        for (int kk = 0; kk < MG_MAX_KK; kk++) xf[kk] = (kk < KK && 4 * kk + g < L && cl < nrow) ? zt[cl * ZS + 4 * kk + g] : 0.0;
+        for (int rt = 0; rt < RT; rt++) {
+            const double *wp = o.Wpack + ((size_t)rt * KK) * 64 + lane;
+            const double c0 = o.bpad[rt * 16 + cl];
+            mg_f64x4 acc = {c0, c0, c0, c0};
+#pragma unroll
+            for (int kk = 0; kk < MG_MAX_KK; kk++)
+                if (kk < KK) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[kk], wp[kk * 64], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) vals[(g + 4 * r) * vs + rt * 16 + cl] = acc[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int e = lane; e < 16 * n; e += 64) {
+            const int cand = e & 15, cc = e >> 4;
+            const double *v = vals + cand * vs;
+            resid[cc * 16 + cand] = mg_constraint_residual(o.sa, cc, [&](int row) { return v[row]; });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < nrow) {
+            double err = 0.0;
+            for (int cc = 0; cc < n; cc++) err += resid[cc * 16 + lane];
+            ((double *)o.sa.out)[row0 + lane] = err;
+            if (err < INFINITY) { best = err; bi = row0 + lane; }   // NaN and +inf never win
+        }
+    }
+    // first minimum of the workgroup
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const long long oi = __shfl_down((long long)bi, off, 64);
+        mg_min_combine(best, bi, ov, (int64_t)oi);
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's candidates and errors have left the CU
+    __syncthreads();
+    const int nwg = dyn.wg0[k + 1] - dyn.wg0[k];
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) mg_min_combine(best, bi, sv[w], si[w]);
+        partials[wg].v = best;
+        partials[wg].i = bi;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(&counters[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == nwg - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the option's last workgroup: every other one has published its partial and its candidates
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    best = INFINITY; bi = INT64_MAX;
+    for (int w = tid; w < nwg; w += 256) {
+        const mg_fused_partial p = partials[dyn.wg0[k] + w];
+        mg_min_combine(best, bi, p.v, p.i);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const long long oi = __shfl_down((long long)bi, off, 64);
+        mg_min_combine(best, bi, ov, (int64_t)oi);
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) mg_min_combine(best, bi, sv[w], si[w]);
+        if (bi == INT64_MAX) { bi = 0; best = INFINITY; }
+        ((int64_t *)o.result)[0] = bi;
+        ((double *)o.result)[1] = best;
+        si[0] = bi;
+        counters[k] = 0;   // ready for the next launch (stream ordered)
+    }
+    __syncthreads();
+    const int64_t idx = si[0];
+    double *row = (double *)((char *)o.result + 16);
+    for (int i = tid; i < Lg; i += 256)
+        row[i] = X_F64 ? ((const double *)o.x)[idx * ld + i] : (double)((const float *)o.x)[idx * ld + i];
+}
+
+int mg_options_fused_attributes() {
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    return MG_OK;
+}
+
+// Can this step run as one launch?  Every option on the MFMA sampler (prefix sums in the arguments) and the MFMA scorer.
+bool mg_options_can_fuse(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n) {
+    if (n_options < 1 || n_options > MG_FUSED_MAX_OPTIONS || n < 1 || n > (int64_t)1 << 30) return false;
+    mg_context *ctx = prims[0]->ctx;
+    if (ctx->opt[MG_OPT_FORCE_VALU_SAMPLE] || ctx->opt[MG_OPT_FORCE_VALU_SCORE] || ctx->opt[MG_OPT_OPTIONS_STEP] == 1) return false;
+    for (int k = 0; k < n_options; k++) {
+        const mg_primitive *p = prims[k];
+        const mg_constraint_set *cs = csets[k];
+        if (!mg_gmm_sample_takes_host_prefix(p) || p->KK <= 0 || !cs || cs->prim != p || !cs->d_Wpack) return false;
+        const int64_t wd = 16 * (4 * p->KKg + 1) + 16 * (cs->RT * 16 + 1) + 16 * (int64_t)std::max(cs->n, 1);
+        if (4 * wd * 8 > 150 * 1024) return false;
+    }
+    return true;
+}
+
+int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
+                            const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
+                            double *const *errors_dev, void *results_dev, int64_t result_stride) {
+    mg_context *ctx = prims[0]->ctx;
+    std::vector<mg_fused_static> tab((size_t)n_options);
+    mg_fused_dyn dyn;
+    memset(&dyn, 0, sizeof(dyn));
+    memset(tab.data(), 0, tab.size() * sizeof(mg_fused_static));
+    int wave_doubles = 0;
+    for (int k = 0; k < n_options; k++) {
+        mg_primitive *p = prims[k];
+        const mg_constraint_set *cs = csets[k];
+        mg_fused_static &o = tab[k];
+        o.cpack = p->d_gcholpack; o.meanpad = p->d_gmeanpad; o.Wpack = cs->d_Wpack; o.bpad = cs->d_bpad;
+        mg_score_args &a = o.sa;
+        a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff;
+        a.align = cs->d_align; a.pose = cs->d_pose; a.lat = x_dev[k]; a.out = errors_dev[k]; a.res = nullptr; a.B = n; a.ld = ld[k];
+        a.n = cs->n; a.nch = cs->nch; a.L = p->L;
+        o.x = x_dev[k]; o.result = (char *)results_dev + (size_t)k * result_stride;
+        o.K = p->K; o.Lg = p->Lg; o.KKg = p->KKg; o.KK = p->KK; o.JT = (p->Lg + 15) / 16; o.RT = cs->RT;
+        wave_doubles = std::max(wave_doubles, 16 * (4 * p->KKg + 1) + 16 * (cs->RT * 16 + 1) + 16 * std::max(cs->n, 1));
+        int64_t tiles = 0, rows = 0;
+        for (int c = 0; c < p->K; c++) {
+            if (counts[k][c] < 0 || counts[k][c] > n) { mg_set_error("mg_options_step: counts[%d][%d] out of range", k, c); return MG_ERR_INVALID_ARGUMENT; }
+            dyn.counts[k][c] = (int32_t)counts[k][c];
+            rows += counts[k][c];
+            tiles += (counts[k][c] + 15) / 16;
+        }
+        if (rows != n) { mg_set_error("mg_options_step: counts of option %d sum to %lld, expected %lld", k, (long long)rows, (long long)n); return MG_ERR_INVALID_ARGUMENT; }
+        dyn.seed[k] = seeds[k];
+        dyn.wg0[k + 1] = dyn.wg0[k] + (int32_t)((tiles + 3) / 4);
+    }
+    const int total_wg = dyn.wg0[n_options];
+    // the static table: uploaded when it differs from the one on the device (a planner reuses its buffers and sets, so: rarely)
+    const size_t tab_bytes = tab.size() * sizeof(mg_fused_static);
+    if (!ctx->fused_tab_dev || ctx->fused_tab_host.size() != tab_bytes || memcmp(ctx->fused_tab_host.data(), tab.data(), tab_bytes) != 0) {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // no launch may still be reading the old table
+        if (!ctx->fused_tab_dev) MG_HIP_CHECK(hipMalloc(&ctx->fused_tab_dev, MG_FUSED_MAX_OPTIONS * sizeof(mg_fused_static)));
+        MG_HIP_CHECK(hipMemcpy(ctx->fused_tab_dev, tab.data(), tab_bytes, hipMemcpyHostToDevice));
+        ctx->fused_tab_host.assign((const unsigned char *)tab.data(), (const unsigned char *)tab.data() + tab_bytes);
+    }
+    if (!ctx->fused_counters) {
+        MG_HIP_CHECK(hipMalloc(&ctx->fused_counters, MG_FUSED_MAX_OPTIONS * sizeof(int32_t)));
+        MG_HIP_CHECK(hipMemset(ctx->fused_counters, 0, MG_FUSED_MAX_OPTIONS * sizeof(int32_t)));
+    }
+    if (ctx->fused_partials_n < total_wg) {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->fused_partials) MG_HIP_CHECK(hipFree(ctx->fused_partials));
+        ctx->fused_partials = nullptr; ctx->fused_partials_n = 0;
+        const int cap = std::max(total_wg, 2048);
+        MG_HIP_CHECK(hipMalloc(&ctx->fused_partials, (size_t)cap * sizeof(mg_fused_partial)));
+        ctx->fused_partials_n = cap;
+    }
+    const size_t lds = (size_t)4 * wave_doubles * 8;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const bool timed = mg_prof_kernel(ctx, 7, -1, &ev0, &ev1);
+    if (xdt == MG_F64)
+        hipExtLaunchKernelGGL((mg_options_fused_kernel<true>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
+                              (const mg_fused_static *)ctx->fused_tab_dev, dyn, (int)n_options, wave_doubles, (mg_fused_partial *)ctx->fused_partials, (int32_t *)ctx->fused_counters);
+    else
+        hipExtLaunchKernelGGL((mg_options_fused_kernel<false>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
+                              (const mg_fused_static *)ctx->fused_tab_dev, dyn, (int)n_options, wave_doubles, (mg_fused_partial *)ctx->fused_partials, (int32_t *)ctx->fused_counters);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
