@@ -541,30 +541,40 @@ def run_graph(args):
     slots = {}
     for c in ctxs:
         c.profile_enable(False)
-        for slot in ("gmm_sample", "score_constraints", "argmin"):
+        for slot in ("gmm_sample", "score_constraints", "argmin", "options_step"):
             ms, cnt = c.profile_get(slot)
             a = slots.setdefault(slot, [0.0, 0])
             a[0] += ms
             a[1] += cnt
-    # flops of the dominant kernel (the scorer, float64 MFMA): X . W^T with 14 keyframe channel rows per candidate,
-    # per option its own L; the sampler's x = mu + z L^T is the other matrix product of a step
+    # flops of a step (float64 matrix pipe): the scorer's X . W^T with 14 keyframe channel rows per candidate, per option its
+    # own L, and the sampler's x = mu + z L^T (triangular: L^2 per candidate)
     Ls = [int(np.shape(p["eigen_vectors_spatial"])[0]) for p in prims]
     score_flop = sum(2 * 14 * l for l in Ls) * n
-    sample_flop = sum(2 * l * l for l in Ls) * n
-    score_ms = slots["score_constraints"][0] / max(1, slots["score_constraints"][1])
+    sample_flop = sum(l * l for l in Ls) * n
+    fused = slots["options_step"][1] > 0
+    if fused:   # the whole step is one launch of mg_options_fused_kernel
+        k_ms = slots["options_step"][0] / slots["options_step"][1]
+        k_flop, k_name, k_n, launches = score_flop + sample_flop, "mg_options_fused_kernel (one launch per step)", slots["options_step"][1], 1
+        note = ("one launch per planner step: workgroups dealt over the options, a wave draws a 16-candidate tile (Philox + Box-Muller, x = mu + z L^T on the f64 "
+                "matrix pipe), scores it from LDS and keeps the first minimum; the last workgroup of an option reduces and copies the winner; one read-back. "
+                "The kernel is bound by its ~17 us latency chain (launch, table and fragment loads, release / counter / acquire, last-block reduction) plus ~7 us per "
+                "1024 candidates x 16 options of float64 vector work (sampler transcendental functions, residuals), not by the matrix pipe")
+    else:
+        k_ms = slots["score_constraints"][0] / max(1, slots["score_constraints"][1])
+        k_flop, k_name, k_n, launches = score_flop / len(names), "mg_score_mfma_kernel (one per option)", slots["score_constraints"][1], 3 * len(names)
+        note = "3 launch-latency-bound kernels per option (sampler, scorer, argmin + winner copy), all options enqueued by one C call and read back by one copy"
     result = {
         "metric": METRIC, "value": len(names) * n * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "graph-walk planner step: 16 synthetic primitives (L 12..40, F 40..160, K 1..8) x %d device-sampled candidates each, "
                                "2 root keyframe constraints, winner per option read back (BASELINE.json configs[2]); score only, no frames written" % n,
-                   "options": len(names), "candidates_per_option": n, "launches_per_step": 3 * len(names), "host_calls_per_step": 1, "read_backs_per_step": 1},
-        "roofline": {"bound": "mfma", "kernel": "mg_score_mfma_kernel (one per option)", "achieved": score_flop / len(names) / (score_ms * 1e-3) / 1e12 if score_ms else None,
+                   "options": len(names), "candidates_per_option": n, "launches_per_step": launches, "host_calls_per_step": 1, "read_backs_per_step": 1},
+        "roofline": {"bound": "mfma", "kernel": k_name, "achieved": k_flop / (k_ms * 1e-3) / 1e12 if k_ms else None,
                      "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (score_flop / len(names) / (score_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS) if score_ms else None, "traffic": None,
-                     "avg_kernel_ms": score_ms, "launches_timed": slots["score_constraints"][1],
-                     "note": "3 launch-latency-bound kernels per option (sampler, scorer, argmin + winner copy), ~%d KB each, all options enqueued by one C call and read back by one copy: the step is bound by "
-                             "launch latency, not by the matrix pipe; step flops %.3g (scorer) + %.3g (sampler)" % (n * 40 * 4 // 1024, score_flop, sample_flop),
+                     "frac": (k_flop / (k_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS) if k_ms else None, "traffic": None,
+                     "avg_kernel_ms": k_ms, "launches_timed": k_n,
+                     "note": note + "; step flops %.3g (scorer) + %.3g (sampler)" % (score_flop, sample_flop),
                      "per_kernel_avg_us": {k: (1e3 * v[0] / v[1] if v[1] else None) for k, v in slots.items()}},
     }
     print(json.dumps(result))

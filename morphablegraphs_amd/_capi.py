@@ -21,11 +21,12 @@ MG_ALIGN_START_POSE = -1   # mg_alignment_desc.joint: the start-pose branch of t
 MG_OPT_FORCE_VALU_SCORE, MG_OPT_FORCE_VALU_SAMPLE, MG_OPT_RING_SLOTS, MG_OPT_CHUNK_WINDOW, MG_OPT_CHUNK_SAMPLES = 0, 1, 2, 3, 4
 MG_OPT_FRAMES_KERNEL = 5   # 0 = by batch size, 1 = tile-major, 2 = chunk-stationary
 MG_OPT_PLACED_FAST_PCT = 6   # mg_device_malloc_placed's acceptance ratio in percent (tests)
-MG_OPT_COUNT = 7
+MG_OPT_OPTIONS_STEP = 7      # mg_options_step: 0 = one launch per step where possible, 1 = a chain of launches per option
+MG_OPT_COUNT = 8
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
-                 "gmm_sample": 4, "spline_evaluate": 5, "step": 6}
+                 "gmm_sample": 4, "spline_evaluate": 5, "step": 6, "options_step": 7}
 
 # every symbol include/mg_hip.h declares (tests check the built library exports them all)
 EXPORTED_SYMBOLS = [

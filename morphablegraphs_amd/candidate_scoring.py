@@ -16,6 +16,8 @@ other joint by forward kinematics (hands, feet).  Trajectory constraints on the 
 (mg_score_trajectory) and add to the same per-candidate error before the argmin.  Anything else raises -- there is no
 silent CPU fallback.
 """
+import collections
+
 import numpy as np
 
 from . import _capi
@@ -172,7 +174,7 @@ def group_residuals(clist, res):
     return out
 
 
-_CSET_CACHE = []   # [(key, ConstraintSet)], most recent last: an optimizer calls the objective hundreds of times with
+_CSET_CACHE = collections.OrderedDict()   # structure key -> ConstraintSet, most recent last: an optimizer calls the objective hundreds of times with
 _CSET_CACHE_SIZE = 64   # the same constraints, and building a set uploads its fused keyframe matrices
 
 
@@ -228,14 +230,30 @@ def _freeze(v):
     return v
 
 
+_STRUCT_FIELDS = ("joint", "joint2", "offset")
+_VALUE_FIELDS = ("weight", "target", "ref_dir", "group")
+
+
+def _flat(v):
+    return tuple(v) if isinstance(v, (list, tuple, np.ndarray)) else v
+
+
 def _structure_key(prim, clist, skeleton, alignment=None):
     """What a device set is built from and cannot change afterwards: per constraint its type, keyframe, joints and
     relative point, plus the aligning joint.  Targets, weights, reference vectors and the previous frame are values
     (ConstraintSet.update)."""
     # (a pose constraint's cloud is part of the set's tables: all of it is structure)
-    items = tuple((c["type"], float(c["t"]), _freeze(c.get("joint")), _freeze(c.get("joint2")), _freeze(c.get("offset")),
+    items = tuple((c["type"], float(c["t"]), _flat(c.get("joint")), _flat(c.get("joint2")), _flat(c.get("offset")),
                    _freeze(c) if c["type"] == "pose" else None) for c in clist)
-    return (id(prim), prim.handle.value, id(skeleton), items, None if alignment is None else _freeze(alignment.get("joint", 0)))
+    return (id(prim), prim.handle.value, id(skeleton), items, None if alignment is None else _flat(alignment.get("joint", 0)))
+
+
+def _values_key(clist, alignment):
+    """The values of a set with a given structure (what ConstraintSet.update rewrites)."""
+    vals = tuple((c.get("weight"), _flat(c.get("target")), _flat(c.get("ref_dir"))) for c in clist)
+    if alignment is None:
+        return (vals, None)
+    return (vals, tuple((k, _flat(alignment[k])) for k in sorted(alignment)))
 
 
 def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
@@ -246,29 +264,29 @@ def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
     it for the call at hand and ask again next time -- a later request with the same structure and other values
     rewrites it in place (stream ordered, so launches already enqueued keep the values they were enqueued with)."""
     key = _structure_key(prim, clist, skeleton, alignment)
-    values = (_freeze(clist), _freeze(alignment) if alignment is not None else None)
-    for i in range(len(_CSET_CACHE) - 1, -1, -1):   # entries whose primitive has been closed meanwhile are dropped
-        if not (_CSET_CACHE[i][1].handle and _CSET_CACHE[i][1].prim.handle and _CSET_CACHE[i][1].prim.ctx.handle):
-            _CSET_CACHE.pop(i)
-    for i, (k, cs) in enumerate(_CSET_CACHE):
-        if k == key:
-            _CSET_CACHE.append(_CSET_CACHE.pop(i))
-            if cs.cached_values != values:
-                cs.update(clist, alignment)
-                cs.cached_values = values
-            return cs
+    values = _values_key(clist, alignment)
+    cs = _CSET_CACHE.get(key)
+    if cs is not None and not (cs.handle and cs.prim.handle and cs.prim.ctx.handle):   # its primitive has been closed meanwhile
+        del _CSET_CACHE[key]
+        cs = None
+    if cs is not None:
+        _CSET_CACHE.move_to_end(key)
+        if cs.cached_values != values:
+            cs.update(clist, alignment)
+            cs.cached_values = values
+        return cs
     cs = _capi.ConstraintSet(prim, clist, skeleton, alignment)
     cs.cached_values = values
-    _CSET_CACHE.append((key, cs))
+    _CSET_CACHE[key] = cs
     while len(_CSET_CACHE) > _CSET_CACHE_SIZE:
-        _CSET_CACHE.pop(0)[1].close()
+        _CSET_CACHE.popitem(last=False)[1].close()
     return cs
 
 
 def clear_constraint_cache():
     """Drop the cached device constraint sets (call before closing a primitive they belong to)."""
     while _CSET_CACHE:
-        _CSET_CACHE.pop()[1].close()
+        _CSET_CACHE.popitem()[1].close()
     while _TRAJ_CACHE:
         _TRAJ_CACHE.pop()[1].close()
 

@@ -312,14 +312,8 @@ __global__ __launch_bounds__(MG_SAMPLE_BLOCK) void mg_gmm_sample_kernel(mg_sampl
     if (b < a.n) {
         double *z = lds_z + (size_t)tid * zs;
         for (int i = 0; i < L; i += 4) {
-            uint32_t r[4];
-            mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)(i >> 2), 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
-            // two Box-Muller pairs from four 32-bit draws; u in (0, 1]
-            const double inv = 1.0 / 4294967296.0;
-            double u0 = ((double)r[0] + 1.0) * inv, u1 = (double)r[1] * inv;
-            double u2 = ((double)r[2] + 1.0) * inv, u3 = (double)r[3] * inv;
-            double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
-            double zz[4] = {m0 * cos(2.0 * M_PI * u1), m0 * sin(2.0 * M_PI * u1), m1 * cos(2.0 * M_PI * u3), m1 * sin(2.0 * M_PI * u3)};
+            double zz[4];
+            mg_normal4(b, i >> 2, a.seed, zz);
             for (int q = 0; q < 4 && i + q < L; q++) z[i + q] = zz[q];
         }
         int c = 0;
@@ -561,16 +555,10 @@ __global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *_
     for (int e = lane; e < 16 * KK; e += 64) {
         const int r = e & 15, q = e >> 4;
         const int64_t b = row0 + r;
-        uint32_t rr[4];
-        mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)q, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
-        const double inv = 1.0 / 4294967296.0;
-        const double u0 = ((double)rr[0] + 1.0) * inv, u1 = (double)rr[1] * inv;
-        const double u2 = ((double)rr[2] + 1.0) * inv, u3 = (double)rr[3] * inv;
-        const double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
-        zt[r * ZS + 4 * q + 0] = m0 * cos(2.0 * M_PI * u1);
-        zt[r * ZS + 4 * q + 1] = m0 * sin(2.0 * M_PI * u1);
-        zt[r * ZS + 4 * q + 2] = m1 * cos(2.0 * M_PI * u3);
-        zt[r * ZS + 4 * q + 3] = m1 * sin(2.0 * M_PI * u3);
+        double z4[4];
+        mg_normal4(b, q, seed, z4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) zt[r * ZS + 4 * q + j] = z4[j];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     double za[KK];

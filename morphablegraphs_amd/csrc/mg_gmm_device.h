@@ -140,3 +140,24 @@ __device__ __forceinline__ void mg_philox4x32_10(uint32_t c0, uint32_t c1, uint3
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+
+// Four standard normals for (row b, group of four q) of a sampler call: one Philox block, two Box-Muller pairs, float64.
+// u in (0, 1] for the logarithm; the angle through sincospi (no 2 pi multiplication, exact argument reduction).  Every
+// device sampler -- lane per row, MFMA tiles, the one-launch planner step -- draws through this function: same seed, same
+// rows, same bits.
+__device__ __forceinline__ void mg_normal4(int64_t b, int q, uint64_t seed, double (&z)[4]) {
+    uint32_t rr[4];
+    mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)q, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+    const double inv = 1.0 / 4294967296.0;
+    const double u0 = ((double)rr[0] + 1.0) * inv, u1 = (double)rr[1] * inv;
+    const double u2 = ((double)rr[2] + 1.0) * inv, u3 = (double)rr[3] * inv;
+#ifdef MG_BM_SKIP
+    z[0] = u0; z[1] = u1; z[2] = u2; z[3] = u3;
+#else
+    const double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
+    double s0, c0, s1, c1;
+    sincospi(2.0 * u1, &s0, &c0);
+    sincospi(2.0 * u3, &s1, &c1);
+    z[0] = m0 * c0; z[1] = m0 * s0; z[2] = m1 * c1; z[3] = m1 * s1;
+#endif
+}

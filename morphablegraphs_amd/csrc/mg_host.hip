@@ -147,6 +147,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
     for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials}) if (q) (void)hipFree(q);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
     for (auto &v : ctx->vmm) mg_vmm_release(v);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1856,6 +1857,22 @@ extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int6
     return rc;
 }
 
+// A small device -> host read-back at the end of a step: through a pinned staging block of the context's (a copy into
+// pageable memory goes through the runtime's own staging and costs tens of microseconds more), then one synchronisation.
+static int mg_read_back_pinned(mg_context *ctx, void *dst, const void *src_dev, size_t bytes) {
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr; ctx->pinned_bytes = 0;
+        const size_t cap = std::max<size_t>(bytes, 64 * 1024);
+        MG_HIP_CHECK(hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+        ctx->pinned_bytes = cap;
+    }
+    MG_HIP_CHECK(hipMemcpyAsync(ctx->pinned, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->pinned, bytes);
+    return MG_OK;
+}
+
 static int mg_ctx_side_streams(mg_context *ctx) {
     if (ctx->side[0]) return MG_OK;
     for (auto &st : ctx->side) MG_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1893,10 +1910,7 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
                                                   errors_dev + k0, (char *)results_dev + (size_t)k0 * result_stride, result_stride);
                 if (rcf != MG_OK) return rcf;
             }
-            if (results_host) {
-                MG_HIP_CHECK(hipMemcpyAsync(results_host, results_dev, (size_t)(n_options * result_stride), hipMemcpyDeviceToHost, ctx->stream));
-                MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            }
+            if (results_host) return mg_read_back_pinned(ctx, results_host, results_dev, (size_t)(n_options * result_stride));
             return MG_OK;
         }
     }
@@ -1930,10 +1944,7 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
         }
     }
     if (rc != MG_OK) return rc;
-    if (results_host) {
-        MG_HIP_CHECK(hipMemcpyAsync(results_host, results_dev, (size_t)(n_options * result_stride), hipMemcpyDeviceToHost, ctx->stream));
-        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    }
+    if (results_host) return mg_read_back_pinned(ctx, results_host, results_dev, (size_t)(n_options * result_stride));
     return MG_OK;
 }
 

@@ -67,6 +67,8 @@ struct mg_context {
     std::vector<unsigned char> fused_tab_host;
     void *fused_counters = nullptr, *fused_partials = nullptr;
     int fused_partials_n = 0;
+    void *pinned = nullptr;         // pinned host staging block for small read-backs
+    size_t pinned_bytes = 0;
     void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
     int dist_rank = 0, dist_ranks = 1;
 };

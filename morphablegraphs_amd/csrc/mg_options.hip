@@ -20,11 +20,16 @@
 #include <algorithm>
 #include <cstring>
 
+#include <hip/hip_ext.h>
+
 #include "mg_internal.h"
 #include "mg_gmm_device.h"
 #include "mg_score_device.h"
 
 #define MG_FUSED_MAX_OPTIONS 24
+#ifndef MG_FUSED_WAVES_PER_SIMD
+#define MG_FUSED_WAVES_PER_SIMD 3   // 167 VGPRs, no spills: 3 workgroups per CU (2: 44.5 us per 16 x 4096 step, 3: 40.9, 4: 51.3 with 36 spilled)
+#endif
 
 struct mg_fused_static {          // one option: what stays the same from step to step
     const double *cpack;          // sampler: [K][JT][KKg][64] fragments of chol^T
@@ -46,7 +51,7 @@ struct mg_fused_dyn {             // one step: what changes every time (kernel a
 struct mg_fused_partial { double v; int64_t i; };
 
 template <bool X_F64>
-__global__ __launch_bounds__(256) void mg_options_fused_kernel(const mg_fused_static *__restrict__ tab, const mg_fused_dyn dyn,
+__global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused_kernel(const mg_fused_static *__restrict__ tab, const mg_fused_dyn dyn,
                                                               const int n_options, const int wave_doubles,
                                                               mg_fused_partial *__restrict__ partials, int32_t *__restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -88,16 +93,10 @@ __global__ __launch_bounds__(256) void mg_options_fused_kernel(const mg_fused_st
         for (int e = lane; e < 16 * KKg; e += 64) {
             const int r = e & 15, q = e >> 4;
             const int64_t b = row0 + r;
-            uint32_t rr[4];
-            mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)q, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
-            const double inv = 1.0 / 4294967296.0;
-            const double u0 = ((double)rr[0] + 1.0) * inv, u1 = (double)rr[1] * inv;
-            const double u2 = ((double)rr[2] + 1.0) * inv, u3 = (double)rr[3] * inv;
-            const double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
-            zt[r * ZS + 4 * q + 0] = m0 * cos(2.0 * M_PI * u1);
-            zt[r * ZS + 4 * q + 1] = m0 * sin(2.0 * M_PI * u1);
-            zt[r * ZS + 4 * q + 2] = m1 * cos(2.0 * M_PI * u3);
-            zt[r * ZS + 4 * q + 3] = m1 * sin(2.0 * M_PI * u3);
+            double z4[4];
+            mg_normal4(b, q, seed, z4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) zt[r * ZS + 4 * q + j] = z4[j];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         double za[MG_MAX_KK];
@@ -197,7 +196,7 @@ __global__ __launch_bounds__(256) void mg_options_fused_kernel(const mg_fused_st
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; w++) mg_min_combine(best, bi, sv[w], si[w]);
-        if (bi == INT64_MAX) { bi = 0; best = INFINITY; }
+        if (bi == INT64_MAX || bi < 0 || bi >= o.sa.B) { bi = 0; best = INFINITY; }   // (an index outside the batch cannot happen; never gather out of bounds)
         ((int64_t *)o.result)[0] = bi;
         ((double *)o.result)[1] = best;
         si[0] = bi;

@@ -267,61 +267,74 @@ class HipPrimitiveSet(object):
         from .candidate_scoring import cached_constraint_set, alignment_from_prev_frames
         import ctypes as C
         n = int(n_samples)
-        item = np.dtype(dtype).itemsize
         code = _capi.MG_F64 if np.dtype(dtype) == np.float64 else _capi.MG_F32
-        steps = []
-        for k, name in enumerate(options):
-            node = self.nodes[name]
-            prim, ctx = node._prim, node._prim.ctx
-            L = prim.n_gmm_dims          # the winner comes back at full width (spatial + time latents)
-            key = (name, n, np.dtype(dtype).str)
-            bufs = self._buffers.get(key)
-            if bufs is None:   # persistent per-option device buffers: no allocation inside a step
-                bufs = self._buffers[key] = (ctx.malloc(max(n, 1) * L * item), ctx.malloc(max(n, 1) * 8), ctx.malloc(16 + 8 * L))
-            d_x, d_e, d_r = bufs
+        plan = self._step_plan(tuple(options), n, np.dtype(dtype))
+        steps = plan["steps"]
+        csets = []
+        for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
             cons = constraints_per_option[name]
             clist = cons.constraints if hasattr(cons, "constraints") else cons
             sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
-            cset = cached_constraint_set(prim, constraints_to_device_form(clist), sk, alignment_from_prev_frames(prev_frames, cons, sk))
-            weights = node.gaussian_mixture_model.weights_
-            counts = np.random.multinomial(n, weights / weights.sum()).astype(np.int64)
-            steps.append((name, prim, ctx, cset, counts, d_x, d_e, d_r, L))
+            csets.append(cached_constraint_set(prim, constraints_to_device_form(clist), sk, alignment_from_prev_frames(prev_frames, cons, sk)))
+            plan["counts"][k, :len(pvals)] = np.random.multinomial(n, pvals)
         results = {}
-        one_context = all(st[2] is steps[0][2] for st in steps)
-        if one_context and steps:
-            # one C call and ONE read-back for the whole step (mg_options_step): the result records side by side
-            ctx = steps[0][2]
-            m = len(steps)
-            stride = 16 + 8 * max(st[8] for st in steps)
-            key = ("step", m, stride)
-            shared = self._buffers.get(key)
-            if shared is None:
-                shared = self._buffers[key] = ctx.malloc(m * stride)
-            vp = C.c_void_p
-            prims = (vp * m)(*[st[1].handle for st in steps])
-            csets = (vp * m)(*[st[3].handle for st in steps])
-            cnts = (vp * m)(*[st[4].ctypes.data for st in steps])
-            seeds = (C.c_uint64 * m)(*[int(seed) + k for k in range(m)])
-            xs = (vp * m)(*[_capi._dev_ptr(st[5]).value for st in steps])
-            lds = (C.c_int64 * m)(*[st[8] for st in steps])
-            errs = (vp * m)(*[_capi._dev_ptr(st[6]).value for st in steps])
-            host = np.empty(m * stride, dtype=np.uint8)
-            _capi._check(steps[0][1].lib.mg_options_step(m, prims, csets, n, cnts, seeds, xs, code, lds, errs, shared.ptr, stride,
-                                                         host.ctypes.data_as(vp)))
+        if plan["one_context"] and steps:
+            # one C call, ONE launch and ONE read-back for the whole step (mg_options_step): the result records side by side
+            m, stride, host = len(steps), plan["stride"], plan["host"]
+            for k, cs in enumerate(csets):
+                plan["csets"][k] = cs.handle.value
+                plan["seeds"][k] = int(seed) + k
+            _capi._check(steps[0][2].lib.mg_options_step(m, plan["prims"], plan["csets"], n, plan["cnts"], plan["seeds"], plan["xs"], code, plan["lds"],
+                                                         plan["errs"], plan["shared"].ptr, stride, host.ctypes.data_as(C.c_void_p)))
             for k, st in enumerate(steps):
-                raw = host[k * stride:k * stride + 16 + 8 * st[8]]
+                raw = host[k * stride:k * stride + 16 + 8 * st[7]]
                 err = float(raw[8:16].view(np.float64)[0])
                 results[st[0]] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
         else:
-            for k, (name, prim, ctx, cset, counts, d_x, d_e, d_r, L) in enumerate(steps):
-                _capi._check(prim.lib.mg_option_step(prim.handle, cset.handle, n, counts.ctypes.data, int(seed) + k, d_x.ptr, code, L,
+            for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
+                _capi._check(prim.lib.mg_option_step(prim.handle, csets[k].handle, n, plan["counts"][k].ctypes.data, int(seed) + k, d_x.ptr, code, L,
                                                      d_e.ptr, d_r.ptr))
-            for name, prim, ctx, cset, counts, d_x, d_e, d_r, L in steps:
+            for name, node, prim, ctx, d_x, d_e, d_r, L, pvals in steps:
                 raw = ctx.download(d_r, (16 + 8 * L,), np.uint8)       # synchronises this option's stream
                 err = float(raw[8:16].view(np.float64)[0])
                 results[name] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
         errors = [results[n][1] for n in options]
         return options[int(np.argmin(errors))], results
+
+    def _step_plan(self, options, n, dtype):
+        """Everything about a planner step that does not change from step to step, built once per (options, n, dtype): the
+        per-option device buffers (no allocation inside a step), the argument arrays of mg_options_step, the normalised
+        mixture weights the component counts are drawn with, the host block the result records land in."""
+        import ctypes as C
+        key = ("plan", options, n, dtype.str)
+        plan = self._buffers.get(key)
+        if plan is not None:
+            return plan
+        item = dtype.itemsize
+        steps = []
+        for name in options:
+            node = self.nodes[name]
+            prim, ctx = node._prim, node._prim.ctx
+            L = prim.n_gmm_dims          # the winner comes back at full width (spatial + time latents)
+            bkey = (name, n, dtype.str)
+            bufs = self._buffers.get(bkey)
+            if bufs is None:
+                bufs = self._buffers[bkey] = (ctx.malloc(max(n, 1) * L * item), ctx.malloc(max(n, 1) * 8), ctx.malloc(16 + 8 * L))
+            weights = np.asarray(node.gaussian_mixture_model.weights_, dtype=np.float64)
+            steps.append((name, node, prim, ctx, bufs[0], bufs[1], bufs[2], L, weights / weights.sum()))
+        m = len(steps)
+        plan = {"steps": steps, "one_context": all(st[3] is steps[0][3] for st in steps),
+                "counts": np.zeros((max(m, 1), max([len(st[8]) for st in steps] + [1])), dtype=np.int64)}
+        if plan["one_context"] and steps:
+            vp = C.c_void_p
+            stride = 16 + 8 * max(st[7] for st in steps)
+            plan.update(stride=stride, shared=steps[0][3].malloc(m * stride), host=np.empty(m * stride, dtype=np.uint8),
+                        prims=(vp * m)(*[st[2].handle for st in steps]), csets=(vp * m)(),
+                        cnts=(vp * m)(*[plan["counts"][k].ctypes.data for k in range(m)]), seeds=(C.c_uint64 * m)(),
+                        xs=(vp * m)(*[_capi._dev_ptr(st[4]).value for st in steps]), lds=(C.c_int64 * m)(*[st[7] for st in steps]),
+                        errs=(vp * m)(*[_capi._dev_ptr(st[5]).value for st in steps]))
+        self._buffers[key] = plan
+        return plan
 
     def evaluate_options(self, options, constraints_per_option, n_samples, rng_seed=None):
         """options: node names; constraints_per_option: name -> constraint list.  Returns

@@ -510,6 +510,80 @@ def test_graph_walk_step_on_device_with_one_stream_per_option():
         assert set(results2) == set(names)
 
 
+def _options_step_raw(pset, names, cons, n, seed, dtype, skeleton=None, prev_frames=None):
+    """One evaluate_options_on_device step; returns per option (result record, all errors, all candidates) as the device left them."""
+    np.random.seed(9)
+    best, results = pset.evaluate_options_on_device(names, cons, n_samples=n, seed=seed, dtype=dtype, skeleton=skeleton, prev_frames=prev_frames)
+    out = {}
+    for name in names:
+        prim = pset.nodes[name]._prim
+        d_x, d_e, d_r = pset._buffers[(name, n, np.dtype(dtype).str)]
+        L = prim.n_gmm_dims
+        out[name] = (results[name][0].copy(), results[name][1], prim.ctx.download(d_e, (n,), np.float64), prim.ctx.download(d_x, (n, L), dtype))
+    return best, out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_planner_step_in_one_launch_is_bit_identical_to_the_per_option_chains(dtype):
+    """mg_options_step as ONE launch (mg_options_fused_kernel: sample -> score -> first minimum -> winner copy, last
+    workgroup per option reduces) against the chain of sampler / scorer / argmin launches per option
+    (MG_OPT_OPTIONS_STEP = 1): the same candidates, the same errors, the same winners, bit for bit -- with root and
+    forward-kinematics constraints, in global coordinates, for batch sizes whose component counts are not multiples of 16."""
+    prims = synthetic.make_graph_primitives(7)
+    names = [p["name"] for p in prims]
+    joints, animated = synthetic.make_skeleton(19)
+    hip_sk = _capi.Skeleton(joints, animated)
+    cons = {}
+    for n, p in zip(names, prims):
+        tlast = float(p["n_canonical_frames"] - 1)
+        cons[n] = [{"type": "position", "t": tlast, "weight": 1.0, "target": [10.0, None, 5.0]},
+                   {"type": "direction", "t": (tlast / 2.0), "weight": 0.5, "target": [0.3, 1.0]},
+                   {"type": "joint_position", "joint": "RightHand", "t": tlast, "weight": 2.0, "target": [12.0, 90.0, 4.0]}]
+    pset = HipPrimitiveSet(prims)
+    for n_samples in (2048, 777):
+        pset.ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, 1)
+        b1, r1 = _options_step_raw(pset, names, cons, n_samples, 41, dtype, skeleton=hip_sk)
+        pset.ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, 0)
+        pset.ctx.profile_enable(1)
+        pset.ctx.profile_reset()
+        b2, r2 = _options_step_raw(pset, names, cons, n_samples, 41, dtype, skeleton=hip_sk)
+        assert pset.ctx.profile_get(7)[1] == 1                 # the whole step was ONE launch of the fused kernel ...
+        assert pset.ctx.profile_get(4)[1] == 0 and pset.ctx.profile_get(2)[1] == 0   # ... no sampler, no scorer launch
+        pset.ctx.profile_enable(0)
+        assert b1 == b2
+        for name in names:
+            np.testing.assert_array_equal(r1[name][3].view(np.uint8), r2[name][3].view(np.uint8))   # candidates
+            np.testing.assert_array_equal(r1[name][2].view(np.uint64), r2[name][2].view(np.uint64))  # errors
+            np.testing.assert_array_equal(r1[name][0].view(np.uint64), r2[name][0].view(np.uint64))  # winning latent
+            assert r1[name][1] == r2[name][1]
+            assert r1[name][1] == np.min(r1[name][2])
+
+
+def test_planner_step_falls_back_to_one_stream_for_large_mixtures():
+    """More than 16 mixture components (prefix sums staged in the context's scratch buffer) or the VALU sampler forced: the
+    options of a step share that ONE staging buffer, so mg_options_step must not run them on side streams.
+    The step must equal mg_option_step called option by option on the context's own stream."""
+    prims = [synthetic.make_primitive(seed=300 + i, n_components=24, n_frames=60, n_gmm=17, name="big%d" % i) for i in range(5)]
+    names = [p["name"] for p in prims]
+    cons = {n: [{"type": "position", "t": 59.0, "weight": 1.0, "target": [3.0, None, -2.0]}] for n in names}
+    pset = HipPrimitiveSet(prims)
+    for force_valu in (0, 1):
+        pset.ctx.set_option(_capi.MG_OPT_FORCE_VALU_SAMPLE, force_valu)
+        _, step = _options_step_raw(pset, names, cons, 1500, 7, np.float32)
+        np.random.seed(9)
+        for k, (name, p) in enumerate(zip(names, prims)):
+            prim = pset.nodes[name]._prim
+            w = np.asarray(p["gmm_weights"], dtype=np.float64)
+            counts = np.random.multinomial(1500, w / w.sum())
+            X, _ = prim.gmm_sample(counts, 7 + k, dtype=np.float32)
+            np.testing.assert_array_equal(step[name][3], X)
+            cp = c_oracle.COraclePrimitive(p)
+            ref = cp.keyframe_errors_f64(X.astype(np.float64), np.array([[0, 59.0, 1.0, 3.0, np.nan, -2.0, 0, 0]]))
+            np.testing.assert_allclose(step[name][2], ref, rtol=1e-9, atol=1e-9)
+            assert step[name][1] == np.min(step[name][2])
+    pset.ctx.set_option(_capi.MG_OPT_FORCE_VALU_SAMPLE, 0)
+
+
 def test_scoring_in_global_coordinates_through_the_adaptors():
     """prev_frames given and constraints not `is_local`: evaluate_samples_using_constraints, the objective
     functions, the generator without use_local_coordinates and the planner's option step all align every candidate

@@ -12,6 +12,12 @@ for i in range(50): pset.evaluate_options_on_device(names, cons, 4096, seed=i)
 t0=time.perf_counter()
 for i in range(500): pset.evaluate_options_on_device(names, cons, 4096, seed=i)
 print("ms/step", (time.perf_counter()-t0)/500*1e3)
+ctx = pset.ctx
+ctx.profile_reset(); ctx.profile_enable(1)
+for i in range(200): pset.evaluate_options_on_device(names, cons, 4096, seed=i)
+ctx.profile_enable(0)
+ms, cnt = ctx.profile_get("options_step")
+print("fused kernel: %.1f us average over %d launches" % (1e3 * ms / max(cnt, 1), cnt))
 pr = cProfile.Profile(); pr.enable()
 for i in range(300): pset.evaluate_options_on_device(names, cons, 4096, seed=i)
 pr.disable()
