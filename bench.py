@@ -260,7 +260,12 @@ def run_walk(args, rank, local_rank, world):
     # the output comes from the library's allocator for large outputs: where 404 MB land in HBM decides between two
     # speed classes of the kernel's store stream (DESIGN.md "Placement"); mg_device_malloc_placed probes for the fast one
     t_alloc = time.perf_counter()
-    frames = ctx.malloc(nbytes) if args.output_alloc == "plain" else ctx.malloc_placed(nbytes)
+    if args.output_alloc == "plain":      # memory that does not come through the library's placed regions: one hipMalloc
+        ctx.set_option(_capi.MG_OPT_PLAIN_MALLOC, 1)
+        frames = ctx.malloc(nbytes)
+        ctx.set_option(_capi.MG_OPT_PLAIN_MALLOC, 0)
+    else:
+        frames = ctx.malloc_placed(nbytes)
     alloc_s = time.perf_counter() - t_alloc
     probe = ctx.probe_placement(frames)   # pattern and fill time on THIS buffer: the in-run achievable ceiling
     fill_us = probe["pattern_us"] / probe["ratio"] if probe["ratio"] > 0 else None
@@ -367,13 +372,14 @@ def run_walk(args, rank, local_rank, world):
     rc = 0
     if rank == 0:
         value = world * B * args.steps / elapsed
-        placement = {"allocator": "mg_device_malloc" if args.output_alloc == "plain" else "mg_device_malloc_placed (the library's allocator for large outputs: first candidate allocation in the fast placement class)",
+        placement = {"allocator": "one hipMalloc (MG_OPT_PLAIN_MALLOC)" if args.output_alloc == "plain" else "the library's placed output regions (mg_device_malloc / mg_device_malloc_placed: every buffer of 64 MiB and more, "
+                                  "the *_host entry points' scratch included, is a piece of a region that went through the placement probe; scan of at most 32 candidates, a quarter of the free memory held at most)",
                      "candidates_probed": frames.placement["probed"] if frames.placement else 0, "alloc_seconds": round(alloc_s, 4),
                      "pattern_over_fill": round(probe["ratio"], 4), "fast_class": probe["fast"]}
         result = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "untimed_steps": args.warmup + args.ramp_steps,
             "config": {"workload": "walk primitive L=40 F=156 D=79 NB=31 GMM k=8, batch=%d candidates/GPU "
                                    "(BASELINE.json configs[%d])" % (B, 1 if world == 1 else 3),
                        "candidates_per_gpu": B, "global_candidates": world * B,
@@ -420,12 +426,27 @@ def run_walk(args, rank, local_rank, world):
                 ctx.synchronize()
                 return 1e6 * (time.perf_counter() - t) / n
             if args.output_alloc != "plain":
-                # beside the headline: the same step on a buffer taken from plain hipMalloc, wherever that landed
+                # beside the headline: (1) a SECOND buffer from the allocation call every device-pointer caller uses (mg_device_malloc: the
+                # headline's region is in use, so this one is a region of its own, scanned for like the first); (2) memory that does not
+                # come from the library at all -- one hipMalloc, wherever it landed -- which is what a caller's own tensor would be
+                second = ctx.malloc(nbytes)
+                ps = ctx.probe_placement(second)
+                us_second = wall_us(200, second)
+                result["config"]["output_placement"]["default_malloc"] = {"allocator": "mg_device_malloc (a second buffer of the same size beside the headline's)", "step_us": round(us_second, 2),
+                                                                          "pattern_over_fill": round(ps["ratio"], 4), "fast_class": ps["fast"]}
+                second.free()
+                ctx.set_option(_capi.MG_OPT_PLAIN_MALLOC, 1)
                 plain = ctx.malloc(nbytes)
+                ctx.set_option(_capi.MG_OPT_PLAIN_MALLOC, 0)
                 pp = ctx.probe_placement(plain)
-                result["config"]["output_placement"]["unplaced"] = {"allocator": "mg_device_malloc (one hipMalloc)", "step_us": round(wall_us(200, plain), 2),
-                                                                    "pattern_over_fill": round(pp["ratio"], 4), "fast_class": pp["fast"]}
+                us_plain = wall_us(200, plain)
+                result["config"]["output_placement"]["foreign_hipMalloc"] = {"allocator": "one hipMalloc outside the library's regions (MG_OPT_PLAIN_MALLOC)", "step_us": round(us_plain, 2),
+                                                                             "pattern_over_fill": round(pp["ratio"], 4), "fast_class": pp["fast"]}
                 plain.free()
+                result["value_default_malloc"] = B / (us_second * 1e-6)
+                result["value_foreign_hipMalloc"] = B / (us_plain * 1e-6)
+                res, used, nreg, nfast = ctx.output_bytes()
+                result["config"]["output_placement"]["regions"] = {"reserved_bytes": res, "in_use_bytes": used, "regions": nreg, "fast": nfast}
             # what the boundary costs when it hands over host buffers (never part of `value`): median of 20 copies
             def med_us(fn):
                 ts = []
@@ -446,7 +467,6 @@ def run_walk(args, rank, local_rank, world):
             }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_leg(data, S_host)
-        print(json.dumps(result))
     for buf in [S, frames, scalar_dev, scalars_dev] + logps + (gathereds or []):
         buf.free()
     prim.close()
@@ -455,6 +475,20 @@ def run_walk(args, rank, local_rank, world):
     ctx.close()
     if use_torch:
         dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_extra_configs and B == 8192 and args.dry_run is False:
+            # BASELINE configs[2] and configs[4] on this GPU, a few hundred steps each, under keys of their own (the headline keys
+            # above are configs[1] and unchanged); `python bench.py --config graph | optimizer` prints each as a line of its own
+            import copy
+            for key, fn in (("graph", run_graph), ("optimizer", run_optimizer)):
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup, a2.batch = 400, 100, 8192
+                try:
+                    r = fn(a2, emit=False)
+                    result[key] = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
+                except Exception as e:   # the headline line is never lost to a secondary configuration
+                    result[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(result))
     return rc
 
 
@@ -518,7 +552,7 @@ def cpu_baseline_leg(data, S_host):
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE configs[2]: one planner step over the 16 options of a graph, 4096 candidates each
 # ---------------------------------------------------------------------------------------------------------
-def run_graph(args):
+def run_graph(args, emit=True):
     ensure_built()
     from morphablegraphs_amd import synthetic
     from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
@@ -577,6 +611,8 @@ def run_graph(args):
                      "note": note + "; step flops %.3g (scorer) + %.3g (sampler)" % (score_flop, sample_flop),
                      "per_kernel_avg_us": {k: (1e3 * v[0] / v[1] if v[1] else None) for k, v in slots.items()}},
     }
+    if not emit:
+        return result
     print(json.dumps(result))
     return 0
 
@@ -584,7 +620,7 @@ def run_graph(args):
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE configs[4] per iteration on one GPU: 131072 candidates, objective only (no frames)
 # ---------------------------------------------------------------------------------------------------------
-def run_optimizer(args):
+def run_optimizer(args, emit=True):
     ensure_built()
     from morphablegraphs_amd import _capi, synthetic
     B = int(args.batch) if args.batch != 8192 else 131072
@@ -631,13 +667,14 @@ def run_optimizer(args):
                      "step_frac": B * flop / (elapsed / args.steps) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                      "peak_note": "float64 matrix peak AMD publishes for MI355X; the microarchitecture guide lists no float64 MFMA row"},
     }
-    print(json.dumps(result))
+    if emit:
+        print(json.dumps(result))
     for b in (S, lp, err):
         b.free()
     cset.close()
     prim.close()
     ctx.close()
-    return 0
+    return 0 if emit else result
 
 
 def main():
@@ -649,6 +686,7 @@ def main():
     ap.add_argument("--config", choices=("walk", "graph", "optimizer"), default="walk",
                     help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="do not attach the graph / optimizer configurations to the default line")
     ap.add_argument("--two-launch", action="store_true",
                     help="frames kernel and log-likelihood kernel as two launches instead of the fused step kernel")
     ap.add_argument("--frames-kernel", type=int, choices=(0, 1, 2), default=0,

@@ -211,7 +211,9 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_PLACED_FAST_PCT    mg_device_malloc_placed: pattern / fill ratio (in percent) up to which a candidate counts as
  *                             fast (0 = 115); tests lower it to walk through both recipes
  *   MG_OPT_OPTIONS_STEP       mg_options_step: 0 = one launch for the whole step where every option allows it, 1 = always one
- *                             chain of launches per option (identical results; tests compare the two) */
+ *                             chain of launches per option (identical results; tests compare the two)
+ *   MG_OPT_PLAIN_MALLOC       1 = mg_device_malloc is one hipMalloc whatever the size (0: buffers of 64 MiB and more are pieces
+ *                             of the context's placed output regions, see mg_device_malloc) */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
@@ -220,7 +222,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_FRAMES_KERNEL 5
 #define MG_OPT_PLACED_FAST_PCT 6
 #define MG_OPT_OPTIONS_STEP 7
-#define MG_OPT_COUNT 8
+#define MG_OPT_PLAIN_MALLOC 8
+#define MG_OPT_COUNT 9
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
@@ -233,29 +236,38 @@ int mg_context_synchronize(mg_context *ctx);
 /* name (256 bytes), CU count, total bytes of the context's device */
 int mg_context_device_info(mg_context *ctx, char *name, int32_t *n_cu, int64_t *total_mem);
 
-/* plain device memory helpers so a host language needs no HIP binding of its own */
+/* Device memory helpers so a host language needs no HIP binding of its own.
+ *
+ * Where a LARGE KERNEL OUTPUT (the (B, T, D) frames) lands decides between two speed classes of the frames kernel's store
+ * stream -- thousands of concurrent ~1 KB-piece streams: 63 vs 80 us for 404 MB stand-alone, 77 vs 97 us for the frames
+ * kernel; a plain fill does not see the difference.  The class is a property of the physical memory behind an allocation
+ * (the same memory mapped at other virtual addresses keeps it, offsets inside an allocation do not change it, fast memory
+ * comes in multi-gigabyte runs), it shows in no translation or L2 counter, and nothing a kernel can choose changes it
+ * (DESIGN.md "Placement", profiles/r03_placement/).  So the library PROBES: it times the store pattern and a plain fill on a
+ * candidate allocation (~1.5 ms) and keeps the first candidate in the fast class.
+ *
+ * mg_device_malloc: buffers below 64 MiB are one hipMalloc.  From 64 MiB on the buffer is a piece of one of the context's
+ * PLACED REGIONS: the first request of a size runs the scan once, later requests (after mg_device_free, which returns a piece
+ * to its region, not to the driver) reuse the region -- an adaptor that allocates its output on every call pays for placement
+ * once, and the scratch blocks behind the *_host entry points are placed the same way.  The scan is bounded: at most 32
+ * candidates, and never more than a quarter of the free device memory held at once (processes sharing a GPU);
+ * mg_context_trim_outputs releases the regions no piece of which is in use, mg_context_output_bytes reports what is held.
+ * A caller that brings memory from elsewhere (a framework's tensor) can ask mg_device_probe_placement which class it is in. */
 int mg_device_malloc(mg_context *ctx, int64_t bytes, void **out_dev);
 int mg_device_free(mg_context *ctx, void *ptr_dev);
+int mg_context_trim_outputs(mg_context *ctx);
+int mg_context_output_bytes(mg_context *ctx, int64_t *reserved, int64_t *in_use, int32_t *n_regions, int32_t *n_fast);
 /* The same buffer assembled from separately created physical chunks (HIP virtual-memory API: one reserved address
- * range, hipMemCreate per chunk_bytes, mapped back to back).  Where a large output lands physically decides between
- * two speed classes of the frames kernel ("Placement"); buffers built from 8 MiB chunks hit the
- * fast class more often than single allocations on boxes where those never do.  Freed with mg_device_free. */
+ * range, hipMemCreate per chunk_bytes, mapped back to back); one of the scan's two recipes.  Freed with mg_device_free. */
 int mg_device_malloc_chunked(mg_context *ctx, int64_t bytes, int64_t chunk_bytes, void **out_dev);
-/* A buffer for a large kernel OUTPUT (the (B, T, D) frames), placed where the frames kernel's store stream runs at
- * the fill rate.  Which part of the card's memory an allocation lands in decides between two speed classes of that
- * stream (thousands of concurrent ~1 KB-piece streams: 63 vs 79 us for 404 MB stand-alone, 10 % of the frames
- * kernel; a plain fill does not see the difference), whole multi-gigabyte regions are of one class, and nothing a
- * kernel can choose -- base offset, stride, unit order -- changes the class ("Placement").  So the
- * library probes: it allocates a candidate, times the store pattern and a plain fill on it (about 1 ms), keeps the
- * first candidate whose ratio is in the fast class, holds the rejected ones until then (so that the next candidate
- * comes from other memory) and frees them.  max_candidates <= 0: a default budget (up to 768 candidates, never
- * more than nine tenths of the free device memory; ~1.5 ms per candidate); where the first sixteen are not fast (and max_candidates != 1) twelve are
- * assembled from physical chunks of 8 / 32 / 2 MiB through the virtual-memory API -- on some boxes only those are fast --
- * before the rest of the budget; if nothing is fast the best candidate of all is returned.  info (may be NULL):
- * [0] candidates probed, [1] pattern time / fill time of the buffer returned, [2] its pattern time in us,
- * [3] 1 if it is in the fast class.  The contents are undefined afterwards.  Freed with mg_device_free. */
+/* mg_device_malloc's placed path with an explicit budget and a report.  max_candidates <= 0: the default scan (16 plain
+ * allocations, then -- unless max_candidates == 1 -- twelve assembled from physical chunks of 32 / 8 / 2 MiB, then plain
+ * again, 32 in all); if nothing is fast the best candidate of all is returned.  info (may be NULL): [0] candidates probed BY
+ * THIS CALL (0: the piece came from a region the context already had), [1] pattern time / fill time of the region, [2] its
+ * pattern time in us, [3] 1 if it is in the fast class.  The contents are undefined afterwards.  Freed with mg_device_free. */
 int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out_dev, double *info4);
-/* the probe alone, on any device buffer of at least 64 MiB: info4 as above ([0] = 1) */
+/* the probe alone, on any device buffer of at least 64 MiB: info4 as above ([0] = 1).  It OVERWRITES the buffer (the probe
+ * is a store pattern and a fill): call it before the buffer holds anything. */
 int mg_device_probe_placement(mg_context *ctx, void *buf_dev, int64_t bytes, double *info4);
 int mg_memcpy_h2d(mg_context *ctx, void *dst_dev, const void *src, int64_t bytes);
 int mg_memcpy_d2h(mg_context *ctx, void *dst, const void *src_dev, int64_t bytes);

@@ -22,7 +22,8 @@ MG_OPT_FORCE_VALU_SCORE, MG_OPT_FORCE_VALU_SAMPLE, MG_OPT_RING_SLOTS, MG_OPT_CHU
 MG_OPT_FRAMES_KERNEL = 5   # 0 = by batch size, 1 = tile-major, 2 = chunk-stationary
 MG_OPT_PLACED_FAST_PCT = 6   # mg_device_malloc_placed's acceptance ratio in percent (tests)
 MG_OPT_OPTIONS_STEP = 7      # mg_options_step: 0 = one launch per step where possible, 1 = a chain of launches per option
-MG_OPT_COUNT = 8
+MG_OPT_PLAIN_MALLOC = 8      # 1 = mg_device_malloc is one hipMalloc whatever the size (no placed output regions)
+MG_OPT_COUNT = 9
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
@@ -33,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
     "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_set_option", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
     "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
-    "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_free", "mg_memcpy_h2d", "mg_memcpy_d2h",
+    "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_free", "mg_context_trim_outputs", "mg_context_output_bytes", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host",
@@ -203,6 +204,8 @@ def load_library(path=None):
         "mg_context_synchronize": [vp],
         "mg_context_device_info": [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(i64)],
         "mg_device_malloc": [vp, i64, C.POINTER(vp)],
+        "mg_context_trim_outputs": [vp],
+        "mg_context_output_bytes": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)],
         "mg_device_free": [vp, vp],
         "mg_memcpy_h2d": [vp, vp, vp, i64],
         "mg_memcpy_d2h": [vp, vp, vp, i64],
@@ -366,6 +369,16 @@ class Context(object):
         """A buffer for a large kernel output in the part of the card's memory where the frames kernel's store stream
         runs at the fill rate (mg_device_malloc_placed).  .placement = {"probed", "ratio", "pattern_us", "fast"}."""
         return DeviceBuffer(self, nbytes, placed=True, max_candidates=max_candidates)
+
+    def trim_outputs(self):
+        """Release the placed output regions no piece of which is in use (mg_context_trim_outputs)."""
+        _check(self.lib.mg_context_trim_outputs(self.handle))
+
+    def output_bytes(self):
+        """(reserved, in_use, regions, fast regions) of the context's placed output regions."""
+        r, u, n, f = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        _check(self.lib.mg_context_output_bytes(self.handle, C.byref(r), C.byref(u), C.byref(n), C.byref(f)))
+        return r.value, u.value, n.value, f.value
 
     def probe_placement(self, buf, nbytes=None):
         info = (C.c_double * 4)()

@@ -144,7 +144,8 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     for (auto &ev : ctx->free_events) (void)hipEventDestroy(ev);
     for (auto &st : ctx->side) if (st) (void)hipStreamDestroy(st);
     for (auto &e : ctx->side_ev) if (e) (void)hipEventDestroy(e);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch) (void)mg_device_free(ctx, ctx->scratch);
+    mg_output_release_all(ctx);
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
     for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials}) if (q) (void)hipFree(q);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -289,6 +290,8 @@ extern "C" int mg_device_malloc(mg_context *ctx, int64_t bytes, void **out_dev) 
     *out_dev = nullptr;
     MG_HIP_CHECK(hipSetDevice(ctx->device));
     if (bytes == 0) bytes = 16;
+    // large buffers are kernel outputs: a piece of a placed region (mg_placement.hip) unless the caller opted out
+    if (bytes >= MG_PLACED_MIN_BYTES && !ctx->opt[MG_OPT_PLAIN_MALLOC]) return mg_output_alloc(ctx, bytes, 0, out_dev, nullptr);
     MG_HIP_CHECK(hipMalloc(out_dev, (size_t)bytes));
     return MG_OK;
 }
@@ -347,6 +350,10 @@ extern "C" int mg_device_free(mg_context *ctx, void *p) {
     MG_REQUIRE(ctx != nullptr, "mg_device_free: ctx is NULL");
     if (!p) return MG_OK;
     MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (mg_output_free(ctx, p)) return MG_OK;   // a piece of a placed region: back to its free list, the region stays
+    return mg_device_free_raw(ctx, p);
+}
+int mg_device_free_raw(mg_context *ctx, void *p) {
     for (size_t i = 0; i < ctx->vmm.size(); i++)
         if (ctx->vmm[i].va == p) {
             mg_vmm_release(ctx->vmm[i]);
@@ -380,9 +387,10 @@ extern "C" int mg_memset(mg_context *ctx, void *dst, int value, int64_t bytes) {
 int mg_ctx_scratch(mg_context *ctx, int64_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes) {
         MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (ctx->scratch) { MG_HIP_CHECK(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+        if (ctx->scratch) { int rcf = mg_device_free(ctx, ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; if (rcf != MG_OK) return rcf; }
         int64_t want = std::max<int64_t>(bytes, 1 << 20);
-        MG_HIP_CHECK(hipMalloc(&ctx->scratch, (size_t)want));
+        int rcm = mg_device_malloc(ctx, want, &ctx->scratch);   // large scratch blocks hold the *_host entry points' outputs: placed like them
+        if (rcm != MG_OK) return rcm;
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,14 @@ struct mg_context {
     std::vector<unsigned char> fused_tab_host;
     void *fused_counters = nullptr, *fused_partials = nullptr;
     int fused_partials_n = 0;
+    // the output arena (mg_placement.hip): buffers that went through the placement probe, sub-allocated in 2 MiB granules
+    struct out_region {
+        char *base = nullptr; size_t bytes = 0; bool vmm = false, fast = false; double ratio = 1.0, us = 0.0; int probed = 0;
+        std::vector<std::pair<size_t, size_t>> free_list;   // (offset, bytes), sorted by offset
+        std::map<size_t, size_t> used;                       // offset -> bytes of the pieces handed out
+        int64_t live = 0;
+    };
+    std::vector<out_region> out_regions;
     void *pinned = nullptr;         // pinned host staging block for small read-backs
     size_t pinned_bytes = 0;
     void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
@@ -221,6 +230,11 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
                             const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
                             double *const *errors_dev, void *results_dev, int64_t result_stride);
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us);   // mg_placement.hip
+#define MG_PLACED_MIN_BYTES ((int64_t)64 << 20)   // below this an output sits in the 256 MiB Infinity Cache anyway
+int mg_output_alloc(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out, double *info4);   // a piece of a placed region
+bool mg_output_free(mg_context *ctx, void *p);
+void mg_output_release_all(mg_context *ctx);
+int mg_device_free_raw(mg_context *ctx, void *p);   // hipFree / virtual-memory release, no arena lookup
 
 // host-side float64 spline basis (FITPACK splev/fpbspl semantics)
 void mg_basis_row(const double *knots, int n_knots, double x, int32_t *i0, double *w4);

@@ -14,6 +14,7 @@
 // candidate allocation and keeps the first fast one, holding the rejected candidates until then so that the next
 // one comes from other memory.
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "mg_internal.h"
@@ -53,7 +54,6 @@ __global__ __launch_bounds__(256) void mg_placement_fill_kernel(f32x4p *buf, siz
     if (i < n) { const f32x4p v = {0.f, 0.f, 0.f, 0.f}; buf[i] = v; }
 }
 
-#define MG_PLACED_MIN_BYTES ((int64_t)64 << 20)   // below this an output sits in the 256 MiB Infinity Cache anyway
 #define MG_PLACED_FAST_RATIO 1.15                  // measured: 1.04-1.06 in the fast class, 1.25-1.33 in the slow one
 
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us) {
@@ -99,6 +99,187 @@ extern "C" int mg_device_probe_placement(mg_context *ctx, void *buf, int64_t byt
     return MG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The context's OUTPUT ARENA.  Every large device allocation the library makes or hands out -- mg_device_malloc from
+// MG_PLACED_MIN_BYTES on, mg_device_malloc_placed, the scratch block behind the *_host entry points -- is a piece of a
+// PLACED REGION: a buffer that went through the probe once.  Regions stay with the context when their pieces are freed
+// (mg_context_trim_outputs releases the idle ones), so an adaptor that allocates its (B, T, D) output on every call pays
+// for placement once, and every caller gets the class the bench's buffer gets.
+//
+// The scan for a new region is bounded so that processes sharing a GPU do not starve each other: at most 32 candidates by
+// default, and the candidates held at any moment (rejected ones are held so that the next one comes from other memory)
+// never exceed a quarter of the memory that was free when the scan began -- the oldest rejects are released first.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MG_REGION_GRANULE ((size_t)2 << 20)
+
+static void mg_region_release(mg_context *ctx, mg_context::out_region &r) {
+    if (!r.base) return;
+    if (r.vmm) (void)mg_device_free_raw(ctx, r.base); else (void)hipFree(r.base);
+    r.base = nullptr;
+}
+
+// a new region of `bytes` (already a multiple of the granule): probe candidates, keep the first fast one (or the best)
+// (probe_bytes: the request itself -- the probe replays the store pattern of a dense (n, 156, 79) block of that size; one tile more
+// or less changes the units per workgroup and with them what the pattern measures)
+static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, int32_t max_candidates, mg_context::out_region *out) {
+    size_t free_b = 0, total_b = 0;
+    MG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const int budget = max_candidates > 0 ? max_candidates : 32;
+    const size_t hold_cap = std::max<size_t>(free_b / 4, 2 * bytes);   // bytes held at once, the best candidate included
+    const double fast_ratio = ctx->opt[MG_OPT_PLACED_FAST_PCT] > 0 ? ctx->opt[MG_OPT_PLACED_FAST_PCT] / 100.0 : MG_PLACED_FAST_RATIO;
+    struct cand { void *p; bool vmm; };
+    std::vector<cand> held;   // rejected candidates, oldest first
+    cand best = {nullptr, false};
+    double best_ratio = 0.0, best_us = 0.0;
+    int probed = 0, rc = MG_OK;
+    auto drop = [&](const cand &c) { if (c.vmm) (void)mg_device_free_raw(ctx, c.p); else (void)hipFree(c.p); };
+    auto consider = [&](void *p, bool vmm) -> bool {   // probe p, keep the better of (best, p), hold the other; false: stop
+        double ratio = 1.0, us = 0.0;
+        rc = mg_probe_placement(ctx, p, (int64_t)probe_bytes, &ratio, &us);
+        if (rc != MG_OK) { drop({p, vmm}); return false; }
+        probed++;
+        if (!best.p || ratio < best_ratio) {
+            if (best.p) held.push_back(best);
+            best = {p, vmm}; best_ratio = ratio; best_us = us;
+        } else {
+            held.push_back({p, vmm});
+        }
+        while (!held.empty() && (held.size() + 2) * bytes > hold_cap) {   // + the best one + the candidate to come
+            (void)hipStreamSynchronize(ctx->stream);
+            drop(held.front());
+            held.erase(held.begin());
+        }
+        return best_ratio > fast_ratio;
+    };
+    auto plain = [&](int count) {
+        for (int i = 0; i < count && probed < budget; i++) {
+            void *p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return; }   // out of memory: settle for the best so far
+            if (!consider(p, false)) return;
+        }
+    };
+    // Two recipes.  Plain allocations first (on most boxes the second or third is fast); where sixteen of them were not,
+    // twelve buffers assembled from physical chunks through the virtual-memory API (on some boxes only those are fast), then
+    // the rest of the budget plain again.
+    plain(std::min(budget, 16));
+    if (best.p && best_ratio > fast_ratio && rc == MG_OK && max_candidates != 1) {
+        static const int64_t chunk_mib[3] = {32, 8, 2};
+        bool go = true;
+        for (int c = 0; c < 3 && go; c++)
+            for (int i = 0; i < 4 && go && probed < budget; i++) {
+                void *p = nullptr;
+                if (mg_device_malloc_chunked(ctx, (int64_t)bytes, chunk_mib[c] << 20, &p) != MG_OK) { (void)hipGetLastError(); go = false; break; }
+                go = consider(p, true);
+            }
+        if (rc == MG_OK && best_ratio > fast_ratio) plain(budget - probed);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (const cand &c : held) drop(c);
+    if (rc != MG_OK) {   // a probe failed: nothing is kept, the error travels up
+        if (best.p) drop(best);
+        return rc;
+    }
+    if (!best.p) {
+        mg_set_error("mg_device_malloc: out of device memory (%lld bytes)", (long long)bytes);
+        return MG_ERR_OUT_OF_MEMORY;
+    }
+    out->base = (char *)best.p; out->bytes = bytes; out->vmm = best.vmm; out->ratio = best_ratio; out->us = best_us;
+    out->probed = probed; out->fast = best_ratio <= fast_ratio; out->live = 0;
+    out->free_list.clear();
+    out->free_list.push_back({0, bytes});
+    return MG_OK;
+}
+
+// a piece of `bytes` from a placed region: first fit in the regions the context has, else a new region of that size
+int mg_output_alloc(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out, double *info) {
+    const size_t need = ((size_t)bytes + MG_REGION_GRANULE - 1) / MG_REGION_GRANULE * MG_REGION_GRANULE;
+    for (int pass = 0; pass < 2; pass++) {
+        for (auto &r : ctx->out_regions) {
+            if (pass == 0 && !r.fast) continue;   // fast regions first
+            for (size_t i = 0; i < r.free_list.size(); i++) {
+                if (r.free_list[i].second < need) continue;
+                *out = r.base + r.free_list[i].first;
+                r.used[(char *)*out - r.base] = need;
+                if (r.free_list[i].second == need) r.free_list.erase(r.free_list.begin() + (long)i);
+                else { r.free_list[i].first += need; r.free_list[i].second -= need; }
+                r.live++;
+                if (info) { info[0] = 0.0; info[1] = r.ratio; info[2] = r.us; info[3] = r.fast ? 1.0 : 0.0; }
+                return MG_OK;
+            }
+        }
+    }
+    mg_context::out_region r;
+    int rc = mg_region_create(ctx, need, (size_t)bytes, max_candidates, &r);
+    if (rc != MG_OK) return rc;
+    *out = r.base;
+    r.used[0] = need;
+    r.free_list.clear();
+    r.live = 1;
+    if (info) { info[0] = r.probed; info[1] = r.ratio; info[2] = r.us; info[3] = r.fast ? 1.0 : 0.0; }
+    ctx->out_regions.push_back(std::move(r));
+    return MG_OK;
+}
+
+// true if p was a piece of a region (and is now free again)
+bool mg_output_free(mg_context *ctx, void *p) {
+    for (auto &r : ctx->out_regions) {
+        if ((char *)p < r.base || (char *)p >= r.base + r.bytes) continue;
+        const size_t off = (size_t)((char *)p - r.base);
+        auto it = r.used.find(off);
+        if (it == r.used.end()) return false;
+        std::pair<size_t, size_t> blk = {off, it->second};
+        r.used.erase(it);
+        r.live--;
+        // insert sorted, merge with neighbours
+        size_t i = 0;
+        while (i < r.free_list.size() && r.free_list[i].first < blk.first) i++;
+        r.free_list.insert(r.free_list.begin() + (long)i, blk);
+        if (i + 1 < r.free_list.size() && r.free_list[i].first + r.free_list[i].second == r.free_list[i + 1].first) {
+            r.free_list[i].second += r.free_list[i + 1].second;
+            r.free_list.erase(r.free_list.begin() + (long)i + 1);
+        }
+        if (i > 0 && r.free_list[i - 1].first + r.free_list[i - 1].second == r.free_list[i].first) {
+            r.free_list[i - 1].second += r.free_list[i].second;
+            r.free_list.erase(r.free_list.begin() + (long)i);
+        }
+        return true;
+    }
+    return false;
+}
+
+void mg_output_release_all(mg_context *ctx) {
+    for (auto &r : ctx->out_regions) mg_region_release(ctx, r);
+    ctx->out_regions.clear();
+}
+
+extern "C" int mg_context_trim_outputs(mg_context *ctx) {
+    if (!ctx) { mg_set_error("mg_context_trim_outputs: ctx is NULL"); return MG_ERR_INVALID_ARGUMENT; }
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = ctx->out_regions.size(); i-- > 0;)
+        if (ctx->out_regions[i].live == 0) {
+            mg_region_release(ctx, ctx->out_regions[i]);
+            ctx->out_regions.erase(ctx->out_regions.begin() + (long)i);
+        }
+    return MG_OK;
+}
+
+extern "C" int mg_context_output_bytes(mg_context *ctx, int64_t *reserved, int64_t *in_use, int32_t *n_regions, int32_t *n_fast) {
+    if (!ctx) { mg_set_error("mg_context_output_bytes: ctx is NULL"); return MG_ERR_INVALID_ARGUMENT; }
+    int64_t res = 0, use = 0;
+    int32_t nf = 0;
+    for (auto &r : ctx->out_regions) {
+        res += (int64_t)r.bytes;
+        for (auto &u : r.used) use += (int64_t)u.second;
+        nf += r.fast ? 1 : 0;
+    }
+    if (reserved) *reserved = res;
+    if (in_use) *in_use = use;
+    if (n_regions) *n_regions = (int32_t)ctx->out_regions.size();
+    if (n_fast) *n_fast = nf;
+    return MG_OK;
+}
+
 extern "C" int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out_dev, double *info) {
     if (!ctx || !out_dev || bytes < 0) {
         mg_set_error("mg_device_malloc_placed: bad arguments");
@@ -108,64 +289,5 @@ extern "C" int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t m
     MG_HIP_CHECK(hipSetDevice(ctx->device));
     if (info) { info[0] = 0.0; info[1] = 1.0; info[2] = 0.0; info[3] = 1.0; }
     if (bytes < MG_PLACED_MIN_BYTES) return mg_device_malloc(ctx, bytes, out_dev);
-    size_t free_b = 0, total_b = 0;
-    MG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    // default budget: up to 768 candidates in nine tenths of the free memory, i.e. a scan of nearly the whole card when it
-    // has to be (a probe takes ~1.5 ms; on the boxes where fast regions are rare the first fast candidate has been the 13th,
-    // the 22nd, the 202nd)
-    int budget = max_candidates > 0 ? max_candidates : 768;
-    budget = (int)std::max<int64_t>(1, std::min<int64_t>(budget, (int64_t)(free_b / 10 * 9) / bytes));
-    const double fast_ratio = ctx->opt[MG_OPT_PLACED_FAST_PCT] > 0 ? ctx->opt[MG_OPT_PLACED_FAST_PCT] / 100.0 : MG_PLACED_FAST_RATIO;
-    std::vector<void *> held, held_vmm;
-    void *best = nullptr;
-    bool best_is_vmm = false;
-    double best_ratio = 0.0, best_us = 0.0;
-    int probed = 0, rc = MG_OK;
-    auto consider = [&](void *p, bool vmm) -> bool {   // probe p, keep the better of (best, p), hold the other; false: stop
-        double ratio = 1.0, us = 0.0;
-        rc = mg_probe_placement(ctx, p, bytes, &ratio, &us);
-        if (rc != MG_OK) { if (vmm) (void)mg_device_free(ctx, p); else (void)hipFree(p); return false; }
-        probed++;
-        if (!best || ratio < best_ratio) {
-            if (best) (best_is_vmm ? held_vmm : held).push_back(best);
-            best = p; best_ratio = ratio; best_us = us; best_is_vmm = vmm;
-        } else {
-            (vmm ? held_vmm : held).push_back(p);
-        }
-        return best_ratio > fast_ratio;
-    };
-    auto plain = [&](int count) {
-        for (int i = 0; i < count; i++) {
-            void *p = nullptr;
-            if (hipMalloc(&p, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); return; }   // out of memory: settle for the best so far
-            if (!consider(p, false)) return;
-        }
-    };
-    // Two recipes.  Plain allocations first (on most boxes the second or third is fast); where sixteen of them were not, twelve
-    // buffers assembled from physical chunks through the virtual-memory API (on some boxes only those are fast: 202 probes
-    // in one measured run, the first fast one a chunked buffer), then the rest of the plain budget.
-    const int first = std::min(budget, 16);
-    plain(first);
-    if (best && best_ratio > fast_ratio && rc == MG_OK && max_candidates != 1) {
-        static const int64_t chunk_mib[3] = {8, 32, 2};
-        bool go = true;
-        for (int c = 0; c < 3 && go; c++)
-            for (int i = 0; i < 4 && go; i++) {
-                void *p = nullptr;
-                if (mg_device_malloc_chunked(ctx, bytes, chunk_mib[c] << 20, &p) != MG_OK) { (void)hipGetLastError(); go = false; break; }
-                go = consider(p, true);
-            }
-        if (rc == MG_OK && best_ratio > fast_ratio) plain(budget - first);
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    for (void *p : held) (void)hipFree(p);
-    for (void *p : held_vmm) (void)mg_device_free(ctx, p);
-    if (!best) {
-        if (rc != MG_OK) return rc;
-        mg_set_error("mg_device_malloc_placed: out of device memory (%lld bytes)", (long long)bytes);
-        return MG_ERR_OUT_OF_MEMORY;
-    }
-    *out_dev = best;
-    if (info) { info[0] = probed; info[1] = best_ratio; info[2] = best_us; info[3] = best_ratio <= fast_ratio ? 1.0 : 0.0; }
-    return MG_OK;
+    return mg_output_alloc(ctx, bytes, max_candidates, out_dev, info);
 }

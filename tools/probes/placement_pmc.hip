@@ -64,6 +64,45 @@ __global__ __launch_bounds__(512) void k_pattern_tag(float *out, int ntiles, flo
             }
     }
 }
+// T11: the same stores under other (workgroup, step) -> (tile, chunk) maps; every map writes every (tile, chunk) once
+__device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> 23); }
+__global__ __launch_bounds__(512) void k_map(float *out, int ntiles, int mode, int prm) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int fsub = lane / 20, ql = lane % 20;
+    const bool on = lane < 60;
+    const int w = blockIdx.x, G = gridDim.x;
+    const int nblk = G / NCH, q = (ntiles + nblk - 1) / nblk;   // chunk-stationary maps: nblk workgroups per chunk, q tiles each
+    const int U = ntiles * NCH, per = (U + G - 1) / G;
+    const int steps = mode == 0 ? per : q;
+    for (int s = 0; s < steps; s++) {
+        int tile, chunk;
+        if (mode == 0) { const int u = w * per + s; if (u >= U) break; tile = u / NCH; chunk = (u % NCH + w) % NCH; }
+        else {
+            chunk = (mode == 5) ? w / nblk : w % NCH;
+            const int j = (mode == 5) ? w % nblk : w / NCH;
+            const int lin = j * q + s;
+            if (mode == 1 || mode == 5) tile = lin;
+            else if (mode == 2) tile = j * q + (s + j) % q;
+            else if (mode == 3) tile = s * nblk + j;
+            else if (mode == 4) tile = (int)(((long long)lin * prm) % ntiles);
+            else if (mode == 6) tile = (lin + chunk * prm) % ntiles;
+            else if (mode == 7) tile = bitrev9(lin) % ntiles;
+            else if (mode == 8) tile = (j * q + (s * prm) % q);          // another order inside the block
+            else tile = lin;
+            if (tile >= ntiles) continue;
+        }
+        for (int f0 = 0; f0 < NF; f0 += 3)
+            for (int half = 0; half < 2; half++) {
+                const size_t cand = (size_t)tile * 16 + wave + 8 * half;
+                const int f = f0 + fsub;
+                if (on && f < NF) {
+                    float *p = out + (cand * T + (size_t)(chunk * NF + f)) * D + (ql == 19 ? 75 : 4 * ql);
+                    const f4u v = {0.f, 0.f, 0.f, 11.f};
+                    *(f4u *)p = v;
+                }
+            }
+    }
+}
 template <int TAG>
 __global__ __launch_bounds__(256) void k_fill(f4 *buf, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -150,6 +189,7 @@ int main(int argc, char **argv) {
     const int n_plain = argc > 1 ? atoi(argv[1]) : 24;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const size_t NBYTES = (size_t)B * T * D * 4, n4 = NBYTES / 16;
+    const size_t ALLOC = (NBYTES + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
     const int ntiles = B / 16;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int grid = prop.multiProcessorCount;
@@ -157,7 +197,7 @@ int main(int argc, char **argv) {
     auto fil = [&](void *p) { return timeit([&] { hipLaunchKernelGGL(k_fill<9>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, (f4 *)p, n4); }); };
 
     // T6 (first, on fresh memory): in-order against shuffled chunk mapping, all buffers of a row held at once
-    if (argc > 2) {
+    if (argc > 2 && atoi(argv[2]) != 10) {
         for (size_t c : {(size_t)2 << 20, (size_t)8 << 20, (size_t)32 << 20}) {
             for (int mode = 0; mode < 3; mode++) {
                 std::vector<vmm_buf> held(4);
@@ -267,7 +307,7 @@ int main(int argc, char **argv) {
     std::vector<void *> plain; std::vector<float> pr, pp;
     for (int i = 0; i < n_plain; i++) {
         void *p = nullptr;
-        if (hipMalloc(&p, NBYTES) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (hipMalloc(&p, ALLOC) != hipSuccess) { (void)hipGetLastError(); break; }
         plain.push_back(p);
         const float f = fil(p), q = pat(p);
         pr.push_back(q / f); pp.push_back(q);
@@ -277,6 +317,42 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < pr.size(); i++) { if (pr[i] < pr[ifast]) ifast = (int)i; if (pr[i] > pr[islow]) islow = (int)i; }
     printf("T1 fast = plain %d (%.3f), slow = plain %d (%.3f)\n", ifast, pr[ifast], islow, pr[islow]);
     void *fast = plain[ifast], *slow = plain[islow];
+    // T10: the same stores from fewer workgroups (and so another unit -> workgroup map): does the slow class need all 256 CUs?
+    for (int gr : {256, 252, 248, 240, 232, 228, 224, 208, 192, 171, 160, 128, 103, 64}) {
+        const float qf = timeit([&] { hipLaunchKernelGGL(k_pattern<9>, dim3(gr), dim3(512), 0, 0, (float *)fast, ntiles); });
+        const float qs = timeit([&] { hipLaunchKernelGGL(k_pattern<9>, dim3(gr), dim3(512), 0, 0, (float *)slow, ntiles); });
+        printf("T10 grid %3d (%2d units per workgroup): fast buffer %5.1f us, slow buffer %5.1f us\n", gr, (ntiles * NCH + gr - 1) / gr, qf, qs);
+    }
+    for (int nt : {512, 513, 514, 520}) {   // one more tile than the buffer's 512 (stays inside the 2 MiB-rounded allocation for 513)
+        if ((size_t)nt * 16 * T * D * 4 > ALLOC) continue;
+        const float qf = timeit([&] { hipLaunchKernelGGL(k_pattern<9>, dim3(grid), dim3(512), 0, 0, (float *)fast, nt); });
+        const float qs = timeit([&] { hipLaunchKernelGGL(k_pattern<9>, dim3(grid), dim3(512), 0, 0, (float *)slow, nt); });
+        printf("T10 ntiles %d grid %d: fast buffer %5.1f us, slow buffer %5.1f us\n", nt, grid, qf, qs);
+    }
+    {
+        struct mp { int mode, prm; const char *what; };
+        const mp maps[] = {{0, 0, "tile-major: u = w per + s, chunk rotated by w (the probe's pattern)"},
+                           {1, 0, "chunk-stationary: chunk w % 4, block of q consecutive tiles per workgroup"},
+                           {5, 0, "chunk-stationary, chunk = w / 64"},
+                           {2, 0, "chunk-stationary, block walked from tile (s + j) % q"},
+                           {3, 0, "chunk-stationary, tiles dealt round-robin (s nblk + j)"},
+                           {4, 77, "chunk-stationary, tile = 77 lin mod 512"},
+                           {4, 3, "chunk-stationary, tile = 3 lin mod 512"},
+                           {4, 171, "chunk-stationary, tile = 171 lin mod 512"},
+                           {6, 1, "chunk-stationary, blocks shifted by chunk x 1 tile"},
+                           {6, 3, "chunk-stationary, blocks shifted by chunk x 3 tiles"},
+                           {6, 37, "chunk-stationary, blocks shifted by chunk x 37 tiles"},
+                           {7, 0, "chunk-stationary, tile = bit-reversed lin"},
+                           {8, 3, "chunk-stationary, block walked in steps of 3"}};
+        for (int gr : {256, 252, 240}) {
+            for (const mp &m : maps) {
+                const float qf = timeit([&] { hipLaunchKernelGGL(k_map, dim3(gr), dim3(512), 0, 0, (float *)fast, ntiles, m.mode, m.prm); });
+                const float qs = timeit([&] { hipLaunchKernelGGL(k_map, dim3(gr), dim3(512), 0, 0, (float *)slow, ntiles, m.mode, m.prm); });
+                printf("T11 grid %3d  fast %5.1f  slow %5.1f  %s\n", gr, qf, qs, m.what);
+            }
+        }
+    }
+    if (argc > 2 && atoi(argv[2]) == 10) return 0;
     for (size_t i = 0; i < plain.size(); i++) if ((int)i != ifast && (int)i != islow) (void)hipFree(plain[i]);
 
     // T2
