@@ -79,58 +79,51 @@ def self_launch(args, argv):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode("utf-8", "replace"))
+    # rank 0's stdout is collected by a thread; the launcher polls ALL children: when one dies the others are ended (a rank
+    # alone in a rendezvous or inside an RCCL collective never returns), and the whole run is bounded
+    import glob
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("MG_BENCH_LAUNCH_TIMEOUT", "1500"))
+    failed = None
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad or time.time() > deadline:
+                failed = ("rank %d exited with %d" % (bad[0], procs[bad[0]].returncode)) if bad else "timed out"
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            time.sleep(0.05)
+    finally:
+        for f in glob.glob(os.path.join(tempfile.gettempdir(), "mg_bench_%d_%d.*" % (os.getpid(), port))):   # rendezvous files a dead rank left
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    reader.join(10)
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(b"".join(c for c in chunks if c).decode("utf-8", "replace"))
     sys.stdout.flush()
+    if failed:
+        sys.stderr.write("bench.py launcher: %s; the other ranks were ended\n" % failed)
+        return 1
     return max(abs(rc) for rc in rcs)
 
 
-class FileRendezvous(object):
-    """How the 128-byte RCCL unique id (and, in a dry run, everything else) travels between the ranks of one node
-    without torch: files named after the launcher's pid and the master port, written with an atomic rename."""
-
-    def __init__(self, rank, world):
-        self.rank, self.world = rank, world
-        self.base = os.path.join(tempfile.gettempdir(), "mg_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
-        self.seq = 0
-
-    def _path(self, tag, r):
-        return "%s.%s.%d" % (self.base, tag, r)
-
-    def put(self, tag, payload):
-        tmp = self._path(tag, self.rank) + ".tmp"
-        with open(tmp, "wb") as f:
-            f.write(payload)
-        os.rename(tmp, self._path(tag, self.rank))
-
-    def get(self, tag, r, timeout=300.0):
-        deadline = time.time() + timeout
-        p = self._path(tag, r)
-        while not os.path.exists(p):
-            if time.time() > deadline:
-                raise SystemExit("rank %d: timed out waiting for rank %d (%s)" % (self.rank, r, tag))
-            time.sleep(0.002)
-        with open(p, "rb") as f:
-            return f.read()
-
-    def all_gather(self, payload):
-        """every rank's bytes on every rank (used for the id hand-over and by the dry run)"""
-        tag = "ag%d" % self.seq
-        self.seq += 1
-        self.put(tag, payload)
-        got = [self.get(tag, r) for r in range(self.world)]
-        self.put(tag + "done", b"1")
-        if self.rank == 0:   # the files go once everybody has read them
-            for r in range(self.world):
-                self.get(tag + "done", r)
-            for r in range(self.world):
-                for t in (tag, tag + "done"):
-                    try:
-                        os.remove(self._path(t, r))
-                    except OSError:
-                        pass
-        return got
+def FileRendezvous(rank, world):
+    """How the 128-byte RCCL unique id (and, in a dry run, everything else) travels between the ranks of one node without
+    torch: morphablegraphs_amd.distributed.FileRendezvous under a name made of the launcher's pid and the master port."""
+    from morphablegraphs_amd.distributed import FileRendezvous as _Rdv
+    return _Rdv(rank, world, base=os.path.join(tempfile.gettempdir(), "mg_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))))
 
 
 def ensure_built():
@@ -154,6 +147,8 @@ def ensure_built():
 # ---------------------------------------------------------------------------------------------------------
 def run_walk(args, rank, local_rank, world):
     dry = args.dry_run
+    if dry and os.environ.get("MG_BENCH_DRY_RUN_DIES") == str(rank):   # launcher test: a rank that dies before the rendezvous
+        raise SystemExit(3)
     rdv = FileRendezvous(rank, world) if world > 1 else None
     B = int(args.batch)
     per_cand, consts, bytes_launch = algorithmic_bytes(B)

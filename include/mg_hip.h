@@ -295,6 +295,9 @@ int mg_profile_get_samples(mg_context *ctx, int slot, float *out_ms, int64_t cap
 int mg_dist_unique_id(void *id_out);
 int mg_dist_init(mg_context *ctx, int32_t rank, int32_t n_ranks, const void *id);
 int mg_dist_all_gather(mg_context *ctx, const void *local_dev, void *gathered_dev, int64_t count, int dtype);
+/* `bytes` bytes of buf_dev from rank `root` to every rank's buf_dev, on the context's stream: how rank 0 -- the one process
+ * that runs the reference's control flow -- hands a step's constraint values, seeds and component counts to the workers */
+int mg_dist_broadcast(mg_context *ctx, void *buf_dev, int64_t bytes, int32_t root);
 int mg_dist_finalize(mg_context *ctx);
 
 /* ---- primitive -------------------------------------------------------------------
@@ -409,6 +412,11 @@ int mg_gmm_log_prob_jac(mg_primitive *prim, const void *x_dev, int x_dtype, int6
  * x_dev (n, ld) of x_dtype, component_dev (n) int32 or NULL. */
 int mg_gmm_sample(mg_primitive *prim, int64_t n_samples, const int64_t *counts, uint64_t seed,
                   void *x_dev, int x_dtype, int64_t ld, int32_t *component_dev);
+/* Rows [row_begin, row_begin + row_count) of that same draw of n_samples rows, bit for bit (the generator is counter based: a
+ * row's values depend on (seed, row, column group) only): x_dev (row_count, ld), component_dev (row_count).  What a rank of a
+ * sharded step draws: the union over the ranks' contiguous blocks IS the single-GPU draw. */
+int mg_gmm_sample_rows(mg_primitive *prim, int64_t n_samples, const int64_t *counts, uint64_t seed, int64_t row_begin, int64_t row_count,
+                       void *x_dev, int x_dtype, int64_t ld, int32_t *component_dev);
 
 /* ---- fused candidate scoring ------------------------------------------------------------
  * MotionPrimitiveConstraints.evaluate summed over root-joint keyframe constraints
@@ -490,6 +498,17 @@ int mg_option_step(mg_primitive *prim, const mg_constraint_set *cs, int64_t n_sa
 int mg_options_step(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n_samples,
                     const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int x_dtype, const int64_t *ld,
                     double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host);
+
+/* One rank's share of a step sharded over GPUs (contiguous candidate blocks, constants replicated): the same
+ * calls restricted to the global rows [row_begin, row_begin + row_count) of every option's draw of n_samples candidates.
+ * x_dev (row_count, ld) and errors_dev (row_count) hold the block; the index in a result record is the GLOBAL row, so the
+ * records of all ranks combine by (smaller error, then smaller index) into exactly the single-GPU result. */
+int mg_option_step_rows(mg_primitive *prim, const mg_constraint_set *cs, int64_t n_samples, const int64_t *counts, uint64_t seed,
+                        int64_t row_begin, int64_t row_count, void *x_dev, int x_dtype, int64_t ld, double *errors_dev, void *result_dev);
+int mg_options_step_rows(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n_samples,
+                         const int64_t *const *counts, const uint64_t *seeds, int64_t row_begin, int64_t row_count,
+                         void *const *x_dev, int x_dtype, const int64_t *ld, double *const *errors_dev, void *results_dev,
+                         int64_t result_stride, void *results_host);
 
 /* ---- host-pointer convenience variants (H2D, launch, D2H, synchronise) ---------------- */
 int mg_back_project_frames_host(mg_primitive *prim, const mg_time_grid *grid, const void *latents,

@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
-    "mg_option_step", "mg_options_step",
+    "mg_option_step", "mg_options_step", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
 ]
 
 
@@ -252,6 +252,10 @@ def load_library(path=None):
         "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_option_step": [vp, vp, i64, vp, u64, vp, i32, i64, vp, vp],
+        "mg_option_step_rows": [vp, vp, i64, vp, u64, i64, i64, vp, i32, i64, vp, vp],
+        "mg_options_step_rows": [i32, vp, vp, i64, vp, vp, i64, i64, vp, i32, vp, vp, vp, i64, vp],
+        "mg_gmm_sample_rows": [vp, i64, vp, u64, i64, i64, vp, i32, i64, vp],
+        "mg_dist_broadcast": [vp, vp, i64, i32],
         "mg_options_step": [i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
         "mg_score_constraint_residuals_host": [vp, vp, vp, i32, i64, i64, vp],
@@ -349,6 +353,14 @@ class Context(object):
         """gathered[r * count + i] = rank r's local[i], on the context's stream."""
         code = MG_F64 if np.dtype(dtype) == np.float64 else MG_F32
         _check(self.lib.mg_dist_all_gather(self.handle, _dev_ptr(local_dev), _dev_ptr(gathered_dev), int(count), code))
+
+    def dist_broadcast(self, buf_dev, nbytes, root=0):
+        """nbytes bytes of buf_dev from rank `root` to every rank, on the context's stream."""
+        _check(self.lib.mg_dist_broadcast(self.handle, _dev_ptr(buf_dev), int(nbytes), int(root)))
+
+    def upload_into(self, buf, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(self.lib.mg_memcpy_h2d(self.handle, _dev_ptr(buf), arr.ctypes.data_as(C.c_void_p), arr.nbytes))
 
     def dist_finalize(self):
         _check(self.lib.mg_dist_finalize(self.handle))
@@ -909,13 +921,16 @@ class Primitive(object):
         oc = MG_F64 if np.dtype(out_dtype) == np.float64 else MG_F32
         _check(self.lib.mg_gmm_log_prob(self.handle, _dev_ptr(x_dev), xc, int(n), int(ld), _dev_ptr(out_dev), oc))
 
-    def gmm_sample_dev(self, counts, seed, x_dev, x_dtype, ld, component_dev=None):
-        """Device Philox sampler into device memory: rows grouped by component like sklearn's sample()."""
+    def gmm_sample_dev(self, counts, seed, x_dev, x_dtype, ld, component_dev=None, rows=None):
+        """Device Philox sampler into device memory: rows grouped by component like sklearn's sample().
+        rows = (begin, count): only those rows of the draw (mg_gmm_sample_rows), x_dev (count, ld)."""
         counts = np.ascontiguousarray(counts, dtype=np.int64)
         xc = MG_F64 if np.dtype(x_dtype) == np.float64 else MG_F32
         comp = _dev_ptr(component_dev) if component_dev is not None else C.c_void_p(0)
-        _check(self.lib.mg_gmm_sample(self.handle, int(counts.sum()), counts.ctypes.data_as(C.c_void_p),
-                                      C.c_uint64(int(seed)), _dev_ptr(x_dev), xc, int(ld), comp))
+        n = int(counts.sum())
+        begin, count = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+        _check(self.lib.mg_gmm_sample_rows(self.handle, n, counts.ctypes.data_as(C.c_void_p), C.c_uint64(int(seed)), begin, count,
+                                           _dev_ptr(x_dev), xc, int(ld), comp))
 
     def score_constraints_dev(self, cset, lat_dev, lat_dtype, n, ld, out_dev, out_dtype=np.float64):
         lc = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32

@@ -317,30 +317,89 @@ class HipSampleFilter(object):
             cset.close()
 
 
-def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frames=None, skeleton=None):
-    """Drop-in for MotionPrimitiveGenerator.evaluate_samples_using_constraints: returns (samples[best_idx],
-    min_error) with the reference's first-minimum rule, and updates constraints.min_error / constraints.evaluations
-    when those attributes exist.  With `prev_frames` (and constraints that are not `is_local`) every candidate is
-    aligned to the previous motion first, like MotionPrimitiveConstraints.evaluate."""
-    samples = np.asarray(samples)
+def _prim_of(mp_node):
     prim_obj = mp_node.motion_primitive if hasattr(mp_node, "motion_primitive") else mp_node
-    prim = prim_obj._prim
-    clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
-    skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
-    keyframes, trajectories = split_trajectories(constraints_to_device_form(clist))
-    alignment = alignment_from_prev_frames(prev_frames, constraints, skeleton)
+    return prim_obj, prim_obj._prim
+
+
+def first_minimum_of_block(mp_node, device_form, alignment, samples, skeleton=None):
+    """(index, error) of the first minimum among `samples` (n, L) for constraints already in device form: what one rank does
+    with its block of a sharded evaluate_samples_using_constraints, and the whole of the single-GPU call."""
+    prim_obj, prim = _prim_of(mp_node)
+    keyframes, trajectories = split_trajectories(device_form)
+    if len(samples) == 0:
+        return 0, float("inf")
     if trajectories:
         S = _capi._latents(samples)
         d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(max(len(S), 1) * 8)
         try:
             _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_S, S.dtype, len(S), S.shape[1], d_e)
-            best_idx, min_error = prim.ctx.argmin_first(d_e, len(S), np.float64)
+            return prim.ctx.argmin_first(d_e, len(S), np.float64)
         finally:
             d_S.free()
             d_e.free()
+    cset = cached_constraint_set(prim, keyframes, skeleton, alignment)
+    return prim.best_candidate(cset, samples)   # one upload, two launches, 16 bytes back
+
+
+def sample_rows_and_first_minimum(mp_node, device_form, alignment, counts, seed, row_begin, row_end, skeleton=None, dtype=np.float32):
+    """Rows [row_begin, row_end) of the device sampler's draw for (counts, seed), scored, first minimum: returns
+    (index relative to row_begin, error, winning latent at full width).  One rank's block of a sharded gpu_batch step; with
+    (0, n) the whole single-GPU step.  Only the winner leaves the GPU."""
+    prim_obj, prim = _prim_of(mp_node)
+    ctx = prim.ctx
+    keyframes, trajectories = split_trajectories(device_form)
+    L = prim.n_gmm_dims          # the full sample (spatial + time latents); scoring reads its first n_components columns
+    m = int(row_end) - int(row_begin)
+    item = np.dtype(dtype).itemsize
+    d_x = ctx.malloc(max(m, 1) * L * item)
+    try:
+        prim.gmm_sample_dev(np.asarray(counts, dtype=np.int64), seed, d_x, dtype, L, rows=(int(row_begin), m))
+        if trajectories:
+            d_e = ctx.malloc(max(m, 1) * 8)
+            try:
+                _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_x, dtype, m, L, d_e)
+                best_idx, min_error = ctx.argmin_first(d_e, m, np.float64)
+            finally:
+                d_e.free()
+        else:
+            cset = cached_constraint_set(prim, keyframes, skeleton, alignment)
+            best_idx, min_error = prim.best_candidate_dev(cset, d_x, dtype, m, L)
+        best = ctx.download(d_x.ptr.value + best_idx * L * item, (L,), dtype)
+    finally:
+        d_x.free()
+    return best_idx, min_error, best.astype(np.float64)
+
+
+def _node_key(mp_node, communicator):
+    """how the ranks of a sharded call name the primitive: the key under which every rank holds it"""
+    key = getattr(mp_node, "node_key", None)
+    if key is None:
+        prim_obj, _ = _prim_of(mp_node)
+        key = getattr(prim_obj, "name", None)
+    return key
+
+
+def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frames=None, skeleton=None, communicator=None):
+    """Drop-in for MotionPrimitiveGenerator.evaluate_samples_using_constraints: returns (samples[best_idx],
+    min_error) with the reference's first-minimum rule, and updates constraints.min_error / constraints.evaluations
+    when those attributes exist.  With `prev_frames` (and constraints that are not `is_local`) every candidate is
+    aligned to the previous motion first, like MotionPrimitiveConstraints.evaluate.
+    communicator (distributed.MgCommunicator / FileCommunicator, rank 0 calling, the other ranks in distributed.worker_loop):
+    the candidates travel to the ranks with the command, every rank scores its contiguous block, one all-gather of the
+    ranks' first minima -- the same winner as the single-GPU call."""
+    samples = np.asarray(samples)
+    clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
+    skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
+    device_form = constraints_to_device_form(clist)
+    alignment = alignment_from_prev_frames(prev_frames, constraints, skeleton)
+    if communicator is not None and communicator.world > 1:
+        from . import distributed
+        best_idx, min_error, _ = distributed.run_command(communicator, {_node_key(mp_node, communicator): mp_node, "__skeleton__": skeleton},
+                                                         {"op": "evaluate_samples", "node": _node_key(mp_node, communicator), "samples": samples,
+                                                          "constraints": device_form, "alignment": alignment, "skeleton": skeleton is not None})
     else:
-        cset = cached_constraint_set(prim, keyframes, skeleton, alignment)
-        best_idx, min_error = prim.best_candidate(cset, samples)   # one upload, two launches, 16 bytes back
+        best_idx, min_error = first_minimum_of_block(mp_node, device_form, alignment, samples, skeleton)
     if hasattr(constraints, "min_error"):
         constraints.min_error = min_error
     if hasattr(constraints, "evaluations"):
@@ -348,40 +407,32 @@ def evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frame
     return samples[best_idx], min_error
 
 
-def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleton=None, dtype=np.float32, prev_frames=None):
+def sample_and_evaluate_on_device(mp_node, constraints, n_samples, seed, skeleton=None, dtype=np.float32, prev_frames=None, communicator=None):
     """The gpu_batch step without the host round trip: component counts from NumPy's global stream (the first
     draw sklearn's GaussianMixture.sample makes), latents from the device Philox sampler (NOT sklearn's Mersenne
     stream: distributional parity only), scoring and first-minimum argmin on the device; only the winning latent
-    vector comes back.  Returns (best_sample, min_error)."""
-    prim_obj = mp_node.motion_primitive if hasattr(mp_node, "motion_primitive") else mp_node
-    prim = prim_obj._prim
-    ctx = prim.ctx
+    vector comes back.  Returns (best_sample, min_error).
+    communicator: rank 0 broadcasts (constraint values, counts, seed); every rank draws ITS rows of the one draw (the
+    generator is counter based: the union of the ranks' blocks is the single-GPU draw, bit for bit), scores them and offers
+    its first minimum; the same (best_sample, min_error) as without a communicator."""
+    prim_obj, prim = _prim_of(mp_node)
     clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
     skeleton = skeleton if skeleton is not None else getattr(constraints, "hip_skeleton", None)
-    keyframes, trajectories = split_trajectories(constraints_to_device_form(clist))
+    device_form = constraints_to_device_form(clist)
     alignment = alignment_from_prev_frames(prev_frames, constraints, skeleton)
-    cset = cached_constraint_set(prim, keyframes, skeleton, alignment)
-    L = prim.n_gmm_dims          # the full sample (spatial + time latents); scoring reads its first n_components columns
     weights = np.asarray(prim_obj.gaussian_mixture_model.weights_, dtype=np.float64)
     counts = np.random.multinomial(int(n_samples), weights / weights.sum()).astype(np.int64)
-    item = np.dtype(dtype).itemsize
-    d_x = ctx.malloc(max(int(n_samples), 1) * L * item)
-    try:
-        prim.gmm_sample_dev(counts, seed, d_x, dtype, L)
-        if trajectories:
-            d_e = ctx.malloc(max(int(n_samples), 1) * 8)
-            try:
-                _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_x, dtype, int(n_samples), L, d_e)
-                best_idx, min_error = ctx.argmin_first(d_e, int(n_samples), np.float64)
-            finally:
-                d_e.free()
-        else:
-            best_idx, min_error = prim.best_candidate_dev(cset, d_x, dtype, int(n_samples), L)
-        best = ctx.download(d_x.ptr.value + best_idx * L * item, (L,), dtype)
-    finally:
-        d_x.free()
+    if communicator is not None and communicator.world > 1:
+        from . import distributed
+        _, min_error, best = distributed.run_command(communicator, {_node_key(mp_node, communicator): mp_node, "__skeleton__": skeleton},
+                                                     {"op": "sample_and_evaluate", "node": _node_key(mp_node, communicator), "constraints": device_form,
+                                                      "alignment": alignment, "skeleton": skeleton is not None, "counts": counts, "seed": int(seed),
+                                                      "dtype": np.dtype(dtype).name})
+        best = best.astype(dtype).astype(np.float64)
+    else:
+        _, min_error, best = sample_rows_and_first_minimum(mp_node, device_form, alignment, counts, seed, 0, int(n_samples), skeleton, dtype)
     if hasattr(constraints, "min_error"):
         constraints.min_error = min_error
     if hasattr(constraints, "evaluations"):
         constraints.evaluations += int(n_samples)
-    return best.astype(np.float64), min_error
+    return best, min_error

@@ -299,6 +299,7 @@ struct mg_sample_args {
     int64_t n, ld;
     uint64_t seed;
     int32_t K, L;
+    int64_t row_lo, row_hi;   // the rows of the global draw this launch produces: x row (b - row_lo)
 };
 
 #define MG_SAMPLE_BLOCK 64   // one wave per workgroup: 8192 samples spread over 128 CUs (the kernel is latency bound)
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(MG_SAMPLE_BLOCK) void mg_gmm_sample_kernel(mg_sampl
     const int L = a.L, zs = L + 1;
     double *lds_z = (double *)smem;   // [MG_SAMPLE_BLOCK][L+1]
     const int tid = threadIdx.x;
-    const int64_t b = (int64_t)blockIdx.x * MG_SAMPLE_BLOCK + tid;
-    if (b < a.n) {
+    const int64_t b = a.row_lo + (int64_t)blockIdx.x * MG_SAMPLE_BLOCK + tid;
+    if (b < a.row_hi) {
         double *z = lds_z + (size_t)tid * zs;
         for (int i = 0; i < L; i += 4) {
             double zz[4];
@@ -323,16 +324,19 @@ __global__ __launch_bounds__(MG_SAMPLE_BLOCK) void mg_gmm_sample_kernel(mg_sampl
         for (int i = 0; i < L; i++) {
             double acc = mu[i];
             for (int j = 0; j <= i; j++) acc = fma(Lc[i * L + j], z[j], acc);
-            if (X_F64) ((double *)a.x)[b * a.ld + i] = acc;
-            else ((float *)a.x)[b * a.ld + i] = (float)acc;
+            if (X_F64) ((double *)a.x)[(b - a.row_lo) * a.ld + i] = acc;
+            else ((float *)a.x)[(b - a.row_lo) * a.ld + i] = (float)acc;
         }
-        if (a.comp) a.comp[b] = c;
+        if (a.comp) a.comp[b - a.row_lo] = c;
     }
 }
 
-int mg_launch_gmm_sample_valu(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
+int mg_launch_gmm_sample_valu(mg_primitive *p, int64_t n, const int64_t *cum_dev, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp,
+                              int64_t row_lo, int64_t row_hi) {
     mg_sample_args a;
     a.chol = p->d_gchol; a.mean = p->d_gmean; a.cum = cum_dev; a.x = x; a.comp = comp; a.n = n; a.ld = ld; a.seed = seed; a.K = p->K; a.L = p->Lg;
+    a.row_lo = row_lo; a.row_hi = row_hi;
+    n = row_hi - row_lo;
     size_t lds = (size_t)MG_SAMPLE_BLOCK * (p->Lg + 1) * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_gmm_sample: n_components %d too large", p->Lg); return MG_ERR_UNSUPPORTED; }
     int64_t grid = (n + MG_SAMPLE_BLOCK - 1) / MG_SAMPLE_BLOCK;
@@ -536,7 +540,8 @@ __global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *_
                                                                 const mg_cum_arg cum_arg,
                                                                 void *__restrict__ x, int32_t *__restrict__ comp,
                                                                 const int64_t n_tiles, const int64_t ld, const uint64_t seed,
-                                                                const int K, const int L, const int JT) {
+                                                                const int K, const int L, const int JT,
+                                                                const int64_t tile0, const int64_t row_lo, const int64_t row_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int JTM = (KK + 3) / 4;
     constexpr int ZS = 4 * KK + 1;
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, g = lane >> 4;
     mg_lds_f64 *zt = (mg_lds_f64 *)smem + wave * 16 * ZS;   // [16][ZS] standard normals of this wave's tile
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t t = tile0 + (int64_t)blockIdx.x * 4 + wave;   // tiles [tile0, n_tiles): the ones that hold rows [row_lo, row_hi)
     if (t >= n_tiles) return;
     const int64_t *cum = CUM_ARG ? cum_arg.v : cum_dev;
     const int64_t *tcum = cum + K + 1;
@@ -577,20 +582,22 @@ __global__ __launch_bounds__(256) void mg_gmm_sample_mfma_kernel(const double *_
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = g + 4 * r;
-                if (row < nrow && i < L) {
-                    if (X_F64) ((double *)x)[(row0 + row) * ld + i] = acc[r];
-                    else ((float *)x)[(row0 + row) * ld + i] = (float)acc[r];
+                const int64_t gr = row0 + row;
+                if (row < nrow && i < L && gr >= row_lo && gr < row_hi) {
+                    if (X_F64) ((double *)x)[(gr - row_lo) * ld + i] = acc[r];
+                    else ((float *)x)[(gr - row_lo) * ld + i] = (float)acc[r];
                 }
             }
         }
     }
-    if (comp && lane < nrow) comp[row0 + lane] = c;
+    if (comp && lane < nrow && row0 + lane >= row_lo && row0 + lane < row_hi) comp[row0 + lane - row_lo] = c;
 }
 
 template <int KK>
 static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed,
-                                        void *x, int xdt, int64_t ld, int32_t *comp) {
-    const int64_t grid = (n_tiles + 3) / 4;
+                                        void *x, int xdt, int64_t ld, int32_t *comp, int64_t tile0, int64_t row_lo, int64_t row_hi) {
+    const int64_t grid = (n_tiles - tile0 + 3) / 4;
+    if (grid <= 0) return MG_OK;
     if (grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
     const size_t lds = (size_t)4 * 16 * (4 * KK + 1) * 8;
     hipStream_t st = p->ctx->stream;
@@ -599,31 +606,33 @@ static int mg_launch_gmm_sample_mfma_kk(mg_primitive *p, const int64_t *cum_dev,
     memset(&ca, 0, sizeof(ca));
     if (cum_host) {
         memcpy(ca.v, cum_host, sizeof(int64_t) * 2 * (p->K + 1));
-        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
-        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
+        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT, tile0, row_lo, row_hi);
+        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, nullptr, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT, tile0, row_lo, row_hi);
     } else {
-        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
-        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT);
+        if (xdt == MG_F64) hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT, tile0, row_lo, row_hi);
+        else hipLaunchKernelGGL((mg_gmm_sample_mfma_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, p->d_gcholpack, p->d_gmeanpad, cum_dev, ca, x, comp, n_tiles, ld, seed, p->K, p->Lg, JT, tile0, row_lo, row_hi);
     }
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
 
-int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp) {
+// rows [row_lo, row_hi) of the draw of n rows; tiles [tile0, n_tiles) are the ones that hold them
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp,
+                         int64_t tile0, int64_t row_lo, int64_t row_hi) {
     if (p->d_gcholpack && (cum_host || cum_dev) && !p->ctx->opt[MG_OPT_FORCE_VALU_SAMPLE]) {
         switch (p->KKg) {
-            case 2: return mg_launch_gmm_sample_mfma_kk<2>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
-            case 4: return mg_launch_gmm_sample_mfma_kk<4>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
-            case 6: return mg_launch_gmm_sample_mfma_kk<6>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
-            case 8: return mg_launch_gmm_sample_mfma_kk<8>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
-            case 10: return mg_launch_gmm_sample_mfma_kk<10>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
-            case 12: return mg_launch_gmm_sample_mfma_kk<12>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
-            case 14: return mg_launch_gmm_sample_mfma_kk<14>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
-            case 16: return mg_launch_gmm_sample_mfma_kk<16>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp);
+            case 2: return mg_launch_gmm_sample_mfma_kk<2>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
+            case 4: return mg_launch_gmm_sample_mfma_kk<4>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
+            case 6: return mg_launch_gmm_sample_mfma_kk<6>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
+            case 8: return mg_launch_gmm_sample_mfma_kk<8>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
+            case 10: return mg_launch_gmm_sample_mfma_kk<10>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
+            case 12: return mg_launch_gmm_sample_mfma_kk<12>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
+            case 14: return mg_launch_gmm_sample_mfma_kk<14>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
+            case 16: return mg_launch_gmm_sample_mfma_kk<16>(p, cum_dev, cum_host, n_tiles, seed, x, xdt, ld, comp, tile0, row_lo, row_hi);
             default: break;
         }
     }
-    return mg_launch_gmm_sample_valu(p, n, cum_dev, seed, x, xdt, ld, comp);
+    return mg_launch_gmm_sample_valu(p, n, cum_dev, seed, x, xdt, ld, comp, row_lo, row_hi);
 }
 
 bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p) {

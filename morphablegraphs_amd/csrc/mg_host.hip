@@ -62,6 +62,7 @@ struct mg_rccl_api {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ mg_nccl_id, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -74,9 +75,10 @@ static int mg_rccl_load() {
     g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (int (*)(void **, int, mg_nccl_id, int))dlsym(h, "ncclCommInitRank");
     g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclBroadcast");
     g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.Broadcast || !g_rccl.CommDestroy) {
         mg_set_error("mg_dist: librccl lacks an expected symbol");
         dlclose(h);
         return MG_ERR_UNSUPPORTED;
@@ -248,6 +250,14 @@ extern "C" int mg_dist_all_gather(mg_context *ctx, const void *local_dev, void *
     int nrc = g_rccl.AllGather(local_dev, gathered_dev, (size_t)count, dtype == MG_F64 ? 8 /* ncclFloat64 */ : 7 /* ncclFloat32 */,
                                ctx->rccl_comm, ctx->stream);
     return nrc == 0 ? MG_OK : mg_rccl_fail(nrc, "ncclAllGather");
+}
+extern "C" int mg_dist_broadcast(mg_context *ctx, void *buf_dev, int64_t bytes, int32_t root) {
+    MG_REQUIRE(ctx && ctx->rccl_comm, "mg_dist_broadcast: mg_dist_init has not been called on this context");
+    MG_REQUIRE(bytes >= 0 && (bytes == 0 || buf_dev) && root >= 0 && root < ctx->dist_ranks, "mg_dist_broadcast: bad arguments");
+    if (bytes == 0) return MG_OK;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    const int rcb = g_rccl.Broadcast(buf_dev, buf_dev, (size_t)bytes, 0 /* ncclInt8 */, root, ctx->rccl_comm, ctx->stream);
+    return rcb == 0 ? MG_OK : mg_rccl_fail(rcb, "ncclBroadcast");
 }
 extern "C" int mg_dist_finalize(mg_context *ctx) {
     MG_REQUIRE(ctx != nullptr, "mg_dist_finalize: ctx is NULL");
@@ -1176,13 +1186,16 @@ extern "C" int mg_time_function_canonical(mg_primitive *p, const void *gamma, in
     return mg_launch_time_function(p, gamma, gdt, B, ld, out);
 }
 
-extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, void *x, int xdt,
-                             int64_t ld, int32_t *comp) {
+// rows [row_begin, row_begin + row_count) of the draw of n rows (mg_gmm_sample: all of them)
+extern "C" int mg_gmm_sample_rows(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, int64_t row_begin, int64_t row_count,
+                                  void *x, int xdt, int64_t ld, int32_t *comp) {
     MG_REQUIRE(p != nullptr && n >= 0, "mg_gmm_sample: bad arguments");
     MG_REQUIRE(p->K > 0, "mg_gmm_sample: primitive has no mixture");
     MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_gmm_sample: bad dtype %d", xdt);
     MG_REQUIRE(counts != nullptr, "mg_gmm_sample: counts is NULL");
     MG_REQUIRE(ld >= p->Lg, "mg_gmm_sample: leading dimension %lld < n_gmm_dims %d", (long long)ld, p->Lg);
+    MG_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n, "mg_gmm_sample_rows: rows [%lld, %lld) outside the draw of %lld",
+               (long long)row_begin, (long long)(row_begin + row_count), (long long)n);
     { int rc0 = mg_use_device(p->ctx); if (rc0 != MG_OK) return rc0; }
     // [0 .. K]: row prefix sums; [K+1 .. 2K+1]: prefix sums of 16-row tiles (a tile never straddles two components)
     std::vector<int64_t> cum(2 * (size_t)p->K + 2, 0);
@@ -1192,12 +1205,19 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
         cum[p->K + 1 + k + 1] = cum[p->K + 1 + k] + (counts[k] + 15) / 16;
     }
     MG_REQUIRE(cum[p->K] == n, "mg_gmm_sample: counts sum to %lld, expected %lld", (long long)cum[p->K], (long long)n);
-    if (n == 0) return MG_OK;
+    if (row_count == 0) return MG_OK;
     MG_REQUIRE(x != nullptr, "mg_gmm_sample: output pointer is NULL");
+    // the tiles that hold the first and the last wanted row
+    auto tile_of = [&](int64_t row) {
+        int c = 0;
+        while (c + 1 < p->K && row >= cum[c + 1]) c++;
+        return cum[p->K + 1 + c] + (row - cum[c]) / 16;
+    };
+    const int64_t tile0 = tile_of(row_begin), tile_end = tile_of(row_begin + row_count - 1) + 1;
     int rc;
     if (mg_gmm_sample_takes_host_prefix(p)) {   // prefix sums travel as a kernel argument: nothing to upload or wait for
         mg_prof_begin(p->ctx, 4);
-        rc = mg_launch_gmm_sample(p, n, nullptr, cum.data(), cum[2 * (size_t)p->K + 1], seed, x, xdt, ld, comp);
+        rc = mg_launch_gmm_sample(p, n, nullptr, cum.data(), tile_end, seed, x, xdt, ld, comp, tile0, row_begin, row_begin + row_count);
         mg_prof_end(p->ctx, 4);
         return rc;
     }
@@ -1207,9 +1227,13 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
     MG_HIP_CHECK(hipMemcpyAsync(scr, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, p->ctx->stream));
     MG_HIP_CHECK(hipStreamSynchronize(p->ctx->stream));  // cum is a stack-lifetime host buffer
     mg_prof_begin(p->ctx, 4);
-    rc = mg_launch_gmm_sample(p, n, (const int64_t *)scr, nullptr, cum[2 * (size_t)p->K + 1], seed, x, xdt, ld, comp);
+    rc = mg_launch_gmm_sample(p, n, (const int64_t *)scr, nullptr, tile_end, seed, x, xdt, ld, comp, tile0, row_begin, row_begin + row_count);
     mg_prof_end(p->ctx, 4);
     return rc;
+}
+extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, void *x, int xdt,
+                             int64_t ld, int32_t *comp) {
+    return mg_gmm_sample_rows(p, n, counts, seed, 0, n < 0 ? 0 : n, x, xdt, ld, comp);
 }
 
 // ---- constraint sets ---------------------------------------------------------------------
@@ -1851,18 +1875,23 @@ extern "C" int mg_best_candidate_host(mg_primitive *p, const mg_constraint_set *
 // One option of a planner step, enqueued without synchronisation (reference graph_walk_planner.py:184-226 evaluates
 // the options one after the other): draw n candidates on the device, score them, first-minimum argmin, copy the
 // winner next to the result.  result_dev: {int64 index, float64 error, float64 latent[n_components]}.
-extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int64_t n, const int64_t *counts, uint64_t seed,
-                              void *x_dev, int xdt, int64_t ld, double *errors_dev, void *result_dev) {
+// rows [row_begin, row_begin + row_count) of the option's draw of n: one rank's share of a sharded step
+extern "C" int mg_option_step_rows(mg_primitive *p, const mg_constraint_set *cs, int64_t n, const int64_t *counts, uint64_t seed,
+                                   int64_t row_begin, int64_t row_count, void *x_dev, int xdt, int64_t ld, double *errors_dev, void *result_dev) {
     MG_REQUIRE(p && cs && cs->prim == p, "mg_option_step: constraint set is NULL or belongs to another primitive");
-    MG_REQUIRE(n > 0 && x_dev && errors_dev && result_dev, "mg_option_step: bad arguments");
-    int rc = mg_gmm_sample(p, n, counts, seed, x_dev, xdt, ld, nullptr);
-    if (rc == MG_OK) rc = mg_score_constraints(p, cs, x_dev, xdt, n, ld, errors_dev, MG_F64);
+    MG_REQUIRE(n > 0 && row_count > 0 && x_dev && errors_dev && result_dev, "mg_option_step: bad arguments");
+    int rc = mg_gmm_sample_rows(p, n, counts, seed, row_begin, row_count, x_dev, xdt, ld, nullptr);
+    if (rc == MG_OK) rc = mg_score_constraints(p, cs, x_dev, xdt, row_count, ld, errors_dev, MG_F64);
     if (rc == MG_OK) {   // first minimum and the copy of the winner (at its full width) in one launch
         mg_prof_begin(p->ctx, 3);
-        rc = mg_launch_argmin_gather(p->ctx, errors_dev, MG_F64, n, result_dev, x_dev, xdt, ld, p->Lg);
+        rc = mg_launch_argmin_gather(p->ctx, errors_dev, MG_F64, row_count, result_dev, x_dev, xdt, ld, p->Lg, row_begin);
         mg_prof_end(p->ctx, 3);
     }
     return rc;
+}
+extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int64_t n, const int64_t *counts, uint64_t seed,
+                              void *x_dev, int xdt, int64_t ld, double *errors_dev, void *result_dev) {
+    return mg_option_step_rows(p, cs, n, counts, seed, 0, n, x_dev, xdt, ld, errors_dev, result_dev);
 }
 
 // A small device -> host read-back at the end of a step: through a pinned staging block of the context's (a copy into
@@ -1894,7 +1923,17 @@ static int mg_ctx_side_streams(mg_context *ctx) {
 extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
                                const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
                                double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host) {
+    return mg_options_step_rows(n_options, prims, csets, n, counts, seeds, 0, n, x_dev, xdt, ld, errors_dev, results_dev, result_stride, results_host);
+}
+// One rank's share of a sharded step: global rows [row_begin, row_begin + row_count) of every option's draw of n candidates;
+// x_dev[k] (row_count, ld[k]) and errors_dev[k] (row_count) hold the block, the result records carry GLOBAL row indices.
+extern "C" int mg_options_step_rows(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
+                                    const int64_t *const *counts, const uint64_t *seeds, int64_t row_begin, int64_t row_count,
+                                    void *const *x_dev, int xdt, const int64_t *ld,
+                                    double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host) {
     MG_REQUIRE(n_options > 0 && prims && csets && counts && seeds && x_dev && ld && errors_dev && results_dev, "mg_options_step: bad arguments");
+    MG_REQUIRE(row_begin >= 0 && row_count > 0 && row_begin + row_count <= n, "mg_options_step_rows: rows [%lld, %lld) outside the draw of %lld",
+               (long long)row_begin, (long long)(row_begin + row_count), (long long)n);
     mg_context *ctx = prims[0] ? prims[0]->ctx : nullptr;
     for (int k = 0; k < n_options; k++) {
         MG_REQUIRE(prims[k] && prims[k]->ctx == ctx, "mg_options_step: option %d is NULL or lives in another context", k);
@@ -1915,7 +1954,7 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
         if (fused) {
             for (int k0 = 0; k0 < n_options; k0 += 24) {
                 int rcf = mg_launch_options_fused(std::min(24, n_options - k0), prims + k0, csets + k0, n, counts + k0, seeds + k0, x_dev + k0, xdt, ld + k0,
-                                                  errors_dev + k0, (char *)results_dev + (size_t)k0 * result_stride, result_stride);
+                                                  errors_dev + k0, (char *)results_dev + (size_t)k0 * result_stride, result_stride, row_begin, row_count);
                 if (rcf != MG_OK) return rcf;
             }
             if (results_host) return mg_read_back_pinned(ctx, results_host, results_dev, (size_t)(n_options * result_stride));
@@ -1942,7 +1981,8 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
     int rc = MG_OK;
     for (int k = 0; k < n_options && rc == MG_OK; k++) {
         if (S > 1) ctx->stream = ctx->side[k % S];
-        rc = mg_option_step(prims[k], csets[k], n, counts[k], seeds[k], x_dev[k], xdt, ld[k], errors_dev[k], (char *)results_dev + k * result_stride);
+        rc = mg_option_step_rows(prims[k], csets[k], n, counts[k], seeds[k], row_begin, row_count, x_dev[k], xdt, ld[k], errors_dev[k],
+                                 (char *)results_dev + k * result_stride);
     }
     ctx->stream = main_stream;
     if (S > 1) {   // join even after an error: nothing may still be running behind the caller's back

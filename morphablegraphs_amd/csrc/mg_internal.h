@@ -213,12 +213,13 @@ int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt);
 #define MG_SAMPLE_ARG_K 16   // mixtures up to this size pass their prefix sums to the sampler as a kernel argument
-int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp);
+int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp,
+                         int64_t tile0, int64_t row_lo, int64_t row_hi);
 bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p);
 int mg_launch_set_params(mg_context *ctx, const double *values, int n_par, int n_align, double *d_par, double *d_align);
 int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res);
 int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld, int L, void *result_dev);
-int mg_launch_argmin_gather(mg_context *ctx, const void *v, int dt, int64_t n, void *result_dev, const void *x, int xdt, int64_t ld, int L);
+int mg_launch_argmin_gather(mg_context *ctx, const void *v, int dt, int64_t n, void *result_dev, const void *x, int xdt, int64_t ld, int L, int64_t index_offset = 0);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);
 int mg_launch_time_function(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double *out);
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
@@ -228,7 +229,7 @@ int mg_options_fused_attributes();   // mg_options.hip
 bool mg_options_can_fuse(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n);
 int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
                             const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
-                            double *const *errors_dev, void *results_dev, int64_t result_stride);
+                            double *const *errors_dev, void *results_dev, int64_t result_stride, int64_t row_begin, int64_t row_count);
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us);   // mg_placement.hip
 #define MG_PLACED_MIN_BYTES ((int64_t)64 << 20)   // below this an output sits in the 256 MiB Infinity Cache anyway
 int mg_output_alloc(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out, double *info4);   // a piece of a placed region

@@ -46,6 +46,10 @@ struct mg_fused_dyn {             // one step: what changes every time (kernel a
     uint64_t seed[MG_FUSED_MAX_OPTIONS];
     int32_t counts[MG_FUSED_MAX_OPTIONS][MG_SAMPLE_ARG_K];
     int32_t wg0[MG_FUSED_MAX_OPTIONS + 1];
+    // a rank's share of a sharded step (mg_options_step_rows): global rows [row_lo, row_hi) of every option's draw, held by
+    // tiles [tile0[k], tile_end[k]); x and errors are indexed by (row - row_lo), the winner's index is global
+    int32_t tile0[MG_FUSED_MAX_OPTIONS], tile_end[MG_FUSED_MAX_OPTIONS];
+    int64_t row_lo, row_hi;
 };
 
 struct mg_fused_partial { double v; int64_t i; };
@@ -73,7 +77,8 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
     double *resid = vals + 16 * vs;                               // [n][16]
 
     // this wave's tile: rows [row0, row0 + nrow) of component c (rows grouped by component, tiles never straddle two)
-    const int64_t t = (int64_t)(wg - dyn.wg0[k]) * 4 + wave;
+    const int64_t t = dyn.tile0[k] + (int64_t)(wg - dyn.wg0[k]) * 4 + wave;
+    const int64_t row_lo = dyn.row_lo, row_hi = dyn.row_hi;
     int c = 0;
     int64_t row_c = 0, tile_c = 0, rows_next, tiles_next;
     for (;;) {
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
         if (c + 1 < K && t >= tiles_next) { c++; row_c = rows_next; tile_c = tiles_next; }
         else break;
     }
-    const bool active = t < tiles_next;
+    const bool active = t < tiles_next && t < dyn.tile_end[k];
     double best = INFINITY;
     int64_t bi = INT64_MAX;
     if (active) {
@@ -119,9 +124,10 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
                     if (i < Lg) {
                         const double xv = X_F64 ? acc[r] : (double)(float)acc[r];
                         zt[row * ZS + i] = xv;
-                        if (row < nrow) {
-                            if (X_F64) ((double *)o.x)[(row0 + row) * ld + i] = acc[r];
-                            else ((float *)o.x)[(row0 + row) * ld + i] = (float)acc[r];
+                        const int64_t gr = row0 + row;
+                        if (row < nrow && gr >= row_lo && gr < row_hi) {
+                            if (X_F64) ((double *)o.x)[(gr - row_lo) * ld + i] = acc[r];
+                            else ((float *)o.x)[(gr - row_lo) * ld + i] = (float)acc[r];
                         }
                     }
                 }
@@ -149,10 +155,10 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
             resid[cc * 16 + cand] = mg_constraint_residual(o.sa, cc, [&](int row) { return v[row]; });
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < nrow) {
+        if (lane < nrow && row0 + lane >= row_lo && row0 + lane < row_hi) {
             double err = 0.0;
             for (int cc = 0; cc < n; cc++) err += resid[cc * 16 + lane];
-            ((double *)o.sa.out)[row0 + lane] = err;
+            ((double *)o.sa.out)[row0 + lane - row_lo] = err;
             if (err < INFINITY) { best = err; bi = row0 + lane; }   // NaN and +inf never win
         }
     }
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; w++) mg_min_combine(best, bi, sv[w], si[w]);
-        if (bi == INT64_MAX || bi < 0 || bi >= o.sa.B) { bi = 0; best = INFINITY; }   // (an index outside the batch cannot happen; never gather out of bounds)
+        if (bi == INT64_MAX || bi < row_lo || bi >= row_hi) { bi = row_lo; best = INFINITY; }   // (an index outside the block cannot happen; never gather out of bounds)
         ((int64_t *)o.result)[0] = bi;
         ((double *)o.result)[1] = best;
         si[0] = bi;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
     const int64_t idx = si[0];
     double *row = (double *)((char *)o.result + 16);
     for (int i = tid; i < Lg; i += 256)
-        row[i] = X_F64 ? ((const double *)o.x)[idx * ld + i] : (double)((const float *)o.x)[idx * ld + i];
+        row[i] = X_F64 ? ((const double *)o.x)[(idx - row_lo) * ld + i] : (double)((const float *)o.x)[(idx - row_lo) * ld + i];
 }
 
 int mg_options_fused_attributes() {
@@ -232,7 +238,7 @@ bool mg_options_can_fuse(int32_t n_options, mg_primitive *const *prims, const mg
 
 int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
                             const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
-                            double *const *errors_dev, void *results_dev, int64_t result_stride) {
+                            double *const *errors_dev, void *results_dev, int64_t result_stride, int64_t row_begin, int64_t row_count) {
     mg_context *ctx = prims[0]->ctx;
     std::vector<mg_fused_static> tab((size_t)n_options);
     mg_fused_dyn dyn;
@@ -251,17 +257,23 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
         o.x = x_dev[k]; o.result = (char *)results_dev + (size_t)k * result_stride;
         o.K = p->K; o.Lg = p->Lg; o.KKg = p->KKg; o.KK = p->KK; o.JT = (p->Lg + 15) / 16; o.RT = cs->RT;
         wave_doubles = std::max(wave_doubles, 16 * (4 * p->KKg + 1) + 16 * (cs->RT * 16 + 1) + 16 * std::max(cs->n, 1));
-        int64_t tiles = 0, rows = 0;
+        int64_t tiles = 0, rows = 0, t_first = -1, t_last = -1;
         for (int c = 0; c < p->K; c++) {
             if (counts[k][c] < 0 || counts[k][c] > n) { mg_set_error("mg_options_step: counts[%d][%d] out of range", k, c); return MG_ERR_INVALID_ARGUMENT; }
             dyn.counts[k][c] = (int32_t)counts[k][c];
+            // the tiles that hold the first and the last row of the block
+            if (t_first < 0 && row_begin < rows + counts[k][c]) t_first = tiles + (row_begin - rows) / 16;
+            if (t_last < 0 && row_begin + row_count - 1 < rows + counts[k][c]) t_last = tiles + (row_begin + row_count - 1 - rows) / 16;
             rows += counts[k][c];
             tiles += (counts[k][c] + 15) / 16;
         }
         if (rows != n) { mg_set_error("mg_options_step: counts of option %d sum to %lld, expected %lld", k, (long long)rows, (long long)n); return MG_ERR_INVALID_ARGUMENT; }
         dyn.seed[k] = seeds[k];
-        dyn.wg0[k + 1] = dyn.wg0[k] + (int32_t)((tiles + 3) / 4);
+        dyn.tile0[k] = (int32_t)t_first;
+        dyn.tile_end[k] = (int32_t)(t_last + 1);
+        dyn.wg0[k + 1] = dyn.wg0[k] + (int32_t)((t_last + 1 - t_first + 3) / 4);
     }
+    dyn.row_lo = row_begin; dyn.row_hi = row_begin + row_count;
     const int total_wg = dyn.wg0[n_options];
     // the static table: uploaded when it differs from the one on the device (a planner reuses its buffers and sets, so: rarely)
     const size_t tab_bytes = tab.size() * sizeof(mg_fused_static);

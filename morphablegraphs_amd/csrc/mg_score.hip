@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void mg_gather_winner_kernel(const void *x, int
 
 // the two in one launch (a planner step is a chain of small launches: every one saved counts)
 template <bool F64>
-__global__ __launch_bounds__(1024) void mg_argmin_gather_kernel(const void *vals, int64_t n, void *out, const void *x, int x_f64, int64_t ld, int L) {
+__global__ __launch_bounds__(1024) void mg_argmin_gather_kernel(const void *vals, int64_t n, void *out, const void *x, int x_f64, int64_t ld, int L, int64_t index_offset) {
     __shared__ double sv[16];
     __shared__ int64_t si[16];
     __shared__ int64_t winner;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(1024) void mg_argmin_gather_kernel(const void *vals
     if (tid == 0) {
         for (int w = 1; w < 16; w++) mg_min_combine(best, bi, sv[w], si[w]);
         if (bi == INT64_MAX) { bi = 0; best = INFINITY; }
-        ((int64_t *)out)[0] = bi;
+        ((int64_t *)out)[0] = bi + index_offset;   // a rank's block of a sharded step reports the global row
         ((double *)out)[1] = best;
         winner = bi;
     }
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(1024) void mg_argmin_gather_kernel(const void *vals
     for (int i = tid; i < L; i += 1024)
         row[i] = x_f64 ? ((const double *)x)[idx * ld + i] : (double)((const float *)x)[idx * ld + i];
 }
-int mg_launch_argmin_gather(mg_context *ctx, const void *v, int dt, int64_t n, void *result_dev, const void *x, int xdt, int64_t ld, int L) {
-    if (dt == MG_F64) hipLaunchKernelGGL((mg_argmin_gather_kernel<true>), dim3(1), dim3(1024), 0, ctx->stream, v, n, result_dev, x, xdt == MG_F64 ? 1 : 0, ld, L);
-    else hipLaunchKernelGGL((mg_argmin_gather_kernel<false>), dim3(1), dim3(1024), 0, ctx->stream, v, n, result_dev, x, xdt == MG_F64 ? 1 : 0, ld, L);
+int mg_launch_argmin_gather(mg_context *ctx, const void *v, int dt, int64_t n, void *result_dev, const void *x, int xdt, int64_t ld, int L, int64_t index_offset) {
+    if (dt == MG_F64) hipLaunchKernelGGL((mg_argmin_gather_kernel<true>), dim3(1), dim3(1024), 0, ctx->stream, v, n, result_dev, x, xdt == MG_F64 ? 1 : 0, ld, L, index_offset);
+    else hipLaunchKernelGGL((mg_argmin_gather_kernel<false>), dim3(1), dim3(1024), 0, ctx->stream, v, n, result_dev, x, xdt == MG_F64 ? 1 : 0, ld, L, index_offset);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

@@ -127,6 +127,9 @@ class HipMotionPrimitiveGenerator(object):
         self.n_cluster_search_candidates = int(algorithm_config.get("n_cluster_search_candidates", 2))
         self.use_local_coordinates = algorithm_config.get("use_local_coordinates", True)
         # gpu_batch only: draw the candidates with the device sampler and keep them on the GPU (not sklearn's stream)
+        # a distributed.MgCommunicator (or FileCommunicator) when the candidate loop is sharded over the GPUs of a node: this
+        # process is rank 0, the other ranks run distributed.worker_loop over the same primitives
+        self.communicator = algorithm_config.get("communicator", getattr(self, "communicator", None))
         self.gpu_sampling = bool(algorithm_config.get("gpu_sampling", False))
         self.gpu_sampling_seed = int(algorithm_config.get("gpu_sampling_seed", 0))
         if self._settings.get("method", "leastsq") != "leastsq":
@@ -200,7 +203,7 @@ class HipMotionPrimitiveGenerator(object):
         elif self.gpu_sampling and self.constrained_sampling_mode == SAMPLING_MODE_GPU_BATCH:
             self.gpu_sampling_seed += 1
             best_sample, _ = sample_and_evaluate_on_device(graph_node, mp_constraints, self.n_random_samples,
-                                                           self.gpu_sampling_seed, prev_frames=prev_frames)
+                                                           self.gpu_sampling_seed, prev_frames=prev_frames, communicator=self.communicator)
             return best_sample
         else:
             samples = graph_node.sample_low_dimensional_vectors(self.n_random_samples)
@@ -222,10 +225,10 @@ class HipMotionPrimitiveGenerator(object):
         once per visited mean or sample.  At GPU batch sizes the whole tree is cheaper to score than to descend:
         every stored sample in one launch, first minimum -- the result of find_best_example_exhaustive."""
         stored = np.asarray(graph_node.cluster_tree.data)[:, :graph_node.get_n_spatial_components()]
-        best, distance = evaluate_samples_using_constraints(stored, graph_node, constraints, prev_frames)
+        best, distance = evaluate_samples_using_constraints(stored, graph_node, constraints, prev_frames, communicator=self.communicator)
         constraints.min_error = distance
         return np.array(best)
 
     # ---- motion_primitive_generator.py:230-261 --------------------------------------------------------
     def evaluate_samples_using_constraints(self, samples, mp_node, constraints, prev_frames):
-        return evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frames)
+        return evaluate_samples_using_constraints(samples, mp_node, constraints, prev_frames, communicator=self.communicator)

@@ -41,11 +41,13 @@ class HipMotionStateGraphNode(HipMotionPrimitiveModelWrapper):
         self.average_step_length = 0
         self.action_name = None
         self.name = None
+        self.node_key = None
         self.cluster_tree = None
 
     def init_from_dict(self, action_name, desc):
         self.name = desc["name"]
         self.action_name = action_name
+        self.node_key = (action_name, self.name)       # motion_state_graph_node.py: the key the graph holds the node under
         self._initialize_from_json(None, desc["mm"])
         if "stats" in desc:
             self.parameter_bb = desc["stats"]["pose_bb"]
@@ -254,7 +256,7 @@ class HipPrimitiveSet(object):
             self.nodes[p.name] = p
 
     def evaluate_options_on_device(self, options, constraints_per_option, n_samples, seed=0, dtype=np.float32,
-                                   prev_frames=None, skeleton=None):
+                                   prev_frames=None, skeleton=None, communicator=None):
         """GraphWalkPlanner's option evaluation (reference graph_walk_planner.py:184-226) without host round trips:
         for every option the component counts come from NumPy's stream, the candidates from the device sampler,
         scoring, first-minimum argmin and the copy of the winner stay on the device (mg_options_step: one C call enqueues
@@ -263,10 +265,33 @@ class HipPrimitiveSet(object):
         With `prev_frames` every candidate is aligned to the last previous frame before scoring, which is how the
         planner scores (its constraints stay global, graph_walk_planner.py:179; `skeleton`: a _capi.Skeleton when
         the aligning node is not the root or joints other than the root are constrained).
+        communicator (distributed.MgCommunicator / FileCommunicator; rank 0 calls, the other ranks sit in
+        distributed.worker_loop with their own HipPrimitiveSet under "__primitive_set__"): rank 0 draws the counts and broadcasts
+        them with the constraint values and the seed, every rank runs the step on its block of the rows of every option's draw
+        (mg_options_step_rows), one all-gather of the result records, per option the first minimum over the ranks: the
+        single-GPU result.
         Returns (best_option, {name: (best_sample, min_error)})."""
         from .candidate_scoring import cached_constraint_set, alignment_from_prev_frames
         import ctypes as C
         n = int(n_samples)
+        if communicator is not None and communicator.world > 1:
+            from . import distributed
+            cmd = {"op": "options_step", "options": list(options), "n_samples": n, "seed": int(seed), "dtype": np.dtype(dtype).name,
+                   "skeleton": skeleton is not None, "counts": {}, "constraints": {}, "alignments": {}, "widths": {}}
+            for name in options:
+                node = self.nodes[name]
+                cons = constraints_per_option[name]
+                clist = cons.constraints if hasattr(cons, "constraints") else cons
+                sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
+                w = np.asarray(node.gaussian_mixture_model.weights_, dtype=np.float64)
+                cmd["counts"][name] = np.random.multinomial(n, w / w.sum()).astype(np.int64)
+                cmd["constraints"][name] = constraints_to_device_form(clist)
+                cmd["alignments"][name] = alignment_from_prev_frames(prev_frames, cons, sk)
+                cmd["widths"][name] = node._prim.n_gmm_dims
+            out = distributed.run_command(communicator, {"__primitive_set__": self, "__skeleton__": skeleton}, cmd)
+            results = {name: (out[name][0].astype(dtype).astype(np.float64), out[name][1]) for name in options}
+            errors = [results[nm][1] for nm in options]
+            return options[int(np.argmin(errors))], results
         code = _capi.MG_F64 if np.dtype(dtype) == np.float64 else _capi.MG_F32
         plan = self._step_plan(tuple(options), n, np.dtype(dtype))
         steps = plan["steps"]
@@ -300,6 +325,36 @@ class HipPrimitiveSet(object):
                 results[name] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
         errors = [results[n][1] for n in options]
         return options[int(np.argmin(errors))], results
+
+    def options_step_rows(self, cmd, row_begin, row_end, skeleton=None):
+        """One rank's share of a sharded planner step (distributed._cmd_options_step): the global rows [row_begin, row_end) of
+        every option's draw, through mg_options_step_rows.  Returns {option: (global index, error, winning latent)}."""
+        from .candidate_scoring import cached_constraint_set
+        import ctypes as C
+        options, n = tuple(cmd["options"]), int(cmd["n_samples"])
+        dtype = np.dtype(cmd.get("dtype", "float32"))
+        code = _capi.MG_F64 if dtype == np.float64 else _capi.MG_F32
+        m_rows = int(row_end) - int(row_begin)
+        plan = self._step_plan(options, m_rows, dtype)       # buffers sized for the block
+        steps = plan["steps"]
+        if not plan["one_context"]:
+            raise NotImplementedError("sharded planner steps need all primitives in one context")
+        m, stride, host = len(steps), plan["stride"], plan["host"]
+        for k, st in enumerate(steps):
+            name = st[0]
+            cs = cached_constraint_set(st[2], cmd["constraints"][name], skeleton, cmd["alignments"][name])
+            plan["csets"][k] = cs.handle.value
+            plan["seeds"][k] = int(cmd["seed"]) + k
+            c = np.asarray(cmd["counts"][name], dtype=np.int64)
+            plan["counts"][k, :len(c)] = c
+        _capi._check(steps[0][2].lib.mg_options_step_rows(m, plan["prims"], plan["csets"], n, plan["cnts"], plan["seeds"], int(row_begin), m_rows,
+                                                          plan["xs"], code, plan["lds"], plan["errs"], plan["shared"].ptr, stride,
+                                                          host.ctypes.data_as(C.c_void_p)))
+        out = {}
+        for k, st in enumerate(steps):
+            raw = host[k * stride:k * stride + 16 + 8 * st[7]]
+            out[st[0]] = (int(raw[0:8].view(np.int64)[0]), float(raw[8:16].view(np.float64)[0]), raw[16:].view(np.float64).copy())
+        return out
 
     def _step_plan(self, options, n, dtype):
         """Everything about a planner step that does not change from step to step, built once per (options, n, dtype): the

@@ -55,3 +55,17 @@ def test_single_rank_dry_run_and_world_size_mismatch():
     e = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode != 0 and b"does not match WORLD_SIZE" in p.stderr
+
+
+def test_a_dead_rank_ends_the_launch_instead_of_hanging_it():
+    """rank 1 dies before the rendezvous; the launcher ends rank 0 (which would wait 300 s for it), removes the
+    rendezvous files and returns non-zero within seconds."""
+    import time
+    e = dict(os.environ, MG_BENCH_DRY_RUN_DIES="1")
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run", "--batch", "32"], cwd=ROOT, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and time.time() - t0 < 60
+    assert b"rank 1 exited with 3" in p.stderr

@@ -73,10 +73,15 @@ __global__ __launch_bounds__(512) void k_map(float *out, int ntiles, int mode, i
     const int w = blockIdx.x, G = gridDim.x;
     const int nblk = G / NCH, q = (ntiles + nblk - 1) / nblk;   // chunk-stationary maps: nblk workgroups per chunk, q tiles each
     const int U = ntiles * NCH, per = (U + G - 1) / G;
-    const int steps = mode == 0 ? per : q;
+    const int steps = (mode == 0 || mode == 20 || mode == 22) ? per : q;
     for (int s = 0; s < steps; s++) {
         int tile, chunk;
         if (mode == 0) { const int u = w * per + s; if (u >= U) break; tile = u / NCH; chunk = (u % NCH + w) % NCH; }
+        else if (mode == 20) { const int u = w * per + s; if (u >= U) break; tile = u / NCH; chunk = (u % NCH + prm * w) % NCH; }
+        else if (mode == 22) {   // all workgroups on the same chunk at the same time: chunk by chunk over the workgroup's own tiles
+            const int tpw = per / NCH; if (tpw * NCH != per) break;
+            const int c = s / tpw, t = s % tpw; tile = w * tpw + t; chunk = (c + prm * w) % NCH; if (tile >= ntiles) continue;
+        }
         else {
             chunk = (mode == 5) ? w / nblk : w % NCH;
             const int j = (mode == 5) ? w % nblk : w / NCH;
@@ -332,6 +337,11 @@ int main(int argc, char **argv) {
     {
         struct mp { int mode, prm; const char *what; };
         const mp maps[] = {{0, 0, "tile-major: u = w per + s, chunk rotated by w (the probe's pattern)"},
+                           {20, 0, "tile-major, chunk = u % 4: every workgroup on the same chunk at a time"},
+                           {20, 2, "tile-major, chunk rotated by 2 w: two chunks active at a time"},
+                           {22, 0, "chunk by chunk over the workgroup's own tiles, all workgroups on the same chunk"},
+                           {22, 2, "chunk by chunk over the workgroup's own tiles, two chunks active at a time"},
+                           {22, 1, "chunk by chunk over the workgroup's own tiles, four chunks active at a time"},
                            {1, 0, "chunk-stationary: chunk w % 4, block of q consecutive tiles per workgroup"},
                            {5, 0, "chunk-stationary, chunk = w / 64"},
                            {2, 0, "chunk-stationary, block walked from tile (s + j) % q"},
@@ -344,7 +354,7 @@ int main(int argc, char **argv) {
                            {6, 37, "chunk-stationary, blocks shifted by chunk x 37 tiles"},
                            {7, 0, "chunk-stationary, tile = bit-reversed lin"},
                            {8, 3, "chunk-stationary, block walked in steps of 3"}};
-        for (int gr : {256, 252, 240}) {
+        for (int gr : {256, 128}) {
             for (const mp &m : maps) {
                 const float qf = timeit([&] { hipLaunchKernelGGL(k_map, dim3(gr), dim3(512), 0, 0, (float *)fast, ntiles, m.mode, m.prm); });
                 const float qs = timeit([&] { hipLaunchKernelGGL(k_map, dim3(gr), dim3(512), 0, 0, (float *)slow, ntiles, m.mode, m.prm); });
