@@ -213,7 +213,10 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_OPTIONS_STEP       mg_options_step: 0 = one launch for the whole step where every option allows it, 1 = always one
  *                             chain of launches per option (identical results; tests compare the two)
  *   MG_OPT_PLAIN_MALLOC       1 = mg_device_malloc is one hipMalloc whatever the size (0: buffers of 64 MiB and more are pieces
- *                             of the context's placed output regions, see mg_device_malloc) */
+ *                             of the context's placed output regions, see mg_device_malloc)
+ *   MG_OPT_GMM_KERNEL         mg_gmm_log_prob on the matrix pipe: 0 = by batch size, 1 = one 16-candidate tile per workgroup, fragments
+ *                             from L2, 2 = persistent workgroups with the mixture's fragments in LDS (from 20 480 candidates on by
+ *                             default; MG_ERR_UNSUPPORTED never: a mixture that does not fit LDS falls back to 1) -- identical results */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
@@ -223,7 +226,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_PLACED_FAST_PCT 6
 #define MG_OPT_OPTIONS_STEP 7
 #define MG_OPT_PLAIN_MALLOC 8
-#define MG_OPT_COUNT 9
+#define MG_OPT_GMM_KERNEL 9
+#define MG_OPT_COUNT 10
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`

@@ -23,7 +23,8 @@ MG_OPT_FRAMES_KERNEL = 5   # 0 = by batch size, 1 = tile-major, 2 = chunk-statio
 MG_OPT_PLACED_FAST_PCT = 6   # mg_device_malloc_placed's acceptance ratio in percent (tests)
 MG_OPT_OPTIONS_STEP = 7      # mg_options_step: 0 = one launch per step where possible, 1 = a chain of launches per option
 MG_OPT_PLAIN_MALLOC = 8      # 1 = mg_device_malloc is one hipMalloc whatever the size (no placed output regions)
-MG_OPT_COUNT = 9
+MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile per workgroup, 2 = fragments resident in LDS
+MG_OPT_COUNT = 10
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,

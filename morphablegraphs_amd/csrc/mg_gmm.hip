@@ -6,6 +6,8 @@
 //  morphablegraphs/motion_model/extended_mgrd_mixture_model.py:60-108).
 #include <cstring>
 
+#include <algorithm>
+
 #include "mg_internal.h"
 #include "mg_gmm_device.h"
 
@@ -246,7 +248,149 @@ static int mg_launch_gmm_mfma_kk(mg_primitive *p, const void *x, int xdt, int64_
     return MG_OK;
 }
 
+// -----------------------------------------------------------------------------------------
+// Large batches (the optimizer's 131 072 candidates per iteration, BASELINE configs[4]): the kernel above re-reads the
+// mixture's fragments from L2 for every 16 candidates (102 KB per tile: 838 MB per launch at B = 131 072) and its matrix
+// pipe waits for them (0.48 of the float64 matrix peak).  Here a persistent 1024-thread workgroup per CU stages the
+// fragments the chains use (the k-steps at or above each column tile's diagonal: 22 of 30 for L = 40) in LDS ONCE -- 90 KB
+// for K = 8 -- and its sixteen waves walk 16-candidate tiles, every wave a tile of its own through all K components:
+// B operand = one conflict-free ds_read_b64 per MFMA, four waves per SIMD cover each other's LDS latency.  The chains,
+// the squares, the butterfly, the log-sum-exp are the functions the kernel above uses, in the same order: same bits.
+// -----------------------------------------------------------------------------------------
+template <int KK>
+__host__ __device__ constexpr int mg_gmm_nf() {
+    int nf = 0;
+    for (int jt = 0; jt < (KK + 3) / 4; jt++) nf += (4 * (jt + 1) < KK) ? 4 * (jt + 1) : KK;
+    return nf;
+}
+template <int KK, bool X_F64, bool OUT_F64>
+__global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__restrict__ Ppack,  // [K][JT][KK][64]
+                                                               const double *__restrict__ mP,     // [K][JT*16]
+                                                               const double *__restrict__ cst,    // [K]
+                                                               const void *__restrict__ x, void *__restrict__ out,
+                                                               const mg_gmm_mfma_args a, const int64_t n_tiles) {
+    constexpr int JTM = (KK + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = a.K;
+    constexpr int JT = JTM;                         // KK is the smallest even number of k-steps for L: ceil(L / 16) == JTM (checked at the launch)
+    constexpr int nf = mg_gmm_nf<KK>();             // fragments per component that the chains use
+    mg_lds_f64 *lds_f = (mg_lds_f64 *)smem;         // [K][nf][64]: component k, column tile jt, k-step kk at ((k nf + off(jt) + kk) 64 + lane)
+    mg_lds_f64 *lds_c = lds_f + (size_t)K * nf * 64;   // [K][JT*16]: -mu_k P_k
+    mg_lds_f64 *lds_w = lds_c + (size_t)K * JT * 16;   // per wave: [K][16] terms, [K][16] exponentials
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, g = lane >> 4;
+    // staging: a wave copies whole 512-byte fragments (wave-uniform index arithmetic, several loads in flight)
+#pragma unroll 4
+    for (int F = wave; F < K * nf; F += 16) {
+        const int k = F / nf, f = F - k * nf;
+        int jt = 0, off = 0;
+#pragma unroll
+        for (int j = 0; j < JTM - 1; j++) {
+            const int n = (4 * (j + 1) < KK) ? 4 * (j + 1) : KK;
+            if (f >= off + n) { off += n; jt = j + 1; }
+        }
+        lds_f[F * 64 + lane] = Ppack[(((size_t)k * JT + jt) * KK + (f - off)) * 64 + lane];
+    }
+    for (int e = tid; e < K * JT * 16; e += 1024) lds_c[e] = -mP[e];
+    __syncthreads();
+    mg_lds_f64 *terms = lds_w + (size_t)wave * 2 * K * 16, *exps = terms + K * 16;
+    // tile t of the launch: workgroup t % grid, wave (t / grid) % 16 -- consecutive tiles go to different CUs.  (Requesting the
+    // next tile's latents a tile ahead changes nothing: the other three waves of the SIMD cover the load.)
+    for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += (int64_t)gridDim.x * 16) {
+        const int64_t b0 = tile * 16;
+        const int ncand = (int)((a.B - b0) < 16 ? (a.B - b0) : 16);
+        typename mg_gmm_xt<X_F64>::type xf[KK];
+        mg_gmm_load_x<KK, X_F64>(xf, x, b0, ncand, a.ld, a.L, cl, g);
+        for (int k = 0; k < K; k++) {
+            __builtin_amdgcn_sched_barrier(0);   // a component's fragment reads stay inside its iteration: the waves of a SIMD cover each other
+            const mg_lds_f64 *fk = lds_f + (size_t)k * nf * 64 + lane;
+            mg_f64x4 acc[JTM];
+#pragma unroll
+            for (int jt = 0; jt < JTM; jt++) {
+                const double c0 = lds_c[(k * JT + jt) * 16 + cl];
+                acc[jt] = {c0, c0, c0, c0};
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                int off = 0;
+#pragma unroll
+                for (int jt = 0; jt < JTM; jt++) {
+                    if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[kk], fk[(off + kk) * 64], acc[jt], 0, 0, 0);
+                    off += (4 * (jt + 1) < KK) ? 4 * (jt + 1) : KK;
+                }
+            }
+            mg_gmm_finish_component<JTM>(acc, JT, cst[k], k, terms, cl, g);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its LDS writes are visible to its reads in order
+        for (int e = lane; e < K * 16; e += 64) exps[e] = mg_gmm_exp_entry(terms, K, e);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < ncand) {
+            const double r = mg_gmm_logsumexp(terms, exps, K, lane);
+            if (OUT_F64) ((double *)out)[b0 + lane] = r;
+            else ((float *)out)[b0 + lane] = (float)r;
+        }
+    }
+}
+
+static int mg_gmm_lds_nf(int KK, int JT) {
+    int nf = 0;
+    for (int jt = 0; jt < JT; jt++) nf += std::min(4 * (jt + 1), KK);
+    return nf;
+}
+// the LDS-resident kernel pays from this many candidates on ('walk', us per launch, one tile per workgroup / LDS-resident:
+// B = 8192 9.9 / 15.6, 16384 16.6 / 16.9, 32768 30.2 / 24.8, 65536 51.0 / 38.9, 131072 91.0 / 67.4)
+#define MG_GMM_LDS_MIN_B 20480
+template <int KK>
+static int mg_launch_gmm_lds_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
+    mg_gmm_mfma_args a;
+    a.B = B; a.ld = ld; a.K = p->K; a.L = p->Lg; a.JT = (p->Lg + 15) / 16;
+    const int64_t n_tiles = (B + 15) / 16;
+    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(KK, a.JT) * 64 + (size_t)p->K * a.JT * 16 + (size_t)16 * 2 * p->K * 16) * 8;
+    // every CU gets a workgroup as soon as there are that many tiles: the tiles of a workgroup run side by side on its sixteen
+    // waves, so few tiles per workgroup mean short chains per SIMD (16 workgroups of 16 busy waves: 36 us at B = 4096)
+    const int grid = (int)std::min<int64_t>(std::max(1, p->ctx->n_cu), n_tiles);
+    hipStream_t st = p->ctx->stream;
+    const bool xf = xdt == MG_F64, of = odt == MG_F64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (xf && of) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
+    else if (xf) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
+    else if (of) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
+    else hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+static bool mg_gmm_use_lds_kernel(const mg_primitive *p, int64_t B) {
+    const int mode = p->ctx->opt[MG_OPT_GMM_KERNEL];   // 0 = by batch size, 1 = one tile per workgroup, 2 = LDS-resident
+    if (mode == 1 || !p->d_gPpack || p->KKg <= 0) return false;
+    const int JT = (p->Lg + 15) / 16;
+    if (JT != (p->KKg + 3) / 4) return false;       // (cannot happen: KKg is the smallest even number of k-steps for Lg)
+    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(p->KKg, JT) * 64 + (size_t)p->K * JT * 16 + (size_t)16 * 2 * p->K * 16) * 8;
+    if (lds > 160 * 1024 - 64) return false;
+    return mode == 2 || B >= MG_GMM_LDS_MIN_B;
+}
+
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
+    if (mg_gmm_use_lds_kernel(p, B)) {
+        switch (p->KKg) {
+            case 2: return mg_launch_gmm_lds_kk<2>(p, x, xdt, B, ld, out, odt);
+            case 4: return mg_launch_gmm_lds_kk<4>(p, x, xdt, B, ld, out, odt);
+            case 6: return mg_launch_gmm_lds_kk<6>(p, x, xdt, B, ld, out, odt);
+            case 8: return mg_launch_gmm_lds_kk<8>(p, x, xdt, B, ld, out, odt);
+            case 10: return mg_launch_gmm_lds_kk<10>(p, x, xdt, B, ld, out, odt);
+            case 12: return mg_launch_gmm_lds_kk<12>(p, x, xdt, B, ld, out, odt);
+            case 14: return mg_launch_gmm_lds_kk<14>(p, x, xdt, B, ld, out, odt);
+            case 16: return mg_launch_gmm_lds_kk<16>(p, x, xdt, B, ld, out, odt);
+            default: break;
+        }
+    }
     if (p->d_gPpack && p->K * 16 * 16 <= 60 * 1024) {
         switch (p->KKg) {
             case 2: return mg_launch_gmm_mfma_kk<2>(p, x, xdt, B, ld, out, odt);

@@ -70,6 +70,46 @@ __device__ __forceinline__ void mg_gmm_load_component(mg_gmm_frag<KK> &f,
     f.cst = cst[k];
 }
 
+// Sum over the 16 lanes of a row group, every lane ending with the total: the butterfly v += v[lane ^ 1], ^ 2, ^ 4, ^ 8 -- on the
+// VALU's data-parallel-primitive path (quad permutes, then the half-row and row mirrors: after the first two steps the four
+// lanes of a quad hold the same value, after the third the eight of a half row, so the mirrored lane holds what the xor
+// partner holds: the same additions, the same bits as the shuffle form) instead of eight ds_bpermute per step pair.
+template <int CTRL>
+__device__ __forceinline__ double mg_dpp_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double mg_row16_sum(double v) {
+    v += mg_dpp_f64<0xB1>(v);    // quad_perm [1, 0, 3, 2]: lane ^ 1
+    v += mg_dpp_f64<0x4E>(v);    // quad_perm [2, 3, 0, 1]: lane ^ 2
+    v += mg_dpp_f64<0x141>(v);   // row_half_mirror: the other quad of the half row
+    v += mg_dpp_f64<0x140>(v);   // row_mirror: the other half row
+    return v;
+}
+
+// The tail of a component: y = the JT accumulators (x P_k - mu_k P_k), squares summed over the column tiles in tile order,
+// Mahalanobis term finished by a butterfly over the 16 lanes of a candidate row group, terms[k*16 + cand] = cst_k - 0.5 |y|^2.
+// Shared by every kernel that evaluates the mixture, so that they all produce the same bits.
+template <int JTM>
+__device__ __forceinline__ void mg_gmm_finish_component(const mg_f64x4 (&acc)[JTM], int JT, double cst, int k, mg_lds_f64 *terms, int cl, int g) {
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int jt = 0; jt < JTM; jt++)
+        if (jt < JT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[r] = fma(acc[jt][r], acc[jt][r], part[r]);
+        }
+    // C/D layout: col = lane & 15, row (candidate) = (lane >> 4) + 4*reg: reduce over the 16 columns
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[r] = mg_row16_sum(part[r]);
+    if (cl == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) terms[k * 16 + g + 4 * r] = cst - 0.5 * part[r];
+    }
+}
+
 // The component applied to a 16-candidate latent tile by one wave:
 // terms[k*16 + cand] = cst_k - 0.5 |x P_k - mu_k P_k|^2, the column tiles' accumulator chains interleaved.
 template <int KK, typename T>
@@ -84,27 +124,7 @@ __device__ __forceinline__ void mg_gmm_apply_component(const mg_gmm_frag<KK> &f,
 #pragma unroll
         for (int jt = 0; jt < JTM; jt++)
             if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[kk], f.pf[jt][kk], acc[jt], 0, 0, 0);
-    double part[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int jt = 0; jt < JTM; jt++)
-        if (jt < JT) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) part[r] = fma(acc[jt][r], acc[jt][r], part[r]);
-        }
-    // C/D layout: col = lane & 15, row (candidate) = (lane >> 4) + 4*reg: reduce over the 16 columns
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        double v = part[r];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        part[r] = v;
-    }
-    if (cl == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) terms[k * 16 + g + 4 * r] = f.cst - 0.5 * part[r];
-    }
+    mg_gmm_finish_component<JTM>(acc, JT, f.cst, k, terms, cl, g);
 }
 
 // exp(term - max over the components of the same candidate) of entry e = k*16 + cand

@@ -1366,3 +1366,34 @@ def test_chunked_device_allocation(ctx):
     with pytest.raises(_capi.MGError):
         ctx.malloc(0, chunk_bytes=1 << 20)
     prim.close()
+
+
+@pytest.mark.parametrize("case", ["walk_seed0", "odd_shape", "k1_near_singular"])
+def test_lds_resident_mixture_kernel_is_bit_identical(ctx, case):
+    """mg_gmm_log_prob's large-batch kernel (persistent workgroups, the mixture's fragments staged in LDS once, a wave per
+    16-candidate tile) against the one-tile-per-workgroup kernel: the same log p(x), bit for bit, for ragged batches and every
+    input / output type -- and so within 1e-9 of sklearn's score_samples on the golden rows."""
+    from conftest import golden_model
+    data, g = golden_model(case)
+    prim = _capi.Primitive(ctx, data)
+    L = prim.n_gmm_dims
+    rng = np.random.default_rng(11)
+    for B in (1, 17, 4099, 40000):
+        X = rng.standard_normal((B, L))
+        for xdt in (np.float32, np.float64):
+            for odt in (np.float32, np.float64):
+                d_x, d_o = ctx.upload(X.astype(xdt)), ctx.malloc(B * np.dtype(odt).itemsize)
+                res = []
+                for mode in (1, 2):
+                    ctx.set_option(_capi.MG_OPT_GMM_KERNEL, mode)
+                    _capi._check(ctx.lib.mg_memset(ctx.handle, d_o.ptr, 0xff, B * np.dtype(odt).itemsize))
+                    prim.gmm_log_prob_dev(d_x, xdt, B, L, d_o, odt)
+                    res.append(ctx.download(d_o, (B,), odt))
+                ctx.set_option(_capi.MG_OPT_GMM_KERNEL, 0)
+                np.testing.assert_array_equal(res[0].view(np.uint8), res[1].view(np.uint8))
+                d_x.free()
+                d_o.free()
+    ctx.set_option(_capi.MG_OPT_GMM_KERNEL, 2)
+    np.testing.assert_allclose(prim.gmm_log_prob(g["X"], dtype=np.float64), g["logp"], rtol=1e-9, atol=1e-7)
+    ctx.set_option(_capi.MG_OPT_GMM_KERNEL, 0)
+    prim.close()

@@ -73,10 +73,13 @@ __global__ __launch_bounds__(512) void k_map(float *out, int ntiles, int mode, i
     const int w = blockIdx.x, G = gridDim.x;
     const int nblk = G / NCH, q = (ntiles + nblk - 1) / nblk;   // chunk-stationary maps: nblk workgroups per chunk, q tiles each
     const int U = ntiles * NCH, per = (U + G - 1) / G;
-    const int steps = (mode == 0 || mode == 20 || mode == 22) ? per : q;
+    const int steps = (mode == 0 || mode == 20 || mode == 22 || mode == 30) ? per : mode == 31 ? 9 : q;
     for (int s = 0; s < steps; s++) {
         int tile, chunk;
         if (mode == 0) { const int u = w * per + s; if (u >= U) break; tile = u / NCH; chunk = (u % NCH + w) % NCH; }
+        else if (mode == 30) { const int u = w * per + (s + prm * (w % NCH)) % per; if (u >= U) continue; tile = u / NCH; chunk = (u % NCH + w) % NCH; }
+        else if (mode == 31) {   // per = 9 on every workgroup: 256 x 9 = 2304 units over 2048: the surplus re-writes units of workgroup w + 1
+            const int u = (w * 8 + s) % U; tile = u / NCH; chunk = (u % NCH + w) % NCH; if (s >= prm) break; }
         else if (mode == 20) { const int u = w * per + s; if (u >= U) break; tile = u / NCH; chunk = (u % NCH + prm * w) % NCH; }
         else if (mode == 22) {   // all workgroups on the same chunk at the same time: chunk by chunk over the workgroup's own tiles
             const int tpw = per / NCH; if (tpw * NCH != per) break;
@@ -337,6 +340,9 @@ int main(int argc, char **argv) {
     {
         struct mp { int mode, prm; const char *what; };
         const mp maps[] = {{0, 0, "tile-major: u = w per + s, chunk rotated by w (the probe's pattern)"},
+                           {30, 1, "tile-major, the workgroup's units walked from unit w % 4: tile switches staggered"},
+                           {30, 3, "tile-major, the workgroup's units walked from unit 3 (w % 4)"},
+                           {31, 8, "tile-major, u = 8 w + s, 8 steps (= the first line, other code path)"},
                            {20, 0, "tile-major, chunk = u % 4: every workgroup on the same chunk at a time"},
                            {20, 2, "tile-major, chunk rotated by 2 w: two chunks active at a time"},
                            {22, 0, "chunk by chunk over the workgroup's own tiles, all workgroups on the same chunk"},
@@ -354,7 +360,7 @@ int main(int argc, char **argv) {
                            {6, 37, "chunk-stationary, blocks shifted by chunk x 37 tiles"},
                            {7, 0, "chunk-stationary, tile = bit-reversed lin"},
                            {8, 3, "chunk-stationary, block walked in steps of 3"}};
-        for (int gr : {256, 128}) {
+        for (int gr : {256}) {
             for (const mp &m : maps) {
                 const float qf = timeit([&] { hipLaunchKernelGGL(k_map, dim3(gr), dim3(512), 0, 0, (float *)fast, ntiles, m.mode, m.prm); });
                 const float qs = timeit([&] { hipLaunchKernelGGL(k_map, dim3(gr), dim3(512), 0, 0, (float *)slow, ntiles, m.mode, m.prm); });
