@@ -1,5 +1,5 @@
 // Device-side pieces of the MFMA log-likelihood, shared by the stand-alone kernel (mg_gmm.hip)
-// and by the fused step kernel (mg_backproject.hip) so that both produce the same bits.
+// and by the fused step kernel (mg_frames_ws.hip, mg_frames_cs.hip) so that both produce the same bits.
 // log p(x) = logsumexp_k [ cst_k - 0.5 |x P_k - mu_k P_k|^2 ]   (sklearn score_samples; reference
 // morphablegraphs/motion_model/motion_primitive.py:126-144).
 #pragma once

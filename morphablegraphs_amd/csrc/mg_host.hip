@@ -1,6 +1,6 @@
 // libmg_hip host side: context, primitive constants, time grids, C-ABI entry points.
 // gfx950 (MI355X) only.  All model preparation is float64 on the host; kernels live in
-// mg_backproject.hip / mg_gmm.hip / mg_score.hip.
+// mg_frames*.hip / mg_gmm.hip / mg_score.hip / mg_options.hip.
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>

@@ -156,15 +156,16 @@ class HipMotionPrimitive(object):
         PARITY UNPINNED for the sample count: the reference passes the FLOAT `num` to np.linspace, which raises
         TypeError on every NumPy >= 1.18; this restatement truncates it with int() -- the value
         NumPy < 1.18 silently used."""
-        import scipy.interpolate as si
-        x_sample = np.arange(self.n_canonical_frames)
-        sample_time_spline = si.splrep(canonical_time_function, x_sample, w=None, k=3)
-        num = int(np.round(canonical_time_function[-2]) * (1.0 / speed))
-        frames = np.linspace(1, stop=canonical_time_function[-2], num=num)
-        sample_time_function = si.splev(frames, sample_time_spline)
-        sample_time_function = np.insert(sample_time_function, 0, 0)
-        sample_time_function = np.insert(sample_time_function, len(sample_time_function), self.n_canonical_frames - 1)
-        return sample_time_function
+        from scipy.interpolate import splev, splrep
+        F = self.n_canonical_frames
+        t_of_tprime = np.asarray(canonical_time_function, dtype=np.float64)
+        # the inverse map as an interpolating cubic: knots at the canonical function's values, ordinates the sample indices
+        inverse = splrep(t_of_tprime, np.arange(F), k=3)
+        last = t_of_tprime[-2]
+        n_inner = int(np.round(last) / speed)
+        inner = splev(np.linspace(1.0, last, n_inner), inverse)
+        # the reference pins both ends: sample time 0 maps to canonical 0, the last one to the last canonical frame
+        return np.concatenate(([0.0], inner, [F - 1.0]))
 
     def _smooth_time_function(self, time_function):
         from scipy.signal import savgol_filter        # motion_primitive.py:321-331

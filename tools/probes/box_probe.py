@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """What kind of box is this?  Fill and store-pattern times of placed and plain output buffers, clocks and power as rocm-smi sees them.
-    python3 tools/box_probe.py [n_buffers]"""
+    python3 tools/probes/box_probe.py [n_buffers]"""
 import os
 import subprocess
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from morphablegraphs_amd import _capi   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6

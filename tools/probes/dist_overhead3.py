@@ -1,8 +1,8 @@
 """All-gather cost per step against RCCL's channel count and CUs left free (world of one rank, one GPU).
-usage: NCCL_MAX_NCHANNELS=.. python3 tools/dist_overhead3.py"""
+usage: NCCL_MAX_NCHANNELS=.. python3 tools/probes/dist_overhead3.py"""
 import os, sys, time
 import numpy as np, torch, torch.distributed as dist
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from morphablegraphs_amd import _capi, synthetic
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29579")
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
