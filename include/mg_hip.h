@@ -357,9 +357,12 @@ int mg_joint_positions(mg_context *ctx, const mg_skeleton_desc *skeleton, const 
  * errors_dev (B) float64: written, or added to with accumulate != 0 (the sum MotionPrimitiveConstraints.evaluate forms);
  * residuals_dev: NULL or (B, T) float64 = weight * distance per sample.  alignment: NULL (local coordinates), the
  * previous-frame record with the ROOT as aligning node, or a start-pose record.
- * The reference searches with scipy's L-BFGS-B from the lower bound; here: grid walk (u = k / granularity) + parabolic
- * refinement, deterministic (mg_trajectory.hip).  PARITY UNPINNED for the search (the reference function does not run on the
- * installed NumPy); the spline itself is pinned by tests/golden/trajectory_spline.npz. */
+ * The reference searches with scipy's L-BFGS-B from the lower bound; here: grid walk (u = k / granularity), parabola through the
+ * three grid points around the minimum, then Newton steps on the squared distance inside that bracket -- deterministic, the
+ * local minimum of the first basin at or after the bound to rounding (mg_trajectory.hip).  PARITY UNPINNED for the search (the
+ * reference function does not run on the installed NumPy); tests hold the device to "frame by frame never farther from the root
+ * than the restated L-BFGS-B search from the same bound" and to a closed-form case on a straight line; the spline itself is
+ * pinned by tests/golden/trajectory_spline.npz. */
 typedef struct mg_trajectory mg_trajectory;
 int mg_trajectory_create(mg_primitive *prim, const double *control_points, int32_t n_points, int32_t granularity, mg_trajectory **out);
 void mg_trajectory_destroy(mg_trajectory *trajectory);

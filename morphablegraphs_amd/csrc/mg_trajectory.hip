@@ -5,8 +5,9 @@
 // the average over the frames.  The reference finds that point with scipy's L-BFGS-B started at the lower bound
 // (splines/parameterized_spline.py:303-322; the function raises ValueError under NumPy >= 1.24, so PARITY UNPINNED);
 // here the search is deterministic: on the grid u_k = k / granularity walk forward from the bound while the distance
-// falls, then refine by the parabola through the three squared distances around the minimum (oracle:
-// oracle/mg_oracle.py closest_point_walk; the two agree to 2e-3 relative on paths that follow the spline).
+// falls, refine by the parabola through the three squared distances around the minimum, then by Newton steps on the
+// squared distance inside that bracket (oracle: oracle/mg_oracle.py closest_point_walk).  The result is the local
+// minimum of the first basin at or after the bound; tests hold it to "never farther than the restated L-BFGS-B search".
 //
 // One thread per candidate (the search is a chain over the frames): the candidate's root coefficient rows
 // (n_basis x 3, float64 fma chains over the latents) are staged in LDS, every frame is four taps of them.
@@ -59,6 +60,25 @@ __device__ __forceinline__ double mg_traj_d2(const double *poly, int n_seg, doub
     mg_traj_point(poly, n_seg, u, p);
     const double x = p[0] - q[0], y = p[1] - q[1], z = p[2] - q[2];
     return x * x + y * y + z * z;
+}
+
+// squared distance, and its first and second derivative in u (the segment's cubic differentiated; false past the last segment)
+__device__ __forceinline__ bool mg_traj_d2_derivs(const double *poly, int n_seg, double u, const double *q, double *f0, double *f1, double *f2) {
+    const double scaled = n_seg * u;
+    int index = (int)floor(scaled);
+    if (index >= n_seg) return false;
+    const double t = scaled - index;
+    const double *A = poly + (size_t)index * 12;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double v = ((A[d] * t + A[3 + d]) * t + A[6 + d]) * t + A[9 + d] - q[d];
+        const double p1 = ((3.0 * A[d] * t + 2.0 * A[3 + d]) * t + A[6 + d]) * n_seg;
+        const double p2 = (6.0 * A[d] * t + 2.0 * A[3 + d]) * n_seg * n_seg;
+        s0 += v * v; s1 += v * p1; s2 += p1 * p1 + v * p2;
+    }
+    *f0 = s0; *f1 = 2.0 * s1; *f2 = 2.0 * s2;
+    return true;
 }
 
 __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_args a) {
@@ -137,6 +157,18 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
             const double da = mg_traj_d2(a.poly, a.n_seg, (k - 1) * invG, q), dc = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
             const double den = da - 2.0 * dk + dc;
             if (den > 0.0) u = (k + 0.5 * (da - dc) / den) * invG;
+        }
+        {   // up to four Newton steps on the squared distance inside the bracket of the grid minimum (one-sided at the ends of the
+            // range): the bracket's local minimum to rounding; a step that does not lower the distance ends the refinement
+            const double lo = fmax(min_u, (k - 1) * invG), hi = fmin(1.0, (k + 1) * invG);
+            u = fmin(hi, fmax(lo, u));
+            for (int it = 0; it < 4; it++) {
+                double f0, f1, f2;
+                if (!mg_traj_d2_derivs(a.poly, a.n_seg, u, q, &f0, &f1, &f2) || !(f2 > 0.0)) break;
+                const double un = fmin(hi, fmax(lo, u - f1 / f2));
+                if (mg_traj_d2(a.poly, a.n_seg, un, q) > f0) break;
+                u = un;
+            }
         }
         u = fmin(1.0, fmax(min_u, u));
         double d2 = mg_traj_d2(a.poly, a.n_seg, u, q);
@@ -259,7 +291,11 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     }
     const size_t lds = (size_t)(p->L + t->rows) * MG_TRAJ_BLOCK * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_score_trajectory: %d basis functions x %d components do not fit LDS", p->NB, p->L); return MG_ERR_UNSUPPORTED; }
-    if (lds > 48 * 1024) MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    static bool attr_set = false;   // once per process, not per launch
+    if (lds > 48 * 1024 && !attr_set) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
     hipLaunchKernelGGL(mg_trajectory_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
     MG_HIP_CHECK(hipGetLastError());

@@ -162,7 +162,7 @@ class HipMotionPrimitive(object):
         # the inverse map as an interpolating cubic: knots at the canonical function's values, ordinates the sample indices
         inverse = splrep(t_of_tprime, np.arange(F), k=3)
         last = t_of_tprime[-2]
-        n_inner = int(np.round(last) / speed)
+        n_inner = int(np.round(last) * (1.0 / speed))      # the product, as the reference forms it (x * (1 / speed) and x / speed can differ in the last bit)
         inner = splev(np.linspace(1.0, last, n_inner), inverse)
         # the reference pins both ends: sample time 0 maps to canonical 0, the last one to the last canonical frame
         return np.concatenate(([0.0], inner, [F - 1.0]))

@@ -393,6 +393,24 @@ def catmull_rom_point(control_points, u):
     return 0.5 * (w @ (_CATMULL_ROM_BASE @ ctrl))
 
 
+def catmull_rom_derivatives(control_points, u):
+    """dP/du and d2P/du2 of the same curve (the segment's cubic differentiated; zero past the last segment)."""
+    P = [np.asarray(p, dtype=np.float64) for p in control_points]
+    n_seg = len(P) - 1
+    padded = [P[0]] + P + [P[-1], P[-1]]
+    scaled = n_seg * float(u)
+    index = min(int(math.floor(scaled)), n_seg)
+    t = scaled - index
+    seg = index + 1
+    if seg > n_seg:
+        return np.zeros_like(P[0]), np.zeros_like(P[0])
+    ctrl = np.stack([padded[seg - 1], padded[seg], padded[seg + 1], padded[seg + 2]])
+    A = 0.5 * (_CATMULL_ROM_BASE @ ctrl)                    # rows: t^3, t^2, t, 1
+    d1 = (3.0 * A[0] * t + 2.0 * A[1]) * t + A[2]
+    d2 = 6.0 * A[0] * t + 2.0 * A[1]
+    return n_seg * d1, n_seg * n_seg * d2
+
+
 def catmull_rom_full_arc_length(control_points, granularity=1000):
     """RelativeArcLengthMap._update_table (splines/arc_length_map.py:45-71): polyline length over granularity + 1 samples."""
     pts = np.array([catmull_rom_point(control_points, k / float(granularity)) for k in range(granularity + 1)])
@@ -428,8 +446,9 @@ def trajectory_residuals(root_path, control_points, min_u=0.0):
 def closest_point_walk(control_points, point, min_u, granularity=1000):
     """The DEVICE's deterministic form of the same search (what mg_score_trajectory computes, restated): on the grid
     u_k = k / granularity walk forward from the first grid point at or after min_u while the distance falls, then refine
-    the parameter by the parabola through the squared distances of the three grid points around the minimum (clamped to
-    [min_u, 1])."""
+    the parameter by the parabola through the squared distances of the three grid points around the minimum, then by up to
+    four Newton steps on the squared distance inside the bracket of those three grid points (clamped to [min_u, 1]): the
+    local minimum of the bracket to rounding, so never farther from the point than a converged search of the same basin."""
     target = np.asarray(point, dtype=np.float64)
     G = int(granularity)
 
@@ -450,6 +469,18 @@ def closest_point_walk(control_points, point, min_u, granularity=1000):
         den = a - 2.0 * b + c
         if den > 0.0:
             u = (k + 0.5 * (a - c) / den) / G
+    lo, hi = max(float(min_u), (k - 1) / G), min(1.0, (k + 1) / G)      # the bracket of the grid minimum (one-sided at the ends)
+    u = min(hi, max(lo, u))
+    for _ in range(4):
+        v = catmull_rom_point(control_points, u) - target
+        p1, p2 = catmull_rom_derivatives(control_points, u)
+        f1, f2 = 2.0 * float(v @ p1), 2.0 * float(p1 @ p1 + v @ p2)
+        if not f2 > 0.0:
+            break
+        un = min(hi, max(lo, u - f1 / f2))
+        if d2(un) > d2(u):
+            break
+        u = un
     u = min(1.0, max(float(min_u), u))
     if d_start <= d2(u):
         u = float(min_u)
