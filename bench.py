@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F64_MFMA_PEAK_TFLOPS = 78.6   # AMD's published MI355X float64 matrix figure (the guide has no float64 row)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_summary.json")   # tools/prof_bench.sh + tools/summarize_prof.py
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_summary.json")   # tools/prof_bench.sh + tools/summarize_prof.py
 METRIC = "motion-primitive samples scored+back-projected/sec; fraction of HBM roofline"
 L, F, D, NB, K = 40, 156, 79, 31, 8
 
@@ -394,7 +394,7 @@ def run_walk(args, rank, local_rank, world):
             result["roofline"] = {
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/r02_summary.json), not measured in this run" if traffic else None,
+                "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/r03_summary.json), not measured in this run" if traffic else None,
                 "avg_kernel_ms": avg_ms, "launches_timed": frames_n, "event_interval": interval,
                 "algorithmic_bytes_per_launch": k_bytes, "launches_per_step": 2 if args.two_launch else 1,
                 "gmm_kernel_avg_ms": (gmm_ms / gmm_n) if gmm_n else None,
@@ -420,7 +420,7 @@ def run_walk(args, rank, local_rank, world):
                     prim.step_frames_and_logp_dev(S, np.float32, B, L, out_buf, logps[0])
                 ctx.synchronize()
                 return 1e6 * (time.perf_counter() - t) / n
-            if args.output_alloc != "plain":
+            if args.output_alloc != "plain" and not args.no_placement_compare:
                 # beside the headline: (1) a SECOND buffer from the allocation call every device-pointer caller uses (mg_device_malloc: the
                 # headline's region is in use, so this one is a region of its own, scanned for like the first); (2) memory that does not
                 # come from the library at all -- one hipMalloc, wherever it landed -- which is what a caller's own tensor would be
@@ -502,7 +502,27 @@ def cpu_baseline_leg(data, S_host):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    nproc = max(1, min(avail, 32))
+    # the cores this process may actually USE: the affinity mask says which CPUs it may run on, the cgroup's CPU quota how
+    # much CPU time it gets (a one-GPU box of the pool shows 256 CPUs and grants 16 cores' worth: thirty-two processes then run
+    # at half speed each, which is what the 15.5 x of round 2's 32-process leg was); one process per granted core
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2
+            q, per = f.read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:      # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    usable = avail if quota is None else max(1, min(avail, int(quota + 0.5)))
+    nproc = max(1, min(usable, 32 if quota is None else 64))
     multi = None
     if nproc > 1:
         import multiprocessing as mp
@@ -535,10 +555,12 @@ def cpu_baseline_leg(data, S_host):
         "vectorised_value": vec["rate"], "vectorised_cores": vec["threads"],
         "vectorised_sample": "%d candidates, float32 GEMM (coefficients) + batched basis GEMM (frames materialised) + "
                              "batched sklearn score_samples, %d BLAS threads, %.1f s" % (vec["n"], vec["threads"], vec["seconds"]),
-        "host_cores_available": os.cpu_count(),
+        "host_cores_available": os.cpu_count(), "affinity_cores": avail, "cgroup_cpu_quota_cores": quota,
     }
     if multi:
         out.update({"multi_process_value": multi["rate"], "multi_process_cores": nproc,
+                    "multi_process_efficiency": multi["rate"] / (nproc * ref["rate"]),   # 1.0 = every process ran as fast as the single one; less: the
+                                                                                        # processes shared cores (CPU quota below the process count) or memory bandwidth
                     "multi_process_sample": "the same reference-shaped loop in %d processes (one core each, disjoint candidate slices), %d candidates, %.1f s"
                                             % (nproc, multi["n"], multi["seconds"])})
     return out
@@ -681,6 +703,7 @@ def main():
     ap.add_argument("--config", choices=("walk", "graph", "optimizer"), default="walk",
                     help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-placement-compare", action="store_true", help="skip the steps on a second library buffer and on a foreign hipMalloc after the timed region (profiling runs)")
     ap.add_argument("--no-extra-configs", action="store_true", help="do not attach the graph / optimizer configurations to the default line")
     ap.add_argument("--two-launch", action="store_true",
                     help="frames kernel and log-likelihood kernel as two launches instead of the fused step kernel")

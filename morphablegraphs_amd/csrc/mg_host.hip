@@ -1280,9 +1280,11 @@ extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_
     }
     for (int c = 0; c < n; c++) {
         const int type = cons[c].type;
-        MG_REQUIRE(type >= MG_CONSTRAINT_POSITION && type <= MG_CONSTRAINT_POSE,
+        MG_REQUIRE(type >= MG_CONSTRAINT_POSITION && type <= MG_CONSTRAINT_VALUE_HEADING,
                    "mg_constraint_set_create: constraint %d has unknown type %d", c, type);
         MG_REQUIRE(std::isfinite(cons[c].canonical_keyframe), "mg_constraint_set_create: constraint %d keyframe not finite", c);
+        MG_REQUIRE((type == MG_CONSTRAINT_VALUE_POSITION || type == MG_CONSTRAINT_VALUE_HEADING) ? (cons[c].target[0] == 0.0 || cons[c].target[0] == 2.0 ||
+                   (type == MG_CONSTRAINT_VALUE_POSITION && cons[c].target[0] == 1.0)) : true, "mg_constraint_set_create: constraint %d: value constraints select a component with target[0] = 0, (1,) 2", c);
         MG_REQUIRE(type == MG_CONSTRAINT_POSITION ? D >= 3 : D >= 7,
                    "mg_constraint_set_create: constraint %d needs more pose channels than n_dim = %d", c, D);
         int rows = nch;
@@ -1353,6 +1355,17 @@ extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_
             MG_REQUIRE(m <= MG_MAX_CHAIN && m2 <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain exceeds %d joints", c, MG_MAX_CHAIN);
             chain_len[c] = m | (m2 << 16);
             rows = 3 + 4 * std::max(m, 1) + 4 * std::max(m2, 1);
+        } else if (type == MG_CONSTRAINT_VALUE_HEADING) {
+            MG_REQUIRE(cons[c].joint == 0 || (sk && cons[c].joint > 0 && cons[c].joint < sk->n_joints),
+                       "mg_constraint_set_create_fk: constraint %d: joint %d needs a skeleton that has it", c, cons[c].joint);
+            if (cons[c].joint == 0) chains[c].push_back(0);
+            else for (int j = cons[c].joint; j >= 0; j = sk->parents[j]) chains[c].insert(chains[c].begin(), j);
+            const int m = (int)chains[c].size();
+            MG_REQUIRE(m <= MG_MAX_CHAIN, "mg_constraint_set_create_fk: constraint %d: chain of %d joints exceeds %d", c, m, MG_MAX_CHAIN);
+            const double rn = std::sqrt(cons[c].ref_dir[0] * cons[c].ref_dir[0] + cons[c].ref_dir[1] * cons[c].ref_dir[1] + cons[c].ref_dir[2] * cons[c].ref_dir[2]);
+            MG_REQUIRE(std::isfinite(rn) && rn > 0.0, "mg_constraint_set_create: constraint %d: zero reference vector", c);
+            chain_len[c] = m;
+            rows = 4 * m;
         } else if (type == MG_CONSTRAINT_JOINT_ORIENTATION) {
             MG_REQUIRE(cons[c].joint == 0 || (sk && cons[c].joint > 0 && cons[c].joint < sk->n_joints),
                        "mg_constraint_set_create_fk: constraint %d: joint %d needs a skeleton that has it", c, cons[c].joint);
@@ -1434,7 +1447,7 @@ extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_
                 fill_quats(r0 + 3 + 4 * std::max(m, 1), chains2[c], std::max(m2, 1));
                 fill_offsets(1, chains2[c], m2);
             }
-        } else if (cons[c].type == MG_CONSTRAINT_JOINT_ORIENTATION) {
+        } else if (cons[c].type == MG_CONSTRAINT_JOINT_ORIENTATION || cons[c].type == MG_CONSTRAINT_VALUE_HEADING) {
             fill_quats(r0, chains[c], chain_len[c]);
         } else {
             for (int d = 0; d < nch; d++) fill_row(r0 + d, d);
@@ -1588,6 +1601,22 @@ extern "C" int mg_score_constraint_residuals(mg_primitive *p, const mg_constrain
     MG_REQUIRE(res != nullptr, "mg_score_constraint_residuals: output pointer is NULL");
     mg_prof_begin(p->ctx, 2);
     rc = mg_launch_score(p, cs, lat, dt, B, ld, nullptr, MG_F64, res);
+    mg_prof_end(p->ctx, 2);
+    return rc;
+}
+
+// The same residual matrix with EVERY candidate aligned to its own previous motion: align_cand (n, 4) = previous heading
+// (x, z; unit) and previous root position (x, z) per candidate, in place of the set's one alignment record.
+extern "C" int mg_score_constraint_residuals_chained(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt, int64_t B, int64_t ld,
+                                                     const double *align_cand, double *res) {
+    int rc = mg_check_latents("mg_score_constraint_residuals_chained", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(cs && cs->prim == p, "mg_score_constraint_residuals_chained: constraint set is NULL or belongs to another primitive");
+    MG_REQUIRE(cs->d_align != nullptr && cs->align_joint >= 0, "mg_score_constraint_residuals_chained: the set needs a previous-frame alignment (its node and reference vector; the values are per candidate)");
+    if (B == 0 || cs->n == 0) return MG_OK;
+    MG_REQUIRE(res != nullptr && align_cand != nullptr, "mg_score_constraint_residuals_chained: NULL pointer");
+    mg_prof_begin(p->ctx, 2);
+    rc = mg_launch_score(p, cs, lat, dt, B, ld, nullptr, MG_F64, res, align_cand);
     mg_prof_end(p->ctx, 2);
     return rc;
 }

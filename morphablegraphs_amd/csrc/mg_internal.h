@@ -217,7 +217,8 @@ int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, con
                          int64_t tile0, int64_t row_lo, int64_t row_hi);
 bool mg_gmm_sample_takes_host_prefix(const mg_primitive *p);
 int mg_launch_set_params(mg_context *ctx, const double *values, int n_par, int n_align, double *d_par, double *d_align);
-int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res);
+int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res,
+                    const double *align_cand = nullptr);
 int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld, int L, void *result_dev);
 int mg_launch_argmin_gather(mg_context *ctx, const void *v, int dt, int64_t n, void *result_dev, const void *x, int xdt, int64_t ld, int L, int64_t index_offset = 0);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);

@@ -252,7 +252,7 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
         o.cpack = p->d_gcholpack; o.meanpad = p->d_gmeanpad; o.Wpack = cs->d_Wpack; o.bpad = cs->d_bpad;
         mg_score_args &a = o.sa;
         a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff;
-        a.align = cs->d_align; a.pose = cs->d_pose; a.lat = x_dev[k]; a.out = errors_dev[k]; a.res = nullptr; a.B = n; a.ld = ld[k];
+        a.align = cs->d_align; a.align_cand = nullptr; a.pose = cs->d_pose; a.lat = x_dev[k]; a.out = errors_dev[k]; a.res = nullptr; a.B = n; a.ld = ld[k];
         a.n = cs->n; a.nch = cs->nch; a.L = p->L;
         o.x = x_dev[k]; o.result = (char *)results_dev + (size_t)k * result_stride;
         o.K = p->K; o.Lg = p->Lg; o.KKg = p->KKg; o.KK = p->KK; o.JT = (p->Lg + 15) / 16; o.RT = cs->RT;

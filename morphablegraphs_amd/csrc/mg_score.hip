@@ -41,7 +41,7 @@ __global__ __launch_bounds__(MG_SC_CANDS *MG_SC_WAVES) void mg_score_kernel(mg_s
             for (int k = 0; k < L; k++) acc = fma(wr[k], x[k], acc);
             return acc;
         };
-        lds_r[c * MG_SC_CANDS + lane] = mg_constraint_residual(a, c, channel);
+        lds_r[c * MG_SC_CANDS + lane] = mg_constraint_residual(a, c, channel, b0 + lane);
     }
     __syncthreads();
     if (a.res)   // (n_samples, n) row-major: consecutive threads write consecutive constraints of a candidate
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void mg_score_mfma_kernel(mg_score_args a, con
     for (int e = lane; e < 16 * a.n; e += 64) {
         const int cand = e & 15, c = e >> 4;
         const double *v = vals + cand * vs;
-        resid[c * 16 + cand] = mg_constraint_residual(a, c, [&](int row) { return v[row]; });
+        resid[c * 16 + cand] = mg_constraint_residual(a, c, [&](int row) { return v[row]; }, b0 + cand);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (a.res)
@@ -129,9 +129,9 @@ static int mg_launch_score_mfma_kk(mg_primitive *p, const mg_constraint_set *cs,
     return MG_OK;
 }
 
-int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res) {
+int mg_launch_score(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int ldt, int64_t B, int64_t ld, void *out, int odt, double *res, const double *align_cand) {
     mg_score_args a;
-    a.res = res;
+    a.res = res; a.align_cand = align_cand;
     a.W = cs->d_W; a.bias = cs->d_bias; a.par = cs->d_par; a.woff = cs->d_woff; a.chain = cs->d_chain; a.choff = cs->d_choff; a.align = cs->d_align; a.pose = cs->d_pose; a.lat = lat; a.out = out; a.B = B; a.ld = ld; a.n = cs->n; a.nch = cs->nch; a.L = p->L;
     const bool lf0 = ldt == MG_F64, of0 = odt == MG_F64;
     if (cs->d_Wpack && !p->ctx->opt[MG_OPT_FORCE_VALU_SCORE]) {

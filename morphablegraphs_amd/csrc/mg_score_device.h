@@ -18,6 +18,8 @@ struct mg_score_args {
     const double *choff;  // [n][2][MG_MAX_CHAIN][3]
     const double *pose;   // pose constraints' tables (MG_POSE_HDR / MG_POSE_REC layout) or NULL
     const double *align;  // [8] or NULL: chain length, previous heading (x,z), previous root (x,z), ref_dir; rows at woff[n]
+    const double *align_cand;   // NULL, or (B, 4): the previous heading (x, z) and root position (x, z) of EVERY candidate, in
+                                // place of align[1..4] (the steps of a graph walk: a candidate's step is aligned to ITS OWN previous step)
     const void *lat;
     void *out;            // (B) summed error, or NULL
     double *res;          // (B, n) weighted residual of every constraint, or NULL
@@ -106,7 +108,7 @@ __device__ __forceinline__ void mg_fk_position_table(ChannelFn channel, int r0, 
 // puts its first root position on the previous one.
 struct mg_align2d { double c, s, tx, tz, ty; };   // ty: the start-pose mode raises every position by the start height
 template <typename ChannelFn>
-__device__ __forceinline__ mg_align2d mg_candidate_alignment(const mg_score_args &a, ChannelFn channel) {
+__device__ __forceinline__ mg_align2d mg_candidate_alignment(const mg_score_args &a, ChannelFn channel, int64_t cand) {
     const double *al = a.align;
     const int r0 = a.woff[a.n], m = (int)al[0];
     if (m == 0) {
@@ -135,23 +137,43 @@ __device__ __forceinline__ mg_align2d mg_candidate_alignment(const mg_score_args
     double bx = rx + 2.0 * (aw * cx + dx), bz = rz + 2.0 * (aw * cz + dz);
     const double bn = 1.0 / sqrt(bx * bx + bz * bz);
     bx *= bn; bz *= bn;
+    const double *pc = a.align_cand ? a.align_cand + cand * 4 - 1 : al;   // [1..4]: previous heading (x, z), previous root (x, z)
     mg_align2d t;
-    t.c = al[1] * bx + al[2] * bz;
-    t.s = al[1] * bz - al[2] * bx;
+    t.c = pc[1] * bx + pc[2] * bz;
+    t.s = pc[1] * bz - pc[2] * bx;
     const double p0x = channel(r0), p0z = channel(r0 + 2);
-    t.tx = al[3] - (t.c * p0x + t.s * p0z);
-    t.tz = al[4] - (t.c * p0z - t.s * p0x);
+    t.tx = pc[3] - (t.c * p0x + t.s * p0z);
+    t.tz = pc[4] - (t.c * p0z - t.s * p0x);
     t.ty = 0.0;
     return t;
 }
 
 template <typename ChannelFn>
-__device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a, int c, ChannelFn channel) {
+__device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a, int c, ChannelFn channel, int64_t cand = 0) {
     const double *par = a.par + (size_t)c * 8;
     const int type = (int)par[0];
     const int r0 = a.woff[c];
     mg_align2d al = {1.0, 0.0, 0.0, 0.0, 0.0};
-    if (a.align) al = mg_candidate_alignment(a, channel);
+    if (a.align) al = mg_candidate_alignment(a, channel, cand);
+    if (type == MG_CONSTRAINT_VALUE_POSITION) {   // not an error: the (aligned) root position's component par[2] at the keyframe
+        double pj[3] = {channel(r0), channel(r0 + 1), channel(r0 + 2)};
+        if (a.align) {
+            const double x = pj[0], z = pj[2];
+            pj[0] = al.c * x + al.s * z + al.tx;
+            pj[2] = al.c * z - al.s * x + al.tz;
+            pj[1] += al.ty;
+        }
+        return par[1] * pj[(int)par[2]];
+    }
+    if (type == MG_CONSTRAINT_VALUE_HEADING) {   // the (aligned) unit heading's x (par[2] = 0) or z component: xz of the joint's global orientation applied to ref_dir
+        double q[4], v[3];
+        mg_chain_orientation(channel, r0, a.chain[c], q);
+        mg_rotate(q, par[5], par[6], par[7], v);
+        double hx = v[0], hz = v[2];
+        if (a.align) { hx = al.c * v[0] + al.s * v[2]; hz = al.c * v[2] - al.s * v[0]; }
+        const double inv = 1.0 / sqrt(hx * hx + hz * hz);
+        return par[1] * ((int)par[2] == 0 ? hx : hz) * inv;
+    }
     if (type == MG_CONSTRAINT_JOINT_POSITION || type == MG_CONSTRAINT_JOINT_MIDPOINT) {
         // forward kinematics along the chain: p = t_root + sum_i R(q_0 .. q_(i-1)) offset_i, unit quaternions (w,x,y,z)
         const int m = a.chain[c] & 0xffff;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/<tag>_* is made from, on the GPU box, summarised there (the raw rocprofv3 output is too large to travel back):
 #   tools/prof_all.sh <tag>   ->  gpurun_out/profiles_<tag>/   (copy into profiles/)
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
@@ -16,5 +16,5 @@ for cfg in graph optimizer; do
   cp $R/gpurun_out/prof_${tag}_$cfg/bench.json $O/${tag}_${cfg}_bench_under_rocprof.json
   rm -rf $R/gpurun_out/prof_${tag}_$cfg
 done
-cd $R && python3 bench.py --steps 20 --warmup 5 > $O/${tag}_bench.json 2> $O/bench.err
+cd $R && python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${tag}_bench.json 2> $O/bench.err
 ls -la $O

@@ -2,12 +2,12 @@
 # Profile bench.py on the GPU box: kernel trace + PMC passes (each in its own run).
 # usage: tools/prof_bench.sh <tag> [extra bench args]
 set -o pipefail
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # the default bench.py command (steps 2000, warmup 200, HIP-event bracketing on), minus the CPU baseline leg
-B="$GRAFT_REPO_ROOT/bench.py --steps 2000 --warmup 200 --no-cpu-baseline $@"
+B="$GRAFT_REPO_ROOT/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-extra-configs --no-placement-compare $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $B > $out/trace.log 2>&1 || { echo trace failed; tail -5 $out/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $B > $out/pmc_fetch.log 2>&1 || { echo fetch failed; tail -5 $out/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $out/pmc_write -- python3 $B > $out/pmc_write.log 2>&1 || { echo write failed; tail -5 $out/pmc_write.log; exit 1; }

@@ -2,7 +2,7 @@
 # Kernel traces of the other two bench configurations (BASELINE.json configs[2] and configs[4] on one GPU).
 # usage: tools/prof_configs.sh <tag>
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 for cfg in graph optimizer; do
   out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_$cfg
