@@ -117,7 +117,14 @@ typedef struct mg_primitive_desc {
  *      product (transformations.angle_between_vectors), clamped to [-1, 1]. */
 enum { MG_CONSTRAINT_POSITION = 0, MG_CONSTRAINT_DIRECTION_2D = 1, MG_CONSTRAINT_JOINT_POSITION = 2,
        MG_CONSTRAINT_JOINT_MIDPOINT = 3, MG_CONSTRAINT_JOINT_ORIENTATION = 4, MG_CONSTRAINT_LOOK_AT = 5,
-       MG_CONSTRAINT_POSE = 6 /* mg_keyframe_constraint.joint = index into the mg_pose_constraint array */ };
+       MG_CONSTRAINT_POSE = 6 /* mg_keyframe_constraint.joint = index into the mg_pose_constraint array */,
+       /* Not errors but VALUES of the (aligned) motion at the keyframe, reported in the residual matrix: what the next step of
+        * a graph walk is aligned to (obj_global_*: reference optimization/objective_functions.py:290-380 hands each step the
+        * aligned frames of the step before).  weight_factor multiplies the value (use 1).
+        *   MG_CONSTRAINT_VALUE_POSITION: component target[0] (0, 1, 2) of the root position;
+        *   MG_CONSTRAINT_VALUE_HEADING:  component target[0] (0 = x, 2 = z) of the unit heading = xz of the global orientation
+        *                                 of `joint` applied to ref_dir (the aligning node and reference vector of mg_alignment_desc) */
+       MG_CONSTRAINT_VALUE_POSITION = 7, MG_CONSTRAINT_VALUE_HEADING = 8 };
 #define MG_MAX_CHAIN 32
 typedef struct mg_keyframe_constraint {
     int32_t type;
@@ -464,6 +471,14 @@ int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
  * naturalness] (reference optimization/objective_functions.py:209-267). */
 int mg_score_constraint_residuals(mg_primitive *prim, const mg_constraint_set *cs, const void *latents_dev,
                                   int latent_dtype, int64_t n_samples, int64_t ld, double *residuals_dev);
+
+/* The same matrix with EVERY candidate aligned to ITS OWN previous motion: align_cand_dev (n_samples, 4) float64 = per candidate
+ * the previous unit heading (x, z) and the previous root position (x, z), in place of the one record the set was made with (the
+ * set must have a previous-frame alignment: its node, chain and reference vector are used).  The steps of a graph walk chained on
+ * the device: step i's MG_CONSTRAINT_VALUE_* columns are step i + 1's align_cand (obj_global_error_sum and its residual-vector
+ * forms, reference optimization/objective_functions.py:290-380, for a whole batch of concatenated latent vectors). */
+int mg_score_constraint_residuals_chained(mg_primitive *prim, const mg_constraint_set *cs, const void *latents_dev, int latent_dtype,
+                                          int64_t n_samples, int64_t ld, const double *align_cand_dev, double *residuals_dev);
 
 /* The argmin rule of evaluate_samples_using_constraints
  * (reference motion_primitive_generator.py:251-257): FIRST strict minimum, NaN never

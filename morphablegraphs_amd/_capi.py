@@ -27,6 +27,7 @@ MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile 
 MG_OPT_COUNT = 10
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
+MG_CONSTRAINT_VALUE_POSITION, MG_CONSTRAINT_VALUE_HEADING = 7, 8   # values of the aligned motion, not errors (chained graph-walk steps)
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
                  "gmm_sample": 4, "spline_evaluate": 5, "step": 6, "options_step": 7}
 
@@ -49,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
-    "mg_option_step", "mg_options_step", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
+    "mg_score_constraint_residuals_chained", "mg_option_step", "mg_options_step", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
 ]
 
 
@@ -252,6 +253,7 @@ def load_library(path=None):
         "mg_constraint_set_create_full": [vp, vp, vp, i32, vp, i32, vp, vp],
         "mg_best_candidate": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
         "mg_best_candidate_host": [vp, vp, vp, i32, i64, i64, C.POINTER(i64), C.POINTER(dbl)],
+        "mg_score_constraint_residuals_chained": [vp, vp, vp, i32, i64, i64, vp, vp],
         "mg_option_step": [vp, vp, i64, vp, u64, vp, i32, i64, vp, vp],
         "mg_option_step_rows": [vp, vp, i64, vp, u64, i64, i64, vp, i32, i64, vp, vp],
         "mg_options_step_rows": [i32, vp, vp, i64, vp, vp, i64, i64, vp, i32, vp, vp, vp, i64, vp],
@@ -648,6 +650,18 @@ class ConstraintSet(object):
             elif c["type"] == "pose":
                 k.type = MG_CONSTRAINT_POSE
                 k.joint = sum(1 for q in constraints[:i] if q["type"] == "pose")   # index into the pose array
+            elif c["type"] == "value_position":      # {"type", "t", "axis": 0 | 1 | 2}: the (aligned) root position's component
+                k.type = MG_CONSTRAINT_VALUE_POSITION
+                k.target[0] = float(int(c["axis"]))
+            elif c["type"] == "value_heading":       # {"type", "t", "axis": 0 | 2, "joint", "ref_dir"}: the (aligned) unit heading's component
+                k.type = MG_CONSTRAINT_VALUE_HEADING
+                if skeleton is None and c.get("joint", 0) not in (0, None):
+                    raise ValueError("the heading of joint %r needs a skeleton (only the root joint, 0, does not)" % (c["joint"],))
+                k.joint = 0 if skeleton is None else skeleton.index(c.get("joint", 0) or 0)
+                k.target[0] = float(int(c["axis"]))
+                rd = c.get("ref_dir", (0.0, 0.0, 1.0))
+                for a in range(3):
+                    k.ref_dir[a] = float(rd[a])
             elif c["type"] == "direction":
                 k.type = MG_CONSTRAINT_DIRECTION_2D
                 k.target[0], k.target[1], k.target[2] = float(c["target"][0]), float(c["target"][1]), 0.0
@@ -902,6 +916,22 @@ class Primitive(object):
                                                            _dtype_code(S), S.shape[0], S.shape[1],
                                                            out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def score_constraint_residuals_chained(self, cset, S, align_cand):
+        """The same matrix with every sample aligned to ITS OWN previous motion: align_cand (n, 4) = previous unit heading
+        (x, z) and previous root position (x, z) per sample (mg_score_constraint_residuals_chained)."""
+        S = _latents(S)
+        A = np.ascontiguousarray(align_cand, dtype=np.float64)
+        assert A.shape == (S.shape[0], 4)
+        ctx = self.ctx
+        d_S, d_A, d_R = ctx.upload(S), ctx.upload(A), ctx.malloc(max(S.shape[0] * cset.n, 1) * 8)
+        try:
+            _check(self.lib.mg_score_constraint_residuals_chained(self.handle, cset.handle, d_S.ptr, _dtype_code(S), S.shape[0], S.shape[1],
+                                                                  d_A.ptr, d_R.ptr))
+            return ctx.download(d_R, (S.shape[0], cset.n), np.float64)
+        finally:
+            for b in (d_S, d_A, d_R):
+                b.free()
 
     def gmm_log_prob_jac(self, X):
         """(n_samples, n_components) float64: the reference's log_likelihood_jac (= -grad log p) per row."""

@@ -104,6 +104,97 @@ class HipLeastSquares(object):
         return result[0]
 
 
+class HipNumericalMinimizer(object):
+    """NumericalMinimizer.run (reference optimization/numerical_minimizer.py:41-76): scipy.optimize.minimize on a scalar
+    objective with the settings' method / tolerance / max_iterations / diff_eps.  Where the reference passes jac=None scipy
+    differentiates the objective itself -- len(s) + 1 sequential objective calls per gradient, forward differences with the
+    absolute step `eps`; here that same gradient ((f(s + eps e_i) - f(s)) / eps, scipy's '2-point' rule with abs_step = eps) is
+    computed from ONE batched launch of the objective over the len(s) + 1 points, so the iterates are scipy's.  A Jacobian set
+    with set_jacobian (step_goal_jac, obj_spatial_error_sum_and_naturalness_jac) is used as the reference uses it."""
+
+    def __init__(self, optimization_settings, objective=None, jacobian=None):
+        self.optimization_settings = optimization_settings
+        self.verbose = optimization_settings.get("verbose", False)
+        self._objective_function = objective
+        self._jacobian = jacobian
+        self._error_func_params = None
+        self.n_launches = 0
+
+    def set_objective_function(self, obj):
+        self._objective_function = obj
+
+    def set_objective_function_parameters(self, data):
+        self._error_func_params = data
+
+    def set_jacobian(self, jac):
+        self._jacobian = jac
+
+    def _fun(self, s, data):
+        self.n_launches += 1
+        return float(self._objective_function(np.asarray(s, dtype=np.float64), data))
+
+    def _batched_forward_differences(self, s, data):
+        s = np.asarray(s, dtype=np.float64)
+        eps = float(self.optimization_settings.get("diff_eps", 1e-8) or 1e-8)
+        L = s.shape[0]
+        pts = np.repeat(s[None, :], L + 1, axis=0)
+        pts[np.arange(1, L + 1), np.arange(L)] += eps
+        self.n_launches += 1
+        f = np.asarray(self._objective_function(pts, data), dtype=np.float64)       # (L + 1,) in one launch
+        return (f[1:] - f[0]) / eps
+
+    def run(self, initial_guess):
+        if self._objective_function is None or initial_guess is None:
+            return initial_guess
+        from scipy.optimize import minimize
+        st = self.optimization_settings
+        jac = self._jacobian if self._jacobian is not None else self._batched_forward_differences
+        derivative_free = str(st["method"]).lower() in ("nelder-mead", "powell", "cobyla")
+        try:
+            result = minimize(self._fun, np.asarray(initial_guess, dtype=np.float64), args=(self._error_func_params,), method=st["method"],
+                              jac=None if derivative_free else (lambda s, data: np.asarray(jac(s, data), dtype=np.float64)),
+                              tol=st.get("tolerance"), options={"maxiter": st["max_iterations"], "disp": bool(self.verbose)})
+        except ValueError as e:              # the reference swallows it and returns the initial guess (numerical_minimizer.py:67-69)
+            if self.verbose:
+                print("Warning:", e.args)
+            return initial_guess
+        return result.x
+
+
+class HipOptimizerBuilder(object):
+    """OptimizerBuilder (reference optimization/optimizer_builder.py:36-88) over the batched objectives."""
+
+    def __init__(self, algorithm_settings):
+        self.algorithm_settings = algorithm_settings
+
+    def build_spatial_and_naturalness_error_minimizer(self):
+        st = self.algorithm_settings["local_optimization_settings"]
+        if st.get("method", "leastsq") == "leastsq":
+            return HipLeastSquares(st, of.obj_spatial_error_residual_vector_and_naturalness)
+        return HipNumericalMinimizer(st, of.obj_spatial_error_sum_and_naturalness)
+
+    def build_spatial_error_minimizer(self):
+        st = self.algorithm_settings["local_optimization_settings"]
+        if st.get("method", "leastsq") == "leastsq":
+            return HipLeastSquares(st, of.obj_spatial_error_residual_vector)
+        return HipNumericalMinimizer(st, of.obj_spatial_error_sum)
+
+    def build_path_following_minimizer(self):
+        return HipNumericalMinimizer(self.algorithm_settings["local_optimization_settings"], of.step_goal_error, of.step_goal_jac)
+
+    def build_path_following_with_likelihood_minimizer(self):
+        return HipNumericalMinimizer(self.algorithm_settings["local_optimization_settings"], of.step_goal_and_naturalness, of.step_goal_and_naturalness_jac)
+
+    def build_time_error_minimizer(self):
+        return HipNumericalMinimizer(self.algorithm_settings["global_time_optimization_settings"], of.obj_time_error_sum)
+
+    def build_global_error_minimizer(self):
+        return HipNumericalMinimizer(self.algorithm_settings["global_spatial_optimization_settings"], of.obj_global_error_sum)
+
+    def build_global_error_minimizer_residual(self):
+        return HipLeastSquares(self.algorithm_settings["global_spatial_optimization_settings"], of.obj_global_residual_vector_and_naturalness)
+
+
 class HipMotionPrimitiveGenerator(object):
     """nodes: {(action_name, primitive_name): HipMotionStateGraphNode-like}; algorithm_config: the reference's
     dict (motion_generator/algorithm_configuration.py:30-110)."""
@@ -113,7 +204,7 @@ class HipMotionPrimitiveGenerator(object):
         self.action_name = action_name
         self.prev_action_name = prev_action_name
         self.set_algorithm_config(algorithm_config)
-        self.numerical_minimizer = HipLeastSquares(self._settings)
+        self.numerical_minimizer = HipOptimizerBuilder(algorithm_config).build_spatial_and_naturalness_error_minimizer()
         self.objective = of.obj_spatial_error_sum
 
     def set_algorithm_config(self, algorithm_config):
@@ -132,8 +223,6 @@ class HipMotionPrimitiveGenerator(object):
         self.communicator = algorithm_config.get("communicator", getattr(self, "communicator", None))
         self.gpu_sampling = bool(algorithm_config.get("gpu_sampling", False))
         self.gpu_sampling_seed = int(algorithm_config.get("gpu_sampling_seed", 0))
-        if self._settings.get("method", "leastsq") != "leastsq":
-            raise NotImplementedError("only the leastsq local optimizer is batched")
 
     # ---- motion_primitive_generator.py:78-124 ---------------------------------------------------------
     def generate_constrained_motion_spline(self, mp_constraints, prev_graph_walk=None):

@@ -159,3 +159,270 @@ def obj_spatial_error_residual_vector_and_naturalness(s, data):
     _note(mp_constraints, float(res[-1].sum()) if len(res) else 0.0, len(S))
     out = _pad(res * error_scale + nll[:, None], S.shape[1]) / init_error_sum
     return out[0] if single else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Graph-walk (global) objectives: reference optimization/objective_functions.py:290-380, driven by
+# motion_generator/graph_walk_optimizer.py:78-105.  `s` concatenates the spatial latents of the walk's steps; per step the
+# reference back-projects, evaluates the step's constraints against the PREVIOUS step's aligned frames and aligns this step's
+# motion for the next one -- a chain.  Batched: S (n, sum L_i); a candidate's chain is its own (its step i is aligned to ITS
+# step i - 1), so per step ONE launch scores all n candidates with a per-candidate alignment record
+# (mg_score_constraint_residuals_chained) and returns, beside the residuals, the four numbers of the aligned motion's last
+# frame the next step is aligned to (MG_CONSTRAINT_VALUE_*): the chain never leaves the device arithmetic, the host only
+# slices.  Alignment itself is PARITY UNPINNED (anim_utils absent), as for the per-primitive objectives.
+# ---------------------------------------------------------------------------------------------------------------------
+def _aligning_node(motion_primitive_graph):
+    sk = getattr(motion_primitive_graph, "skeleton", None)
+    node = getattr(sk, "aligning_root_node", None)
+    ref_dir = tuple(float(v) for v in getattr(sk, "aligning_root_dir", (0.0, 0.0, 1.0)))
+    if node is not None and node == getattr(sk, "root", None):
+        node = None
+    return node, ref_dir
+
+
+def _global_blocks(s, motion_primitive_graph, graph_walk_steps, prev_frames, exit_from="frames"):
+    """Per step the (n, n_residuals_i) matrix of a batch of concatenated latent vectors, every candidate's steps chained.
+    exit_from: "frames" -- the next step is aligned to the last FRAME of this step's aligned motion (obj_global_error_sum,
+    obj_global_residual_vector: get_motion_vector()[-1], canonical time F); "coeffs" -- to its last CONTROL POINT
+    (obj_global_residual_vector_and_naturalness hands `.coeffs` on, objective_functions.py:373: the spline at its last knot)."""
+    S, single = _batch(s)
+    S = np.asarray(S, dtype=np.float64)
+    n = len(S)
+    hip_sk = getattr(motion_primitive_graph, "hip_skeleton", None)
+    node_name, ref_dir = _aligning_node(motion_primitive_graph)
+    if node_name is not None and hip_sk is None:
+        raise NotImplementedError("aligning node %r is not the root joint: the graph needs a _capi.Skeleton as .hip_skeleton" % (node_name,))
+    joint = 0 if node_name is None else node_name
+    state, offset, blocks = None, 0, []
+    for step in graph_walk_steps:
+        node = motion_primitive_graph.nodes[step.node_key]
+        prim = _prim_of(node)
+        Li = int(step.n_spatial_components)
+        alpha = np.ascontiguousarray(S[:, offset:offset + Li])
+        offset += Li
+        cons = step.motion_primitive_constraints
+        keyframes, trajectories = split_trajectories(constraints_to_device_form(_constraint_list(cons)))
+        if trajectories:
+            raise NotImplementedError("trajectory constraints inside a chained graph-walk objective")
+        sk = getattr(cons, "hip_skeleton", None) or hip_sk
+        F = float(prim.n_canonical_frames)
+        t_exit = F if exit_from == "frames" else F - 1.0
+        exits = [{"type": "value_heading", "t": t_exit, "weight": 1.0, "axis": 0, "joint": joint, "ref_dir": ref_dir},
+                 {"type": "value_heading", "t": t_exit, "weight": 1.0, "axis": 2, "joint": joint, "ref_dir": ref_dir},
+                 {"type": "value_position", "t": t_exit, "weight": 1.0, "axis": 0},
+                 {"type": "value_position", "t": t_exit, "weight": 1.0, "axis": 2}]
+        local = bool(getattr(cons, "is_local", False))
+        if state is None:
+            # first step: the walk's previous frames (or start pose, or nothing) -- the same record for every candidate
+            al_motion = alignment_from_prev_frames(prev_frames, type("_NotLocal", (), {"start_pose": getattr(cons, "start_pose", None), "is_local": False,
+                                                                                      "skeleton": getattr(cons, "skeleton", getattr(motion_primitive_graph, "skeleton", None))})(), sk)
+            al_cons = None if local else al_motion
+            if al_cons is al_motion:
+                res = prim.score_constraint_residuals(cached_constraint_set(prim, keyframes + exits, sk, al_motion), alpha)
+                res_k, new_state = res[:, :len(keyframes)], res[:, len(keyframes):]
+            else:
+                res_k = prim.score_constraint_residuals(cached_constraint_set(prim, keyframes, sk, None), alpha) if keyframes else np.zeros((n, 0))
+                new_state = prim.score_constraint_residuals(cached_constraint_set(prim, exits, sk, al_motion), alpha)
+        else:
+            template = {"joint": joint, "position": (0.0, 0.0, 0.0), "heading": (0.0, 1.0), "ref_dir": ref_dir}
+            if local:
+                res_k = prim.score_constraint_residuals(cached_constraint_set(prim, keyframes, sk, None), alpha) if keyframes else np.zeros((n, 0))
+                new_state = prim.score_constraint_residuals_chained(cached_constraint_set(prim, exits, sk, template), alpha, state)
+            else:
+                res = prim.score_constraint_residuals_chained(cached_constraint_set(prim, keyframes + exits, sk, template), alpha, state)
+                res_k, new_state = res[:, :len(keyframes)], res[:, len(keyframes):]
+        blocks.append(group_residuals(keyframes, res_k) if keyframes else res_k)
+        state = np.ascontiguousarray(new_state)
+        if hasattr(cons, "evaluations"):
+            cons.evaluations += n
+    return S, single, blocks
+
+
+def obj_global_error_sum(s, data):
+    """objective_functions.py:290-316: the sum over the walk's steps of MotionPrimitiveConstraints.evaluate, each step scored
+    against the previous step's aligned frames -> (n,) (float for 1-D s).  (The reference prints the value on every call.)"""
+    motion_primitive_graph, graph_walk_steps, error_scale, quality_scale, prev_frames = data
+    S, single, blocks = _global_blocks(s, motion_primitive_graph, graph_walk_steps, prev_frames, "frames")
+    err = np.zeros(len(S))
+    for b in blocks:
+        err = err + b.sum(axis=1)
+    return float(err[0]) if single else err
+
+
+def obj_global_residual_vector(s, data):
+    """objective_functions.py:319-345: the steps' residual vectors (each zero-padded to its number of variables) side by side,
+    divided by init_error_sum.  NB the reference hands obj_spatial_error_residual_vector a FIVE-element step_data where that
+    function unpacks six (:341 vs :220), so the reference raises ValueError here; this is the evident intent, with the missing
+    per-step init_error_sum = 1 as in the _and_naturalness form (:369)."""
+    motion_primitive_graph, graph_walk_steps, error_scale, quality_scale, prev_frames, init_error_sum = data
+    S, single, blocks = _global_blocks(s, motion_primitive_graph, graph_walk_steps, prev_frames, "frames")
+    cols = [_pad(b, int(step.n_spatial_components)) for b, step in zip(blocks, graph_walk_steps)]
+    out = np.hstack(cols) / init_error_sum
+    return out[0] if single else out
+
+
+def obj_global_residual_vector_and_naturalness(s, data):
+    """objective_functions.py:348-380: per step residual_i * error_scale - log p(concat(alpha, the step's time latents)) *
+    quality_scale, zero-padded to the step's FULL number of latents, side by side, divided by init_error_sum; the next step is
+    aligned to this step's aligned CONTROL POINTS (the reference passes `.coeffs` on as frames, :362,:373)."""
+    motion_primitive_graph, graph_walk_steps, error_scale, quality_scale, prev_frames, init_error_sum = data
+    S, single, blocks = _global_blocks(s, motion_primitive_graph, graph_walk_steps, prev_frames, "coeffs")
+    cols, offset = [], 0
+    for b, step in zip(blocks, graph_walk_steps):
+        Li = int(step.n_spatial_components)
+        node = motion_primitive_graph.nodes[step.node_key]
+        prim = _prim_of(node)
+        tail = np.asarray(step.parameters, dtype=np.float64)[Li:]
+        concat = np.hstack([S[:, offset:offset + Li], np.tile(tail, (len(S), 1))]) if len(tail) else S[:, offset:offset + Li]
+        offset += Li
+        nll = -prim.gmm_log_prob(np.ascontiguousarray(concat, dtype=np.float64)) * quality_scale
+        cols.append(_pad(b * error_scale + nll[:, None], concat.shape[1]))
+    out = np.hstack(cols) / init_error_sum
+    return out[0] if single else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Time constraints (reference constraints/time_constraints.py:25-110, objective optimization/objective_functions.py:270-287)
+# ---------------------------------------------------------------------------------------------------------------------
+class HipTimeConstraints(object):
+    """TimeConstraints for batches: `s` concatenates the TIME latents of the steps start_step .. end_step; per step the
+    canonical time functions of all candidates come from one launch (mg_time_function_canonical), their inversion runs on the
+    host with scipy as in the reference, the naturalness term is one mixture launch per step."""
+
+    def __init__(self, motion_primitive_graph, graph_walk, start_step, end_step, constraint_list):
+        self.start_step, self.end_step, self.constraint_list = start_step, end_step, constraint_list
+        self.start_keyframe = self._get_start_frame(motion_primitive_graph, graph_walk, start_step)
+
+    def _get_start_frame(self, graph, graph_walk, start_step):
+        start_keyframe = 0
+        for i in range(0, max(start_step, 0)):
+            tf = graph.nodes[graph_walk.steps[i].node_key].back_project_time_function(graph_walk.steps[i].parameters)
+            start_keyframe += tf[-1]
+        return start_keyframe
+
+    def _time_functions(self, S, graph, graph_walk):
+        """[step][candidate] -> time function t'(t) (1-D array)"""
+        out, offset = [], 0
+        for step in graph_walk.steps[self.start_step:self.end_step]:
+            nt = int(step.n_time_components)
+            base = np.asarray(step.parameters, dtype=np.float64)
+            vecs = np.tile(base, (len(S), 1))
+            vecs[:, int(step.n_spatial_components):] = S[:, offset:offset + nt]
+            offset += nt
+            node = graph.nodes[step.node_key]
+            # the wrapper's back_project_time_function (motion_primitive_wrapper.py:233-249, legacy branch) for every candidate:
+            # one launch where the node offers the batched form
+            out.append(node.back_project_time_functions(vecs) if hasattr(node, "back_project_time_functions")
+                       else [node.back_project_time_function(v) for v in vecs])
+        return out
+
+    def evaluate_graph_walk(self, s, graph, graph_walk):
+        """time_constraints.py:40-50,68-91 for every candidate -> (n,)"""
+        S, single = _batch(s)
+        S = np.asarray(S, dtype=np.float64)
+        tfs = self._time_functions(S, graph, graph_walk)
+        frame_time = graph.skeleton.frame_time
+        err = np.zeros(len(S))
+        for b in range(len(S)):
+            for step_index, keyframe_index, desired_time in self.constraint_list:
+                n_frames, e = self.start_keyframe, 10000.0        # (the reference's value when the constrained step is beyond the walk)
+                for k, per_step in enumerate(tfs):
+                    tf = per_step[b]
+                    if k < step_index:
+                        n_frames += tf[-1]
+                    else:
+                        if keyframe_index >= len(tf):
+                            e = 0.0
+                        else:
+                            n_frames += int(tf[keyframe_index]) + 1
+                            e = (desired_time - n_frames * frame_time) ** 2
+                        break
+                err[b] += e
+        return float(err[0]) if single else err
+
+    def get_average_loglikelihood(self, s, graph, graph_walk):
+        """time_constraints.py:93-102 for every candidate -> (n,)"""
+        S, single = _batch(s)
+        S = np.asarray(S, dtype=np.float64)
+        total, count, offset = np.zeros(len(S)), 0, 0
+        for step in graph_walk.steps[self.start_step:self.end_step]:
+            nt, ns = int(step.n_time_components), int(step.n_spatial_components)
+            X = np.hstack([np.tile(np.asarray(step.parameters, dtype=np.float64)[:ns], (len(S), 1)), S[:, offset:offset + nt]])
+            offset += nt
+            total += _prim_of(graph.nodes[step.node_key]).gmm_log_prob(np.ascontiguousarray(X))
+            count += 1
+        out = total / max(count, 1)
+        return float(out[0]) if single else out
+
+    def get_initial_guess(self, graph_walk):
+        parameters = []
+        for step in graph_walk.steps[self.start_step:self.end_step]:
+            parameters += np.asarray(step.parameters)[int(step.n_spatial_components):].tolist()
+        return parameters
+
+
+def obj_time_error_sum(s, data):
+    """objective_functions.py:270-287: error_scale * time_error + quality_scale * (-average log-likelihood) -> (n,)"""
+    motion_primitive_graph, graph_walk, time_constraints, error_scale, quality_scale = data
+    time_error = time_constraints.evaluate_graph_walk(s, motion_primitive_graph, graph_walk)
+    nll = -np.asarray(time_constraints.get_average_loglikelihood(s, motion_primitive_graph, graph_walk))
+    out = error_scale * np.asarray(time_error) + nll * quality_scale
+    return float(out) if np.ndim(out) == 0 else out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Step goals (reference optimization/objective_functions.py:59-140).  The reference reads the LAST control point's root position
+# straight from the projection (`sfpca.project(s)[idx:idx+3]`, idx = (n_coeffs - 1) * n_dims) of an MGRD model; here the same
+# three numbers are rows of E' and mean' of the legacy primitive: pos = E_last . s + mean_last, y dropped.
+# ---------------------------------------------------------------------------------------------------------------------
+def _last_control_point_rows(motion_primitive):
+    mp = motion_primitive.motion_primitive if hasattr(motion_primitive, "motion_primitive") else motion_primitive
+    sp = mp.s_pca
+    NB, D = int(sp["n_basis"]), int(sp["n_dim"])
+    E = np.asarray(sp["eigen_vectors"], dtype=np.float64)            # (NB * D, L) as loaded (motion_primitive.py:156)
+    mean = np.asarray(sp["mean_vector"], dtype=np.float64)
+    scale = np.asarray(getattr(mp, "translation_maxima", (1.0, 1.0, 1.0)), dtype=np.float64)
+    idx = (NB - 1) * D
+    return E[idx:idx + 3] * scale[:, None], mean[idx:idx + 3] * scale
+
+
+def _step_goal(s, data):
+    motion_primitive, mp_constraints = data[0], data[1]
+    target = np.asarray(_constraint_list(mp_constraints)[0].position, dtype=np.float64)
+    S, single = _batch(s)
+    S = np.asarray(S, dtype=np.float64)
+    E3, m3 = _last_control_point_rows(motion_primitive)
+    n_spatial = E3.shape[1]
+    pos = S[:, :n_spatial] @ E3.T + m3
+    pos[:, 1] = 0.0
+    delta = target[None, :] - pos
+    return S, single, E3, delta, n_spatial
+
+
+def step_goal_error(s, data):
+    """objective_functions.py:59-71 -> (n,)"""
+    S, single, E3, delta, _ = _step_goal(s, data)
+    err = np.einsum("ij,ij->i", delta, delta)
+    return float(err[0]) if single else err
+
+
+def step_goal_jac(s, data):
+    """objective_functions.py:73-90 -> (n, len(s)): 2 * E_last^T (pos - target) on the spatial latents, zeros elsewhere"""
+    S, single, E3, delta, n_spatial = _step_goal(s, data)
+    jac = np.zeros_like(S)
+    jac[:, :n_spatial] = 2.0 * (-delta) @ E3
+    return jac[0] if single else jac
+
+
+def step_goal_and_naturalness(s, data):
+    """objective_functions.py:94-107: step_goal_error - log p(s)"""
+    S, single, E3, delta, _ = _step_goal(s, data)
+    err = np.einsum("ij,ij->i", delta, delta) - _prim_of(data[0]).gmm_log_prob(np.ascontiguousarray(S))
+    return float(err[0]) if single else err
+
+
+def step_goal_and_naturalness_jac(s, data):
+    """objective_functions.py:122-140: step_goal_jac - log_likelihood_jac"""
+    S, single = _batch(s)
+    jac = np.atleast_2d(step_goal_jac(S, data)) - np.atleast_2d(log_likelihood_jac(S, data[0]))
+    return jac[0] if single else jac

@@ -734,3 +734,33 @@ class OraclePrimitive(object):
                     err += c["weight"] * direction_2d_error(c["target"], frame[3:7], c.get("ref_dir", (0, 0, 1)))
             out[b] = err
         return out
+
+
+# --------------------------------------------------------------------------
+# graph-walk (global) objectives: optimization/objective_functions.py:290-380 restated for ONE concatenated latent vector
+# --------------------------------------------------------------------------
+def graph_walk_residual_blocks(primitives, alphas, constraints_per_step, prev_frame, joints, animated_joints, align_joint,
+                               ref_dir=(0.0, 0.0, 1.0), exit_from="frames", local_steps=()):
+    """Per step the weighted residuals of its constraints, the steps chained as obj_global_error_sum /
+    obj_global_residual_vector[_and_naturalness] chain them: back-project the step's latents, evaluate its constraints on
+    the motion aligned to the PREVIOUS step's aligned motion (unaligned for steps in `local_steps`: is_local constraints,
+    motion_primitive_constraints.py:111), then align this step's motion for the next one (always).  `prev_frame`: the last
+    frame before the walk, or None (the first step stays as it is).  exit_from "frames": the next step is aligned to the
+    last sample of the aligned get_motion_vector() (canonical time F); "coeffs": to the last aligned control point (the
+    _and_naturalness form passes `.coeffs` on as if they were frames, :362,:373).  Alignment as align_coeffs_to_previous_frame
+    restates it (PARITY UNPINNED: anim_utils)."""
+    blocks, prev = [], None if prev_frame is None else np.asarray(prev_frame, dtype=np.float64)
+    for i, (prim, alpha, cons) in enumerate(zip(primitives, alphas, constraints_per_step)):
+        coeffs = prim.back_project_spatial_coeffs(np.asarray(alpha, dtype=np.float64))
+        aligned = coeffs if prev is None else align_coeffs_to_previous_frame(coeffs, prev, joints, animated_joints, align_joint, ref_dir)
+        scored = coeffs if i in local_steps else aligned
+        res = np.zeros(len(cons))
+        for ci, c in enumerate(cons):
+            frame = spline_frames(prim.knots, scored, [c["t"]])[0]
+            res[ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
+        blocks.append(res)
+        if exit_from == "frames":
+            prev = spline_frames(prim.knots, aligned, [float(prim.n_canonical_frames)])[0]
+        else:
+            prev = np.array(aligned[-1], dtype=np.float64)
+    return blocks
