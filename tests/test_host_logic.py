@@ -326,3 +326,16 @@ def test_graph_zip_reader_follows_format_version_and_the_references_stats_path(t
     with zipfile.ZipFile(path, "a") as z:
         z.writestr("elementary_action_run/run_fast_quaternion_mm.json", json.dumps(prim))
     assert sorted(model_io.read_graph_zip(path)["subgraphs"]) == ["walk"]
+
+
+def test_integration_md_names_every_entry_point_of_the_header():
+    """INTEGRATION.md section 1 maps EVERY function include/mg_hip.h declares to the reference lines it replaces (the *_host
+    convenience variants go with their device-pointer forms)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "mg_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) > 70
+    missing = [n for n in names if n not in doc and not n.endswith("_host")]
+    assert missing == [], missing
