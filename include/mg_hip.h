@@ -377,6 +377,12 @@ int mg_score_trajectory(mg_primitive *prim, const mg_trajectory *trajectory, con
                         int latent_dtype, int64_t n_samples, int64_t ld, double min_u, double weight, const mg_alignment_desc *alignment,
                         double *errors_dev, int accumulate, double *residuals_dev);
 
+/* The same search for positions the caller supplies: points_dev (n_samples, n_times, 3) float64 -- one joint's track from
+ * mg_back_project_frames_f64 + mg_joint_positions, aligned by the caller -- for TrajectoryConstraint on joints other than the
+ * root (trajectory_constraint.py:95-121 over skeleton.nodes[joint].get_global_position(frame)). */
+int mg_score_trajectory_points(mg_primitive *prim, const mg_trajectory *trajectory, const double *points_dev, int64_t n_samples, int32_t n_times,
+                               double min_u, double weight, double *errors_dev, int accumulate, double *residuals_dev);
+
 /* ---- hot path, device pointers ------------------------------------------------------ */
 
 /* MotionPrimitive.back_project(s, False).get_motion_vector() for a batch

@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host",
-    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_joint_positions",
+    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_score_trajectory_points", "mg_joint_positions",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
@@ -223,6 +223,7 @@ def load_library(path=None):
         "mg_trajectory_create": [vp, vp, i32, i32, C.POINTER(vp)],
         "mg_joint_positions": [vp, vp, vp, i32, vp, i64, i32, vp],
         "mg_score_trajectory": [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, i32, vp],
+        "mg_score_trajectory_points": [vp, vp, vp, i64, i32, dbl, dbl, vp, i32, vp],
         "mg_time_function_canonical_host": [vp, vp, i32, i64, i64, vp],
         "mg_primitive_get_precisions_cholesky": [vp, vp],
         "mg_time_grid_create": [vp, vp, C.c_int32, C.POINTER(vp)],
@@ -811,6 +812,44 @@ class Primitive(object):
             return (err, self.ctx.download(d_r, (n, T), np.float64)) if residuals else err
         finally:
             for b in (d_S, d_e, d_r):
+                if b is not None:
+                    b.free()
+
+    def joint_tracks(self, skeleton, joints, S, grid=None):
+        """(B, T, len(joints), 3) float64: the global positions of `joints` in every frame of every sample's motion -- float64
+        back projection (mg_back_project_frames_f64) and forward kinematics (mg_joint_positions) on the device, only the
+        tracks come back.  What the per-frame constraints of the reference walk a motion for (trajectory constraints on other
+        joints than the root, collision avoidance, local and discrete trajectories)."""
+        S = _latents(S)
+        n, T = S.shape[0], self._grid_size(grid)
+        idx = np.ascontiguousarray([skeleton.index(j) for j in joints], dtype=np.int32)
+        ctx = self.ctx
+        d_S = ctx.upload(S)
+        d_f = ctx.malloc(max(n * T * self.n_dim, 1) * 8)
+        d_o = ctx.malloc(max(n * T * len(idx) * 3, 1) * 8)
+        try:
+            _check(self.lib.mg_back_project_frames_f64(self.handle, self._grid_handle(grid), d_S.ptr, _dtype_code(S), n, S.shape[1], d_f.ptr))
+            d = skeleton.desc()
+            _check(self.lib.mg_joint_positions(ctx.handle, C.byref(d), idx.ctypes.data_as(C.c_void_p), len(idx), d_f.ptr, n * T, self.n_dim, d_o.ptr))
+            return ctx.download(d_o, (n, T, len(idx), 3), np.float64)
+        finally:
+            for b in (d_S, d_f, d_o):
+                b.free()
+
+    def score_trajectory_points(self, trajectory, points, min_u=0.0, weight=1.0, residuals=False):
+        """mg_score_trajectory_points: points (n, T, 3) float64 followed along the trajectory instead of the root path."""
+        P = np.ascontiguousarray(points, dtype=np.float64)
+        n, T = P.shape[0], P.shape[1]
+        ctx = self.ctx
+        d_p, d_e = ctx.upload(P), ctx.malloc(max(n, 1) * 8)
+        d_r = ctx.malloc(max(n * T, 1) * 8) if residuals else None
+        try:
+            _check(self.lib.mg_score_trajectory_points(self.handle, trajectory.handle, d_p.ptr, n, T, float(min_u), float(weight), d_e.ptr, 0,
+                                                       d_r.ptr if d_r is not None else None))
+            err = ctx.download(d_e, (n,), np.float64)
+            return (err, ctx.download(d_r, (n, T), np.float64)) if residuals else err
+        finally:
+            for b in (d_p, d_e, d_r):
                 if b is not None:
                     b.free()
 

@@ -41,8 +41,38 @@ def constraints_to_device_form(constraints, root_joint=None):
             out.append(c)
             group += 1
             continue
+        if hasattr(c, "joint_trajectories") and hasattr(c, "joint_names"):            # TrajectorySetConstraint
+            out.append({"type": "frame_trajectory_set", "joints": list(c.joint_names), "weight": float(getattr(c, "weight_factor", 1.0)),
+                        "trajectories": [dict(_spline_control_points(t), range_start=getattr(t, "range_start", None), range_end=getattr(t, "range_end", None))
+                                         for t in c.joint_trajectories],
+                        "arc_lengths": [float(v) for v in c.joint_arc_lengths], "n_frames": int(c.n_canonical_frames), "group": group})
+            group += 1
+            continue
+        if hasattr(c, "point_list") and hasattr(c, "unconstrained_indices"):           # DiscreteTrajectoryConstraint
+            out.append({"type": "frame_discrete_trajectory", "joint": c.joint_name, "points": [[float(v) for v in p] for p in c.point_list],
+                        # target[None] = 0 zeroes the whole point (discrete_trajectory_constraint.py:81-82): no indices = no axis constrained
+                        "unconstrained": [0, 1, 2] if c.unconstrained_indices is None else [int(i) for i in c.unconstrained_indices],
+                        "weight": float(getattr(c, "weight_factor", 1.0)), "group": group})
+            group += 1
+            continue
         if getattr(c, "constraint_type", None) == "trajectory" or (hasattr(c, "min_arc_length") and hasattr(c, "full_arc_length")):
             out.append(trajectory_to_device_form(c, root_joint, group))
+            group += 1
+            continue
+        if getattr(c, "constraint_type", None) == "local_trajectory":                  # LocalTrajectoryConstraint
+            out.append(dict(_spline_control_points(c.trajectory), type="frame_local_trajectory", joint=c.joint_name, start_t=float(c.start_t),
+                            n_frames=int(c.n_canonical_frames), weight=float(getattr(c, "weight_factor", 1.0)), group=group))
+            group += 1
+            continue
+        if hasattr(c, "rotation_constraint") and hasattr(c, "frame_idx"):              # JointRotationConstraint
+            names = list(c.skeleton.node_name_frame_map.keys())
+            out.append({"type": "frame_joint_rotation", "joint_index": names.index(c.joint_name), "quaternion": _rotation_constraint_quaternion(c),
+                        "frame_idx": float(c.frame_idx), "weight": float(getattr(c, "weight_factor", 1.0)), "group": group})
+            group += 1
+            continue
+        if getattr(c, "constraint_type", None) == "ca_constraint":                      # GlobalTransformCAConstraint
+            out.append({"type": "frame_ca_position", "joint": c.joint_name, "target": [None if v is None else float(v) for v in c.position],
+                        "n_frames": int(c.n_canonical_frames), "weight": float(getattr(c, "weight_factor", 1.0)), "group": group})
             group += 1
             continue
         t = float(c.canonical_keyframe)
@@ -104,16 +134,50 @@ def constraints_to_device_form(constraints, root_joint=None):
     return out
 
 
+def _spline_control_points(spline_owner):
+    """{"control_points", "granularity"} of a reference ParameterizedSpline / TrajectoryConstraint (the padding of
+    catmull_rom_spline.py:66-71 undone)"""
+    spline = getattr(spline_owner, "spline", None)
+    padded = getattr(spline, "control_points", None)
+    if padded is None or not hasattr(spline, "_catmullrom_basematrix"):
+        raise NotImplementedError("trajectory without a Catmull-Rom spline")
+    return {"control_points": [list(map(float, p)) for p in padded[1:-2]], "granularity": int(getattr(spline_owner, "granularity", 1000))}
+
+
+def _rotation_constraint_quaternion(c):
+    """The wanted local rotation of a JointRotationConstraint as a unit quaternion (w, x, y, z): given as one, or as Euler angles in
+    degrees, axes 'rxyz' (joint_rotation_constraint.py:41-52: rotations about the joint's own x, then y, then z)."""
+    if c.rotation_type == "quaternion":
+        q = np.asarray(c.rotation_constraint, dtype=np.float64)
+        return (q / np.linalg.norm(q)).tolist()
+    if c.rotation_type != "euler":
+        raise ValueError("Unknown rotation type!")
+    ax, ay, az = (np.deg2rad(float(v)) for v in c.rotation_constraint)
+
+    def about(axis, angle):
+        q = np.zeros(4)
+        q[0], q[1 + axis] = np.cos(0.5 * angle), np.sin(0.5 * angle)
+        return q
+
+    def mul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+    return mul(mul(about(0, ax), about(1, ay)), about(2, az)).tolist()       # rotating axes: R = Rx Ry Rz
+
+
 def trajectory_to_device_form(c, root_joint=None, group=None):
     """A reference TrajectoryConstraint (trajectory_constraint.py:33-52: an AnnotatedSpline over control points with
-    min_arc_length / full_arc_length, a joint and a weight) as the dict the device path takes.  Root joint and Catmull-Rom
-    splines only; collision-avoidance trajectories are scored differently in the reference and are not covered."""
-    if getattr(c, "is_collision_avoidance_constraint", False):
-        raise NotImplementedError("collision-avoidance trajectory constraints are not covered by the GPU scorer")
+    min_arc_length / full_arc_length, a joint and a weight) as the dict the device path takes.  Catmull-Rom splines only.  The root
+    joint's path is scored inside the fused kernels ("trajectory"); any other joint's -- a collision-avoidance trajectory is one of
+    those, the reference's optimiser evaluates it with the same method (graph_walk_optimizer.py:168-176) -- from the joint's
+    forward-kinematics track ("frame_joint_trajectory")."""
     root = root_joint if root_joint is not None else getattr(getattr(c, "skeleton", None), "root", None)
     joint = getattr(c, "joint_name", root)
     if root is not None and joint is not None and joint != root:
-        raise NotImplementedError("trajectory constraint on joint %r: only the root joint's path is scored on the device" % (joint,))
+        # another joint's path: forward kinematics over every frame (frame_constraints.py), the same search over its track
+        full = float(c.full_arc_length)
+        return dict(_spline_control_points(c), type="frame_joint_trajectory", joint=joint, min_u=float(c.min_arc_length) / full if full > 0.0 else 0.0,
+                    weight=float(getattr(c, "weight_factor", 1.0)), group=group)
     spline = getattr(c, "spline", None)
     padded = getattr(spline, "control_points", None)
     if padded is None or not hasattr(spline, "_catmullrom_basematrix"):
@@ -299,8 +363,12 @@ class HipSampleFilter(object):
     def score_samples(motion_primitive, samples, constraints, dtype=np.float64, skeleton=None, prev_frames=None):
         prim = motion_primitive._prim if hasattr(motion_primitive, "_prim") else motion_primitive
         clist = constraints.constraints if hasattr(constraints, "constraints") else constraints
-        keyframes, trajectories = split_trajectories(constraints_to_device_form(clist))
+        device_form = constraints_to_device_form(clist)
         alignment = alignment_from_prev_frames(prev_frames, constraints, skeleton)
+        from .frame_constraints import is_frame_constraint
+        if any(is_frame_constraint(c) for c in device_form):
+            return errors_of_samples(prim, device_form, skeleton, alignment, samples).astype(dtype)
+        keyframes, trajectories = split_trajectories(device_form)
         if trajectories:
             S = _capi._latents(samples)
             d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(max(len(S), 1) * 8)
@@ -322,13 +390,42 @@ def _prim_of(mp_node):
     return prim_obj, prim_obj._prim
 
 
+def errors_of_samples(prim, device_form, skeleton, alignment, samples):
+    """(n,) float64: the sum of ALL constraints' weighted errors for host-resident candidates -- keyframe and root-trajectory
+    constraints by the fused scorers, per-frame constraints (frame_constraints.py) from the device's frame and joint tracks."""
+    from .frame_constraints import split_frame_constraints, frame_constraints_errors
+    fused, frames = split_frame_constraints(device_form)
+    keyframes, trajectories = split_trajectories(fused)
+    S = _capi._latents(samples)
+    total = np.zeros(len(S))
+    if len(S) == 0:
+        return total
+    if trajectories:
+        d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(max(len(S), 1) * 8)
+        try:
+            _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_S, S.dtype, len(S), S.shape[1], d_e)
+            total = total + prim.ctx.download(d_e, (len(S),), np.float64)
+        finally:
+            d_S.free()
+            d_e.free()
+    elif keyframes:
+        total = total + prim.score_constraints(cached_constraint_set(prim, keyframes, skeleton, alignment), S, dtype=np.float64)
+    if frames:
+        total = total + frame_constraints_errors(prim, S, frames, skeleton, alignment)[0]
+    return total
+
+
 def first_minimum_of_block(mp_node, device_form, alignment, samples, skeleton=None):
     """(index, error) of the first minimum among `samples` (n, L) for constraints already in device form: what one rank does
     with its block of a sharded evaluate_samples_using_constraints, and the whole of the single-GPU call."""
     prim_obj, prim = _prim_of(mp_node)
-    keyframes, trajectories = split_trajectories(device_form)
+    from .frame_constraints import is_frame_constraint
     if len(samples) == 0:
         return 0, float("inf")
+    if any(is_frame_constraint(c) for c in device_form):       # per-frame constraints: their errors are summed on the host
+        from .distributed import first_min_argmin
+        return first_min_argmin(errors_of_samples(prim, device_form, skeleton, alignment, samples))
+    keyframes, trajectories = split_trajectories(device_form)
     if trajectories:
         S = _capi._latents(samples)
         d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(max(len(S), 1) * 8)
@@ -348,6 +445,7 @@ def sample_rows_and_first_minimum(mp_node, device_form, alignment, counts, seed,
     (0, n) the whole single-GPU step.  Only the winner leaves the GPU."""
     prim_obj, prim = _prim_of(mp_node)
     ctx = prim.ctx
+    from .frame_constraints import is_frame_constraint
     keyframes, trajectories = split_trajectories(device_form)
     L = prim.n_gmm_dims          # the full sample (spatial + time latents); scoring reads its first n_components columns
     m = int(row_end) - int(row_begin)
@@ -355,6 +453,11 @@ def sample_rows_and_first_minimum(mp_node, device_form, alignment, counts, seed,
     d_x = ctx.malloc(max(m, 1) * L * item)
     try:
         prim.gmm_sample_dev(np.asarray(counts, dtype=np.int64), seed, d_x, dtype, L, rows=(int(row_begin), m))
+        if any(is_frame_constraint(c) for c in device_form):   # per-frame constraints read the candidates back (m x L numbers)
+            from .distributed import first_min_argmin
+            X = ctx.download(d_x, (m, L), dtype)
+            best_idx, min_error = first_min_argmin(errors_of_samples(prim, device_form, skeleton, alignment, X))
+            return best_idx, min_error, X[best_idx].astype(np.float64)
         if trajectories:
             d_e = ctx.malloc(max(m, 1) * 8)
             try:

@@ -37,6 +37,8 @@ struct mg_traj_args {
     int32_t T, L, NB, n_seg, G, lat_f64, accumulate, align_mode;   // align_mode 0: none, 1: previous frame (root node), 2: start pose
     double min_u, weight;
     double al[7];   // heading (x, z) or (cos, sin); landing (x, z); ref_dir (3) or height
+    const double *points;   // NULL, or (B, T, 3): the positions to follow the trajectory with, given instead of derived from the
+                            // candidates' root rows (any joint's track from mg_joint_positions; already aligned by the caller)
 };
 
 #define MG_TRAJ_BLOCK 64
@@ -89,13 +91,15 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
     const int64_t bb = valid ? b : a.B - 1;
     const int rows = a.NB * 3 + 4;
     double *ls = lds, *lc = lds + (size_t)a.L * MG_TRAJ_BLOCK;
-    for (int k = 0; k < a.L; k++)
-        ls[k * MG_TRAJ_BLOCK + tid] = a.lat_f64 ? ((const double *)a.lat)[bb * a.ld + k] : (double)((const float *)a.lat)[bb * a.ld + k];
-    for (int r = 0; r < rows; r++) {
-        double acc = a.mean[r];
-        const double *e = a.E + (size_t)r * a.L;
-        for (int k = 0; k < a.L; k++) acc = fma(e[k], ls[k * MG_TRAJ_BLOCK + tid], acc);
-        lc[r * MG_TRAJ_BLOCK + tid] = acc;
+    if (!a.points) {
+        for (int k = 0; k < a.L; k++)
+            ls[k * MG_TRAJ_BLOCK + tid] = a.lat_f64 ? ((const double *)a.lat)[bb * a.ld + k] : (double)((const float *)a.lat)[bb * a.ld + k];
+        for (int r = 0; r < rows; r++) {
+            double acc = a.mean[r];
+            const double *e = a.E + (size_t)r * a.L;
+            for (int k = 0; k < a.L; k++) acc = fma(e[k], ls[k * MG_TRAJ_BLOCK + tid], acc);
+            lc[r * MG_TRAJ_BLOCK + tid] = acc;
+        }
     }
     // the candidate's aligning transform (mg_score.hip's closed form): rotation about y and an xz translation
     double ac = 1.0, as = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
@@ -124,16 +128,21 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
     const double invG = 1.0 / (double)G;
     double min_u = a.min_u, sum = 0.0;
     for (int f = 0; f < a.T; f++) {
-        const int i0 = a.i0[f];
-        const double *w = a.w + 4 * (size_t)f;
         double q[3];
+        if (a.points) {
+            const double *pp = a.points + ((size_t)bb * a.T + f) * 3;
+            q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2];
+        } else {
+            const int i0 = a.i0[f];
+            const double *w = a.w + 4 * (size_t)f;
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            double v = w[0] * lc[((i0 + 0) * 3 + d) * MG_TRAJ_BLOCK + tid];
-            v = fma(w[1], lc[((i0 + 1) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
-            v = fma(w[2], lc[((i0 + 2) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
-            v = fma(w[3], lc[((i0 + 3) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
-            q[d] = v;
+            for (int d = 0; d < 3; d++) {
+                double v = w[0] * lc[((i0 + 0) * 3 + d) * MG_TRAJ_BLOCK + tid];
+                v = fma(w[1], lc[((i0 + 1) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+                v = fma(w[2], lc[((i0 + 2) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+                v = fma(w[3], lc[((i0 + 3) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+                q[d] = v;
+            }
         }
         if (a.align_mode != 0) {
             const double x = q[0], z = q[2];
@@ -274,7 +283,7 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = lat; a.i0 = g->d_i0; a.w = g->d_w; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = ld; a.T = g->T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = dt == MG_F64 ? 1 : 0;
-    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = nullptr;
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
     if (al) {
@@ -298,6 +307,30 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     }
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
     hipLaunchKernelGGL(mg_trajectory_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// The same search for positions the caller supplies: points_dev (B, T, 3) float64 (e.g. one joint's track from mg_joint_positions,
+// aligned by the caller) -- TrajectoryConstraint for joints other than the root (trajectory_constraint.py:95-121 with
+// skeleton.nodes[joint].get_global_position(frame)).
+extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *t, const double *points_dev, int64_t B, int32_t T, double min_u,
+                                          double weight, double *errors_dev, int accumulate, double *residuals_dev) {
+    if (!p || !t || t->prim != p || B < 0 || T < 1 || !(min_u >= 0.0 && min_u <= 1.0) || !std::isfinite(weight)) {
+        mg_set_error("mg_score_trajectory_points: bad arguments");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    if (B == 0) return MG_OK;
+    if (!points_dev || !errors_dev) { mg_set_error("mg_score_trajectory_points: NULL pointer"); return MG_ERR_INVALID_ARGUMENT; }
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    mg_traj_args a;
+    a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = nullptr; a.i0 = nullptr; a.w = nullptr; a.out = errors_dev; a.res = residuals_dev;
+    a.B = B; a.ld = 0; a.T = T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = 1;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = points_dev;
+    a.align_mode = 0;
+    for (double &v : a.al) v = 0.0;
+    const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
+    hipLaunchKernelGGL(mg_trajectory_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), 0, p->ctx->stream, a);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

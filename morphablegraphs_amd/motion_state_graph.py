@@ -8,6 +8,7 @@ import numpy as np
 
 from . import _capi
 from .candidate_scoring import constraints_to_device_form, evaluate_samples_using_constraints
+from .frame_constraints import is_frame_constraint
 from .motion_primitive import HipMotionPrimitive, get_context
 from .motion_primitive_wrapper import HipMotionPrimitiveModelWrapper
 
@@ -300,7 +301,11 @@ class HipPrimitiveSet(object):
             cons = constraints_per_option[name]
             clist = cons.constraints if hasattr(cons, "constraints") else cons
             sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
-            csets.append(cached_constraint_set(prim, constraints_to_device_form(clist), sk, alignment_from_prev_frames(prev_frames, cons, sk)))
+            form = constraints_to_device_form(clist)
+            if any(is_frame_constraint(c) for c in form):
+                raise NotImplementedError("the one-launch planner step scores keyframe constraints only: option %r carries per-frame "
+                                          "constraints, score it with evaluate_samples_using_constraints" % (name,))
+            csets.append(cached_constraint_set(prim, form, sk, alignment_from_prev_frames(prev_frames, cons, sk)))
             plan["counts"][k, :len(pvals)] = np.random.multinomial(n, pvals)
         results = {}
         if plan["one_context"] and steps:

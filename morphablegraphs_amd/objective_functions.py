@@ -57,6 +57,8 @@ def _residuals(prim, mp_constraints, S, prev_frames=None, sums=False):
         return np.zeros(len(S)) if sums else np.zeros((len(S), 0))
     skeleton = getattr(mp_constraints, "hip_skeleton", None)
     alignment = alignment_from_prev_frames(prev_frames, mp_constraints, skeleton)
+    from .frame_constraints import split_frame_constraints, frame_constraints_errors
+    clist, frame_list = split_frame_constraints(clist)
     keyframes, trajectories = split_trajectories(clist)
     if trajectories and alignment is not None and alignment.get("joint", 0) not in (0, _capi.MG_ALIGN_START_POSE):
         raise NotImplementedError("trajectory constraints in global coordinates need the root joint as aligning node")
@@ -69,6 +71,10 @@ def _residuals(prim, mp_constraints, S, prev_frames=None, sums=False):
     for c in trajectories:
         err, res = prim.score_trajectory(cached_trajectory(prim, c), S, c.get("min_u", 0.0), c.get("weight", 1.0), alignment, residuals=True)
         blocks.append(res)
+        total = total + err
+    if frame_list:   # per-frame constraints (other joints' trajectories, collision avoidance, ...): tracks from the device, arithmetic on the host
+        err, fblocks = frame_constraints_errors(prim, S, frame_list, skeleton, alignment)
+        blocks += fblocks
         total = total + err
     if sums:
         return total

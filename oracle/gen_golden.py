@@ -131,6 +131,12 @@ def run_trajectory_spline_case(name):
         out["parameters_%d" % ci] = us
         out["points_%d" % ci] = np.stack([np.asarray(sp.query_point_by_parameter(float(u)), dtype=np.float64) for u in us])
         out["full_arc_length_%d" % ci] = np.float64(sp.full_arc_length)
+        # the arc-length parameterisation (query_point_by_absolute_arc_length: arc_length_map.py's table, searched and
+        # interpolated; beyond the full length the last control point): what LocalTrajectoryConstraint, DiscreteTrajectoryConstraint
+        # and TrajectorySetConstraint look their targets up with
+        arcs = np.concatenate([[0.0, sp.full_arc_length, 0.5 * sp.full_arc_length, 1.25 * sp.full_arc_length], np.random.default_rng(780 + ci).uniform(0, sp.full_arc_length, 40)])   # (a stream of its own: the vectors above stay what they were)
+        out["arc_lengths_%d" % ci] = arcs
+        out["points_by_arc_%d" % ci] = np.stack([np.asarray(sp.query_point_by_absolute_arc_length(float(a)), dtype=np.float64) for a in arcs])
     out["n_cases"] = np.int64(3)
     path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)

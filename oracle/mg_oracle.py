@@ -487,6 +487,126 @@ def closest_point_walk(control_points, point, min_u, granularity=1000):
     return catmull_rom_point(control_points, u), u
 
 
+def arc_length_table(control_points, granularity=1000):
+    """RelativeArcLengthMap._update_table (splines/arc_length_map.py:45-71): [(parameter, relative arc length)] over
+    granularity + 1 samples, and the full arc length.  PINNED by tests/golden/trajectory_spline.npz (points_by_arc_*)."""
+    table, full, last = [], 0.0, None
+    for k in range(granularity + 1):
+        u = k / float(granularity)
+        pt = catmull_rom_point(control_points, u)
+        if last is not None:
+            full += float(np.linalg.norm(pt - last))
+        table.append([u, full])
+        last = pt
+    if full == 0.0:
+        raise ValueError("Not enough control points in trajectory constraint definition")
+    for row in table:
+        row[1] /= full
+    return table, full
+
+
+def catmull_rom_point_by_arc_length(control_points, table, full, arc):
+    """ParameterizedSpline.query_point_by_absolute_arc_length (splines/parameterized_spline.py:131-155) with
+    map_relative_arc_length_to_parameter (arc_length_map.py:97-160): the table entries bounding the relative arc length,
+    interpolated linearly; past the full arc length the last control point."""
+    if arc > full:
+        return np.asarray(control_points[-1], dtype=np.float64).copy()
+    rel = arc / full
+    if rel <= table[0][1]:
+        return catmull_rom_point(control_points, table[0][0])
+    if rel >= table[-1][1]:
+        return catmull_rom_point(control_points, table[-1][0])
+    lo = 0
+    while lo + 1 < len(table) and table[lo + 1][1] <= rel:       # the closest lower entry
+        lo += 1
+    if table[lo][1] == rel:
+        return catmull_rom_point(control_points, table[lo][0])
+    (p0, l0), (p1, l1) = table[lo], table[lo + 1]
+    return catmull_rom_point(control_points, p0 + (rel - l0) / (l1 - l0) * (p1 - p0))
+
+
+def per_frame_constraint_residuals(c, knots, coeffs, n_canonical_frames, joints, animated_joints):
+    """(residual vector, error), both WITHOUT the weight factor, of the constraints that walk every frame of one aligned
+    motion (coeffs: its aligned control points) -- what get_residual_vector_spline / evaluate_motion_spline of the
+    reference classes return:
+      frame_joint_trajectory   TrajectoryConstraint, trajectory_constraint.py:79-116 (closest point: the device's walk)
+      frame_ca_position        GlobalTransformCAConstraint, keyframe_constraints/global_transform_ca_constraint.py:33-46
+      frame_discrete_trajectory DiscreteTrajectoryConstraint, discrete_trajectory_constraint.py:66-90
+      frame_local_trajectory   LocalTrajectoryConstraint, keyframe_constraints/local_trajectory_constraint.py:45-78
+      frame_trajectory_set     TrajectorySetConstraint, trajectory_set_constraint.py:41-104
+      frame_joint_rotation     JointRotationConstraint, keyframe_constraints/joint_rotation_constraint.py:55-72
+    PARITY UNPINNED (forward kinematics is anim_utils')."""
+    F = int(n_canonical_frames)
+    motion_vector = spline_frames(knots, coeffs, np.linspace(0, F, F))        # MotionSpline.get_motion_vector()
+    kind = c["type"]
+
+    def position(frame, joint):
+        return np.asarray(joint_global_position(frame, joints, animated_joints, joint), dtype=np.float64)
+    if kind == "frame_joint_trajectory":
+        cps, min_u = c["control_points"], float(c.get("min_u", 0.0))
+        errors = np.empty(len(motion_vector))
+        for i, frame in enumerate(motion_vector):
+            p = position(frame, c["joint"])
+            target, min_u = closest_point_walk(cps, p, min_u, c.get("granularity", 1000))
+            errors[i] = np.linalg.norm(p - target)
+        return errors, float(np.average(errors))
+    if kind == "frame_ca_position":
+        nf = int(c.get("n_frames", F))
+        errors = np.zeros(nf)
+        for i in range(nf):
+            errors[i] = point_distance(c["target"], position(spline_frames(knots, coeffs, [float(i)])[0], c["joint"]))
+        return np.array([min(errors)]), float(min(errors))
+    if kind == "frame_discrete_trajectory":
+        pts, free = [np.array(p, dtype=np.float64) for p in c["points"]], [int(a) for a in (c.get("unconstrained") or ())]
+        errors = []
+        for index, frame in enumerate(motion_vector):
+            if index < len(pts):
+                p, target = position(frame, c["joint"]), pts[index].copy()
+                target[free] = 0
+                p[free] = 0
+                errors.append(np.linalg.norm(p - target))
+            else:
+                errors.append(0.0)
+        return np.array(errors), float(np.average(errors))
+    if kind == "frame_local_trajectory":
+        nf = int(c.get("n_frames", F))
+        table, full = arc_length_table(c["control_points"], c.get("granularity", 1000))
+        errors, last_p, current_t = [], None, float(c.get("start_t", 0.0))
+        for idx in range(nf):
+            p = position(spline_frames(knots, coeffs, [float(idx)])[0], c["joint"])
+            if last_p is not None:
+                current_t += np.linalg.norm(last_p - p)
+            target = catmull_rom_point_by_arc_length(c["control_points"], table, full, current_t)
+            delta = np.array([target[0] - p[0], target[2] - p[2]])
+            errors.append(float(np.dot(delta, delta)))
+            last_p = p
+        return np.array(errors), float(sum(errors))
+    if kind == "frame_trajectory_set":
+        nf = int(c.get("n_frames", F))
+        tables = [arc_length_table(t["control_points"], t.get("granularity", 1000)) for t in c["trajectories"]]
+        arcs = [float(a) for a in c.get("arc_lengths", [0.0] * len(c["joints"]))]
+        residual, last = np.zeros(nf), None
+        for i in range(nf):
+            ps = [position(motion_vector[i], j) for j in c["joints"]]
+            active = [t.get("range_start") is not None and t["range_start"] <= a <= t["range_end"] for t, a in zip(c["trajectories"], arcs)]
+            if np.any(active):
+                targets = [catmull_rom_point_by_arc_length(t["control_points"], tab, full, a) for t, (tab, full), a in zip(c["trajectories"], tables, arcs)]
+                residual[i] = np.linalg.norm(np.average(ps) - np.average(targets))
+            if last is not None:
+                arcs = [a + np.linalg.norm(p - q) for p, q, a in zip(ps, last, arcs)]
+            last = ps
+        return residual, float(np.average(residual))
+    if kind == "frame_joint_rotation":
+        frame = spline_frames(knots, coeffs, [float(c["frame_idx"])])[0]
+        ji = int(c["joint_index"])
+        q = np.array(frame[3 + 4 * ji:3 + 4 * (ji + 1)], dtype=np.float64)
+        q /= np.linalg.norm(q)
+        t = np.asarray(c["quaternion"], dtype=np.float64)
+        err = float(np.linalg.norm(np.ravel(quaternion_matrix3(t / np.linalg.norm(t)) - quaternion_matrix3(q))))
+        return np.array([err]), err
+    raise ValueError(kind)
+
+
 def align_point_clouds_2d(a, b, weights):
     """The optimal weighted 2-D rigid fit of cloud b onto cloud a (rotation about y by theta, then translation in x
     and z): the closed form of Kovar, Gleicher, Pighin, "Motion Graphs" (2002), which the reference reaches through
@@ -713,6 +833,24 @@ class OraclePrimitive(object):
                 else:
                     out[b, ci] = c["weight"] * constraint_error_on_frame(c, frame, joints, animated_joints)
         return out
+
+    def frame_constraint_errors(self, S, constraints, joints, animated_joints, prev_frame=None, align_joint=None, ref_dir=(0.0, 0.0, 1.0),
+                                start_pose=None):
+        """(n,) the weighted sum of per-frame constraints' errors (MotionPrimitiveConstraints.evaluate,
+        motion_primitive_constraints.py:100-122) and per constraint the (n, m) weighted residual vectors."""
+        S = np.atleast_2d(S)
+        total, blocks = np.zeros(S.shape[0]), [[] for _ in constraints]
+        for b in range(S.shape[0]):
+            coeffs = self.back_project_spatial_coeffs(S[b][:self.n_components])
+            if prev_frame is not None:
+                coeffs = align_coeffs_to_previous_frame(coeffs, prev_frame, joints, animated_joints, align_joint, ref_dir)
+            elif start_pose is not None:
+                coeffs = align_coeffs_to_start_pose(coeffs, start_pose)
+            for ci, c in enumerate(constraints):
+                res, err = per_frame_constraint_residuals(c, self.knots, coeffs, self.n_canonical_frames, joints, animated_joints)
+                total[b] += c.get("weight", 1.0) * err
+                blocks[ci].append(c.get("weight", 1.0) * res)
+        return total, [np.array(v) for v in blocks]
 
     def log_likelihood_jac(self, S):
         S = np.atleast_2d(np.asarray(S, dtype=np.float64))

@@ -1,0 +1,154 @@
+"""GPU tests of the constraints that walk a joint through EVERY frame of a candidate (morphablegraphs_amd/frame_constraints.py):
+trajectory constraints on other joints than the root, collision-avoidance positions, discrete / local trajectories, trajectory
+sets and the local joint rotation -- device tracks + host arithmetic against the oracle's frame-by-frame restatements of the
+reference classes (oracle/mg_oracle.py per_frame_constraint_residuals), in local coordinates, aligned to a previous frame and to
+a start pose, and through the reference-shaped entry points (evaluate_samples_using_constraints, the sample filter, the
+optimiser's objectives)."""
+import numpy as np
+import pytest
+
+from morphablegraphs_amd import _capi, synthetic
+from morphablegraphs_amd.candidate_scoring import (HipSampleFilter, alignment_from_start_pose, errors_of_samples,
+                                                   evaluate_samples_using_constraints)
+from morphablegraphs_amd.frame_constraints import frame_constraint_residuals, frame_constraints_errors
+from test_gpu_adaptors import _path_following_model, _primitive
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=9, seed=21):
+    from oracle import mg_oracle as orc
+    data = _path_following_model()
+    mp = _primitive(data)
+    op = orc.OraclePrimitive(data)
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    S = np.random.default_rng(seed).standard_normal((n, 40))
+    return orc, data, mp, op, joints, animated, sk, S
+
+
+def _constraints(op, orc, S, joints, animated):
+    """One constraint of every per-frame type near the candidates' own motions (targets from candidate 0's joints)."""
+    frames0 = op.back_project_frames(S[0])
+    hand = np.array([orc.joint_global_position(f, joints, animated, "LeftHand") for f in frames0])
+    foot = np.array([orc.joint_global_position(f, joints, animated, "RightFoot") for f in frames0])
+    hand_cps = hand[::22].copy() + np.array([1.0, -0.5, 2.0])
+    foot_cps = foot[::30].copy() + np.array([-1.0, 0.3, 1.0])
+    F = op.n_canonical_frames
+    return [
+        {"type": "frame_joint_trajectory", "joint": "LeftHand", "control_points": hand_cps.tolist(), "min_u": 0.05, "granularity": 1000, "weight": 1.5},
+        {"type": "frame_ca_position", "joint": "RightFoot", "target": [float(foot[60, 0]) + 3.0, None, float(foot[60, 2]) - 2.0], "n_frames": F, "weight": 2.0},
+        {"type": "frame_discrete_trajectory", "joint": "LeftHand", "points": (hand[:120] + 0.7).tolist(), "unconstrained": [1], "weight": 0.8},
+        {"type": "frame_local_trajectory", "joint": "Hips", "control_points": (frames0[::20, :3] + np.array([0.5, 0.0, -0.5])).tolist(), "granularity": 1000,
+         "start_t": 3.0, "n_frames": F, "weight": 1.2},
+        {"type": "frame_trajectory_set", "joints": ["LeftHand", "RightFoot"],
+         "trajectories": [{"control_points": hand_cps.tolist(), "granularity": 1000, "range_start": 20.0, "range_end": 1500.0},
+                          {"control_points": foot_cps.tolist(), "granularity": 1000, "range_start": None, "range_end": None}],
+         "arc_lengths": [4.0, 1.0], "n_frames": F, "weight": 1.1},
+        {"type": "frame_joint_rotation", "joint_index": 7, "quaternion": [0.9, 0.1, -0.3, 0.2], "frame_idx": 40.0, "weight": 0.6},
+        {"type": "frame_joint_rotation", "joint_index": 0, "quaternion": [0.8, 0.0, 0.6, 0.0], "frame_idx": 12.0, "weight": 0.4},
+    ]
+
+
+def _check(mp, op, S, clist, sk, joints, animated, alignment, **oracle_alignment):
+    total_ref, blocks_ref = op.frame_constraint_errors(S, clist, joints, animated, **oracle_alignment)
+    total, blocks = frame_constraints_errors(mp._prim, S, clist, sk, alignment)
+    for c, b, br in zip(clist, blocks, blocks_ref):
+        assert b.shape == br.shape, (c["type"], b.shape, br.shape)
+        scale = max(1.0, np.abs(br).max())
+        # float64 end to end; the trajectory search carries the device walk's 1e-9 (tests/test_gpu_adaptors.py)
+        tol = 1e-8 if c["type"] == "frame_joint_trajectory" else 1e-9
+        assert np.abs(b - br).max() <= tol * scale, (c["type"], np.abs(b - br).max(), scale)
+    np.testing.assert_allclose(total, total_ref, rtol=1e-8, atol=1e-8)
+    return total
+
+
+def test_every_per_frame_constraint_in_local_coordinates():
+    orc, data, mp, op, joints, animated, sk, S = _setup()
+    clist = _constraints(op, orc, S, joints, animated)
+    total = _check(mp, op, S, clist, sk, joints, animated, None)
+    assert np.all(total > 0.0) and len(np.unique(total)) == len(total)
+    # the trajectory-set term is live (its active range is met) and the inactive range alone silences it
+    res, err = frame_constraint_residuals(mp._prim, S, clist[4], sk, None)
+    assert np.count_nonzero(res[0]) > 10
+    quiet = dict(clist[4], trajectories=[dict(t, range_start=None, range_end=None) for t in clist[4]["trajectories"]])
+    assert not frame_constraint_residuals(mp._prim, S, quiet, sk, None)[0].any()
+
+
+def test_per_frame_constraints_on_aligned_candidates():
+    """Global coordinates: every candidate is turned and moved onto the previous motion's last frame (or a start pose) first; the
+    tracks follow with the same per-candidate transform the fused scorer derives."""
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=6, seed=5)
+    clist = _constraints(op, orc, S, joints, animated)
+    prev = op.back_project_frames(np.random.default_rng(3).standard_normal(40))[-1].copy()
+    prev[:3] = [25.0, 89.0, -12.0]
+    for align_joint in ("Hips", "Spine1"):
+        al = sk.alignment_to(prev, sk.index(align_joint))
+        alignment = {"joint": sk.index(align_joint), "position": al["position"], "heading": al["heading"]}
+        _check(mp, op, S, clist, sk, joints, animated, alignment, prev_frame=prev, align_joint=align_joint)
+    sp = {"position": [3.0, 2.0, 1.0], "orientation": [0.0, 25.0, 0.0]}
+    total_ref, blocks_ref = [], None
+    # the reference's start-pose alignment rewrites the pose it is given: a fresh copy per candidate keeps candidates independent
+    for b in range(len(S)):
+        t, _ = op.frame_constraint_errors(S[b:b + 1], clist, joints, animated, start_pose={"position": list(sp["position"]), "orientation": list(sp["orientation"])})
+        total_ref.append(t[0])
+    total, _ = frame_constraints_errors(mp._prim, S, clist, sk, alignment_from_start_pose(sp))
+    np.testing.assert_allclose(total, total_ref, rtol=1e-8, atol=1e-8)
+
+
+def test_per_frame_constraints_through_the_reference_entry_points():
+    """evaluate_samples_using_constraints / the sample filter / the objectives take per-frame constraints beside keyframe and
+    root-trajectory ones: the errors add up constraint by constraint, the first minimum wins."""
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=12, seed=9)
+    frames = _constraints(op, orc, S, joints, animated)[:3]
+    frames0 = op.back_project_frames(S[0])
+    keyframes = [{"type": "position", "t": 100.0, "weight": 1.0, "target": [float(frames0[100, 0]) + 1.0, None, float(frames0[100, 2])]},
+                 {"type": "joint_position", "t": 50.0, "weight": 0.5, "target": [10.0, 100.0, 5.0], "joint": "Head"}]
+    root_traj = {"type": "trajectory", "control_points": (frames0[::26, :3] + 0.25).tolist(), "min_u": 0.0, "weight": 1.0, "granularity": 1000}
+    clist = keyframes + [root_traj] + frames
+    ref_frames, _ = op.frame_constraint_errors(S, frames, joints, animated)
+    ref_key = op.skeleton_residuals(S, keyframes, joints, animated).sum(axis=1)
+    paths = [op.back_project_frames(s)[:, :3] for s in S]
+    ref_traj = []
+    for path in paths:
+        min_u, walk = 0.0, []
+        for p in path:
+            pt, min_u = orc.closest_point_walk(root_traj["control_points"], p, min_u)
+            walk.append(np.linalg.norm(p - pt))
+        ref_traj.append(np.mean(walk))
+    want = ref_key + np.array(ref_traj) + ref_frames
+    got = errors_of_samples(mp._prim, clist, sk, None, S)
+    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-8)
+
+    class Cons(object):
+        constraints = clist
+        hip_skeleton = sk
+        is_local = True
+    best, err = evaluate_samples_using_constraints(S, mp, Cons())
+    np.testing.assert_array_equal(best, S[int(np.argmin(want))])
+    assert abs(err - want.min()) <= 1e-8 * max(1.0, want.min())
+    np.testing.assert_allclose(HipSampleFilter.score_samples(mp, S, Cons(), skeleton=sk), want, rtol=1e-8, atol=1e-8)
+    # the optimiser's objectives: the residual vector carries the per-frame blocks behind the fused ones
+    from morphablegraphs_amd import objective_functions as of
+    np.testing.assert_allclose(of.obj_spatial_error_sum(S[2], (mp, Cons(), None, 1.0, 1.0)), want[2], rtol=1e-8, atol=1e-8)
+    r = of.obj_spatial_error_residual_vector(S[2], (mp, Cons(), None, 1.0, 1.0, 2.0))
+    fblocks = frame_constraints_errors(mp._prim, S[2:3], frames, sk, None)[1]
+    n_frame_entries = sum(b.shape[1] for b in fblocks)
+    assert len(r) == len(keyframes) + op.n_canonical_frames + n_frame_entries
+    np.testing.assert_allclose(r[-n_frame_entries:], np.concatenate([b[0] for b in fblocks]) / 2.0, rtol=1e-12)
+
+
+def test_per_frame_constraints_need_a_skeleton_for_other_joints():
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=2)
+    c = {"type": "frame_ca_position", "joint": "LeftHand", "target": [0.0, 0.0, 0.0], "n_frames": 10, "weight": 1.0}
+    with pytest.raises(NotImplementedError):
+        frame_constraint_residuals(mp._prim, S, c, None, None)
+    # the root alone needs none
+    root = {"type": "frame_ca_position", "joint": "root", "target": [80.0, None, 20.0], "n_frames": op.n_canonical_frames, "weight": 1.0}
+    res, err = frame_constraint_residuals(mp._prim, S, root, None, None)
+    ref = []
+    for s in S:
+        coeffs = op.back_project_spatial_coeffs(s)
+        fr = orc.spline_frames(op.knots, coeffs, np.arange(op.n_canonical_frames, dtype=np.float64))
+        ref.append(min(np.hypot(80.0 - f[0], 20.0 - f[2]) for f in fr))
+    np.testing.assert_allclose(err, ref, rtol=1e-10)

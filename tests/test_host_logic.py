@@ -237,6 +237,68 @@ def test_batched_jacobian_reproduces_minpack_forward_differences():
     assert J.shape == (7, 4)
 
 
+def test_per_frame_constraints_of_the_reference_become_frame_device_forms():
+    """TrajectoryConstraint on another joint, TrajectorySet / Discrete / Local trajectory, GlobalTransformCA and JointRotation
+    constraints (objects shaped like the reference classes) -> the frame_* device forms of frame_constraints.py."""
+    from morphablegraphs_amd.frame_constraints import is_frame_constraint, split_frame_constraints
+    cps = np.array([[0.0, 0.0, 0.0], [10.0, 0.0, 2.0], [20.0, 1.0, 3.0], [30.0, 1.0, 9.0]])
+
+    class Spline(object):
+        control_points = [cps[0]] + list(cps) + [cps[-1], cps[-1]]                    # padded like catmull_rom_spline.py:66-71
+        _catmullrom_basematrix = None
+
+    class Skel(object):
+        root = "Hips"
+        node_name_frame_map = {"Hips": 0, "Spine": 1, "LeftHand": 2}
+
+    class Traj(object):
+        constraint_type, joint_name, spline, granularity, weight_factor = "trajectory", "LeftHand", Spline(), 1000, 2.0
+        min_arc_length, full_arc_length, skeleton, is_collision_avoidance_constraint = 5.0, 50.0, Skel(), True
+        range_start, range_end = 1.0, 9.0
+
+    class RootTraj(Traj):
+        joint_name = "Hips"
+
+    class Set(object):
+        joint_trajectories, joint_names, joint_arc_lengths, n_canonical_frames, weight_factor = [Traj(), RootTraj()], ["LeftHand", "Hips"], [1.0, 2.0], 47, 1.0
+
+    class Discrete(object):
+        joint_name, point_list, unconstrained_indices, weight_factor = "LeftHand", [np.zeros(3), np.ones(3)], None, 1.0
+
+    class Param(object):
+        spline, granularity = Spline(), 500
+
+    class Local(object):
+        constraint_type, trajectory, start_t, n_canonical_frames, joint_name, weight_factor = "local_trajectory", Param(), 2.5, 47, "Hips", 1.0
+
+    class CA(object):
+        constraint_type, joint_name, position, n_canonical_frames, weight_factor, canonical_keyframe = "ca_constraint", "LeftHand", [1.0, None, 2.0], 47, 1.0, 3
+
+    class Rot(object):
+        joint_name, rotation_type, rotation_constraint, frame_idx, skeleton, weight_factor = "LeftHand", "euler", [30.0, -20.0, 45.0], 12, Skel(), 1.5
+
+    out = constraints_to_device_form([Traj(), RootTraj(), Set(), Discrete(), Local(), CA(), Rot()])
+    assert [c["type"] for c in out] == ["frame_joint_trajectory", "trajectory", "frame_trajectory_set", "frame_discrete_trajectory",
+                                        "frame_local_trajectory", "frame_ca_position", "frame_joint_rotation"]
+    assert [c["group"] for c in out] == list(range(7))
+    fused, frames = split_frame_constraints(out)
+    assert len(fused) == 1 and len(frames) == 6 and all(is_frame_constraint(c) for c in frames)
+    np.testing.assert_array_equal(out[0]["control_points"], cps)
+    assert out[0]["min_u"] == 0.1 and out[0]["joint"] == "LeftHand" and out[0]["weight"] == 2.0
+    assert out[2]["trajectories"][0]["range_start"] == 1.0 and out[2]["arc_lengths"] == [1.0, 2.0] and out[2]["n_frames"] == 47
+    assert out[3]["unconstrained"] == [0, 1, 2]              # target[None] = 0 zeroes every axis in the reference
+    assert out[4]["granularity"] == 500 and out[4]["start_t"] == 2.5
+    assert out[5]["target"] == [1.0, None, 2.0]
+    assert out[6]["joint_index"] == 2 and out[6]["frame_idx"] == 12.0
+    # the Euler target: rotations about the joint's own x, then y, then z (transformations.euler_matrix 'rxyz') = Rx Ry Rz
+    from oracle import mg_oracle as orc
+    ax, ay, az = np.deg2rad([30.0, -20.0, 45.0])
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    np.testing.assert_allclose(orc.quaternion_matrix3(out[6]["quaternion"]), Rx @ Ry @ Rz, atol=1e-14)
+
+
 def test_skeleton_description_for_the_c_abi():
     joints, animated = synthetic.make_skeleton()
     sk = _capi.Skeleton(joints, animated)
