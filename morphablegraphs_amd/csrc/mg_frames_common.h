@@ -116,7 +116,11 @@ extern "C" int mg_debug_dump_stamps(void) {
     return 0;
 }
 #else
+#ifdef MG_DBG_CONST   // tools/build_variant.sh NAME -DMG_DBG_CONST=bits: an ablation compiled in, without the diagnostic build's stamps
+#define MG_DBG(bits) ((MG_DBG_CONST) & (bits))
+#else
 #define MG_DBG(bits) 0
+#endif
 #define MG_STAMP_DECL
 #define MG_STAMP(ph) do { } while (0)
 #define MG_STAMP_DUMP do { } while (0)

@@ -55,6 +55,17 @@ __global__ __launch_bounds__(256) void mg_placement_fill_kernel(f32x4p *buf, siz
 }
 
 #define MG_PLACED_FAST_RATIO 1.15                  // measured: 1.04-1.06 in the fast class, 1.25-1.33 in the slow one
+// ... and an absolute floor for probes that fill the chip (256 tiles and more): a process can meet memory where the plain fill is
+// slow as well (fill 77 us, pattern 80 us for the bench's 404 MB: ratio 1.04, 5.0 TB/s -- against 61-63.5 us = 6.4-6.6 TB/s in
+// the fast class and 54-57 us in the best regions), which the ratio alone waves through
+#define MG_PLACED_FAST_TBPS 6.2
+static bool mg_placement_is_fast(int64_t bytes, double ratio, double pattern_us, double fast_ratio) {
+    if (ratio > fast_ratio) return false;
+    const int64_t cand_bytes = (int64_t)MG_PP_T * MG_PP_D * 4;
+    const int64_t ntiles = std::min<int64_t>(bytes / (16 * cand_bytes), 1 << 20);
+    if (ntiles < 256 || pattern_us <= 0.0) return true;
+    return (double)(ntiles * 16 * cand_bytes) / pattern_us * 1e-6 >= MG_PLACED_FAST_TBPS;
+}
 
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us) {
     const int64_t cand_bytes = (int64_t)MG_PP_T * MG_PP_D * 4;
@@ -95,7 +106,7 @@ extern "C" int mg_device_probe_placement(mg_context *ctx, void *buf, int64_t byt
     double ratio = 1.0, us = 0.0;
     int rc = mg_probe_placement(ctx, buf, bytes, &ratio, &us);
     if (rc != MG_OK) return rc;
-    info[0] = 1.0; info[1] = ratio; info[2] = us; info[3] = ratio <= MG_PLACED_FAST_RATIO ? 1.0 : 0.0;
+    info[0] = 1.0; info[1] = ratio; info[2] = us; info[3] = mg_placement_is_fast(bytes, ratio, us, MG_PLACED_FAST_RATIO) ? 1.0 : 0.0;
     return MG_OK;
 }
 
@@ -131,6 +142,7 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
     std::vector<cand> held;   // rejected candidates, oldest first
     cand best = {nullptr, false};
     double best_ratio = 0.0, best_us = 0.0;
+    bool best_fast = false;
     int probed = 0, rc = MG_OK;
     auto drop = [&](const cand &c) { if (c.vmm) (void)mg_device_free_raw(ctx, c.p); else (void)hipFree(c.p); };
     auto consider = [&](void *p, bool vmm) -> bool {   // probe p, keep the better of (best, p), hold the other; false: stop
@@ -138,9 +150,12 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
         rc = mg_probe_placement(ctx, p, (int64_t)probe_bytes, &ratio, &us);
         if (rc != MG_OK) { drop({p, vmm}); return false; }
         probed++;
-        if (!best.p || ratio < best_ratio) {
+        // (every candidate is probed with the same probe_bytes: the pattern's own time orders them; the ratio where the probe is too
+        // small to time)
+        if (!best.p || (us > 0.0 && best_us > 0.0 ? us < best_us : ratio < best_ratio)) {
             if (best.p) held.push_back(best);
             best = {p, vmm}; best_ratio = ratio; best_us = us;
+            best_fast = mg_placement_is_fast((int64_t)probe_bytes, ratio, us, fast_ratio);
         } else {
             held.push_back({p, vmm});
         }
@@ -149,7 +164,7 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
             drop(held.front());
             held.erase(held.begin());
         }
-        return best_ratio > fast_ratio;
+        return !best_fast;
     };
     auto plain = [&](int count) {
         for (int i = 0; i < count && probed < budget; i++) {
@@ -162,7 +177,7 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
     // twelve buffers assembled from physical chunks through the virtual-memory API (on some boxes only those are fast), then
     // the rest of the budget plain again.
     plain(std::min(budget, 16));
-    if (best.p && best_ratio > fast_ratio && rc == MG_OK && max_candidates != 1) {
+    if (best.p && !best_fast && rc == MG_OK && max_candidates != 1) {
         static const int64_t chunk_mib[3] = {32, 8, 2};
         bool go = true;
         for (int c = 0; c < 3 && go; c++)
@@ -171,7 +186,7 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
                 if (mg_device_malloc_chunked(ctx, (int64_t)bytes, chunk_mib[c] << 20, &p) != MG_OK) { (void)hipGetLastError(); go = false; break; }
                 go = consider(p, true);
             }
-        if (rc == MG_OK && best_ratio > fast_ratio) plain(budget - probed);
+        if (rc == MG_OK && !best_fast) plain(budget - probed);
     }
     (void)hipStreamSynchronize(ctx->stream);
     for (const cand &c : held) drop(c);
@@ -184,7 +199,7 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
         return MG_ERR_OUT_OF_MEMORY;
     }
     out->base = (char *)best.p; out->bytes = bytes; out->vmm = best.vmm; out->ratio = best_ratio; out->us = best_us;
-    out->probed = probed; out->fast = best_ratio <= fast_ratio; out->live = 0;
+    out->probed = probed; out->fast = best_fast; out->live = 0;
     out->free_list.clear();
     out->free_list.push_back({0, bytes});
     return MG_OK;

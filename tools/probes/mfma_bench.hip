@@ -37,6 +37,22 @@ __global__ void k_f32(float *out, unsigned long long *cyc, int n) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
+template <int CHAINS>
+__global__ void k_f64_4x4(double *out, unsigned long long *cyc, int n) {   // v_mfma_f64_4x4x4_4b_f64: four 4x4x4 blocks per instruction
+    double acc[CHAINS];
+    for (int c = 0; c < CHAINS; c++) acc[c] = 0;
+    double a = threadIdx.x * 0.5, b = 1.0 + threadIdx.x;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) acc[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[c], 0, 0, 0);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0;
+    for (int c = 0; c < CHAINS; c++) s += acc[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
 __global__ void k_dfma(double *out, unsigned long long *cyc, int n) {
     double acc[4] = {0, 0, 0, 0};
     double a = threadIdx.x * 0.5, b = 1.0 + threadIdx.x;
@@ -61,6 +77,10 @@ int main() {
     RUN("f64 mfma 16x16x4, 3 chains, 1 wave", k_f64<3>, o64, 64, 3)
     RUN("f64 mfma 16x16x4, 4 chains, 1 wave", k_f64<4>, o64, 64, 4)
     RUN("f64 mfma 16x16x4, 4 chains, 4 waves", k_f64<4>, o64, 256, 4)
+    RUN("f64 mfma 4x4x4 (4 blocks), 1 chain, 1 wave", k_f64_4x4<1>, o64, 64, 1)
+    RUN("f64 mfma 4x4x4 (4 blocks), 4 chains, 1 wave", k_f64_4x4<4>, o64, 64, 4)
+    RUN("f64 mfma 4x4x4 (4 blocks), 8 chains, 1 wave", k_f64_4x4<8>, o64, 64, 8)
+    RUN("f64 mfma 4x4x4 (4 blocks), 8 chains, 4 waves", k_f64_4x4<8>, o64, 256, 8)
     RUN("f32 mfma 16x16x4, 1 chain, 1 wave", k_f32<1>, o32, 64, 1)
     RUN("f32 mfma 16x16x4, 2 chains, 1 wave", k_f32<2>, o32, 64, 2)
     RUN("f32 mfma 16x16x4, 4 chains, 1 wave", k_f32<4>, o32, 64, 4)
