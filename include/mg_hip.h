@@ -383,6 +383,61 @@ int mg_score_trajectory(mg_primitive *prim, const mg_trajectory *trajectory, con
 int mg_score_trajectory_points(mg_primitive *prim, const mg_trajectory *trajectory, const double *points_dev, int64_t n_samples, int32_t n_times,
                                double min_u, double weight, double *errors_dev, int accumulate, double *residuals_dev);
 
+/* Constraints that walk a joint through EVERY frame of a candidate (mg_frame_constraints.hip), on float64 frames and joint tracks
+ * that are on the device already (mg_back_project_frames_f64, mg_joint_positions):
+ *
+ * mg_align_frames -- frames_dev (n_samples, n_times, n_dim) float64, in place: every candidate turned about y and moved like
+ *   MotionPrimitiveConstraints.evaluate aligns it (reference constraints/motion_primitive_constraints.py:106-116 through
+ *   anim_utils' align_quaternion_frames / start-pose transform), the transform derived per candidate from ITS first control point:
+ *   vals_dev (n_samples, n_vals) float64 = its root position x, z [and its heading x, z]: the residuals of
+ *   MG_CONSTRAINT_VALUE_POSITION (axes 0, 2) [and MG_CONSTRAINT_VALUE_HEADING (axes 0, 2)] constraints at t = 0 with weight 1
+ *   (mg_score_constraint_residuals).  alignment: the previous-frame record (n_vals 4) or a start-pose record (n_vals 2).
+ *
+ * mg_score_frame_constraint -- one constraint for the whole batch, one lane per candidate.  tracks_dev (n_samples, n_times,
+ *   n_joints, 3) float64; errors_dev (n_samples) written or, with accumulate != 0, added to; residuals_dev NULL or (n_samples,
+ *   mg_frame_constraint_width()) = weight * the constraint's residual vector.  Types (reference classes under
+ *   constraints/spatial_constraints/):
+ *     MG_FRAME_CA_POSITION          GlobalTransformCAConstraint, keyframe_constraints/global_transform_ca_constraint.py:33-46: the
+ *                                   smallest distance of the joint to `target` over the first n_frames frames (axes with axis_on 0 ignored)
+ *     MG_FRAME_DISCRETE_TRAJECTORY  DiscreteTrajectoryConstraint, discrete_trajectory_constraint.py:66-90: frame i against points_dev[i]
+ *                                   (axes with axis_on 0 zeroed on both sides, frames beyond n_points count 0), averaged over all frames
+ *     MG_FRAME_LOCAL_TRAJECTORY     LocalTrajectoryConstraint, keyframe_constraints/local_trajectory_constraint.py:45-78: the target is
+ *                                   the point of trajectories[0] at arc length start_arc + the path walked so far; squared xz distances summed
+ *     MG_FRAME_TRAJECTORY_SET       TrajectorySetConstraint, trajectory_set_constraint.py:82-104: n_joints joints, one trajectory each,
+ *                                   arc0 = joint_arc_lengths, has_range / range_start / range_end = each trajectory's active range
+ *     MG_FRAME_JOINT_ROTATION       JointRotationConstraint, keyframe_constraints/joint_rotation_constraint.py:55-72: tracks_dev is the
+ *                                   (n_samples, n_times, n_joints = n_dim) FRAME block at the constraint's frame index (n_times 1),
+ *                                   quat_channel = 3 + 4 * the joint's index among the animated joints, quaternion = the wanted rotation
+ *   A TrajectoryConstraint on any joint is mg_score_trajectory_points.  PARITY UNPINNED (forward kinematics and alignment are
+ *   anim_utils'); the arc-length look-up is pinned by tests/golden/trajectory_spline.npz. */
+#define MG_FRAME_CA_POSITION 1
+#define MG_FRAME_DISCRETE_TRAJECTORY 2
+#define MG_FRAME_LOCAL_TRAJECTORY 3
+#define MG_FRAME_TRAJECTORY_SET 4
+#define MG_FRAME_JOINT_ROTATION 5
+#define MG_FRAME_MAX_JOINTS 8
+typedef struct mg_frame_constraint_desc {
+    int32_t type;
+    int32_t n_frames;                 /* frames evaluated, 0 = all n_times (CA_POSITION, LOCAL_TRAJECTORY, TRAJECTORY_SET) */
+    int32_t n_points;                 /* DISCRETE_TRAJECTORY */
+    int32_t n_joints;                 /* TRAJECTORY_SET; 1 otherwise */
+    double weight;
+    double target[3];                 /* CA_POSITION */
+    int32_t axis_on[3];               /* CA_POSITION: axes of the target that count; DISCRETE_TRAJECTORY: constrained axes */
+    int32_t quat_channel;             /* JOINT_ROTATION */
+    const double *points_dev;         /* DISCRETE_TRAJECTORY: (n_points, 3) float64 on the device */
+    double start_arc;                 /* LOCAL_TRAJECTORY */
+    const mg_trajectory *trajectories[MG_FRAME_MAX_JOINTS];
+    double arc0[MG_FRAME_MAX_JOINTS], range_start[MG_FRAME_MAX_JOINTS], range_end[MG_FRAME_MAX_JOINTS];
+    int32_t has_range[MG_FRAME_MAX_JOINTS];
+    double quaternion[4];             /* JOINT_ROTATION: (w, x, y, z) */
+} mg_frame_constraint_desc;
+int mg_align_frames(mg_primitive *prim, double *frames_dev, int64_t n_samples, int32_t n_times, const double *vals_dev, int32_t n_vals,
+                    const mg_alignment_desc *alignment);
+int mg_frame_constraint_width(const mg_frame_constraint_desc *constraint, int32_t n_times);
+int mg_score_frame_constraint(mg_primitive *prim, const mg_frame_constraint_desc *constraint, const double *tracks_dev, int64_t n_samples,
+                              int32_t n_times, int32_t n_joints, double *errors_dev, int accumulate, double *residuals_dev);
+
 /* ---- hot path, device pointers ------------------------------------------------------ */
 
 /* MotionPrimitive.back_project(s, False).get_motion_vector() for a batch

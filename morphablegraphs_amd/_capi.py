@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = [
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
+    "mg_align_frames", "mg_frame_constraint_width", "mg_score_frame_constraint",
     "mg_score_constraint_residuals_chained", "mg_option_step", "mg_options_step", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
 ]
 
@@ -89,6 +90,18 @@ class SkeletonDesc(C.Structure):   # struct mg_skeleton_desc
 class AlignmentDesc(C.Structure):   # struct mg_alignment_desc
     _fields_ = [("joint", C.c_int32), ("reserved", C.c_int32), ("position", C.c_double * 3), ("heading", C.c_double * 2),
                 ("ref_dir", C.c_double * 3)]
+
+
+MG_FRAME_CA_POSITION, MG_FRAME_DISCRETE_TRAJECTORY, MG_FRAME_LOCAL_TRAJECTORY, MG_FRAME_TRAJECTORY_SET, MG_FRAME_JOINT_ROTATION = 1, 2, 3, 4, 5
+MG_FRAME_MAX_JOINTS = 8
+
+
+class FrameConstraintDesc(C.Structure):   # struct mg_frame_constraint_desc
+    _fields_ = [("type", C.c_int32), ("n_frames", C.c_int32), ("n_points", C.c_int32), ("n_joints", C.c_int32), ("weight", C.c_double),
+                ("target", C.c_double * 3), ("axis_on", C.c_int32 * 3), ("quat_channel", C.c_int32), ("points_dev", C.c_void_p),
+                ("start_arc", C.c_double), ("trajectories", C.c_void_p * MG_FRAME_MAX_JOINTS), ("arc0", C.c_double * MG_FRAME_MAX_JOINTS),
+                ("range_start", C.c_double * MG_FRAME_MAX_JOINTS), ("range_end", C.c_double * MG_FRAME_MAX_JOINTS),
+                ("has_range", C.c_int32 * MG_FRAME_MAX_JOINTS), ("quaternion", C.c_double * 4)]
 
 
 def _quat_mul(a, b):
@@ -224,6 +237,9 @@ def load_library(path=None):
         "mg_joint_positions": [vp, vp, vp, i32, vp, i64, i32, vp],
         "mg_score_trajectory": [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, i32, vp],
         "mg_score_trajectory_points": [vp, vp, vp, i64, i32, dbl, dbl, vp, i32, vp],
+        "mg_align_frames": [vp, vp, i64, i32, vp, i32, C.POINTER(AlignmentDesc)],
+        "mg_frame_constraint_width": [C.POINTER(FrameConstraintDesc), i32],
+        "mg_score_frame_constraint": [vp, C.POINTER(FrameConstraintDesc), vp, i64, i32, i32, vp, i32, vp],
         "mg_time_function_canonical_host": [vp, vp, i32, i64, i64, vp],
         "mg_primitive_get_precisions_cholesky": [vp, vp],
         "mg_time_grid_create": [vp, vp, C.c_int32, C.POINTER(vp)],

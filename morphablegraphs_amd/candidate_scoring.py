@@ -390,29 +390,30 @@ def _prim_of(mp_node):
     return prim_obj, prim_obj._prim
 
 
-def errors_of_samples(prim, device_form, skeleton, alignment, samples):
-    """(n,) float64: the sum of ALL constraints' weighted errors for host-resident candidates -- keyframe and root-trajectory
-    constraints by the fused scorers, per-frame constraints (frame_constraints.py) from the device's frame and joint tracks."""
-    from .frame_constraints import split_frame_constraints, frame_constraints_errors
+def all_errors_dev(prim, device_form, skeleton, alignment, S, d_S, d_err):
+    """The sum of ALL constraints' weighted errors of candidates S (host latents, d_S their copy on the device) into d_err (n,)
+    float64 on the device: keyframe and root-trajectory constraints by the fused scorers, then the per-frame constraints
+    (frame_constraints.py) adding to the same buffer."""
+    from .frame_constraints import split_frame_constraints, add_frame_constraints_dev
     fused, frames = split_frame_constraints(device_form)
     keyframes, trajectories = split_trajectories(fused)
-    S = _capi._latents(samples)
-    total = np.zeros(len(S))
-    if len(S) == 0:
-        return total
-    if trajectories:
-        d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(max(len(S), 1) * 8)
-        try:
-            _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_S, S.dtype, len(S), S.shape[1], d_e)
-            total = total + prim.ctx.download(d_e, (len(S),), np.float64)
-        finally:
-            d_S.free()
-            d_e.free()
-    elif keyframes:
-        total = total + prim.score_constraints(cached_constraint_set(prim, keyframes, skeleton, alignment), S, dtype=np.float64)
+    _errors_with_trajectories_dev(prim, keyframes, trajectories, skeleton, alignment, d_S, S.dtype, len(S), S.shape[1], d_err)
     if frames:
-        total = total + frame_constraints_errors(prim, S, frames, skeleton, alignment)[0]
-    return total
+        add_frame_constraints_dev(prim, S, frames, skeleton, alignment, d_err, accumulate=True)
+
+
+def errors_of_samples(prim, device_form, skeleton, alignment, samples):
+    """(n,) float64: the sum of ALL constraints' weighted errors for host-resident candidates."""
+    S = _capi._latents(samples)
+    if len(S) == 0:
+        return np.zeros(0)
+    d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(len(S) * 8)
+    try:
+        all_errors_dev(prim, device_form, skeleton, alignment, S, d_S, d_e)
+        return prim.ctx.download(d_e, (len(S),), np.float64)
+    finally:
+        d_S.free()
+        d_e.free()
 
 
 def first_minimum_of_block(mp_node, device_form, alignment, samples, skeleton=None):
@@ -422,9 +423,15 @@ def first_minimum_of_block(mp_node, device_form, alignment, samples, skeleton=No
     from .frame_constraints import is_frame_constraint
     if len(samples) == 0:
         return 0, float("inf")
-    if any(is_frame_constraint(c) for c in device_form):       # per-frame constraints: their errors are summed on the host
-        from .distributed import first_min_argmin
-        return first_min_argmin(errors_of_samples(prim, device_form, skeleton, alignment, samples))
+    if any(is_frame_constraint(c) for c in device_form):       # per-frame constraints add to the fused scorers' sum on the device
+        S = _capi._latents(samples)
+        d_S, d_e = prim.ctx.upload(S), prim.ctx.malloc(len(S) * 8)
+        try:
+            all_errors_dev(prim, device_form, skeleton, alignment, S, d_S, d_e)
+            return prim.ctx.argmin_first(d_e, len(S), np.float64)
+        finally:
+            d_S.free()
+            d_e.free()
     keyframes, trajectories = split_trajectories(device_form)
     if trajectories:
         S = _capi._latents(samples)
@@ -453,10 +460,14 @@ def sample_rows_and_first_minimum(mp_node, device_form, alignment, counts, seed,
     d_x = ctx.malloc(max(m, 1) * L * item)
     try:
         prim.gmm_sample_dev(np.asarray(counts, dtype=np.int64), seed, d_x, dtype, L, rows=(int(row_begin), m))
-        if any(is_frame_constraint(c) for c in device_form):   # per-frame constraints read the candidates back (m x L numbers)
-            from .distributed import first_min_argmin
-            X = ctx.download(d_x, (m, L), dtype)
-            best_idx, min_error = first_min_argmin(errors_of_samples(prim, device_form, skeleton, alignment, X))
+        if any(is_frame_constraint(c) for c in device_form):   # per-frame constraints: frames and joint tracks of the drawn rows
+            X = ctx.download(d_x, (m, L), dtype)                 # (the batch object keeps its own copy of the latents)
+            d_e = ctx.malloc(max(m, 1) * 8)
+            try:
+                all_errors_dev(prim, device_form, skeleton, alignment, X, d_x, d_e)
+                best_idx, min_error = ctx.argmin_first(d_e, m, np.float64)
+            finally:
+                d_e.free()
             return best_idx, min_error, X[best_idx].astype(np.float64)
         if trajectories:
             d_e = ctx.malloc(max(m, 1) * 8)

@@ -240,3 +240,14 @@ int mg_device_free_raw(mg_context *ctx, void *p);   // hipFree / virtual-memory 
 
 // host-side float64 spline basis (FITPACK splev/fpbspl semantics)
 void mg_basis_row(const double *knots, int n_knots, double x, int32_t *i0, double *w4);
+
+// A trajectory constraint's target spline on the device (mg_trajectory.hip; read by mg_frame_constraints.hip as well)
+struct mg_trajectory {
+    mg_primitive *prim = nullptr;
+    int32_t n_seg = 0, granularity = 1000, rows = 0;
+    double *d_poly = nullptr;    // [n_seg][4][3]: point(t) = ((A0 t + A1) t + A2) t + A3 on a segment; then the last control point [3]
+    double *d_arc = nullptr;     // [granularity + 1]: relative arc length at u = k / granularity (arc_length_map.py:45-71)
+    double full_arc = 0.0;
+    double *d_E = nullptr;       // [rows][L]: root coefficient rows (i * 3 + d), then the first control point's root quaternion (4 rows)
+    double *d_mean = nullptr;    // [rows]
+};

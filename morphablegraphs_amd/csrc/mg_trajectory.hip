@@ -19,14 +19,6 @@
 
 #include "mg_internal.h"
 
-struct mg_trajectory {
-    mg_primitive *prim = nullptr;
-    int32_t n_seg = 0, granularity = 1000, rows = 0;
-    double *d_poly = nullptr;    // [n_seg][4][3]: point(t) = ((A0 t + A1) t + A2) t + A3 on a segment; then the last control point [3]
-    double *d_E = nullptr;       // [rows][L]: root coefficient rows (i * 3 + d), then the first control point's root quaternion (4 rows)
-    double *d_mean = nullptr;    // [rows]
-};
-
 struct mg_traj_args {
     const double *poly, *E, *mean;
     const void *lat;
@@ -207,6 +199,7 @@ extern "C" void mg_trajectory_destroy(mg_trajectory *t) {
     (void)hipFree(t->d_poly);
     (void)hipFree(t->d_E);
     (void)hipFree(t->d_mean);
+    (void)hipFree(t->d_arc);
     delete t;
 }
 
@@ -259,7 +252,31 @@ extern "C" int mg_trajectory_create(mg_primitive *p, const double *cp, int32_t n
             mean[row] = e == 0 ? 1.0 : 0.0;
         }
     }
+    // the arc-length parameterisation (splines/arc_length_map.py:45-71): the polyline over granularity + 1 samples, accumulated and
+    // normalised -- what the constraints that look targets up BY ARC LENGTH search (mg_frame_constraints.hip)
+    std::vector<double> arc((size_t)granularity + 1, 0.0);
+    {
+        auto point = [&](double u, double *q) {
+            const double scaled = t->n_seg * u;
+            int index = (int)std::floor(scaled);
+            if (index >= t->n_seg) { for (int d = 0; d < 3; d++) q[d] = poly[(size_t)t->n_seg * 12 + d]; return; }
+            const double tt = scaled - index;
+            const double *A = &poly[(size_t)index * 12];
+            for (int d = 0; d < 3; d++) q[d] = ((A[d] * tt + A[3 + d]) * tt + A[6 + d]) * tt + A[9 + d];
+        };
+        double last[3], cur[3], acc = 0.0;
+        point(0.0, last);
+        for (int k = 1; k <= granularity; k++) {
+            point(k / (double)granularity, cur);
+            acc += std::sqrt((cur[0] - last[0]) * (cur[0] - last[0]) + (cur[1] - last[1]) * (cur[1] - last[1]) + (cur[2] - last[2]) * (cur[2] - last[2]));
+            arc[(size_t)k] = acc;
+            for (int d = 0; d < 3; d++) last[d] = cur[d];
+        }
+        t->full_arc = acc;
+        if (acc > 0.0) for (double &v : arc) v /= acc;
+    }
     int rc = mg_traj_upload(poly, &t->d_poly);
+    if (rc == MG_OK) rc = mg_traj_upload(arc, &t->d_arc);
     if (rc == MG_OK) rc = mg_traj_upload(E, &t->d_E);
     if (rc == MG_OK) rc = mg_traj_upload(mean, &t->d_mean);
     if (rc != MG_OK) { mg_trajectory_destroy(t); return rc; }

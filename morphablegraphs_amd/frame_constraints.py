@@ -2,13 +2,16 @@
 constraints/spatial_constraints/): trajectory constraints on joints other than the root, trajectory sets, discrete and local
 trajectories, collision-avoidance position constraints -- and the local joint-rotation constraint, which reads one frame.
 
-The fused keyframe scorer never materialises frames; these constraints need them.  The device does the heavy part for the
-whole batch in three launches -- float64 back projection of every candidate, forward kinematics of the wanted joints in every
-frame (`_capi.Primitive.joint_tracks`: mg_back_project_frames_f64 + mg_joint_positions), and, for trajectory constraints, the
-monotone closest-point search over the tracks (mg_score_trajectory_points) -- and only (n, T, joints, 3) positions come back;
-the constraints' own arithmetic (minimum over frames, arc-length look-ups, averages) is a few vectorised NumPy lines per
-type, restated from the reference line by line.  The candidate's alignment to the previous motion (rotation about y and xz
-translation per candidate, the same closed form the scorer applies) is applied to the tracks here.
+The fused keyframe scorer never materialises frames; these constraints need them, and everything about them happens on the
+device, for the whole batch at once:
+  mg_back_project_frames_f64   float64 frames of every candidate at the times the constraint reads
+  mg_score_constraint_residuals + mg_align_frames
+                               the candidate's own aligning transform (rotation about y, xz translation: the closed form the
+                               fused scorer applies), derived from its first control point and applied to its frames
+  mg_joint_positions           forward kinematics of the wanted joints in every frame -> (n, T, joints, 3) tracks
+  mg_score_trajectory_points   TrajectoryConstraint on any joint: the monotone closest-point search over a track
+  mg_score_frame_constraint    the other classes: running minimum / arc length / averages, one lane per candidate
+Only the (n,) errors and, when asked for, the residual vectors come back.
 
 Device forms (what candidate_scoring.constraints_to_device_form makes of the reference objects):
   {"type": "frame_joint_trajectory", "joint", "control_points", "min_u", "granularity", "weight"}
@@ -25,13 +28,14 @@ Device forms (what candidate_scoring.constraints_to_device_form makes of the ref
   {"type": "frame_joint_rotation", "joint_index", "quaternion" (w, x, y, z), "frame_idx", "weight"}
         JointRotationConstraint -- keyframe_constraints/joint_rotation_constraint.py:55-72
 
-PARITY UNPINNED where forward kinematics and alignment are (anim_utils); the target splines are pinned
-(tests/golden/trajectory_spline.npz).  There is no CPU fallback: the tracks come from the GPU or the call raises.
+PARITY UNPINNED where forward kinematics and alignment are (anim_utils); the target splines and their arc-length look-up are
+pinned (tests/golden/trajectory_spline.npz).  There is no CPU fallback: without the library and a GPU every call raises.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _capi
-from .splines import CatmullRomPath
 
 FRAME_TYPES = ("frame_joint_trajectory", "frame_ca_position", "frame_discrete_trajectory", "frame_local_trajectory",
                "frame_trajectory_set", "frame_joint_rotation")
@@ -58,163 +62,198 @@ def _skeleton_or_root(skeleton):
     return _ROOT_ONLY
 
 
-def candidate_transforms(prim, S, skeleton, alignment):
-    """The aligning transform of every candidate as the scorer derives it (mg_candidate_alignment): (cos, sin, tx, tz, ty),
-    each (n,), or None in local coordinates.  The candidate's heading and root position in its FIRST control point come from
-    the device (value constraints at t = 0: a clamped spline's first control point is its value there)."""
-    if alignment is None:
-        return None
-    joint = alignment.get("joint", 0)
-    ref_dir = tuple(alignment.get("ref_dir", (0.0, 0.0, 1.0)))
-    start_pose = joint == _capi.MG_ALIGN_START_POSE
-    probes = [{"type": "value_position", "t": 0.0, "weight": 1.0, "axis": 0}, {"type": "value_position", "t": 0.0, "weight": 1.0, "axis": 2}]
-    if not start_pose:
-        probes += [{"type": "value_heading", "t": 0.0, "weight": 1.0, "axis": 0, "joint": joint, "ref_dir": ref_dir},
-                   {"type": "value_heading", "t": 0.0, "weight": 1.0, "axis": 2, "joint": joint, "ref_dir": ref_dir}]
-    from .candidate_scoring import cached_constraint_set
-    v = prim.score_constraint_residuals(cached_constraint_set(prim, probes, skeleton, None), S)
-    p0x, p0z = v[:, 0], v[:, 1]
-    h = np.asarray(alignment["heading"], dtype=np.float64)
-    h = h / np.linalg.norm(h)
-    if start_pose:
-        c, s = np.full(len(v), h[0]), np.full(len(v), h[1])
-        ty = np.full(len(v), float(alignment["position"][1]))
-    else:
-        bx, bz = v[:, 2], v[:, 3]
-        c, s = h[0] * bx + h[1] * bz, h[0] * bz - h[1] * bx
-        ty = np.zeros(len(v))
-    tx = float(alignment["position"][0]) - (c * p0x + s * p0z)
-    tz = float(alignment["position"][2]) - (c * p0z - s * p0x)
-    return c, s, tx, tz, ty
+class _Batch(object):
+    """The candidates of one scoring call on the device, and what has been derived from them so far: aligned float64 frames per
+    set of times, joint tracks per (times, joints).  close() frees everything."""
+
+    def __init__(self, prim, S, skeleton, alignment):
+        self.prim, self.ctx, self.lib = prim, prim.ctx, prim.lib
+        self.S = _capi._latents(S)
+        self.n = len(self.S)
+        self.skeleton, self.alignment = skeleton, alignment
+        self.d_S = self.ctx.upload(self.S)
+        self._frames, self._tracks, self._vals, self._buffers = {}, {}, None, [self.d_S]
+
+    def close(self):
+        for b in self._buffers:
+            b.free()
+        self._buffers = []
+
+    def _malloc(self, n_bytes):
+        b = self.ctx.malloc(max(int(n_bytes), 8))
+        self._buffers.append(b)
+        return b
+
+    def _alignment_values(self):
+        """(n, 2 | 4) on the device: every candidate's root position (x, z) [and heading (x, z)] in its FIRST control point (a clamped
+        spline's value at t = 0) -- what its aligning transform is derived from"""
+        if self._vals is None:
+            al = self.alignment
+            joint = al.get("joint", 0)
+            probes = [{"type": "value_position", "t": 0.0, "weight": 1.0, "axis": 0}, {"type": "value_position", "t": 0.0, "weight": 1.0, "axis": 2}]
+            if joint != _capi.MG_ALIGN_START_POSE:
+                ref_dir = tuple(al.get("ref_dir", (0.0, 0.0, 1.0)))
+                probes += [{"type": "value_heading", "t": 0.0, "weight": 1.0, "axis": 0, "joint": joint, "ref_dir": ref_dir},
+                           {"type": "value_heading", "t": 0.0, "weight": 1.0, "axis": 2, "joint": joint, "ref_dir": ref_dir}]
+            from .candidate_scoring import cached_constraint_set
+            cset = cached_constraint_set(self.prim, probes, self.skeleton, None)
+            d_v = self._malloc(self.n * len(probes) * 8)
+            _capi._check(self.lib.mg_score_constraint_residuals(self.prim.handle, cset.handle, self.d_S.ptr, _capi._dtype_code(self.S), self.n,
+                                                                self.S.shape[1], d_v.ptr))
+            self._vals = (d_v, len(probes))
+        return self._vals
+
+    def frames(self, times):
+        """(device buffer (n, T, n_dim) float64, T): the candidates' frames at `times` (canonical times; None = the canonical grid of
+        get_motion_vector()), aligned like the candidates"""
+        key = None if times is None else tuple(float(t) for t in times)
+        if key not in self._frames:
+            prim = self.prim
+            grid = None if times is None else prim.time_grid(np.asarray(times, dtype=np.float64))
+            try:
+                T = prim._grid_size(grid)
+                d_f = self._malloc(self.n * T * prim.n_dim * 8)
+                _capi._check(self.lib.mg_back_project_frames_f64(prim.handle, prim._grid_handle(grid), self.d_S.ptr, _capi._dtype_code(self.S), self.n,
+                                                                 self.S.shape[1], d_f.ptr))
+            finally:
+                if grid is not None:
+                    self.ctx.synchronize()      # the launch reads the grid's tables
+                    grid.close()
+            if self.alignment is not None:
+                d_v, nv = self._alignment_values()
+                al = _capi.ConstraintSet._marshal_alignment(self.alignment, self.skeleton)
+                _capi._check(self.lib.mg_align_frames(prim.handle, d_f.ptr, self.n, T, d_v.ptr, nv, C.byref(al)))
+            self._frames[key] = (d_f, T)
+        return self._frames[key]
+
+    def tracks(self, joints, times=None):
+        """(device buffer (n, T, len(joints), 3) float64, T): the joints' global positions in every frame"""
+        sk = _skeleton_or_root(self.skeleton)
+        if self.skeleton is None:
+            if any(j not in ("root", 0, None) for j in joints):
+                raise NotImplementedError("per-frame constraints on joints %r need a skeleton (hip_skeleton); without one only the root's "
+                                          "path (joint 0) exists" % (list(joints),))
+            joints = [0] * len(joints)
+        key = (None if times is None else tuple(float(t) for t in times), tuple(sk.index(j) for j in joints))
+        if key not in self._tracks:
+            d_f, T = self.frames(times)
+            idx = np.ascontiguousarray(key[1], dtype=np.int32)
+            d_o = self._malloc(self.n * T * len(idx) * 3 * 8)
+            d = sk.desc()
+            _capi._check(self.lib.mg_joint_positions(self.ctx.handle, C.byref(d), idx.ctypes.data_as(C.c_void_p), len(idx), d_f.ptr, self.n * T,
+                                                     self.prim.n_dim, d_o.ptr))
+            self._tracks[key] = (d_o, T)
+        return self._tracks[key]
 
 
-def aligned_tracks(prim, S, skeleton, joints, alignment, times=None):
-    """(n, T, len(joints), 3): the joints' global positions in every frame (times: canonical times, None = the canonical grid
-    of get_motion_vector()), aligned like the candidate"""
-    sk = _skeleton_or_root(skeleton)
-    if skeleton is None:
-        if any(j not in ("root", 0, None) for j in joints):
-            raise NotImplementedError("per-frame constraints on joints %r need a skeleton (hip_skeleton); without one only the root's "
-                                      "path (joint 0) exists" % (list(joints),))
-        joints = [0] * len(joints)
-    grid = None if times is None else prim.time_grid(np.asarray(times, dtype=np.float64))
+def _score(batch, desc, d_tracks, T, J, d_err, accumulate, want_residuals):
+    """one mg_score_frame_constraint launch; the residual vectors (n, m) downloaded when wanted"""
+    lib, n = batch.lib, batch.n
+    m = lib.mg_frame_constraint_width(C.byref(desc), T)
+    d_res = batch._malloc(n * m * 8) if want_residuals else None
+    _capi._check(lib.mg_score_frame_constraint(batch.prim.handle, C.byref(desc), d_tracks.ptr, n, T, J, d_err.ptr, 1 if accumulate else 0,
+                                               d_res.ptr if d_res is not None else None))
+    return batch.ctx.download(d_res, (n, m), np.float64) if want_residuals else None
+
+
+def _add_frame_constraint(batch, c, d_err, accumulate, want_residuals):
+    """Add (or write) constraint c's weighted errors of the batch to d_err (n,) on the device; the residual vectors when wanted."""
+    from .candidate_scoring import cached_trajectory
+    prim = batch.prim
+    kind, w, F = c["type"], float(c.get("weight", 1.0)), prim.n_canonical_frames
+
+    def trajectory_of(t):
+        return cached_trajectory(prim, {"type": "trajectory", "control_points": t["control_points"], "granularity": t.get("granularity", 1000)})
+    if kind == "frame_joint_trajectory":
+        d_tr, T = batch.tracks([c["joint"]])
+        d_res = batch._malloc(batch.n * T * 8) if want_residuals else None
+        _capi._check(batch.lib.mg_score_trajectory_points(prim.handle, trajectory_of(c).handle, d_tr.ptr, batch.n, T, float(c.get("min_u", 0.0)), w,
+                                                          d_err.ptr, 1 if accumulate else 0, d_res.ptr if d_res is not None else None))
+        return batch.ctx.download(d_res, (batch.n, T), np.float64) if want_residuals else None
+    desc = _capi.FrameConstraintDesc()
+    desc.weight, desc.n_joints = w, 1
+    keep = []   # what the descriptor points to must outlive the launch
+    if kind == "frame_ca_position":
+        nf = int(c.get("n_frames", F))
+        desc.type, desc.n_frames = _capi.MG_FRAME_CA_POSITION, nf
+        for a in range(3):
+            t = c["target"][a]
+            on = t is not None and not (isinstance(t, float) and np.isnan(t))
+            desc.axis_on[a], desc.target[a] = (1, float(t)) if on else (0, 0.0)
+        d_tr, T = batch.tracks([c["joint"]], times=np.arange(nf, dtype=np.float64))      # aligned_spline.evaluate(i), i = 0 .. n_canonical_frames - 1
+        return _score(batch, desc, d_tr, T, 1, d_err, accumulate, want_residuals)
+    if kind == "frame_discrete_trajectory":
+        pts = np.ascontiguousarray(np.asarray(c["points"], dtype=np.float64).reshape(-1, 3))
+        d_p = batch.ctx.upload(pts) if len(pts) else None
+        if d_p is not None:
+            batch._buffers.append(d_p)
+        desc.type, desc.n_points, desc.points_dev = _capi.MG_FRAME_DISCRETE_TRAJECTORY, len(pts), (d_p.ptr.value if d_p is not None else None)
+        free = set(int(a) for a in (c.get("unconstrained") or ()))
+        for a in range(3):
+            desc.axis_on[a] = 0 if a in free else 1
+        d_tr, T = batch.tracks([c["joint"]])
+        return _score(batch, desc, d_tr, T, 1, d_err, accumulate, want_residuals)
+    if kind == "frame_local_trajectory":
+        nf = int(c.get("n_frames", F))
+        desc.type, desc.n_frames, desc.start_arc = _capi.MG_FRAME_LOCAL_TRAJECTORY, nf, float(c.get("start_t", 0.0))
+        keep.append(trajectory_of(c))
+        desc.trajectories[0] = keep[-1].handle.value
+        d_tr, T = batch.tracks([c["joint"]], times=np.arange(nf, dtype=np.float64))
+        return _score(batch, desc, d_tr, T, 1, d_err, accumulate, want_residuals)
+    if kind == "frame_trajectory_set":
+        joints = list(c["joints"])
+        if not 1 <= len(joints) <= _capi.MG_FRAME_MAX_JOINTS or len(c["trajectories"]) != len(joints):
+            raise ValueError("a trajectory set takes 1..%d joints with one trajectory each" % _capi.MG_FRAME_MAX_JOINTS)
+        desc.type, desc.n_frames, desc.n_joints = _capi.MG_FRAME_TRAJECTORY_SET, int(c.get("n_frames", F)), len(joints)
+        arcs = c.get("arc_lengths", [0.0] * len(joints))
+        for j, t in enumerate(c["trajectories"]):
+            keep.append(trajectory_of(t))
+            desc.trajectories[j] = keep[-1].handle.value
+            desc.arc0[j] = float(arcs[j])
+            rs, re = t.get("range_start"), t.get("range_end")
+            desc.has_range[j] = 0 if rs is None else 1
+            desc.range_start[j], desc.range_end[j] = (0.0, 0.0) if rs is None else (float(rs), float(re))
+        d_tr, T = batch.tracks(joints)                                                     # the frames of get_motion_vector()
+        return _score(batch, desc, d_tr, T, len(joints), d_err, accumulate, want_residuals)
+    if kind == "frame_joint_rotation":
+        desc.type, desc.quat_channel = _capi.MG_FRAME_JOINT_ROTATION, 3 + 4 * int(c["joint_index"])
+        for e in range(4):
+            desc.quaternion[e] = float(c["quaternion"][e])
+        d_f, T = batch.frames([float(c["frame_idx"])])                                     # aligned_spline.evaluate(frame_idx)
+        return _score(batch, desc, d_f, T, prim.n_dim, d_err, accumulate, want_residuals)
+    raise ValueError("unknown per-frame constraint %r" % (kind,))
+
+
+def add_frame_constraints_dev(prim, S, frame_list, skeleton, alignment, d_err, accumulate=True, residuals=False):
+    """Add the per-frame constraints' weighted errors of candidates S (host latents) to d_err (n,) float64 on the device (accumulate
+    False: the first one overwrites).  Returns the list of residual blocks (n, m_c) when residuals is set."""
+    batch = _Batch(prim, S, skeleton, alignment)
     try:
-        tr = prim.joint_tracks(sk, joints, S, grid)
+        blocks = []
+        for i, c in enumerate(frame_list):
+            blocks.append(_add_frame_constraint(batch, c, d_err, accumulate or i > 0, residuals))
+        batch.ctx.synchronize()
+        return blocks if residuals else None
     finally:
-        if grid is not None:
-            grid.close()
-    tf = candidate_transforms(prim, S, skeleton, alignment)
-    if tf is not None:
-        c, s, tx, tz, ty = (a[:, None, None] for a in tf)
-        x, z = tr[..., 0].copy(), tr[..., 2].copy()
-        tr[..., 0] = c * x + s * z + tx
-        tr[..., 2] = c * z - s * x + tz
-        tr[..., 1] += ty
-    return tr
-
-
-def _masked_distance(target, p):
-    """GlobalTransformConstraint._point_distance: axes whose target is None are ignored"""
-    d2 = np.zeros(p.shape[:-1])
-    for a in range(3):
-        if target[a] is not None and not (isinstance(target[a], float) and np.isnan(target[a])):
-            d2 = d2 + (float(target[a]) - p[..., a]) ** 2
-    return np.sqrt(d2)
+        batch.close()
 
 
 def frame_constraint_residuals(prim, S, c, skeleton=None, alignment=None):
     """The constraint's residual vector for every candidate, times its weight, and what MotionPrimitiveConstraints.evaluate adds
     for it: ((n, m) residuals, (n,) errors)."""
-    S = np.asarray(S)
-    n = len(S)
-    w = float(c.get("weight", 1.0))
-    kind = c["type"]
-    F = prim.n_canonical_frames
-    if kind == "frame_joint_trajectory":
-        tr = aligned_tracks(prim, S, skeleton, [c["joint"]], alignment)[:, :, 0, :]
-        from .candidate_scoring import cached_trajectory
-        err, res = prim.score_trajectory_points(cached_trajectory(prim, {"type": "trajectory", "control_points": c["control_points"],
-                                                                         "granularity": c.get("granularity", 1000)}),
-                                                tr, c.get("min_u", 0.0), w, residuals=True)
-        return res, err
-    if kind == "frame_ca_position":
-        nf = int(c.get("n_frames", F))
-        tr = aligned_tracks(prim, S, skeleton, [c["joint"]], alignment, times=np.arange(nf, dtype=np.float64))[:, :, 0, :]
-        err = w * _masked_distance(c["target"], tr).min(axis=1)            # the closest the joint ever comes (:37-38)
-        return err[:, None], err
-    if kind == "frame_discrete_trajectory":
-        tr = aligned_tracks(prim, S, skeleton, [c["joint"]], alignment)[:, :, 0, :]
-        pts = np.asarray(c["points"], dtype=np.float64)
-        T, m = tr.shape[1], min(len(pts), tr.shape[1])
-        keep = np.ones(3)
-        for a in c.get("unconstrained", ()) or ():
-            keep[int(a)] = 0.0
-        res = np.zeros((n, T))
-        res[:, :m] = np.linalg.norm((tr[:, :m] - pts[None, :m]) * keep, axis=2)
-        return w * res, w * res.mean(axis=1)                               # np.average over all frames, zeros included (:66-90)
-    if kind == "frame_local_trajectory":
-        nf = int(c.get("n_frames", F))
-        tr = aligned_tracks(prim, S, skeleton, [c["joint"]], alignment, times=np.arange(nf, dtype=np.float64))[:, :, 0, :]
-        path = CatmullRomPath(c["control_points"], c.get("granularity", 1000))
-        steps = np.linalg.norm(tr[:, 1:] - tr[:, :-1], axis=2)
-        arc = float(c.get("start_t", 0.0)) + np.concatenate([np.zeros((n, 1)), np.cumsum(steps, axis=1)], axis=1)
-        target = path.point_by_absolute_arc_length(arc.reshape(-1)).reshape(n, nf, -1)
-        res = (target[..., 0] - tr[..., 0]) ** 2 + (target[..., 2] - tr[..., 2]) ** 2          # squared xz distance (:61-73)
-        return w * res, w * res.sum(axis=1)
-    if kind == "frame_trajectory_set":
-        joints = list(c["joints"])
-        nf = int(c.get("n_frames", F))
-        tr = aligned_tracks(prim, S, skeleton, joints, alignment)[:, :nf]                          # frames of get_motion_vector()
-        paths = [CatmullRomPath(t["control_points"], t.get("granularity", 1000)) for t in c["trajectories"]]
-        steps = np.linalg.norm(tr[:, 1:] - tr[:, :-1], axis=3)                                      # (n, nf - 1, J)
-        # the reference adds a frame's step AFTER it has looked the frame's targets up (:98-102): frames 0 and 1 use the initial
-        # arc lengths, frame i >= 2 the path walked up to frame i - 1
-        walked = np.concatenate([np.zeros((n, 2, len(joints))), np.cumsum(steps, axis=1)[:, :max(nf - 2, 0)]], axis=1)[:, :nf]
-        arc = np.asarray(c.get("arc_lengths", np.zeros(len(joints))), dtype=np.float64)[None, None, :] + walked
-        active = np.zeros((n, nf), dtype=bool)
-        targets = np.empty_like(tr)
-        for j, (path, t) in enumerate(zip(paths, c["trajectories"])):
-            rs, re = t.get("range_start"), t.get("range_end")
-            if rs is not None:
-                active |= (arc[:, :, j] >= rs) & (arc[:, :, j] <= re)
-            targets[:, :, j, :] = path.point_by_absolute_arc_length(arc[:, :, j].reshape(-1)).reshape(n, nf, -1)
-        # np.average over the LIST of positions is the mean of all their components: a scalar centre (:93-96)
-        res = np.abs(tr.reshape(n, nf, -1).mean(axis=2) - targets.reshape(n, nf, -1).mean(axis=2)) * active
-        return w * res, w * res.mean(axis=1)                                                         # np.average of the n_canonical_frames entries
-    if kind == "frame_joint_rotation":
-        grid = prim.time_grid(np.array([float(c["frame_idx"])]))
-        try:
-            fr = prim.back_project_frames_f64(S, grid)[:, 0, :]
-        finally:
-            grid.close()
-        ji = int(c["joint_index"])
-        q = fr[:, 3 + 4 * ji:7 + 4 * ji].copy()
-        if ji == 0:
-            tf = candidate_transforms(prim, S, skeleton, alignment)
-            if tf is not None:                                               # the root's quaternion turns with the candidate
-                phi = np.arctan2(tf[1], tf[0])
-                aw, ay = np.cos(0.5 * phi), np.sin(0.5 * phi)
-                qw, qx, qy, qz = q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy(), q[:, 3].copy()
-                q[:, 0], q[:, 1], q[:, 2], q[:, 3] = aw * qw - ay * qy, aw * qx + ay * qz, aw * qy + ay * qw, aw * qz - ay * qx
-        q /= np.linalg.norm(q, axis=1, keepdims=True)
-        t = np.asarray(c["quaternion"], dtype=np.float64)
-        t = t / np.linalg.norm(t)
-
-        def rotmat(qq):
-            ww, x, y, z = qq[..., 0], qq[..., 1], qq[..., 2], qq[..., 3]
-            return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww),
-                             2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww),
-                             2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)], axis=-1)
-        err = w * np.linalg.norm(rotmat(t)[None, :] - rotmat(q), axis=1)     # Frobenius norm of the matrix difference (:63-69)
-        return err[:, None], err
-    raise ValueError("unknown per-frame constraint %r" % (kind,))
+    err, blocks = frame_constraints_errors(prim, S, [c], skeleton, alignment)
+    return blocks[0], err
 
 
 def frame_constraints_errors(prim, S, frame_list, skeleton=None, alignment=None):
     """(n,) the sum of the per-frame constraints' errors, and their residual columns side by side"""
-    total, blocks = np.zeros(len(S)), []
-    for c in frame_list:
-        res, err = frame_constraint_residuals(prim, S, c, skeleton, alignment)
-        total = total + err
-        blocks.append(res)
-    return total, blocks
+    S = _capi._latents(S)
+    n = len(S)
+    if n == 0 or not frame_list:
+        return np.zeros(n), [np.zeros((n, 0)) for _ in frame_list]
+    d_err = prim.ctx.malloc(n * 8)
+    try:
+        blocks = add_frame_constraints_dev(prim, S, frame_list, skeleton, alignment, d_err, accumulate=False, residuals=True)
+        return prim.ctx.download(d_err, (n,), np.float64), blocks
+    finally:
+        d_err.free()

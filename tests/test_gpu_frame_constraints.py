@@ -152,3 +152,32 @@ def test_per_frame_constraints_need_a_skeleton_for_other_joints():
         fr = orc.spline_frames(op.knots, coeffs, np.arange(op.n_canonical_frames, dtype=np.float64))
         ref.append(min(np.hypot(80.0 - f[0], 20.0 - f[2]) for f in fr))
     np.testing.assert_allclose(err, ref, rtol=1e-10)
+
+
+def test_arc_length_look_up_on_the_device_against_the_reference_vectors():
+    """query_point_by_absolute_arc_length on the device (mg_score_frame_constraint's LOCAL_TRAJECTORY branch) against the points the
+    reference's own ParameterizedSpline returned (tests/golden/trajectory_spline.npz): a track that climbs straight up in y walks
+    exactly the arc lengths of the vectors, so the residual of frame f is the squared xz distance of the looked-up point from the
+    y axis."""
+    import ctypes as C
+    from conftest import load_golden
+    from morphablegraphs_amd.candidate_scoring import cached_trajectory
+    g = load_golden("trajectory_spline")
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=1)
+    prim, ctx = mp._prim, mp._prim.ctx
+    for ci in range(int(g["n_cases"])):
+        order = np.argsort(g["arc_lengths_%d" % ci], kind="stable")
+        arcs, want = g["arc_lengths_%d" % ci][order], g["points_by_arc_%d" % ci][order]
+        track = np.zeros((1, len(arcs), 1, 3))
+        track[0, :, 0, 1] = arcs - arcs[0]
+        traj = cached_trajectory(prim, {"control_points": g["control_points_%d" % ci], "granularity": 1000})
+        desc = _capi.FrameConstraintDesc()
+        desc.type, desc.weight, desc.n_joints, desc.start_arc = _capi.MG_FRAME_LOCAL_TRAJECTORY, 1.0, 1, float(arcs[0])
+        desc.trajectories[0] = traj.handle.value
+        d_t, d_e, d_r = ctx.upload(track), ctx.malloc(8), ctx.malloc(len(arcs) * 8)
+        _capi._check(prim.lib.mg_score_frame_constraint(prim.handle, C.byref(desc), d_t.ptr, 1, len(arcs), 1, d_e.ptr, 0, d_r.ptr))
+        res = ctx.download(d_r, (len(arcs),), np.float64)
+        np.testing.assert_allclose(res, want[:, 0] ** 2 + want[:, 2] ** 2, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ctx.download(d_e, (1,), np.float64)[0], res.sum(), rtol=1e-12)
+        for b in (d_t, d_e, d_r):
+            b.free()
