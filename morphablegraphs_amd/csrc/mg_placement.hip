@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void mg_placement_fill_kernel(f32x4p *buf, siz
 // ... and an absolute floor for probes that fill the chip (256 tiles and more): a process can meet memory where the plain fill is
 // slow as well (fill 77 us, pattern 80 us for the bench's 404 MB: ratio 1.04, 5.0 TB/s -- against 61-63.5 us = 6.4-6.6 TB/s in
 // the fast class and 54-57 us in the best regions), which the ratio alone waves through
-#define MG_PLACED_FAST_TBPS 6.2
+#define MG_PLACED_FAST_TBPS 6.0
 static bool mg_placement_is_fast(int64_t bytes, double ratio, double pattern_us, double fast_ratio) {
     if (ratio > fast_ratio) return false;
     const int64_t cand_bytes = (int64_t)MG_PP_T * MG_PP_D * 4;
