@@ -223,7 +223,10 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *                             of the context's placed output regions, see mg_device_malloc)
  *   MG_OPT_GMM_KERNEL         mg_gmm_log_prob on the matrix pipe: 0 = by batch size, 1 = one 16-candidate tile per workgroup, fragments
  *                             from L2, 2 = persistent workgroups with the mixture's fragments in LDS (from 20 480 candidates on by
- *                             default; MG_ERR_UNSUPPORTED never: a mixture that does not fit LDS falls back to 1) -- identical results */
+ *                             default; MG_ERR_UNSUPPORTED never: a mixture that does not fit LDS falls back to 1) -- identical results
+ *   MG_OPT_SCORE_KERNEL       mg_score_constraints on the matrix pipe: 0 = by batch size, 1 = a wave per 16-candidate tile, (candidate,
+ *                             constraint) pairs on the lanes, 2 = a wave per 64 candidates, a lane per candidate (from 49 152
+ *                             candidates on by default) -- identical results */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
@@ -234,7 +237,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_OPTIONS_STEP 7
 #define MG_OPT_PLAIN_MALLOC 8
 #define MG_OPT_GMM_KERNEL 9
-#define MG_OPT_COUNT 10
+#define MG_OPT_SCORE_KERNEL 10
+#define MG_OPT_COUNT 11
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`

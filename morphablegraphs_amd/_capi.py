@@ -24,7 +24,8 @@ MG_OPT_PLACED_FAST_PCT = 6   # mg_device_malloc_placed's acceptance ratio in per
 MG_OPT_OPTIONS_STEP = 7      # mg_options_step: 0 = one launch per step where possible, 1 = a chain of launches per option
 MG_OPT_PLAIN_MALLOC = 8      # 1 = mg_device_malloc is one hipMalloc whatever the size (no placed output regions)
 MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile per workgroup, 2 = fragments resident in LDS
-MG_OPT_COUNT = 10
+MG_OPT_SCORE_KERNEL = 10     # mg_score_constraints: 0 = by batch size, 1 = a wave per 16 candidates, 2 = a wave per 64 candidates
+MG_OPT_COUNT = 11
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 MG_CONSTRAINT_VALUE_POSITION, MG_CONSTRAINT_VALUE_HEADING = 7, 8   # values of the aligned motion, not errors (chained graph-walk steps)

@@ -108,13 +108,86 @@ __global__ __launch_bounds__(256) void mg_score_mfma_kernel(mg_score_args a, con
     }
 }
 
+// The same for large batches: a wave owns FOUR tiles, 64 candidates.  The matrix part is the same chains (four tiles' latents
+// requested up front); in the residual part a LANE is a candidate and walks the constraints in order -- every lane busy and all
+// lanes in the same constraint's code at the same time, where the kernel above has (candidate, constraint) pairs on the lanes: with
+// two constraints of different kinds half its lanes idle and the two kinds' float64 arithmetic (square roots, arc tangents) runs one
+// after the other at a quarter of the wave each.  Same residual function, same order of the sum: the same bits.
+template <int KK, bool LAT_F64, bool OUT_F64>
+__global__ __launch_bounds__(256) void mg_score_mfma64_kernel(mg_score_args a, const double *__restrict__ Wpack, const double *__restrict__ bpad,
+                                                             const int RT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = lane & 15, g = lane >> 4;
+    const int vs = RT * 16 + 1;
+    double *vals = (double *)smem + (size_t)wave * (64 * vs);            // [64][vs]
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (b0 >= a.B) return;
+    const int ncand = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    typename mg_gmm_xt<LAT_F64>::type xf[4][KK];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int nt = ncand - 16 * t;                                   // candidates of tile t (a tile past the end re-reads the last row)
+        mg_gmm_load_x<KK, LAT_F64>(xf[t], a.lat, nt > 0 ? b0 + 16 * t : b0, nt > 0 ? (nt < 16 ? nt : 16) : 1, a.ld, a.L, cl, g);
+    }
+    for (int rt = 0; rt < RT; rt++) {
+        const double *wp = Wpack + ((size_t)rt * KK) * 64 + lane;
+        const double c0 = bpad[rt * 16 + cl];
+        mg_f64x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = {c0, c0, c0, c0};
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            const double w = wp[kk * 64];
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[t][kk], w, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) vals[(16 * t + g + 4 * r) * vs + rt * 16 + cl] = acc[t][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < ncand) {
+        const double *v = vals + lane * vs;
+        double err = 0.0;
+        for (int c = 0; c < a.n; c++) {
+            const double r = mg_constraint_residual(a, c, [&](int row) { return v[row]; }, b0 + lane);
+            if (a.res) a.res[(b0 + lane) * a.n + c] = r;
+            err += r;
+        }
+        if (a.out) {
+            if (OUT_F64) ((double *)a.out)[b0 + lane] = err;
+            else ((float *)a.out)[b0 + lane] = (float)err;
+        }
+    }
+}
+
+#define MG_SCORE_WIDE_MIN_B 49152   // measured crossover (tools/probes/score_kernel_ab.py): below, the tile kernel's eight waves per SIMD hide more latency than its idle lanes cost
+
 template <int KK>
 static int mg_launch_score_mfma_kk(mg_primitive *p, const mg_constraint_set *cs, const mg_score_args &a, bool lf, bool of) {
+    hipStream_t st = p->ctx->stream;
+    const int kernel_opt = p->ctx->opt[MG_OPT_SCORE_KERNEL];   // 0: by batch size, 1: 16-candidate waves, 2: 64-candidate waves
+    const bool wide = kernel_opt == 2 || (kernel_opt == 0 && a.B >= MG_SCORE_WIDE_MIN_B);
+    if (wide) {
+        const size_t lds = (size_t)4 * 64 * (cs->RT * 16 + 1) * 8;
+        if (lds <= 64 * 1024) {
+            const int64_t grid = (a.B + 255) / 256;
+            if (grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
+            if (lf && of) hipLaunchKernelGGL((mg_score_mfma64_kernel<KK, true, true>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+            else if (lf) hipLaunchKernelGGL((mg_score_mfma64_kernel<KK, true, false>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+            else if (of) hipLaunchKernelGGL((mg_score_mfma64_kernel<KK, false, true>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+            else hipLaunchKernelGGL((mg_score_mfma64_kernel<KK, false, false>), dim3((int)grid), dim3(256), lds, st, a, cs->d_Wpack, cs->d_bpad, cs->RT);
+            MG_HIP_CHECK(hipGetLastError());
+            return MG_OK;
+        }
+    }
     const size_t lds = (size_t)4 * (16 * (cs->RT * 16 + 1) + (size_t)std::max(cs->n, 1) * 16) * 8;
     if (lds > 150 * 1024) return MG_ERR_UNSUPPORTED;
     const int64_t grid = (a.B + 63) / 64;
     if (grid > 0x7fffffff) return MG_ERR_UNSUPPORTED;
-    hipStream_t st = p->ctx->stream;
     if (lds > 64 * 1024) {
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_mfma_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_score_mfma_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -947,6 +947,42 @@ def test_start_pose_alignment_branch(ctx):
     prim.close()
 
 
+def test_wide_scoring_kernel_is_bit_identical(ctx):
+    """mg_score_constraints' large-batch kernel (a wave per 64 candidates, a lane per candidate walking the constraints in order)
+    against the tile kernel (a wave per 16 candidates, (candidate, constraint) pairs on the lanes) and the VALU kernel: the same
+    errors and residual matrices bit for bit, for ragged batches, both latent types, forward-kinematics constraints and candidates
+    aligned to a start pose."""
+    from morphablegraphs_amd.candidate_scoring import alignment_from_start_pose
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    prim = _capi.Primitive(ctx, synthetic.make_walk_primitive(seed=0))
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [30.0, None, -20.0]},
+            {"type": "direction", "t": 155.0, "weight": 0.3, "target": [0.2, 1.0]},
+            {"type": "joint_position", "joint": "LeftHand_EndSite", "t": 100.0, "weight": 2.0, "target": [40.0, 120.0, -10.0]},
+            {"type": "joint_orientation", "joint": "Hips", "t": 20.0, "weight": 1.0, "orientation": [0.9, 0.1, 0.3, -0.2]},
+            {"type": "look_at", "joint": "Head", "t": 77.5, "weight": 0.7, "target": [100.0, 150.0, 30.0]}]
+    rng = np.random.default_rng(5)
+    for alignment in (None, alignment_from_start_pose({"position": [55.0, 7.5, -80.0], "orientation": [0.0, 37.5, 0.0]})):
+        cset = _capi.ConstraintSet(prim, cons, sk, alignment=alignment)
+        for B in (1, 63, 64, 65, 4099, 40000):
+            S = rng.standard_normal((B, 40))
+            for dt in (np.float32, np.float64):
+                out = []
+                for mode in (1, 2):
+                    ctx.set_option(_capi.MG_OPT_SCORE_KERNEL, mode)
+                    out.append((prim.score_constraints(cset, S.astype(dt), dtype=np.float64), prim.score_constraints(cset, S.astype(dt), dtype=np.float32),
+                                prim.score_constraint_residuals(cset, S.astype(dt))))
+                ctx.set_option(_capi.MG_OPT_SCORE_KERNEL, 0)
+                for a, b in zip(out[0], out[1]):
+                    np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8))
+                if B == 4099:
+                    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 1)
+                    np.testing.assert_array_equal(prim.score_constraint_residuals(cset, S.astype(dt)), out[1][2])
+                    ctx.set_option(_capi.MG_OPT_FORCE_VALU_SCORE, 0)
+        cset.close()
+    prim.close()
+
+
 def test_two_hand_midpoint_and_joint_orientation_constraints(ctx):
     """MG_CONSTRAINT_JOINT_MIDPOINT (first residual of TwoHandConstraint, reference two_hand_constraint.py:66-74) and
     MG_CONSTRAINT_JOINT_ORIENTATION (GlobalTransformConstraint._quaternion_distance, global_transform_constraint.py:
