@@ -297,16 +297,35 @@ class HipPrimitiveSet(object):
         plan = self._step_plan(tuple(options), n, np.dtype(dtype))
         steps = plan["steps"]
         csets = []
+        memo = plan.setdefault("memo", [None] * len(steps))
+        multinomial = np.random.multinomial
         for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
             cons = constraints_per_option[name]
             clist = cons.constraints if hasattr(cons, "constraints") else cons
-            sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
-            form = constraints_to_device_form(clist)
-            if any(is_frame_constraint(c) for c in form):
-                raise NotImplementedError("the one-launch planner step scores keyframe constraints only: option %r carries per-frame "
-                                          "constraints, score it with evaluate_samples_using_constraints" % (name,))
-            csets.append(cached_constraint_set(prim, form, sk, alignment_from_prev_frames(prev_frames, cons, sk)))
-            plan["counts"][k, :len(pvals)] = np.random.multinomial(n, pvals)
+            # A planner asks the same questions step after step: when an option's constraints are plain device-form dicts whose
+            # every value is what it was at the last step (compared value by value: callers rewrite targets in place), the set of
+            # the last step is the set of this one.  Anything else -- reference objects, a previous motion to align to -- takes the
+            # general route (device form, structure and values keys, the shared cache).
+            fp = None
+            if prev_frames is None and skeleton is None and type(clist) is list:
+                try:
+                    fp = [tuple([tuple(v) if type(v) is list else v for v in c.values()]) for c in clist]
+                except AttributeError:
+                    fp = None
+            last = memo[k]
+            if fp is not None and last is not None and last[0] == fp and last[1].handle and last[1].cached_values is last[2] and \
+                    getattr(cons, "hip_skeleton", None) is None and getattr(cons, "is_local", True):   # (cached_values: nobody else rewrote the shared set)
+                csets.append(last[1])
+            else:
+                sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
+                form = constraints_to_device_form(clist)
+                if any(is_frame_constraint(c) for c in form):
+                    raise NotImplementedError("the one-launch planner step scores keyframe constraints only: option %r carries per-frame "
+                                              "constraints, score it with evaluate_samples_using_constraints" % (name,))
+                cs = cached_constraint_set(prim, form, sk, alignment_from_prev_frames(prev_frames, cons, sk))
+                csets.append(cs)
+                memo[k] = (fp, cs, cs.cached_values) if fp is not None and all(type(c) is dict for c in clist) else None
+            plan["counts"][k, :len(pvals)] = multinomial(n, pvals)
         results = {}
         if plan["one_context"] and steps:
             # one C call, ONE launch and ONE read-back for the whole step (mg_options_step): the result records side by side
@@ -316,10 +335,11 @@ class HipPrimitiveSet(object):
                 plan["seeds"][k] = int(seed) + k
             _capi._check(steps[0][2].lib.mg_options_step(m, plan["prims"], plan["csets"], n, plan["cnts"], plan["seeds"], plan["xs"], code, plan["lds"],
                                                          plan["errs"], plan["shared"].ptr, stride, host.ctypes.data_as(C.c_void_p)))
+            rec = host[:m * stride].copy().reshape(m, stride)          # one copy: the host block is reused by the next step
+            errs = rec[:, 8:16].copy().view(np.float64)[:, 0].tolist()
+            lat = rec[:, 16:].copy().view(np.float64)                    # (m, widest L): the winners, already rounded to the caller's type
             for k, st in enumerate(steps):
-                raw = host[k * stride:k * stride + 16 + 8 * st[7]]
-                err = float(raw[8:16].view(np.float64)[0])
-                results[st[0]] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
+                results[st[0]] = (lat[k, :st[7]], errs[k])
         else:
             for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
                 _capi._check(prim.lib.mg_option_step(prim.handle, csets[k].handle, n, plan["counts"][k].ctypes.data, int(seed) + k, d_x.ptr, code, L,

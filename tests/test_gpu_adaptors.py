@@ -510,6 +510,47 @@ def test_graph_walk_step_on_device_with_one_stream_per_option():
         assert set(results2) == set(names)
 
 
+def test_planner_step_notices_constraints_rewritten_in_place():
+    """The planner step keeps the device constraint set of the previous step when an option's constraints compare equal value by
+    value (no keys, no cache look-up: half of the step's host time): a target rewritten IN PLACE between two steps, and the shared
+    set rewritten by another caller, must both be noticed."""
+    from morphablegraphs_amd.candidate_scoring import cached_constraint_set
+    prims = synthetic.make_graph_primitives(4)
+    names = [p["name"] for p in prims]
+
+    def constraints(x):
+        return {n: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [x, None, 5.0]},
+                    {"type": "direction", "t": float(p["n_canonical_frames"] - 1), "weight": 0.5, "target": [0.3, 1.0]}] for n, p in zip(names, prims)}
+
+    def step(pset, cons):
+        np.random.seed(3)
+        best, res = pset.evaluate_options_on_device(names, cons, n_samples=1024, seed=7)
+        return best, {n: (res[n][0].copy(), res[n][1]) for n in names}
+    pset, fresh = HipPrimitiveSet(prims), HipPrimitiveSet(prims)
+    cons = constraints(10.0)
+    b1, r1 = step(pset, cons)
+    b1b, r1b = step(pset, cons)                              # the remembered sets: the same answer
+    for n in names:
+        np.testing.assert_array_equal(r1[n][0], r1b[n][0])
+        assert r1[n][1] == r1b[n][1]
+    for n in names:
+        cons[n][0]["target"][0] = -35.0                      # in place: same dicts, same lists
+    b2, r2 = step(pset, cons)
+    b2f, r2f = step(fresh, constraints(-35.0))               # a set that never saw the old target
+    assert any(r2[n][1] != r1[n][1] for n in names)
+    for n in names:
+        np.testing.assert_array_equal(r2[n][0], r2f[n][0])
+        assert r2[n][1] == r2f[n][1]
+    assert b2 == b2f
+    # somebody else scores the same kind of constraints on one of the primitives with other values: the shared set is rewritten
+    other = constraints(77.0)[names[1]]
+    cached_constraint_set(pset.nodes[names[1]]._prim, other, None, None)
+    b3, r3 = step(pset, cons)
+    for n in names:
+        np.testing.assert_array_equal(r3[n][0], r2[n][0])
+        assert r3[n][1] == r2[n][1]
+
+
 def _options_step_raw(pset, names, cons, n, seed, dtype, skeleton=None, prev_frames=None):
     """One evaluate_options_on_device step; returns per option (result record, all errors, all candidates) as the device left them."""
     np.random.seed(9)
