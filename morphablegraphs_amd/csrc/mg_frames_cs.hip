@@ -300,13 +300,24 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                         } else if (!root_lane) {   // all 16 tap rows are requested before the first FMA
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
-                            const mg_tap_rows r0a = mg_quad_load<DP4>(img0 + moa, dp4), r0b = mg_quad_load<DP4>(img0 + mob, dp4);
-                            const mg_tap_rows r1a = mg_quad_load<DP4>(img1 + moa, dp4), r1b = mg_quad_load<DP4>(img1 + mob, dp4);
+                            mg_tap_rows r0a, r0b, r1a, r1b;
+                            if (MG_DBG(16384)) {   // ablation: no tap reads (the FMAs run on what is in registers anyway)
+                                const f32x4 k = {wa.x, wa.y, wb.z, wb.w};
+                                r0a = r0b = r1a = r1b = mg_tap_rows{k, k, k, k};
+                            } else {
+                                r0a = mg_quad_load<DP4>(img0 + moa, dp4); r0b = mg_quad_load<DP4>(img0 + mob, dp4);
+                                r1a = mg_quad_load<DP4>(img1 + moa, dp4); r1b = mg_quad_load<DP4>(img1 + mob, dp4);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
-                            v0a = mg_quad_fma(r0a, wa);
-                            v0b = mg_quad_fma(r0b, wb);
-                            v1a = mg_quad_fma(r1a, wa);
-                            v1b = mg_quad_fma(r1b, wb);
+                            if (MG_DBG(8192)) {   // ablation: the tap reads, no FMAs
+                                v0a = r0a.t0 + r0a.t1 * 0.f; v0b = r0b.t2; v1a = r1a.t3; v1b = r1b.t1;
+                                asm volatile("" ::"v"(r0a.t2), "v"(r0a.t3), "v"(r0b.t0), "v"(r0b.t1), "v"(r0b.t3), "v"(r1a.t0), "v"(r1a.t1), "v"(r1a.t2), "v"(r1b.t0), "v"(r1b.t2), "v"(r1b.t3));
+                            } else {
+                                v0a = mg_quad_fma(r0a, wa);
+                                v0b = mg_quad_fma(r0b, wb);
+                                v1a = mg_quad_fma(r1a, wa);
+                                v1b = mg_quad_fma(r1b, wb);
+                            }
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v0b = *(const f32x4 *)&ro0[fb_ * 4];
