@@ -222,6 +222,47 @@ def run_walk(args, rank, local_rank, world):
         import torch.distributed as dist
         n_dev = torch.cuda.device_count()
     dev_index = local_rank   # one rank per GPU of the node
+    if os.environ.get("MG_BENCH_OVERSUBSCRIBE") and not use_torch:   # rehearsal on a box with fewer GPUs than ranks: ranks share devices
+        import torch as _t
+        dev_index = local_rank % max(1, _t.cuda.device_count())
+    collective_note = None
+    if not use_torch:
+        try:
+            ctx = _capi.Context(dev_index)
+        except _capi.MGError as e:
+            raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback (%s)" % e)
+        if world > 1:
+            # The library's own RCCL communicator (librccl loaded by libmg_hip, the unique id handed over through the file
+            # rendezvous).  If it cannot be set up -- on ANY rank: the ranks tell each other -- every rank falls back to
+            # torch.distributed's communicator (`--collective torch`) and the line says so; the data path is the same kernels.
+            uid, err = b"", b""
+            if rank == 0:
+                try:
+                    uid = ctx.dist_unique_id()
+                except Exception as e:   # noqa: BLE001 -- whatever went wrong, the other ranks must hear of it
+                    err = ("rank 0: mg_dist_unique_id: %s" % e).encode()[:300]
+            uid, err0 = rdv.all_gather(uid)[0], rdv.all_gather(err)[0]
+            if not err0:
+                try:
+                    ctx.dist_init(rank, world, uid)
+                except Exception as e:   # noqa: BLE001
+                    err = ("rank %d: mg_dist_init: %s" % (rank, e)).encode()[:300]
+                errs = [e for e in rdv.all_gather(err) if e]
+                err0 = errs[0] if errs else b""
+                if err0:
+                    try:
+                        ctx.dist_finalize()
+                    except Exception:   # noqa: BLE001
+                        pass
+            if err0:
+                collective_note = "mg_dist_* could not be set up (%s): torch.distributed's communicator instead" % err0.decode(errors="replace")
+                if rank == 0:
+                    print("bench.py: " + collective_note, file=sys.stderr)
+                ctx.close()
+                use_torch = True
+                import torch
+                import torch.distributed as dist
+                n_dev = torch.cuda.device_count()
     if use_torch:
         torch.cuda.set_device(dev_index % n_dev)
         stream = torch.cuda.Stream(device=dev_index % n_dev)
@@ -232,15 +273,6 @@ def run_walk(args, rank, local_rank, world):
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index % n_dev))
         else:
             dist.init_process_group(backend)
-    else:
-        try:
-            ctx = _capi.Context(dev_index)
-        except _capi.MGError as e:
-            raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback (%s)" % e)
-        if world > 1:
-            uid = ctx.dist_unique_id() if rank == 0 else b""
-            uid = rdv.all_gather(uid)[0]
-            ctx.dist_init(rank, world, uid)
     prim = _capi.Primitive(ctx, data)
     if args.frames_kernel:
         ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, args.frames_kernel)
@@ -380,6 +412,7 @@ def run_walk(args, rank, local_rank, world):
                        "candidates_per_gpu": B, "global_candidates": world * B,
                        "collective": ("all_gather(logp) every step, %s" % ("RCCL through mg_dist_all_gather on the kernels' stream" if not use_torch
                                       else "torch.distributed %s (double-buffered, overlapped)" % backend)) if world > 1 else "none",
+                       "collective_fallback": collective_note,
                        "sharding": "contiguous candidate blocks, constants replicated",
                        "clock_ramp_steps": args.ramp_steps,
                        "output_placement": placement},

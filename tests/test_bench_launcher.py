@@ -69,3 +69,18 @@ def test_a_dead_rank_ends_the_launch_instead_of_hanging_it():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode != 0 and time.time() - t0 < 60
     assert b"rank 1 exited with 3" in p.stderr
+
+
+@pytest.mark.gpu
+def test_collective_set_up_failure_falls_back_to_torch_on_every_rank():
+    """Two ranks on ONE GPU: RCCL refuses the second rank of a device, so mg_dist_init fails -- on both ranks; they tell each other
+    through the file rendezvous, switch to torch.distributed's communicator (gloo here, the CPU rehearsal backend) and the line
+    says so.  What an 8-GPU node would do if the library's own communicator could not be set up there."""
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "30", "--warmup", "3", "--ramp-steps", "30", "--no-cpu-baseline",
+                "--no-extra-configs", "--no-placement-compare"], env={"MG_BENCH_OVERSUBSCRIBE": "1", "MG_BENCH_BACKEND": "gloo"}, timeout=400)
+    lines = _json_lines(out)
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 2 and r["config"]["global_candidates"] == 2 * r["config"]["candidates_per_gpu"]
+    assert "torch.distributed gloo" in r["config"]["collective"] and "mg_dist_init" in r["config"]["collective_fallback"]
+    assert r["value"] > 0
