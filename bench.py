@@ -369,8 +369,9 @@ def run_walk(args, rank, local_rank, world):
         step()
     barrier()
     # timing events ride on the kernel's own dispatch (hipExtLaunchKernel: no marker packets, the duration is the kernel's
-    # own); they still cost ~4 us of step time each, so a long run samples every 8th launch and a short one times them all
-    interval = max(1, args.event_interval) if args.event_interval else (1 if args.steps <= 64 else 8)
+    # own); they still cost ~4 us of step time each, so a long run samples every 8th launch, the driver's 20 steps every second one
+    # and only the shortest runs time them all
+    interval = max(1, args.event_interval) if args.event_interval else (1 if args.steps <= 8 else (2 if args.steps <= 64 else 8))
     if not args.no_profile_events:
         ctx.profile_reset()
         ctx.profile_enable(interval)
@@ -745,7 +746,7 @@ def main():
     ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-interval", type=int, default=0,
                     help="every n-th launch of the timed region carries HIP start/stop events attached to the dispatch "
-                         "(0: every launch up to 64 steps, else every 8th)")
+                         "(0: every launch up to 8 steps, every second one up to 64, else every 8th)")
     ap.add_argument("--ramp-steps", type=int, default=1500,
                     help="untimed steps before the warm-up that let the chip reach its steady clock (~0.13 s; reported in config)")
     ap.add_argument("--output-alloc", choices=("placed", "plain"), default="placed",
