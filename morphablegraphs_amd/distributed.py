@@ -225,15 +225,54 @@ class FileCommunicator(object):
         return np.stack([np.frombuffer(b, dtype=np.float64) for b in self.rdv.all_gather(row.tobytes())])
 
 
+def open_communicator(ctx, rank, world, rendezvous=None, transport="rccl"):
+    """The communicator of a rank of the sharded seam -- the driver (rank 0) and every worker call this with the same arguments.
+    transport "rccl": MgCommunicator; its set-up is a collective that has to succeed on EVERY rank or on none, so the ranks tell
+    each other how it went through the rendezvous, and if any rank failed (no librccl, a device RCCL refuses, ...) all of them
+    finalise and carry the exchange through files instead (FileCommunicator: same results, the payloads are a few hundred bytes
+    per step), with a warning that says why.  transport "files": FileCommunicator."""
+    rank, world = int(rank), int(world)
+    if world == 1:
+        return LocalCommunicator()
+    if transport == "files":
+        return FileCommunicator(rendezvous)
+    uid, err = b"", b""
+    if rank == 0:
+        try:
+            uid = ctx.dist_unique_id()
+        except Exception as e:   # noqa: BLE001 -- whatever it was, the other ranks must hear of it
+            err = ("rank 0: mg_dist_unique_id: %s" % e).encode()[:300]
+    uid, err0 = rendezvous.all_gather(uid)[0], rendezvous.all_gather(err)[0]
+    comm = None
+    if not err0:
+        try:
+            comm = MgCommunicator(ctx, rank, world, unique_id=uid)
+        except Exception as e:   # noqa: BLE001
+            err = ("rank %d: mg_dist_init: %s" % (rank, e)).encode()[:300]
+        errs = [e for e in rendezvous.all_gather(err) if e]
+        err0 = errs[0] if errs else b""
+    if err0:
+        try:
+            ctx.dist_finalize()
+        except Exception:   # noqa: BLE001
+            pass
+        import warnings
+        warnings.warn("RCCL communicator could not be set up (%s): the ranks exchange through files instead" % err0.decode(errors="replace"))
+        return FileCommunicator(rendezvous)
+    return comm
+
+
 class MgCommunicator(object):
     """Both calls through libmg_hip's RCCL entry points on the context's stream (mg_dist_broadcast, mg_dist_all_gather): what
     runs on a node of MI355X over xGMI.  The unique id travels through `rendezvous` (any object with all_gather(bytes))."""
 
-    def __init__(self, ctx, rank, world, rendezvous=None):
+    def __init__(self, ctx, rank, world, rendezvous=None, unique_id=None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
-        uid = ctx.dist_unique_id() if self.rank == 0 else b""
-        if self.world > 1:
-            uid = rendezvous.all_gather(uid)[0]
+        uid = unique_id
+        if uid is None:
+            uid = ctx.dist_unique_id() if self.rank == 0 else b""
+            if self.world > 1:
+                uid = rendezvous.all_gather(uid)[0]
         ctx.dist_init(self.rank, self.world, uid)
         self._stage = None
 

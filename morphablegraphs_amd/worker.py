@@ -57,7 +57,7 @@ def main(argv=None):
     from . import _capi, distributed
     rdv = distributed.FileRendezvous(rank, world, base=os.environ.get("MG_RDV_BASE"))
     ctx = _capi.Context(device)            # raises when there is no GPU: no CPU fallback
-    comm = distributed.MgCommunicator(ctx, rank, world, rdv) if args.transport == "rccl" else distributed.FileCommunicator(rdv)
+    comm = distributed.open_communicator(ctx, rank, world, rdv, transport=args.transport)   # (rank 0 opens its own the same way)
     nodes = load_nodes(args, ctx)
     if rank == 0:
         raise SystemExit("rank 0 is the driver (the process that runs the graph walk), not a worker")

@@ -219,15 +219,20 @@ def test_a_planner_step_in_blocks_is_the_unsharded_step():
     pset.ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, 0)
 
 
-def _gpu_rank(rank, world, base, out_dir):
-    """a rank of the sharded seam on the test box's one GPU: HIP scorers, files as transport"""
+def _gpu_rank(rank, world, base, out_dir, transport="files"):
+    """a rank of the sharded seam on the test box's one GPU: HIP scorers, files as transport (asked for, or fallen back to)"""
     sys.path.insert(0, ROOT)
     import pickle
     from morphablegraphs_amd import _capi, distributed, synthetic
     from morphablegraphs_amd.candidate_scoring import evaluate_samples_using_constraints, sample_and_evaluate_on_device
     from morphablegraphs_amd.motion_state_graph import HipMotionStateGraphNode, HipPrimitiveSet
-    comm = distributed.FileCommunicator(distributed.FileRendezvous(rank, world, base=base, timeout=120.0))
     ctx = _capi.Context(0)
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        comm = distributed.open_communicator(ctx, rank, world, distributed.FileRendezvous(rank, world, base=base, timeout=120.0), transport=transport)
+    if transport == "rccl":   # two ranks on one device: RCCL refuses, every rank must have fallen back
+        assert isinstance(comm, distributed.FileCommunicator) and any("RCCL communicator could not be set up" in str(w.message) for w in caught)
     node = HipMotionStateGraphNode(context=ctx)
     node.init_from_dict("walk", {"name": "leftStance", "mm": synthetic.make_walk_primitive(seed=0)})
     prims = synthetic.make_graph_primitives(4)
@@ -256,13 +261,15 @@ def _gpu_rank(rank, world, base, out_dir):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_pick_the_single_process_winner(tmp_path):
+@pytest.mark.parametrize("transport", ["files", "rccl"])
+def test_two_ranks_on_one_gpu_pick_the_single_process_winner(tmp_path, transport):
     """Rank 0 drives through the product entry points with a communicator, rank 1 sits in worker_loop; both use the HIP library
-    on the box's one GPU, the exchange goes through files.  Same winners, same errors, bit for bit, as without a communicator."""
+    on the box's one GPU, the exchange goes through files -- asked for, or ("rccl") after the RCCL set-up failed on the shared
+    device and both ranks fell back.  Same winners, same errors, bit for bit, as without a communicator."""
     import pickle
     base = str(tmp_path / "rdv")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_gpu_rank, args=(r, 2, base, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_rank, args=(r, 2, base, str(tmp_path), transport)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
