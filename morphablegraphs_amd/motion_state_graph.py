@@ -296,7 +296,7 @@ class HipPrimitiveSet(object):
         code = _capi.MG_F64 if np.dtype(dtype) == np.float64 else _capi.MG_F32
         plan = self._step_plan(tuple(options), n, np.dtype(dtype))
         steps = plan["steps"]
-        csets = []
+        csets, general = [], []
         memo = plan.setdefault("memo", [None] * len(steps))
         multinomial = np.random.multinomial
         for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
@@ -316,16 +316,37 @@ class HipPrimitiveSet(object):
             if fp is not None and last is not None and last[0] == fp and last[1].handle and last[1].cached_values is last[2] and \
                     getattr(cons, "hip_skeleton", None) is None and getattr(cons, "is_local", True):   # (cached_values: nobody else rewrote the shared set)
                 csets.append(last[1])
+                general.append(None)
             else:
                 sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
                 form = constraints_to_device_form(clist)
-                if any(is_frame_constraint(c) for c in form):
-                    raise NotImplementedError("the one-launch planner step scores keyframe constraints only: option %r carries per-frame "
-                                              "constraints, score it with evaluate_samples_using_constraints" % (name,))
-                cs = cached_constraint_set(prim, form, sk, alignment_from_prev_frames(prev_frames, cons, sk))
+                alignment = alignment_from_prev_frames(prev_frames, cons, sk)
+                if any(is_frame_constraint(c) or c.get("type") == "trajectory" for c in form):
+                    # trajectory and per-frame constraints are not keyframe channels: this option is scored by the general chain
+                    # (device sampler, fused scorers, the per-frame kernels adding to the same errors, first minimum)
+                    csets.append(None)
+                    general.append((form, alignment, sk))
+                    memo[k] = None
+                    continue
+                cs = cached_constraint_set(prim, form, sk, alignment)
                 csets.append(cs)
+                general.append((form, alignment, sk))
                 memo[k] = (fp, cs, cs.cached_values) if fp is not None and all(type(c) is dict for c in clist) else None
-            plan["counts"][k, :len(pvals)] = multinomial(n, pvals)
+        for k, st in enumerate(steps):   # the component counts, in option order, from NumPy's global stream
+            plan["counts"][k, :len(st[8])] = multinomial(n, st[8])
+        if any(cs is None for cs in csets):
+            # at least one option needs the general chain: the whole step goes option by option (same draws: the sampler is keyed
+            # by seed + option index and the counts above)
+            from .candidate_scoring import sample_rows_and_first_minimum
+            results = {}
+            for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
+                form, alignment, sk = general[k] if general[k] is not None else (constraints_to_device_form(
+                    constraints_per_option[name].constraints if hasattr(constraints_per_option[name], "constraints") else constraints_per_option[name]), None, None)
+                idx, err, lat = sample_rows_and_first_minimum(node, form, alignment, plan["counts"][k, :len(pvals)].copy(), int(seed) + k, 0, n,
+                                                              skeleton=sk, dtype=dtype)
+                results[name] = (np.asarray(lat, dtype=np.float64), err)
+            errors = [results[nm][1] for nm in options]
+            return options[int(np.argmin(errors))], results
         results = {}
         if plan["one_context"] and steps:
             # one C call, ONE launch and ONE read-back for the whole step (mg_options_step): the result records side by side

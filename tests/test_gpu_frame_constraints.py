@@ -181,3 +181,36 @@ def test_arc_length_look_up_on_the_device_against_the_reference_vectors():
         np.testing.assert_allclose(ctx.download(d_e, (1,), np.float64)[0], res.sum(), rtol=1e-12)
         for b in (d_t, d_e, d_r):
             b.free()
+
+
+def test_planner_step_scores_options_with_per_frame_constraints_by_the_general_chain():
+    """evaluate_options_on_device is one launch for keyframe constraints; an option that carries a trajectory or per-frame
+    constraint sends the step through the general chain option by option -- the same draws (component counts in option order from
+    NumPy's stream, sampler keyed by seed + option index), so every option's answer is what sample_and_evaluate_on_device gives."""
+    from morphablegraphs_amd.candidate_scoring import sample_and_evaluate_on_device
+    from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
+    prims = synthetic.make_graph_primitives(3)
+    names = [p["name"] for p in prims]
+    pset = HipPrimitiveSet(prims)
+    cons = {}
+    for nm, p in zip(names, prims):
+        tl = float(p["n_canonical_frames"] - 1)
+        cons[nm] = [{"type": "position", "t": tl, "weight": 1.0, "target": [10.0, None, 5.0]}]
+    F1 = prims[1]["n_canonical_frames"]
+    cons[names[1]] = cons[names[1]] + [{"type": "frame_ca_position", "joint": "root", "target": [3.0, None, -2.0], "n_frames": F1, "weight": 2.0},
+                                       {"type": "trajectory", "control_points": [[0.0, 0.0, 0.0], [5.0, 0.0, 2.0], [12.0, 0.0, 3.0]], "min_u": 0.0, "weight": 0.5,
+                                        "granularity": 1000}]
+    np.random.seed(17)
+    best, res = pset.evaluate_options_on_device(names, cons, n_samples=777, seed=40)
+    np.random.seed(17)
+    for k, nm in enumerate(names):
+        lat, err = sample_and_evaluate_on_device(pset.nodes[nm], cons[nm], 777, seed=40 + k)
+        np.testing.assert_array_equal(res[nm][0], lat)
+        assert res[nm][1] == err
+    assert best == names[int(np.argmin([res[nm][1] for nm in names]))]
+    # keyframe-only steps stay one launch
+    only = {nm: cons[nm][:1] for nm in names}
+    pset.ctx.profile_reset(); pset.ctx.profile_enable(1)
+    pset.evaluate_options_on_device(names, only, n_samples=777, seed=40)
+    assert pset.ctx.profile_get(7)[1] == 1
+    pset.ctx.profile_enable(0)
