@@ -289,7 +289,20 @@ class HipPrimitiveSet(object):
                 cmd["constraints"][name] = constraints_to_device_form(clist)
                 cmd["alignments"][name] = alignment_from_prev_frames(prev_frames, cons, sk)
                 cmd["widths"][name] = node._prim.n_gmm_dims
-            out = distributed.run_command(communicator, {"__primitive_set__": self, "__skeleton__": skeleton}, cmd)
+            local = {"__primitive_set__": self, "__skeleton__": skeleton}
+            if any(is_frame_constraint(c) or c.get("type") == "trajectory" for name in options for c in cmd["constraints"][name]):
+                # an option with a trajectory or per-frame constraint: the step as one sample-and-evaluate command per option (every
+                # rank holds the primitives under their names), the same draws
+                local.update(self.nodes)
+                out = {}
+                for k, name in enumerate(options):
+                    _, err, lat = distributed.run_command(communicator, local, {
+                        "op": "sample_and_evaluate", "node": name, "constraints": cmd["constraints"][name], "alignment": cmd["alignments"][name],
+                        "skeleton": cmd["skeleton"], "counts": cmd["counts"][name], "seed": int(seed) + k, "dtype": cmd["dtype"],
+                        "width": cmd["widths"][name]})
+                    out[name] = (np.asarray(lat, dtype=np.float64), err)
+            else:
+                out = distributed.run_command(communicator, local, cmd)
             results = {name: (out[name][0].astype(dtype).astype(np.float64), out[name][1]) for name in options}
             errors = [results[nm][1] for nm in options]
             return options[int(np.argmin(errors))], results

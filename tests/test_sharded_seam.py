@@ -248,13 +248,18 @@ def _gpu_rank(rank, world, base, out_dir, transport="files"):
             {"type": "direction", "t": 155.0, "weight": 1.0, "target": [0.5, 1.0]}]
     names = [p["name"] for p in prims]
     ocons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]}] for nm, p in zip(names, prims)}
+    # ... and a step in which one option carries a per-frame constraint (the root never closer than ... to a point): option by option
+    fcons = dict(ocons)
+    fcons[names[2]] = ocons[names[2]] + [{"type": "frame_ca_position", "joint": "root", "target": [3.0, None, -2.0],
+                                          "n_frames": prims[2]["n_canonical_frames"], "weight": 2.0}]
     out = {}
     for label, c in (("sharded", comm), ("single", None)):
         np.random.seed(5)
         S = node.motion_primitive.sample_low_dimensional_vector(1001)
         out[label] = [evaluate_samples_using_constraints(S, node, cons, communicator=c),
                       sample_and_evaluate_on_device(node, cons, 3001, seed=9, communicator=c),
-                      pset.evaluate_options_on_device(names, ocons, n_samples=2049, seed=3, communicator=c)]
+                      pset.evaluate_options_on_device(names, ocons, n_samples=2049, seed=3, communicator=c),
+                      pset.evaluate_options_on_device(names, fcons, n_samples=1025, seed=11, communicator=c)]
     distributed.stop_workers(comm)
     with open(os.path.join(out_dir, "r0.pkl"), "wb") as f:
         pickle.dump(out, f)
@@ -275,16 +280,17 @@ def test_two_ranks_on_one_gpu_pick_the_single_process_winner(tmp_path, transport
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    assert (tmp_path / "served1").read_text() == "3"
+    assert (tmp_path / "served1").read_text() == "7"          # three commands + one per option of the step with a per-frame constraint
     with open(tmp_path / "r0.pkl", "rb") as f:
         out = pickle.load(f)
     for k in (0, 1):
         np.testing.assert_array_equal(out["sharded"][k][0], out["single"][k][0])
         assert out["sharded"][k][1] == out["single"][k][1]
-    assert out["sharded"][2][0] == out["single"][2][0]
-    for nm, (lat, err) in out["single"][2][1].items():
-        np.testing.assert_array_equal(out["sharded"][2][1][nm][0], lat)
-        assert out["sharded"][2][1][nm][1] == err
+    for k in (2, 3):
+        assert out["sharded"][k][0] == out["single"][k][0]
+        for nm, (lat, err) in out["single"][k][1].items():
+            np.testing.assert_array_equal(out["sharded"][k][1][nm][0], lat)
+            assert out["sharded"][k][1][nm][1] == err
 
 
 @pytest.mark.gpu
