@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libmg_hip.so")   # the product library; tools pass another build to load_library(path)
 
 MG_OK = 0
+MG_ERR_INVALID_ARGUMENT = -1     # enum mg_status (include/mg_hip.h)
 MG_F32, MG_F64 = 0, 1
 MG_PATH_AUTO, MG_PATH_MFMA, MG_PATH_DIRECT = 0, 1, 2
 MG_ALIGN_START_POSE = -1   # mg_alignment_desc.joint: the start-pose branch of the reference's alignment

@@ -214,3 +214,54 @@ def test_planner_step_scores_options_with_per_frame_constraints_by_the_general_c
     pset.evaluate_options_on_device(names, only, n_samples=777, seed=40)
     assert pset.ctx.profile_get(7)[1] == 1
     pset.ctx.profile_enable(0)
+
+
+def test_frame_constraint_entry_points_refuse_bad_arguments():
+    """The C-ABI checks what a kernel would otherwise index with: unknown types, a joint count that does not match the tracks, a
+    quaternion channel outside the frame, trajectories of another primitive, NULL buffers, a previous-frame alignment without the
+    candidates' headings."""
+    import ctypes as C
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=2)
+    prim, ctx, lib = mp._prim, mp._prim.ctx, mp._prim.lib
+    other = _primitive(synthetic.make_walk_primitive(seed=1))
+    d_t, d_e = ctx.malloc(2 * 4 * 3 * 3 * 8), ctx.malloc(16)
+
+    def call(desc, J=1, tracks=d_t, err=d_e):
+        return lib.mg_score_frame_constraint(prim.handle, C.byref(desc), tracks.ptr if tracks is not None else None, 2, 4, J,
+                                             err.ptr if err is not None else None, 0, None)
+    d = _capi.FrameConstraintDesc()
+    d.type, d.weight, d.n_joints = 99, 1.0, 1
+    assert call(d) == _capi.MG_ERR_INVALID_ARGUMENT
+    d.type = _capi.MG_FRAME_CA_POSITION
+    d.axis_on[0], d.target[0] = 1, float("nan")
+    assert call(d) == _capi.MG_ERR_INVALID_ARGUMENT                      # a constrained axis without a finite target
+    d.target[0] = 1.0
+    assert call(d, J=2) == _capi.MG_ERR_INVALID_ARGUMENT                 # one joint's track expected
+    assert call(d, tracks=None) == _capi.MG_ERR_INVALID_ARGUMENT
+    assert call(d) == 0
+    d.type = _capi.MG_FRAME_TRAJECTORY_SET
+    d.n_joints = 3
+    assert call(d, J=2) == _capi.MG_ERR_INVALID_ARGUMENT                 # n_joints must be the tracks' joint count
+    d.n_joints = 2
+    assert call(d, J=2) == _capi.MG_ERR_INVALID_ARGUMENT                 # no trajectories
+    foreign = _capi.Trajectory(other._prim, np.array([[0.0, 0, 0], [1.0, 0, 0], [2.0, 0, 1.0]]))
+    d.trajectories[0] = d.trajectories[1] = foreign.handle.value
+    assert call(d, J=2) == _capi.MG_ERR_INVALID_ARGUMENT                 # ... of another primitive
+    d.type, d.n_joints, d.quat_channel = _capi.MG_FRAME_JOINT_ROTATION, 1, 2
+    d.quaternion[0] = 1.0
+    assert call(d, J=9) == _capi.MG_ERR_INVALID_ARGUMENT                 # channel 2 is root translation
+    d.quat_channel = 7
+    assert call(d, J=9) == _capi.MG_ERR_INVALID_ARGUMENT                 # 7 + 4 > 9
+    d.quaternion[0] = 0.0
+    d.quat_channel = 3
+    assert call(d, J=9) == _capi.MG_ERR_INVALID_ARGUMENT                 # a zero rotation target
+    # mg_align_frames: a previous-frame record needs the candidates' headings
+    al = _capi.ConstraintSet._marshal_alignment({"joint": 0, "position": (0.0, 0.0, 0.0), "heading": (0.0, 1.0)}, None)
+    d_f, d_v = ctx.malloc(2 * 4 * prim.n_dim * 8), ctx.malloc(2 * 4 * 8)
+    assert lib.mg_align_frames(prim.handle, d_f.ptr, 2, 4, d_v.ptr, 2, C.byref(al)) == _capi.MG_ERR_INVALID_ARGUMENT
+    assert lib.mg_align_frames(prim.handle, d_f.ptr, 2, 4, d_v.ptr, 3, C.byref(al)) == _capi.MG_ERR_INVALID_ARGUMENT
+    al.heading[0], al.heading[1] = 0.0, 0.0
+    assert lib.mg_align_frames(prim.handle, d_f.ptr, 2, 4, d_v.ptr, 4, C.byref(al)) == _capi.MG_ERR_INVALID_ARGUMENT
+    foreign.close()
+    for b in (d_t, d_e, d_f, d_v):
+        b.free()
