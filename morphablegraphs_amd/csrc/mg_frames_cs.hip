@@ -370,37 +370,15 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 }
             };
             const bool mine = cj < ncand && !MG_DBG(2);
-#ifndef MG_CS_PRODUCE_AT
-#define MG_CS_PRODUCE_AT 0   // > 0: the producing sweep waves make their tiles of the next unit after this many trips of the sweep, not after it
-#endif
-            auto produce_next = [&]() {
-                // this wave's row tiles of the NEXT unit go into the slot the unit before this one was swept from
-                mg_cs_wait_swept(prog, u);
-                mg_cs_wait_latents(prog, u + 2);
-                MG_STAMP(3);
-                mg_cs_produce<KK, TPWS>(ef, lds_latb + ((u + 1) & 1) * KK * 64, lds_mean, (float *)(smem + (size_t)((u + 1) & 1) * buf_bytes), stride,
-                                        nt_p + cj, MG_CS_NSP, ck.ntiles, lane, cl, g);
-                mg_publish(prog, wave, lane, u + 2);
-                MG_STAMP(2);
-            };
-            const bool early_produce = MG_CS_PRODUCE_AT > 0 && u + 1 < n_units && producing;
-            const int f_split = early_produce ? (MG_CS_PRODUCE_AT * 2 * rpi < ck.nT ? MG_CS_PRODUCE_AT * 2 * rpi : ck.nT) : ck.nT;
             if (mine) {
-                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, 0, f_split);
-                else sweep_rows(std::integral_constant<int, 0>{}, 0, f_split);
-            }
-            if (early_produce) {
-                produce_next();
-                if (mine && f_split < ck.nT) {
-                    if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, f_split, ck.nT);
-                    else sweep_rows(std::integral_constant<int, 0>{}, f_split, ck.nT);
-                }
+                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, 0, ck.nT);
+                else sweep_rows(std::integral_constant<int, 0>{}, 0, ck.nT);
             }
             MG_STAMP(4);
             MG_UNIT_STAMP(u, 1);
             mg_publish(prog + MG_CS_PROG_SWEPT, cj, lane, u + 1);
             MG_STAMP(5);
-            if (MG_CS_PRODUCE_AT == 0 && u + 1 < n_units && producing) {
+            if (u + 1 < n_units && producing) {
                 // the producing sweep waves are the four oldest, which finish a unit first: its row tiles of the NEXT unit go
                 // into the slot the unit before this one was swept from (every sweep wave is past it by now, as a rule)
                 mg_cs_wait_swept(prog, u);
