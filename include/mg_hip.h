@@ -563,6 +563,10 @@ int mg_step_frames_and_logp(mg_primitive *prim, const void *latents_dev, int lat
  * plan[1] = 1 when log p(x) is scored inside the frames kernel (one launch per step), 0 when it is a second launch,
  * plan[2] = workgroups, plan[3] = LDS bytes per workgroup. */
 int mg_step_plan(const mg_primitive *prim, int64_t n_samples, int32_t plan[4]);
+/* The same for a given output buffer: where the frames go can change the kernel -- a piece of a placed region whose scan found
+ * only slow-class memory (mg_device_malloc) is written by the tile-major kernel, which is the faster one there (frames_dev NULL:
+ * mg_step_plan). */
+int mg_step_plan_for(const mg_primitive *prim, int64_t n_samples, const void *frames_dev, int32_t plan[4]);
 
 /* evaluate_samples_using_constraints (reference motion_primitive_generator.py:230-261) in one call: score all
  * candidates against the set, first-minimum argmin, result on the host (no allocation, one synchronisation). */

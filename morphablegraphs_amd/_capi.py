@@ -47,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
     "mg_gmm_log_prob", "mg_gmm_sample", "mg_constraint_set_create", "mg_constraint_set_destroy",
-    "mg_score_constraints", "mg_argmin_first", "mg_argmin_first_dev", "mg_step_frames_and_logp", "mg_step_plan",
+    "mg_score_constraints", "mg_argmin_first", "mg_argmin_first_dev", "mg_step_frames_and_logp", "mg_step_plan", "mg_step_plan_for",
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
@@ -258,6 +258,7 @@ def load_library(path=None):
         "mg_argmin_first_dev": [vp, vp, i32, i64, vp],
         "mg_step_frames_and_logp": [vp, vp, i32, i64, i64, vp, vp],
         "mg_step_plan": [vp, i64, C.POINTER(C.c_int32)],
+        "mg_step_plan_for": [vp, i64, vp, C.POINTER(C.c_int32)],
         "mg_back_project_frames_host": [vp, vp, vp, i32, i64, i64, vp, i32],
         "mg_back_project_frames_f64_host": [vp, vp, vp, i32, i64, i64, vp],
         "mg_back_project_coeffs_host": [vp, vp, i32, i64, i64, vp, i32],
@@ -1028,10 +1029,11 @@ class Primitive(object):
 
     FRAMES_KERNEL_NAMES = ("mg_frames_direct_kernel", "mg_frames_ws_kernel", "mg_frames_cs_kernel")
 
-    def step_plan(self, n):
-        """What step_frames_and_logp_dev launches for n candidates: dict(kernel, fused, workgroups, lds_bytes)."""
+    def step_plan(self, n, frames_dev=None):
+        """What step_frames_and_logp_dev launches for n candidates (into frames_dev, when given: slow-class pieces of the output
+        arena get the tile-major kernel): dict(kernel, fused, workgroups, lds_bytes)."""
         plan = (C.c_int32 * 4)()
-        _check(self.lib.mg_step_plan(self.handle, int(n), plan))
+        _check(self.lib.mg_step_plan_for(self.handle, int(n), _dev_ptr(frames_dev) if frames_dev is not None else None, plan))
         return dict(kernel=self.FRAMES_KERNEL_NAMES[plan[0]], fused=bool(plan[1]), workgroups=int(plan[2]), lds_bytes=int(plan[3]))
 
     def step_frames_and_logp_dev(self, lat_dev, lat_dtype, n, ld, frames_dev, logp_dev):

@@ -43,7 +43,11 @@ bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_
 // gets at least two units out of the one-time load of its chunk's eigenvector window ('walk', same box and buffer, us per
 // step, tile-major / chunk-stationary: B = 1024 18.9 / 18.9, 2048 26.6 / 25.7, 4096 45.4 / 43.8, 6144 65.0 / 61.8,
 // 8192 83.3 / 81.0 before the start-up work and 87.4 / 81-83 after it), the tile-major one for smaller batches.
-int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused) {
+// out (may be NULL = unknown): where the frames go.  On slow-class memory -- a piece of one of the context's placed regions whose
+// scan found nothing better; a whole box can be like that -- the tile-major kernel is the faster one for the large outputs the class
+// exists for ('walk', us per step, chunk-stationary / tile-major: B = 8192 95.8 / 93.1 on a slow buffer and 78.4 / 82.8 on a fast
+// one in the same process; B = 16 384 195.2 / 186.4 slow), so there the batch-size rule gives way.
+int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused, const void *out) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t units = n_tiles * g->n_chunks;
     const int64_t grid0 = std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
@@ -53,7 +57,7 @@ int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_
               (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
     if (want == 2 && !cs) return -1;
     if (want == 1) cs = false;
-    else if (want == 0) cs = cs && units >= 2 * grid0;
+    else if (want == 0) cs = cs && units >= 2 * grid0 && mg_output_class(p->ctx, out) != 0;
     return cs ? 2 : 1;
 }
 int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int which) {
@@ -86,7 +90,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     for (int i = 0; i < MG_ARG_CHUNKS; i++) a.ck[i] = i < g->n_chunks ? g->chunks[i] : mg_chunk{};
     a.cs_magic = a.cs_per = a.cs_rem = 0;
     const bool lf = (ldt == MG_F64);
-    const int which = mg_frames_kernel_choice(p, g, B, logp != nullptr);
+    const int which = mg_frames_kernel_choice(p, g, B, logp != nullptr, out);
     if (which < 0) {
         mg_set_error("mg_back_project_frames: the chunk-stationary kernel does not cover this shape (window of %d row tiles, %d bytes of LDS)",
                      g->max_tiles, g->cs_lds_bytes);

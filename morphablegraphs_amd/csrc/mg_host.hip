@@ -1675,7 +1675,10 @@ extern "C" int mg_step_frames_and_logp(mg_primitive *p, const void *lat, int dt,
     return rc;
 }
 
-extern "C" int mg_step_plan(const mg_primitive *p, int64_t B, int32_t *plan) {
+static int mg_step_plan_impl(const mg_primitive *p, int64_t B, const void *frames_dev, int32_t *plan);
+extern "C" int mg_step_plan(const mg_primitive *p, int64_t B, int32_t *plan) { return mg_step_plan_impl(p, B, nullptr, plan); }
+extern "C" int mg_step_plan_for(const mg_primitive *p, int64_t B, const void *frames_dev, int32_t *plan) { return mg_step_plan_impl(p, B, frames_dev, plan); }
+static int mg_step_plan_impl(const mg_primitive *p, int64_t B, const void *frames_dev, int32_t *plan) {
     MG_REQUIRE(p && plan && B >= 0, "mg_step_plan: bad arguments");
     const mg_time_grid *g = p->canonical;
     plan[0] = plan[1] = plan[2] = plan[3] = 0;
@@ -1685,7 +1688,7 @@ extern "C" int mg_step_plan(const mg_primitive *p, int64_t B, int32_t *plan) {
         plan[2] = (int32_t)std::min<int64_t>((B * (int64_t)g->T * p->D + 255) / 256, (int64_t)p->ctx->n_cu * 32);
         return MG_OK;
     }
-    const int which = mg_frames_kernel_choice(p, g, B, fused);
+    const int which = mg_frames_kernel_choice(p, g, B, fused, frames_dev);
     MG_REQUIRE(which > 0, "mg_step_plan: the chunk-stationary kernel does not cover this shape");
     plan[0] = which;
     plan[1] = fused ? 1 : 0;

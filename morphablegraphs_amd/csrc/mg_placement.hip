@@ -279,6 +279,14 @@ extern "C" int mg_context_trim_outputs(mg_context *ctx) {
     return MG_OK;
 }
 
+// the placement class of memory the arena handed out: 1 fast, 0 slow, -1 unknown (not a piece of a placed region)
+int mg_output_class(mg_context *ctx, const void *p) {
+    if (!ctx || !p) return -1;
+    for (const auto &r : ctx->out_regions)
+        if (r.base && (const char *)p >= r.base && (const char *)p < r.base + r.bytes) return r.fast ? 1 : 0;
+    return -1;
+}
+
 extern "C" int mg_context_output_bytes(mg_context *ctx, int64_t *reserved, int64_t *in_use, int32_t *n_regions, int32_t *n_fast) {
     if (!ctx) { mg_set_error("mg_context_output_bytes: ctx is NULL"); return MG_ERR_INVALID_ARGUMENT; }
     int64_t res = 0, use = 0;

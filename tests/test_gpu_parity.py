@@ -573,6 +573,13 @@ def test_placed_allocator_walks_both_recipes_when_nothing_is_fast(ctx):
     prim.back_project_frames_dev(d_S, np.float32, 2048, 40, buf, path=_capi.MG_PATH_MFMA)
     got = ctx.download(buf, (2048, 156, 79), np.float32)
     np.testing.assert_array_equal(_bits(got), _bits(prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)))
+    # where the frames go decides the kernel: a piece of a region whose scan found nothing fast is written by the tile-major kernel
+    # (the faster one on slow-class memory), anything else by the batch-size rule; the bits are the same either way
+    assert prim.step_plan(2048)["kernel"] == "mg_frames_cs_kernel"
+    assert prim.step_plan(2048, buf)["kernel"] == "mg_frames_ws_kernel"
+    plain = ctx.malloc(1 << 20)
+    assert prim.step_plan(2048, plain)["kernel"] == "mg_frames_cs_kernel"        # not the arena's: class unknown
+    plain.free()
     for b in (d_S, buf):
         b.free()
     prim.close()

@@ -25,6 +25,7 @@ ap.add_argument("--rounds", type=int, default=6)
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--plain", action="store_true")
+ap.add_argument("--slow", action="store_true", help="a slow-class output buffer: plain allocations are held until one probes slow")
 ap.add_argument("--two-launch", action="store_true")
 args = ap.parse_args()
 
@@ -52,8 +53,25 @@ for v in args.variants:
 ctx0 = libs[var[0][1]][1]
 S = ctx0.upload(np.random.default_rng(0).standard_normal((B, L)).astype(np.float32))
 lp = ctx0.malloc(B * 4)
-out = ctx0.malloc(B * F * D * 4) if args.plain else ctx0.malloc_placed(B * F * D * 4)
-print("output buffer:", "plain" if args.plain else out.placement, flush=True)
+if args.slow:
+    ctx0.set_option(_capi.MG_OPT_PLAIN_MALLOC, 1)
+    held, out = [], None
+    for _ in range(40):
+        b = ctx0.malloc(B * F * D * 4)
+        info = ctx0.probe_placement(b)
+        if info["ratio"] > 1.15:
+            out = b
+            print("output buffer: slow class", info, "after", len(held), "fast ones", flush=True)
+            break
+        held.append(b)
+    for b in held:
+        b.free()
+    ctx0.set_option(_capi.MG_OPT_PLAIN_MALLOC, 0)
+    if out is None:
+        raise SystemExit("no slow-class buffer among 40 plain allocations")
+else:
+    out = ctx0.malloc(B * F * D * 4) if args.plain else ctx0.malloc_placed(B * F * D * 4)
+    print("output buffer:", "plain" if args.plain else out.placement, flush=True)
 
 
 def run(prim, n):
