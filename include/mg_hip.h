@@ -226,7 +226,10 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *                             default; MG_ERR_UNSUPPORTED never: a mixture that does not fit LDS falls back to 1) -- identical results
  *   MG_OPT_SCORE_KERNEL       mg_score_constraints on the matrix pipe: 0 = by batch size, 1 = a wave per 16-candidate tile, (candidate,
  *                             constraint) pairs on the lanes, 2 = a wave per 64 candidates, a lane per candidate (from 49 152
- *                             candidates on by default) -- identical results */
+ *                             candidates on by default) -- identical results
+ *   MG_OPT_ROOT_MODE          how the float32 frames kernels compute the root-translation channels (the two forms differ in
+ *                             the last bits; see mg_primitive_root_mode): 0 = what the primitive's accuracy gate says,
+ *                             1 = the float64 pipeline, 2 = the mean/delta split */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
@@ -238,7 +241,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_PLAIN_MALLOC 8
 #define MG_OPT_GMM_KERNEL 9
 #define MG_OPT_SCORE_KERNEL 10
-#define MG_OPT_COUNT 11
+#define MG_OPT_ROOT_MODE 11
+#define MG_OPT_COUNT 12
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
@@ -327,6 +331,18 @@ void mg_primitive_destroy(mg_primitive *prim);
  *           n_basis_time, kk of the mixture} */
 int mg_primitive_info(const mg_primitive *prim, int32_t *out8);
 int mg_primitive_info2(const mg_primitive *prim, int32_t *out4);
+/* How the float32 frames kernels compute the root-translation channels d < 3 of this primitive (the reference computes
+ * everything in float64: motion_primitive.py:236-256, motion_spline.py:71-86; the other channels are a float32 pipeline).
+ *   split = 0: the float64 pipeline -- control points and spline taps as float64 fma chains, rounded to float32 once;
+ *   split = 1: the mean/delta split -- the output is linear in the latent vector, frames[f][d] = M[f][d] + delta[f][d] with
+ *              M = the spline of mean' alone, a constant of the time grid evaluated ONCE in float64 on the host and kept as
+ *              a float32 pair (Mhi, Mlo), and delta = the spline of E'.s alone, which rides in the ordinary float32 row
+ *              tiles; out = Mhi + (Mlo + delta), two float32 additions.
+ * The split is used when its error estimate -- (L + 8) 2^-24 max_r sqrt(sum_k E'[r][k]^2 m2[k]) over the root rows r, m2[k] the
+ * second moment of latent k under the primitive's mixture (1 without a mixture): the float32 rounding a root control point
+ * of typical size can collect -- is at most 5e-6, half of the 1e-5 the float32 pose values are held to; *estimate returns
+ * it.  MG_OPT_ROOT_MODE overrides the choice (tests). */
+int mg_primitive_root_mode(const mg_primitive *prim, int32_t *split, double *estimate);
 /* (K, L, L) float64, upper triangular: sklearn's precisions_cholesky_ */
 int mg_primitive_get_precisions_cholesky(const mg_primitive *prim, double *out);
 

@@ -26,7 +26,8 @@ MG_OPT_OPTIONS_STEP = 7      # mg_options_step: 0 = one launch per step where po
 MG_OPT_PLAIN_MALLOC = 8      # 1 = mg_device_malloc is one hipMalloc whatever the size (no placed output regions)
 MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile per workgroup, 2 = fragments resident in LDS
 MG_OPT_SCORE_KERNEL = 10     # mg_score_constraints: 0 = by batch size, 1 = a wave per 16 candidates, 2 = a wave per 64 candidates
-MG_OPT_COUNT = 11
+MG_OPT_ROOT_MODE = 11        # root channels of the float32 frames kernels: 0 = the primitive's gate, 1 = float64 pipeline, 2 = mean/delta split
+MG_OPT_COUNT = 12
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 MG_CONSTRAINT_VALUE_POSITION, MG_CONSTRAINT_VALUE_HEADING = 7, 8   # values of the aligned motion, not errors (chained graph-walk steps)
@@ -40,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
     "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_free", "mg_context_trim_outputs", "mg_context_output_bytes", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
-    "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_get_precisions_cholesky",
+    "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_root_mode", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host",
     "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_score_trajectory_points", "mg_joint_positions",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
@@ -234,6 +235,7 @@ def load_library(path=None):
         "mg_primitive_create": [vp, C.POINTER(PrimitiveDesc), C.POINTER(vp)],
         "mg_primitive_info": [vp, C.POINTER(C.c_int32)],
         "mg_primitive_info2": [vp, C.POINTER(C.c_int32)],
+        "mg_primitive_root_mode": [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)],
         "mg_time_function_canonical": [vp, vp, i32, i64, i64, vp],
         "mg_trajectory_create": [vp, vp, i32, i32, C.POINTER(vp)],
         "mg_joint_positions": [vp, vp, vp, i32, vp, i64, i32, vp],
@@ -790,7 +792,18 @@ class Primitive(object):
         info2 = (C.c_int32 * 4)()
         _check(self.lib.mg_primitive_info2(self.handle, info2))
         self.n_gmm_dims, self.n_time_components, self.n_basis_time, self.kk_gmm = [int(v) for v in info2]
+        est = C.c_double()
+        _check(self.lib.mg_primitive_root_mode(self.handle, None, C.byref(est)))
+        self.root_split_estimate = float(est.value)   # the mean/delta split's error estimate (mg_primitive_root_mode)
         self.canonical_grid = TimeGrid(self, handle=C.c_void_p(self.lib.mg_primitive_canonical_grid(self.handle)))
+
+    @property
+    def root_split(self):
+        """True when the float32 frames kernels compute this primitive's root channels by the mean/delta split (the accuracy
+        gate of mg_primitive_root_mode, or MG_OPT_ROOT_MODE), False for the float64 pipeline."""
+        split = C.c_int32()
+        _check(self.lib.mg_primitive_root_mode(self.handle, C.byref(split), None))
+        return bool(split.value)
 
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:

@@ -8,7 +8,11 @@
 //   channels d >= nroot : c[r] = fmaf chain over k ascending starting from (float)mean'[r]
 //       (== the v_mfma_f32_16x16x4_f32 accumulation order with C-in = mean),
 //       out = w0*c0, fmaf(w1,c1,.), fmaf(w2,c2,.), fmaf(w3,c3,.)
-//   channels d <  nroot : the same in float64 (v_mfma_f64_16x16x4_f64 / fma), out = (float)v64.
+//   channels d <  nroot : either the same in float64 (v_mfma_f64_16x16x4_f64 / fma), out = (float)v64,
+//       or -- where the primitive's accuracy gate allows it (mg_primitive_root_mode) -- the mean/delta split:
+//       delta = the float32 pipeline above with C-in = 0 (the root rows of the ordinary row tiles),
+//       out = Mhi[f][d] + (Mlo[f][d] + delta), (Mhi, Mlo) = the float64 spline of mean' alone as a float32 pair
+//       (a table of the time grid): no float64 arithmetic on the device.
 //
 // This translation unit: which kernel a launch uses (mg_frames_kernel_choice), its grid and LDS, the dispatch.  The kernels:
 // mg_frames_cs.hip (chunk-stationary), mg_frames_ws.hip (tile-major), mg_frames_direct.hip (one thread per element).
@@ -24,6 +28,11 @@
 int mg_setup_kernel_attributes(mg_context *) {
     int rc = mg_frames_ws_attributes();
     return rc != MG_OK ? rc : mg_frames_cs_attributes();
+}
+
+bool mg_frames_root_split(const mg_primitive *p) {
+    const int want = p->ctx->opt[MG_OPT_ROOT_MODE];
+    return want == 2 || (want == 0 && p->root_split);
 }
 
 // LDS of the fused mixture scoring: two term buffers and two exp buffers of [K][16] float64
@@ -115,6 +124,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     }
     mg_launch_events ev;
     if (prof_slot >= 0) (void)mg_prof_kernel(p->ctx, prof_slot, prof_slot2, &ev.start, &ev.stop);
-    return cs ? mg_launch_frames_cs(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, ev)
-              : mg_launch_frames_ws(p, g, lat, out, logp, a, lf, buf_bytes, lds, grid, ev);
+    const bool split = mg_frames_root_split(p);
+    return cs ? mg_launch_frames_cs(p, g, lat, out, logp, a, lf, split, buf_bytes, lds, grid, ev)
+              : mg_launch_frames_ws(p, g, lat, out, logp, a, lf, split, buf_bytes, lds, grid, ev);
 }

@@ -160,12 +160,13 @@ extern "C" int mg_debug_dump_stamps(void) {
 // [max_nt] float4 + image tap byte offsets [max_nt] int (max_nt = the grid's longest chunk, padded to 16); rs = float64 root image; prog = 32 counters
 // (producer/consumer progress, mixture hand-off); FUSE_GMM: mixture terms and exponentials [2][K*16] f64 each.
 // -----------------------------------------------------------------------------------------
+#ifndef MG_SWEEP_LANEMAP
+#define MG_SWEEP_LANEMAP 1   // the sweep's third sample in lanes 44 .. 63 (see the kernels)
+#endif
 #define MG_FUSE_MAX_KK 10   // fused mixture scoring: k-steps (4 latent components each) that fit the register budget
 #define MG_WS_NPW 4      // producer waves
 #define MG_WS_NCW 8      // consumer waves, two candidates each
 #define MG_WS_BLOCK (64 * (MG_WS_NPW + MG_WS_NCW))
-#define MG_TB_BYTES_N(nt) ((nt) * 16 + (nt) * 4)      // nt = the grid's longest chunk, rounded up to 16 samples
-#define MG_RO_BYTES_N(nt) (MG_NCAND * (nt) * 16)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -283,6 +284,23 @@ __device__ __forceinline__ f32x4 mg_quad_fma(const mg_tap_rows &r, const float4 
         v[e] = x;
     }
     return v;
+}
+
+// The mean/delta split's finish in the root lane of a row group: that lane's quad is the first quad of the padded rows,
+// {padding..., root channels} = columns 0 .. 3 with root channel d in column cshift + d; v holds its four taps' sums (the deltas),
+// mh / ml the sample's (Mhi, Mlo).  out[d] = Mhi[d] + (Mlo[d] + delta[d]) for d < nroot; the other elements are not stored
+// (or, where every lane stores four floats, replaced by the row's borrowed channel 3).
+template <int CSHIFT>
+__device__ __forceinline__ f32x4 mg_root_finish(const f32x4 &v, const float4 &mh, const float4 &ml) {
+    f32x4 o;
+    o[0] = mh.x + (ml.x + v[CSHIFT]);
+    o[1] = CSHIFT + 1 < 4 ? mh.y + (ml.y + v[CSHIFT + 1 < 4 ? CSHIFT + 1 : 3]) : 0.f;
+    o[2] = CSHIFT + 2 < 4 ? mh.z + (ml.z + v[CSHIFT + 2 < 4 ? CSHIFT + 2 : 3]) : 0.f;
+    o[3] = 0.f;
+    return o;
+}
+__device__ __forceinline__ f32x4 mg_root_finish_rt(const f32x4 &v, const float4 &mh, const float4 &ml, int cshift) {
+    return cshift == 1 ? mg_root_finish<1>(v, mh, ml) : cshift == 2 ? mg_root_finish<2>(v, mh, ml) : mg_root_finish<3>(v, mh, ml);
 }
 
 // all active lanes store four floats at base (wave-uniform) + a 32-bit byte offset: one store instruction, no lane classes
@@ -443,8 +461,8 @@ __device__ __forceinline__ void mg_fused_gmm_finish(mg_lds_int *prog, float *__r
 struct mg_launch_events { hipEvent_t start = nullptr, stop = nullptr; };   // both NULL: an ordinary launch
 // per-kernel launchers (each in its kernel's translation unit) and their dynamic-LDS attributes
 int mg_launch_frames_ws(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a, bool lat_f64,
-                        int buf_bytes, int lds, int grid, const mg_launch_events &ev);
+                        bool split, int buf_bytes, int lds, int grid, const mg_launch_events &ev);
 int mg_launch_frames_cs(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a, bool lat_f64,
-                        int buf_bytes, int lds, int grid, const mg_launch_events &ev);
+                        bool split, int buf_bytes, int lds, int grid, const mg_launch_events &ev);
 int mg_frames_ws_attributes();
 int mg_frames_cs_attributes();

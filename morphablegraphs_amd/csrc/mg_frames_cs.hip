@@ -150,7 +150,7 @@ __device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const 
     }
 }
 
-template <int KK, bool LAT_F64, bool FUSE_GMM>
+template <int KK, bool LAT_F64, bool FUSE_GMM, bool SPLIT>
 __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     const float *__restrict__ Epack,      // [RT][KK/2][64][2]
     const float *__restrict__ mean32,     // [RT*16]
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     const int32_t *__restrict__ i0tab,    // (T)
     const float4 *__restrict__ w32,       // (T)
     const double *__restrict__ wtap,      // [n_chunks][FT][KS][64]
+    const float4 *__restrict__ rootm,     // (T, 2): SPLIT: the root channels' mean part {Mhi, Mlo}
     const mg_chunk *__restrict__ chunks,
     float *__restrict__ out,              // (B,T,D)
     const double *__restrict__ gPpack, const double *__restrict__ gmP, const double *__restrict__ gcst,
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     // Kernel arguments: left alone, the compiler fetches each where a role first uses it -- a dependent trip to memory per
     // 64-byte line of the argument block (wave 0 alone made eight in a row before it had issued its loads, 4.8 us after entry).
     // Asking for all of them here makes that one trip; the later uses hit the scalar cache.
-    asm volatile("" ::"s"(Epack), "s"(mean32), "s"(Erpack), "s"(meanroot), "s"(lat), "s"(i0tab), "s"(w32), "s"(wtap), "s"(out), "s"(gPpack),
+    asm volatile("" ::"s"(Epack), "s"(mean32), "s"(Erpack), "s"(meanroot), "s"(lat), "s"(i0tab), "s"(w32), "s"(wtap), "s"(rootm), "s"(out), "s"(gPpack),
                  "s"(gmP), "s"(gcst), "s"(logp), "s"(a.B), "s"(a.ld), "s"(a.T), "s"(a.L), "s"(a.n_chunks), "s"(a.stride), "s"(a.max_tiles),
                  "s"(a.ck[1].t0), "s"(a.ck[3].t0), "s"(a.ck[5].t0), "s"(a.ck[7].t0), "s"(gK), "s"(gJT), "s"(buf_bytes));
     const int stride = a.stride, D = a.D, Dp = a.Dp, L = a.L, nroot = a.nroot;
@@ -244,14 +245,23 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
         const int gl = nql + 1;                           // + the root lane
         const int rpi = 64 / gl;                          // samples per wave instruction
-        const int fsub = lane / gl, ql = lane - fsub * gl;
-        const bool lane_on = lane < rpi * gl;
+        // Three samples of 20 lanes: the third one sits in lanes 44 .. 63, not 40 .. 59.  ds_read_b128 serves the lanes in four
+        // groups of sixteen ({36-43, 48-51, 60-63} is one), and a row of 80 floats wraps around the 64 banks: the second sample's
+        // last quads (columns 68 .. 79, lanes 36-38) and the third sample's first ones (columns 4 .. 15, lanes 40-42) are different
+        // addresses in the same banks whenever the two samples share their tap rows -- one extra LDS cycle on most tap reads.
+        // Shifted, lanes 60-62 read the addresses lanes 36-38 read (a broadcast).
+        const bool shift3 = MG_SWEEP_LANEMAP && gl == 20;
+        const int lane_s = (shift3 && lane >= 40) ? lane - 4 : lane;
+        const int fsub = lane_s / gl, ql = lane_s - fsub * gl;
+        const bool lane_on = shift3 ? (lane < 40 || lane >= 44) : lane < rpi * gl;
         const bool root_lane = ql == nql;
         const int d0 = root_lane ? 0 : nroot + 4 * ql;    // first channel of this lane
         const int nst = root_lane ? nroot : (D - d0 < 4 ? D - d0 : 4);
         const int64_t TD = (int64_t)a.T * D;
         const int dp4 = Dp * 4;
-        const int lane_img = (d0 + a.cshift) * 4;         // byte offset of the lane's quad inside a basis row
+        // byte offset of the lane's quad inside a basis row; SPLIT: the root lane takes the row's first quad, {padding, root channels}
+        const int lane_img = (SPLIT && root_lane) ? 0 : (d0 + a.cshift) * 4;
+        const float4 *lds_m = (const float4 *)ro_base;    // SPLIT: {Mhi, Mlo} per sample of the chunk (where the root outputs would be)
         const int lane_out = fsub * D + d0;               // float offset inside a row group
         const bool all4 = nroot == 3 && ((D - nroot) & 3) == 0;   // every lane stores four floats (see the tile-major kernel)
         const int q0_lane = (lane - nql) << 2;            // byte index of this row's quad lane 0 for ds_bpermute
@@ -282,11 +292,13 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             const int c1 = has1 ? cj + 8 : cj;
             const unsigned char *img0 = img + (size_t)(cj * stride + col0) * 4 + lane_img;
             const unsigned char *img1 = img + (size_t)(c1 * stride + col0) * 4 + lane_img;
-            const float *ro0 = lds_ro + cj * max_nt * 4, *ro1 = lds_ro + c1 * max_nt * 4;
+            const float *ro0 = lds_ro + cj * MG_RO_CS(max_nt), *ro1 = lds_ro + c1 * MG_RO_CS(max_nt);
             float *or0 = out + (size_t)(b0 + cj) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
             float *or1 = out + (size_t)(b0 + c1) * TD + (size_t)ck.t0 * D;
-            auto sweep_rows = [&](auto pitch_tag, int f_first, int f_last) {
+            auto sweep_rows = [&](auto pitch_tag, auto all4_tag, int f_first, int f_last) {
                 constexpr int DP4 = decltype(pitch_tag)::value;
+                constexpr bool ALL4 = decltype(all4_tag)::value;   // the usual shape as a constant: every lane stores four floats
+                const bool all4l = ALL4 ? true : all4;
                 for (int f0 = f_first; f0 < f_last; f0 += 2 * rpi) {
                     const int fla = f0 + fsub, flb = fla + rpi;
                     const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
@@ -297,9 +309,11 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                         f32x4 v0a, v0b, v1a, v1b;
                         if (MG_DBG(4)) {   // ablation: stores only
                             v0a = v0b = v1a = v1b = f32x4{1.f, 2.f, 3.f, 4.f};
-                        } else if (!root_lane) {   // all 16 tap rows are requested before the first FMA
+                        } else if (SPLIT || !root_lane) {   // all 16 tap rows are requested before the first FMA
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
+                            float4 mha, mla, mhb, mlb;   // SPLIT: every lane asks (a broadcast read), the root lanes use them
+                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; mhb = lds_m[2 * fb_]; mlb = lds_m[2 * fb_ + 1]; }
                             mg_tap_rows r0a, r0b, r1a, r1b;
                             if (MG_DBG(16384)) {   // ablation: no tap reads (the FMAs run on what is in registers anyway)
                                 const f32x4 k = {wa.x, wa.y, wb.z, wb.w};
@@ -318,18 +332,29 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                                 v1a = mg_quad_fma(r1a, wa);
                                 v1b = mg_quad_fma(r1b, wb);
                             }
+                            if constexpr (SPLIT) {
+                                if (root_lane) {
+                                    if constexpr (ALL4) {   // (all4: three root channels in columns 1 .. 3)
+                                        v0a = mg_root_finish<1>(v0a, mha, mla); v0b = mg_root_finish<1>(v0b, mhb, mlb);
+                                        v1a = mg_root_finish<1>(v1a, mha, mla); v1b = mg_root_finish<1>(v1b, mhb, mlb);
+                                    } else {
+                                        v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v0b = mg_root_finish_rt(v0b, mhb, mlb, a.cshift);
+                                        v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); v1b = mg_root_finish_rt(v1b, mhb, mlb, a.cshift);
+                                    }
+                                }
+                            }
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v0b = *(const f32x4 *)&ro0[fb_ * 4];
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
                             v1b = *(const f32x4 *)&ro1[fb_ * 4];
                         }
-                        if (all4 && MG_DBG(4)) {
+                        if (all4l && MG_DBG(4)) {
                             if (oa) mg_store4_at(pa0, lane_out_b, v0a);
                             if (ob) mg_store4_at(pb0, lane_out_b, v0b);
                             if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
                             if (ob && has1) mg_store4_at(pb1, lane_out_b, v1b);
-                        } else if (all4) {
+                        } else if (all4l) {
                             const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
                             const float b0b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0b[0])));
                             const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
@@ -347,16 +372,24 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                         }
                     } else {                                     // the chunk's last rows fill one group only: half the work
                         f32x4 v0a, v1a;
-                        if (!root_lane) {
+                        if (SPLIT || !root_lane) {
                             const float4 wa = lds_w[fa_];
                             const int moa = lds_mo[fa_];
+                            float4 mha, mla;
+                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; }
                             v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
                             v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
+                            if constexpr (SPLIT) {
+                                if (root_lane) {
+                                    if constexpr (ALL4) { v0a = mg_root_finish<1>(v0a, mha, mla); v1a = mg_root_finish<1>(v1a, mha, mla); }
+                                    else { v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); }
+                                }
+                            }
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
                         }
-                        if (all4) {
+                        if (all4l) {
                             const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
                             const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
                             if (root_lane) { v0a[3] = b0a; v1a[3] = b1a; }
@@ -371,8 +404,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             };
             const bool mine = cj < ncand && !MG_DBG(2);
             if (mine) {
-                if (dp4 == 320) sweep_rows(std::integral_constant<int, 320>{}, 0, ck.nT);
-                else sweep_rows(std::integral_constant<int, 0>{}, 0, ck.nT);
+                if (dp4 == 320 && all4) sweep_rows(std::integral_constant<int, 320>{}, std::true_type{}, 0, ck.nT);
+                else sweep_rows(std::integral_constant<int, 0>{}, std::false_type{}, 0, ck.nT);
             }
             MG_STAMP(4);
             MG_UNIT_STAMP(u, 1);
@@ -440,6 +473,46 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         typename mg_gmm_xt<LAT_F64>::type s64frag[KK], s64next[KK];
         load_latents(s64next, 0);
         asm volatile("" ::: "memory");   // keep this issue order: results return in it
+        if constexpr (SPLIT) {
+            // the mean/delta split: no root stage.  Wave 0 parks the chunk's per-sample tables (tap weights, tap row offsets, the
+            // root channels' {Mhi, Mlo}) once and stages a latent tile per unit; the root channels' deltas are rows of the ordinary
+            // float32 tiles and the sweep's root lanes finish them.
+            const int tl = lane < ck.nT ? lane : ck.nT - 1;   // clamped, unconditional
+            const float4 tw_v = w32[ck.t0 + tl];
+            const int ti_v = i0tab[ck.t0 + tl];
+            const float4 mh_v = rootm[2 * (ck.t0 + tl)], ml_v = rootm[2 * (ck.t0 + tl) + 1];
+            mg_lds_barrier();
+            {
+                float4 *tw = (float4 *)tb_base;
+                int *tmo = (int *)(tw + max_nt);
+                float4 *tm = (float4 *)ro_base;
+                if (lane < ck.nT) {
+                    tw[lane] = tw_v;
+                    tmo[lane] = (ti_v - ck.imin) * Dp * 4;   // byte offset of the first tap row in the f32 image
+                    tm[2 * lane] = mh_v;
+                    tm[2 * lane + 1] = ml_v;
+                }
+            }
+            MG_STAMP_DECL
+            for (int u = 0; u < n_units; u++) {
+                MG_STAMP(0);
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) s64frag[kk] = s64next[kk];
+                if (u >= 2) mg_cs_wait_swept(prog, u - 1);   // every wave is done with the slot's previous unit, its latent tile included
+                MG_STAMP(5);
+                MG_UNIT_STAMP(u, 0);
+                float *lb = lds_latb + (u & 1) * KK * 64;
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) lb[kk * 64 + lane] = (float)s64frag[kk];
+                mg_publish(prog, MG_CS_PROG_LAT, lane, u + 1);
+                load_latents(s64next, u + 1);   // a unit ahead
+                MG_STAMP(3);
+                MG_UNIT_STAMP(u, 1);
+                mg_publish(prog, wave, lane, u + 1);   // (the first one: the tables are in LDS)
+                MG_STAMP(4);
+            }
+            MG_STAMP_DUMP;
+        } else {
         const double *rpp[3];
         double rm_v[3][4];   // mean of the root rows: the C-in of the root chains, parked in LDS
 #pragma unroll
@@ -482,7 +555,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             const int col = ct * 16 + cl;
             const bool colok = col < MG_NCAND * nroot;
             const int cc = colok ? col / nroot : 0, cd = colok ? col - cc * nroot : 0;
-            tap_o_off[ct] = colok ? cc * max_nt * 4 + cd : 3;
+            tap_o_off[ct] = colok ? cc * MG_RO_CS(max_nt) + cd : 3;
 #pragma unroll
             for (int ks = 0; ks < MG_TAP_KS; ks++) {
                 const int m = 4 * ks + g;   // rows at or beyond the window are never written: 0 * stale LDS could be NaN
@@ -614,6 +687,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         if (n_units > 0) root_unit(0, std::true_type{});
         for (int u = 1; u < n_units; u++) root_unit(u, std::false_type{});
         MG_STAMP_DUMP;
+        }
     }
     if (FUSE_GMM && wave < MG_WS_NPW) {   // the mixture: the four producer waves, as in the tile-major kernel
         mg_lds_int *gprog = prog + MG_CS_PROG_GMM;
@@ -632,13 +706,14 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
 // -----------------------------------------------------------------------------------------
 // launch
 // -----------------------------------------------------------------------------------------
-template <int KK, bool LAT_F64, bool FUSE>
+template <int KK, bool LAT_F64, bool FUSE, bool SPLIT>
 static int mg_launch_cs_inst(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
                                  int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
     // hipExtLaunchKernelGGL with NULL events is hipLaunchKernelGGL; with events the dispatch records its own begin and end
-    hipExtLaunchKernelGGL((mg_frames_cs_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_CS_BLOCK), lds, p->ctx->stream, ev.start, ev.stop, 0,
+    hipExtLaunchKernelGGL((mg_frames_cs_kernel<KK, LAT_F64, FUSE, SPLIT>), dim3(grid), dim3(MG_CS_BLOCK), lds, p->ctx->stream, ev.start, ev.stop, 0,
                           (const float *)p->d_Epack, (const float *)p->d_mean32, (const double *)p->d_Erpack, (const double *)p->d_meanroot, lat,
-                          (const int32_t *)g->d_i0, (const float4 *)g->d_w32, (const double *)g->d_wtap, (const mg_chunk *)g->d_chunks, out,
+                          (const int32_t *)g->d_i0, (const float4 *)g->d_w32, (const double *)g->d_wtap, (const float4 *)g->d_rootm,
+                          (const mg_chunk *)g->d_chunks, out,
                           (const double *)p->d_gPpack, (const double *)p->d_gmPpad, (const double *)p->d_gconst, logp, a, (int)p->K,
                           (int)((p->L + 15) / 16), buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
@@ -647,34 +722,41 @@ static int mg_launch_cs_inst(mg_primitive *p, const mg_time_grid *g, const void 
 
 template <int KK>
 static int mg_launch_cs_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
-                               bool lat_f64, int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
+                               bool lat_f64, bool split, int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
     if (logp) {
         // fused instances exist for <= 40 components: beyond that the mixture fragments no longer fit the
         // register budget next to the sweep (mg_frames_can_fuse_gmm refuses, so this is never reached)
-        if constexpr (KK <= MG_FUSE_MAX_KK)
-            return lat_f64 ? mg_launch_cs_inst<KK, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev)
-                           : mg_launch_cs_inst<KK, false, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev);
+        if constexpr (KK <= MG_FUSE_MAX_KK) {
+            if (split)
+                return lat_f64 ? mg_launch_cs_inst<KK, true, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev)
+                               : mg_launch_cs_inst<KK, false, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev);
+            return lat_f64 ? mg_launch_cs_inst<KK, true, true, false>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev)
+                           : mg_launch_cs_inst<KK, false, true, false>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev);
+        }
         mg_set_error("mg_step_frames_and_logp: no fused kernel for %d components", p->L);
         return MG_ERR_UNSUPPORTED;
     }
-    return lat_f64 ? mg_launch_cs_inst<KK, true, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev)
-                   : mg_launch_cs_inst<KK, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev);
+    if (split)
+        return lat_f64 ? mg_launch_cs_inst<KK, true, false, true>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev)
+                       : mg_launch_cs_inst<KK, false, false, true>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev);
+    return lat_f64 ? mg_launch_cs_inst<KK, true, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev)
+                   : mg_launch_cs_inst<KK, false, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev);
 }
 
 int mg_launch_frames_cs(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a, bool lat_f64,
-                        int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
+                        bool split, int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
     switch (p->KK) {
 #ifndef MG_ONLY_KK10
-        case 2: return mg_launch_cs_kk<2>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 4: return mg_launch_cs_kk<4>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 6: return mg_launch_cs_kk<6>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 8: return mg_launch_cs_kk<8>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
+        case 2: return mg_launch_cs_kk<2>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 4: return mg_launch_cs_kk<4>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 6: return mg_launch_cs_kk<6>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 8: return mg_launch_cs_kk<8>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
 #endif
-        case 10: return mg_launch_cs_kk<10>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
+        case 10: return mg_launch_cs_kk<10>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
 #ifndef MG_ONLY_KK10
-        case 12: return mg_launch_cs_kk<12>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 14: return mg_launch_cs_kk<14>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 16: return mg_launch_cs_kk<16>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
+        case 12: return mg_launch_cs_kk<12>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 14: return mg_launch_cs_kk<14>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 16: return mg_launch_cs_kk<16>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
 #endif
         default: mg_set_error("mg_back_project_frames: MFMA path needs n_components <= 64"); return MG_ERR_UNSUPPORTED;
     }
@@ -682,11 +764,15 @@ int mg_launch_frames_cs(mg_primitive *p, const mg_time_grid *g, const void *lat,
 
 template <int KK>
 static int mg_cs_attr_kk() {
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if constexpr (KK <= MG_FUSE_MAX_KK) {
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_cs_kernel<KK, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return MG_OK;
 }

@@ -13,9 +13,11 @@ struct mg_direct_args {
     const void *lat;
     const int32_t *i0;
     const double *w;
+    const float *rootm;   // (T, 8): {Mhi[0..2], 0, Mlo[0..2], 0}, the mean/delta split of the root channels
     void *out;
     int64_t B, ld;
     int32_t T, D, L, R, nroot;
+    int32_t split;        // float32 output: root channels by the mean/delta split instead of the float64 pipeline
 };
 
 template <bool LAT_F64, bool OUT_F64>
@@ -29,7 +31,22 @@ __global__ __launch_bounds__(256) void mg_frames_direct_kernel(mg_direct_args a)
         const int i0v = a.i0[f];
         const double *wq = a.w + 4 * (size_t)f;
         const int r0 = i0v * a.D + d;
-        if (OUT_F64 || d < a.nroot) {
+        if (!OUT_F64 && d < a.nroot && a.split) {
+            float c[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float *e = a.Et32 + (r0 + j * a.D);
+                float acc = 0.0f;
+                for (int k = 0; k < a.L; k++) acc = fmaf(e[(size_t)k * a.R], (float)mg_load_lat<LAT_F64>(a.lat, b * a.ld + k), acc);
+                c[j] = acc;
+            }
+            float v = (float)wq[0] * c[0];
+            v = fmaf((float)wq[1], c[1], v);
+            v = fmaf((float)wq[2], c[2], v);
+            v = fmaf((float)wq[3], c[3], v);
+            const float *m = a.rootm + 8 * (size_t)f;
+            ((float *)a.out)[idx] = m[d] + (m[4 + d] + v);
+        } else if (OUT_F64 || d < a.nroot) {
             double c[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -86,6 +103,7 @@ __global__ __launch_bounds__(256) void mg_spline_eval_kernel(const double *coeff
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64) {
     mg_direct_args a;
     a.Et32 = p->d_Et32; a.Et64 = p->d_Et64; a.mean = p->d_mean; a.lat = lat; a.i0 = g->d_i0; a.w = g->d_w; a.out = out;
+    a.rootm = g->d_rootm; a.split = (!out_f64 && mg_frames_root_split(p)) ? 1 : 0;
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.L = p->L; a.R = p->R; a.nroot = p->nroot;
     int64_t total = B * (int64_t)g->T * p->D;
     int64_t blocks = (total + 255) / 256;

@@ -3,7 +3,7 @@
 // Arithmetic contract and the roles of the waves: mg_frames_common.h.
 #include "mg_frames_common.h"
 
-template <int KK, bool LAT_F64, bool FUSE_GMM>
+template <int KK, bool LAT_F64, bool FUSE_GMM, bool SPLIT>
 __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const float *__restrict__ Epack,      // [RT][KK/2][64][2]
     const float *__restrict__ mean32,     // [RT*16]
@@ -13,6 +13,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
     const int32_t *__restrict__ i0tab,    // (T)
     const float4 *__restrict__ w32,       // (T)
     const double *__restrict__ wtap,      // [n_chunks][2][2][64] banded tap weights as f64 MFMA A fragments
+    const float4 *__restrict__ rootm,     // (T, 2): SPLIT (the mean/delta split of the root channels): {Mhi, Mlo} per time sample
     const mg_chunk *__restrict__ chunks,
     float *__restrict__ out,              // (B,T,D)
     const double *__restrict__ gPpack,    // FUSE_GMM: precision-Cholesky fragments [K][JT][KK][64]
@@ -56,14 +57,22 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
         const int gl = nql + 1;                           // + the root lane
         const int rpi = 64 / gl;                          // samples per wave instruction
-        const int fsub = lane / gl, ql = lane - fsub * gl;
-        const bool lane_on = lane < rpi * gl;
+        // Three samples of 20 lanes: the third one sits in lanes 44 .. 63, not 40 .. 59.  ds_read_b128 serves the lanes in four
+        // groups of sixteen ({36-43, 48-51, 60-63} is one), and a row of 80 floats wraps around the 64 banks: the second sample's
+        // last quads (columns 68 .. 79, lanes 36-38) and the third sample's first ones (columns 4 .. 15, lanes 40-42) are different
+        // addresses in the same banks whenever the two samples share their tap rows -- one extra LDS cycle on most tap reads.
+        // Shifted, lanes 60-62 read the addresses lanes 36-38 read (a broadcast).
+        const bool shift3 = MG_SWEEP_LANEMAP && gl == 20;
+        const int lane_s = (shift3 && lane >= 40) ? lane - 4 : lane;
+        const int fsub = lane_s / gl, ql = lane_s - fsub * gl;
+        const bool lane_on = shift3 ? (lane < 40 || lane >= 44) : lane < rpi * gl;
         const bool root_lane = ql == nql;
         const int d0 = root_lane ? 0 : nroot + 4 * ql;    // first channel of this lane
         const int nst = root_lane ? nroot : (D - d0 < 4 ? D - d0 : 4);
         const int64_t TD = (int64_t)a.T * D;
         const int dp4 = Dp * 4;
-        const int lane_img = (d0 + a.cshift) * 4;         // byte offset of the lane's quad inside a basis row
+        // byte offset of the lane's quad inside a basis row; SPLIT: the root lane takes the row's first quad, {padding, root channels}
+        const int lane_img = (SPLIT && root_lane) ? 0 : (d0 + a.cshift) * 4;
         const int lane_out = fsub * D + d0;               // float offset inside a row group
         // When every quad lane holds four floats and the root lane three (D = 79: 3 + 19 x 4), the root lane borrows the
         // row's channel 3 from quad lane 0 (a cross-lane read) and ALL lanes store four floats with one instruction;
@@ -82,6 +91,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 const mg_chunk &ck = un_prev.ck;
                 const unsigned char *img = smem + (size_t)slot * buf_bytes;
                 const float *lds_ro = (const float *)(ro_base + (size_t)slot * MG_RO_BYTES);
+                const float4 *lds_m = (const float4 *)lds_ro;   // SPLIT: {Mhi, Mlo} per sample where the root outputs would be
                 const float4 *lds_w = (const float4 *)(tb_base + (size_t)slot * MG_TB_BYTES);
                 const int *lds_mo = (const int *)(lds_w + max_nt);
                 const int col0 = ck.imin * Dp - ck.rt0 * 16;
@@ -89,13 +99,15 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 const int c1 = has1 ? cj + MG_WS_NCW : cj;
                 const unsigned char *img0 = img + (size_t)(cj * stride + col0) * 4 + lane_img;
                 const unsigned char *img1 = img + (size_t)(c1 * stride + col0) * 4 + lane_img;
-                const float *ro0 = lds_ro + cj * max_nt * 4, *ro1 = lds_ro + c1 * max_nt * 4;
+                const float *ro0 = lds_ro + cj * MG_RO_CS(max_nt), *ro1 = lds_ro + c1 * MG_RO_CS(max_nt);
                 float *or0 = out + (size_t)(un_prev.b0 + cj) * TD + (size_t)ck.t0 * D;   // wave-uniform row bases
                 float *or1 = out + (size_t)(un_prev.b0 + c1) * TD + (size_t)ck.t0 * D;
                 // two row groups x two candidates in flight per trip; the loop exists twice: with the usual row pitch
                 // (Dp = 80 floats) as a constant, and with a run-time pitch
-                auto sweep_rows = [&](auto pitch_tag) {
+                auto sweep_rows = [&](auto pitch_tag, auto all4_tag) {
                 constexpr int DP4 = decltype(pitch_tag)::value;
+                constexpr bool ALL4 = decltype(all4_tag)::value;   // the usual shape as a constant: every lane stores four floats
+                const bool all4l = ALL4 ? true : all4;
                 for (int f0 = 0; f0 < ck.nT; f0 += 2 * rpi) {
                     const int fla = f0 + fsub, flb = fla + rpi;
                     const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
@@ -106,9 +118,11 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         f32x4 v0a, v0b, v1a, v1b;
                         if (MG_DBG(4)) {   // ablation: stores only
                             v0a = v0b = v1a = v1b = f32x4{1.f, 2.f, 3.f, 4.f};
-                        } else if (!root_lane) {
+                        } else if (SPLIT || !root_lane) {
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
+                            float4 mha, mla, mhb, mlb;   // SPLIT: every lane asks (a broadcast read), the root lanes use them
+                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; mhb = lds_m[2 * fb_]; mlb = lds_m[2 * fb_ + 1]; }
                             if (MG_DBG(131072)) {
                                 v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
                                 v0b = mg_quad_taps_t<DP4>(img0 + mob, wb, dp4);
@@ -123,18 +137,29 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                                 v1a = mg_quad_fma(r1a, wa);
                                 v1b = mg_quad_fma(r1b, wb);
                             }
+                            if constexpr (SPLIT) {
+                                if (root_lane) {
+                                    if constexpr (ALL4) {   // (all4: three root channels in columns 1 .. 3)
+                                        v0a = mg_root_finish<1>(v0a, mha, mla); v0b = mg_root_finish<1>(v0b, mhb, mlb);
+                                        v1a = mg_root_finish<1>(v1a, mha, mla); v1b = mg_root_finish<1>(v1b, mhb, mlb);
+                                    } else {
+                                        v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v0b = mg_root_finish_rt(v0b, mhb, mlb, a.cshift);
+                                        v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); v1b = mg_root_finish_rt(v1b, mhb, mlb, a.cshift);
+                                    }
+                                }
+                            }
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v0b = *(const f32x4 *)&ro0[fb_ * 4];
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
                             v1b = *(const f32x4 *)&ro1[fb_ * 4];
                         }
-                        if (all4 && MG_DBG(4)) {
+                        if (all4l && MG_DBG(4)) {
                             if (oa) mg_store4_at(pa0, lane_out_b, v0a);
                             if (ob) mg_store4_at(pb0, lane_out_b, v0b);
                             if (oa && has1) mg_store4_at(pa1, lane_out_b, v1a);
                             if (ob && has1) mg_store4_at(pb1, lane_out_b, v1b);
-                        } else if (all4) {
+                        } else if (all4l) {
                             const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
                             const float b0b = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0b[0])));
                             const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
@@ -152,16 +177,24 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         }
                     } else {                                     // the chunk's last rows fill one group only: half the work
                         f32x4 v0a, v1a;
-                        if (!root_lane) {
+                        if (SPLIT || !root_lane) {
                             const float4 wa = lds_w[fa_];
                             const int moa = lds_mo[fa_];
+                            float4 mha, mla;
+                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; }
                             v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
                             v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
+                            if constexpr (SPLIT) {
+                                if (root_lane) {
+                                    if constexpr (ALL4) { v0a = mg_root_finish<1>(v0a, mha, mla); v1a = mg_root_finish<1>(v1a, mha, mla); }
+                                    else { v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); }
+                                }
+                            }
                         } else {
                             v0a = *(const f32x4 *)&ro0[fa_ * 4];
                             v1a = *(const f32x4 *)&ro1[fa_ * 4];
                         }
-                        if (all4) {
+                        if (all4l) {
                             const float b0a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v0a[0])));
                             const float b1a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(q0_lane, __builtin_bit_cast(int, v1a[0])));
                             if (root_lane) { v0a[3] = b0a; v1a[3] = b1a; }
@@ -174,8 +207,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                     }
                 }
                 };
-                if (dp4 == 320 && !MG_DBG(16384)) sweep_rows(std::integral_constant<int, 320>{});
-                else sweep_rows(std::integral_constant<int, 0>{});
+                if (dp4 == 320 && all4 && !MG_DBG(16384)) sweep_rows(std::integral_constant<int, 320>{}, std::true_type{});
+                else sweep_rows(std::integral_constant<int, 0>{}, std::false_type{});
             }
             MG_STAMP(4);
             mg_publish(prog, wave, lane, u + 1);
@@ -252,7 +285,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             const int col = ct * 16 + cl;
             const bool colok = col < MG_NCAND * nroot;
             const int cc = colok ? col / nroot : 0, cd = colok ? col - cc * nroot : 0;
-            tap_o_off[ct] = colok ? cc * max_nt * 4 + cd : -1;
+            tap_o_off[ct] = colok ? cc * MG_RO_CS(max_nt) + cd : -1;
 #pragma unroll
             for (int ks = 0; ks < MG_TAP_KS; ks++) {
                 const int m = 4 * ks + g;
@@ -269,6 +302,17 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
             float4 r_w = {0.f, 0.f, 0.f, 0.f};
             int r_i0 = 0;
             if (lane < ck.nT) { r_w = w32[ck.t0 + lane]; r_i0 = i0tab[ck.t0 + lane]; }
+            if constexpr (SPLIT) {   // the mean/delta split: the unit's tables only; the root lanes of the sweep finish the root channels
+                float4 *tm = (float4 *)(ro_base + (size_t)slot * MG_RO_BYTES);
+                if (lane < ck.nT) {
+                    const float4 mh = rootm[2 * (ck.t0 + lane)], ml = rootm[2 * (ck.t0 + lane) + 1];
+                    tw[lane] = r_w;
+                    tmo[lane] = (r_i0 - ck.imin) * Dp * 4;
+                    tm[2 * lane] = mh;
+                    tm[2 * lane + 1] = ml;
+                }
+                return;
+            }
             double r_wt[MG_TAP_FT * MG_TAP_KS];
 #pragma unroll
             for (int e = 0; e < MG_TAP_FT * MG_TAP_KS; e++) r_wt[e] = wtap[((size_t)un.chunk * (MG_TAP_FT * MG_TAP_KS) + e) * 64 + lane];
@@ -390,13 +434,14 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
 // -----------------------------------------------------------------------------------------
 // launch
 // -----------------------------------------------------------------------------------------
-template <int KK, bool LAT_F64, bool FUSE>
+template <int KK, bool LAT_F64, bool FUSE, bool SPLIT>
 static int mg_launch_ws_inst(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
                                  int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
     // hipExtLaunchKernelGGL with NULL events is hipLaunchKernelGGL; with events the dispatch records its own begin and end
-    hipExtLaunchKernelGGL((mg_frames_ws_kernel<KK, LAT_F64, FUSE>), dim3(grid), dim3(MG_WS_BLOCK), lds, p->ctx->stream, ev.start, ev.stop, 0,
+    hipExtLaunchKernelGGL((mg_frames_ws_kernel<KK, LAT_F64, FUSE, SPLIT>), dim3(grid), dim3(MG_WS_BLOCK), lds, p->ctx->stream, ev.start, ev.stop, 0,
                           (const float *)p->d_Epack, (const float *)p->d_mean32, (const double *)p->d_Erpack, (const double *)p->d_meanroot, lat,
-                          (const int32_t *)g->d_i0, (const float4 *)g->d_w32, (const double *)g->d_wtap, (const mg_chunk *)g->d_chunks, out,
+                          (const int32_t *)g->d_i0, (const float4 *)g->d_w32, (const double *)g->d_wtap, (const float4 *)g->d_rootm,
+                          (const mg_chunk *)g->d_chunks, out,
                           (const double *)p->d_gPpack, (const double *)p->d_gmPpad, (const double *)p->d_gconst, logp, a, (int)p->K,
                           (int)((p->L + 15) / 16), buf_bytes);
     MG_HIP_CHECK(hipGetLastError());
@@ -405,34 +450,41 @@ static int mg_launch_ws_inst(mg_primitive *p, const mg_time_grid *g, const void 
 
 template <int KK>
 static int mg_launch_ws_kk(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a,
-                               bool lat_f64, int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
+                               bool lat_f64, bool split, int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
     if (logp) {
         // fused instances exist for <= 40 components: beyond that the mixture fragments no longer fit the
         // register budget next to the sweep (mg_frames_can_fuse_gmm refuses, so this is never reached)
-        if constexpr (KK <= MG_FUSE_MAX_KK)
-            return lat_f64 ? mg_launch_ws_inst<KK, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev)
-                           : mg_launch_ws_inst<KK, false, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev);
+        if constexpr (KK <= MG_FUSE_MAX_KK) {
+            if (split)
+                return lat_f64 ? mg_launch_ws_inst<KK, true, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev)
+                               : mg_launch_ws_inst<KK, false, true, true>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev);
+            return lat_f64 ? mg_launch_ws_inst<KK, true, true, false>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev)
+                           : mg_launch_ws_inst<KK, false, true, false>(p, g, lat, out, logp, a, buf_bytes, lds, grid, ev);
+        }
         mg_set_error("mg_step_frames_and_logp: no fused kernel for %d components", p->L);
         return MG_ERR_UNSUPPORTED;
     }
-    return lat_f64 ? mg_launch_ws_inst<KK, true, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev)
-                   : mg_launch_ws_inst<KK, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev);
+    if (split)
+        return lat_f64 ? mg_launch_ws_inst<KK, true, false, true>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev)
+                       : mg_launch_ws_inst<KK, false, false, true>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev);
+    return lat_f64 ? mg_launch_ws_inst<KK, true, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev)
+                   : mg_launch_ws_inst<KK, false, false, false>(p, g, lat, out, nullptr, a, buf_bytes, lds, grid, ev);
 }
 
 int mg_launch_frames_ws(mg_primitive *p, const mg_time_grid *g, const void *lat, float *out, float *logp, const mg_frames_args &a, bool lat_f64,
-                        int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
+                        bool split, int buf_bytes, int lds, int grid, const mg_launch_events &ev) {
     switch (p->KK) {
 #ifndef MG_ONLY_KK10
-        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
+        case 2: return mg_launch_ws_kk<2>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 4: return mg_launch_ws_kk<4>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 6: return mg_launch_ws_kk<6>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 8: return mg_launch_ws_kk<8>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
 #endif
-        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
+        case 10: return mg_launch_ws_kk<10>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
 #ifndef MG_ONLY_KK10
-        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
-        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, logp, a, lat_f64, buf_bytes, lds, grid, ev);
+        case 12: return mg_launch_ws_kk<12>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 14: return mg_launch_ws_kk<14>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
+        case 16: return mg_launch_ws_kk<16>(p, g, lat, out, logp, a, lat_f64, split, buf_bytes, lds, grid, ev);
 #endif
         default: mg_set_error("mg_back_project_frames: MFMA path needs n_components <= 64"); return MG_ERR_UNSUPPORTED;
     }
@@ -440,11 +492,15 @@ int mg_launch_frames_ws(mg_primitive *p, const mg_time_grid *g, const void *lat,
 
 template <int KK>
 static int mg_ws_attr_kk() {
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if constexpr (KK <= MG_FUSE_MAX_KK) {
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frames_ws_kernel<KK, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return MG_OK;
 }

@@ -572,6 +572,8 @@ static void mg_free_grid_device(mg_time_grid *g) {
     mg_dev_free(ctx, g->d_i0);
     mg_dev_free(ctx, g->d_w);
     mg_dev_free(ctx, g->d_w32);
+    mg_dev_free(ctx, g->d_rootm);
+    g->d_rootm = nullptr;
     mg_dev_free(ctx, g->d_wtap);
     g->d_wtap = nullptr;
     mg_dev_free(ctx, g->d_chunks);
@@ -590,7 +592,7 @@ static int mg_round_stride(int nlocal) {
 // three per-sample table sets, two float64 root images.
 static int mg_lds_bytes(const mg_primitive *p, int stride, int wi, int nbuf = 2, int max_nt = MG_MAX_NT) {
     int buf = (MG_NCAND * stride * 4 + 255) / 256 * 256;
-    int rout = MG_NCAND * max_nt * 16;
+    int rout = MG_RO_BYTES_N(max_nt);
     int tabs = max_nt * 16 + max_nt * 4;
     int root = MG_NCAND * (wi * p->nroot + 1) * 8;
     return nbuf * (buf + rout + tabs) + root + 128;
@@ -683,7 +685,7 @@ static void mg_plan_chunks(mg_primitive *p, mg_time_grid *g) {
     for (const mg_chunk &c : g->chunks) g->max_tiles = std::max(g->max_tiles, c.ntiles);
     {
         const int buf = (MG_NCAND * max_stride * 4 + 255) / 256 * 256;
-        g->cs_lds_bytes = 2 * (buf + MG_NCAND * g->max_nt * 16) + g->max_nt * 20 + MG_NCAND * (max_wi * p->nroot + 1) * 8 + g->max_tiles * 64 +
+        g->cs_lds_bytes = 2 * (buf + MG_RO_BYTES_N(g->max_nt)) + g->max_nt * 20 + MG_NCAND * (max_wi * p->nroot + 1) * 8 + g->max_tiles * 64 +
                           MG_TAP_FT * MG_TAP_KS * 64 * 8 + 512 + 2 * p->KK * 64 * 4 + 256;   // + tap weights, root means, two latent tiles, 64 counters
         g->cs_ok = g->mfma_ok && g->max_tiles <= mg_cs_max_tiles(p->KK) && g->cs_lds_bytes <= budget1 && (int)g->chunks.size() <= MG_ARG_CHUNKS;
     }
@@ -712,6 +714,20 @@ static int mg_grid_build(mg_primitive *p, mg_time_grid *g, const double *times, 
     if ((rc = mg_upload(p->ctx, g->i0, &g->d_i0)) != MG_OK) return rc;
     if ((rc = mg_upload(p->ctx, g->w, &g->d_w)) != MG_OK) return rc;
     if ((rc = mg_upload(p->ctx, w32, &g->d_w32)) != MG_OK) return rc;
+    {   // the root channels' mean part (mean/delta split, mg_primitive_root_mode): M[f][d] = w0 m0, fma(w1, m1, .), fma(w2, m2, .),
+        // fma(w3, m3, .) in float64 with m_j = mean'[(i0[f] + j) D + d]; Mhi = (float)M, Mlo = (float)(M - Mhi)
+        std::vector<float> rootm((size_t)std::max(T, 1) * 8, 0.0f);
+        for (int f = 0; f < T; f++)
+            for (int d = 0; d < p->nroot; d++) {
+                const double *m = &p->means_[(size_t)g->i0[f] * p->D + d];
+                double M = g->w[4 * (size_t)f] * m[0];
+                for (int j = 1; j < 4; j++) M = std::fma(g->w[4 * (size_t)f + j], m[(size_t)j * p->D], M);
+                const float hi = (float)M;
+                rootm[8 * (size_t)f + d] = hi;
+                rootm[8 * (size_t)f + 4 + d] = (float)(M - (double)hi);
+            }
+        if ((rc = mg_upload(p->ctx, rootm, &g->d_rootm)) != MG_OK) return rc;
+    }
     if ((rc = mg_upload(p->ctx, g->chunks, &g->d_chunks)) != MG_OK) return rc;
     {   // banded tap weights of every chunk as v_mfma_f64_16x16x4_f64 A fragments: lane l supplies
         // W[f = 16 ft + (l & 15)][m = 4 ks + (l >> 4)],  W[f][m] = w[f][m - (i0[f] - imin)] inside the band
@@ -847,7 +863,8 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
         {
             std::vector<float> m32((size_t)p->RT * 16, 0.0f);
             for (int i = 0; i < NB; i++)
-                for (int dd = 0; dd < D; dd++) m32[(size_t)i * p->Dp + dd + p->cshift] = (float)p->means_[(size_t)i * D + dd];
+                for (int dd = p->nroot; dd < D; dd++)   // the root rows' C-in is zero: they hold E'.s alone (the split's delta)
+                    m32[(size_t)i * p->Dp + dd + p->cshift] = (float)p->means_[(size_t)i * D + dd];
             if (rc == MG_OK) rc = mg_upload(ctx, m32, &p->d_mean32);
         }
         if (rc == MG_OK && p->KK > 0) {
@@ -980,6 +997,31 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
         if (rc != MG_OK) { mg_primitive_free(p); return rc; }
     }
 
+    {   // the mean/delta split's accuracy gate (mg_primitive_root_mode)
+        std::vector<double> m2(L, 1.0);
+        double wsum = 0.0;
+        for (int j = 0; j < K; j++) wsum += p->gw[j];
+        if (K > 0)
+            for (int k = 0; k < L; k++) {
+                double acc = 0.0;
+                for (int j = 0; j < K; j++) {
+                    const double mu = p->gm[(size_t)j * Lg + k];
+                    acc += p->gw[j] * (mu * mu + p->gc[(size_t)j * Lg * Lg + (size_t)k * Lg + k]);
+                }
+                m2[k] = acc / wsum;
+            }
+        double worst = 0.0;
+        for (int i = 0; i < NB; i++)
+            for (int dd = 0; dd < p->nroot; dd++) {
+                const double *e = &p->Es[((size_t)i * D + dd) * L];
+                double ss = 0.0;
+                for (int k = 0; k < L; k++) ss += e[k] * e[k] * m2[k];
+                worst = std::max(worst, std::sqrt(ss));
+            }
+        p->root_split_est = (double)(L + 8) * 0x1p-24 * worst;
+        p->root_split = std::isfinite(p->root_split_est) && p->root_split_est <= MG_ROOT_SPLIT_MAX_EST;
+    }
+
     if (Lt > 0) {
         // mean time spline and harmonics at the canonical frames 0 .. F-1 (reference motion_primitive.py:258-268,293-296:
         // si.splev(canonical_time_range, (knots_t, coefficients, 3)); column l of eigen_vectors_time = coefficients of harmonic l)
@@ -1048,6 +1090,13 @@ extern "C" int mg_primitive_info(const mg_primitive *p, int32_t *o) {
     o[0] = p->NB; o[1] = p->D; o[2] = p->L; o[3] = p->F; o[4] = p->K; o[5] = p->KK;
     o[6] = (p->canonical && p->canonical->mfma_ok) ? 1 : 0;
     o[7] = p->canonical ? p->canonical->n_chunks : 0;
+    return MG_OK;
+}
+
+extern "C" int mg_primitive_root_mode(const mg_primitive *p, int32_t *split, double *estimate) {
+    MG_REQUIRE(p != nullptr, "mg_primitive_root_mode: primitive is NULL");
+    if (split) *split = mg_frames_root_split(p) ? 1 : 0;
+    if (estimate) *estimate = p->root_split_est;
     return MG_OK;
 }
 

@@ -97,6 +97,16 @@ int mg_prof_resolve(mg_context *ctx);
 #define MG_TAP_KS ((MG_MAX_WI + 3) / 4)   // k-steps of the banded root-tap MFMA (4 basis functions each)
 #define MG_TAP_FT (MG_MAX_NT / 16)       // sample tiles of 16 of the root-tap MFMA
 #define MG_ARG_CHUNKS 8   // chunk descriptors that travel in the frames kernels' arguments
+// LDS of the frames kernels per ring slot: per-sample tables (tap weights + tap row offsets) and the root outputs
+// [candidate][sample][4] float32.  nt = the grid's longest chunk, rounded up to 16 samples.  A candidate's root outputs are
+// MG_RO_PAD floats apart from a multiple of 32: wave 0 writes them one float per lane, (candidate, channel) x sample, and with a
+// stride of 4 nt floats (0 mod 32 banks for nt = 16, 32, 48) the six candidates of a column tile meet in the same banks.
+#ifndef MG_RO_PAD
+#define MG_RO_PAD 8
+#endif
+#define MG_RO_CS(nt) ((nt) * 4 + MG_RO_PAD)              // floats per candidate
+#define MG_TB_BYTES_N(nt) ((nt) * 16 + (nt) * 4)
+#define MG_RO_BYTES_N(nt) (MG_NCAND * MG_RO_CS(nt) * 4)
 struct mg_chunk {
     int32_t t0;        // first time index (chunks are runs of consecutive time indices)
     int32_t nT;        // number of time samples in the chunk, <= MG_MAX_NT
@@ -120,6 +130,8 @@ struct mg_time_grid {
     int32_t *d_i0 = nullptr;
     double *d_w = nullptr;      // (T,4) float64 weights
     float *d_w32 = nullptr;     // (T,4) float32 weights
+    float *d_rootm = nullptr;   // (T,8) the root channels' mean part M[f][d] = spline of mean' alone (float64 on the host) as
+                                // float32 pairs: {Mhi[0..2], 0, Mlo[0..2], 0} (the mean/delta split of the frames kernels)
     double *d_wtap = nullptr;   // [n_chunks][2][2][64] banded tap weights, f64 MFMA A fragments
     mg_chunk *d_chunks = nullptr;
     int32_t n_chunks = 0;
@@ -137,7 +149,9 @@ struct mg_time_grid {
 struct mg_primitive {
     mg_context *ctx = nullptr;
     int32_t NB = 0, D = 0, L = 0, F = 0, K = 0, R = 0;
-    int32_t nroot = 0;  // min(3, D): channels computed in float64
+    int32_t nroot = 0;  // min(3, D): root-translation channels (float64 pipeline or mean/delta split)
+    bool root_split = false;      // the accuracy gate allows the mean/delta split (mg_primitive_root_mode)
+    double root_split_est = 0.0;  // its error estimate
     int32_t KK = 0;     // MFMA k-steps (even), 0 when L > 64
     int32_t Lg = 0;     // dimension of the mixture (>= L: spatial + time latents)
     int32_t KKg = 0;    // MFMA k-steps of the mixture kernels (even), 0 when Lg > 64
@@ -158,7 +172,8 @@ struct mg_primitive {
     double *d_Et64 = nullptr;    // [L][R] f64
     double *d_Erpack = nullptr;  // [RRT][KK][64] f64 MFMA A fragments of the root rows (row = i*nroot + d)
     double *d_meanroot = nullptr;  // [RRT*16] f64 mean' of the root rows
-    float *d_mean32 = nullptr;   // [RT*16] f32 mean' in padded-row order (zero padded)
+    float *d_mean32 = nullptr;   // [RT*16] f32 mean' in padded-row order (zero padded; zero on the root rows as well, which
+                                 // therefore hold E'.s alone: the delta of the mean/delta split)
     double *d_mean = nullptr;    // (R) f64
     int32_t RRT = 0;             // 16-row tiles of the root-row space
     // GMM device constants
@@ -209,6 +224,8 @@ int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_
 int mg_output_class(mg_context *ctx, const void *p);   // mg_placement.hip: 1 fast, 0 slow (a piece of a placed region), -1 not the arena's
 int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused);
 int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int which);
+bool mg_frames_root_split(const mg_primitive *p);   // the root-channel mode a launch uses (gate + MG_OPT_ROOT_MODE)
+#define MG_ROOT_SPLIT_MAX_EST 5e-6
 int mg_cs_max_tiles(int KK);   // row tiles of a chunk window the chunk-stationary kernel can hold in registers
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);

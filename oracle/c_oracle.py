@@ -32,6 +32,7 @@ def lib():
         _lib.orc_first_min_argmin_f64.restype = C.c_int64
         _lib.orc_first_min_argmin_f32.restype = C.c_int64
         _lib.orc_precision_cholesky.restype = C.c_int
+        _lib.orc_root_split_estimate.restype = C.c_double
     return _lib
 
 
@@ -63,6 +64,13 @@ class COraclePrimitive(object):
         rc = lib().orc_precision_cholesky(_ptr(self.covars, _dp), self.K, self.L, _ptr(self.prec_chol, _dp))
         if rc != 0:
             raise ValueError("covariance %d not positive definite" % (rc - 1))
+        # the root channels' mode of the float32 contract (include/mg_hip.h, mg_primitive_root_mode): the mean/delta split
+        # where its error estimate is at most 5e-6, the float64 pipeline otherwise
+        Lg = self.means.shape[1] if self.K else self.L
+        self.root_split_estimate = float(lib().orc_root_split_estimate(
+            _ptr(self.E, _dp), _ptr(self.tm, _dp), self.NB, self.D, self.L, self.K, Lg,
+            _ptr(self.weights, _dp), _ptr(self.means, _dp), _ptr(self.covars, _dp)))
+        self.root_split = bool(np.isfinite(self.root_split_estimate) and self.root_split_estimate <= 5e-6)
 
     def canonical_time_function(self):
         out = np.empty(self.F)
@@ -93,13 +101,16 @@ class COraclePrimitive(object):
                                           C.c_int64(S.shape[1]), _ptr(out, _dp))
         return out
 
-    def frames_f32model(self, S, tp=None):
+    def frames_f32model(self, S, tp=None, root_split=None):
+        """root_split: None = the mode the contract's accuracy gate prescribes for this primitive."""
         S = _d(np.atleast_2d(S))   # float32 callers pass exactly representable values
         tp = self.canonical_time_function() if tp is None else _d(np.atleast_1d(tp))
         out = np.empty((S.shape[0], len(tp), self.D), dtype=np.float32)
-        lib().orc_back_project_frames_f32model(_ptr(self.E, _dp), _ptr(self.mean, _dp), _ptr(self.tm, _dp),
-                                               self.NB, self.D, self.L, _ptr(self.knots, _dp), _ptr(tp, _dp), len(tp),
-                                               _ptr(S, _dp), C.c_int64(S.shape[0]), C.c_int64(S.shape[1]), _ptr(out, _fp))
+        split = self.root_split if root_split is None else bool(root_split)
+        lib().orc_back_project_frames_f32model_mode(_ptr(self.E, _dp), _ptr(self.mean, _dp), _ptr(self.tm, _dp),
+                                                    self.NB, self.D, self.L, _ptr(self.knots, _dp), _ptr(tp, _dp), len(tp),
+                                                    _ptr(S, _dp), C.c_int64(S.shape[0]), C.c_int64(S.shape[1]),
+                                                    C.c_int(1 if split else 0), _ptr(out, _fp))
         return out
 
     def log_prob_f64(self, X):

@@ -1440,3 +1440,103 @@ def test_lds_resident_mixture_kernel_is_bit_identical(ctx, case):
     np.testing.assert_allclose(prim.gmm_log_prob(g["X"], dtype=np.float64), g["logp"], rtol=1e-9, atol=1e-7)
     ctx.set_option(_capi.MG_OPT_GMM_KERNEL, 0)
     prim.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The root channels' two modes (include/mg_hip.h, mg_primitive_root_mode): float64 pipeline and mean/delta split
+# ---------------------------------------------------------------------------------------------------------------------
+def test_root_mode_gate_agrees_with_the_oracle(ctx, golden_case):
+    """The accuracy gate is part of the float32 contract: the library and the oracle's restatement of it pick the same mode
+    for every golden primitive (and every other test's cp.frames_f32model(S) relies on that)."""
+    name, data, g = golden_case
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    np.testing.assert_allclose(prim.root_split_estimate, cp.root_split_estimate, rtol=1e-12)
+    assert prim.root_split == cp.root_split, name
+    ctx.set_option(_capi.MG_OPT_ROOT_MODE, 1)
+    assert prim.root_split is False
+    ctx.set_option(_capi.MG_OPT_ROOT_MODE, 2)
+    assert prim.root_split is True
+    prim.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_root_modes_bit_exact_on_every_kernel(ctx, golden_case, mode):
+    """Both modes forced on every golden primitive: the direct kernel, the tile-major and the chunk-stationary kernel (where
+    they cover the shape), float64 and float32 latents, canonical grid and an evaluation grid -- bit for bit the oracle's model
+    of that mode; the float64 pipeline also within the north-star tolerance of the reference's frames whatever the primitive
+    (the split only where the gate allows it: test_root_split_where_the_gate_allows_it)."""
+    name, data, g = golden_case
+    ctx.set_option(_capi.MG_OPT_ROOT_MODE, mode)
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    split = mode == 2
+    assert prim.root_split == split
+    rng = np.random.default_rng(41)
+    L = g["S"].shape[1]
+    S = np.concatenate([g["S"], rng.standard_normal((300, L))]).astype(np.float64)
+    model = cp.frames_f32model(S, root_split=split)
+    got = prim.back_project_frames(S, path=_capi.MG_PATH_DIRECT)
+    np.testing.assert_array_equal(_bits(got), _bits(model), err_msg="%s direct" % name)
+    ref = g["frames"]
+    if not split:
+        assert np.all(np.abs(got[:len(ref)].astype(np.float64) - ref) <= pose_tol(ref))
+    if prim.mfma_supported:
+        S32 = S.astype(np.float32)
+        model32 = cp.frames_f32model(S32.astype(np.float64), root_split=split)
+        times = np.array([0.0, 0.25, (prim.n_canonical_frames - 1) / 2.0, prim.n_canonical_frames - 1.0, prim.n_canonical_frames + 2.0, -1.0])
+        grid = prim.time_grid(times)
+        model_t = cp.frames_f32model(S, tp=times, root_split=split)
+        for kern in (1, 2):
+            _set_frames_kernel(ctx, kern)
+            try:
+                got = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+            except _capi.MGError as e:
+                assert kern == 2 and e.status == -4, e   # MG_ERR_UNSUPPORTED: the window does not fit the registers
+                continue
+            np.testing.assert_array_equal(_bits(got), _bits(model), err_msg="%s kernel %d" % (name, kern))
+            np.testing.assert_array_equal(_bits(prim.back_project_frames(S32, path=_capi.MG_PATH_MFMA)), _bits(model32))
+            try:
+                got_t = prim.back_project_frames(S, grid=grid, path=_capi.MG_PATH_MFMA)
+            except _capi.MGError as e:
+                assert kern == 2 and e.status == -4, e
+                continue
+            np.testing.assert_array_equal(_bits(got_t), _bits(model_t), err_msg="%s kernel %d, evaluation grid" % (name, kern))
+        grid.close()
+    prim.close()
+
+
+@pytest.mark.parametrize("B", [17, 1000, 8192 + 5])
+def test_root_split_where_the_gate_allows_it(ctx, B):
+    """A 'walk'-sized primitive whose root translation varies little between candidates (root rows of the eigenvectors not
+    scaled up): the gate picks the split by itself; results are bit for bit the oracle's model, within the north-star
+    tolerance of the float64 frames (the reference's arithmetic, device float64 kernel pinned by the golden tests), the same
+    from all three kernels and from the fused step."""
+    data = synthetic.make_walk_primitive(seed=3, realistic=False)
+    m = np.array(data["mean_spatial_vector"]).reshape(-1, 79)
+    m[:, :3] *= 100.0                       # root translation of realistic size, its variation small
+    data["mean_spatial_vector"] = m.reshape(-1).tolist()
+    prim = _capi.Primitive(ctx, data)
+    cp = c_oracle.COraclePrimitive(data)
+    assert cp.root_split and prim.root_split and prim.root_split_estimate <= 5e-6
+    rng = np.random.default_rng(B)
+    for dtype in (np.float32, np.float64):
+        S = (2.2 * rng.standard_normal((B, 40))).astype(dtype)   # the spread of the primitive's mixture (second moment ~5)
+        n_model = min(B, 300)
+        model = cp.frames_f32model(S[:n_model].astype(np.float64))
+        ref = prim.back_project_frames_f64(S[:n_model].astype(np.float64))
+        direct = prim.back_project_frames(S[:n_model], path=_capi.MG_PATH_DIRECT)
+        np.testing.assert_array_equal(_bits(direct), _bits(model))
+        err = np.abs(model.astype(np.float64) - ref)
+        assert np.all(err <= pose_tol(ref)), float((err / pose_tol(ref)).max())
+        outs = []
+        for kern in (1, 2):
+            _set_frames_kernel(ctx, kern)
+            outs.append(prim.back_project_frames(S, path=_capi.MG_PATH_MFMA))
+            np.testing.assert_array_equal(_bits(outs[-1][:n_model]), _bits(model), err_msg="kernel %d B=%d" % (kern, B))
+        np.testing.assert_array_equal(_bits(outs[0]), _bits(outs[1]))
+        _set_frames_kernel(ctx, 0)
+        frames, logp = _fused_step(ctx, prim, S, 156, 79)
+        np.testing.assert_array_equal(_bits(frames), _bits(outs[0]))
+        np.testing.assert_array_equal(logp, prim.gmm_log_prob(S, dtype=np.float32))
+    prim.close()

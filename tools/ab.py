@@ -3,7 +3,7 @@
 SAME output buffer, variants interleaved round by round (cdna_hip_programming.md, methodology rule 24).
 
     python3 tools/ab.py VARIANT [VARIANT ...] [--rounds 6] [--steps 300] [--plain] [--two-launch]
-    VARIANT = path/to/lib.so[:debug_flags[:kernel[:window[:arena_MiB]]]]   kernel: 0 = by batch size, 1 = tile-major, 2 = chunk-stationary;
+    VARIANT = path/to/lib.so[:debug_flags[:kernel[:window[:arena_MiB[:root]]]]]   root: MG_OPT_ROOT_MODE (0 gate, 1 float64, 2 split); kernel: 0 = by batch size, 1 = tile-major, 2 = chunk-stationary;
               window: MG_OPT_CHUNK_WINDOW (basis functions per time chunk, 0 = the planner's choice)
               e.g.  morphablegraphs_amd/csrc/libmg_hip.so  build/lib_x.so::1  dbg.so:1  dbg.so:512:2  lib.so::2:7
 
@@ -38,6 +38,7 @@ for v in args.variants:
     path, flags, kern = os.path.abspath(parts[0]), (parts[1] if len(parts) > 1 else ""), int(parts[2]) if len(parts) > 2 and parts[2] else 0
     window = int(parts[3]) if len(parts) > 3 and parts[3] else 0
     arena = int(parts[4]) if len(parts) > 4 and parts[4] else 0   # MiB per arena block for the primitive's constants (0: one hipMalloc each)
+    root = int(parts[5]) if len(parts) > 5 and parts[5] else 0
     path = (path, window, arena)
     if path not in libs:
         lib = _capi.load_library(path[0])
@@ -49,7 +50,7 @@ for v in args.variants:
         if arena:
             ctx.arena_end()
         print(v, libs[path][2].step_plan(B), flush=True)
-    var.append((v, path, flags, kern))
+    var.append((v, path, flags, kern, root))
 ctx0 = libs[var[0][1]][1]
 S = ctx0.upload(np.random.default_rng(0).standard_normal((B, L)).astype(np.float32))
 lp = ctx0.malloc(B * 4)
@@ -85,9 +86,10 @@ def run(prim, n):
 
 times = {v[0]: [] for v in var}
 for r in range(args.rounds + 1):
-    for name, path, flags, kern in var:
+    for name, path, flags, kern, root in var:
         lib, ctx, prim = libs[path]
         ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, kern)
+        ctx.set_option(_capi.MG_OPT_ROOT_MODE, root)
         if flags:
             os.environ["MG_DEBUG_FLAGS"] = flags
         else:
@@ -100,9 +102,10 @@ for r in range(args.rounds + 1):
         if r > 0:   # round 0 warms the clocks
             times[name].append(1e6 * (time.perf_counter() - t0) / args.steps)
 ref = None
-for name, path, flags, kern in var:   # every variant must write the same bytes as the first one
+for name, path, flags, kern, root in var:   # every variant must write the same bytes as the first one (of its root mode)
     lib, ctx, prim = libs[path]
     ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, kern)
+    ctx.set_option(_capi.MG_OPT_ROOT_MODE, root)
     if flags:
         continue                       # ablations change the results by design
     os.environ.pop("MG_DEBUG_FLAGS", None)
@@ -116,6 +119,6 @@ for name, path, flags, kern in var:   # every variant must write the same bytes 
     else:
         print("%-60s frames %s  log p %s" % (name, "identical" if np.array_equal(ref[0], got[0], equal_nan=True) else "DIFFER",
                                              "identical" if np.array_equal(ref[1], got[1], equal_nan=True) else "DIFFER"))
-for name, _, _, _ in var:
+for name, _, _, _, _ in var:
     t = np.array(times[name])
     print("%-60s median %.2f  min %.2f  max %.2f us" % (name, np.median(t), t.min(), t.max()))
