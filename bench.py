@@ -404,7 +404,12 @@ def run_walk(args, rank, local_rank, world):
         placement = {"allocator": "one hipMalloc (MG_OPT_PLAIN_MALLOC)" if args.output_alloc == "plain" else "the library's placed output regions (mg_device_malloc / mg_device_malloc_placed: every buffer of 64 MiB and more, "
                                   "the *_host entry points' scratch included, is a piece of a region that went through the placement probe; scan of at most 32 candidates, a quarter of the free memory held at most)",
                      "candidates_probed": frames.placement["probed"] if frames.placement else 0, "alloc_seconds": round(alloc_s, 4),
-                     "pattern_over_fill": round(probe["ratio"], 4), "fast_class": probe["fast"]}
+                     "pattern_over_fill": round(probe["ratio"], 4)}
+        # the class is the arena's: decided once from the scan's own measurement and kept (mg_device_placement_info); the probe
+        # above only supplies the in-run fill / pattern times of the roofline's 'achievable' figures
+        arena = ctx.placement_info(frames)
+        placement["fast_class"] = arena["fast"] if arena["region"] else probe["fast"]
+        placement["pattern_TBps"] = round(arena["pattern_TBps"], 3) if arena["region"] else round(B * F * D * 4 / probe["pattern_us"] * 1e-6, 3)
         result = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -460,10 +465,10 @@ def run_walk(args, rank, local_rank, world):
                 # headline's region is in use, so this one is a region of its own, scanned for like the first); (2) memory that does not
                 # come from the library at all -- one hipMalloc, wherever it landed -- which is what a caller's own tensor would be
                 second = ctx.malloc(nbytes)
-                ps = ctx.probe_placement(second)
+                ps = ctx.placement_info(second)      # the arena's own record of the region this piece came from
                 us_second = wall_us(200, second)
                 result["config"]["output_placement"]["default_malloc"] = {"allocator": "mg_device_malloc (a second buffer of the same size beside the headline's)", "step_us": round(us_second, 2),
-                                                                          "pattern_over_fill": round(ps["ratio"], 4), "fast_class": ps["fast"]}
+                                                                          "pattern_over_fill": round(ps["ratio"], 4), "fast_class": ps["fast"], "pattern_TBps": round(ps["pattern_TBps"], 3)}
                 second.free()
                 ctx.set_option(_capi.MG_OPT_PLAIN_MALLOC, 1)
                 plain = ctx.malloc(nbytes)
@@ -471,7 +476,8 @@ def run_walk(args, rank, local_rank, world):
                 pp = ctx.probe_placement(plain)
                 us_plain = wall_us(200, plain)
                 result["config"]["output_placement"]["foreign_hipMalloc"] = {"allocator": "one hipMalloc outside the library's regions (MG_OPT_PLAIN_MALLOC)", "step_us": round(us_plain, 2),
-                                                                             "pattern_over_fill": round(pp["ratio"], 4), "fast_class": pp["fast"]}
+                                                                             "pattern_over_fill": round(pp["ratio"], 4), "fast_class": pp["fast"],
+                                                                             "pattern_TBps": round(B * F * D * 4 / pp["pattern_us"] * 1e-6, 3) if pp["pattern_us"] > 0 else None}
                 plain.free()
                 result["value_default_malloc"] = B / (us_second * 1e-6)
                 result["value_foreign_hipMalloc"] = B / (us_plain * 1e-6)

@@ -227,6 +227,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_SCORE_KERNEL       mg_score_constraints on the matrix pipe: 0 = by batch size, 1 = a wave per 16-candidate tile, (candidate,
  *                             constraint) pairs on the lanes, 2 = a wave per 64 candidates, a lane per candidate (from 49 152
  *                             candidates on by default) -- identical results
+ *   MG_OPT_PLACED_HOLD        n > 0: the placement scan holds at most n candidates at once (default: a quarter of the free memory);
+ *                             tests use it to make the scan drop candidates while it runs
  *   MG_OPT_ROOT_MODE          how the float32 frames kernels compute the root-translation channels (the two forms differ in
  *                             the last bits; see mg_primitive_root_mode): 0 = what the primitive's accuracy gate says,
  *                             1 = the float64 pipeline, 2 = the mean/delta split */
@@ -242,7 +244,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_GMM_KERNEL 9
 #define MG_OPT_SCORE_KERNEL 10
 #define MG_OPT_ROOT_MODE 11
-#define MG_OPT_COUNT 12
+#define MG_OPT_PLACED_HOLD 12
+#define MG_OPT_COUNT 13
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
@@ -288,6 +291,12 @@ int mg_device_malloc_placed(mg_context *ctx, int64_t bytes, int32_t max_candidat
 /* the probe alone, on any device buffer of at least 64 MiB: info4 as above ([0] = 1).  It OVERWRITES the buffer (the probe
  * is a store pattern and a fill): call it before the buffer holds anything. */
 int mg_device_probe_placement(mg_context *ctx, void *buf_dev, int64_t bytes, double *info4);
+/* What the arena already knows about memory it handed out -- no probe, nothing written: info4 = {1 if buf_dev is (inside) a piece
+ * of one of the context's placed regions, the region's pattern / fill ratio, its pattern time in us, 1 if the region is in the
+ * fast class}; *tbps (may be NULL) = the pattern's rate in TB/s in the scan that classified the region (0: the request was too
+ * small to fill the chip).  A region's class is decided ONCE, from its scan (fast from 5.9 TB/s on; the scan stops at the first
+ * candidate of 6.0 TB/s and more), and stays: this is what mg_step_plan_for and the kernels' choice go by. */
+int mg_device_placement_info(mg_context *ctx, const void *buf_dev, double *info4, double *tbps);
 int mg_memcpy_h2d(mg_context *ctx, void *dst_dev, const void *src, int64_t bytes);
 int mg_memcpy_d2h(mg_context *ctx, void *dst, const void *src_dev, int64_t bytes);
 int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);

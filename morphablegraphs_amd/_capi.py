@@ -7,6 +7,7 @@ only owns handles and converts NumPy arrays; the reference-shaped classes live i
 motion_primitive.py / motion_spline.py / gaussian_mixture.py.
 """
 import ctypes as C
+import itertools
 import os
 
 import numpy as np
@@ -27,7 +28,8 @@ MG_OPT_PLAIN_MALLOC = 8      # 1 = mg_device_malloc is one hipMalloc whatever th
 MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile per workgroup, 2 = fragments resident in LDS
 MG_OPT_SCORE_KERNEL = 10     # mg_score_constraints: 0 = by batch size, 1 = a wave per 16 candidates, 2 = a wave per 64 candidates
 MG_OPT_ROOT_MODE = 11        # root channels of the float32 frames kernels: 0 = the primitive's gate, 1 = float64 pipeline, 2 = mean/delta split
-MG_OPT_COUNT = 12
+MG_OPT_PLACED_HOLD = 12      # n > 0: the placement scan holds at most n candidates at once (tests)
+MG_OPT_COUNT = 13
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 MG_CONSTRAINT_VALUE_POSITION, MG_CONSTRAINT_VALUE_HEADING = 7, 8   # values of the aligned motion, not errors (chained graph-walk steps)
@@ -39,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
     "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_set_option", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
     "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
-    "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_free", "mg_context_trim_outputs", "mg_context_output_bytes", "mg_memcpy_h2d", "mg_memcpy_d2h",
+    "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_placement_info", "mg_device_free", "mg_context_trim_outputs", "mg_context_output_bytes", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_root_mode", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host",
@@ -126,7 +128,10 @@ class Skeleton(object):
     (ox, oy, oz)), ...] with parents before children and the root first; animated_joints = names in pose-vector
     order (root translation at [0:3], then one (w,x,y,z) quaternion per animated joint)."""
 
+    _serials = itertools.count(1)
+
     def __init__(self, joints, animated_joints):
+        self.serial = next(Skeleton._serials)   # a stable identity for caches (id() of a collected object can be reused)
         self.names = [j[0] for j in joints]
         index = {n: i for i, n in enumerate(self.names)}
         if len(index) != len(self.names):
@@ -211,6 +216,7 @@ def load_library(path=None):
         "mg_context_set_option": [vp, i32, i32],
         "mg_device_malloc_placed": [vp, i64, i32, C.POINTER(vp), C.POINTER(dbl)],
         "mg_device_probe_placement": [vp, vp, i64, C.POINTER(dbl)],
+        "mg_device_placement_info": [vp, vp, C.POINTER(dbl), C.POINTER(dbl)],
         "mg_device_malloc_chunked": [vp, i64, i64, C.POINTER(vp)],
         "mg_context_arena_begin": [vp, i64],
         "mg_context_arena_end": [vp],
@@ -421,6 +427,12 @@ class Context(object):
         info = (C.c_double * 4)()
         _check(self.lib.mg_device_probe_placement(self.handle, _dev_ptr(buf), int(nbytes if nbytes is not None else buf.nbytes), info))
         return {"probed": int(info[0]), "ratio": float(info[1]), "pattern_us": float(info[2]), "fast": bool(info[3])}
+
+    def placement_info(self, buf):
+        """What the output arena knows about memory it handed out (no probe): 'region' False for memory from elsewhere."""
+        info, tbps = (C.c_double * 4)(), C.c_double()
+        _check(self.lib.mg_device_placement_info(self.handle, _dev_ptr(buf), info, C.byref(tbps)))
+        return {"region": bool(info[0]), "ratio": float(info[1]), "pattern_us": float(info[2]), "fast": bool(info[3]), "pattern_TBps": float(tbps.value)}
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)

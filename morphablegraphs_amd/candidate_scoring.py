@@ -287,10 +287,16 @@ def alignment_from_start_pose(start_pose):
 
 
 def _freeze(v):
+    """Nested tuples of plain Python values: hashable, and comparable with == / != whatever the caller handed over (arrays
+    of any rank, NumPy scalars, nested lists)."""
     if isinstance(v, dict):
         return tuple(sorted((k, _freeze(x)) for k, x in v.items()))
-    if isinstance(v, (list, tuple, np.ndarray)):
+    if isinstance(v, np.ndarray):
+        v = v.tolist()
+    if isinstance(v, (list, tuple)):
         return tuple(_freeze(x) for x in v)
+    if isinstance(v, np.generic):
+        return v.item()
     return v
 
 
@@ -299,7 +305,7 @@ _VALUE_FIELDS = ("weight", "target", "ref_dir", "group")
 
 
 def _flat(v):
-    return tuple(v) if isinstance(v, (list, tuple, np.ndarray)) else v
+    return _freeze(v) if isinstance(v, (list, tuple, np.ndarray, np.generic)) else v
 
 
 def _structure_key(prim, clist, skeleton, alignment=None):
@@ -309,7 +315,9 @@ def _structure_key(prim, clist, skeleton, alignment=None):
     # (a pose constraint's cloud is part of the set's tables: all of it is structure)
     items = tuple((c["type"], float(c["t"]), _flat(c.get("joint")), _flat(c.get("joint2")), _flat(c.get("offset")),
                    _freeze(c) if c["type"] == "pose" else None) for c in clist)
-    return (id(prim), prim.handle.value, id(skeleton), items, None if alignment is None else _flat(alignment.get("joint", 0)))
+    # (a Skeleton carries a serial number: id() of a collected one can be handed to a new object)
+    sk = None if skeleton is None else getattr(skeleton, "serial", id(skeleton))
+    return (id(prim), prim.handle.value, sk, items, None if alignment is None else _flat(alignment.get("joint", 0)))
 
 
 def _values_key(clist, alignment):

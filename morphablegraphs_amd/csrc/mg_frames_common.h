@@ -163,6 +163,9 @@ extern "C" int mg_debug_dump_stamps(void) {
 #ifndef MG_SWEEP_LANEMAP
 #define MG_SWEEP_LANEMAP 1   // the sweep's third sample in lanes 44 .. 63 (see the kernels)
 #endif
+#ifndef MG_SWEEP_FAST
+#define MG_SWEEP_FAST 1      // the lean loop over a chunk's full trips (see the chunk-stationary kernel)
+#endif
 #define MG_FUSE_MAX_KK 10   // fused mixture scoring: k-steps (4 latent components each) that fit the register budget
 #define MG_WS_NPW 4      // producer waves
 #define MG_WS_NCW 8      // consumer waves, two candidates each
@@ -290,22 +293,42 @@ __device__ __forceinline__ f32x4 mg_quad_fma(const mg_tap_rows &r, const float4 
 // {padding..., root channels} = columns 0 .. 3 with root channel d in column cshift + d; v holds its four taps' sums (the deltas),
 // mh / ml the sample's (Mhi, Mlo).  out[d] = Mhi[d] + (Mlo[d] + delta[d]) for d < nroot; the other elements are not stored
 // (or, where every lane stores four floats, replaced by the row's borrowed channel 3).
+struct mg_rootm { float4 a; float2 b; };   // {Mhi[0], Mhi[1], Mhi[2], Mlo[0]}, {Mlo[1], Mlo[2]}: one ds_read_b128 + one ds_read_b64
+__device__ __forceinline__ mg_rootm mg_rootm_load(const float *tab, int f) {
+    mg_rootm m;
+    m.a = *(const float4 *)(tab + 8 * f);
+    m.b = *(const float2 *)(tab + 8 * f + 4);
+    return m;
+}
 template <int CSHIFT>
-__device__ __forceinline__ f32x4 mg_root_finish(const f32x4 &v, const float4 &mh, const float4 &ml) {
+__device__ __forceinline__ f32x4 mg_root_finish(const f32x4 &v, const mg_rootm &m) {
     f32x4 o;
-    o[0] = mh.x + (ml.x + v[CSHIFT]);
-    o[1] = CSHIFT + 1 < 4 ? mh.y + (ml.y + v[CSHIFT + 1 < 4 ? CSHIFT + 1 : 3]) : 0.f;
-    o[2] = CSHIFT + 2 < 4 ? mh.z + (ml.z + v[CSHIFT + 2 < 4 ? CSHIFT + 2 : 3]) : 0.f;
+    o[0] = m.a.x + (m.a.w + v[CSHIFT]);
+    o[1] = CSHIFT + 1 < 4 ? m.a.y + (m.b.x + v[CSHIFT + 1 < 4 ? CSHIFT + 1 : 3]) : 0.f;
+    o[2] = CSHIFT + 2 < 4 ? m.a.z + (m.b.y + v[CSHIFT + 2 < 4 ? CSHIFT + 2 : 3]) : 0.f;
     o[3] = 0.f;
     return o;
 }
-__device__ __forceinline__ f32x4 mg_root_finish_rt(const f32x4 &v, const float4 &mh, const float4 &ml, int cshift) {
-    return cshift == 1 ? mg_root_finish<1>(v, mh, ml) : cshift == 2 ? mg_root_finish<2>(v, mh, ml) : mg_root_finish<3>(v, mh, ml);
+__device__ __forceinline__ f32x4 mg_root_finish_rt(const f32x4 &v, const mg_rootm &m, int cshift) {
+    return cshift == 1 ? mg_root_finish<1>(v, m) : cshift == 2 ? mg_root_finish<2>(v, m) : mg_root_finish<3>(v, m);
 }
 
 // all active lanes store four floats at base (wave-uniform) + a 32-bit byte offset: one store instruction, no lane classes
 __device__ __forceinline__ void mg_store4_at(float *base, unsigned byte_off, const f32x4 &v) {
     *(f32x4u *)((char *)base + byte_off) = v;
+}
+
+// the same with the base in scalar registers and the lane's part as the instruction's 32-bit offset: no 64-bit address per lane
+__device__ __forceinline__ void mg_store4_s(float *base, unsigned byte_off, const f32x4 &v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+// The root lane of a row group after the taps: it ran them on the first quad lane's columns, so v[0] is the row's channel 3;
+// its own three channels come from wave 0's root outputs {r0, r1, r2, -}.  Stored: {r0, r1, r2, channel 3}.
+__device__ __forceinline__ f32x4 mg_root_merge(const f32x4 &v, const float *ro) {
+    const float c3 = v[0];
+    f32x4 o = *(const f32x4 *)ro;
+    o[3] = c3;
+    return o;
 }
 
 __device__ __forceinline__ void mg_store_n(float *op, const f32x4 &v, int n) {

@@ -260,8 +260,10 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         const int64_t TD = (int64_t)a.T * D;
         const int dp4 = Dp * 4;
         // byte offset of the lane's quad inside a basis row; SPLIT: the root lane takes the row's first quad, {padding, root channels}
-        const int lane_img = (SPLIT && root_lane) ? 0 : (d0 + a.cshift) * 4;
-        const float4 *lds_m = (const float4 *)ro_base;    // SPLIT: {Mhi, Mlo} per sample of the chunk (where the root outputs would be)
+        // (float64 pipeline: the root lane reads what its row's first quad lane reads -- a broadcast -- and so holds channel 3, the
+        // fourth float of its store, without asking another lane for it)
+        const int lane_img = (SPLIT && root_lane) ? 0 : ((root_lane ? nroot : d0) + a.cshift) * 4;
+        const float *lds_m = (const float *)ro_base;    // SPLIT: {Mhi, Mlo} per sample of the chunk (where the root outputs would be)
         const int lane_out = fsub * D + d0;               // float offset inside a row group
         const bool all4 = nroot == 3 && ((D - nroot) & 3) == 0;   // every lane stores four floats (see the tile-major kernel)
         const int q0_lane = (lane - nql) << 2;            // byte index of this row's quad lane 0 for ds_bpermute
@@ -299,6 +301,38 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 constexpr int DP4 = decltype(pitch_tag)::value;
                 constexpr bool ALL4 = decltype(all4_tag)::value;   // the usual shape as a constant: every lane stores four floats
                 const bool all4l = ALL4 ? true : all4;
+                if constexpr (ALL4 && !SPLIT && MG_SWEEP_FAST) {
+                    // The trips whose six samples all lie inside the chunk, lean: the lanes that hold no sample sit the whole loop
+                    // out (one exec mask for the loop, none per store); every lane runs the taps -- the root lane on the first
+                    // quad lane's columns, so that channel 3 is already in its first register: no cross-lane read -- and the root
+                    // lanes then take the three root outputs from wave 0's table; the stores address memory as a scalar base +
+                    // a 32-bit lane offset.  Same operations on the same values as the general loop below: the same bits.
+                    if (lane_on) {
+                        for (; f_first + 2 * rpi <= f_last; f_first += 2 * rpi) {
+                            const int fa_ = f_first + fsub, fb_ = fa_ + rpi;
+                            const float4 wa = lds_w[fa_], wb = lds_w[fb_];
+                            const int moa = lds_mo[fa_], mob = lds_mo[fb_];
+                            const mg_tap_rows r0a = mg_quad_load<DP4>(img0 + moa, dp4), r0b = mg_quad_load<DP4>(img0 + mob, dp4);
+                            const mg_tap_rows r1a = mg_quad_load<DP4>(img1 + moa, dp4), r1b = mg_quad_load<DP4>(img1 + mob, dp4);
+                            __builtin_amdgcn_sched_barrier(0);
+                            f32x4 v0a = mg_quad_fma(r0a, wa), v0b = mg_quad_fma(r0b, wb);
+                            f32x4 v1a = mg_quad_fma(r1a, wa), v1b = mg_quad_fma(r1b, wb);
+                            if (root_lane) {
+                                v0a = mg_root_merge(v0a, ro0 + fa_ * 4); v0b = mg_root_merge(v0b, ro0 + fb_ * 4);
+                                v1a = mg_root_merge(v1a, ro1 + fa_ * 4); v1b = mg_root_merge(v1b, ro1 + fb_ * 4);
+                            }
+                            float *pa0 = or0 + (size_t)f_first * D, *pa1 = or1 + (size_t)f_first * D;          // uniform
+                            mg_store4_s(pa0, lane_out_b, v0a);
+                            mg_store4_s(pa0 + (size_t)rpi * D, lane_out_b, v0b);
+                            if (has1) {
+                                mg_store4_s(pa1, lane_out_b, v1a);
+                                mg_store4_s(pa1 + (size_t)rpi * D, lane_out_b, v1b);
+                            }
+                        }
+                    } else {
+                        f_first += (f_last - f_first) / (2 * rpi) * (2 * rpi);
+                    }
+                }
                 for (int f0 = f_first; f0 < f_last; f0 += 2 * rpi) {
                     const int fla = f0 + fsub, flb = fla + rpi;
                     const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
@@ -312,8 +346,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                         } else if (SPLIT || !root_lane) {   // all 16 tap rows are requested before the first FMA
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
-                            float4 mha, mla, mhb, mlb;   // SPLIT: every lane asks (a broadcast read), the root lanes use them
-                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; mhb = lds_m[2 * fb_]; mlb = lds_m[2 * fb_ + 1]; }
+                            mg_rootm ma, mb;   // SPLIT: every lane asks (a broadcast read), the root lanes use them
+                            if constexpr (SPLIT) { ma = mg_rootm_load(lds_m, fa_); mb = mg_rootm_load(lds_m, fb_); }
                             mg_tap_rows r0a, r0b, r1a, r1b;
                             if (MG_DBG(16384)) {   // ablation: no tap reads (the FMAs run on what is in registers anyway)
                                 const f32x4 k = {wa.x, wa.y, wb.z, wb.w};
@@ -335,11 +369,11 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                             if constexpr (SPLIT) {
                                 if (root_lane) {
                                     if constexpr (ALL4) {   // (all4: three root channels in columns 1 .. 3)
-                                        v0a = mg_root_finish<1>(v0a, mha, mla); v0b = mg_root_finish<1>(v0b, mhb, mlb);
-                                        v1a = mg_root_finish<1>(v1a, mha, mla); v1b = mg_root_finish<1>(v1b, mhb, mlb);
+                                        v0a = mg_root_finish<1>(v0a, ma); v0b = mg_root_finish<1>(v0b, mb);
+                                        v1a = mg_root_finish<1>(v1a, ma); v1b = mg_root_finish<1>(v1b, mb);
                                     } else {
-                                        v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v0b = mg_root_finish_rt(v0b, mhb, mlb, a.cshift);
-                                        v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); v1b = mg_root_finish_rt(v1b, mhb, mlb, a.cshift);
+                                        v0a = mg_root_finish_rt(v0a, ma, a.cshift); v0b = mg_root_finish_rt(v0b, mb, a.cshift);
+                                        v1a = mg_root_finish_rt(v1a, ma, a.cshift); v1b = mg_root_finish_rt(v1b, mb, a.cshift);
                                     }
                                 }
                             }
@@ -375,14 +409,14 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                         if (SPLIT || !root_lane) {
                             const float4 wa = lds_w[fa_];
                             const int moa = lds_mo[fa_];
-                            float4 mha, mla;
-                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; }
+                            mg_rootm ma;
+                            if constexpr (SPLIT) ma = mg_rootm_load(lds_m, fa_);
                             v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
                             v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
                             if constexpr (SPLIT) {
                                 if (root_lane) {
-                                    if constexpr (ALL4) { v0a = mg_root_finish<1>(v0a, mha, mla); v1a = mg_root_finish<1>(v1a, mha, mla); }
-                                    else { v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); }
+                                    if constexpr (ALL4) { v0a = mg_root_finish<1>(v0a, ma); v1a = mg_root_finish<1>(v1a, ma); }
+                                    else { v0a = mg_root_finish_rt(v0a, ma, a.cshift); v1a = mg_root_finish_rt(v1a, ma, a.cshift); }
                                 }
                             }
                         } else {

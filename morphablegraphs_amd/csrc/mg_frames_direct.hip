@@ -13,7 +13,7 @@ struct mg_direct_args {
     const void *lat;
     const int32_t *i0;
     const double *w;
-    const float *rootm;   // (T, 8): {Mhi[0..2], 0, Mlo[0..2], 0}, the mean/delta split of the root channels
+    const float *rootm;   // (T, 8): {Mhi[0..2], Mlo[0..2], 0, 0}, the mean/delta split of the root channels
     void *out;
     int64_t B, ld;
     int32_t T, D, L, R, nroot;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void mg_frames_direct_kernel(mg_direct_args a)
             v = fmaf((float)wq[2], c[2], v);
             v = fmaf((float)wq[3], c[3], v);
             const float *m = a.rootm + 8 * (size_t)f;
-            ((float *)a.out)[idx] = m[d] + (m[4 + d] + v);
+            ((float *)a.out)[idx] = m[d] + (m[3 + d] + v);
         } else if (OUT_F64 || d < a.nroot) {
             double c[4];
 #pragma unroll

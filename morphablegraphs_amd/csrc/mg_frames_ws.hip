@@ -91,7 +91,7 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 const mg_chunk &ck = un_prev.ck;
                 const unsigned char *img = smem + (size_t)slot * buf_bytes;
                 const float *lds_ro = (const float *)(ro_base + (size_t)slot * MG_RO_BYTES);
-                const float4 *lds_m = (const float4 *)lds_ro;   // SPLIT: {Mhi, Mlo} per sample where the root outputs would be
+                const float *lds_m = lds_ro;   // SPLIT: {Mhi, Mlo} per sample where the root outputs would be
                 const float4 *lds_w = (const float4 *)(tb_base + (size_t)slot * MG_TB_BYTES);
                 const int *lds_mo = (const int *)(lds_w + max_nt);
                 const int col0 = ck.imin * Dp - ck.rt0 * 16;
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         } else if (SPLIT || !root_lane) {
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];
                             const int moa = lds_mo[fa_], mob = lds_mo[fb_];
-                            float4 mha, mla, mhb, mlb;   // SPLIT: every lane asks (a broadcast read), the root lanes use them
-                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; mhb = lds_m[2 * fb_]; mlb = lds_m[2 * fb_ + 1]; }
+                            mg_rootm ma, mb;   // SPLIT: every lane asks (a broadcast read), the root lanes use them
+                            if constexpr (SPLIT) { ma = mg_rootm_load(lds_m, fa_); mb = mg_rootm_load(lds_m, fb_); }
                             if (MG_DBG(131072)) {
                                 v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
                                 v0b = mg_quad_taps_t<DP4>(img0 + mob, wb, dp4);
@@ -140,11 +140,11 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                             if constexpr (SPLIT) {
                                 if (root_lane) {
                                     if constexpr (ALL4) {   // (all4: three root channels in columns 1 .. 3)
-                                        v0a = mg_root_finish<1>(v0a, mha, mla); v0b = mg_root_finish<1>(v0b, mhb, mlb);
-                                        v1a = mg_root_finish<1>(v1a, mha, mla); v1b = mg_root_finish<1>(v1b, mhb, mlb);
+                                        v0a = mg_root_finish<1>(v0a, ma); v0b = mg_root_finish<1>(v0b, mb);
+                                        v1a = mg_root_finish<1>(v1a, ma); v1b = mg_root_finish<1>(v1b, mb);
                                     } else {
-                                        v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v0b = mg_root_finish_rt(v0b, mhb, mlb, a.cshift);
-                                        v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); v1b = mg_root_finish_rt(v1b, mhb, mlb, a.cshift);
+                                        v0a = mg_root_finish_rt(v0a, ma, a.cshift); v0b = mg_root_finish_rt(v0b, mb, a.cshift);
+                                        v1a = mg_root_finish_rt(v1a, ma, a.cshift); v1b = mg_root_finish_rt(v1b, mb, a.cshift);
                                     }
                                 }
                             }
@@ -180,14 +180,14 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                         if (SPLIT || !root_lane) {
                             const float4 wa = lds_w[fa_];
                             const int moa = lds_mo[fa_];
-                            float4 mha, mla;
-                            if constexpr (SPLIT) { mha = lds_m[2 * fa_]; mla = lds_m[2 * fa_ + 1]; }
+                            mg_rootm ma;
+                            if constexpr (SPLIT) ma = mg_rootm_load(lds_m, fa_);
                             v0a = mg_quad_taps_t<DP4>(img0 + moa, wa, dp4);
                             v1a = mg_quad_taps_t<DP4>(img1 + moa, wa, dp4);
                             if constexpr (SPLIT) {
                                 if (root_lane) {
-                                    if constexpr (ALL4) { v0a = mg_root_finish<1>(v0a, mha, mla); v1a = mg_root_finish<1>(v1a, mha, mla); }
-                                    else { v0a = mg_root_finish_rt(v0a, mha, mla, a.cshift); v1a = mg_root_finish_rt(v1a, mha, mla, a.cshift); }
+                                    if constexpr (ALL4) { v0a = mg_root_finish<1>(v0a, ma); v1a = mg_root_finish<1>(v1a, ma); }
+                                    else { v0a = mg_root_finish_rt(v0a, ma, a.cshift); v1a = mg_root_finish_rt(v1a, ma, a.cshift); }
                                 }
                             }
                         } else {

@@ -136,7 +136,7 @@ extern "C" int mg_context_create(int device, void *stream, mg_context **out) {
     return MG_OK;
 }
 
-static void mg_vmm_release(mg_context::vmm_alloc &v);
+static void mg_vmm_release(mg_context *ctx, mg_context::vmm_alloc &v);
 extern "C" void mg_context_destroy(mg_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -152,7 +152,10 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials}) if (q) (void)hipFree(q);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
-    for (auto &v : ctx->vmm) mg_vmm_release(v);
+    for (auto &v : ctx->vmm) mg_vmm_release(ctx, v);
+    (void)hipDeviceSynchronize();   // nothing of this process is in flight when the parked address ranges go back to the runtime
+    for (auto &r : ctx->vmm_parked) (void)hipMemAddressFree(r.first, r.second);
+    ctx->vmm_parked.clear();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -305,10 +308,12 @@ extern "C" int mg_device_malloc(mg_context *ctx, int64_t bytes, void **out_dev) 
     MG_HIP_CHECK(hipMalloc(out_dev, (size_t)bytes));
     return MG_OK;
 }
-static void mg_vmm_release(mg_context::vmm_alloc &v) {
+// Unmap and release the physical chunks; the ADDRESS RANGE stays reserved (parked with the context) so that no later
+// reservation of this process can land on it while the context lives (see mg_context::vmm_parked).
+static void mg_vmm_release(mg_context *ctx, mg_context::vmm_alloc &v) {
     if (v.va) {
         (void)hipMemUnmap(v.va, v.total);
-        (void)hipMemAddressFree(v.va, v.total);
+        ctx->vmm_parked.push_back({v.va, v.total});
     }
     for (auto h : v.handles) (void)hipMemRelease(h);
     v.handles.clear();
@@ -366,7 +371,7 @@ extern "C" int mg_device_free(mg_context *ctx, void *p) {
 int mg_device_free_raw(mg_context *ctx, void *p) {
     for (size_t i = 0; i < ctx->vmm.size(); i++)
         if (ctx->vmm[i].va == p) {
-            mg_vmm_release(ctx->vmm[i]);
+            mg_vmm_release(ctx, ctx->vmm[i]);
             ctx->vmm.erase(ctx->vmm.begin() + (long)i);
             return MG_OK;
         }
@@ -723,8 +728,8 @@ static int mg_grid_build(mg_primitive *p, mg_time_grid *g, const double *times, 
                 double M = g->w[4 * (size_t)f] * m[0];
                 for (int j = 1; j < 4; j++) M = std::fma(g->w[4 * (size_t)f + j], m[(size_t)j * p->D], M);
                 const float hi = (float)M;
-                rootm[8 * (size_t)f + d] = hi;
-                rootm[8 * (size_t)f + 4 + d] = (float)(M - (double)hi);
+                rootm[8 * (size_t)f + d] = hi;                              // {Mhi[0..2], Mlo[0], Mlo[1], Mlo[2], 0, 0}: the sweep reads
+                rootm[8 * (size_t)f + 3 + d] = (float)(M - (double)hi);    // a float4 and a float2 per sample, every element used
             }
         if ((rc = mg_upload(p->ctx, rootm, &g->d_rootm)) != MG_OK) return rc;
     }

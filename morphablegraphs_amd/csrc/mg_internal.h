@@ -60,6 +60,10 @@ struct mg_context {
     size_t arena_block_bytes = 0;   // > 0 while an arena section is open
     struct vmm_alloc { void *va; size_t total, chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
     std::vector<vmm_alloc> vmm;     // buffers from mg_device_malloc_chunked
+    // Address ranges of released chunked buffers.  Their physical memory is gone, the reservation stays until the context is
+    // destroyed: a range the runtime hands out again for ANOTHER mapping while translations of the old one are still cached
+    // makes kernels store through the stale ones (profiles/r03_placement/t8_remap_stale_translation.log: "STORES LOST").
+    std::vector<std::pair<void *, size_t>> vmm_parked;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // mg_options_step: the options of a step are independent chains of small
     hipEvent_t side_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // launches; four of them run side by side ([4]: the fork)
     // mg_options_step as one launch (mg_options.hip): the per-option constants on the device and their host copy, the
@@ -70,7 +74,7 @@ struct mg_context {
     int fused_partials_n = 0;
     // the output arena (mg_placement.hip): buffers that went through the placement probe, sub-allocated in 2 MiB granules
     struct out_region {
-        char *base = nullptr; size_t bytes = 0; bool vmm = false, fast = false; double ratio = 1.0, us = 0.0; int probed = 0;
+        char *base = nullptr; size_t bytes = 0; bool vmm = false, fast = false; double ratio = 1.0, us = 0.0, tbps = 0.0; int probed = 0;
         std::vector<std::pair<size_t, size_t>> free_list;   // (offset, bytes), sorted by offset
         std::map<size_t, size_t> used;                       // offset -> bytes of the pieces handed out
         int64_t live = 0;
@@ -131,7 +135,7 @@ struct mg_time_grid {
     double *d_w = nullptr;      // (T,4) float64 weights
     float *d_w32 = nullptr;     // (T,4) float32 weights
     float *d_rootm = nullptr;   // (T,8) the root channels' mean part M[f][d] = spline of mean' alone (float64 on the host) as
-                                // float32 pairs: {Mhi[0..2], 0, Mlo[0..2], 0} (the mean/delta split of the frames kernels)
+                                // float32 pairs: {Mhi[0..2], Mlo[0..2], 0, 0} (the mean/delta split of the frames kernels)
     double *d_wtap = nullptr;   // [n_chunks][2][2][64] banded tap weights, f64 MFMA A fragments
     mg_chunk *d_chunks = nullptr;
     int32_t n_chunks = 0;

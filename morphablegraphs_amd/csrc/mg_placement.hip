@@ -59,12 +59,21 @@ __global__ __launch_bounds__(256) void mg_placement_fill_kernel(f32x4p *buf, siz
 // slow as well (fill 77 us, pattern 80 us for the bench's 404 MB: ratio 1.04, 5.0 TB/s -- against 61-63.5 us = 6.4-6.6 TB/s in
 // the fast class and 54-57 us in the best regions), which the ratio alone waves through
 #define MG_PLACED_FAST_TBPS 6.0
-static bool mg_placement_is_fast(int64_t bytes, double ratio, double pattern_us, double fast_ratio) {
-    if (ratio > fast_ratio) return false;
+// Hysteresis: the scan STOPS at the first candidate of 6.0 TB/s and more; a region's CLASS -- what the frames kernels' choice
+// and every report go by, decided once from the scan's own measurement and kept for the region's life -- is fast from 5.9 TB/s
+// on.  (Round 3's bench met a buffer at 5.996: one threshold for both made a 0.07 % margin flip the kernel choice, and a second
+// probe of the same buffer contradict the arena.)
+#define MG_PLACED_CLASS_TBPS 5.9
+static double mg_placement_tbps(int64_t bytes, double pattern_us) {   // 0: the probe is too small to fill the chip (or was not timed)
     const int64_t cand_bytes = (int64_t)MG_PP_T * MG_PP_D * 4;
     const int64_t ntiles = std::min<int64_t>(bytes / (16 * cand_bytes), 1 << 20);
-    if (ntiles < 256 || pattern_us <= 0.0) return true;
-    return (double)(ntiles * 16 * cand_bytes) / pattern_us * 1e-6 >= MG_PLACED_FAST_TBPS;
+    if (ntiles < 256 || pattern_us <= 0.0) return 0.0;
+    return (double)(ntiles * 16 * cand_bytes) / pattern_us * 1e-6;
+}
+static bool mg_placement_is_fast(int64_t bytes, double ratio, double pattern_us, double fast_ratio, double floor_tbps = MG_PLACED_FAST_TBPS) {
+    if (ratio > fast_ratio) return false;
+    const double tbps = mg_placement_tbps(bytes, pattern_us);
+    return tbps == 0.0 || tbps >= floor_tbps;
 }
 
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us) {
@@ -106,7 +115,23 @@ extern "C" int mg_device_probe_placement(mg_context *ctx, void *buf, int64_t byt
     double ratio = 1.0, us = 0.0;
     int rc = mg_probe_placement(ctx, buf, bytes, &ratio, &us);
     if (rc != MG_OK) return rc;
-    info[0] = 1.0; info[1] = ratio; info[2] = us; info[3] = mg_placement_is_fast(bytes, ratio, us, MG_PLACED_FAST_RATIO) ? 1.0 : 0.0;
+    info[0] = 1.0; info[1] = ratio; info[2] = us; info[3] = mg_placement_is_fast(bytes, ratio, us, MG_PLACED_FAST_RATIO, MG_PLACED_CLASS_TBPS) ? 1.0 : 0.0;
+    return MG_OK;
+}
+
+// What the arena knows about memory it handed out, WITHOUT probing again: info4 = {1 if p is a piece of a placed region,
+// pattern / fill of the region's scan, its pattern time in us, 1 if the region is in the fast class}; tbps (may be NULL): the
+// pattern's rate in TB/s for the probe that classified the region (0 where the probe was too small to fill the chip).
+extern "C" int mg_device_placement_info(mg_context *ctx, const void *buf, double *info, double *tbps) {
+    if (!ctx || !buf || !info) { mg_set_error("mg_device_placement_info: needs a context, a pointer and info4"); return MG_ERR_INVALID_ARGUMENT; }
+    info[0] = 0.0; info[1] = 1.0; info[2] = 0.0; info[3] = 0.0;
+    if (tbps) *tbps = 0.0;
+    for (const auto &r : ctx->out_regions)
+        if (r.base && (const char *)buf >= r.base && (const char *)buf < r.base + r.bytes) {
+            info[0] = 1.0; info[1] = r.ratio; info[2] = r.us; info[3] = r.fast ? 1.0 : 0.0;
+            if (tbps) *tbps = r.tbps;
+            return MG_OK;
+        }
     return MG_OK;
 }
 
@@ -136,7 +161,8 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
     size_t free_b = 0, total_b = 0;
     MG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const int budget = max_candidates > 0 ? max_candidates : 32;
-    const size_t hold_cap = std::max<size_t>(free_b / 4, 2 * bytes);   // bytes held at once, the best candidate included
+    size_t hold_cap = std::max<size_t>(free_b / 4, 2 * bytes);   // bytes held at once, the best candidate included
+    if (ctx->opt[MG_OPT_PLACED_HOLD] > 0) hold_cap = std::max<size_t>((size_t)ctx->opt[MG_OPT_PLACED_HOLD], 2) * bytes;   // (tests: drops in mid-scan)
     const double fast_ratio = ctx->opt[MG_OPT_PLACED_FAST_PCT] > 0 ? ctx->opt[MG_OPT_PLACED_FAST_PCT] / 100.0 : MG_PLACED_FAST_RATIO;
     struct cand { void *p; bool vmm; };
     std::vector<cand> held;   // rejected candidates, oldest first
@@ -199,7 +225,10 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
         return MG_ERR_OUT_OF_MEMORY;
     }
     out->base = (char *)best.p; out->bytes = bytes; out->vmm = best.vmm; out->ratio = best_ratio; out->us = best_us;
-    out->probed = probed; out->fast = best_fast; out->live = 0;
+    out->tbps = mg_placement_tbps((int64_t)probe_bytes, best_us);
+    // the class: from the scan's own measurement, with the lower threshold (see MG_PLACED_CLASS_TBPS), and it stays
+    out->probed = probed; out->fast = best_fast || mg_placement_is_fast((int64_t)probe_bytes, best_ratio, best_us, fast_ratio, MG_PLACED_CLASS_TBPS);
+    out->live = 0;
     out->free_list.clear();
     out->free_list.push_back({0, bytes});
     return MG_OK;
@@ -223,8 +252,30 @@ int mg_output_alloc(mg_context *ctx, int64_t bytes, int32_t max_candidates, void
             }
         }
     }
+    // No region can serve the request.  Idle regions that are too small for it would stay reserved beside the new one for as long
+    // as the workload's sizes keep growing: they go first.
+    bool released = false;
+    for (size_t i = ctx->out_regions.size(); i-- > 0;)
+        if (ctx->out_regions[i].live == 0) {
+            if (!released) { (void)hipStreamSynchronize(ctx->stream); released = true; }
+            mg_region_release(ctx, ctx->out_regions[i]);
+            ctx->out_regions.erase(ctx->out_regions.begin() + (long)i);
+        }
     mg_context::out_region r;
     int rc = mg_region_create(ctx, need, (size_t)bytes, max_candidates, &r);
+    if (rc == MG_ERR_OUT_OF_MEMORY) {
+        // not even one candidate of the scan could be allocated: the last resort is what mg_device_malloc was before there were
+        // regions -- ONE allocation, unprobed (class unknown: reported as slow)
+        void *p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess) {
+            (void)hipGetLastError();
+            mg_set_error("mg_device_malloc: out of device memory (%lld bytes)", (long long)need);
+            return MG_ERR_OUT_OF_MEMORY;
+        }
+        r = mg_context::out_region();
+        r.base = (char *)p; r.bytes = need; r.vmm = false; r.fast = false; r.ratio = 1.0; r.us = 0.0; r.probed = 0;
+        rc = MG_OK;
+    }
     if (rc != MG_OK) return rc;
     *out = r.base;
     r.used[0] = need;

@@ -242,6 +242,34 @@ class HipMotionStateGraph(object):
         self.nodes = {}
 
 
+def _fp_value(v):
+    t = type(v)
+    if v is None or t is float or t is int or t is str or t is bool:
+        return v
+    if t is list or t is tuple:
+        return tuple([x if type(x) is float else _fp_value(x) for x in v])
+    if t is np.ndarray:
+        return (v.dtype.str, v.shape, v.tobytes())
+    if isinstance(v, np.generic):
+        return v.item()
+    if t is dict:
+        return tuple([(k, _fp_value(x)) for k, x in v.items()])
+    raise TypeError(t)
+
+
+def constraint_fingerprint(clist):
+    """A value copy of a list of plain device-form constraint dicts, for "same as last step?" comparisons: key names and
+    values, nested lists and arrays copied element by element (a caller that rewrites a target list or array IN PLACE changes
+    the next fingerprint, not the remembered one).  None when the list holds anything else (reference constraint objects,
+    values of unknown types): such lists take the general route."""
+    if type(clist) is not list:
+        return None
+    try:
+        return [tuple([(k, _fp_value(v)) for k, v in c.items()]) for c in clist]
+    except (AttributeError, TypeError):
+        return None
+
+
 class HipPrimitiveSet(object):
     """separate_streams: every primitive gets its own libmg_hip context, i.e. its own HIP stream, so that the small,
     latency-bound launches of different options overlap on the GPU (evaluate_options_on_device)."""
@@ -319,12 +347,7 @@ class HipPrimitiveSet(object):
             # every value is what it was at the last step (compared value by value: callers rewrite targets in place), the set of
             # the last step is the set of this one.  Anything else -- reference objects, a previous motion to align to -- takes the
             # general route (device form, structure and values keys, the shared cache).
-            fp = None
-            if prev_frames is None and skeleton is None and type(clist) is list:
-                try:
-                    fp = [tuple([tuple(v) if type(v) is list else v for v in c.values()]) for c in clist]
-                except AttributeError:
-                    fp = None
+            fp = constraint_fingerprint(clist) if prev_frames is None and skeleton is None else None
             last = memo[k]
             if fp is not None and last is not None and last[0] == fp and last[1].handle and last[1].cached_values is last[2] and \
                     getattr(cons, "hip_skeleton", None) is None and getattr(cons, "is_local", True):   # (cached_values: nobody else rewrote the shared set)

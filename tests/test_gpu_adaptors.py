@@ -551,6 +551,37 @@ def test_planner_step_notices_constraints_rewritten_in_place():
         assert r3[n][1] == r2[n][1]
 
 
+def test_planner_step_notices_array_targets_rewritten_in_place():
+    """targets held as NumPy arrays (and a fresh array of more than one element on the second step) must neither be
+    compared by identity nor raise 'truth value of an array is ambiguous'; key names are part of the comparison."""
+    prims = synthetic.make_graph_primitives(3)
+    names = [p["name"] for p in prims]
+
+    def constraints(x, as_array=True):
+        wrap = (lambda v: np.array(v, dtype=np.float64)) if as_array else (lambda v: list(v))
+        return {n: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": wrap([x, np.nan, 5.0])},
+                    {"type": "direction", "t": float(p["n_canonical_frames"] - 1), "weight": 0.5, "target": wrap([0.3, 1.0])}] for n, p in zip(names, prims)}
+
+    def step(pset, cons):
+        np.random.seed(3)
+        best, res = pset.evaluate_options_on_device(names, cons, n_samples=1024, seed=7)
+        return best, {n: (res[n][0].copy(), res[n][1]) for n in names}
+    pset, fresh = HipPrimitiveSet(prims), HipPrimitiveSet(prims)
+    cons = constraints(10.0)
+    b1, r1 = step(pset, cons)
+    b1b, r1b = step(pset, constraints(10.0))                 # fresh arrays with the same values: the same answer, no ValueError
+    assert b1 == b1b and all(r1[n][1] == r1b[n][1] for n in names)
+    for n in names:
+        cons[n][0]["target"][0] = -35.0                      # the array rewritten in place
+    b2, r2 = step(pset, cons)
+    b2f, r2f = step(fresh, constraints(-35.0, as_array=False))
+    assert any(r2[n][1] != r1[n][1] for n in names)
+    for n in names:
+        np.testing.assert_array_equal(r2[n][0], r2f[n][0])
+        assert r2[n][1] == r2f[n][1]
+    assert b2 == b2f
+
+
 def _options_step_raw(pset, names, cons, n, seed, dtype, skeleton=None, prev_frames=None):
     """One evaluate_options_on_device step; returns per option (result record, all errors, all candidates) as the device left them."""
     np.random.seed(9)

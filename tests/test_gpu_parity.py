@@ -585,6 +585,75 @@ def test_placed_allocator_walks_both_recipes_when_nothing_is_fast(ctx):
     prim.close()
 
 
+def test_placement_scan_that_drops_candidates_leaves_no_stale_mapping():
+    """VERDICT r3 item 3a.  The builder's own probe had found that unmap + map at an overlapping virtual range makes kernels store
+    through stale translations (profiles/r03_placement/t8_remap_stale_translation.log, "STORES LOST").  The product guard: the
+    address range of a released chunked buffer stays reserved with the context (parked), so no later reservation can land on it.
+    Here a scan that may hold only two candidates at once walks all 32 -- sixteen plain, twelve assembled from chunks, four
+    plain: candidates are dropped all along -- and the frames kernel then writes a position-dependent result through the
+    surviving region, which must read back bit for bit what a plain hipMalloc buffer reads back; and a chunked buffer
+    allocated after another one was freed gets a range of its own and holds its data."""
+    ctx = _capi.Context(0)
+    nbytes = 2048 * 156 * 79 * 4           # 101 MB
+    ctx.set_option(_capi.MG_OPT_PLACED_FAST_PCT, 1)      # no candidate can be accepted: the scan runs to its end
+    ctx.set_option(_capi.MG_OPT_PLACED_HOLD, 2)
+    buf = ctx.malloc_placed(nbytes)
+    assert buf.placement["probed"] in (20, 32) and not buf.placement["fast"]      # (20: a box without the virtual-memory API)
+    info = ctx.placement_info(buf)
+    assert info["region"] and info["fast"] == buf.placement["fast"] and info["pattern_us"] == buf.placement["pattern_us"]
+    ctx.set_option(_capi.MG_OPT_PLACED_FAST_PCT, 0)
+    ctx.set_option(_capi.MG_OPT_PLACED_HOLD, 0)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    S = np.random.default_rng(8).standard_normal((2048, 40)).astype(np.float32)
+    d_S = ctx.upload(S)
+    ctx.set_option(_capi.MG_OPT_PLAIN_MALLOC, 1)
+    plain = ctx.malloc(nbytes)
+    ctx.set_option(_capi.MG_OPT_PLAIN_MALLOC, 0)
+    for kern in (1, 2):
+        ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, kern)
+        for target in (buf, plain):
+            _capi._check(ctx.lib.mg_memset(ctx.handle, target.ptr, 0xff, nbytes))
+            prim.back_project_frames_dev(d_S, np.float32, 2048, 40, target, path=_capi.MG_PATH_MFMA)
+        a = ctx.download(buf, (2048, 156, 79), np.float32)
+        b = ctx.download(plain, (2048, 156, 79), np.float32)
+        np.testing.assert_array_equal(_bits(a), _bits(b), err_msg="kernel %d" % kern)
+        assert np.isfinite(a).all()
+    ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, 0)
+    # chunked buffers one after the other: every one at an address range no earlier one had
+    seen = set()
+    for chunk_mib in (2, 8, 2, 32, 8):
+        c = ctx.malloc(nbytes, chunk_bytes=chunk_mib << 20)
+        assert c.address not in seen, "the address range of a released chunked buffer was handed out again"
+        seen.add(c.address)
+        prim.back_project_frames_dev(d_S, np.float32, 2048, 40, c, path=_capi.MG_PATH_MFMA)
+        np.testing.assert_array_equal(_bits(ctx.download(c, (2048, 156, 79), np.float32)), _bits(b))
+        c.free()
+    for x in (d_S, buf, plain):
+        x.free()
+    prim.close()
+    ctx.close()
+
+
+def test_growing_requests_do_not_pile_up_idle_regions():
+    """a workload whose output grows from call to call (each buffer freed before the next is asked for) must not keep
+    every earlier, too small region reserved beside the new one: idle regions that cannot serve a request go before its scan."""
+    ctx = _capi.Context(0)
+    unit = 1024 * 156 * 79 * 4            # 50 MB
+    last = 0
+    for k in (2, 3, 5, 8):
+        b = ctx.malloc(k * unit)
+        reserved, used, regions, _ = ctx.output_bytes()
+        assert regions == 1 and used == reserved and k * unit <= reserved < k * unit + (4 << 20), (k, reserved, regions)
+        assert reserved > last
+        last = reserved
+        b.free()
+    b = ctx.malloc(3 * unit)              # a smaller one afterwards is a piece of the region that is there
+    assert ctx.output_bytes()[0] == last and ctx.output_bytes()[2] == 1
+    b.free()
+    ctx.close()
+
+
 def _set_frames_kernel(ctx, which):
     ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, which)
 

@@ -401,3 +401,29 @@ def test_integration_md_names_every_entry_point_of_the_header():
     assert len(names) > 70
     missing = [n for n in names if n not in doc and not n.endswith("_host")]
     assert missing == [], missing
+
+
+def test_constraint_fingerprint_is_a_value_copy():
+    """ADVICE r3 (motion_state_graph.py): the planner step's "same constraints as last step?" test copies values -- arrays,
+    nested lists, key names -- so that a target rewritten in place is a different fingerprint, and anything it does not know
+    takes the general route."""
+    from morphablegraphs_amd.motion_state_graph import constraint_fingerprint as fp
+    from morphablegraphs_amd import candidate_scoring as cs
+    a = np.array([1.0, 2.0, 3.0])
+    clist = [{"type": "position", "t": 5.0, "target": a, "weight": 1.0, "nested": [[1.0, 2.0], [3.0]]}]
+    f1 = fp(clist)
+    assert f1 == fp([dict(clist[0], target=a.copy())])          # a fresh array with the same values compares equal
+    a[0] = 9.0
+    f2 = fp(clist)
+    assert f1 != f2
+    clist[0]["nested"][1][0] = 4.0
+    assert fp(clist) != f2
+    assert fp([{"type": "position", "t": 5.0, "goal": 1.0}]) != fp([{"type": "position", "t": 5.0, "target": 1.0}])   # key names count
+    assert fp([object()]) is None and fp("x") is None and fp([{"type": "position", "target": object()}]) is None
+    # the shared constraint-set cache: two-dimensional array targets compare without raising, skeletons by serial number
+    v1 = cs._values_key([{"weight": 1.0, "target": np.ones((2, 3)), "ref_dir": None}], None)
+    v2 = cs._values_key([{"weight": 1.0, "target": np.ones((2, 3)), "ref_dir": None}], None)
+    assert not (v1 != v2) and hash(v1) == hash(v2)
+    from morphablegraphs_amd import _capi, synthetic
+    joints, animated = synthetic.make_skeleton()
+    assert _capi.Skeleton(joints, animated).serial != _capi.Skeleton(joints, animated).serial
