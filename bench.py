@@ -621,14 +621,15 @@ def run_graph(args, emit=True):
                  {"type": "direction", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [0.5, 1.0]}] for nm, p in zip(names, prims)}
     pset = HipPrimitiveSet(prims, separate_streams=False)
     ctxs = list({id(pset.nodes[nm]._prim.ctx): pset.nodes[nm]._prim.ctx for nm in names}.values())
+    dev_counts = not getattr(args, "host_counts", False)
     for i in range(args.warmup):
-        pset.evaluate_options_on_device(names, cons, n, seed=i)
+        pset.evaluate_options_on_device(names, cons, n, seed=i, device_counts=dev_counts)
     for c in ctxs:
         c.profile_reset()
         c.profile_enable(1 if args.steps < 200 else 8)   # every 8th launch of a kind: event pairs around 4-us kernels are not free
     t0 = time.perf_counter()
     for i in range(args.steps):
-        best, results = pset.evaluate_options_on_device(names, cons, n, seed=i)
+        best, results = pset.evaluate_options_on_device(names, cons, n, seed=i, device_counts=dev_counts)
     elapsed = time.perf_counter() - t0
     slots = {}
     for c in ctxs:
@@ -661,7 +662,11 @@ def run_graph(args, emit=True):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "graph-walk planner step: 16 synthetic primitives (L 12..40, F 40..160, K 1..8) x %d device-sampled candidates each, "
                                "2 root keyframe constraints, winner per option read back (BASELINE.json configs[2]); score only, no frames written" % n,
-                   "options": len(names), "candidates_per_option": n, "launches_per_step": launches, "host_calls_per_step": 1, "read_backs_per_step": 1},
+                   "options": len(names), "candidates_per_option": n, "launches_per_step": launches + (1 if dev_counts and fused else 0), "host_calls_per_step": 1,
+                   "read_backs_per_step": 1,
+                   "component_counts": ("drawn on the device (mg_options_step_device_counts: Philox-keyed multinomial per option, distributed like "
+                                        "numpy.random.multinomial's counts, not NumPy's stream; --host-counts keeps the host draw)") if dev_counts else
+                                       "numpy.random.multinomial on the host, one call per option"},
         "roofline": {"bound": "mfma", "kernel": k_name, "achieved": k_flop / (k_ms * 1e-3) / 1e12 if k_ms else None,
                      "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (k_flop / (k_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS) if k_ms else None, "traffic": None,
@@ -744,6 +749,7 @@ def main():
     ap.add_argument("--config", choices=("walk", "graph", "optimizer"), default="walk",
                     help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-counts", action="store_true", help="--config graph: component counts from numpy.random.multinomial on the host (one call per option) instead of the device draw")
     ap.add_argument("--no-placement-compare", action="store_true", help="skip the steps on a second library buffer and on a foreign hipMalloc after the timed region (profiling runs)")
     ap.add_argument("--no-extra-configs", action="store_true", help="do not attach the graph / optimizer configurations to the default line")
     ap.add_argument("--two-launch", action="store_true",

@@ -615,6 +615,20 @@ int mg_options_step(int32_t n_options, mg_primitive *const *prims, const mg_cons
                     const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int x_dtype, const int64_t *ld,
                     double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host);
 
+/* mg_options_step with the COMPONENT COUNTS DRAWN ON THE DEVICE: what GaussianMixture.sample draws with
+ * numpy.random.multinomial(n, weights) (reference motion_primitive.py:182-189; 4 us of host time per option) becomes the histogram
+ * of n categorical draws per option, keyed by the option's seed:
+ *     u_i = (Philox4x32-10(counter = (i >> 2, 0, 0, 0x636e7473), key = seed)[i & 3] + 0.5) / 2^32,   i = 0 .. n_samples - 1
+ *     counts[c] = #{i : cum[c-1] <= u_i < cum[c]}, cum = cumulative normalised weights (float64), the last component takes the rest.
+ * Distributed like NumPy's counts, NOT NumPy's stream (the status of the device sampler itself); given the counts the step is the one
+ * mg_options_step makes, bit for bit.  Two launches per step, no host work per option; the kernels leave the result records (and
+ * the counts) in pinned host memory themselves, so results_host / counts_host cost one synchronisation and no copy.
+ * counts_host (may be NULL): [n_options][16] int64.  At most 24 options; MG_ERR_UNSUPPORTED where an option does not run on the
+ * one-launch kernel (more than 16 components, more than 64 mixture dimensions, a VALU kernel forced): draw on the host then. */
+int mg_options_step_device_counts(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n_samples,
+                                  const uint64_t *seeds, void *const *x_dev, int x_dtype, const int64_t *ld,
+                                  double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host, int64_t *counts_host);
+
 /* One rank's share of a step sharded over GPUs (contiguous candidate blocks, constants replicated): the same
  * calls restricted to the global rows [row_begin, row_begin + row_count) of every option's draw of n_samples candidates.
  * x_dev (row_count, ld) and errors_dev (row_count) hold the block; the index in a result record is the GLOBAL row, so the

@@ -56,7 +56,7 @@ EXPORTED_SYMBOLS = [
     "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
     "mg_align_frames", "mg_frame_constraint_width", "mg_score_frame_constraint",
-    "mg_score_constraint_residuals_chained", "mg_option_step", "mg_options_step", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
+    "mg_score_constraint_residuals_chained", "mg_option_step", "mg_options_step", "mg_options_step_device_counts", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
 ]
 
 
@@ -197,6 +197,11 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise OSError("libmg_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C morphablegraphs_amd/csrc` (there is no CPU fallback)" % p)
+    # Kernel arguments in device memory instead of host memory the GPU reads over PCIe: the persistent kernels fetch their
+    # argument block once per workgroup before anything else can start (0.3-0.5 us of a ~78 us frames launch, tools/ab.py).
+    # A setting of the HIP runtime, read when it initialises: it takes effect when this library is the first user of HIP in the
+    # process; a value the caller has set is left alone.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     lib = C.CDLL(p)
     lib.mg_version.restype = C.c_char_p
     lib.mg_last_error.restype = C.c_char_p
@@ -288,6 +293,7 @@ def load_library(path=None):
         "mg_gmm_sample_rows": [vp, i64, vp, u64, i64, i64, vp, i32, i64, vp],
         "mg_dist_broadcast": [vp, vp, i64, i32],
         "mg_options_step": [i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, vp],
+        "mg_options_step_device_counts": [i32, vp, vp, i64, vp, vp, i32, vp, vp, vp, i64, vp, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
         "mg_score_constraint_residuals_host": [vp, vp, vp, i32, i64, i64, vp],
         "mg_gmm_log_prob_jac_host": [vp, vp, i32, i64, i64, vp],

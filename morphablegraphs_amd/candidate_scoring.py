@@ -328,6 +328,11 @@ def _values_key(clist, alignment):
     return (vals, tuple((k, _flat(alignment[k])) for k in sorted(alignment)))
 
 
+# bumped whenever a shared set is created, rewritten or closed: "nothing happened to any set since" is one integer comparison
+# (the planner step's whole-step shortcut, motion_state_graph.HipPrimitiveSet.evaluate_options_on_device)
+CSET_GENERATION = [0]
+
+
 def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
     """A device constraint set for these (device-form) constraints, reused across calls.  An optimizer evaluates the
     same constraints again and again (same values: nothing to do); a planner scores the same KIND of constraints with
@@ -340,16 +345,19 @@ def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
     cs = _CSET_CACHE.get(key)
     if cs is not None and not (cs.handle and cs.prim.handle and cs.prim.ctx.handle):   # its primitive has been closed meanwhile
         del _CSET_CACHE[key]
+        CSET_GENERATION[0] += 1
         cs = None
     if cs is not None:
         _CSET_CACHE.move_to_end(key)
         if cs.cached_values != values:
             cs.update(clist, alignment)
             cs.cached_values = values
+            CSET_GENERATION[0] += 1
         return cs
     cs = _capi.ConstraintSet(prim, clist, skeleton, alignment)
     cs.cached_values = values
     _CSET_CACHE[key] = cs
+    CSET_GENERATION[0] += 1
     while len(_CSET_CACHE) > _CSET_CACHE_SIZE:
         _CSET_CACHE.popitem(last=False)[1].close()
     return cs
@@ -357,6 +365,7 @@ def cached_constraint_set(prim, clist, skeleton=None, alignment=None):
 
 def clear_constraint_cache():
     """Drop the cached device constraint sets (call before closing a primitive they belong to)."""
+    CSET_GENERATION[0] += 1
     while _CSET_CACHE:
         _CSET_CACHE.popitem()[1].close()
     while _TRAJ_CACHE:

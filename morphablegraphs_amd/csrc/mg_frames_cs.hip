@@ -307,7 +307,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                     // quad lane's columns, so that channel 3 is already in its first register: no cross-lane read -- and the root
                     // lanes then take the three root outputs from wave 0's table; the stores address memory as a scalar base +
                     // a 32-bit lane offset.  Same operations on the same values as the general loop below: the same bits.
-                    if (lane_on) {
+                    if (MG_DBG(4 | 8192 | 16384)) {   // (the sweep's ablations live in the general loop)
+                    } else if (lane_on) {
                         for (; f_first + 2 * rpi <= f_last; f_first += 2 * rpi) {
                             const int fa_ = f_first + fsub, fb_ = fa_ + rpi;
                             const float4 wa = lds_w[fa_], wb = lds_w[fb_];

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
         const int64_t TD = (int64_t)a.T * D;
         const int dp4 = Dp * 4;
         // byte offset of the lane's quad inside a basis row; SPLIT: the root lane takes the row's first quad, {padding, root channels}
-        const int lane_img = (SPLIT && root_lane) ? 0 : (d0 + a.cshift) * 4;
+        // (float64 pipeline: the root lane reads what its row's first quad lane reads -- a broadcast -- and so holds channel 3, the
+        // fourth float of its store, without asking another lane for it)
+        const int lane_img = (SPLIT && root_lane) ? 0 : ((root_lane ? nroot : d0) + a.cshift) * 4;
         const int lane_out = fsub * D + d0;               // float offset inside a row group
         // When every quad lane holds four floats and the root lane three (D = 79: 3 + 19 x 4), the root lane borrows the
         // row's channel 3 from quad lane 0 (a cross-lane read) and ALL lanes store four floats with one instruction;
@@ -108,7 +110,39 @@ __global__ __launch_bounds__(MG_WS_BLOCK) void mg_frames_ws_kernel(
                 constexpr int DP4 = decltype(pitch_tag)::value;
                 constexpr bool ALL4 = decltype(all4_tag)::value;   // the usual shape as a constant: every lane stores four floats
                 const bool all4l = ALL4 ? true : all4;
-                for (int f0 = 0; f0 < ck.nT; f0 += 2 * rpi) {
+                int f_first = 0;
+                if constexpr (ALL4 && !SPLIT && MG_SWEEP_FAST) {
+                    // the trips whose six samples all lie inside the chunk, lean (see the chunk-stationary kernel): same operations on
+                    // the same values as the general loop below
+                    if (!MG_DBG(4 | 8192 | 131072 | 2048)) {
+                        if (lane_on) {
+                            for (; f_first + 2 * rpi <= ck.nT; f_first += 2 * rpi) {
+                                const int fa_ = f_first + fsub, fb_ = fa_ + rpi;
+                                const float4 wa = lds_w[fa_], wb = lds_w[fb_];
+                                const int moa = lds_mo[fa_], mob = lds_mo[fb_];
+                                const mg_tap_rows r0a = mg_quad_load<DP4>(img0 + moa, dp4), r0b = mg_quad_load<DP4>(img0 + mob, dp4);
+                                const mg_tap_rows r1a = mg_quad_load<DP4>(img1 + moa, dp4), r1b = mg_quad_load<DP4>(img1 + mob, dp4);
+                                __builtin_amdgcn_sched_barrier(0);
+                                f32x4 v0a = mg_quad_fma(r0a, wa), v0b = mg_quad_fma(r0b, wb);
+                                f32x4 v1a = mg_quad_fma(r1a, wa), v1b = mg_quad_fma(r1b, wb);
+                                if (root_lane) {
+                                    v0a = mg_root_merge(v0a, ro0 + fa_ * 4); v0b = mg_root_merge(v0b, ro0 + fb_ * 4);
+                                    v1a = mg_root_merge(v1a, ro1 + fa_ * 4); v1b = mg_root_merge(v1b, ro1 + fb_ * 4);
+                                }
+                                float *pa0 = or0 + (size_t)f_first * D, *pa1 = or1 + (size_t)f_first * D;          // uniform
+                                mg_store4_s(pa0, lane_out_b, v0a);
+                                mg_store4_s(pa0 + (size_t)rpi * D, lane_out_b, v0b);
+                                if (has1) {
+                                    mg_store4_s(pa1, lane_out_b, v1a);
+                                    mg_store4_s(pa1 + (size_t)rpi * D, lane_out_b, v1b);
+                                }
+                            }
+                        } else {
+                            f_first = ck.nT / (2 * rpi) * (2 * rpi);
+                        }
+                    }
+                }
+                for (int f0 = f_first; f0 < ck.nT; f0 += 2 * rpi) {
                     const int fla = f0 + fsub, flb = fla + rpi;
                     const bool oa = lane_on && fla < ck.nT, ob = lane_on && flb < ck.nT;
                     const int fa_ = fla < ck.nT ? fla : ck.nT - 1, fb_ = flb < ck.nT ? flb : ck.nT - 1;

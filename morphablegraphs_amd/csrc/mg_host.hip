@@ -149,7 +149,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     if (ctx->scratch) (void)mg_device_free(ctx, ctx->scratch);
     mg_output_release_all(ctx);
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
-    for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials}) if (q) (void)hipFree(q);
+    for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials, ctx->fused_dyn_dev}) if (q) (void)hipFree(q);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
     for (auto &v : ctx->vmm) mg_vmm_release(ctx, v);
@@ -1982,14 +1982,40 @@ extern "C" int mg_option_step(mg_primitive *p, const mg_constraint_set *cs, int6
 
 // A small device -> host read-back at the end of a step: through a pinned staging block of the context's (a copy into
 // pageable memory goes through the runtime's own staging and costs tens of microseconds more), then one synchronisation.
-static int mg_read_back_pinned(mg_context *ctx, void *dst, const void *src_dev, size_t bytes) {
+// the context's pinned (page-locked, device-visible) staging block, at least `bytes` large
+static int mg_ctx_pinned(mg_context *ctx, size_t bytes) {
     if (ctx->pinned_bytes < bytes) {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // a kernel may still be writing the old block
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         ctx->pinned = nullptr; ctx->pinned_bytes = 0;
         const size_t cap = std::max<size_t>(bytes, 64 * 1024);
         MG_HIP_CHECK(hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+        memset(ctx->pinned, 0, cap);   // (completion flags below compare against sequence numbers that start at 1)
         ctx->pinned_bytes = cap;
     }
+    return MG_OK;
+}
+// A planner step's results without a copy and without the runtime's synchronisation: the step's kernel writes the records into
+// pinned memory and then, per option, the step's sequence number into a flag word there (mg_options.hip); the host spins on the
+// flags -- a few hundred nanoseconds after the last workgroup's write instead of the microseconds hipStreamSynchronize takes
+// to wake up.  Bounded: after ~2 ms of polling the stream is synchronised the ordinary way (which also surfaces a failed launch).
+static int mg_wait_flags(mg_context *ctx, const volatile unsigned long long *flags, int n, unsigned long long seq) {
+    for (int k = 0; k < n; k++) {
+        long spins = 0;
+        while (flags[k] != seq) {
+            __builtin_ia32_pause();
+            if (++spins > 4000000L) {
+                MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (flags[k] != seq) { mg_set_error("mg_options_step: the step's kernel finished without writing its result records"); return MG_ERR_HIP; }
+                break;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return MG_OK;
+}
+static int mg_read_back_pinned(mg_context *ctx, void *dst, const void *src_dev, size_t bytes) {
+    { int rcp = mg_ctx_pinned(ctx, bytes); if (rcp != MG_OK) return rcp; }
     MG_HIP_CHECK(hipMemcpyAsync(ctx->pinned, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     memcpy(dst, ctx->pinned, bytes);
@@ -2011,6 +2037,55 @@ extern "C" int mg_options_step(int32_t n_options, mg_primitive *const *prims, co
                                double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host) {
     return mg_options_step_rows(n_options, prims, csets, n, counts, seeds, 0, n, x_dev, xdt, ld, errors_dev, results_dev, result_stride, results_host);
 }
+// The step with the component counts drawn on the device (mg_options.hip: mg_options_counts_kernel): two launches, no host
+// work per option.  counts_host (may be NULL): [n_options][16] int64, the counts the device drew.
+extern "C" int mg_options_step_device_counts(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
+                                             const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
+                                             double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host,
+                                             int64_t *counts_host) {
+    MG_REQUIRE(n_options > 0 && n_options <= 24 && prims && csets && seeds && x_dev && ld && errors_dev && results_dev && n > 0,
+               "mg_options_step_device_counts: bad arguments (at most 24 options)");
+    mg_context *ctx = prims[0] ? prims[0]->ctx : nullptr;
+    for (int k = 0; k < n_options; k++) {
+        MG_REQUIRE(prims[k] && prims[k]->ctx == ctx, "mg_options_step_device_counts: option %d is NULL or lives in another context", k);
+        MG_REQUIRE(result_stride >= 16 + 8 * (int64_t)prims[k]->Lg && result_stride % 8 == 0, "mg_options_step_device_counts: result_stride %lld too small for option %d",
+                   (long long)result_stride, k);
+        MG_REQUIRE(csets[k] && csets[k]->prim == prims[k], "mg_options_step_device_counts: constraint set %d is NULL or belongs to another primitive", k);
+        MG_REQUIRE(x_dev[k] && errors_dev[k] && ld[k] >= prims[k]->Lg, "mg_options_step_device_counts: bad arguments for option %d", k);
+    }
+    MG_REQUIRE(xdt == MG_F32 || xdt == MG_F64, "mg_options_step_device_counts: bad dtype %d", xdt);
+    { int rc0 = mg_use_device(ctx); if (rc0 != MG_OK) return rc0; }
+    if (!mg_options_can_fuse(n_options, prims, csets, n)) {
+        mg_set_error("mg_options_step_device_counts: an option does not run on the one-launch kernel (mixture of more than 16 components or 64 dimensions, "
+                     "constraint tables beyond LDS, or a VALU kernel forced): draw the counts on the host and call mg_options_step");
+        return MG_ERR_UNSUPPORTED;
+    }
+    const size_t rec_bytes = ((size_t)n_options * (size_t)result_stride + 63) / 64 * 64, flag_bytes = 64 * 4,
+                 cnt_bytes = (size_t)n_options * MG_SAMPLE_ARG_K * sizeof(int32_t);
+    char *rec_host = nullptr;
+    int32_t *cnt_host = nullptr;
+    unsigned long long *flags = nullptr;
+    if (results_host || counts_host) {
+        int rcp = mg_ctx_pinned(ctx, rec_bytes + flag_bytes + cnt_bytes);
+        if (rcp != MG_OK) return rcp;
+        rec_host = (char *)ctx->pinned;              // (the records are what the flags wait for: written whenever anything is wanted)
+        flags = (unsigned long long *)(rec_host + rec_bytes);
+        if (counts_host) cnt_host = (int32_t *)(rec_host + rec_bytes + flag_bytes);
+    }
+    const unsigned long long seq = ++ctx->fused_seq;
+    int rc = mg_launch_options_fused(n_options, prims, csets, n, nullptr, seeds, x_dev, xdt, ld, errors_dev, results_dev, result_stride, 0, n, rec_host, cnt_host,
+                                     flags, seq);
+    if (rc != MG_OK) return rc;
+    if (results_host || counts_host) {
+        int rcw = mg_wait_flags(ctx, flags, n_options, seq);   // (the counts were written by an earlier kernel of the same stream)
+        if (rcw != MG_OK) return rcw;
+        if (results_host) memcpy(results_host, rec_host, (size_t)n_options * (size_t)result_stride);
+        if (counts_host)
+            for (size_t i = 0; i < (size_t)n_options * MG_SAMPLE_ARG_K; i++) counts_host[i] = cnt_host[i];
+    }
+    return MG_OK;
+}
+
 // One rank's share of a sharded step: global rows [row_begin, row_begin + row_count) of every option's draw of n candidates;
 // x_dev[k] (row_count, ld[k]) and errors_dev[k] (row_count) hold the block, the result records carry GLOBAL row indices.
 extern "C" int mg_options_step_rows(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
@@ -2038,12 +2113,29 @@ extern "C" int mg_options_step_rows(int32_t n_options, mg_primitive *const *prim
         bool fused = true;
         for (int k0 = 0; k0 < n_options && fused; k0 += 24) fused = mg_options_can_fuse(std::min(24, n_options - k0), prims + k0, csets + k0, n);
         if (fused) {
+            // results wanted on the host: the kernel leaves a second copy of every record in the context's pinned block -- no copy
+            // operation behind the launch (a 4 us blit kernel and its launch gap), only the synchronisation
+            char *rec_host = nullptr;
+            unsigned long long *flags = nullptr;
+            const size_t rec_bytes = ((size_t)n_options * (size_t)result_stride + 63) / 64 * 64;
+            if (results_host) {
+                int rcp = mg_ctx_pinned(ctx, rec_bytes + (size_t)n_options * 8);
+                if (rcp != MG_OK) return rcp;
+                rec_host = (char *)ctx->pinned;
+                flags = (unsigned long long *)(rec_host + rec_bytes);
+            }
+            const unsigned long long seq = ++ctx->fused_seq;
             for (int k0 = 0; k0 < n_options; k0 += 24) {
                 int rcf = mg_launch_options_fused(std::min(24, n_options - k0), prims + k0, csets + k0, n, counts + k0, seeds + k0, x_dev + k0, xdt, ld + k0,
-                                                  errors_dev + k0, (char *)results_dev + (size_t)k0 * result_stride, result_stride, row_begin, row_count);
+                                                  errors_dev + k0, (char *)results_dev + (size_t)k0 * result_stride, result_stride, row_begin, row_count,
+                                                  rec_host ? rec_host + (size_t)k0 * result_stride : nullptr, nullptr, flags ? flags + k0 : nullptr, seq);
                 if (rcf != MG_OK) return rcf;
             }
-            if (results_host) return mg_read_back_pinned(ctx, results_host, results_dev, (size_t)(n_options * result_stride));
+            if (results_host) {
+                int rcw = mg_wait_flags(ctx, flags, n_options, seq);
+                if (rcw != MG_OK) return rcw;
+                memcpy(results_host, rec_host, (size_t)n_options * (size_t)result_stride);
+            }
             return MG_OK;
         }
     }

@@ -71,6 +71,8 @@ struct mg_context {
     void *fused_tab_dev = nullptr;
     std::vector<unsigned char> fused_tab_host;
     void *fused_counters = nullptr, *fused_partials = nullptr;
+    void *fused_dyn_dev = nullptr;   // a step's per-option values where the device draws the component counts itself
+    unsigned long long fused_seq = 0;   // sequence number of the planner steps whose records the kernel leaves in pinned memory
     int fused_partials_n = 0;
     // the output arena (mg_placement.hip): buffers that went through the placement probe, sub-allocated in 2 MiB granules
     struct out_region {
@@ -252,7 +254,9 @@ int mg_options_fused_attributes();   // mg_options.hip
 bool mg_options_can_fuse(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n);
 int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
                             const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
-                            double *const *errors_dev, void *results_dev, int64_t result_stride, int64_t row_begin, int64_t row_count);
+                            double *const *errors_dev, void *results_dev, int64_t result_stride, int64_t row_begin, int64_t row_count,
+                            void *records_host = nullptr, int32_t *counts_host = nullptr, unsigned long long *flags_host = nullptr,
+                            unsigned long long seq = 0);
 int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio, double *pattern_us);   // mg_placement.hip
 #define MG_PLACED_MIN_BYTES ((int64_t)64 << 20)   // below this an output sits in the 256 MiB Infinity Cache anyway
 int mg_output_alloc(mg_context *ctx, int64_t bytes, int32_t max_candidates, void **out, double *info4);   // a piece of a placed region

@@ -39,6 +39,9 @@ struct mg_fused_static {          // one option: what stays the same from step t
     mg_score_args sa;             // constraint tables; sa.out = errors (n) float64, sa.B = n, sa.ld = ld of x
     void *x;                      // (n, ld) candidates, written
     void *result;                 // {int64 index, float64 error, float64 latent[Lg]}
+    void *result_host;            // the same record in pinned host memory (or NULL): written by the kernel, so that a step that
+                                  // wants its results on the host needs no copy after the launch, only the synchronisation
+    double cumw[MG_SAMPLE_ARG_K]; // cumulative normalised mixture weights (float64): the device draw of the component counts
     int32_t K, Lg, KKg, KK, JT, RT;
 };
 
@@ -50,14 +53,88 @@ struct mg_fused_dyn {             // one step: what changes every time (kernel a
     // tiles [tile0[k], tile_end[k]); x and errors are indexed by (row - row_lo), the winner's index is global
     int32_t tile0[MG_FUSED_MAX_OPTIONS], tile_end[MG_FUSED_MAX_OPTIONS];
     int64_t row_lo, row_hi;
+    // results on the host without a copy: an option's last workgroup writes its record into pinned memory and then, behind a
+    // system-scope fence, the step's sequence number into the option's flag word there (NULL: no host copy wanted)
+    unsigned long long *flags_host;
+    unsigned long long seq;
+};
+
+struct mg_fused_devcounts {       // what mg_options_counts_kernel leaves for the step's main kernel (device memory)
+    int32_t counts[MG_FUSED_MAX_OPTIONS][MG_SAMPLE_ARG_K];
+    int32_t tile_end[MG_FUSED_MAX_OPTIONS];
 };
 
 struct mg_fused_partial { double v; int64_t i; };
 
-template <bool X_F64>
-__global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused_kernel(const mg_fused_static *__restrict__ tab, const mg_fused_dyn dyn,
+// The component counts of a step drawn ON THE DEVICE (mg_options_step_device_counts): a multinomial(n, weights) draw per option
+// as the histogram of n categorical draws, keyed by the option's seed --
+//     u_i = (Philox4x32-10(counter = (i >> 2, 0, 0, MG_COUNTS_TAG), key = seed)[i & 3] + 0.5) / 2^32,   i = 0 .. n-1,
+//     counts[c] = #{i : cum[c-1] <= u_i < cum[c]},  cum = cumulative normalised weights in float64, the last component takes the rest
+// -- distributed like numpy.random.multinomial's counts (what GaussianMixture.sample draws, reference
+// motion_primitive.py:182-189), not NumPy's stream: the same status as the device sampler.  One workgroup per option writes the
+// step's mg_fused_dyn into device memory, where mg_options_fused_kernel<., true> reads it; the host, not knowing the counts,
+// sizes every option's share of the grid for the most tiles n candidates in K components can take (n / 16 + K).
+#define MG_COUNTS_TAG 0x636e7473u
+struct mg_counts_args {
+    uint64_t seed[MG_FUSED_MAX_OPTIONS];
+    int64_t n;
+};
+__global__ __launch_bounds__(256) void mg_options_counts_kernel(const mg_fused_static *__restrict__ tab, const mg_counts_args a,
+                                                               mg_fused_devcounts *__restrict__ dc, int32_t *__restrict__ counts_host) {
+    __shared__ int below[4][MG_SAMPLE_ARG_K];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = tab[k].K;
+    double cum[MG_SAMPLE_ARG_K];     // the thresholds in registers: +inf from K - 1 on, so that the comparisons below need no bound
+#pragma unroll
+    for (int c = 0; c < MG_SAMPLE_ARG_K; c++) cum[c] = tab[k].cumw[c];
+#pragma unroll
+    for (int c = 0; c < MG_SAMPLE_ARG_K; c++) cum[c] = c < K - 1 ? cum[c] : -1.0;   // (u >= 0: never below)
+    int lt[MG_SAMPLE_ARG_K];   // this thread's draws below cum[c]
+#pragma unroll
+    for (int c = 0; c < MG_SAMPLE_ARG_K; c++) lt[c] = 0;
+    const int64_t n = a.n, groups = (n + 3) >> 2;
+    const uint64_t seed = a.seed[k];
+    for (int64_t j = tid; j < groups; j += 256) {
+        uint32_t rr[4];
+        mg_philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), 0u, MG_COUNTS_TAG, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const double u = 4 * j + e < n ? ((double)rr[e] + 0.5) * (1.0 / 4294967296.0) : 2.0;   // (beyond the draw: below nothing)
+#pragma unroll
+            for (int c = 0; c < MG_SAMPLE_ARG_K; c++) lt[c] += u < cum[c] ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MG_SAMPLE_ARG_K; c++) {
+        int v = lt[c];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) below[wave][c] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t tiles = 0;
+        int prev = 0;
+        for (int c = 0; c < MG_SAMPLE_ARG_K; c++) {
+            int cnt = 0;
+            if (c < K) {
+                const int cumc = c < K - 1 ? below[0][c] + below[1][c] + below[2][c] + below[3][c] : (int)n;
+                cnt = cumc - prev;
+                prev = cumc;
+            }
+            dc->counts[k][c] = cnt;
+            if (counts_host) counts_host[k * MG_SAMPLE_ARG_K + c] = cnt;
+            tiles += (cnt + 15) / 16;
+        }
+        dc->tile_end[k] = (int32_t)tiles;
+    }
+}
+
+template <bool X_F64, bool DYN_DEV>
+__global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused_kernel(const mg_fused_static *__restrict__ tab, const mg_fused_dyn dyn_arg,
+                                                              const mg_fused_devcounts *__restrict__ dyn_dev,
                                                               const int n_options, const int wave_doubles,
                                                               mg_fused_partial *__restrict__ partials, int32_t *__restrict__ counters) {
+    const mg_fused_dyn &dyn = dyn_arg;   // the step's values; DYN_DEV: the component counts and the tile count come from dyn_dev
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double sv[4];
     __shared__ int64_t si[4];
@@ -81,14 +158,20 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
     const int64_t row_lo = dyn.row_lo, row_hi = dyn.row_hi;
     int c = 0;
     int64_t row_c = 0, tile_c = 0, rows_next, tiles_next;
+    int32_t cnts[MG_SAMPLE_ARG_K];   // (one 64-byte line: a single trip to memory where the counts were drawn on the device)
+#pragma unroll
+    for (int q = 0; q < MG_SAMPLE_ARG_K; q++) cnts[q] = DYN_DEV ? dyn_dev->counts[k][q] : dyn.counts[k][q];
+    const int tile_end_k = DYN_DEV ? dyn_dev->tile_end[k] : dyn.tile_end[k];
     for (;;) {
-        const int cnt = dyn.counts[k][c];
+        int cnt = cnts[0];
+#pragma unroll
+        for (int q = 1; q < MG_SAMPLE_ARG_K; q++) cnt = c == q ? cnts[q] : cnt;
         rows_next = row_c + cnt;
         tiles_next = tile_c + (cnt + 15) / 16;
         if (c + 1 < K && t >= tiles_next) { c++; row_c = rows_next; tile_c = tiles_next; }
         else break;
     }
-    const bool active = t < tiles_next && t < dyn.tile_end[k];
+    const bool active = t < tiles_next && t < tile_end_k;
     double best = INFINITY;
     int64_t bi = INT64_MAX;
     if (active) {
@@ -205,19 +288,33 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
         if (bi == INT64_MAX || bi < row_lo || bi >= row_hi) { bi = row_lo; best = INFINITY; }   // (an index outside the block cannot happen; never gather out of bounds)
         ((int64_t *)o.result)[0] = bi;
         ((double *)o.result)[1] = best;
+        if (o.result_host) { ((int64_t *)o.result_host)[0] = bi; ((double *)o.result_host)[1] = best; }
         si[0] = bi;
         counters[k] = 0;   // ready for the next launch (stream ordered)
     }
     __syncthreads();
     const int64_t idx = si[0];
     double *row = (double *)((char *)o.result + 16);
-    for (int i = tid; i < Lg; i += 256)
-        row[i] = X_F64 ? ((const double *)o.x)[(idx - row_lo) * ld + i] : (double)((const float *)o.x)[(idx - row_lo) * ld + i];
+    double *row_h = o.result_host ? (double *)((char *)o.result_host + 16) : nullptr;
+    for (int i = tid; i < Lg; i += 256) {
+        const double v = X_F64 ? ((const double *)o.x)[(idx - row_lo) * ld + i] : (double)((const float *)o.x)[(idx - row_lo) * ld + i];
+        row[i] = v;
+        if (row_h) row_h[i] = v;
+    }
+    if (dyn.flags_host) {   // the record is complete on the host before its flag says so
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(dyn.flags_host + k, dyn.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 int mg_options_fused_attributes() {
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     return MG_OK;
 }
 
@@ -236,10 +333,22 @@ bool mg_options_can_fuse(int32_t n_options, mg_primitive *const *prims, const mg
     return true;
 }
 
+// counts == NULL: the component counts are drawn on the device (mg_options_counts_kernel; whole draws only: row_begin = 0,
+// row_count = n).  records_host / counts_host (device-visible pinned memory, or NULL): where the kernels also leave the result
+// records (record k at k * result_stride) and the drawn counts [n_options][MG_SAMPLE_ARG_K].
 int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n,
                             const int64_t *const *counts, const uint64_t *seeds, void *const *x_dev, int xdt, const int64_t *ld,
-                            double *const *errors_dev, void *results_dev, int64_t result_stride, int64_t row_begin, int64_t row_count) {
+                            double *const *errors_dev, void *results_dev, int64_t result_stride, int64_t row_begin, int64_t row_count,
+                            void *records_host, int32_t *counts_host, unsigned long long *flags_host, unsigned long long seq) {
     mg_context *ctx = prims[0]->ctx;
+    const bool dev_counts = counts == nullptr;
+    if (dev_counts && (row_begin != 0 || row_count != n)) {
+        mg_set_error("mg_options_step_device_counts: the device draws the counts of whole draws only");
+        return MG_ERR_UNSUPPORTED;
+    }
+    mg_counts_args ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.n = n;
     std::vector<mg_fused_static> tab((size_t)n_options);
     mg_fused_dyn dyn;
     memset(&dyn, 0, sizeof(dyn));
@@ -255,9 +364,22 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
         a.align = cs->d_align; a.align_cand = nullptr; a.pose = cs->d_pose; a.lat = x_dev[k]; a.out = errors_dev[k]; a.res = nullptr; a.B = n; a.ld = ld[k];
         a.n = cs->n; a.nch = cs->nch; a.L = p->L;
         o.x = x_dev[k]; o.result = (char *)results_dev + (size_t)k * result_stride;
+        o.result_host = records_host ? (char *)records_host + (size_t)k * result_stride : nullptr;
+        {
+            double wsum = 0.0, acc = 0.0;
+            for (int c = 0; c < p->K; c++) wsum += p->gw[c];
+            for (int c = 0; c < p->K && c < MG_SAMPLE_ARG_K; c++) { acc += p->gw[c]; o.cumw[c] = acc / wsum; }
+        }
         o.K = p->K; o.Lg = p->Lg; o.KKg = p->KKg; o.KK = p->KK; o.JT = (p->Lg + 15) / 16; o.RT = cs->RT;
         wave_doubles = std::max(wave_doubles, 16 * (4 * p->KKg + 1) + 16 * (cs->RT * 16 + 1) + 16 * std::max(cs->n, 1));
         int64_t tiles = 0, rows = 0, t_first = -1, t_last = -1;
+        if (dev_counts) {   // the grid's share of this option: the most tiles n rows in K components can take
+            ca.seed[k] = seeds[k];
+            dyn.seed[k] = seeds[k];
+            dyn.tile0[k] = 0;
+            dyn.wg0[k + 1] = dyn.wg0[k] + (int32_t)((n / 16 + p->K + 3) / 4);
+            continue;
+        }
         for (int c = 0; c < p->K; c++) {
             if (counts[k][c] < 0 || counts[k][c] > n) { mg_set_error("mg_options_step: counts[%d][%d] out of range", k, c); return MG_ERR_INVALID_ARGUMENT; }
             dyn.counts[k][c] = (int32_t)counts[k][c];
@@ -274,6 +396,7 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
         dyn.wg0[k + 1] = dyn.wg0[k] + (int32_t)((t_last + 1 - t_first + 3) / 4);
     }
     dyn.row_lo = row_begin; dyn.row_hi = row_begin + row_count;
+    dyn.flags_host = flags_host; dyn.seq = seq;
     const int total_wg = dyn.wg0[n_options];
     // the static table: uploaded when it differs from the one on the device (a planner reuses its buffers and sets, so: rarely)
     const size_t tab_bytes = tab.size() * sizeof(mg_fused_static);
@@ -298,12 +421,26 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
     const size_t lds = (size_t)4 * wave_doubles * 8;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool timed = mg_prof_kernel(ctx, 7, -1, &ev0, &ev1);
-    if (xdt == MG_F64)
-        hipExtLaunchKernelGGL((mg_options_fused_kernel<true>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
-                              (const mg_fused_static *)ctx->fused_tab_dev, dyn, (int)n_options, wave_doubles, (mg_fused_partial *)ctx->fused_partials, (int32_t *)ctx->fused_counters);
-    else
-        hipExtLaunchKernelGGL((mg_options_fused_kernel<false>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
-                              (const mg_fused_static *)ctx->fused_tab_dev, dyn, (int)n_options, wave_doubles, (mg_fused_partial *)ctx->fused_partials, (int32_t *)ctx->fused_counters);
+    const mg_fused_static *tabd = (const mg_fused_static *)ctx->fused_tab_dev;
+    mg_fused_partial *part = (mg_fused_partial *)ctx->fused_partials;
+    int32_t *ctr = (int32_t *)ctx->fused_counters;
+    if (dev_counts) {
+        if (!ctx->fused_dyn_dev) MG_HIP_CHECK(hipMalloc(&ctx->fused_dyn_dev, sizeof(mg_fused_devcounts)));
+        mg_fused_devcounts *dd = (mg_fused_devcounts *)ctx->fused_dyn_dev;
+        hipLaunchKernelGGL(mg_options_counts_kernel, dim3(n_options), dim3(256), 0, ctx->stream, tabd, ca, dd, counts_host);
+        if (xdt == MG_F64)
+            hipExtLaunchKernelGGL((mg_options_fused_kernel<true, true>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
+                                  tabd, dyn, (const mg_fused_devcounts *)dd, (int)n_options, wave_doubles, part, ctr);
+        else
+            hipExtLaunchKernelGGL((mg_options_fused_kernel<false, true>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
+                                  tabd, dyn, (const mg_fused_devcounts *)dd, (int)n_options, wave_doubles, part, ctr);
+    } else if (xdt == MG_F64) {
+        hipExtLaunchKernelGGL((mg_options_fused_kernel<true, false>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
+                              tabd, dyn, (const mg_fused_devcounts *)nullptr, (int)n_options, wave_doubles, part, ctr);
+    } else {
+        hipExtLaunchKernelGGL((mg_options_fused_kernel<false, false>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
+                              tabd, dyn, (const mg_fused_devcounts *)nullptr, (int)n_options, wave_doubles, part, ctr);
+    }
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

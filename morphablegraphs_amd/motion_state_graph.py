@@ -6,6 +6,8 @@ the option with the smallest error (np.argmin over options, graph_walk_planner.p
 Graph loading / transitions / control flow stay in the reference; only the scoring is replaced."""
 import numpy as np
 
+from . import candidate_scoring as _cs
+
 from . import _capi
 from .candidate_scoring import constraints_to_device_form, evaluate_samples_using_constraints
 from .frame_constraints import is_frame_constraint
@@ -257,6 +259,55 @@ def _fp_value(v):
     raise TypeError(t)
 
 
+_FLAT = frozenset((float, int, str, bool, type(None)))
+_DTYPES = {np.float32: np.dtype(np.float32), np.float64: np.dtype(np.float64)}
+
+
+def flat_constraint_copy(clist):
+    """A value copy of a list of plain device-form constraint dicts whose every value is a scalar or a flat list of scalars (the
+    usual form: targets as lists of floats / None), for the planner step's "same constraints as last step?" test; None for
+    anything else -- arrays, nested lists, reference objects -- which takes the general route every step.  The copy shares
+    nothing mutable with the caller's dicts: a target rewritten in place changes the comparison's outcome."""
+    if type(clist) is not list:
+        return None
+    out = []
+    for c in clist:
+        if type(c) is not dict:
+            return None
+        d = {}
+        for k, v in c.items():
+            t = type(v)
+            if t in _FLAT:
+                d[k] = v
+            elif t is list:
+                for x in v:
+                    if type(x) not in _FLAT:
+                        return None
+                d[k] = v[:]
+            else:
+                return None
+        out.append(d)
+    return out
+
+
+def _same_mapping(cons, remembered):
+    """{option: constraint list} == the remembered flat copy, by value, in one comparison."""
+    try:
+        return cons == remembered
+    except (ValueError, TypeError):
+        return False
+
+
+def _same_constraints(clist, remembered):
+    """clist == remembered by value (the interpreter's own recursive comparison of lists, dicts and scalars: key names, lengths
+    and values; NaN compares unequal, so a NaN target is "changed" every step -- safe).  Values that cannot be compared this way
+    (arrays) are "not the same"."""
+    try:
+        return type(clist) is list and clist == remembered
+    except (ValueError, TypeError):
+        return False
+
+
 def constraint_fingerprint(clist):
     """A value copy of a list of plain device-form constraint dicts, for "same as last step?" comparisons: key names and
     values, nested lists and arrays copied element by element (a caller that rewrites a target list or array IN PLACE changes
@@ -284,8 +335,44 @@ class HipPrimitiveSet(object):
             p._initialize_from_json(data)
             self.nodes[p.name] = p
 
+    @property
+    def last_counts(self):
+        """{option: component counts} the device drew in the last step with device_counts=True."""
+        raw = getattr(self, "_last_counts", None)
+        if raw is None:
+            return None
+        cnt, steps = raw
+        return {st[0]: cnt[k, :len(st[8])].copy() for k, st in enumerate(steps)}
+
+    def _repeat_step(self, plan, options, n, seed, dt, device_counts):
+        """evaluate_options_on_device for a step whose constraint sets are the last step's (the caller has checked): the C call and
+        the unpacking of the result records, nothing else.  None: the device cannot draw this step's counts (host route)."""
+        steps = plan["steps"]
+        m, stride, host = len(steps), plan["stride"], plan["host"]
+        code = _capi.MG_F64 if dt == np.float64 else _capi.MG_F32
+        np.add(plan["karange"], np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out=plan["seeds_np"])
+        if device_counts and m <= 24:
+            rc = plan["lib"].mg_options_step_device_counts(m, plan["prims"], plan["csets"], n, plan["seeds"], plan["xs"], code, plan["lds"],
+                                                           plan["errs"], plan["shared_ptr"], stride, plan["host_ptr"], plan["device_counts_ptr"])
+            if rc == -4:
+                return None
+            self._last_counts = (plan["device_counts"], steps)
+        else:
+            counts, multinomial = plan["counts"], np.random.multinomial
+            for k, st in enumerate(steps):   # the component counts, in option order, from NumPy's global stream
+                counts[k, :len(st[8])] = multinomial(n, st[8])
+            rc = plan["lib"].mg_options_step(m, plan["prims"], plan["csets"], n, plan["cnts"], plan["seeds"], plan["xs"], code, plan["lds"],
+                                             plan["errs"], plan["shared_ptr"], stride, plan["host_ptr"])
+        if rc != 0:
+            _capi._check(rc)
+        rec = host[:m * stride].copy().reshape(m, stride)          # one copy: the host block is reused by the next step
+        errs = rec[:, 8:16].copy().view(np.float64)[:, 0].tolist()
+        lat = rec[:, 16:].copy().view(np.float64)                    # (m, widest L): the winners, already rounded to the caller's type
+        results = {st[0]: (lat[k, :st[7]], errs[k]) for k, st in enumerate(steps)}
+        return options[min(range(m), key=errs.__getitem__)], results      # first minimum (the kernel never reports NaN)
+
     def evaluate_options_on_device(self, options, constraints_per_option, n_samples, seed=0, dtype=np.float32,
-                                   prev_frames=None, skeleton=None, communicator=None):
+                                   prev_frames=None, skeleton=None, communicator=None, device_counts=False):
         """GraphWalkPlanner's option evaluation (reference graph_walk_planner.py:184-226) without host round trips:
         for every option the component counts come from NumPy's stream, the candidates from the device sampler,
         scoring, first-minimum argmin and the copy of the winner stay on the device (mg_options_step: one C call enqueues
@@ -299,10 +386,25 @@ class HipPrimitiveSet(object):
         them with the constraint values and the seed, every rank runs the step on its block of the rows of every option's draw
         (mg_options_step_rows), one all-gather of the result records, per option the first minimum over the ranks: the
         single-GPU result.
+        device_counts: the component counts of every option's draw come from the device as well (mg_options_step_device_counts:
+        a Philox-keyed multinomial per option, distributed like NumPy's, not NumPy's stream -- the status the device sampler has
+        anyway) instead of 16 x np.random.multinomial on the host, which is most of a step's host time; steps the one-launch
+        kernel does not cover fall back to the host draw.  self.last_counts holds the counts of the last such step.
         Returns (best_option, {name: (best_sample, min_error)})."""
-        from .candidate_scoring import cached_constraint_set, alignment_from_prev_frames
-        import ctypes as C
         n = int(n_samples)
+        # The step a planner repeats: same options, same batch, same plain constraint values as last time, nothing in between
+        # (see "The whole step's shortcut" below) -- everything the C call needs is in the plan, made once.
+        dt = _DTYPES.get(dtype) or np.dtype(dtype)
+        if communicator is None and prev_frames is None and skeleton is None and type(constraints_per_option) is dict:
+            plan = self._buffers.get(("plan", options if type(options) is tuple else tuple(options), n, dt.str))
+            whole = plan.get("whole") if plan is not None else None
+            if whole is not None and whole[1] == _cs.CSET_GENERATION[0] and len(constraints_per_option) == len(whole[0]) and \
+                    plan["one_context"] and _same_mapping(constraints_per_option, whole[0]):
+                out = self._repeat_step(plan, options, n, seed, dt, device_counts)
+                if out is not None:
+                    return out
+        cached_constraint_set, alignment_from_prev_frames, CSET_GENERATION = _cs.cached_constraint_set, _cs.alignment_from_prev_frames, _cs.CSET_GENERATION
+        import ctypes as C
         if communicator is not None and communicator.world > 1:
             from . import distributed
             cmd = {"op": "options_step", "options": list(options), "n_samples": n, "seed": int(seed), "dtype": np.dtype(dtype).name,
@@ -340,20 +442,32 @@ class HipPrimitiveSet(object):
         csets, general = [], []
         memo = plan.setdefault("memo", [None] * len(steps))
         multinomial = np.random.multinomial
-        for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
+        # The whole step's shortcut.  A planner that asks the same questions as at the last step -- every option's constraints plain
+        # device-form dicts with the values they had (ONE comparison by value of the whole mapping against a copy that shares nothing
+        # mutable with the caller's: a target rewritten in place is seen), no shared set created, rewritten or closed since (one
+        # integer) -- scores against the sets the last step used: no per-option host work at all.
+        whole = plan.get("whole")
+        if whole is not None and prev_frames is None and skeleton is None and whole[1] == CSET_GENERATION[0] and \
+                type(constraints_per_option) is dict and len(constraints_per_option) == len(whole[0]) and _same_mapping(constraints_per_option, whole[0]):
+            csets, general = whole[2], whole[3]
+            steps_loop = ()
+        else:
+            steps_loop = steps
+            plan["whole"] = None
+        for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps_loop):
             cons = constraints_per_option[name]
             clist = cons.constraints if hasattr(cons, "constraints") else cons
             # A planner asks the same questions step after step: when an option's constraints are plain device-form dicts whose
             # every value is what it was at the last step (compared value by value: callers rewrite targets in place), the set of
             # the last step is the set of this one.  Anything else -- reference objects, a previous motion to align to -- takes the
             # general route (device form, structure and values keys, the shared cache).
-            fp = constraint_fingerprint(clist) if prev_frames is None and skeleton is None else None
             last = memo[k]
-            if fp is not None and last is not None and last[0] == fp and last[1].handle and last[1].cached_values is last[2] and \
-                    getattr(cons, "hip_skeleton", None) is None and getattr(cons, "is_local", True):   # (cached_values: nobody else rewrote the shared set)
-                csets.append(last[1])
+            if last is not None and prev_frames is None and skeleton is None and _same_constraints(clist, last[0]) and last[1].handle and \
+                    last[1].cached_values is last[2] and getattr(cons, "hip_skeleton", None) is None and getattr(cons, "is_local", True):
+                csets.append(last[1])      # (cached_values: nobody else rewrote the shared set)
                 general.append(None)
             else:
+                fp = flat_constraint_copy(clist) if prev_frames is None and skeleton is None else None
                 sk = skeleton if skeleton is not None else getattr(cons, "hip_skeleton", None)
                 form = constraints_to_device_form(clist)
                 alignment = alignment_from_prev_frames(prev_frames, cons, sk)
@@ -367,7 +481,33 @@ class HipPrimitiveSet(object):
                 cs = cached_constraint_set(prim, form, sk, alignment)
                 csets.append(cs)
                 general.append((form, alignment, sk))
-                memo[k] = (fp, cs, cs.cached_values) if fp is not None and all(type(c) is dict for c in clist) else None
+                memo[k] = (fp, cs, cs.cached_values) if fp is not None else None
+        if steps_loop and prev_frames is None and skeleton is None and type(constraints_per_option) is dict and len(constraints_per_option) == len(steps) and \
+                all(m is not None for m in memo) and all(cs is not None for cs in csets) and \
+                all(getattr(constraints_per_option[st[0]], "hip_skeleton", None) is None for st in steps):
+            plan["whole"] = ({st[0]: memo[k][0] for k, st in enumerate(steps)}, CSET_GENERATION[0], csets, general)
+        on_device = bool(device_counts) and plan["one_context"] and steps and len(steps) <= 24 and all(cs is not None for cs in csets)
+        if on_device:
+            # the whole step on the device: counts (mg_options_counts_kernel), candidates, scores, first minima; records and
+            # counts arrive in pinned host memory, one synchronisation
+            m, stride, host = len(steps), plan["stride"], plan["host"]
+            if steps_loop:
+                for k, cs in enumerate(csets):
+                    plan["csets"][k] = cs.handle.value
+            np.add(plan["karange"], np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out=plan["seeds_np"])
+            rc = plan["lib"].mg_options_step_device_counts(m, plan["prims"], plan["csets"], n, plan["seeds"], plan["xs"], code, plan["lds"],
+                                                           plan["errs"], plan["shared_ptr"], stride, plan["host_ptr"], plan["device_counts_ptr"])
+            if rc == -4:           # MG_ERR_UNSUPPORTED: an option the one-launch kernel does not cover -- host draw below
+                on_device = False
+            else:
+                if rc != 0:
+                    _capi._check(rc)
+                self._last_counts = (plan["device_counts"], steps)
+                rec = host[:m * stride].copy().reshape(m, stride)
+                errs = rec[:, 8:16].copy().view(np.float64)[:, 0].tolist()
+                lat = rec[:, 16:].copy().view(np.float64)
+                results = {st[0]: (lat[k, :st[7]], errs[k]) for k, st in enumerate(steps)}
+                return options[int(np.argmin(errs))], results
         for k, st in enumerate(steps):   # the component counts, in option order, from NumPy's global stream
             plan["counts"][k, :len(st[8])] = multinomial(n, st[8])
         if any(cs is None for cs in csets):
@@ -387,16 +527,19 @@ class HipPrimitiveSet(object):
         if plan["one_context"] and steps:
             # one C call, ONE launch and ONE read-back for the whole step (mg_options_step): the result records side by side
             m, stride, host = len(steps), plan["stride"], plan["host"]
-            for k, cs in enumerate(csets):
-                plan["csets"][k] = cs.handle.value
-                plan["seeds"][k] = int(seed) + k
-            _capi._check(steps[0][2].lib.mg_options_step(m, plan["prims"], plan["csets"], n, plan["cnts"], plan["seeds"], plan["xs"], code, plan["lds"],
-                                                         plan["errs"], plan["shared"].ptr, stride, host.ctypes.data_as(C.c_void_p)))
+            if steps_loop:
+                for k, cs in enumerate(csets):
+                    plan["csets"][k] = cs.handle.value
+            np.add(plan["karange"], np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out=plan["seeds_np"])
+            rc = plan["lib"].mg_options_step(m, plan["prims"], plan["csets"], n, plan["cnts"], plan["seeds"], plan["xs"], code, plan["lds"],
+                                             plan["errs"], plan["shared_ptr"], stride, plan["host_ptr"])
+            if rc != 0:
+                _capi._check(rc)
             rec = host[:m * stride].copy().reshape(m, stride)          # one copy: the host block is reused by the next step
             errs = rec[:, 8:16].copy().view(np.float64)[:, 0].tolist()
             lat = rec[:, 16:].copy().view(np.float64)                    # (m, widest L): the winners, already rounded to the caller's type
-            for k, st in enumerate(steps):
-                results[st[0]] = (lat[k, :st[7]], errs[k])
+            results = {st[0]: (lat[k, :st[7]], errs[k]) for k, st in enumerate(steps)}
+            return options[int(np.argmin(errs))], results
         else:
             for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
                 _capi._check(prim.lib.mg_option_step(prim.handle, csets[k].handle, n, plan["counts"][k].ctypes.data, int(seed) + k, d_x.ptr, code, L,
@@ -469,7 +612,11 @@ class HipPrimitiveSet(object):
                         prims=(vp * m)(*[st[2].handle for st in steps]), csets=(vp * m)(),
                         cnts=(vp * m)(*[plan["counts"][k].ctypes.data for k in range(m)]), seeds=(C.c_uint64 * m)(),
                         xs=(vp * m)(*[_capi._dev_ptr(st[4]).value for st in steps]), lds=(C.c_int64 * m)(*[st[7] for st in steps]),
-                        errs=(vp * m)(*[_capi._dev_ptr(st[5]).value for st in steps]))
+                        errs=(vp * m)(*[_capi._dev_ptr(st[5]).value for st in steps]), lib=steps[0][2].lib,
+                        device_counts=np.zeros((m, 16), dtype=np.int64), karange=np.arange(m, dtype=np.uint64))
+            # (everything a step hands to the C call, made once: no ctypes object is created inside a step)
+            plan.update(seeds_np=np.ctypeslib.as_array(plan["seeds"]), shared_ptr=plan["shared"].ptr, host_ptr=plan["host"].ctypes.data_as(vp),
+                        device_counts_ptr=plan["device_counts"].ctypes.data_as(vp))
         self._buffers[key] = plan
         return plan
 

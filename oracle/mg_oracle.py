@@ -902,3 +902,44 @@ def graph_walk_residual_blocks(primitives, alphas, constraints_per_step, prev_fr
         else:
             prev = np.array(aligned[-1], dtype=np.float64)
     return blocks
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The component counts of a planner step drawn on the device (include/mg_hip.h, mg_options_step_device_counts).  The
+# reference draws them with numpy.random.multinomial inside sklearn's GaussianMixture.sample
+# (/root/reference morphablegraphs/motion_model/motion_primitive.py:182-189); the device draw is distributed the same way and
+# has its own stream, restated here so that the counts themselves are pinned bit for bit.
+# ---------------------------------------------------------------------------------------------------------------------
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11: the published algorithm, constants M0 = 0xD2511F53, M1 = 0xCD9E8D57,
+    W0 = 0x9E3779B9, W1 = 0xBB67AE85) on arrays of 32-bit counters; returns the four output words."""
+    c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint64) & 0xFFFFFFFF for c in (c0, c1, c2, c3)]
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0, k1 = np.uint64(k0 & 0xFFFFFFFF), np.uint64(k1 & 0xFFFFFFFF)
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        h0, l0, h1, l1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = h1 ^ c1 ^ k0, l1, h0 ^ c3 ^ k1, l0
+        k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+    return c0, c1, c2, c3
+
+
+def device_multinomial_counts(n, weights, seed):
+    """counts[c] = #{i < n : cum[c-1] <= u_i < cum[c]}, u_i = (Philox(counter = (i >> 2, 0, 0, 0x636e7473), key = seed)[i & 3] + 0.5) / 2^32,
+    cum = cumulative normalised weights (float64, summed in order), the last component takes the rest."""
+    w = np.asarray(weights, dtype=np.float64)
+    K = len(w)
+    wsum = 0.0
+    for v in w:
+        wsum += float(v)
+    cum, acc = [], 0.0
+    for v in w:
+        acc += float(v)
+        cum.append(acc / wsum)
+    j = np.arange((n + 3) // 4, dtype=np.uint64)
+    words = philox4x32_10(j & np.uint64(0xFFFFFFFF), j >> np.uint64(32), 0, 0x636e7473, int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    u = (np.stack(words, axis=1).reshape(-1)[:n].astype(np.float64) + 0.5) * (1.0 / 4294967296.0)
+    below = [int(np.count_nonzero(u < cum[c])) for c in range(K - 1)] + [int(n)]
+    return np.diff([0] + below).astype(np.int64)

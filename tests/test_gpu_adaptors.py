@@ -631,6 +631,55 @@ def test_planner_step_in_one_launch_is_bit_identical_to_the_per_option_chains(dt
             assert r1[name][1] == np.min(r1[name][2])
 
 
+def test_planner_step_with_component_counts_drawn_on_the_device(monkeypatch):
+    """mg_options_step_device_counts: the counts are the ones the oracle's restatement of the device draw gives (Philox4x32-10
+    keyed by seed + option index, histogram of n categorical draws), bit for bit; given those counts the step is the step
+    mg_options_step makes (same candidates, errors, winners); the draw is reproducible, sums to n, and is distributed like
+    numpy.random.multinomial's counts (means and variances over many seeds)."""
+    from oracle import mg_oracle as orc
+    prims = synthetic.make_graph_primitives(7)
+    names = [p["name"] for p in prims]
+    cons = {}
+    for n, p in zip(names, prims):
+        tlast = float(p["n_canonical_frames"] - 1)
+        cons[n] = [{"type": "position", "t": tlast, "weight": 1.0, "target": [10.0, None, 5.0]},
+                   {"type": "direction", "t": (tlast / 2.0), "weight": 0.5, "target": [0.3, 1.0]}]
+    pset = HipPrimitiveSet(prims)
+    for n_samples, seed in ((2048, 41), (777, 5)):
+        best, res = pset.evaluate_options_on_device(names, cons, n_samples=n_samples, seed=seed, device_counts=True)
+        counts = {k: v.copy() for k, v in pset.last_counts.items()}
+        for k, (name, p) in enumerate(zip(names, prims)):
+            ref = orc.device_multinomial_counts(n_samples, p["gmm_weights"], seed + k)
+            np.testing.assert_array_equal(counts[name], ref, err_msg=name)
+            assert counts[name].sum() == n_samples
+        best_b, res_b = pset.evaluate_options_on_device(names, cons, n_samples=n_samples, seed=seed, device_counts=True)
+        assert best_b == best and all(res_b[nm][1] == res[nm][1] for nm in names)          # reproducible
+        # the host route fed the same counts: the same step
+        feed = iter([counts[nm] for nm in names])
+        monkeypatch.setattr(np.random, "multinomial", lambda n, pvals: next(feed))
+        best_h, res_h = pset.evaluate_options_on_device(names, cons, n_samples=n_samples, seed=seed)
+        monkeypatch.undo()
+        assert best_h == best
+        for nm in names:
+            np.testing.assert_array_equal(res_h[nm][0].view(np.uint64), res[nm][0].view(np.uint64))
+            assert res_h[nm][1] == res[nm][1]
+    # distribution: one option, many seeds
+    name, p = names[0], prims[0]
+    w = np.asarray(p["gmm_weights"], dtype=np.float64)
+    w = w / w.sum()
+    n_samples, reps = 4096, 300
+    draws = []
+    for s in range(reps):
+        pset.evaluate_options_on_device([name], {name: cons[name]}, n_samples=n_samples, seed=1000 + s, device_counts=True)
+        draws.append(pset.last_counts[name].copy())
+    draws = np.array(draws, dtype=np.float64)
+    mean, var = draws.mean(axis=0), draws.var(axis=0)
+    sd = np.sqrt(n_samples * w * (1 - w))
+    assert np.all(np.abs(mean - n_samples * w) <= 5 * sd / np.sqrt(reps) + 1e-9), (mean, n_samples * w)
+    if len(w) > 1:
+        assert np.all(np.abs(var - sd ** 2) <= 0.35 * sd ** 2 + 1.0), (var, sd ** 2)
+
+
 def test_planner_step_falls_back_to_one_stream_for_large_mixtures():
     """More than 16 mixture components (prefix sums staged in the context's scratch buffer) or the VALU sampler forced: the
     options of a step share that ONE staging buffer, so mg_options_step must not run them on side streams.

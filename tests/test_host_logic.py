@@ -420,6 +420,20 @@ def test_constraint_fingerprint_is_a_value_copy():
     assert fp(clist) != f2
     assert fp([{"type": "position", "t": 5.0, "goal": 1.0}]) != fp([{"type": "position", "t": 5.0, "target": 1.0}])   # key names count
     assert fp([object()]) is None and fp("x") is None and fp([{"type": "position", "target": object()}]) is None
+    # the planner step's own test: a flat value copy + the interpreter's comparison
+    from morphablegraphs_amd.motion_state_graph import flat_constraint_copy, _same_constraints
+    plain = [{"type": "position", "t": 5.0, "weight": 1.0, "target": [10.0, None, 5.0]}, {"type": "direction", "t": 5.0, "target": [0.3, 1.0]}]
+    keep = flat_constraint_copy(plain)
+    assert _same_constraints(plain, keep) and keep[0]["target"] is not plain[0]["target"]
+    plain[0]["target"][0] = -35.0                                   # rewritten in place: noticed
+    assert not _same_constraints(plain, keep)
+    plain[0]["target"][0] = 10.0
+    assert _same_constraints(plain, keep) and not _same_constraints(plain[:1], keep)
+    assert not _same_constraints([dict(plain[0], goal=1.0), plain[1]], keep)      # another key
+    assert flat_constraint_copy(clist) is None and flat_constraint_copy([{"target": [[1.0]]}]) is None and flat_constraint_copy("x") is None
+    assert not _same_constraints([{"target": np.ones(3)}], [{"target": np.ones(3)}])   # arrays: never "the same", no exception
+    nan = [{"target": [float("nan"), 1.0]}]
+    assert not _same_constraints(nan, flat_constraint_copy([{"target": [float("nan"), 1.0]}]))
     # the shared constraint-set cache: two-dimensional array targets compare without raising, skeletons by serial number
     v1 = cs._values_key([{"weight": 1.0, "target": np.ones((2, 3)), "ref_dir": None}], None)
     v2 = cs._values_key([{"weight": 1.0, "target": np.ones((2, 3)), "ref_dir": None}], None)
