@@ -697,10 +697,20 @@ def run_optimizer(args, emit=True):
     flop = K * (2 * L * L + 2 * L) + 2 * rows * L          # mixture (dense x P_k, as sklearn does) + the keyframe channel rows
     S = ctx.upload(np.random.default_rng(0).standard_normal((B, L)).astype(np.float32))
     lp, err = ctx.malloc(B * 4), ctx.malloc(B * 8)
+    obj = ctx.malloc(B * 8)
+    fused = not getattr(args, "two_launch", False)
+    if fused:
+        try:   # the iteration in ONE launch (mg_objective_error_and_naturalness: the mixture kernel scores the constraints on the tile it holds)
+            prim.objective_dev(cset, S, np.float32, B, L, 1.0, 1.0, obj_dev=obj)
+        except _capi.MGError:
+            fused = False
 
     def step():
-        prim.gmm_log_prob_dev(S, np.float32, B, L, lp, np.float32)
-        prim.score_constraints_dev(cset, S, np.float32, B, L, err, np.float64)
+        if fused:
+            prim.objective_dev(cset, S, np.float32, B, L, 1.0, 1.0, obj_dev=obj)
+        else:
+            prim.gmm_log_prob_dev(S, np.float32, B, L, lp, np.float32)
+            prim.score_constraints_dev(cset, S, np.float32, B, L, err, np.float64)
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
@@ -714,7 +724,7 @@ def run_optimizer(args, emit=True):
     ctx.profile_enable(False)
     g_ms, g_n = ctx.profile_get("gmm_log_prob")
     s_ms, s_n = ctx.profile_get("score_constraints")
-    gmm_flop = B * K * (2 * L * L + 2 * L)
+    gmm_flop = B * K * (2 * L * L + 2 * L) + (B * 2 * rows * L if fused else 0)   # fused: the one kernel does the keyframe channel rows as well
     g_avg = g_ms / max(1, g_n)
     result = {
         "metric": METRIC, "value": B * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -722,17 +732,19 @@ def run_optimizer(args, emit=True):
         "data": "synthetic",
         "config": {"workload": "optimizer inner loop, score only: log p(x) + 2 root keyframe constraints of %d candidates per iteration on one GPU "
                                "(BASELINE.json configs[4] is this per iteration over 8 GPUs); no frames written, %d bytes per candidate" % (B, 4 * L + 12),
-                   "candidates_per_iteration": B, "launches_per_step": 2, "flop_per_candidate": flop},
-        "roofline": {"bound": "mfma", "kernel": "mg_gmm_logp_mfma_kernel", "achieved": gmm_flop / (g_avg * 1e-3) / 1e12 if g_avg else None,
+                   "candidates_per_iteration": B, "launches_per_step": 1 if fused else 2, "flop_per_candidate": flop,
+                   "objective": ("error_scale * constraint error + quality_scale * (-log p) written by one launch (mg_objective_error_and_naturalness), %d bytes per candidate"
+                                 % (4 * L + 8)) if fused else "log p (float32) and constraint errors (float64) by two launches"},
+        "roofline": {"bound": "mfma", "kernel": "mg_gmm_logp_lds_kernel<.., SCORE> (mixture + keyframe constraints on the same latent tile)" if fused else "mg_gmm_logp_lds_kernel", "achieved": gmm_flop / (g_avg * 1e-3) / 1e12 if g_avg else None,
                      "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (gmm_flop / (g_avg * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS) if g_avg else None,
                      "traffic": None, "avg_kernel_ms": g_avg, "launches_timed": g_n,
-                     "score_kernel_avg_ms": s_ms / max(1, s_n), "step_achieved_TFLOPs": B * flop / (elapsed / args.steps) / 1e12,
+                     "score_kernel_avg_ms": (s_ms / max(1, s_n)) if not fused else None, "step_achieved_TFLOPs": B * flop / (elapsed / args.steps) / 1e12,
                      "step_frac": B * flop / (elapsed / args.steps) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                      "peak_note": "float64 matrix peak AMD publishes for MI355X; the microarchitecture guide lists no float64 MFMA row"},
     }
     if emit:
         print(json.dumps(result))
-    for b in (S, lp, err):
+    for b in (S, lp, err, obj):
         b.free()
     cset.close()
     prim.close()

@@ -364,6 +364,22 @@ int mg_time_function_canonical(mg_primitive *prim, const void *gamma_dev, int ga
                                double *out_dev);
 int mg_time_function_canonical_host(mg_primitive *prim, const void *gamma, int gamma_dtype, int64_t n_samples, int64_t ld,
                                     double *out);
+/* The TIME-WARPED synthesis of a batch (reference motion_primitive.py:268-319 behind back_project(s, use_time_parameters=True);
+ * graph_walk.py:154-176 turns every step of a finished walk into frames this way).
+ * mg_time_function_sample: per candidate the spline's time function t'(t) = {0, inverse of the canonical time function t(t') at
+ * numpy.linspace(1, t(F-2), num), F - 1}, num = int(round(t(F-2)) * (1 / speed)) -- the reference passes this FLOAT to linspace, a
+ * TypeError on NumPy >= 1.18; int() is what older NumPy made of it.  The inverse is the interpolating cubic through (t(i), i),
+ * i = 0 .. F-1, that scipy's splrep(k=3, s=0) builds: knots at every data point but the second and the second-to-last, i.e. the
+ * not-a-knot cubic, computed here from its second derivatives (the same function; 1e-12 F from FITPACK's B-spline form).
+ * times (n, t_cap) float64, lengths (n) int32: samples of row b = lengths[b]; a row that would need more than t_cap samples gets
+ * lengths[b] = -needed and is not written.  canonical_out (may be NULL): (n, F) float64, the canonical time functions.
+ * mg_back_project_frames_at: frames of every candidate at its own times, (n, t_cap, D) float64 or float32 -- the float64 arithmetic
+ * of mg_back_project_frames_f64 (control points as fma chains from the mean, FITPACK basis rows, four taps), one launch for the
+ * batch; lengths NULL: every row has t_cap samples.  Device pointers. */
+int mg_time_function_sample(mg_primitive *prim, const void *gamma, int dtype, int64_t n, int64_t ld, double speed, double *times, int32_t *lengths,
+                            int32_t t_cap, double *canonical_out);
+int mg_back_project_frames_at(mg_primitive *prim, const void *latents, int dtype, int64_t n, int64_t ld, const double *times, const int32_t *lengths,
+                              int32_t t_cap, void *out, int out_dtype);
 
 /* ---- time grids ---------------------------------------------------------------------
  * A set of canonical times with its B-spline basis rows (FITPACK splev semantics,
@@ -554,6 +570,17 @@ void mg_constraint_set_destroy(mg_constraint_set *cs);
 int mg_score_constraints(mg_primitive *prim, const mg_constraint_set *cs,
                          const void *latents_dev, int latent_dtype, int64_t n_samples, int64_t ld,
                          void *errors_dev, int out_dtype);
+
+/* The optimiser's objective for a batch in ONE launch: obj[b] = error_scale * err[b] + quality_scale * (-log p(s_b))
+ * (reference optimization/objective_functions.py:163-185, obj_spatial_error_sum_and_naturalness; err = what mg_score_constraints
+ * returns, log p = what mg_gmm_log_prob returns in float64 -- the same bits: the wave that holds a 16-candidate tile's latents for
+ * the mixture scores the constraints on them, and the products and the sum are rounded one by one like NumPy's array arithmetic).
+ * logp_out / err_out / obj_out: (n) float64 device pointers, any of them NULL.  Covers sets of root position / 2-D direction
+ * constraints (path following), local or aligned through the root joint; MG_ERR_UNSUPPORTED for anything else -- joint
+ * constraints, a mixture over time latents, more than 64 dimensions: the kernel runs four waves per SIMD and has no registers for
+ * forward-kinematics chains -- then two calls (mg_score_constraints, mg_gmm_log_prob) give the same numbers. */
+int mg_objective_error_and_naturalness(mg_primitive *prim, const mg_constraint_set *cs, const void *latents, int dtype, int64_t n, int64_t ld,
+                                       double error_scale, double quality_scale, double *logp_out, double *err_out, double *obj_out);
 
 /* MotionPrimitiveConstraints.get_residual_vector (reference motion_primitive_constraints.py:124-144) for the
  * same root-joint keyframe constraints: residuals_dev (n_samples, n_constraints) float64 row-major, entry

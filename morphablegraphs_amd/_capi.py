@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_placement_info", "mg_device_free", "mg_context_trim_outputs", "mg_context_output_bytes", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_root_mode", "mg_primitive_get_precisions_cholesky",
-    "mg_time_function_canonical", "mg_time_function_canonical_host",
+    "mg_time_function_canonical", "mg_time_function_canonical_host", "mg_time_function_sample", "mg_back_project_frames_at",
     "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_score_trajectory_points", "mg_joint_positions",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
     "mg_score_constraints", "mg_argmin_first", "mg_argmin_first_dev", "mg_step_frames_and_logp", "mg_step_plan", "mg_step_plan_for",
     "mg_back_project_frames_host", "mg_back_project_frames_f64_host", "mg_back_project_coeffs_host",
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
-    "mg_score_constraint_residuals", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
+    "mg_score_constraint_residuals", "mg_objective_error_and_naturalness", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
     "mg_align_frames", "mg_frame_constraint_width", "mg_score_frame_constraint",
     "mg_score_constraint_residuals_chained", "mg_option_step", "mg_options_step", "mg_options_step_device_counts", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
@@ -292,6 +292,9 @@ def load_library(path=None):
         "mg_options_step_rows": [i32, vp, vp, i64, vp, vp, i64, i64, vp, i32, vp, vp, vp, i64, vp],
         "mg_gmm_sample_rows": [vp, i64, vp, u64, i64, i64, vp, i32, i64, vp],
         "mg_dist_broadcast": [vp, vp, i64, i32],
+        "mg_objective_error_and_naturalness": [vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, vp],
+        "mg_time_function_sample": [vp, vp, i32, i64, i64, dbl, vp, vp, i32, vp],
+        "mg_back_project_frames_at": [vp, vp, i32, i64, i64, vp, vp, i32, vp, i32],
         "mg_options_step": [i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, vp],
         "mg_options_step_device_counts": [i32, vp, vp, i64, vp, vp, i32, vp, vp, vp, i64, vp, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
@@ -912,6 +915,55 @@ class Primitive(object):
                                                         out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def time_function_sample(self, gamma, speed=1.0, t_cap=None, with_canonical=False):
+        """(B, n_time_components) time latents -> (times (B, t_cap) float64 padded with NaN, lengths (B)): the spline's time function
+        t'(t) of every row (mg_time_function_sample: back_project_time_function, motion_primitive.py:268-319, for the batch)."""
+        G = _latents(gamma)
+        B, F = G.shape[0], self.n_canonical_frames
+        ctx = self.ctx
+        cap = int(t_cap) if t_cap is not None else int(4 * F / min(float(speed), 1.0)) + 8
+        while True:
+            d_g, d_t, d_l = ctx.upload(G), ctx.malloc(max(B, 1) * cap * 8), ctx.malloc(max(B, 1) * 4)
+            d_c = ctx.malloc(max(B, 1) * F * 8) if with_canonical else None
+            try:
+                _check(self.lib.mg_memset(ctx.handle, d_t.ptr, 0xff, max(B, 1) * cap * 8))      # NaN padding
+                _check(self.lib.mg_time_function_sample(self.handle, d_g.ptr, _dtype_code(G), B, G.shape[1], float(speed), d_t.ptr, d_l.ptr, cap,
+                                                        d_c.ptr if d_c is not None else None))
+                lens = ctx.download(d_l, (B,), np.int32)
+                if B and lens.min() < 0 and t_cap is None:      # a row needs more samples than assumed: once more with room for it
+                    cap = int(-lens.min()) + 8
+                    continue
+                times = ctx.download(d_t, (B, cap), np.float64)
+                canonical = ctx.download(d_c, (B, F), np.float64) if d_c is not None else None
+            finally:
+                for b in (d_g, d_t, d_l, d_c):
+                    if b is not None:
+                        b.free()
+            return (times, lens, canonical) if with_canonical else (times, lens)
+
+    def back_project_frames_at(self, S, times, lengths=None, dtype=np.float64):
+        """(B, ld) latents, (B, t_cap) float64 times, (B) lengths -> (B, t_cap, D) frames of every candidate at ITS OWN times
+        (mg_back_project_frames_at); samples beyond a row's length are NaN."""
+        S = _latents(S)
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        B, cap = times.shape
+        if S.shape[0] != B:
+            raise ValueError("one row of times per candidate")
+        lens = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.int32)
+        item = np.dtype(dtype).itemsize
+        ctx = self.ctx
+        d_s, d_t, d_o = ctx.upload(S), ctx.upload(np.where(np.isnan(times), 0.0, times)), ctx.malloc(max(B, 1) * cap * self.n_dim * item)
+        d_l = ctx.upload(lens) if lens is not None else None
+        try:
+            _check(self.lib.mg_memset(ctx.handle, d_o.ptr, 0xff, max(B, 1) * cap * self.n_dim * item))
+            _check(self.lib.mg_back_project_frames_at(self.handle, d_s.ptr, _dtype_code(S), B, S.shape[1], d_t.ptr, d_l.ptr if d_l is not None else None, cap,
+                                                      d_o.ptr, MG_F64 if np.dtype(dtype) == np.float64 else MG_F32))
+            return ctx.download(d_o, (B, cap, self.n_dim), dtype)
+        finally:
+            for b in (d_s, d_t, d_o, d_l):
+                if b is not None:
+                    b.free()
+
     def time_grid(self, times):
         return TimeGrid(self, times)
 
@@ -1051,6 +1103,28 @@ class Primitive(object):
         begin, count = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
         _check(self.lib.mg_gmm_sample_rows(self.handle, n, counts.ctypes.data_as(C.c_void_p), C.c_uint64(int(seed)), begin, count,
                                            _dev_ptr(x_dev), xc, int(ld), comp))
+
+    def objective_dev(self, cset, lat_dev, lat_dtype, n, ld, error_scale, quality_scale, obj_dev=None, err_dev=None, logp_dev=None):
+        """error_scale * constraint error + quality_scale * (-log p) of n device-resident candidates in one launch
+        (mg_objective_error_and_naturalness); outputs float64 device buffers, any of them None."""
+        lc = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        ptr = lambda b: _dev_ptr(b) if b is not None else None
+        _check(self.lib.mg_objective_error_and_naturalness(self.handle, cset.handle, _dev_ptr(lat_dev), lc, int(n), int(ld), float(error_scale),
+                                                           float(quality_scale), ptr(logp_dev), ptr(err_dev), ptr(obj_dev)))
+
+    def objective(self, cset, S, error_scale, quality_scale):
+        """(objective, errors, log p) for host latents S (n, >= n_gmm_dims); raises MGError(-4) where the one-launch kernel does
+        not carry the set."""
+        S = _latents(S)
+        n = S.shape[0]
+        ctx = self.ctx
+        d_S, bufs = ctx.upload(S), [ctx.malloc(max(n, 1) * 8) for _ in range(3)]
+        try:
+            self.objective_dev(cset, d_S, S.dtype, n, S.shape[1], error_scale, quality_scale, bufs[0], bufs[1], bufs[2])
+            return tuple(ctx.download(b, (n,), np.float64) for b in bufs)
+        finally:
+            for b in [d_S] + bufs:
+                b.free()
 
     def score_constraints_dev(self, cset, lat_dev, lat_dtype, n, ld, out_dev, out_dtype=np.float64):
         lc = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32

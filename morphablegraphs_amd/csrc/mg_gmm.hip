@@ -10,6 +10,7 @@
 
 #include "mg_internal.h"
 #include "mg_gmm_device.h"
+#include "mg_score_device.h"
 
 #define MG_GMM_CANDS 64    // candidates per workgroup: one per lane
 #define MG_GMM_WAVES 8     // waves per workgroup: components are dealt round-robin to waves
@@ -263,12 +264,23 @@ __host__ __device__ constexpr int mg_gmm_nf() {
     for (int jt = 0; jt < (KK + 3) / 4; jt++) nf += (4 * (jt + 1) < KK) ? 4 * (jt + 1) : KK;
     return nf;
 }
-template <int KK, bool X_F64, bool OUT_F64>
+// SCORE (mg_objective_error_and_naturalness): the optimiser's objective in ONE launch.  The wave that holds a tile's latents for
+// the mixture also scores the keyframe constraints on them -- the pose channels X . W^T + bias on the f64 matrix pipe, residuals by
+// mg_constraint_residual, summed in constraint order: the arithmetic of mg_score_mfma_kernel, so the same bits -- and writes
+// error_scale * error + quality_scale * (-log p) beside (or instead of) the two parts; the 21 MB of latents are read once.
+struct mg_objective_args {
+    mg_score_args sa;            // sa.out unused
+    const double *Wpack, *bpad;  // [RT][KK][64], [RT*16]
+    int32_t RT, rows, wave_doubles;   // wave_doubles: the wave's LDS buffer (terms + exponentials, then reused for channels + residuals)
+    double error_scale, quality_scale;
+    double *err_out, *obj_out;   // (B) float64 each, or NULL
+};
+template <int KK, bool X_F64, bool OUT_F64, bool SCORE>
 __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__restrict__ Ppack,  // [K][JT][KK][64]
                                                                const double *__restrict__ mP,     // [K][JT*16]
                                                                const double *__restrict__ cst,    // [K]
                                                                const void *__restrict__ x, void *__restrict__ out,
-                                                               const mg_gmm_mfma_args a, const int64_t n_tiles) {
+                                                               const mg_gmm_mfma_args a, const int64_t n_tiles, const mg_objective_args oa) {
     constexpr int JTM = (KK + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K;
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
     }
     for (int e = tid; e < K * JT * 16; e += 1024) lds_c[e] = -mP[e];
     __syncthreads();
-    mg_lds_f64 *terms = lds_w + (size_t)wave * 2 * K * 16, *exps = terms + K * 16;
+    mg_lds_f64 *terms = lds_w + (size_t)wave * (SCORE ? oa.wave_doubles : 2 * K * 16), *exps = terms + K * 16;
     // tile t of the launch: workgroup t % grid, wave (t / grid) % 16 -- consecutive tiles go to different CUs.  (Requesting the
     // next tile's latents a tile ahead changes nothing: the other three waves of the SIMD cover the load.)
     for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += (int64_t)gridDim.x * 16) {
@@ -325,10 +337,46 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its LDS writes are visible to its reads in order
         for (int e = lane; e < K * 16; e += 64) exps[e] = mg_gmm_exp_entry(terms, K, e);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double r = 0.0;
         if (lane < ncand) {
-            const double r = mg_gmm_logsumexp(terms, exps, K, lane);
-            if (OUT_F64) ((double *)out)[b0 + lane] = r;
-            else ((float *)out)[b0 + lane] = (float)r;
+            r = mg_gmm_logsumexp(terms, exps, K, lane);
+            if (out) {
+                if (OUT_F64) ((double *)out)[b0 + lane] = r;
+                else ((float *)out)[b0 + lane] = (float)r;
+            }
+        }
+        if constexpr (SCORE) {
+            // the wave's buffer again, now for the tile's pose channels and residuals (LDS serves a wave's requests in order)
+            const int RT = oa.RT, rows = oa.rows, vs = rows + 1, n = oa.sa.n;   // (only the rows in use are kept: sixteen waves share the LDS)
+            double *vals = (double *)terms, *resid = vals + 16 * vs;
+            for (int rt = 0; rt < RT; rt++) {
+                const double *wp = oa.Wpack + ((size_t)rt * KK) * 64 + lane;
+                const double c0 = oa.bpad[rt * 16 + cl];
+                mg_f64x4 acc = {c0, c0, c0, c0};
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[kk], wp[kk * 64], acc, 0, 0, 0);
+                if (rt * 16 + cl < rows) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) vals[(g + 4 * rr) * vs + rt * 16 + cl] = acc[rr];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int e = lane; e < 16 * n; e += 64) {
+                const int cand = e & 15, c = e >> 4;
+                const double *v = vals + cand * vs;
+                resid[c * 16 + cand] = mg_constraint_residual<true>(oa.sa, c, [&](int row) { return v[row]; }, b0 + cand);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < ncand) {
+                double err = 0.0;
+                for (int c = 0; c < n; c++) err += resid[c * 16 + lane];
+                if (oa.err_out) oa.err_out[b0 + lane] = err;
+                if (oa.obj_out) {
+                    const double e_part = oa.error_scale * err, q_part = -r * oa.quality_scale;   // (rounded separately, like the host's array arithmetic)
+                    oa.obj_out[b0 + lane] = e_part + q_part;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the next tile's terms land in the same buffer
         }
     }
 }
@@ -341,31 +389,85 @@ static int mg_gmm_lds_nf(int KK, int JT) {
 // the LDS-resident kernel pays from this many candidates on ('walk', us per launch, one tile per workgroup / LDS-resident:
 // B = 8192 9.9 / 15.6, 16384 16.6 / 16.9, 32768 30.2 / 24.8, 65536 51.0 / 38.9, 131072 91.0 / 67.4)
 #define MG_GMM_LDS_MIN_B 20480
+static int mg_objective_wave_doubles(const mg_primitive *p, const mg_constraint_set *cs) {
+    return std::max(2 * p->K * 16, 16 * (cs->rows + 1) + 16 * std::max(cs->n, 1));   // channels [16][rows + 1], residuals [n][16]
+}
 template <int KK>
-static int mg_launch_gmm_lds_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt) {
+static int mg_launch_gmm_lds_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt,
+                                const mg_constraint_set *cs = nullptr, double error_scale = 0.0, double quality_scale = 0.0,
+                                double *err_out = nullptr, double *obj_out = nullptr) {
     mg_gmm_mfma_args a;
     a.B = B; a.ld = ld; a.K = p->K; a.L = p->Lg; a.JT = (p->Lg + 15) / 16;
     const int64_t n_tiles = (B + 15) / 16;
-    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(KK, a.JT) * 64 + (size_t)p->K * a.JT * 16 + (size_t)16 * 2 * p->K * 16) * 8;
+    mg_objective_args oa;
+    memset(&oa, 0, sizeof(oa));
+    const int wave_doubles = cs ? mg_objective_wave_doubles(p, cs) : 2 * p->K * 16;
+    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(KK, a.JT) * 64 + (size_t)p->K * a.JT * 16 + (size_t)16 * wave_doubles) * 8;
+    if (cs) {
+        mg_score_args &sa = oa.sa;
+        sa.W = cs->d_W; sa.bias = cs->d_bias; sa.par = cs->d_par; sa.woff = cs->d_woff; sa.chain = cs->d_chain; sa.choff = cs->d_choff;
+        sa.align = cs->d_align; sa.align_cand = nullptr; sa.pose = cs->d_pose; sa.lat = x; sa.out = nullptr; sa.res = nullptr; sa.B = B; sa.ld = ld;
+        sa.n = cs->n; sa.nch = cs->nch; sa.L = p->L;
+        oa.Wpack = cs->d_Wpack; oa.bpad = cs->d_bpad; oa.RT = cs->RT; oa.rows = cs->rows; oa.wave_doubles = wave_doubles;
+        oa.error_scale = error_scale; oa.quality_scale = quality_scale; oa.err_out = err_out; oa.obj_out = obj_out;
+    }
     // every CU gets a workgroup as soon as there are that many tiles: the tiles of a workgroup run side by side on its sixteen
     // waves, so few tiles per workgroup mean short chains per SIMD (16 workgroups of 16 busy waves: 36 us at B = 4096)
     const int grid = (int)std::min<int64_t>(std::max(1, p->ctx->n_cu), n_tiles);
     hipStream_t st = p->ctx->stream;
     const bool xf = xdt == MG_F64, of = odt == MG_F64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    // the dynamic-LDS attribute is a property of (kernel, device): once per context (a per-process flag left a second
+    // GPU's context without it)
+    const unsigned abit = 1u << (KK / 2);
+    if (!(p->ctx->attr_gmm_lds & abit)) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_gmm_logp_lds_kernel<KK, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        p->ctx->attr_gmm_lds |= abit;
     }
-    if (xf && of) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
-    else if (xf) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
-    else if (of) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
-    else hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles);
+    if (cs) {   // the objective: log p in float64 (or not at all), errors and objective in float64
+        if (xf) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, true, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
+        else hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, true, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
+    }
+    else if (xf && of) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, true, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
+    else if (xf) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, false, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
+    else if (of) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, true, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
+    else hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, false, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
+}
+
+// The optimiser's objective in one launch: can the LDS-resident mixture kernel carry this constraint set?
+bool mg_objective_can_fuse(const mg_primitive *p, const mg_constraint_set *cs) {
+    if (!p->d_gPpack || p->KKg <= 0 || p->Lg != p->L || p->KK != p->KKg || !cs || !cs->d_Wpack || p->ctx->opt[MG_OPT_FORCE_VALU_SCORE]) return false;
+    // root position / 2-D direction constraints (path following: what the optimiser's keyframe constraints are when no hand or
+    // foot is constrained), aligned to the root joint if at all: the kinds the kernel compiles in
+    for (const mg_keyframe_constraint &kc : cs->structure)
+        if (kc.type != MG_CONSTRAINT_POSITION && kc.type != MG_CONSTRAINT_DIRECTION_2D) return false;
+    if (cs->has_pose || cs->align_joint > 0) return false;
+    const int JT = (p->Lg + 15) / 16;
+    if (JT != (p->KKg + 3) / 4) return false;
+    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(p->KKg, JT) * 64 + (size_t)p->K * JT * 16 + (size_t)16 * mg_objective_wave_doubles(p, cs)) * 8;
+    return lds <= 160 * 1024 - 64;
+}
+int mg_launch_objective(mg_primitive *p, const mg_constraint_set *cs, const void *x, int xdt, int64_t B, int64_t ld, double error_scale,
+                        double quality_scale, double *logp_out, double *err_out, double *obj_out) {
+    switch (p->KKg) {
+        case 2: return mg_launch_gmm_lds_kk<2>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        case 4: return mg_launch_gmm_lds_kk<4>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        case 6: return mg_launch_gmm_lds_kk<6>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        case 8: return mg_launch_gmm_lds_kk<8>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        case 10: return mg_launch_gmm_lds_kk<10>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        case 12: return mg_launch_gmm_lds_kk<12>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        case 14: return mg_launch_gmm_lds_kk<14>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        case 16: return mg_launch_gmm_lds_kk<16>(p, x, xdt, B, ld, logp_out, MG_F64, cs, error_scale, quality_scale, err_out, obj_out);
+        default: break;
+    }
+    mg_set_error("mg_objective_error_and_naturalness: no one-launch kernel for this mixture");
+    return MG_ERR_UNSUPPORTED;
 }
 static bool mg_gmm_use_lds_kernel(const mg_primitive *p, int64_t B) {
     const int mode = p->ctx->opt[MG_OPT_GMM_KERNEL];   // 0 = by batch size, 1 = one tile per workgroup, 2 = LDS-resident

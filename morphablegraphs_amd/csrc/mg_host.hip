@@ -787,7 +787,7 @@ static void mg_primitive_free(mg_primitive *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean,
+    void *ptrs[] = {p->d_Epack, p->d_Et32, p->d_Et64, p->d_Erpack, p->d_meanroot, p->d_mean32, p->d_mean, p->d_knots,
                     p->d_gP, p->d_gmP, p->d_gconst, p->d_gmean, p->d_gchol, p->d_gPpack, p->d_gmPpad, p->d_gPTpack, p->d_gcholpack, p->d_gmeanpad,
                     p->d_tphi, p->d_tmean};
     for (void *q : ptrs) mg_dev_free(p->ctx, q);
@@ -865,6 +865,7 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
         if (rc == MG_OK) rc = mg_upload(ctx, et32, &p->d_Et32);
         if (rc == MG_OK) rc = mg_upload(ctx, et64, &p->d_Et64);
         if (rc == MG_OK) rc = mg_upload(ctx, p->means_, &p->d_mean);
+        if (rc == MG_OK) rc = mg_upload(ctx, p->knots, &p->d_knots);
         {
             std::vector<float> m32((size_t)p->RT * 16, 0.0f);
             for (int i = 0; i < NB; i++)
@@ -1240,6 +1241,36 @@ extern "C" int mg_time_function_canonical(mg_primitive *p, const void *gamma, in
     return mg_launch_time_function(p, gamma, gdt, B, ld, out);
 }
 
+// back_project_time_function for a batch (reference motion_primitive.py:268-319): the spline's time function t'(t) of every
+// candidate -- 0, the inverse of its canonical time function at linspace(1, t(F-2), num), F - 1 -- padded to t_cap per row.
+extern "C" int mg_time_function_sample(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double speed, double *times, int32_t *lengths,
+                                       int32_t t_cap, double *canonical_out) {
+    MG_REQUIRE(p != nullptr, "mg_time_function_sample: primitive is NULL");
+    MG_REQUIRE(p->Lt > 0, "mg_time_function_sample: the primitive has no time model");
+    MG_REQUIRE(B >= 0 && B < ((int64_t)1 << 31) && (gdt == MG_F32 || gdt == MG_F64) && ld >= p->Lt, "mg_time_function_sample: bad arguments (ld %lld, n_time_components %d)",
+               (long long)ld, p->Lt);
+    MG_REQUIRE(speed > 0.0 && std::isfinite(speed) && t_cap >= 2, "mg_time_function_sample: speed must be positive and finite, t_cap >= 2");
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(gamma && times && lengths, "mg_time_function_sample: NULL pointer");
+    { int rc0 = mg_use_device(p->ctx); if (rc0 != MG_OK) return rc0; }
+    return mg_launch_timewarp(p, gamma, gdt, B, ld, speed, times, lengths, t_cap, canonical_out);
+}
+
+// MotionSpline.get_motion_vector of every candidate at ITS OWN time function (reference motion_spline.py:71-86 behind
+// back_project(s, True), motion_primitive.py:206-234): times (B, t_cap) float64, lengths (B) (NULL: every row has t_cap samples;
+// rows with length <= 0 are skipped), out (B, t_cap, D) float64 or float32 (the float64 value rounded once); samples beyond a
+// row's length are left as they were.
+extern "C" int mg_back_project_frames_at(mg_primitive *p, const void *lat, int dt, int64_t B, int64_t ld, const double *times, const int32_t *lengths,
+                                         int32_t t_cap, void *out, int odt) {
+    int rc = mg_check_latents("mg_back_project_frames_at", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(odt == MG_F32 || odt == MG_F64, "mg_back_project_frames_at: bad output dtype %d", odt);
+    MG_REQUIRE(t_cap >= 1 && B < ((int64_t)1 << 31), "mg_back_project_frames_at: t_cap must be >= 1");
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(times && out, "mg_back_project_frames_at: NULL pointer");
+    return mg_launch_frames_at(p, lat, dt, B, ld, times, lengths, t_cap, out, odt);
+}
+
 // rows [row_begin, row_begin + row_count) of the draw of n rows (mg_gmm_sample: all of them)
 extern "C" int mg_gmm_sample_rows(mg_primitive *p, int64_t n, const int64_t *counts, uint64_t seed, int64_t row_begin, int64_t row_count,
                                   void *x, int xdt, int64_t ld, int32_t *comp) {
@@ -1553,6 +1584,7 @@ extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_
                     if (k < L && row < rows_total) wpack[((size_t)rt * KK + kk) * 64 + lane] = W[row * L + k];
                 }
         cs->RT = RT;
+        cs->rows = (int32_t)rows_total;
         rc = mg_upload(p->ctx, wpack, &cs->d_Wpack);
         if (rc == MG_OK) rc = mg_upload(p->ctx, bpad, &cs->d_bpad);
     }
@@ -1644,6 +1676,28 @@ extern "C" int mg_score_constraints(mg_primitive *p, const mg_constraint_set *cs
     rc = mg_launch_score(p, cs, lat, dt, B, ld, out, odt, nullptr);
     mg_prof_end(p->ctx, 2);
     return rc;
+}
+
+// obj_spatial_error_sum_and_naturalness for a batch in ONE launch (reference optimization/objective_functions.py:163-185):
+// error_scale * sum of the weighted constraint errors + quality_scale * (-log p(s)).
+extern "C" int mg_objective_error_and_naturalness(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt, int64_t B, int64_t ld,
+                                                  double error_scale, double quality_scale, double *logp_out, double *err_out, double *obj_out) {
+    int rc = mg_check_latents("mg_objective_error_and_naturalness", p, lat, dt, B, ld);
+    if (rc != MG_OK) return rc;
+    MG_REQUIRE(cs && cs->prim == p, "mg_objective_error_and_naturalness: constraint set is NULL or belongs to another primitive");
+    MG_REQUIRE(p->K > 0, "mg_objective_error_and_naturalness: the primitive has no mixture");
+    MG_REQUIRE(ld >= p->Lg, "mg_objective_error_and_naturalness: ld = %lld < the mixture's %d dimensions", (long long)ld, p->Lg);
+    if (B == 0) return MG_OK;
+    MG_REQUIRE(logp_out || err_out || obj_out, "mg_objective_error_and_naturalness: no output pointer");
+    if (mg_objective_can_fuse(p, cs)) {
+        mg_prof_begin(p->ctx, 1);
+        rc = mg_launch_objective(p, cs, lat, dt, B, ld, error_scale, quality_scale, logp_out, err_out, obj_out);
+        mg_prof_end(p->ctx, 1);
+        return rc;
+    }
+    mg_set_error("mg_objective_error_and_naturalness: this mixture / constraint set does not run on the one-launch kernel (mixture over time "
+                 "latents, more than 64 dimensions, tables beyond LDS, or the VALU scorer forced): call mg_gmm_log_prob and mg_score_constraints");
+    return MG_ERR_UNSUPPORTED;
 }
 
 extern "C" int mg_score_constraint_residuals(mg_primitive *p, const mg_constraint_set *cs, const void *lat, int dt,

@@ -72,6 +72,7 @@ struct mg_context {
     std::vector<unsigned char> fused_tab_host;
     void *fused_counters = nullptr, *fused_partials = nullptr;
     void *fused_dyn_dev = nullptr;   // a step's per-option values where the device draws the component counts itself
+    unsigned attr_gmm_lds = 0, attr_traj = 0;   // dynamic-LDS attributes already set for this context's device (bit per instantiation)
     unsigned long long fused_seq = 0;   // sequence number of the planner steps whose records the kernel leaves in pinned memory
     int fused_partials_n = 0;
     // the output arena (mg_placement.hip): buffers that went through the placement probe, sub-allocated in 2 MiB granules
@@ -181,6 +182,7 @@ struct mg_primitive {
     float *d_mean32 = nullptr;   // [RT*16] f32 mean' in padded-row order (zero padded; zero on the root rows as well, which
                                  // therefore hold E'.s alone: the delta of the mean/delta split)
     double *d_mean = nullptr;    // (R) f64
+    double *d_knots = nullptr;   // (NB + 4) f64: the spatial knot vector (basis rows computed on the device: mg_frames_at_kernel)
     int32_t RRT = 0;             // 16-row tiles of the root-row space
     // GMM device constants
     double *d_gPpack = nullptr;  // [K][JT][KK][64]: v_mfma_f64_16x16x4_f64 B fragments of P_k (L <= 64)
@@ -210,6 +212,7 @@ struct mg_constraint_set {
     double *d_Wpack = nullptr;  // [RT][KK][64] MFMA B fragments of W (n_components <= 64), RT = ceil(rows / 16)
     double *d_bpad = nullptr;   // [RT*16] bias, zero padded
     int32_t RT = 0;
+    int32_t rows = 0;           // rows of W in use (RT = ceil(rows / 16))
     std::vector<mg_keyframe_constraint> structure;   // what mg_constraint_set_update must find unchanged
     int32_t align_joint = -1;   // -1: local mode
     double *d_pose = nullptr;   // pose constraints' tables (MG_POSE_* layout), NULL if there are none
@@ -236,6 +239,9 @@ int mg_cs_max_tiles(int KK);   // row tiles of a chunk window the chunk-stationa
 int mg_launch_frames_direct(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, void *out, bool out_f64);
 int mg_launch_spline_eval(mg_primitive *p, const mg_time_grid *g, const double *coeffs, int64_t n, double *out);
 int mg_launch_gmm_logp(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt);
+bool mg_objective_can_fuse(const mg_primitive *p, const mg_constraint_set *cs);
+int mg_launch_objective(mg_primitive *p, const mg_constraint_set *cs, const void *x, int xdt, int64_t B, int64_t ld, double error_scale,
+                        double quality_scale, double *logp_out, double *err_out, double *obj_out);
 #define MG_SAMPLE_ARG_K 16   // mixtures up to this size pass their prefix sums to the sampler as a kernel argument
 int mg_launch_gmm_sample(mg_primitive *p, int64_t n, const int64_t *cum_dev, const int64_t *cum_host, int64_t n_tiles, uint64_t seed, void *x, int xdt, int64_t ld, int32_t *comp,
                          int64_t tile0, int64_t row_lo, int64_t row_hi);
@@ -247,6 +253,10 @@ int mg_launch_gather_winner(mg_context *ctx, const void *x, int xdt, int64_t ld,
 int mg_launch_argmin_gather(mg_context *ctx, const void *v, int dt, int64_t n, void *result_dev, const void *x, int xdt, int64_t ld, int L, int64_t index_offset = 0);
 int mg_launch_gmm_jac(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, double *out);
 int mg_launch_time_function(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double *out);
+int mg_launch_timewarp(mg_primitive *p, const void *gamma, int gdt, int64_t B, int64_t ld, double speed, double *times, int32_t *lens, int32_t t_cap,
+                       double *canonical_out);   // mg_timewarp.hip
+int mg_launch_frames_at(mg_primitive *p, const void *lat, int ldt, int64_t B, int64_t ld, const double *times, const int32_t *lens, int32_t t_cap,
+                        void *out, int odt);
 int mg_launch_argmin(mg_context *ctx, const void *v, int dt, int64_t n, void *out_dev);
 int mg_launch_joint_positions(mg_context *ctx, const double *frames, const double *table, int64_t N, int D, int J, double *out);
 int mg_setup_kernel_attributes(mg_context *ctx);

@@ -148,13 +148,17 @@ __device__ __forceinline__ mg_align2d mg_candidate_alignment(const mg_score_args
     return t;
 }
 
-template <typename ChannelFn>
+// ROOT_ONLY: the set holds root position / 2-D direction constraints only (the caller has checked): the other kinds' code -- and
+// the registers their forward-kinematics chains want -- stay out of a kernel that has none to spare (the optimiser's objective
+// inside the LDS-resident mixture kernel, four waves per SIMD).  The two kinds compiled in are the same statements: the same bits.
+template <bool ROOT_ONLY = false, typename ChannelFn>
 __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a, int c, ChannelFn channel, int64_t cand = 0) {
     const double *par = a.par + (size_t)c * 8;
     const int type = (int)par[0];
     const int r0 = a.woff[c];
     mg_align2d al = {1.0, 0.0, 0.0, 0.0, 0.0};
     if (a.align) al = mg_candidate_alignment(a, channel, cand);
+    if constexpr (!ROOT_ONLY) {
     if (type == MG_CONSTRAINT_VALUE_POSITION) {   // not an error: the (aligned) root position's component par[2] at the keyframe
         double pj[3] = {channel(r0), channel(r0 + 1), channel(r0 + 2)};
         if (a.align) {
@@ -274,6 +278,7 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
                            (sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) * sqrt(par[2] * par[2] + par[3] * par[3] + par[4] * par[4]));
         return par[1] * acos(fmin(1.0, fmax(dot, -1.0)));
     }
+    }   // !ROOT_ONLY
     if (type == MG_CONSTRAINT_POSITION) {
         // _point_distance: axes whose target is NaN (the reference's None) are ignored
         double ds = 0.0;

@@ -317,10 +317,10 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     }
     const size_t lds = (size_t)(p->L + t->rows) * MG_TRAJ_BLOCK * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_score_trajectory: %d basis functions x %d components do not fit LDS", p->NB, p->L); return MG_ERR_UNSUPPORTED; }
-    static bool attr_set = false;   // once per process, not per launch
-    if (lds > 48 * 1024 && !attr_set) {
+    // (a property of kernel AND device: once per context, not per process -- ADVICE r3)
+    if (lds > 48 * 1024 && !(p->ctx->attr_traj & 1u)) {
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        p->ctx->attr_traj |= 1u;
     }
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
     hipLaunchKernelGGL(mg_trajectory_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);

@@ -172,13 +172,32 @@ class HipMotionPrimitive(object):
         return np.array(savgol_filter(time_function, 15, 3))
 
     def back_project_time_function(self, gamma, speed=1.0):
-        """The time-warp t'(t) of a sample (motion_primitive.py:268-287): canonical time function on the device,
-        its inversion on the host."""
-        canonical_time_function = self._back_transform_gamma_to_canonical_time_function(gamma)
-        sample_time_function = self._invert_canonical_to_sample_time_function(canonical_time_function, speed)
+        """The time-warp t'(t) of a sample (motion_primitive.py:268-287), canonical time function and its inversion on the
+        device (mg_time_function_sample; the host route with scipy, _invert_canonical_to_sample_time_function, stays for
+        callers that hold a canonical time function of their own)."""
+        times, lens = self._prim.time_function_sample(np.asarray(gamma, dtype=np.float64).reshape(1, -1), speed)
+        sample_time_function = times[0, :lens[0]].copy()
         if self.smooth_time_parameters:
             return self._smooth_time_function(sample_time_function)
         return sample_time_function
+
+    def back_project_warped_batch(self, samples, speed=1.0, dtype=np.float64):
+        """back_project(s, use_time_parameters=True).get_motion_vector() for every row of `samples` (n, n_spatial + n_time
+        latents) in two launches -- what GraphWalk.convert_graph_walk_to_quaternion_frames does step by step
+        (graph_walk.py:154-176).  Returns (frames (n, t_max, D) padded with NaN, lengths (n), times (n, t_max) padded with NaN).
+        With smooth_time_parameters the time functions pass through the host (savgol_filter, as in the reference)."""
+        S = np.ascontiguousarray(np.asarray(samples, dtype=np.float64))
+        n_s = self.s_pca["n_components"]
+        if not self.has_time_parameters:
+            raise ValueError("the primitive has no time parameters")
+        times, lens = self._prim.time_function_sample(S[:, n_s:], speed)
+        t_max = int(lens.max()) if len(lens) else 0
+        times = np.ascontiguousarray(times[:, :t_max])
+        if self.smooth_time_parameters:
+            for b in range(len(S)):
+                times[b, :lens[b]] = self._smooth_time_function(times[b, :lens[b]])
+        frames = self._prim.back_project_frames_at(S[:, :n_s], times, lens, dtype=dtype)
+        return frames, lens, times
 
     # ---- batched hot path ------------------------------------------------------------------------
     def back_project_frames_batch(self, samples, times=None):

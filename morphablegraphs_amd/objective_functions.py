@@ -97,6 +97,26 @@ def log_likelihood_jac(s, gmm_or_primitive):
     return jac[0] if single else jac
 
 
+def _objective_in_one_launch(prim, mp_constraints, S, prev_frames, error_scale, quality_scale):
+    """(objective, constraint errors) from mg_objective_error_and_naturalness -- the mixture kernel scores the keyframe constraints
+    on the latent tile it holds: one launch, the latents read once -- for the sets that kernel carries (root position / 2-D
+    direction constraints, local or aligned through the root joint); None for everything else (the caller then makes the two
+    calls, which give the same numbers)."""
+    clist = constraints_to_device_form(_constraint_list(mp_constraints))
+    if len(clist) == 0 or any(c.get("type") not in ("position", "direction") for c in clist):
+        return None
+    skeleton = getattr(mp_constraints, "hip_skeleton", None)
+    alignment = alignment_from_prev_frames(prev_frames, mp_constraints, skeleton)
+    cset = cached_constraint_set(prim, clist, skeleton, alignment)
+    try:
+        obj, err, _ = prim.objective(cset, np.asarray(S, dtype=np.float64), error_scale, quality_scale)
+    except _capi.MGError as e:
+        if e.status != -4:        # MG_ERR_UNSUPPORTED: a shape the one-launch kernel does not carry
+            raise
+        return None
+    return obj, err
+
+
 def obj_spatial_error_sum_and_naturalness(s, data):
     """objective_functions.py:162-184: error_scale * spatial_error + quality_scale * (-log p(s)).
     (The reference function computes this value and then falls off its end without `return`, so scipy receives
@@ -104,9 +124,13 @@ def obj_spatial_error_sum_and_naturalness(s, data):
     motion_primitive, mp_constraints, prev_frames, error_scale, quality_scale = data[0], data[1], data[2], data[-3], data[-2]
     S, single = _batch(s)
     prim = _prim_of(motion_primitive)
-    spatial = _residuals(prim, mp_constraints, S, prev_frames, sums=True)
+    fused = _objective_in_one_launch(prim, mp_constraints, S, prev_frames, error_scale, quality_scale)
+    if fused is not None:
+        err, spatial = fused
+    else:
+        spatial = _residuals(prim, mp_constraints, S, prev_frames, sums=True)
+        err = error_scale * spatial + (-prim.gmm_log_prob(S.astype(np.float64))) * quality_scale
     _note(mp_constraints, float(spatial[-1]) if len(spatial) else 0.0, len(S))
-    err = error_scale * spatial + (-prim.gmm_log_prob(S.astype(np.float64))) * quality_scale
     return float(err[0]) if single else err
 
 

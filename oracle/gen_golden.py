@@ -96,6 +96,29 @@ def run_time_case(ref, name, data, n_samples, seed):
     frames = np.stack([sp.get_motion_vector() for sp in splines])
     ctf = np.stack([mp._back_transform_gamma_to_canonical_time_function(s[n_s:]) for s in S])
     gmm = mp.gaussian_mixture_model
+    # The time-warped route, back_project(s, True): the reference hands np.linspace the FLOAT round(t(F-2)) * (1 / speed)
+    # (motion_primitive.py:313-314), which NumPy >= 1.18 refuses; NumPy up to 1.17 truncated it.  The reference's own lines run
+    # here unmodified with that behaviour of linspace restored for the duration of the calls.
+    real_linspace = np.linspace
+    np.linspace = lambda start, stop, num=50, **kw: real_linspace(start, stop, int(num), **kw)
+    try:
+        warped = {}
+        for speed in (1.0, 1.6):
+            stf = [mp._invert_canonical_to_sample_time_function(c, speed) for c in ctf]
+            fr = [mp.back_project(s, use_time_parameters=True, speed=speed).get_motion_vector() for s in S]
+            lens = np.array([len(t) for t in stf], dtype=np.int64)
+            assert all(len(f) == n for f, n in zip(fr, lens))
+            pad_t = np.full((len(S), lens.max()), np.nan)
+            pad_f = np.full((len(S), lens.max(), frames.shape[2]), np.nan)
+            for b in range(len(S)):
+                pad_t[b, :lens[b]] = stf[b]
+                pad_f[b, :lens[b]] = fr[b]
+            tag = "speed%02d" % int(round(10 * speed))
+            warped["sample_time_functions_" + tag] = pad_t
+            warped["warped_frames_" + tag] = pad_f
+            warped["warped_lengths_" + tag] = lens
+    finally:
+        np.linspace = real_linspace
     out = dict(S=S, frames=frames, canonical_time_functions=ctf, mean_temporal=mp._mean_temporal(), logp_S=gmm.score_samples(S),
                precisions_cholesky=gmm.precisions_cholesky_, seed=np.int64(seed), digest=np.array(model_digest(data)),
                n_canonical_frames=np.int64(mp.get_n_canonical_frames()), n_spatial_components=np.int64(n_s),
@@ -107,6 +130,7 @@ def run_time_case(ref, name, data, n_samples, seed):
     out["model_n_basis"] = np.int64(data["n_basis_spatial"])
     out["model_n_dim"] = np.int64(data["n_dim_spatial"])
     out["model_n_basis_time"] = np.int64(data["n_basis_time"])
+    out.update(warped)
     path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
@@ -146,6 +170,11 @@ def run_trajectory_spline_case(name):
 def main():
     ref = import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "time_model":   # only this fixture (the archives carry time stamps: untouched ones stay byte-identical)
+        timed = synthetic.make_primitive(seed=13, n_components=12, n_frames=60, n_dim=15, n_gmm=3, name="timed",
+                                         n_time_components=3, n_basis_time=8)
+        run_time_case(ref, "time_model", timed, 9, 41)
+        return
     # (i) tiny model, non-unit translation maxima, times incl. out-of-range (extrapolated) ones
     tiny = synthetic.make_tiny_primitive(seed=1, translation_maxima=(1.5, 2.0, 0.5))
     run_case(ref, "tiny_tm", tiny, 5, [0.0, 0.25, 5.5, 10.999, 11.0, 11.5, 12.0, -0.5], 3, True, n_score=16)

@@ -722,6 +722,27 @@ class OraclePrimitive(object):
             out.append(acc)
         return np.array(out) - 1.0
 
+    # motion_primitive.py:304-319
+    def invert_canonical_to_sample_time_function(self, canonical_time_function, speed=1.0):
+        """_invert_canonical_to_sample_time_function: t'(t) from t(t') -- scipy's interpolating cubic through (t(t'), t')
+        (splrep, k = 3, no smoothing) evaluated at linspace(1, t(F-2), num), 0 in front, F - 1 behind.  num = int(round(t(F-2)) *
+        (1 / speed)): the reference passes the float, which NumPy >= 1.18 refuses; up to 1.17 it was truncated
+        (tests/golden/time_model.npz holds the reference's own output with that behaviour restored: oracle/gen_golden.py)."""
+        from scipy.interpolate import splev as si_splev, splrep
+        F = self.n_canonical_frames
+        ctf = np.asarray(canonical_time_function, dtype=np.float64)
+        inverse = splrep(ctf, np.arange(F), w=None, k=B_SPLINE_DEGREE)
+        num = int(np.round(ctf[-2]) * (1.0 / speed))
+        inner = si_splev(np.linspace(1, stop=ctf[-2], num=num), inverse)
+        return np.concatenate(([0.0], inner, [F - 1.0]))
+
+    # motion_primitive.py:206-234 with use_time_parameters=True, + motion_spline.py:71-86
+    def back_project_warped_frames(self, s, speed=1.0):
+        s = np.asarray(s, dtype=np.float64)
+        ctf = self.back_transform_gamma_to_canonical_time_function(s[self.n_components:self.n_components + self.n_time_components])
+        tf = self.invert_canonical_to_sample_time_function(ctf, speed)
+        return tf, spline_frames(self.knots, self.back_project_spatial_coeffs(s[:self.n_components]), tf)
+
     # motion_primitive.py:236-256
     def back_project_spatial_coeffs(self, alpha):
         coefs = np.dot(self.eigen_vectors, np.asarray(alpha, dtype=np.float64))

@@ -1005,6 +1005,59 @@ def test_model_with_time_latents_end_to_end():
     assert abs(res[0] - err) < 1e-4 * max(1.0, abs(err))
 
 
+def test_time_warped_synthesis_of_a_batch_against_the_reference():
+    """back_project(s, use_time_parameters=True).get_motion_vector() for a batch on the device: the spline's time
+    functions (mg_time_function_sample: canonical time function, not-a-knot inversion, sampling) and the frames at every
+    candidate's own times (mg_back_project_frames_at), against vectors the REFERENCE's own lines produced
+    (tests/golden/time_model.npz: oracle/gen_golden.py runs motion_primitive.py:206-234,268-319 with np.linspace truncating its
+    float sample count as NumPy <= 1.17 did), at speed 1 and 1.6, for float64 and float32 output; and against the host route."""
+    from conftest import golden_model
+    data, g = golden_model("time_model")
+    mp = HipMotionPrimitive(None)
+    mp._initialize_from_json(data)
+    F, n_s = mp.n_canonical_frames, int(g["n_spatial_components"])
+    S = g["S"]
+    for tag, speed in (("speed10", 1.0), ("speed16", 1.6)):
+        want_t, want_f, want_n = g["sample_time_functions_" + tag], g["warped_frames_" + tag], g["warped_lengths_" + tag]
+        frames, lens, times = mp.back_project_warped_batch(S, speed)
+        np.testing.assert_array_equal(lens, want_n)                    # the sample counts: exact
+        scale = max(1.0, np.nanmax(np.abs(want_f)))
+        for b in range(len(S)):
+            n = int(lens[b])
+            np.testing.assert_allclose(times[b, :n], want_t[b, :n], rtol=0, atol=1e-11 * F)        # FITPACK's B-spline form vs second derivatives
+            assert times[b, 0] == 0.0 and times[b, n - 1] == F - 1 and np.all(np.isnan(times[b, n:]))
+            np.testing.assert_allclose(frames[b, :n], want_f[b, :n], rtol=0, atol=4e-9 * scale)    # 1e-11 F in time x the frames' slope
+            assert np.all(np.isnan(frames[b, n:]))
+            # given the reference's times the frames are the float64 kernels' frames: 4e-12 scale
+            exact = mp._prim.back_project_frames_at(S[b:b + 1, :n_s], want_t[b:b + 1, :n], None)
+            np.testing.assert_allclose(exact[0], want_f[b, :n], rtol=0, atol=4e-12 * scale)
+            grid = mp._prim.time_grid(want_t[b, :n])
+            np.testing.assert_array_equal(exact[0], mp._prim.back_project_frames_f64(S[b:b + 1, :n_s], grid)[0])     # the same arithmetic
+            grid.close()
+            # the adaptor's single-sample calls
+            np.testing.assert_array_equal(mp.back_project_time_function(S[b, n_s:], speed), times[b, :n])
+            host = mp._invert_canonical_to_sample_time_function(g["canonical_time_functions"][b], speed)
+            np.testing.assert_allclose(times[b, :n], host, rtol=0, atol=1e-11 * F)
+        f32, _, _ = mp.back_project_warped_batch(S, speed, dtype=np.float32)
+        ok = ~np.isnan(frames)
+        np.testing.assert_array_equal(f32[ok], frames[ok].astype(np.float32))
+    warped = mp.back_project(S[0], use_time_parameters=True)
+    np.testing.assert_allclose(warped.get_motion_vector(), g["warped_frames_speed10"][0, :g["warped_lengths_speed10"][0]], rtol=0, atol=4e-9 * scale)
+    # a larger batch of mixture draws: monotone maps with the reference's end points, every row of its own length
+    np.random.seed(3)
+    big = mp.sample_low_dimensional_vector(3000)
+    frames, lens, times = mp.back_project_warped_batch(big, 1.0)
+    assert lens.min() >= 2 and len(set(lens.tolist())) > 3 and frames.shape == (3000, lens.max(), mp.s_pca["n_dim"])
+    for b in (0, 1, 777, 2999):
+        n = int(lens[b])
+        tf = times[b, :n]
+        assert tf[0] == 0 and tf[-1] == F - 1 and np.all(np.diff(tf[1:-1]) > 0)
+        op_t, op_f = None, None
+    # rows too short for a candidate's samples are reported, not overrun
+    t2, l2 = mp._prim.time_function_sample(big[:4, n_s:], 1.0, t_cap=8)
+    assert np.all(l2 < 0) and np.all(-l2 == lens[:4])
+
+
 def _path_following_model():
     """The 'walk' shape with a root path a path-following constraint meets in practice: a gentle curve the candidates
     vary around by a few units (the plain synthetic model's root coefficients are noise of amplitude 100)."""

@@ -210,3 +210,65 @@ def test_time_objective_for_batches():
         assert abs(got[b] - (2.0 * err - 0.3 * ll)) <= 1e-8 * max(1.0, abs(got[b])), (b, got[b], 2.0 * err - 0.3 * ll)
     assert len(tc.get_initial_guess(walk)) == 2 * n_t
     node.motion_primitive._prim.close()
+
+
+@pytest.mark.parametrize("n", [17, 4099, 40000])
+def test_objective_in_one_launch_is_bit_identical_to_the_two_calls(n):
+    """mg_objective_error_and_naturalness: the LDS-resident mixture kernel scores the keyframe constraints on
+    the latent tile it holds and writes error_scale * error + quality_scale * (-log p).  The three outputs must be the bits of
+    mg_score_constraints, mg_gmm_log_prob (float64) and of NumPy's array arithmetic on them -- root and forward-kinematics
+    constraints, local and aligned to a previous frame, float32 and float64 latents, ragged last tile."""
+    from morphablegraphs_amd import _capi, synthetic
+    from morphablegraphs_amd.candidate_scoring import alignment_from_prev_frames
+    ctx = _capi.Context(0)
+    data = synthetic.make_walk_primitive(seed=0)
+    prim = _capi.Primitive(ctx, data)
+    joints, animated = synthetic.make_skeleton(19)
+    sk = _capi.Skeleton(joints, animated)
+    cons_root = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+                 {"type": "direction", "t": 155.0, "weight": 1.0, "target": [0.5, 1.0]}]
+    cons_fk = cons_root + [{"type": "joint_position", "joint": "RightHand", "t": 77.5, "weight": 2.0, "target": [12.0, 90.0, 4.0]}]
+    prev = np.random.default_rng(1).standard_normal((3, 79))
+    prev[:, 3:7] = [1.0, 0.1, 0.0, 0.05]
+    rng = np.random.default_rng(n)
+    for clist, skeleton, alignment in ((cons_root, None, None), (cons_fk, sk, None), (cons_root, None, sk.alignment_to(prev[-1]))):
+        cset = _capi.ConstraintSet(prim, clist, skeleton, alignment)
+        if skeleton is not None:      # joint constraints: not on the one-launch kernel (it has no registers for the chains) -- it must say so
+            with pytest.raises(_capi.MGError) as e:
+                prim.objective(cset, np.zeros((4, 40)), 0.75, 1.25)
+            assert e.value.status == -4
+            cset.close()
+            continue
+        for dtype in (np.float32, np.float64):
+            S = (1.5 * rng.standard_normal((n, 40))).astype(dtype)
+            obj, err, lp = prim.objective(cset, S, 0.75, 1.25)
+            err2 = prim.score_constraints(cset, S)
+            lp2 = prim.gmm_log_prob(S.astype(np.float64) if dtype == np.float64 else S, dtype=np.float64)
+            np.testing.assert_array_equal(err.view(np.uint64), err2.view(np.uint64))
+            np.testing.assert_array_equal(lp.view(np.uint64), lp2.view(np.uint64))
+            np.testing.assert_array_equal(obj.view(np.uint64), (0.75 * err2 + (-lp2) * 1.25).view(np.uint64))
+        cset.close()
+    prim.close()
+    ctx.close()
+
+
+def test_naturalness_objective_takes_the_one_launch_route_and_agrees_with_the_two_calls(monkeypatch):
+    """obj_spatial_error_sum_and_naturalness uses mg_objective_error_and_naturalness for root constraint sets; with that route
+    switched off it makes the two calls -- the same values (the sum over constraints is NumPy's there: 1e-12)."""
+    from morphablegraphs_amd import objective_functions as of, synthetic
+    from morphablegraphs_amd.motion_primitive import HipMotionPrimitive
+    prim = HipMotionPrimitive(None)
+    prim._initialize_from_json(synthetic.make_walk_primitive(seed=0))
+    cons = [{"type": "position", "t": 155.0, "weight": 1.0, "target": [40.0, None, -30.0]},
+            {"type": "direction", "t": 100.0, "weight": 0.5, "target": [0.5, 1.0]}]
+    S = 1.3 * np.random.default_rng(2).standard_normal((3000, 40))
+    data = (prim, cons, None, 0.8, 1.7, 1.0)      # (..., error_scale, quality_scale, init_error_sum): the objective reads data[-3], data[-2]
+    calls = []
+    real = of._objective_in_one_launch
+    monkeypatch.setattr(of, "_objective_in_one_launch", lambda *a: calls.append(1) or real(*a))
+    a = of.obj_spatial_error_sum_and_naturalness(S, data)
+    assert calls and real(of._prim_of(prim), cons, S, None, 0.8, 1.7) is not None       # the one-launch route was taken
+    monkeypatch.setattr(of, "_objective_in_one_launch", lambda *a: None)
+    b = of.obj_spatial_error_sum_and_naturalness(S, data)
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+    assert isinstance(of.obj_spatial_error_sum_and_naturalness(S[0], data), float)

@@ -273,6 +273,15 @@ def test_time_model_fixture():
     np.random.seed(int(g["seed"]))
     np.testing.assert_allclose(prim.sample_low_dimensional_vector(len(g["S"])), g["S"], rtol=1e-12, atol=1e-12)
     np.testing.assert_array_equal(g["low_dimensional_parameters"], g["S"][0])      # the spline keeps the full vector
+    # the time-warped route (motion_primitive.py:206-234 with use_time_parameters=True, :268-319): vectors made by the reference's
+    # own lines with np.linspace truncating its float sample count as NumPy <= 1.17 did (oracle/gen_golden.py)
+    for tag, speed in (("speed10", 1.0), ("speed16", 1.6)):
+        for b, s in enumerate(g["S"]):
+            tf, fr = prim.back_project_warped_frames(s, speed)
+            n = int(g["warped_lengths_" + tag][b])
+            assert len(tf) == n
+            np.testing.assert_allclose(tf, g["sample_time_functions_" + tag][b, :n], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(fr, g["warped_frames_" + tag][b, :n], rtol=0, atol=2e-12 * max(1.0, np.nanmax(np.abs(fr))))
 
 
 def test_trajectory_spline_against_the_reference():

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../morphablegraphs_amd/csrc"
 name=$1; shift
 mkdir -p ../../build/$name
 pids=""
-for f in mg_host mg_frames mg_frames_cs mg_frames_ws mg_frames_direct mg_gmm mg_score mg_placement mg_trajectory mg_options mg_frame_constraints; do
+for f in mg_host mg_frames mg_frames_cs mg_frames_ws mg_frames_direct mg_gmm mg_score mg_placement mg_trajectory mg_options mg_frame_constraints mg_timewarp; do
     extra=""; case "$f" in mg_frames_cs|mg_frames_ws) extra=-DMG_ONLY_KK10;; esac
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wall -Wno-unused-result $extra "$@" \
         -c -o ../../build/$name/$f.o $f.hip &
