@@ -68,14 +68,16 @@ def algorithmic_bytes(B):
 def self_launch(args, argv):
     """`python bench.py --gpus N` typed as is: N child processes (one rank per GPU), started before this process has
     touched a GPU and never exec'ed into; rank 0's stdout is forwarded, the exit code is the worst child's."""
+    import shutil
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    rdv_dir = tempfile.mkdtemp(prefix="mg_bench_rdv_")      # 0700, a name nobody can guess: the ranks' rendezvous files
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
-        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus), "MG_RDV_DIR": rdv_dir,
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -87,12 +89,21 @@ def self_launch(args, argv):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     deadline = time.time() + float(os.environ.get("MG_BENCH_LAUNCH_TIMEOUT", "1500"))
+    # the communicator's set-up is bounded on its own: every rank drops a file once it is through mg_dist_init (a collective: a
+    # rank whose peer never arrives would sit in it until the run's deadline); ranks missing after MG_BENCH_RDV_TIMEOUT seconds end
+    # the launch -- fresh children or an exit, never a re-exec of a process that touched the GPU
+    rdv_deadline = time.time() + float(os.environ.get("MG_BENCH_RDV_TIMEOUT", "240"))
+    joined = args.gpus == 1 or args.dry_run
     failed = None
     try:
         while any(p.poll() is None for p in procs):
             bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-            if bad or time.time() > deadline:
-                failed = ("rank %d exited with %d" % (bad[0], procs[bad[0]].returncode)) if bad else "timed out"
+            if not joined:
+                joined = all(os.path.exists(os.path.join(rdv_dir, "joined.%d" % r)) for r in range(args.gpus))
+            if bad or time.time() > deadline or (not joined and time.time() > rdv_deadline):
+                missing = [r for r in range(args.gpus) if not os.path.exists(os.path.join(rdv_dir, "joined.%d" % r))]
+                failed = ("rank %d exited with %d" % (bad[0], procs[bad[0]].returncode)) if bad else \
+                    ("timed out" if joined else "ranks %s had not joined the communicator after %s s" % (missing, os.environ.get("MG_BENCH_RDV_TIMEOUT", "240")))
                 for p in procs:
                     if p.poll() is None:
                         p.terminate()
@@ -104,11 +115,7 @@ def self_launch(args, argv):
                 break
             time.sleep(0.05)
     finally:
-        for f in glob.glob(os.path.join(tempfile.gettempdir(), "mg_bench_%d_%d.*" % (os.getpid(), port))):   # rendezvous files a dead rank left
-            try:
-                os.remove(f)
-            except OSError:
-                pass
+        shutil.rmtree(rdv_dir, ignore_errors=True)   # the rendezvous files, whatever a dead rank left
     reader.join(10)
     rcs = [p.wait() for p in procs]
     sys.stdout.write(b"".join(c for c in chunks if c).decode("utf-8", "replace"))
@@ -123,7 +130,7 @@ def FileRendezvous(rank, world):
     """How the 128-byte RCCL unique id (and, in a dry run, everything else) travels between the ranks of one node without
     torch: morphablegraphs_amd.distributed.FileRendezvous under a name made of the launcher's pid and the master port."""
     from morphablegraphs_amd.distributed import FileRendezvous as _Rdv
-    return _Rdv(rank, world, base=os.path.join(tempfile.gettempdir(), "mg_bench_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))))
+    return _Rdv(rank, world)     # $MG_RDV_DIR (this launcher's mkdtemp) or, under torch.distributed.run, a private directory named after its pid and port
 
 
 def ensure_built():
@@ -149,6 +156,8 @@ def run_walk(args, rank, local_rank, world):
     dry = args.dry_run
     if dry and os.environ.get("MG_BENCH_DRY_RUN_DIES") == str(rank):   # launcher test: a rank that dies before the rendezvous
         raise SystemExit(3)
+    if world > 1 and os.environ.get("MG_BENCH_STALL_IN_SETUP"):        # launcher test: ranks that never get through the set-up
+        time.sleep(600)
     rdv = FileRendezvous(rank, world) if world > 1 else None
     B = int(args.batch)
     per_cand, consts, bytes_launch = algorithmic_bytes(B)
@@ -226,6 +235,7 @@ def run_walk(args, rank, local_rank, world):
         import torch as _t
         dev_index = local_rank % max(1, _t.cuda.device_count())
     collective_note = None
+    rccl_info = None
     if not use_torch:
         try:
             ctx = _capi.Context(dev_index)
@@ -233,15 +243,19 @@ def run_walk(args, rank, local_rank, world):
             raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback (%s)" % e)
         if world > 1:
             # The library's own RCCL communicator (librccl loaded by libmg_hip, the unique id handed over through the file
-            # rendezvous).  If it cannot be set up -- on ANY rank: the ranks tell each other -- every rank falls back to
-            # torch.distributed's communicator (`--collective torch`) and the line says so; the data path is the same kernels.
+            # rendezvous).  Preflight first (what can fail on one rank alone), then the collective set-up; the ranks tell each other
+            # how it went.  If it cannot be set up on ANY rank the run ends with the reason -- unless --collective-fallback torch
+            # asks for the tensor framework's communicator instead (then every rank switches, and the line says so).
             uid, err = b"", b""
-            if rank == 0:
-                try:
+            try:
+                ctx.dist_preflight()
+                if rank == 0:
                     uid = ctx.dist_unique_id()
-                except Exception as e:   # noqa: BLE001 -- whatever went wrong, the other ranks must hear of it
-                    err = ("rank 0: mg_dist_unique_id: %s" % e).encode()[:300]
-            uid, err0 = rdv.all_gather(uid)[0], rdv.all_gather(err)[0]
+            except Exception as e:   # noqa: BLE001 -- whatever went wrong, the other ranks must hear of it
+                err = ("rank %d: %s" % (rank, e)).encode()[:300]
+            errs = [e for e in rdv.all_gather(err) if e]
+            uid, err0 = rdv.all_gather(uid)[0], (errs[0] if errs else b"")
+            err = b""
             if not err0:
                 try:
                     ctx.dist_init(rank, world, uid)
@@ -255,7 +269,12 @@ def run_walk(args, rank, local_rank, world):
                     except Exception:   # noqa: BLE001
                         pass
             if err0:
-                collective_note = "mg_dist_* could not be set up (%s): torch.distributed's communicator instead" % err0.decode(errors="replace")
+                collective_note = "mg_dist_* could not be set up (%s)" % err0.decode(errors="replace")
+                if args.collective_fallback != "torch":
+                    if rank == 0:
+                        print("bench.py: %s; no fallback was asked for (--collective-fallback torch)" % collective_note, file=sys.stderr)
+                    raise SystemExit(4)
+                collective_note += ": torch.distributed's communicator instead (--collective-fallback torch)"
                 if rank == 0:
                     print("bench.py: " + collective_note, file=sys.stderr)
                 ctx.close()
@@ -263,6 +282,10 @@ def run_walk(args, rank, local_rank, world):
                 import torch
                 import torch.distributed as dist
                 n_dev = torch.cuda.device_count()
+            else:
+                rccl_info = ctx.dist_info()
+    if world > 1 and os.environ.get("MG_RDV_DIR"):      # tell the launcher's watchdog: this rank is through the set-up
+        open(os.path.join(os.environ["MG_RDV_DIR"], "joined.%d" % rank), "w").close()
     if use_torch:
         torch.cuda.set_device(dev_index % n_dev)
         stream = torch.cuda.Stream(device=dev_index % n_dev)
@@ -385,6 +408,17 @@ def run_walk(args, rank, local_rank, world):
         ctx.profile_enable(False)
     elapsed = max_over_ranks(elapsed)
     last = (step_no[0] - 1) & 1
+    gather_us = None
+    if world > 1 and not use_torch:
+        # the collective alone: 200 all-gathers of the step's size back to back on the kernels' stream, nothing else running
+        for _ in range(20):
+            ctx.dist_all_gather(logps[0], gathereds[0], B, np.float32)
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(200):
+            ctx.dist_all_gather(logps[0], gathereds[0], B, np.float32)
+        sync()
+        gather_us = max_over_ranks(1e6 * (time.perf_counter() - tg) / 200)
     if world > 1:
         # every rank holds the same global score vector: the graph-walk argmin needs no further exchange
         g_host = t_gath[last].float().cpu().numpy() if use_torch else ctx.download(gathereds[last], (world * B,), np.float32)
@@ -420,6 +454,9 @@ def run_walk(args, rank, local_rank, world):
                        "collective": ("all_gather(logp) every step, %s" % ("RCCL through mg_dist_all_gather on the kernels' stream" if not use_torch
                                       else "torch.distributed %s (double-buffered, overlapped)" % backend)) if world > 1 else "none",
                        "collective_fallback": collective_note,
+                       "rccl": ({"ranks_seen_by_rccl": rccl_info["ranks"], "rank0_device": rccl_info["device"],
+                                 "all_gather_alone_us": round(gather_us, 2) if gather_us is not None else None,
+                                 "all_gather_bytes_per_rank": 4 * B} if rccl_info else None),
                        "sharding": "contiguous candidate blocks, constants replicated",
                        "clock_ramp_steps": args.ramp_steps,
                        "output_placement": placement},
@@ -761,6 +798,9 @@ def main():
     ap.add_argument("--config", choices=("walk", "graph", "optimizer"), default="walk",
                     help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective-fallback", choices=("none", "torch"), default="none",
+                    help="N > 1: what to do when the library's own RCCL communicator cannot be set up on some rank: none = end the run with the reason "
+                         "(default), torch = every rank switches to torch.distributed's communicator")
     ap.add_argument("--host-counts", action="store_true", help="--config graph: component counts from numpy.random.multinomial on the host (one call per option) instead of the device draw")
     ap.add_argument("--no-placement-compare", action="store_true", help="skip the steps on a second library buffer and on a foreign hipMalloc after the timed region (profiling runs)")
     ap.add_argument("--no-extra-configs", action="store_true", help="do not attach the graph / optimizer configurations to the default line")

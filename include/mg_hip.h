@@ -327,6 +327,12 @@ int mg_dist_all_gather(mg_context *ctx, const void *local_dev, void *gathered_de
  * that runs the reference's control flow -- hands a step's constraint values, seeds and component counts to the workers */
 int mg_dist_broadcast(mg_context *ctx, void *buf_dev, int64_t bytes, int32_t root);
 int mg_dist_finalize(mg_context *ctx);
+/* mg_dist_preflight: everything about the set-up that can fail on one rank alone (librccl and its symbols, the context's device)
+ * -- call it on every rank and exchange the outcome BEFORE any rank calls mg_dist_init: ncclCommInitRank is a collective, a rank
+ * that enters it alone does not return.  mg_dist_info: the communicator as RCCL reports it, out3 = {rank, ranks, device}
+ * (ncclCommUserRank / ncclCommCount / ncclCommCuDevice; -1 where a query is missing), {-1, 0, -1} without a communicator. */
+int mg_dist_preflight(mg_context *ctx);
+int mg_dist_info(mg_context *ctx, int32_t *out3);
 
 /* ---- primitive -------------------------------------------------------------------
  * Replaces MotionPrimitive._initialize_from_json (reference motion_primitive.py:96-163):

@@ -40,7 +40,7 @@ PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin
 EXPORTED_SYMBOLS = [
     "mg_version", "mg_last_error", "mg_status_string",
     "mg_context_create", "mg_context_destroy", "mg_context_set_stream", "mg_context_set_reserved_cus", "mg_context_set_option", "mg_context_arena_begin", "mg_context_arena_end", "mg_context_arena_bytes", "mg_context_synchronize",
-    "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize",
+    "mg_dist_unique_id", "mg_dist_init", "mg_dist_all_gather", "mg_dist_finalize", "mg_dist_preflight", "mg_dist_info",
     "mg_context_device_info", "mg_device_malloc", "mg_device_malloc_chunked", "mg_device_malloc_placed", "mg_device_probe_placement", "mg_device_placement_info", "mg_device_free", "mg_context_trim_outputs", "mg_context_output_bytes", "mg_memcpy_h2d", "mg_memcpy_d2h",
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_root_mode", "mg_primitive_get_precisions_cholesky",
@@ -230,6 +230,8 @@ def load_library(path=None):
         "mg_dist_init": [vp, i32, i32, vp],
         "mg_dist_all_gather": [vp, vp, vp, i64, i32],
         "mg_dist_finalize": [vp],
+        "mg_dist_preflight": [vp],
+        "mg_dist_info": [vp, C.POINTER(C.c_int32)],
         "mg_context_synchronize": [vp],
         "mg_context_device_info": [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(i64)],
         "mg_device_malloc": [vp, i64, C.POINTER(vp)],
@@ -404,6 +406,16 @@ class Context(object):
 
     def dist_finalize(self):
         _check(self.lib.mg_dist_finalize(self.handle))
+
+    def dist_preflight(self):
+        """librccl loads and the context's device answers (mg_dist_preflight): exchanged between the ranks before mg_dist_init."""
+        _check(self.lib.mg_dist_preflight(self.handle))
+
+    def dist_info(self):
+        """{'rank', 'ranks', 'device'} of the communicator as RCCL reports them (mg_dist_info); ranks 0 without one."""
+        out = (C.c_int32 * 3)()
+        _check(self.lib.mg_dist_info(self.handle, out))
+        return {"rank": int(out[0]), "ranks": int(out[1]), "device": int(out[2])}
 
     def set_stream(self, stream):
         _check(self.lib.mg_context_set_stream(self.handle, C.c_void_p(stream) if stream else None))

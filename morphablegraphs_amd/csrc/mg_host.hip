@@ -230,6 +230,31 @@ extern "C" int mg_dist_unique_id(void *id_out) {
     int nrc = g_rccl.GetUniqueId(id_out);
     return nrc == 0 ? MG_OK : mg_rccl_fail(nrc, "ncclGetUniqueId");
 }
+// What can fail on ONE rank before the collective set-up: librccl and its entry points, the context's device.  A rank tells the
+// others how this went BEFORE any of them enters ncclCommInitRank, where a rank left alone would wait for good.
+extern "C" int mg_dist_preflight(mg_context *ctx) {
+    MG_REQUIRE(ctx != nullptr, "mg_dist_preflight: ctx is NULL");
+    int rc = mg_rccl_load();
+    if (rc != MG_OK) return rc;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MG_OK;
+}
+// The communicator as RCCL itself sees it: out[0] = this rank (ncclCommUserRank), out[1] = ranks (ncclCommCount), out[2] = the
+// device RCCL bound it to (ncclCommCuDevice); -1 where the installed librccl lacks the query.  {-1, 0, -1} without a communicator.
+extern "C" int mg_dist_info(mg_context *ctx, int32_t *out3) {
+    MG_REQUIRE(ctx && out3, "mg_dist_info: NULL argument");
+    out3[0] = -1; out3[1] = 0; out3[2] = -1;
+    if (!ctx->rccl_comm || !g_rccl.lib) return MG_OK;
+    typedef int (*q_fn)(void *, int *);
+    const char *names[3] = {"ncclCommUserRank", "ncclCommCount", "ncclCommCuDevice"};
+    for (int i = 0; i < 3; i++) {
+        q_fn f = (q_fn)dlsym(g_rccl.lib, names[i]);
+        int v = -1;
+        if (f && f(ctx->rccl_comm, &v) == 0) out3[i] = v; else out3[i] = -1;
+    }
+    return MG_OK;
+}
 extern "C" int mg_dist_init(mg_context *ctx, int32_t rank, int32_t n_ranks, const void *id) {
     MG_REQUIRE(ctx && id && n_ranks >= 1 && rank >= 0 && rank < n_ranks, "mg_dist_init: bad arguments");
     MG_REQUIRE(ctx->rccl_comm == nullptr, "mg_dist_init: the context already has a communicator");

@@ -3,13 +3,15 @@
 Candidates are independent units: rank r owns the contiguous block [r*B/N, (r+1)*B/N), the per-primitive
 constants are replicated, and the only exchange is one all-gather of the per-rank scores (RCCL over xGMI
 on GPUs, gloo in the CPU tests) followed by the reference's first-minimum argmin over the GLOBAL index order
-(reference motion_primitive_generator.py:251-257).  Two carriers of the same exchange: torch.distributed (the
-*_scores / *_minloc / sharded_best_candidate functions; plumbing only) and, for hosts without torch, the library's
-own RCCL entry points (mg_all_gather_scores / mg_sharded_best_candidate over a _capi.Context after dist_init).
+(reference motion_primitive_generator.py:251-257).  The carrier is the library's own RCCL entry points
+(mg_all_gather_scores / mg_sharded_best_candidate over a _capi.Context after dist_init; MgCommunicator for the product seam) or,
+for CPU rehearsals and ranks that share a GPU, files (FileCommunicator).  This package imports no tensor framework: the
+framework-collective rehearsal of the same exchange lives with the tests (tests/framework_collective_helpers.py).
 The scores come from the scorer callable (libmg_hip on a GPU box).
 """
+import json
 import os
-import pickle
+import stat
 import tempfile
 import time
 
@@ -35,69 +37,9 @@ def first_min_argmin(values):
     return i, float(w[i])
 
 
-def all_gather_scores(local_scores, n_total, group=None):
-    """All-gather variable-length per-rank score blocks into the global (n_total,) order."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    t = local_scores if isinstance(local_scores, torch.Tensor) else torch.as_tensor(np.asarray(local_scores))
-    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
-    assert t.numel() == sizes[rank], "local block has %d scores, expected %d" % (t.numel(), sizes[rank])
-    m = max(sizes) if sizes else 0
-    padded = torch.full((m,), float("inf"), dtype=t.dtype, device=t.device)
-    padded[: t.numel()] = t
-    gathered = torch.empty((world * m,), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(gathered, padded, group=group)
-    parts = [gathered[r * m: r * m + sizes[r]] for r in range(world)]
-    return torch.cat(parts) if parts else gathered
-
-
-def all_gather_minloc(local_index, local_value, offset, group=None):
-    """The light exchange: every rank contributes its own first minimum as (global index, value), 16 bytes, and
-    every rank picks the smallest value, ties to the smaller global index -- the same winner as the first-minimum
-    argmin over the gathered score vector.  A rank with nothing to offer sends (inf, its offset)."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    mine = torch.tensor([float(local_value), float(offset + local_index)], dtype=torch.float64)
-    if dist.get_backend(group) == "nccl":
-        mine = mine.cuda()
-    everyone = torch.empty((world * 2,), dtype=torch.float64, device=mine.device)
-    dist.all_gather_into_tensor(everyone, mine, group=group)
-    pairs = everyone.cpu().numpy().reshape(world, 2)
-    best_v, best_i = float("inf"), None
-    for v, i in pairs:                      # ranks in order = global index order: strict '<' keeps the first
-        if v < best_v:
-            best_v, best_i = float(v), int(i)
-    return (0, float("inf")) if best_i is None else (best_i, best_v)
-
-
-def sharded_best_candidate(samples, scorer, group=None, exchange="scores"):
-    """Every rank holds the same `samples` (n, L); each scores its block with `scorer(block) -> (len(block),)`.
-    exchange="scores": the scores are all-gathered and every rank returns the same (best_index, min_error,
-    all_scores); exchange="minloc": only each rank's (index, value) pair travels and all_scores is None."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    n = len(samples)
-    b, e = shard_range(n, rank, world)
-    local = scorer(samples[b:e])
-    if exchange == "minloc":
-        li, lv = first_min_argmin(local.detach().cpu().numpy() if isinstance(local, torch.Tensor) else local)
-        idx, val = all_gather_minloc(li, lv, b, group)
-        return idx, val, None
-    if not isinstance(local, torch.Tensor):
-        local = torch.as_tensor(np.asarray(local, dtype=np.float64))
-    scores = all_gather_scores(local, n, group)
-    idx, val = first_min_argmin(scores.detach().cpu().numpy())
-    return idx, val, scores
-
-
 def mg_all_gather_scores(ctx, local_scores, n_total, rank, world, dtype=np.float64):
     """The all-gather of per-rank score blocks through mg_dist_all_gather (RCCL loaded by libmg_hip.so, communicator
-    made by ctx.dist_init): no torch anywhere.  Blocks of different lengths are padded with +inf to the longest."""
+    made by ctx.dist_init): no tensor framework anywhere.  Blocks of different lengths are padded with +inf to the longest."""
     local = np.ascontiguousarray(local_scores, dtype=dtype)
     sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
     assert local.size == sizes[rank], "local block has %d scores, expected %d" % (local.size, sizes[rank])
@@ -118,7 +60,7 @@ def mg_all_gather_scores(ctx, local_scores, n_total, rank, world, dtype=np.float
 
 
 def mg_sharded_best_candidate(ctx, samples, scorer, rank, world):
-    """sharded_best_candidate without torch: every rank scores its contiguous block with `scorer(block)` and the
+    """The sharded argmin on the library's own collective: every rank scores its contiguous block with `scorer(block)` and the
     blocks travel through mg_all_gather_scores; returns the same (best_index, min_error, all_scores) on every rank."""
     n = len(samples)
     b, e = shard_range(n, rank, world)
@@ -142,16 +84,38 @@ def mg_sharded_best_candidate(ctx, samples, scorer, rank, world):
 #
 # A communicator is two calls -- broadcast_bytes(payload, root) and all_gather_rows(float64 vector) -- so that the same
 # algorithm runs over RCCL (MgCommunicator: mg_dist_broadcast / mg_dist_all_gather on the context's stream), over files
-# (FileCommunicator: CPU rehearsals and tests, no torch, no GPU) and in one process (LocalCommunicator).
+# (FileCommunicator: CPU rehearsals and tests, no GPU) and in one process (LocalCommunicator).
 # ---------------------------------------------------------------------------------------------------------------------
+def private_rendezvous_dir(name):
+    """A directory only this user can enter, under the temporary directory: created 0700, or -- if it exists -- checked to belong
+    to this user and to be closed to everybody else (another local user cannot plant files the ranks would read).  The ranks
+    of a run share it by NAME (launcher's pid + master port); a launcher creates it with tempfile.mkdtemp and hands the path
+    down (MG_RDV_DIR)."""
+    path = os.path.join(tempfile.gettempdir(), name)
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError("rendezvous directory %s is not a private directory of this user" % path)
+    return path
+
+
 class FileRendezvous(object):
-    """Bytes between the ranks of one node without torch: files under a common base name, written with an atomic rename.
-    Carries the 128-byte RCCL unique id to the ranks (bench.py, worker processes) and, in CPU rehearsals, everything else."""
+    """Bytes between the ranks of one node: files in a PRIVATE directory (0700, owned by this user), written with an
+    atomic rename.  Carries the 128-byte RCCL unique id to the ranks (bench.py, worker processes) and, in CPU rehearsals,
+    everything else.  base: a path prefix inside such a directory (default: $MG_RDV_DIR/rdv, else a directory named after the
+    launcher's pid and the master port); a run's leftovers under the same prefix are removed when rank 0 starts."""
 
     def __init__(self, rank, world, base=None, timeout=300.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
-        self.base = base or os.path.join(tempfile.gettempdir(), "mg_rdv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+        if base is None:
+            d = os.environ.get("MG_RDV_DIR") or private_rendezvous_dir("mg_rdv_%d_%d_%s" % (os.getuid(), os.getppid(), os.environ.get("MASTER_PORT", "0")))
+            base = os.path.join(d, "rdv")
+        self.base = base
         self.seq = 0
+        self.cleanup()      # what a run that ended early left behind under this rank's names (give every run a base of its own)
 
     def _path(self, tag, r):
         return "%s.%s.%d" % (self.base, tag, r)
@@ -236,13 +200,18 @@ def open_communicator(ctx, rank, world, rendezvous=None, transport="rccl"):
         return LocalCommunicator()
     if transport == "files":
         return FileCommunicator(rendezvous)
+    # Preflight: what can fail on ONE rank before the collective set-up (no librccl, an unusable device) is found out and told to
+    # the others first -- a rank that entered ncclCommInitRank alone would sit there for good.
     uid, err = b"", b""
-    if rank == 0:
-        try:
+    try:
+        ctx.dist_preflight()
+        if rank == 0:
             uid = ctx.dist_unique_id()
-        except Exception as e:   # noqa: BLE001 -- whatever it was, the other ranks must hear of it
-            err = ("rank 0: mg_dist_unique_id: %s" % e).encode()[:300]
-    uid, err0 = rendezvous.all_gather(uid)[0], rendezvous.all_gather(err)[0]
+    except Exception as e:   # noqa: BLE001 -- whatever it was, the other ranks must hear of it
+        err = ("rank %d: %s" % (rank, e)).encode()[:300]
+    errs = [e for e in rendezvous.all_gather(err) if e]
+    uid, err0 = rendezvous.all_gather(uid)[0], (errs[0] if errs else b"")
+    err = b""
     comm = None
     if not err0:
         try:
@@ -417,11 +386,64 @@ def _cmd_options_step(comm, nodes, cmd, stepper=None):
 COMMANDS = {"evaluate_samples": _cmd_evaluate_samples, "sample_and_evaluate": _cmd_sample_and_evaluate, "options_step": _cmd_options_step}
 
 
+def encode_command(cmd):
+    """A command as bytes without pickle: an 8-byte length, a JSON document in which every NumPy array (and NumPy scalar) has
+    been replaced by a reference {"__nd__": k} / a plain number, then the arrays' raw bytes back to back.  Nothing a reader
+    executes: a rank that reads a planted file gets a ValueError or wrong numbers, never code."""
+    arrays = []
+
+    def enc(v):
+        if isinstance(v, np.ndarray):
+            a = np.ascontiguousarray(v)
+            arrays.append(a)
+            return {"__nd__": len(arrays) - 1, "dtype": a.dtype.str, "shape": list(a.shape)}
+        if isinstance(v, np.generic):
+            return v.item()
+        if isinstance(v, dict):
+            return {"__dict__": [[enc(k), enc(x)] for k, x in v.items()]} if any(not isinstance(k, str) for k in v) else {k: enc(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [enc(x) for x in v]
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return v
+        raise TypeError("a command may hold numbers, strings, lists, dicts and arrays, not %r" % type(v).__name__)
+    doc = json.dumps(enc(cmd), allow_nan=True).encode("utf-8")
+    return len(doc).to_bytes(8, "little") + doc + b"".join(a.tobytes() for a in arrays)
+
+
+def decode_command(payload):
+    n = int.from_bytes(payload[:8], "little")
+    doc = json.loads(payload[8:8 + n].decode("utf-8"))
+    blob, pos = memoryview(payload)[8 + n:], [0]
+    arrays = {}
+
+    def dec(v):
+        if isinstance(v, dict):
+            if "__nd__" in v:
+                dt = np.dtype(v["dtype"])
+                if dt.hasobject:
+                    raise ValueError("object arrays do not travel")
+                count = int(np.prod(v["shape"])) if v["shape"] else 1
+                k = v["__nd__"]
+                if k not in arrays:                     # arrays are referenced in the order they were appended
+                    if k != len(arrays):
+                        raise ValueError("malformed command")
+                    arrays[k] = np.frombuffer(blob, dtype=dt, count=count, offset=pos[0]).reshape(v["shape"]).copy()
+                    pos[0] += count * dt.itemsize
+                return arrays[k]
+            if "__dict__" in v:
+                return {dec(k): dec(x) for k, x in v["__dict__"]}
+            return {k: dec(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [dec(x) for x in v]
+        return v
+    return dec(doc)
+
+
 def run_command(comm, nodes, cmd=None, **hooks):
     """Rank 0 passes the command; the other ranks pass None and receive it.  Every rank returns the command's result
     (the same on all ranks), or None for {"op": "stop"}."""
-    payload = comm.broadcast_bytes(pickle.dumps(cmd, protocol=4) if comm.rank == 0 else b"", 0)
-    cmd = pickle.loads(payload)
+    payload = comm.broadcast_bytes(encode_command(cmd) if comm.rank == 0 else b"", 0)
+    cmd = decode_command(payload)
     if cmd.get("op") == "stop":
         return None
     return COMMANDS[cmd["op"]](comm, nodes, cmd, **hooks)

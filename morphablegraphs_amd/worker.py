@@ -2,7 +2,7 @@
 
 One process per GPU, started as a FRESH process (before anything has touched a GPU):
 
-    RANK=r WORLD_SIZE=N LOCAL_RANK=r MG_RDV_BASE=/tmp/some_prefix python -m morphablegraphs_amd.worker --zip graph.zip
+    RANK=r WORLD_SIZE=N LOCAL_RANK=r MG_RDV_BASE=$(mktemp -d)/rdv python -m morphablegraphs_amd.worker --zip graph.zip      (a fresh private directory per run)
     ... or --synthetic-graph 16 / --synthetic-walk for the synthetic models of bench.py and the tests
 
 Every rank loads the same model, joins the communicator (the RCCL unique id travels through files under MG_RDV_BASE) and sits
@@ -61,9 +61,12 @@ def main(argv=None):
     nodes = load_nodes(args, ctx)
     if rank == 0:
         raise SystemExit("rank 0 is the driver (the process that runs the graph walk), not a worker")
-    served = distributed.worker_loop(comm, nodes)
-    if hasattr(comm, "close"):
-        comm.close()
+    try:
+        served = distributed.worker_loop(comm, nodes)     # a rank that waits longer than the rendezvous' timeout raises: the process exits non-zero
+    finally:
+        if hasattr(comm, "close"):
+            comm.close()
+        rdv.cleanup()
     print("worker rank %d served %d commands" % (rank, served), flush=True)
     return 0
 

@@ -72,15 +72,36 @@ def test_a_dead_rank_ends_the_launch_instead_of_hanging_it():
 
 
 @pytest.mark.gpu
-def test_collective_set_up_failure_falls_back_to_torch_on_every_rank():
+def test_collective_set_up_failure_ends_the_run_or_falls_back_when_asked():
     """Two ranks on ONE GPU: RCCL refuses the second rank of a device, so mg_dist_init fails -- on both ranks; they tell each other
-    through the file rendezvous, switch to torch.distributed's communicator (gloo here, the CPU rehearsal backend) and the line
-    says so.  What an 8-GPU node would do if the library's own communicator could not be set up there."""
-    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "30", "--warmup", "3", "--ramp-steps", "30", "--no-cpu-baseline",
-                "--no-extra-configs", "--no-placement-compare"], env={"MG_BENCH_OVERSUBSCRIBE": "1", "MG_BENCH_BACKEND": "gloo"}, timeout=400)
+    through the file rendezvous.  By default the run ends with the reason (no tensor framework on the product's path); with
+    --collective-fallback torch every rank switches to torch.distributed's communicator (gloo here, the CPU rehearsal backend)
+    and the line says so.  What an 8-GPU node would do if the library's own communicator could not be set up there."""
+    base = [sys.executable, "bench.py", "--gpus", "2", "--steps", "30", "--warmup", "3", "--ramp-steps", "30", "--no-cpu-baseline",
+            "--no-extra-configs", "--no-placement-compare"]
+    env = dict(os.environ, MG_BENCH_OVERSUBSCRIBE="1", MG_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run(base, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
+    assert p.returncode != 0 and b"could not be set up" in p.stderr and b"--collective-fallback torch" in p.stderr and not _json_lines(p.stdout.decode())
+    out = _run(base + ["--collective-fallback", "torch"], env={"MG_BENCH_OVERSUBSCRIBE": "1", "MG_BENCH_BACKEND": "gloo"}, timeout=400)
     lines = _json_lines(out)
     assert len(lines) == 1
     r = lines[0]
     assert r["n_gpus"] == 2 and r["config"]["global_candidates"] == 2 * r["config"]["candidates_per_gpu"]
     assert "torch.distributed gloo" in r["config"]["collective"] and "mg_dist_init" in r["config"]["collective_fallback"]
     assert r["value"] > 0
+
+
+def test_ranks_that_never_join_the_communicator_end_the_launch(tmp_path):
+    """the launcher bounds the communicator's set-up on its own -- ranks that have not reported 'joined' within
+    MG_BENCH_RDV_TIMEOUT seconds are ended and the launch returns non-zero (here: a stand-in rank that sleeps in its set-up)."""
+    import time
+    e = dict(os.environ, MG_BENCH_RDV_TIMEOUT="3", MG_BENCH_STALL_IN_SETUP="1")
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "0", "--batch", "32", "--no-cpu-baseline"], cwd=ROOT, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and time.time() - t0 < 60, p.stderr.decode()[-500:]
+    assert b"had not joined the communicator" in p.stderr

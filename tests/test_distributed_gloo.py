@@ -25,7 +25,9 @@ def _worker(rank, world, port, n, seed, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from morphablegraphs_amd import distributed, synthetic
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from morphablegraphs_amd import synthetic
+    import framework_collective_helpers as distributed      # the torch.distributed carriers of the exchange live with the tests
     from oracle import c_oracle
     data = synthetic.make_primitive(seed=4, n_components=8, n_frames=30, n_dim=11, n_gmm=2)
     cp = c_oracle.COraclePrimitive(data)

@@ -441,3 +441,43 @@ def test_constraint_fingerprint_is_a_value_copy():
     from morphablegraphs_amd import _capi, synthetic
     joints, animated = synthetic.make_skeleton()
     assert _capi.Skeleton(joints, animated).serial != _capi.Skeleton(joints, animated).serial
+
+
+def test_commands_travel_without_pickle_and_rendezvous_directories_are_private(tmp_path):
+    """what crosses the ranks is a length-prefixed JSON document + raw array bytes (nothing a reader
+    executes), and the default rendezvous lives in a directory only this user can enter."""
+    import stat
+    from morphablegraphs_amd import distributed
+    cmd = {"op": "options_step", "options": ["a", "b"], "n_samples": 4096, "seed": 7, "dtype": "float32", "skeleton": False,
+           "counts": {"a": np.array([10, 20, 30], dtype=np.int64), "b": np.array([60], dtype=np.int64)},
+           "constraints": {"a": [{"type": "position", "t": 5.0, "weight": 1.0, "target": [1.0, None, float("nan")]}], "b": []},
+           "alignments": {"a": None, "b": {"joint": 0, "heading": (0.0, 1.0), "position": np.array([1.0, 2.0, 3.0])}},
+           "samples": np.random.default_rng(0).standard_normal((5, 3)).astype(np.float32), "widths": {"a": 12, "b": np.int64(40)},
+           "by_int": {3: "x"}}
+    blob = distributed.encode_command(cmd)
+    assert b"numpy" not in blob and not blob.startswith(b"\x80")          # no pickle
+    back = distributed.decode_command(blob)
+    assert back["options"] == ["a", "b"] and back["n_samples"] == 4096 and back["alignments"]["a"] is None and back["by_int"] == {3: "x"}
+    np.testing.assert_array_equal(back["counts"]["a"], cmd["counts"]["a"])
+    assert back["samples"].dtype == np.float32 and np.array_equal(back["samples"], cmd["samples"])
+    t = back["constraints"]["a"][0]["target"]
+    assert t[0] == 1.0 and t[1] is None and np.isnan(t[2]) and back["widths"] == {"a": 12, "b": 40}
+    assert distributed.decode_command(distributed.encode_command({"op": "stop"})) == {"op": "stop"}
+    with pytest.raises(TypeError):
+        distributed.encode_command({"op": "x", "callable": print})
+    with pytest.raises(ValueError):
+        distributed.decode_command(blob[:-8])                                  # truncated array bytes
+    d = distributed.private_rendezvous_dir("mg_rdv_test_%d" % os.getpid())
+    try:
+        st = os.lstat(d)
+        assert stat.S_ISDIR(st.st_mode) and not (st.st_mode & 0o077) and st.st_uid == os.getuid()
+        os.chmod(d, 0o755)
+        with pytest.raises(PermissionError):
+            distributed.private_rendezvous_dir("mg_rdv_test_%d" % os.getpid())
+    finally:
+        os.rmdir(d)
+    # the package imports no tensor framework (north_star: "no PyTorch")
+    import subprocess
+    pkg = os.path.join(ROOT, "morphablegraphs_amd")
+    hits = subprocess.run(["grep", "-rn", "--include=*.py", "torch", pkg], capture_output=True, text=True).stdout
+    assert hits == "", hits

@@ -99,7 +99,7 @@ def _cpu_rank(rank, world, base, n, out_dir):
         while True:
             import pickle
             payload = comm.broadcast_bytes(b"", 0)
-            cmd = pickle.loads(payload)
+            cmd = distributed.decode_command(payload)
             if cmd["op"] == "stop":
                 break
             h = {"evaluate_samples": {"scorer": cpu_scorer}, "sample_and_evaluate": {"sampler": cpu_sampler}, "options_step": {"stepper": cpu_stepper}}[cmd["op"]]
