@@ -401,7 +401,9 @@ def encode_command(cmd):
             return v.item()
         if isinstance(v, dict):
             return {"__dict__": [[enc(k), enc(x)] for k, x in v.items()]} if any(not isinstance(k, str) for k in v) else {k: enc(x) for k, x in v.items()}
-        if isinstance(v, (list, tuple)):
+        if isinstance(v, tuple):          # (node keys are tuples: they must come back hashable)
+            return {"__tuple__": [enc(x) for x in v]}
+        if isinstance(v, list):
             return [enc(x) for x in v]
         if v is None or isinstance(v, (bool, int, float, str)):
             return v
@@ -430,6 +432,8 @@ def decode_command(payload):
                     arrays[k] = np.frombuffer(blob, dtype=dt, count=count, offset=pos[0]).reshape(v["shape"]).copy()
                     pos[0] += count * dt.itemsize
                 return arrays[k]
+            if "__tuple__" in v:
+                return tuple(dec(x) for x in v["__tuple__"])
             if "__dict__" in v:
                 return {dec(k): dec(x) for k, x in v["__dict__"]}
             return {k: dec(x) for k, x in v.items()}

@@ -451,13 +451,13 @@ def test_commands_travel_without_pickle_and_rendezvous_directories_are_private(t
     cmd = {"op": "options_step", "options": ["a", "b"], "n_samples": 4096, "seed": 7, "dtype": "float32", "skeleton": False,
            "counts": {"a": np.array([10, 20, 30], dtype=np.int64), "b": np.array([60], dtype=np.int64)},
            "constraints": {"a": [{"type": "position", "t": 5.0, "weight": 1.0, "target": [1.0, None, float("nan")]}], "b": []},
-           "alignments": {"a": None, "b": {"joint": 0, "heading": (0.0, 1.0), "position": np.array([1.0, 2.0, 3.0])}},
+           "alignments": {"a": None, "b": {"joint": 0, "heading": [0.0, 1.0], "position": np.array([1.0, 2.0, 3.0])}},
            "samples": np.random.default_rng(0).standard_normal((5, 3)).astype(np.float32), "widths": {"a": 12, "b": np.int64(40)},
-           "by_int": {3: "x"}}
+           "by_int": {3: "x"}, "node": ("walk", "leftStance"), "by_tuple": {("a", 1): 2.5}}
     blob = distributed.encode_command(cmd)
     assert b"numpy" not in blob and not blob.startswith(b"\x80")          # no pickle
     back = distributed.decode_command(blob)
-    assert back["options"] == ["a", "b"] and back["n_samples"] == 4096 and back["alignments"]["a"] is None and back["by_int"] == {3: "x"}
+    assert back["options"] == ["a", "b"] and back["n_samples"] == 4096 and back["alignments"]["a"] is None and back["by_int"] == {3: "x"} and back["node"] == ("walk", "leftStance") and back["by_tuple"] == {("a", 1): 2.5}
     np.testing.assert_array_equal(back["counts"]["a"], cmd["counts"]["a"])
     assert back["samples"].dtype == np.float32 and np.array_equal(back["samples"], cmd["samples"])
     t = back["constraints"]["a"][0]["target"]
