@@ -113,7 +113,8 @@ extern "C" int mg_context_create(int device, void *stream, mg_context **out) {
     ctx->n_cu = prop.multiProcessorCount;
     ctx->total_mem = (int64_t)prop.totalGlobalMem;
     ctx->max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
-    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    // (some boxes of the pool report an empty marketing name: the architecture and the CU count always identify the part)
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         mg_set_error("mg_context_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         delete ctx;

@@ -136,6 +136,70 @@ def run_time_case(ref, name, data, n_samples, seed):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+# ---- the reference's optimiser wrappers on toy objectives (no model, no GPU): what HipLeastSquares / HipNumericalMinimizer
+# must reproduce as wrappers -- the evaluation budget's meaning, the returned point -----------------------------------------
+def toy_residuals(s, data=None):
+    """6 residuals of 4 variables; rows of a batch are evaluated independently (the batched wrappers hand over (n, 4))."""
+    s = np.asarray(s, dtype=np.float64)
+    x = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
+    return np.stack([x[0] ** 2 + x[1] - 11.0, x[0] + x[1] ** 2 - 7.0, np.sin(x[2]) - 0.3, x[3] * x[0] - 1.0, 0.1 * (x[2] - x[3]), x[1] - 2.0 * x[3]], axis=-1)
+
+
+def toy_scalar(s, data=None):
+    r = toy_residuals(s)
+    return np.sum(r * r, axis=-1)
+
+
+def run_optimizer_drivers_case(name):
+    """LeastSquares.run (least_squares.py:35-64) and NumericalMinimizer.run (numerical_minimizer.py:41-76), the reference's
+    unmodified files imported through a stub parent package, on the toy objectives above."""
+    pkg = types.ModuleType("mg_ref_optimization")
+    pkg.__path__ = ["/root/reference/morphablegraphs/motion_generator/optimization"]
+    sys.modules["mg_ref_optimization"] = pkg
+    ls_mod = importlib.import_module("mg_ref_optimization.least_squares")
+    nm_mod = importlib.import_module("mg_ref_optimization.numerical_minimizer")
+    x0 = np.array([1.0, 1.5, 0.2, -0.4])
+    out = {"x0": x0}
+    for budget in (12, 30, 400):
+        calls = [0]
+
+        def counted(s, data):
+            calls[0] += 1
+            return toy_residuals(s, data)
+        opt = ls_mod.LeastSquares({"max_iterations": budget, "verbose": False})
+        opt.set_objective_function(counted)
+        opt.set_objective_function_parameters(None)
+        out["leastsq_%d" % budget] = np.asarray(opt.run(x0.copy()))
+        out["leastsq_calls_%d" % budget] = np.int64(calls[0])
+    for method, maxiter in (("BFGS", 6), ("BFGS", 200), ("L-BFGS-B", 50), ("Nelder-Mead", 40)):
+        st = {"method": method, "max_iterations": maxiter, "diff_eps": 1e-6, "tolerance": 1e-10, "verbose": False}
+        opt = nm_mod.NumericalMinimizer(st)
+        opt.set_objective_function(lambda s, data: float(toy_scalar(s, data)))
+        opt.set_objective_function_parameters(None)
+        out["minimize_%s_%d" % (method.replace("-", "_"), maxiter)] = np.asarray(opt.run(x0.copy()))
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def run_walk_32_case(ref, name, data, seed):
+    """BASELINE configs[0]: one 'walk' primitive, 32 latent samples drawn the reference's way, back-projected by the reference
+    (examples/run_construction.py:212-220 draws and back-projects samples of a freshly built model the same way); frames kept at
+    40 of the 156 canonical frames (first, last two, 37 drawn) to hold the fixture to ~1 MB."""
+    mp = ref.MotionPrimitive(None)
+    mp._initialize_from_json(data)
+    np.random.seed(seed)
+    S = mp.sample_low_dimensional_vector(32)
+    F = mp.get_n_canonical_frames()
+    rows = np.unique(np.concatenate([[0, F - 2, F - 1], np.random.default_rng(seed).choice(F, 37, replace=False)]))
+    frames = np.stack([mp.back_project(s, use_time_parameters=False).get_motion_vector()[rows] for s in S])
+    gmm = mp.gaussian_mixture_model
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, S=S, frame_rows=rows.astype(np.int64), frames_at_rows=frames, logp=gmm.score_samples(S), seed=np.int64(seed),
+                        digest=np.array(model_digest(data)), n_canonical_frames=np.int64(F))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def run_trajectory_spline_case(name):
     """The spline under a TrajectoryConstraint (reference constraints/spatial_constraints/splines/{parameterized_spline,
     catmull_rom_spline,arc_length_map}.py, which need only numpy / scipy / matplotlib): points at given parameters and the
@@ -175,6 +239,10 @@ def main():
                                          n_time_components=3, n_basis_time=8)
         run_time_case(ref, "time_model", timed, 9, 41)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "round4":       # the fixtures added in round 4
+        run_optimizer_drivers_case("optimizer_drivers")
+        run_walk_32_case(ref, "walk_32", synthetic.make_walk_primitive(seed=0), 17)
+        return
     # (i) tiny model, non-unit translation maxima, times incl. out-of-range (extrapolated) ones
     tiny = synthetic.make_tiny_primitive(seed=1, translation_maxima=(1.5, 2.0, 0.5))
     run_case(ref, "tiny_tm", tiny, 5, [0.0, 0.25, 5.5, 10.999, 11.0, 11.5, 12.0, -0.5], 3, True, n_score=16)
@@ -200,6 +268,8 @@ def main():
                                      n_time_components=3, n_basis_time=8)
     run_time_case(ref, "time_model", timed, 9, 41)
     run_trajectory_spline_case("trajectory_spline")
+    run_optimizer_drivers_case("optimizer_drivers")
+    run_walk_32_case(ref, "walk_32", walk, 17)
 
 
 if __name__ == "__main__":

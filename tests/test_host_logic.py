@@ -481,3 +481,36 @@ def test_commands_travel_without_pickle_and_rendezvous_directories_are_private(t
     pkg = os.path.join(ROOT, "morphablegraphs_amd")
     hits = subprocess.run(["grep", "-rn", "--include=*.py", "torch", pkg], capture_output=True, text=True).stdout
     assert hits == "", hits
+
+
+def test_optimizer_wrappers_reproduce_the_references_on_toy_objectives():
+    """HipLeastSquares / HipNumericalMinimizer against the REFERENCE's own LeastSquares.run / NumericalMinimizer.run
+    (least_squares.py:35-64, numerical_minimizer.py:41-76; run by oracle/gen_golden.py on toy objectives, results in
+    tests/golden/optimizer_drivers.npz): the point returned for an evaluation budget that cuts the run short (12, 30) and for one
+    that does not (400), and scipy.minimize's routes with the wrappers' batched forward differences in place of scipy's own.
+    No GPU: the objectives are NumPy."""
+    from conftest import load_golden
+    from morphablegraphs_amd.motion_primitive_generator import HipLeastSquares, HipNumericalMinimizer
+    sys_path_gen = os.path.join(ROOT, "oracle")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden_toy", os.path.join(sys_path_gen, "gen_golden.py"))
+    src = open(spec.origin).read()
+    ns = {"np": np}
+    start, end = src.index("def toy_residuals("), src.index("def run_optimizer_drivers_case(")
+    exec(compile(src[start:end], spec.origin, "exec"), ns)          # the toy objectives themselves, from the generating script
+    toy_residuals, toy_scalar = ns["toy_residuals"], ns["toy_scalar"]
+    g = load_golden("optimizer_drivers")
+    x0 = g["x0"]
+    for budget in (12, 30, 400):
+        opt = HipLeastSquares({"max_iterations": budget, "verbose": False}, objective=toy_residuals)
+        opt.set_objective_function_parameters(None)
+        got = opt.run(x0.copy())
+        np.testing.assert_allclose(got, g["leastsq_%d" % budget], rtol=0, atol=2e-7, err_msg="budget %d" % budget)
+        # the evaluations MINPACK's lmdif would have counted stay within one iteration of the reference's objective calls
+        assert abs(opt.n_equivalent_evaluations - int(g["leastsq_calls_%d" % budget])) <= 6, (budget, opt.n_equivalent_evaluations)
+    for method, maxiter, tol in (("BFGS", 6, 1e-5), ("BFGS", 200, 1e-5), ("L-BFGS-B", 50, 1e-5), ("Nelder-Mead", 40, 1e-12)):
+        st = {"method": method, "max_iterations": maxiter, "diff_eps": 1e-6, "tolerance": 1e-10, "verbose": False}
+        opt = HipNumericalMinimizer(st, objective=toy_scalar)
+        opt.set_objective_function_parameters(None)
+        got = opt.run(x0.copy())
+        np.testing.assert_allclose(got, g["minimize_%s_%d" % (method.replace("-", "_"), maxiter)], rtol=0, atol=tol, err_msg=method)
