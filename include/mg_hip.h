@@ -466,6 +466,9 @@ int mg_score_trajectory_points(mg_primitive *prim, const mg_trajectory *trajecto
 #define MG_FRAME_LOCAL_TRAJECTORY 3
 #define MG_FRAME_TRAJECTORY_SET 4
 #define MG_FRAME_JOINT_ROTATION 5
+#define MG_FRAME_JOINT_TRAJECTORY 6   /* TrajectoryConstraint on any joint, trajectory_constraint.py:79-121: per frame the distance to the closest
+                                         point of trajectories[0] at or after the previous frame's parameter (start_arc = the constraint's min_u),
+                                         averaged -- mg_score_trajectory_points' arithmetic, as a member of a list (mg_score_frame_constraints) */
 #define MG_FRAME_MAX_JOINTS 8
 typedef struct mg_frame_constraint_desc {
     int32_t type;
@@ -488,6 +491,24 @@ int mg_align_frames(mg_primitive *prim, double *frames_dev, int64_t n_samples, i
 int mg_frame_constraint_width(const mg_frame_constraint_desc *constraint, int32_t n_times);
 int mg_score_frame_constraint(mg_primitive *prim, const mg_frame_constraint_desc *constraint, const double *tracks_dev, int64_t n_samples,
                               int32_t n_times, int32_t n_joints, double *errors_dev, int accumulate, double *residuals_dev);
+/* The per-frame constraints WITHOUT frames in memory (two launches for a whole constraint list):
+ * mg_joint_tracks: the tracks (n, T, joints, 3) float64 that mg_back_project_frames_f64 -> mg_align_frames -> mg_joint_positions give
+ * through (n, T, n_dim) float64 frames -- ~98 KB of traffic per 'walk' candidate -- from ONE launch that keeps a candidate's control
+ * points of the channels the joints' chains read in LDS: the same operations on the same values (bit-identical tracks), 24 bytes per
+ * (candidate, time, joint) written.  A plan (mg_track_plan_create) fixes up to 4 requests = (time grid at the call, 1 .. 8 joints);
+ * align_joint = the node candidates are aligned through when mg_joint_tracks gets an alignment (0: the root; -1: never aligned).
+ * mg_score_frame_constraints: a LIST of constraints over those tracks in one launch per 4 constraints, errors added in list order
+ * (what mg_score_frame_constraint gives called once per constraint with accumulate); residuals_dev: NULL, or one pointer (or NULL)
+ * per constraint. */
+typedef struct mg_track_plan mg_track_plan;
+int mg_track_plan_create(mg_primitive *prim, const mg_skeleton_desc *skeleton, int32_t n_requests, const int32_t *n_joints, const int32_t *joints,
+                         int32_t align_joint, mg_track_plan **out);
+void mg_track_plan_destroy(mg_track_plan *plan);
+int mg_joint_tracks(mg_track_plan *plan, const void *latents, int dtype, int64_t n_samples, int64_t ld, const mg_alignment_desc *alignment,
+                    const mg_time_grid *const *grids, double *const *tracks_dev);
+int mg_score_frame_constraints(mg_primitive *prim, int32_t n_constraints, const mg_frame_constraint_desc *const *constraints, const double *const *tracks_dev,
+                               const int32_t *n_times, const int32_t *n_joints, int64_t n_samples, double *errors_dev, int accumulate,
+                               double *const *residuals_dev);
 
 /* ---- hot path, device pointers ------------------------------------------------------ */
 

@@ -55,7 +55,7 @@ EXPORTED_SYMBOLS = [
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_objective_error_and_naturalness", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
-    "mg_align_frames", "mg_frame_constraint_width", "mg_score_frame_constraint",
+    "mg_align_frames", "mg_frame_constraint_width", "mg_score_frame_constraint", "mg_score_frame_constraints", "mg_track_plan_create", "mg_track_plan_destroy", "mg_joint_tracks",
     "mg_score_constraint_residuals_chained", "mg_option_step", "mg_options_step", "mg_options_step_device_counts", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
 ]
 
@@ -98,7 +98,9 @@ class AlignmentDesc(C.Structure):   # struct mg_alignment_desc
 
 
 MG_FRAME_CA_POSITION, MG_FRAME_DISCRETE_TRAJECTORY, MG_FRAME_LOCAL_TRAJECTORY, MG_FRAME_TRAJECTORY_SET, MG_FRAME_JOINT_ROTATION = 1, 2, 3, 4, 5
+MG_FRAME_JOINT_TRAJECTORY = 6      # a TrajectoryConstraint on any joint as a member of a constraint list (start_arc = its min_u)
 MG_FRAME_MAX_JOINTS = 8
+MG_TRACK_MAX_REQUESTS = 4
 
 
 class FrameConstraintDesc(C.Structure):   # struct mg_frame_constraint_desc
@@ -210,7 +212,7 @@ def load_library(path=None):
     lib.mg_primitive_canonical_grid.restype = C.c_void_p
     lib.mg_primitive_canonical_grid.argtypes = [C.c_void_p]
     lib.mg_time_grid_size.argtypes = [C.c_void_p]
-    for name in ("mg_context_destroy", "mg_primitive_destroy", "mg_time_grid_destroy", "mg_constraint_set_destroy", "mg_trajectory_destroy"):
+    for name in ("mg_context_destroy", "mg_primitive_destroy", "mg_time_grid_destroy", "mg_constraint_set_destroy", "mg_trajectory_destroy", "mg_track_plan_destroy"):
         getattr(lib, name).restype = None
         getattr(lib, name).argtypes = [C.c_void_p]
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_double
@@ -297,6 +299,9 @@ def load_library(path=None):
         "mg_objective_error_and_naturalness": [vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, vp],
         "mg_time_function_sample": [vp, vp, i32, i64, i64, dbl, vp, vp, i32, vp],
         "mg_back_project_frames_at": [vp, vp, i32, i64, i64, vp, vp, i32, vp, i32],
+        "mg_track_plan_create": [vp, vp, i32, vp, vp, i32, C.POINTER(vp)],
+        "mg_joint_tracks": [vp, vp, i32, i64, i64, vp, vp, vp],
+        "mg_score_frame_constraints": [vp, i32, vp, vp, vp, vp, i64, vp, i32, vp],
         "mg_options_step": [i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, vp],
         "mg_options_step_device_counts": [i32, vp, vp, i64, vp, vp, i32, vp, vp, vp, i64, vp, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],
@@ -756,6 +761,42 @@ class Trajectory(object):
     def close(self):
         if getattr(self, "handle", None) and self.prim.handle and self.prim.ctx.handle:
             self.prim.lib.mg_trajectory_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TrackPlan(object):
+    """What mg_joint_tracks needs that does not change between calls (mg_track_plan_create): per request its joints' chains; the
+    channels to keep; the aligning node's chain.  requests: [[joint, ...], ...] (indices or names of `skeleton`), at most 4."""
+
+    def __init__(self, prim, skeleton, requests, align_joint=0):
+        self.prim, self.skeleton = prim, skeleton
+        self.requests = [[skeleton.index(j) for j in r] for r in requests]
+        nj = np.ascontiguousarray([len(r) for r in self.requests], dtype=np.int32)
+        flat = np.ascontiguousarray([j for r in self.requests for j in r], dtype=np.int32)
+        d = skeleton.desc()
+        h = C.c_void_p()
+        _check(prim.lib.mg_track_plan_create(prim.handle, C.byref(d), len(self.requests), nj.ctypes.data_as(C.c_void_p), flat.ctypes.data_as(C.c_void_p),
+                                             int(align_joint), C.byref(h)))
+        self.handle = h
+
+    def tracks_dev(self, lat_dev, lat_dtype, n, ld, grids, out_devs, alignment=None):
+        """grids: one TimeGrid or None (canonical) per request; out_devs: one device buffer (n, T, joints, 3) float64 per request."""
+        m = len(self.requests)
+        g = (C.c_void_p * m)(*[(x.handle if x is not None else None) for x in grids])
+        o = (C.c_void_p * m)(*[_dev_ptr(x).value for x in out_devs])
+        al = ConstraintSet._marshal_alignment(alignment, self.skeleton) if alignment is not None else None
+        lc = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        _check(self.prim.lib.mg_joint_tracks(self.handle, _dev_ptr(lat_dev), lc, int(n), int(ld), C.byref(al) if al is not None else None, g, o))
+
+    def close(self):
+        if getattr(self, "handle", None) and self.prim.handle and self.prim.ctx.handle:
+            self.prim.lib.mg_track_plan_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

@@ -13,7 +13,13 @@
 // the arc-length look-up is pinned (tests/golden/trajectory_spline.npz through the oracle's restatement).
 #include <cmath>
 
+#include <algorithm>
+#include <new>
+#include <vector>
+
 #include "mg_internal.h"
+#include "mg_score_device.h"
+#include "mg_traj_device.h"
 
 #define MG_FC_BLOCK 64
 
@@ -155,13 +161,27 @@ __device__ __forceinline__ void mg_fc_rotmat(const double *q, double *m) {
     m[6] = 2.0 * (x * z - y * w); m[7] = 2.0 * (y * z + x * w); m[8] = 1.0 - 2.0 * (x * x + y * y);
 }
 
-__global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_kernel(mg_fc_args a) {
-    const int64_t b = (int64_t)blockIdx.x * MG_FC_BLOCK + threadIdx.x;
-    if (b >= a.B) return;
+// one constraint for candidate b: its weighted error (and, if a.res is set, its residual vector)
+__device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int64_t b) {
     const int T = a.T, J = a.J;
     const double *tr = a.tracks + b * (int64_t)T * J * 3;
     double err = 0.0;
-    if (a.type == MG_FRAME_CA_POSITION) {
+    if (a.type == MG_FRAME_JOINT_TRAJECTORY) {
+        // TrajectoryConstraint on the joint whose track this is (trajectory_constraint.py:79-121): per frame the distance to the closest
+        // point of the spline at or after the previous frame's parameter; the error is the average (mg_score_trajectory_points'
+        // arithmetic: mg_traj_device.h)
+        const mg_fc_traj &t = a.traj[0];
+        const double invG = 1.0 / (double)t.G;
+        double min_u = a.start_arc, sum = 0.0;       // (start_arc carries the constraint's min_u)
+        for (int f = 0; f < T; f++) {
+            const double *pp = tr + (int64_t)f * 3;
+            const double q[3] = {pp[0], pp[1], pp[2]};
+            const double dist = mg_traj_closest_dist(t.poly, t.n_seg, t.G, invG, &min_u, q);
+            sum += dist;
+            if (a.res) a.res[b * T + f] = a.weight * dist;
+        }
+        err = a.weight * (T > 0 ? sum / (double)T : 0.0);
+    } else if (a.type == MG_FRAME_CA_POSITION) {
         // errors[i] = _point_distance(position, joint position in frame i); error = min (global_transform_ca_constraint.py:33-39)
         double best = INFINITY;
         for (int f = 0; f < a.nf; f++) {
@@ -251,64 +271,421 @@ __global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_kernel(mg_fc_
         err = a.weight * sqrt(s2);
         if (a.res) a.res[b] = err;
     }
+    return err;
+}
+
+__global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_kernel(mg_fc_args a) {
+    const int64_t b = (int64_t)blockIdx.x * MG_FC_BLOCK + threadIdx.x;
+    if (b >= a.B) return;
+    const double err = mg_fc_evaluate(a, b);
     a.out[b] = a.accumulate ? a.out[b] + err : err;
+}
+
+// A LIST of per-frame constraints in one launch: candidate b's errors added up in list order -- what the same constraints give
+// launched one after the other with accumulate (the first one overwriting unless `accumulate`): the same additions, the same bits.
+#define MG_FC_LIST_MAX 4
+struct mg_fc_list { int32_t n, accumulate; int64_t B; double *out; mg_fc_args c[MG_FC_LIST_MAX]; };
+__global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_list_kernel(const mg_fc_list L) {
+    const int64_t b = (int64_t)blockIdx.x * MG_FC_BLOCK + threadIdx.x;
+    if (b >= L.B) return;
+    double total = L.accumulate ? L.out[b] : 0.0;
+    for (int i = 0; i < L.n; i++) {
+        const double e = mg_fc_evaluate(L.c[i], b);
+        total = (i == 0 && !L.accumulate) ? e : total + e;
+    }
+    L.out[b] = total;
 }
 
 extern "C" int mg_frame_constraint_width(const mg_frame_constraint_desc *c, int32_t n_times) {
     if (!c) return 0;
     switch (c->type) {
         case MG_FRAME_CA_POSITION: case MG_FRAME_JOINT_ROTATION: return 1;
-        case MG_FRAME_DISCRETE_TRAJECTORY: return n_times;
+        case MG_FRAME_DISCRETE_TRAJECTORY: case MG_FRAME_JOINT_TRAJECTORY: return n_times;
         case MG_FRAME_LOCAL_TRAJECTORY: case MG_FRAME_TRAJECTORY_SET: return c->n_frames > 0 && c->n_frames < n_times ? c->n_frames : n_times;
         default: return 0;
     }
 }
 
-extern "C" int mg_score_frame_constraint(mg_primitive *p, const mg_frame_constraint_desc *c, const double *tracks_dev, int64_t B, int32_t T,
-                                         int32_t J, double *errors_dev, int accumulate, double *residuals_dev) {
-    if (!p || !c || B < 0 || T < 1 || J < 1 || !std::isfinite(c->weight)) { mg_set_error("mg_score_frame_constraint: bad arguments"); return MG_ERR_INVALID_ARGUMENT; }
+// desc -> kernel arguments (validated); the output pointers are the caller's business
+static int mg_fc_args_from_desc(const char *who, mg_primitive *p, const mg_frame_constraint_desc *c, const double *tracks_dev, int64_t B, int32_t T, int32_t J,
+                                double *residuals_dev, mg_fc_args *out) {
+    if (!p || !c || B < 0 || T < 1 || J < 1 || !std::isfinite(c->weight)) { mg_set_error("%s: bad arguments", who); return MG_ERR_INVALID_ARGUMENT; }
     mg_fc_args a = {};
-    a.tracks = tracks_dev; a.out = errors_dev; a.res = residuals_dev; a.B = B; a.T = T; a.J = J; a.type = c->type; a.accumulate = accumulate ? 1 : 0;
+    a.tracks = tracks_dev; a.out = nullptr; a.res = residuals_dev; a.B = B; a.T = T; a.J = J; a.type = c->type; a.accumulate = 0;
     a.weight = c->weight; a.start_arc = c->start_arc; a.points = c->points_dev; a.n_points = c->n_points; a.quat_channel = c->quat_channel;
     a.nf = c->n_frames > 0 && c->n_frames < T ? c->n_frames : T;
     for (int d = 0; d < 3; d++) { a.target[d] = c->target[d]; a.axis_on[d] = c->axis_on[d] ? 1 : 0; }
     int n_traj = 0;
     switch (c->type) {
+        case MG_FRAME_JOINT_TRAJECTORY:
+            if (J != 1 || !(c->start_arc >= 0.0 && c->start_arc <= 1.0)) { mg_set_error("%s: a joint trajectory takes one track and min_u (start_arc) in [0, 1]", who); return MG_ERR_INVALID_ARGUMENT; }
+            n_traj = 1;
+            break;
         case MG_FRAME_CA_POSITION:
-            if (J != 1) { mg_set_error("mg_score_frame_constraint: one joint's track expected"); return MG_ERR_INVALID_ARGUMENT; }
+            if (J != 1) { mg_set_error("%s: one joint's track expected", who); return MG_ERR_INVALID_ARGUMENT; }
             for (int d = 0; d < 3; d++)
-                if (a.axis_on[d] && !std::isfinite(a.target[d])) { mg_set_error("mg_score_frame_constraint: target axis %d is not finite", d); return MG_ERR_INVALID_ARGUMENT; }
+                if (a.axis_on[d] && !std::isfinite(a.target[d])) { mg_set_error("%s: target axis %d is not finite", who, d); return MG_ERR_INVALID_ARGUMENT; }
             break;
         case MG_FRAME_DISCRETE_TRAJECTORY:
-            if (J != 1 || c->n_points < 0 || (c->n_points > 0 && !c->points_dev)) { mg_set_error("mg_score_frame_constraint: discrete trajectory needs one track and its points on the device"); return MG_ERR_INVALID_ARGUMENT; }
+            if (J != 1 || c->n_points < 0 || (c->n_points > 0 && !c->points_dev)) { mg_set_error("%s: discrete trajectory needs one track and its points on the device", who); return MG_ERR_INVALID_ARGUMENT; }
             break;
         case MG_FRAME_LOCAL_TRAJECTORY:
-            if (J != 1) { mg_set_error("mg_score_frame_constraint: one joint's track expected"); return MG_ERR_INVALID_ARGUMENT; }
+            if (J != 1) { mg_set_error("%s: one joint's track expected", who); return MG_ERR_INVALID_ARGUMENT; }
             n_traj = 1;
             break;
         case MG_FRAME_TRAJECTORY_SET:
-            if (J > MG_FRAME_MAX_JOINTS || c->n_joints != J) { mg_set_error("mg_score_frame_constraint: a trajectory set takes 1..%d joints, one track each", MG_FRAME_MAX_JOINTS); return MG_ERR_INVALID_ARGUMENT; }
+            if (J > MG_FRAME_MAX_JOINTS || c->n_joints != J) { mg_set_error("%s: a trajectory set takes 1..%d joints, one track each", who, MG_FRAME_MAX_JOINTS); return MG_ERR_INVALID_ARGUMENT; }
             n_traj = J;
             break;
         case MG_FRAME_JOINT_ROTATION: {
-            if (c->quat_channel < 3 || c->quat_channel + 4 > J) { mg_set_error("mg_score_frame_constraint: quaternion channel %d outside the frame (n_dim = %d)", c->quat_channel, J); return MG_ERR_INVALID_ARGUMENT; }
+            if (c->quat_channel < 3 || c->quat_channel + 4 > J) { mg_set_error("%s: quaternion channel %d outside the frame (n_dim = %d)", who, c->quat_channel, J); return MG_ERR_INVALID_ARGUMENT; }
             const double n = std::sqrt(c->quaternion[0] * c->quaternion[0] + c->quaternion[1] * c->quaternion[1] + c->quaternion[2] * c->quaternion[2] + c->quaternion[3] * c->quaternion[3]);
-            if (!(n > 0.0) || !std::isfinite(n)) { mg_set_error("mg_score_frame_constraint: rotation target is zero or not finite"); return MG_ERR_INVALID_ARGUMENT; }
+            if (!(n > 0.0) || !std::isfinite(n)) { mg_set_error("%s: rotation target is zero or not finite", who); return MG_ERR_INVALID_ARGUMENT; }
             for (int e = 0; e < 4; e++) a.quat[e] = c->quaternion[e] / n;
             break;
         }
-        default: mg_set_error("mg_score_frame_constraint: unknown type %d", c->type); return MG_ERR_INVALID_ARGUMENT;
+        default: mg_set_error("%s: unknown type %d", who, c->type); return MG_ERR_INVALID_ARGUMENT;
     }
     for (int j = 0; j < n_traj; j++) {
         const mg_trajectory *t = c->trajectories[j];
-        if (!t || t->prim != p) { mg_set_error("mg_score_frame_constraint: trajectory %d missing or of another primitive", j); return MG_ERR_INVALID_ARGUMENT; }
+        if (!t || t->prim != p) { mg_set_error("%s: trajectory %d missing or of another primitive", who, j); return MG_ERR_INVALID_ARGUMENT; }
         a.traj[j] = {t->d_poly, t->d_arc, t->full_arc, t->n_seg, t->granularity};
         a.arc0[j] = c->arc0[j]; a.range_start[j] = c->range_start[j]; a.range_end[j] = c->range_end[j]; a.has_range[j] = c->has_range[j] ? 1 : 0;
     }
+    *out = a;
+    return MG_OK;
+}
+
+extern "C" int mg_score_frame_constraint(mg_primitive *p, const mg_frame_constraint_desc *c, const double *tracks_dev, int64_t B, int32_t T,
+                                         int32_t J, double *errors_dev, int accumulate, double *residuals_dev) {
+    mg_fc_args a;
+    int rc = mg_fc_args_from_desc("mg_score_frame_constraint", p, c, tracks_dev, B, T, J, residuals_dev, &a);
+    if (rc != MG_OK) return rc;
+    a.out = errors_dev; a.accumulate = accumulate ? 1 : 0;
     if (B == 0) return MG_OK;
     if (!tracks_dev || !errors_dev) { mg_set_error("mg_score_frame_constraint: NULL pointer"); return MG_ERR_INVALID_ARGUMENT; }
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
     hipLaunchKernelGGL(mg_frame_constraint_kernel, dim3((unsigned)((B + MG_FC_BLOCK - 1) / MG_FC_BLOCK)), dim3(MG_FC_BLOCK), 0, p->ctx->stream, a);
+    MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// Several per-frame constraints of the same candidates in ONE launch (lists longer than MG_FC_LIST_MAX: one launch per group).
+extern "C" int mg_score_frame_constraints(mg_primitive *p, int32_t n_constraints, const mg_frame_constraint_desc *const *constraints, const double *const *tracks_dev,
+                                          const int32_t *n_times, const int32_t *n_joints, int64_t B, double *errors_dev, int accumulate,
+                                          double *const *residuals_dev) {
+    if (!p || n_constraints < 0 || (n_constraints > 0 && (!constraints || !tracks_dev || !n_times || !n_joints)) || B < 0) {
+        mg_set_error("mg_score_frame_constraints: bad arguments");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    if (B > 0 && !errors_dev) { mg_set_error("mg_score_frame_constraints: errors_dev is NULL"); return MG_ERR_INVALID_ARGUMENT; }
+    if (n_constraints == 0 || B == 0) return MG_OK;
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    for (int k0 = 0; k0 < n_constraints; k0 += MG_FC_LIST_MAX) {
+        mg_fc_list L = {};
+        L.n = std::min(MG_FC_LIST_MAX, n_constraints - k0);
+        L.accumulate = (accumulate || k0 > 0) ? 1 : 0;
+        L.B = B; L.out = errors_dev;
+        for (int i = 0; i < L.n; i++) {
+            if (!tracks_dev[k0 + i]) { mg_set_error("mg_score_frame_constraints: tracks of constraint %d are NULL", k0 + i); return MG_ERR_INVALID_ARGUMENT; }
+            int rc = mg_fc_args_from_desc("mg_score_frame_constraints", p, constraints[k0 + i], tracks_dev[k0 + i], B, n_times[k0 + i], n_joints[k0 + i],
+                                          residuals_dev ? residuals_dev[k0 + i] : nullptr, &L.c[i]);
+            if (rc != MG_OK) return rc;
+        }
+        hipLaunchKernelGGL(mg_frame_constraint_list_kernel, dim3((unsigned)((B + MG_FC_BLOCK - 1) / MG_FC_BLOCK)), dim3(MG_FC_BLOCK), 0, p->ctx->stream, L);
+        MG_HIP_CHECK(hipGetLastError());
+    }
+    return MG_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mg_joint_tracks: the joints' global positions in every frame, for the whole batch, WITHOUT materialising frames.
+//
+// What the chain mg_back_project_frames_f64 -> mg_align_frames -> mg_joint_positions produces through (n, T, n_dim) float64 frames
+// (808 MB for 8192 'walk' candidates; ~98 KB moved per candidate for a scorer whose algorithmic input is its 160-byte latent) comes
+// from ONE launch here: a workgroup per candidate keeps the control points of the channels the wanted joints' chains READ -- root
+// translation and the quaternions along the chains, a third of the pose for a hand -- in LDS (fma chains over the latents from the
+// mean: the float64 frames kernel's arithmetic), derives the candidate's aligning transform from its first control point (the
+// statements of MG_CONSTRAINT_VALUE_POSITION / _HEADING at t = 0 and of mg_align_frames_kernel), and for every (time, joint)
+// evaluates just those channels (four taps each), turns the root, walks the chain (mg_joint_positions_kernel's loop).  The same
+// operations on the same values: the tracks are the chain's, bit for bit; 24 bytes per (candidate, time, joint) leave the chip.
+// A PLAN holds what does not change between calls: the joints' chain records, the channel list, per request its joints.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MG_TRACK_MAX_REQUESTS 4
+#define MG_TRACK_REC (1 + 4 * MG_MAX_CHAIN)       // chain length m, then per link (quaternion channel or -1, offset xyz): mg_joint_positions' record
+struct mg_track_plan {
+    mg_primitive *prim = nullptr;
+    int32_t n_requests = 0, n_chan = 0, align_m = -1;        // align_m: links of the aligning node's chain (-1: plans without alignment support)
+    int32_t req_joint0[MG_TRACK_MAX_REQUESTS + 1] = {0};     // request q owns records req_joint0[q] .. req_joint0[q + 1]
+    double *d_records = nullptr;    // [n_joints_total][MG_TRACK_REC]
+    double *d_align_rec = nullptr;  // [MG_TRACK_REC]: the aligning node's chain (quaternion channels only are read)
+    int32_t *d_chan = nullptr;      // [n_chan] pose channels kept in LDS
+    int32_t *d_slot = nullptr;      // [D] channel -> slot or -1
+};
+
+struct mg_track_args {
+    const double *Et64, *mean;
+    const void *lat;
+    int64_t B, ld;
+    int32_t L, R, D, NB, lat_f64, n_requests, n_chan, align_mode;   // align_mode 0 none, 1 previous frame, 2 start pose
+    const double *records, *align_rec;
+    const int32_t *chan, *slot;
+    int32_t req_joint0[MG_TRACK_MAX_REQUESTS + 1], T[MG_TRACK_MAX_REQUESTS];
+    const int32_t *i0[MG_TRACK_MAX_REQUESTS];
+    const double *w[MG_TRACK_MAX_REQUESTS];
+    double *out[MG_TRACK_MAX_REQUESTS];
+    double h0, h1, px, py, pz, ref[3];
+    int32_t align_m;
+};
+
+#define MG_TRACK_BLOCK 128
+__global__ __launch_bounds__(MG_TRACK_BLOCK) void mg_joint_tracks_kernel(const mg_track_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *cp = (double *)smem;                    // [NB][n_chan] control points of the kept channels
+    double *s = cp + (size_t)a.NB * a.n_chan;       // [L]
+    double *al = s + a.L;                           // [8]: c, s, tx, tz, ty, aw, ay
+    int *slot = (int *)(al + 8);                    // [D]
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x, nc = a.n_chan, D = a.D, R = a.R, L = a.L;
+    for (int k = tid; k < L; k += MG_TRACK_BLOCK) s[k] = a.lat_f64 ? ((const double *)a.lat)[b * a.ld + k] : (double)((const float *)a.lat)[b * a.ld + k];
+    for (int d = tid; d < D; d += MG_TRACK_BLOCK) slot[d] = a.slot[d];
+    __syncthreads();
+    for (int e = tid; e < a.NB * nc; e += MG_TRACK_BLOCK) {
+        const int i = e / nc, q = e - i * nc;
+        const int r = i * D + a.chan[q];
+        double acc = a.mean[r];
+        for (int k = 0; k < L; k++) acc = fma(a.Et64[(size_t)k * R + r], s[k], acc);
+        cp[e] = acc;
+    }
+    __syncthreads();
+    if (tid == 0 && a.align_mode != 0) {
+        // the candidate's aligning transform from its FIRST control point (a clamped spline's value at t = 0)
+        auto ch0 = [&](int ch) { return cp[slot[ch]]; };
+        const double p0x = ch0(0), p0z = ch0(2);
+        double c, sn, ty;
+        if (a.align_mode == 2) {
+            c = a.h0; sn = a.h1; ty = a.py;
+        } else {
+            // MG_CONSTRAINT_VALUE_HEADING at t = 0 (mg_constraint_residual): the aligning node's global orientation applied to ref_dir, xz, unit
+            double q[4], v[3];
+            const double *rec = a.align_rec;
+            double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;
+            for (int i = 0; i < a.align_m; i++) {
+                const int qc = (int)rec[1 + 4 * i];
+                double qw = ch0(qc), qx = ch0(qc + 1), qy = ch0(qc + 2), qz = ch0(qc + 3);
+                const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+                qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+                const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+                const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+                aw = nw; ax = nx; ay = ny; az = nz;
+            }
+            q[0] = aw; q[1] = ax; q[2] = ay; q[3] = az;
+            mg_rotate(q, a.ref[0], a.ref[1], a.ref[2], v);
+            const double hx = v[0], hz = v[2];
+            const double inv = 1.0 / sqrt(hx * hx + hz * hz);
+            const double bx = 1.0 * hx * inv, bz = 1.0 * hz * inv;      // (weight 1 of the probing constraint)
+            c = a.h0 * bx + a.h1 * bz;
+            sn = a.h0 * bz - a.h1 * bx;
+            ty = 0.0;
+        }
+        al[0] = c; al[1] = sn;
+        al[2] = a.px - (c * p0x + sn * p0z);
+        al[3] = a.pz - (c * p0z - sn * p0x);
+        al[4] = ty;
+        const double phi = atan2(sn, c);
+        al[5] = cos(0.5 * phi); al[6] = sin(0.5 * phi);
+    }
+    __syncthreads();
+    const bool aligned = a.align_mode != 0;
+    const double ac = al[0], as = al[1], tx = al[2], tz = al[3], ty = al[4], qaw = al[5], qay = al[6];
+    for (int rq = 0; rq < a.n_requests; rq++) {
+        const int T = a.T[rq], j0 = a.req_joint0[rq], J = a.req_joint0[rq + 1] - j0;
+        const int32_t *i0 = a.i0[rq];
+        const double *w = a.w[rq];
+        double *out = a.out[rq] + b * (int64_t)T * J * 3;
+        for (int e = tid; e < T * J; e += MG_TRACK_BLOCK) {
+            const int f = e / J, j = e - f * J;
+            const double *wf = w + 4 * (size_t)f;
+            const double *cf = cp + (size_t)i0[f] * nc;
+            auto chan = [&](int ch) {       // the frame's channel: four taps of its control points (mg_back_project_frames_f64's statement)
+                const double *cq = cf + slot[ch];
+                double v = wf[0] * cq[0];
+                v = fma(wf[1], cq[nc], v);
+                v = fma(wf[2], cq[2 * nc], v);
+                v = fma(wf[3], cq[3 * nc], v);
+                return v;
+            };
+            double p0 = chan(0), p1 = chan(1), p2 = chan(2);
+            if (aligned) {                  // mg_align_frames_kernel's statements
+                const double x = p0, z = p2;
+                p0 = ac * x + as * z + tx;
+                p1 += ty;
+                p2 = ac * z - as * x + tz;
+            }
+            const double *rec = a.records + (size_t)(j0 + j) * MG_TRACK_REC;
+            const int m = (int)rec[0];
+            double aw = 1.0, ax = 0.0, ay = 0.0, az = 0.0;
+            for (int k = 0; k < m; k++) {   // mg_joint_positions_kernel's loop
+                const int ch = (int)rec[1 + 4 * k];
+                if (ch >= 0) {
+                    double qw = chan(ch), qx = chan(ch + 1), qy = chan(ch + 2), qz = chan(ch + 3);
+                    if (aligned && ch == 3 && D >= 7) {   // the root's quaternion turns with the candidate: (cos(phi / 2), 0, sin(phi / 2), 0) x q
+                        const double w0 = qw, x0 = qx, y0 = qy, z0 = qz;
+                        qw = qaw * w0 - qay * y0;
+                        qx = qaw * x0 + qay * z0;
+                        qy = qaw * y0 + qay * w0;
+                        qz = qaw * z0 - qay * x0;
+                    }
+                    const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+                    qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+                    const double nw = aw * qw - ax * qx - ay * qy - az * qz, nx = aw * qx + ax * qw + ay * qz - az * qy;
+                    const double ny = aw * qy - ax * qz + ay * qw + az * qx, nz = aw * qz + ax * qy - ay * qx + az * qw;
+                    aw = nw; ax = nx; ay = ny; az = nz;
+                }
+                const double ox = rec[2 + 4 * k], oy = rec[3 + 4 * k], oz = rec[4 + 4 * k];
+                const double cx = ay * oz - az * oy, cy = az * ox - ax * oz, cz = ax * oy - ay * ox;
+                const double dx = ay * cz - az * cy, dy = az * cx - ax * cz, dz = ax * cy - ay * cx;
+                p0 += ox + 2.0 * (aw * cx + dx);
+                p1 += oy + 2.0 * (aw * cy + dy);
+                p2 += oz + 2.0 * (aw * cz + dz);
+            }
+            out[(size_t)e * 3] = p0; out[(size_t)e * 3 + 1] = p1; out[(size_t)e * 3 + 2] = p2;
+        }
+    }
+}
+
+extern "C" void mg_track_plan_destroy(mg_track_plan *pl) {
+    if (!pl) return;
+    if (pl->prim) { (void)hipSetDevice(pl->prim->ctx->device); (void)hipStreamSynchronize(pl->prim->ctx->stream); }
+    (void)hipFree(pl->d_records); (void)hipFree(pl->d_align_rec); (void)hipFree(pl->d_chan); (void)hipFree(pl->d_slot);
+    delete pl;
+}
+
+static int mg_track_chain_record(const char *who, const mg_skeleton_desc *sk, int joint, int n_dim, double *rec, std::vector<char> &need) {
+    if (joint < 0 || joint >= sk->n_joints) { mg_set_error("%s: joint %d out of range", who, joint); return MG_ERR_INVALID_ARGUMENT; }
+    std::vector<int> ch;
+    for (int j = joint; j >= 0; j = sk->parents[j]) {
+        if (sk->parents[j] >= j) { mg_set_error("%s: joint %d: parents must precede their children", who, j); return MG_ERR_INVALID_ARGUMENT; }
+        ch.insert(ch.begin(), j);
+    }
+    const int m = (int)ch.size() - 1;
+    if (m > MG_MAX_CHAIN) { mg_set_error("%s: chain of %d joints exceeds %d", who, m, MG_MAX_CHAIN); return MG_ERR_INVALID_ARGUMENT; }
+    rec[0] = m;
+    for (int k = 0; k < m; k++) {   // link k: rotation of chain joint k, offset of chain joint k + 1
+        const int qc = sk->quat_channel[ch[(size_t)k]];
+        if (qc >= 0 && qc + 4 > n_dim) { mg_set_error("%s: quaternion channel %d outside n_dim = %d", who, qc, n_dim); return MG_ERR_INVALID_ARGUMENT; }
+        rec[1 + 4 * k] = qc;
+        if (qc >= 0) for (int e = 0; e < 4; e++) need[(size_t)qc + e] = 1;
+        for (int e = 0; e < 3; e++) rec[2 + 4 * k + e] = sk->offsets[(size_t)ch[(size_t)k + 1] * 3 + e];
+    }
+    return MG_OK;
+}
+
+// joints: the requests' joints back to back, n_joints[q] of them for request q (each 1 .. MG_FRAME_MAX_JOINTS).  align_joint: the
+// node candidates are aligned through when an alignment is given at the call (0 = the root; -1: no alignment will ever be given).
+extern "C" int mg_track_plan_create(mg_primitive *p, const mg_skeleton_desc *sk, int32_t n_requests, const int32_t *n_joints, const int32_t *joints,
+                                    int32_t align_joint, mg_track_plan **out) {
+    if (!p || !sk || !out || n_requests < 1 || n_requests > MG_TRACK_MAX_REQUESTS || !n_joints || !joints) {
+        mg_set_error("mg_track_plan_create: bad arguments (1 .. %d requests)", MG_TRACK_MAX_REQUESTS);
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    *out = nullptr;
+    if (!(sk->n_joints > 0 && sk->parents && sk->offsets && sk->quat_channel && sk->parents[0] < 0) || p->D < 3) {
+        mg_set_error("mg_track_plan_create: incomplete skeleton, or a primitive without root channels");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    mg_track_plan *pl = new (std::nothrow) mg_track_plan();
+    if (!pl) return MG_ERR_OUT_OF_MEMORY;
+    pl->prim = p; pl->n_requests = n_requests;
+    std::vector<char> need((size_t)p->D + 4, 0);
+    need[0] = need[1] = need[2] = 1;
+    int total = 0;
+    for (int q = 0; q < n_requests; q++) {
+        if (n_joints[q] < 1 || n_joints[q] > MG_FRAME_MAX_JOINTS) { mg_set_error("mg_track_plan_create: request %d has %d joints (1 .. %d)", q, n_joints[q], MG_FRAME_MAX_JOINTS); delete pl; return MG_ERR_INVALID_ARGUMENT; }
+        pl->req_joint0[q] = total;
+        total += n_joints[q];
+    }
+    pl->req_joint0[n_requests] = total;
+    std::vector<double> records((size_t)total * MG_TRACK_REC, 0.0), arec(MG_TRACK_REC, 0.0);
+    int rc = MG_OK;
+    for (int o = 0; o < total && rc == MG_OK; o++) rc = mg_track_chain_record("mg_track_plan_create", sk, joints[o], p->D, &records[(size_t)o * MG_TRACK_REC], need);
+    if (rc == MG_OK && align_joint >= 0) {
+        // the aligning node's global orientation: the quaternions of the chain root .. node, the node's own included
+        if (align_joint >= sk->n_joints) { mg_set_error("mg_track_plan_create: aligning joint %d out of range", align_joint); rc = MG_ERR_INVALID_ARGUMENT; }
+        else {
+            std::vector<int> ch;
+            for (int j = align_joint; j >= 0; j = sk->parents[j]) ch.insert(ch.begin(), j);
+            int m = 0;
+            for (int j : ch) {
+                const int qc = sk->quat_channel[j];
+                if (qc < 0) continue;
+                if (qc + 4 > p->D || m >= MG_MAX_CHAIN) { mg_set_error("mg_track_plan_create: aligning chain does not fit"); rc = MG_ERR_INVALID_ARGUMENT; break; }
+                arec[1 + 4 * m] = qc;
+                for (int e = 0; e < 4; e++) need[(size_t)qc + e] = 1;
+                m++;
+            }
+            arec[0] = m;
+            pl->align_m = m;
+        }
+    }
+    if (rc != MG_OK) { delete pl; return rc; }
+    std::vector<int32_t> chan, slot((size_t)p->D, -1);
+    for (int d = 0; d < p->D; d++)
+        if (need[(size_t)d]) { slot[(size_t)d] = (int32_t)chan.size(); chan.push_back(d); }
+    pl->n_chan = (int32_t)chan.size();
+    auto up = [&](const void *h, size_t bytes, void **d) -> int {
+        MG_HIP_CHECK(hipMalloc(d, std::max<size_t>(bytes, 16)));
+        MG_HIP_CHECK(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        return MG_OK;
+    };
+    rc = up(records.data(), records.size() * 8, (void **)&pl->d_records);
+    if (rc == MG_OK) rc = up(arec.data(), arec.size() * 8, (void **)&pl->d_align_rec);
+    if (rc == MG_OK) rc = up(chan.data(), chan.size() * 4, (void **)&pl->d_chan);
+    if (rc == MG_OK) rc = up(slot.data(), slot.size() * 4, (void **)&pl->d_slot);
+    if (rc != MG_OK) { mg_track_plan_destroy(pl); return rc; }
+    *out = pl;
+    return MG_OK;
+}
+
+// grids[q] (NULL = the canonical grid) and tracks_dev[q] (n, T_q, n_joints[q], 3) float64 per request; alignment NULL = local
+// coordinates, else the record mg_constraint_set_create_aligned takes (joint must be the plan's align_joint, or MG_ALIGN_START_POSE).
+extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64_t B, int64_t ld, const mg_alignment_desc *al,
+                               const mg_time_grid *const *grids, double *const *tracks_dev) {
+    if (!pl || !pl->prim || !grids || !tracks_dev) { mg_set_error("mg_joint_tracks: bad arguments"); return MG_ERR_INVALID_ARGUMENT; }
+    mg_primitive *p = pl->prim;
+    if (B < 0 || B >= ((int64_t)1 << 31) || (dt != MG_F32 && dt != MG_F64) || ld < p->L) { mg_set_error("mg_joint_tracks: bad batch (ld %lld < %d components?)", (long long)ld, p->L); return MG_ERR_INVALID_ARGUMENT; }
+    if (B == 0) return MG_OK;
+    if (!lat) { mg_set_error("mg_joint_tracks: latents are NULL"); return MG_ERR_INVALID_ARGUMENT; }
+    mg_track_args a = {};
+    a.Et64 = p->d_Et64; a.mean = p->d_mean; a.lat = lat; a.B = B; a.ld = ld; a.L = p->L; a.R = p->R; a.D = p->D; a.NB = p->NB; a.lat_f64 = dt == MG_F64 ? 1 : 0;
+    a.n_requests = pl->n_requests; a.n_chan = pl->n_chan; a.records = pl->d_records; a.align_rec = pl->d_align_rec; a.chan = pl->d_chan; a.slot = pl->d_slot;
+    a.align_m = pl->align_m;
+    for (int q = 0; q <= pl->n_requests; q++) a.req_joint0[q] = pl->req_joint0[q];
+    for (int q = 0; q < pl->n_requests; q++) {
+        const mg_time_grid *g = grids[q] ? grids[q] : p->canonical;
+        if (g->prim != p) { mg_set_error("mg_joint_tracks: grid %d belongs to another primitive", q); return MG_ERR_INVALID_ARGUMENT; }
+        if (!tracks_dev[q] || g->T < 1) { mg_set_error("mg_joint_tracks: request %d has no output or an empty grid", q); return MG_ERR_INVALID_ARGUMENT; }
+        a.T[q] = g->T; a.i0[q] = g->d_i0; a.w[q] = g->d_w; a.out[q] = tracks_dev[q];
+    }
+    a.align_mode = 0;
+    if (al) {
+        const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
+        if (!(hn > 0.0) || !std::isfinite(hn)) { mg_set_error("mg_joint_tracks: heading is zero or not finite"); return MG_ERR_INVALID_ARGUMENT; }
+        a.align_mode = al->joint == MG_ALIGN_START_POSE ? 2 : 1;
+        if (a.align_mode == 1 && pl->align_m < 0) { mg_set_error("mg_joint_tracks: the plan was made without an aligning joint"); return MG_ERR_INVALID_ARGUMENT; }
+        a.h0 = al->heading[0] / hn; a.h1 = al->heading[1] / hn; a.px = al->position[0]; a.py = al->position[1]; a.pz = al->position[2];
+        for (int e = 0; e < 3; e++) a.ref[e] = al->ref_dir[e];
+    }
+    const size_t lds = ((size_t)p->NB * pl->n_chan + p->L + 8) * 8 + (size_t)p->D * 4 + 16;
+    if (lds > 160 * 1024 - 64) { mg_set_error("mg_joint_tracks: %d basis functions x %d channels do not fit LDS", p->NB, pl->n_chan); return MG_ERR_UNSUPPORTED; }
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    if (lds > 48 * 1024 && !(p->ctx->attr_traj & 4u)) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_joint_tracks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        p->ctx->attr_traj |= 4u;
+    }
+    hipLaunchKernelGGL(mg_joint_tracks_kernel, dim3((unsigned)B), dim3(MG_TRACK_BLOCK), lds, p->ctx->stream, a);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

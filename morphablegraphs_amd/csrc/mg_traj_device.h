@@ -1,0 +1,90 @@
+// Device-side pieces of the trajectory constraints (gfx950): the Catmull-Rom target spline and the monotone closest-point search,
+// shared by mg_trajectory.hip (the root's own path, or any joint's track) and mg_frame_constraints.hip (the per-frame
+// constraints scored as a list) so that both produce the same bits.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+__device__ __forceinline__ void mg_traj_point(const double *__restrict__ poly, int n_seg, double u, double *p) {
+    const double scaled = n_seg * u;
+    int index = (int)floor(scaled);
+    index = index < n_seg ? index : n_seg;
+    if (index >= n_seg) {                       // past the last segment: the last control point
+        const double *q = poly + (size_t)n_seg * 12;
+        p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+        return;
+    }
+    const double t = scaled - index;
+    const double *A = poly + (size_t)index * 12;
+#pragma unroll
+    for (int d = 0; d < 3; d++) p[d] = ((A[d] * t + A[3 + d]) * t + A[6 + d]) * t + A[9 + d];
+}
+__device__ __forceinline__ double mg_traj_d2(const double *poly, int n_seg, double u, const double *q) {
+    double p[3];
+    mg_traj_point(poly, n_seg, u, p);
+    const double x = p[0] - q[0], y = p[1] - q[1], z = p[2] - q[2];
+    return x * x + y * y + z * z;
+}
+
+// squared distance, and its first and second derivative in u (the segment's cubic differentiated; false past the last segment)
+__device__ __forceinline__ bool mg_traj_d2_derivs(const double *poly, int n_seg, double u, const double *q, double *f0, double *f1, double *f2) {
+    const double scaled = n_seg * u;
+    int index = (int)floor(scaled);
+    if (index >= n_seg) return false;
+    const double t = scaled - index;
+    const double *A = poly + (size_t)index * 12;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double v = ((A[d] * t + A[3 + d]) * t + A[6 + d]) * t + A[9 + d] - q[d];
+        const double p1 = ((3.0 * A[d] * t + 2.0 * A[3 + d]) * t + A[6 + d]) * n_seg;
+        const double p2 = (6.0 * A[d] * t + 2.0 * A[3 + d]) * n_seg * n_seg;
+        s0 += v * v; s1 += v * p1; s2 += p1 * p1 + v * p2;
+    }
+    *f0 = s0; *f1 = 2.0 * s1; *f2 = 2.0 * s2;
+    return true;
+}
+
+// The distance from q to the closest point of the spline whose parameter is at or after *min_u, and that parameter back in *min_u
+// (the bound of the next frame's search): on the grid u_k = k / G walk forward from the bound while the squared distance falls,
+// refine by the parabola through the three values around the minimum, then by up to four Newton steps inside that bracket
+// (oracle/mg_oracle.py closest_point_walk; trajectory_constraint.py:113-131 bounds the search the same way).
+__device__ __forceinline__ double mg_traj_closest_dist(const double *__restrict__ poly, int n_seg, int G, double invG, double *min_u_io, const double *q) {
+    const double min_u = *min_u_io;
+    struct { const double *poly; int n_seg; } a = {poly, n_seg};
+    // closest point at or after min_u: grid walk + parabola (oracle closest_point_walk)
+    int k = (int)ceil(min_u * G - 1e-12);
+    k = k < G ? k : G;
+    double dk = mg_traj_d2(a.poly, a.n_seg, k * invG, q);
+    const double d_start = mg_traj_d2(a.poly, a.n_seg, min_u, q);
+    while (k < G) {
+        const double dn = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
+        if (dn >= dk) break;
+        k++;
+        dk = dn;
+    }
+    double u = k * invG;
+    if (k > 0 && k < G) {
+        const double da = mg_traj_d2(a.poly, a.n_seg, (k - 1) * invG, q), dc = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
+        const double den = da - 2.0 * dk + dc;
+        if (den > 0.0) u = (k + 0.5 * (da - dc) / den) * invG;
+    }
+    {   // up to four Newton steps on the squared distance inside the bracket of the grid minimum (one-sided at the ends of the
+        // range): the bracket's local minimum to rounding; a step that does not lower the distance ends the refinement
+        const double lo = fmax(min_u, (k - 1) * invG), hi = fmin(1.0, (k + 1) * invG);
+        u = fmin(hi, fmax(lo, u));
+        for (int it = 0; it < 4; it++) {
+            double f0, f1, f2;
+            if (!mg_traj_d2_derivs(a.poly, a.n_seg, u, q, &f0, &f1, &f2) || !(f2 > 0.0)) break;
+            const double un = fmin(hi, fmax(lo, u - f1 / f2));
+            if (mg_traj_d2(a.poly, a.n_seg, un, q) > f0) break;
+            u = un;
+        }
+    }
+    u = fmin(1.0, fmax(min_u, u));
+    double d2 = mg_traj_d2(a.poly, a.n_seg, u, q);
+    if (d_start <= d2) { u = min_u; d2 = d_start; }
+    *min_u_io = u;
+    return sqrt(d2);
+}

@@ -224,18 +224,158 @@ def _add_frame_constraint(batch, c, d_err, accumulate, want_residuals):
     raise ValueError("unknown per-frame constraint %r" % (kind,))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The same constraints WITHOUT frames in memory: mg_joint_tracks (one launch: a workgroup per candidate keeps the control points of
+# the channels the joints' chains read in LDS and writes the tracks -- 24 bytes per candidate, time and joint instead of ~98 KB of
+# float64 frames per candidate) + mg_score_frame_constraints (the whole list in one launch).  Bit for bit the tracks and errors of
+# the chain above, which stays as the route for what the plan does not cover (the local joint-rotation constraint, which reads a
+# frame, not a track; more than four distinct (times, joints) requests) and as the oracle-checked reference of the tests.
+# ---------------------------------------------------------------------------------------------------------------------
+_PLAN_CACHE = {}     # (primitive, skeleton serial, aligning joint, requests) -> _capi.TrackPlan
+_GRID_CACHE = {}     # (primitive, n) -> TimeGrid over arange(n)
+FUSED = True         # tests switch the fused route off to compare the two
+
+
+def _request_of(prim, c):
+    """(times key, joints) constraint c reads: None = the canonical grid of get_motion_vector(), n = frames 0 .. n-1"""
+    kind, F = c["type"], prim.n_canonical_frames
+    if kind in ("frame_ca_position", "frame_local_trajectory"):
+        return int(c.get("n_frames", F)), (c["joint"],)
+    if kind == "frame_trajectory_set":
+        return None, tuple(c["joints"])
+    return None, (c["joint"],)          # frame_joint_trajectory, frame_discrete_trajectory
+
+
+def _integer_grid(prim, n):
+    key = (id(prim), prim.handle.value, n)
+    g = _GRID_CACHE.get(key)
+    if g is None or not g.handle:
+        if len(_GRID_CACHE) > 64:
+            _GRID_CACHE.clear()
+        g = _GRID_CACHE[key] = prim.time_grid(np.arange(n, dtype=np.float64))
+    return g
+
+
+def _fused(prim, S, frame_list, skeleton, alignment, d_err, accumulate, residuals):
+    """The fused route; None when the list is not covered (the caller takes the chain)."""
+    from .candidate_scoring import cached_trajectory
+    track_list = frame_list
+    if not FUSED or not track_list or any(c["type"] == "frame_joint_rotation" for c in track_list):
+        return None
+    sk = _skeleton_or_root(skeleton)
+    if skeleton is None and any(j not in ("root", 0, None) for c in track_list for j in _request_of(prim, c)[1]):
+        return None                      # (the chain raises the explanatory error)
+    al_joint = 0
+    if alignment is not None:
+        j = alignment.get("joint", 0)
+        al_joint = 0 if j == _capi.MG_ALIGN_START_POSE else sk.index(j)
+    reqs, req_of = [], []
+    for c in track_list:
+        tk, joints = _request_of(prim, c)
+        key = (tk, tuple(sk.index(j) if skeleton is not None else 0 for j in joints))
+        if key not in reqs:
+            reqs.append(key)
+        req_of.append(reqs.index(key))
+    if len(reqs) > _capi.MG_TRACK_MAX_REQUESTS or any(not 1 <= len(k[1]) <= _capi.MG_FRAME_MAX_JOINTS for k in reqs):
+        return None
+    pkey = (id(prim), prim.handle.value, sk.serial, al_joint, tuple(k[1] for k in reqs))
+    plan = _PLAN_CACHE.get(pkey)
+    if plan is None or not plan.handle:
+        if len(_PLAN_CACHE) > 64:
+            for old in _PLAN_CACHE.values():
+                old.close()
+            _PLAN_CACHE.clear()
+        plan = _PLAN_CACHE[pkey] = _capi.TrackPlan(prim, sk, [list(k[1]) for k in reqs], al_joint)
+    S = _capi._latents(S)
+    n, ctx, F = len(S), prim.ctx, prim.n_canonical_frames
+    grids = [None if k[0] is None else _integer_grid(prim, k[0]) for k in reqs]
+    Ts = [prim._grid_size(g) for g in grids]
+    bufs = [ctx.upload(S)]
+    try:
+        tracks = [ctx.malloc(max(n, 1) * T * len(k[1]) * 3 * 8) for T, k in zip(Ts, reqs)]
+        bufs += tracks
+        plan.tracks_dev(bufs[0], S.dtype, n, S.shape[1], grids, tracks, alignment)
+        m = len(track_list)
+        descs, keep, widths = (_capi.FrameConstraintDesc * m)(), [], []
+        for i, c in enumerate(track_list):
+            d, T = descs[i], Ts[req_of[i]]
+            kind = c["type"]
+            d.weight, d.n_joints = float(c.get("weight", 1.0)), 1
+            if kind == "frame_joint_trajectory":
+                keep.append(cached_trajectory(prim, {"type": "trajectory", "control_points": c["control_points"], "granularity": c.get("granularity", 1000)}))
+                d.type, d.start_arc = _capi.MG_FRAME_JOINT_TRAJECTORY, float(c.get("min_u", 0.0))
+                d.trajectories[0] = keep[-1].handle.value
+            elif kind == "frame_ca_position":
+                d.type, d.n_frames = _capi.MG_FRAME_CA_POSITION, int(c.get("n_frames", F))
+                for a in range(3):
+                    t = c["target"][a]
+                    on = t is not None and not (isinstance(t, float) and np.isnan(t))
+                    d.axis_on[a], d.target[a] = (1, float(t)) if on else (0, 0.0)
+            elif kind == "frame_discrete_trajectory":
+                pts = np.ascontiguousarray(np.asarray(c["points"], dtype=np.float64).reshape(-1, 3))
+                d_p = ctx.upload(pts) if len(pts) else None
+                if d_p is not None:
+                    bufs.append(d_p)
+                d.type, d.n_points, d.points_dev = _capi.MG_FRAME_DISCRETE_TRAJECTORY, len(pts), (d_p.ptr.value if d_p is not None else None)
+                free = set(int(a) for a in (c.get("unconstrained") or ()))
+                for a in range(3):
+                    d.axis_on[a] = 0 if a in free else 1
+            elif kind == "frame_local_trajectory":
+                keep.append(cached_trajectory(prim, {"type": "trajectory", "control_points": c["control_points"], "granularity": c.get("granularity", 1000)}))
+                d.type, d.n_frames, d.start_arc = _capi.MG_FRAME_LOCAL_TRAJECTORY, int(c.get("n_frames", F)), float(c.get("start_t", 0.0))
+                d.trajectories[0] = keep[-1].handle.value
+            elif kind == "frame_trajectory_set":
+                joints = list(c["joints"])
+                if len(c["trajectories"]) != len(joints):
+                    raise ValueError("a trajectory set takes 1..%d joints with one trajectory each" % _capi.MG_FRAME_MAX_JOINTS)
+                d.type, d.n_frames, d.n_joints = _capi.MG_FRAME_TRAJECTORY_SET, int(c.get("n_frames", F)), len(joints)
+                arcs = c.get("arc_lengths", [0.0] * len(joints))
+                for j, t in enumerate(c["trajectories"]):
+                    keep.append(cached_trajectory(prim, {"type": "trajectory", "control_points": t["control_points"], "granularity": t.get("granularity", 1000)}))
+                    d.trajectories[j] = keep[-1].handle.value
+                    d.arc0[j] = float(arcs[j])
+                    rs, re = t.get("range_start"), t.get("range_end")
+                    d.has_range[j] = 0 if rs is None else 1
+                    d.range_start[j], d.range_end[j] = (0.0, 0.0) if rs is None else (float(rs), float(re))
+            else:
+                raise ValueError("unknown per-frame constraint %r" % (kind,))
+            widths.append(prim.lib.mg_frame_constraint_width(C.byref(d), T))
+        vp = C.c_void_p
+        dptr = (vp * m)(*[C.addressof(descs[i]) for i in range(m)])
+        tptr = (vp * m)(*[tracks[req_of[i]].ptr.value for i in range(m)])
+        tT = (C.c_int32 * m)(*[Ts[req_of[i]] for i in range(m)])
+        tJ = (C.c_int32 * m)(*[len(reqs[req_of[i]][1]) for i in range(m)])
+        res = [ctx.malloc(max(n, 1) * w * 8) for w in widths] if residuals else []
+        bufs += res
+        rptr = (vp * m)(*[r.ptr.value for r in res]) if residuals else None
+        _capi._check(prim.lib.mg_score_frame_constraints(prim.handle, m, dptr, tptr, tT, tJ, n, d_err.ptr, 1 if accumulate else 0, rptr))
+        blocks = [ctx.download(r, (n, w), np.float64) for r, w in zip(res, widths)] if residuals else None
+        ctx.synchronize()
+        return blocks if residuals else []
+    finally:
+        for b in bufs:
+            b.free()
+
+
 def add_frame_constraints_dev(prim, S, frame_list, skeleton, alignment, d_err, accumulate=True, residuals=False):
     """Add the per-frame constraints' weighted errors of candidates S (host latents) to d_err (n,) float64 on the device (accumulate
     False: the first one overwrites).  Returns the list of residual blocks (n, m_c) when residuals is set."""
-    batch = _Batch(prim, S, skeleton, alignment)
-    try:
-        blocks = []
-        for i, c in enumerate(frame_list):
-            blocks.append(_add_frame_constraint(batch, c, d_err, accumulate or i > 0, residuals))
-        batch.ctx.synchronize()
-        return blocks if residuals else None
-    finally:
-        batch.close()
+    on_tracks = [i for i, c in enumerate(frame_list) if c["type"] != "frame_joint_rotation"]
+    fused = _fused(prim, S, [frame_list[i] for i in on_tracks], skeleton, alignment, d_err, accumulate, residuals) if on_tracks else None
+    rest = list(range(len(frame_list))) if fused is None else [i for i in range(len(frame_list)) if i not in on_tracks]
+    blocks = [None] * len(frame_list)
+    if fused is not None and residuals:
+        for i, b in zip(on_tracks, fused):
+            blocks[i] = b
+    if rest:
+        batch = _Batch(prim, S, skeleton, alignment)
+        try:
+            for k, i in enumerate(rest):
+                blocks[i] = _add_frame_constraint(batch, frame_list[i], d_err, accumulate or fused is not None or k > 0, residuals)
+            batch.ctx.synchronize()
+        finally:
+            batch.close()
+    return blocks if residuals else None
 
 
 def frame_constraint_residuals(prim, S, c, skeleton=None, alignment=None):

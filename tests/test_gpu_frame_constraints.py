@@ -96,6 +96,42 @@ def test_per_frame_constraints_on_aligned_candidates():
     np.testing.assert_allclose(total, total_ref, rtol=1e-8, atol=1e-8)
 
 
+def test_fused_track_scorer_is_the_chain_bit_for_bit(monkeypatch):
+    """mg_joint_tracks + mg_score_frame_constraints (two launches, no frames in memory) against the chain they replace
+    (mg_back_project_frames_f64 -> mg_align_frames -> mg_joint_positions -> one scorer launch per constraint): the same residual
+    vectors and the same sums, BIT for bit (the verdict's bar was 1e-12), in local coordinates, aligned to a previous frame by two
+    different nodes, and to a start pose; float32 and float64 latents; a list longer than one scorer launch takes (> 4)."""
+    from morphablegraphs_amd import frame_constraints as fc
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=33, seed=4)
+    clist = _constraints(op, orc, S, joints, animated)
+    prev = op.back_project_frames(np.random.default_rng(3).standard_normal(40))[-1].copy()
+    prev[:3] = [25.0, 89.0, -12.0]
+    alignments = [None]
+    for align_joint in ("Hips", "Spine1"):
+        al = sk.alignment_to(prev, sk.index(align_joint))
+        alignments.append({"joint": sk.index(align_joint), "position": al["position"], "heading": al["heading"]})
+    alignments.append(alignment_from_start_pose({"position": [3.0, 2.0, 1.0], "orientation": [0.0, 25.0, 0.0]}))
+    # the list with one more CA constraint on a third joint and other frames: 4 requests, 6 track constraints + 2 rotations
+    longer = clist + [{"type": "frame_ca_position", "joint": "Head", "target": [5.0, 150.0, None], "n_frames": 57, "weight": 0.3}]
+    for lat in (S, S.astype(np.float32)):
+        for alignment in alignments:
+            for cl in (clist, longer, clist[1:2], clist[:1]):
+                monkeypatch.setattr(fc, "FUSED", True)
+                total, blocks = frame_constraints_errors(mp._prim, lat, cl, sk, alignment)
+                monkeypatch.setattr(fc, "FUSED", False)
+                total_c, blocks_c = frame_constraints_errors(mp._prim, lat, cl, sk, alignment)
+                for c, b, bc in zip(cl, blocks, blocks_c):
+                    assert np.array_equal(b.view(np.uint64), bc.view(np.uint64)), (c["type"], np.abs(b - bc).max())
+                assert np.array_equal(total.view(np.uint64), total_c.view(np.uint64))
+    # the fused route really ran: its plan is cached, and the root alone (no skeleton) goes the same way
+    assert len(fc._PLAN_CACHE) >= 4
+    monkeypatch.setattr(fc, "FUSED", True)
+    root = {"type": "frame_ca_position", "joint": "root", "target": [80.0, None, 20.0], "n_frames": op.n_canonical_frames, "weight": 1.0}
+    a = frame_constraints_errors(mp._prim, S, [root], None, None)[0]
+    monkeypatch.setattr(fc, "FUSED", False)
+    assert np.array_equal(a, frame_constraints_errors(mp._prim, S, [root], None, None)[0])
+
+
 def test_per_frame_constraints_through_the_reference_entry_points():
     """evaluate_samples_using_constraints / the sample filter / the objectives take per-frame constraints beside keyframe and
     root-trajectory ones: the errors add up constraint by constraint, the first minimum wins."""
