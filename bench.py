@@ -553,9 +553,9 @@ def run_walk(args, rank, local_rank, world):
             # BASELINE configs[2] and configs[4] on this GPU, a few hundred steps each, under keys of their own (the headline keys
             # above are configs[1] and unchanged); `python bench.py --config graph | optimizer` prints each as a line of its own
             import copy
-            for key, fn in (("graph", run_graph), ("optimizer", run_optimizer)):
+            for key, fn in (("graph", run_graph), ("optimizer", run_optimizer), ("frame_constraints", run_frame_constraints)):
                 a2 = copy.copy(args)
-                a2.steps, a2.warmup, a2.batch = 400, 100, 8192
+                a2.steps, a2.warmup, a2.batch = (400, 100, 8192) if key != "frame_constraints" else (200, 20, 8192)
                 try:
                     r = fn(a2, emit=False)
                     result[key] = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
@@ -789,14 +789,115 @@ def run_optimizer(args, emit=True):
     return 0 if emit else result
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Candidates against constraints that walk EVERY frame: a root trajectory + a collision-avoidance position of the hand
+# ---------------------------------------------------------------------------------------------------------
+def run_frame_constraints(args, emit=True):
+    """4096 resident candidates of the 'walk' shape scored against a TrajectoryConstraint on the root path and a
+    GlobalTransformCAConstraint on the left hand (the per-frame constraint classes of SURVEY 8 row 'next'): three launches, no frames
+    in memory -- mg_score_trajectory (root rows in LDS, closest-point walk), mg_joint_tracks (the hand's track from the control points
+    of its chain's channels, in LDS), mg_score_frame_constraints.  The chain these replace (float64 frames -> forward kinematics ->
+    scorer) is timed beside it on the same candidates, after the timed region."""
+    ensure_built()
+    from morphablegraphs_amd import _capi, synthetic
+    from morphablegraphs_amd import frame_constraints as fc
+    from morphablegraphs_amd.candidate_scoring import cached_trajectory
+    B = int(args.batch) if args.batch != 8192 else 4096
+    ctx = _capi.Context(0)
+    prim = _capi.Primitive(ctx, synthetic.make_path_following_primitive(seed=0))
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    S_host = np.random.default_rng(0).standard_normal((B, L)).astype(np.float32)
+    frames0 = prim.back_project_frames_f64(S_host[:1])[0]
+    hand0 = prim.joint_tracks(sk, ["LeftHand"], S_host[:1])[0, :, 0]
+    root_traj = {"type": "trajectory", "control_points": (frames0[::26, :3] + 0.25).tolist(), "min_u": 0.0, "weight": 1.0, "granularity": 1000}
+    ca = {"type": "frame_ca_position", "joint": "LeftHand", "target": [float(hand0[60, 0]) + 3.0, None, float(hand0[60, 2]) - 2.0], "n_frames": F, "weight": 2.0}
+    traj = cached_trajectory(prim, root_traj)
+    scorer = fc.TrackScorer(prim, [ca], sk, None)
+    S, err = ctx.upload(S_host), ctx.malloc(B * 8)
+
+    def step():
+        prim.score_trajectory_dev(traj, S, np.float32, B, L, err)
+        scorer.score_dev(S, np.float32, B, L, err, accumulate=True)
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    ctx.profile_reset()
+    ctx.profile_enable(1 if args.steps < 200 else 4)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    per_kernel = {}
+    for slot in ("trajectory", "joint_tracks", "frame_constraints"):
+        ms, cnt = ctx.profile_get(slot)
+        per_kernel[slot] = (ms / cnt) if cnt else None
+    got = ctx.download(err, (B,), np.float64)
+    # the chain the two new launches replace, on the same candidates: float64 frames in memory, forward kinematics over them, one scorer launch
+    fc.FUSED = False
+    chain_err = ctx.malloc(B * 8)
+    n_chain = max(3, min(20, args.steps // 10))
+    for timed in (False, True):
+        if timed:
+            ctx.synchronize()
+            ctx.profile_reset()
+            ctx.profile_enable(1)
+            tc = time.perf_counter()
+        for _ in range(n_chain if timed else 2):
+            prim.score_trajectory_dev(traj, S, np.float32, B, L, chain_err)
+            fc.add_frame_constraints_dev(prim, S_host, [ca], sk, None, chain_err, accumulate=True)
+    ctx.synchronize()
+    chain_ms = 1e3 * (time.perf_counter() - tc) / n_chain
+    ctx.profile_enable(False)
+    fms, fcnt = ctx.profile_get("frames")
+    fc.FUSED = True
+    same = bool(np.array_equal(got, ctx.download(chain_err, (B,), np.float64)))
+    # mg_joint_tracks per candidate: the latent in, the hand's track out; what it keeps OUT of memory: F x D float64 frames written, read by the
+    # forward kinematics, the track written and read again
+    T, J = F, 1
+    alg = B * (4 * L + T * J * 24 + 8)
+    chain_bytes = B * (4 * L + 2 * 8 * F * D + 2 * T * J * 24 + 8)
+    k_ms = per_kernel["joint_tracks"]
+    result = {
+        "metric": METRIC, "value": B * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d resident candidates of the 'walk' shape against a root TrajectoryConstraint (6 control points, granularity 1000) and a "
+                               "collision-avoidance position of the left hand over all %d frames (the reference's per-frame constraint classes, "
+                               "constraints/spatial_constraints/); score only, no frames in memory" % (B, F),
+                   "candidates": B, "launches_per_step": 3,
+                   "chain_replaced": {"ms_per_step": chain_ms, "frames_kernel_avg_ms": (fms / fcnt) if fcnt else None, "steps": n_chain,
+                                      "what": "mg_back_project_frames_f64 -> mg_joint_positions -> mg_score_frame_constraint with %d-byte float64 frames per candidate in "
+                                              "memory (round 3's route, kept as the fallback); host-side latents uploaded per call" % (8 * F * D),
+                                      "same_bits": same, "algorithmic_bytes": chain_bytes}},
+        "roofline": {"bound": "hbm", "kernel": "mg_joint_tracks_kernel", "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k_ms else None, "traffic": pmc_traffic_bytes("mg_joint_tracks_kernel"),
+                     "algorithmic_bytes": alg, "avg_kernel_ms": k_ms,
+                     "per_kernel_avg_us": {k: (1e3 * v if v is not None else None) for k, v in per_kernel.items()},
+                     "note": "the step's time is the two closest-point / minimum walks (one lane per candidate, a chain of dependent float64 evaluations per frame: "
+                             "latency bound, neither HBM nor the matrix pipe); mg_joint_tracks moves %d bytes per candidate where the chain moved %d, and is bound "
+                             "by the L2 reads of the eigenvector rows its control points are made from, not by HBM" % (alg // B, chain_bytes // B)},
+    }
+    if emit:
+        print(json.dumps(result))
+    scorer.close()
+    for b in (S, err, chain_err):
+        b.free()
+    prim.close()
+    ctx.close()
+    return 0 if emit else result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=8192, help="candidates per GPU")
-    ap.add_argument("--config", choices=("walk", "graph", "optimizer"), default="walk",
-                    help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU")
+    ap.add_argument("--config", choices=("walk", "graph", "optimizer", "frame_constraints"), default="walk",
+                    help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU; "
+                         "frame_constraints = candidates against constraints that walk every frame (a root trajectory + a hand position)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective-fallback", choices=("none", "torch"), default="none",
                     help="N > 1: what to do when the library's own RCCL communicator cannot be set up on some rank: none = end the run with the reason "
@@ -831,7 +932,7 @@ def main():
     if args.config != "walk":
         if world > 1:
             raise SystemExit("--config %s is a single-GPU workload" % args.config)
-        return run_graph(args) if args.config == "graph" else run_optimizer(args)
+        return {"graph": run_graph, "optimizer": run_optimizer, "frame_constraints": run_frame_constraints}[args.config](args)
     return run_walk(args, rank, local_rank, world)
 
 

@@ -229,6 +229,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *                             candidates on by default) -- identical results
  *   MG_OPT_PLACED_HOLD        n > 0: the placement scan holds at most n candidates at once (default: a quarter of the free memory);
  *                             tests use it to make the scan drop candidates while it runs
+ *   MG_OPT_TRAJECTORY_LANES   1 = one lane per candidate in the closest-point walks of mg_score_trajectory[_points] whatever the batch
+ *                             (default: eight lanes per candidate up to 65536 candidates -- the same bits, a shorter chain per frame)
  *   MG_OPT_ROOT_MODE          how the float32 frames kernels compute the root-translation channels (the two forms differ in
  *                             the last bits; see mg_primitive_root_mode): 0 = what the primitive's accuracy gate says,
  *                             1 = the float64 pipeline, 2 = the mean/delta split */
@@ -245,7 +247,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_SCORE_KERNEL 10
 #define MG_OPT_ROOT_MODE 11
 #define MG_OPT_PLACED_HOLD 12
-#define MG_OPT_COUNT 13
+#define MG_OPT_TRAJECTORY_LANES 13
+#define MG_OPT_COUNT 14
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
@@ -305,7 +308,8 @@ int mg_memset(mg_context *ctx, void *dst_dev, int value, int64_t bytes);
  * n-th launch of each slot with an event pair (n = 1: every launch; an event pair costs a few
  * microseconds of stream time, so a timed region samples with n ~ 8); totals are resolved on query.
  * slot: 0 = back_project_frames, 1 = gmm_log_prob, 2 = score_constraints, 3 = argmin,
- *       4 = gmm_sample, 5 = spline_evaluate, 6 = fused step, 7 = a planner step in one launch (mg_options_step). */
+ *       4 = gmm_sample, 5 = spline_evaluate, 6 = fused step, 7 = a planner step in one launch (mg_options_step),
+ *       8 = mg_joint_tracks, 9 = mg_score_frame_constraints, 10 = mg_score_trajectory[_points]. */
 int mg_profile_enable(mg_context *ctx, int enabled);
 int mg_profile_reset(mg_context *ctx);
 int mg_profile_get(mg_context *ctx, int slot, double *total_ms, int64_t *launches);

@@ -29,12 +29,13 @@ MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile 
 MG_OPT_SCORE_KERNEL = 10     # mg_score_constraints: 0 = by batch size, 1 = a wave per 16 candidates, 2 = a wave per 64 candidates
 MG_OPT_ROOT_MODE = 11        # root channels of the float32 frames kernels: 0 = the primitive's gate, 1 = float64 pipeline, 2 = mean/delta split
 MG_OPT_PLACED_HOLD = 12      # n > 0: the placement scan holds at most n candidates at once (tests)
-MG_OPT_COUNT = 13
+MG_OPT_TRAJECTORY_LANES = 13  # 1: one lane per candidate in the closest-point walks whatever the batch (A/B; default: 8 lanes up to 65536 candidates)
+MG_OPT_COUNT = 14
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 MG_CONSTRAINT_VALUE_POSITION, MG_CONSTRAINT_VALUE_HEADING = 7, 8   # values of the aligned motion, not errors (chained graph-walk steps)
 PROFILE_SLOTS = {"frames": 0, "gmm_log_prob": 1, "score_constraints": 2, "argmin": 3,
-                 "gmm_sample": 4, "spline_evaluate": 5, "step": 6, "options_step": 7}
+                 "gmm_sample": 4, "spline_evaluate": 5, "step": 6, "options_step": 7, "joint_tracks": 8, "frame_constraints": 9, "trajectory": 10}
 
 # every symbol include/mg_hip.h declares (tests check the built library exports them all)
 EXPORTED_SYMBOLS = [

@@ -96,7 +96,16 @@ extern "C" int mg_align_frames(mg_primitive *p, double *frames_dev, int64_t B, i
 // ---------------------------------------------------------------------------------------------------------------------
 // mg_score_frame_constraint
 // ---------------------------------------------------------------------------------------------------------------------
-struct mg_fc_traj { const double *poly, *arc; double full; int32_t n_seg, G; };
+struct mg_fc_traj { const double *poly, *arc; double full; int32_t n_seg, G; int32_t poly_off, arc_off; };   // *_off: the table's place in LDS (doubles), TABLES_LDS kernels
+// Where a trajectory's tables are read from: the copies the workgroup made in LDS (TABLES_LDS: every look-up of the walks below is a
+// dependent read -- the closest-point search makes about 17 per frame, the arc-length search 10 -- so LDS latency instead of L2's is
+// most of the kernel's time), or global memory when the list's tables do not fit.
+template <bool TABLES_LDS> __device__ __forceinline__ const double *mg_fc_poly(const mg_fc_traj &t, const double *lds) {
+    if constexpr (TABLES_LDS) return lds + t.poly_off; else return t.poly;
+}
+template <bool TABLES_LDS> __device__ __forceinline__ const double *mg_fc_arc(const mg_fc_traj &t, const double *lds) {
+    if constexpr (TABLES_LDS) return lds + t.arc_off; else return t.arc;
+}
 struct mg_fc_args {
     const double *tracks;        // (B, T, J, 3), or (B, T, D) frames for MG_FRAME_JOINT_ROTATION
     double *out, *res;
@@ -112,16 +121,16 @@ struct mg_fc_args {
     int32_t has_range[MG_FRAME_MAX_JOINTS];
 };
 
-__device__ __forceinline__ void mg_fc_point(const mg_fc_traj &t, double u, double *p) {
+__device__ __forceinline__ void mg_fc_point(const mg_fc_traj &t, const double *poly, double u, double *p) {
     const double scaled = t.n_seg * u;
     int index = (int)floor(scaled);
     if (index >= t.n_seg) {
-        const double *q = t.poly + (size_t)t.n_seg * 12;
+        const double *q = poly + (size_t)t.n_seg * 12;
         p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
         return;
     }
     const double tt = scaled - index;
-    const double *A = t.poly + (size_t)index * 12;
+    const double *A = poly + (size_t)index * 12;
 #pragma unroll
     for (int d = 0; d < 3; d++) p[d] = ((A[d] * tt + A[3 + d]) * tt + A[6 + d]) * tt + A[9 + d];
 }
@@ -129,29 +138,29 @@ __device__ __forceinline__ void mg_fc_point(const mg_fc_traj &t, double u, doubl
 // ParameterizedSpline.query_point_by_absolute_arc_length (splines/parameterized_spline.py:131-155): beyond the full arc length the last
 // control point; else the table entries bounding the relative arc length, their parameters interpolated linearly
 // (arc_length_map.py:97-160)
-__device__ __forceinline__ void mg_fc_point_by_arc(const mg_fc_traj &t, double arc, double *p) {
+__device__ __forceinline__ void mg_fc_point_by_arc(const mg_fc_traj &t, const double *poly, const double *arcs, double arc, double *p) {
     if (arc > t.full || !(t.full > 0.0)) {
-        const double *q = t.poly + (size_t)t.n_seg * 12;
+        const double *q = poly + (size_t)t.n_seg * 12;
         p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
         return;
     }
     const double rel = arc / t.full;
     double u;
-    if (rel <= t.arc[0]) {
+    if (rel <= arcs[0]) {
         u = 0.0;
-    } else if (rel >= t.arc[t.G]) {
+    } else if (rel >= arcs[t.G]) {
         u = 1.0;
     } else {
         int lo = 0, hi = t.G;                       // arc[lo] <= rel < arc[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (t.arc[mid] <= rel) lo = mid; else hi = mid;
+            if (arcs[mid] <= rel) lo = mid; else hi = mid;
         }
-        const double l0 = t.arc[lo], l1 = t.arc[lo + 1];
+        const double l0 = arcs[lo], l1 = arcs[lo + 1];
         const double u0 = lo / (double)t.G, u1 = (lo + 1) / (double)t.G;
         u = l0 == rel ? u0 : u0 + (rel - l0) / (l1 - l0) * (u1 - u0);
     }
-    mg_fc_point(t, u, p);
+    mg_fc_point(t, poly, u, p);
 }
 
 __device__ __forceinline__ void mg_fc_rotmat(const double *q, double *m) {
@@ -162,7 +171,8 @@ __device__ __forceinline__ void mg_fc_rotmat(const double *q, double *m) {
 }
 
 // one constraint for candidate b: its weighted error (and, if a.res is set, its residual vector)
-__device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int64_t b) {
+template <bool TABLES_LDS>
+__device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int64_t b, const double *lds) {
     const int T = a.T, J = a.J;
     const double *tr = a.tracks + b * (int64_t)T * J * 3;
     double err = 0.0;
@@ -172,11 +182,12 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
         // arithmetic: mg_traj_device.h)
         const mg_fc_traj &t = a.traj[0];
         const double invG = 1.0 / (double)t.G;
+        const double *poly = mg_fc_poly<TABLES_LDS>(t, lds);
         double min_u = a.start_arc, sum = 0.0;       // (start_arc carries the constraint's min_u)
         for (int f = 0; f < T; f++) {
             const double *pp = tr + (int64_t)f * 3;
             const double q[3] = {pp[0], pp[1], pp[2]};
-            const double dist = mg_traj_closest_dist(t.poly, t.n_seg, t.G, invG, &min_u, q);
+            const double dist = mg_traj_closest_dist(poly, t.n_seg, t.G, invG, &min_u, q);
             sum += dist;
             if (a.res) a.res[b * T + f] = a.weight * dist;
         }
@@ -214,11 +225,12 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
     } else if (a.type == MG_FRAME_LOCAL_TRAJECTORY) {
         // the arc length walked so far picks the target on the spline; squared xz distance, summed (local_trajectory_constraint.py:61-78)
         double arc = a.start_arc, sum = 0.0, last[3] = {0.0, 0.0, 0.0};
+        const double *poly = mg_fc_poly<TABLES_LDS>(a.traj[0], lds), *arcs = mg_fc_arc<TABLES_LDS>(a.traj[0], lds);
         for (int f = 0; f < a.nf; f++) {
             const double *p = tr + (int64_t)f * 3;
             if (f > 0) arc += sqrt((last[0] - p[0]) * (last[0] - p[0]) + (last[1] - p[1]) * (last[1] - p[1]) + (last[2] - p[2]) * (last[2] - p[2]));
             double tg[3];
-            mg_fc_point_by_arc(a.traj[0], arc, tg);
+            mg_fc_point_by_arc(a.traj[0], poly, arcs, arc, tg);
             const double dx = tg[0] - p[0], dz = tg[2] - p[2];
             const double r = dx * dx + dz * dz;
             sum += r;
@@ -242,7 +254,7 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
                 double actual = 0.0, target = 0.0;
                 for (int j = 0; j < J; j++) {
                     double tg[3];
-                    mg_fc_point_by_arc(a.traj[j], arcs[j], tg);
+                    mg_fc_point_by_arc(a.traj[j], mg_fc_poly<TABLES_LDS>(a.traj[j], lds), mg_fc_arc<TABLES_LDS>(a.traj[j], lds), arcs[j], tg);
                     actual += p[j * 3] + p[j * 3 + 1] + p[j * 3 + 2];
                     target += tg[0] + tg[1] + tg[2];
                 }
@@ -274,10 +286,26 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
     return err;
 }
 
+// the workgroup's copies of a constraint's tables (a table two trajectories share is written twice with the same values)
+__device__ __forceinline__ void mg_fc_stage_tables(const mg_fc_args &a, double *lds) {
+    for (int j = 0; j < MG_FRAME_MAX_JOINTS; j++) {
+        const mg_fc_traj &t = a.traj[j];
+        if (!t.poly) continue;
+        if (t.poly_off >= 0) for (int e = threadIdx.x; e < t.n_seg * 12 + 3; e += MG_FC_BLOCK) lds[t.poly_off + e] = t.poly[e];
+        if (t.arc_off >= 0) for (int e = threadIdx.x; e <= t.G; e += MG_FC_BLOCK) lds[t.arc_off + e] = t.arc[e];
+    }
+}
+
+template <bool TABLES_LDS>
 __global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_kernel(mg_fc_args a) {
+    extern __shared__ double fc_lds[];
+    if constexpr (TABLES_LDS) {
+        mg_fc_stage_tables(a, fc_lds);
+        __syncthreads();
+    }
     const int64_t b = (int64_t)blockIdx.x * MG_FC_BLOCK + threadIdx.x;
     if (b >= a.B) return;
-    const double err = mg_fc_evaluate(a, b);
+    const double err = mg_fc_evaluate<TABLES_LDS>(a, b, fc_lds);
     a.out[b] = a.accumulate ? a.out[b] + err : err;
 }
 
@@ -285,12 +313,18 @@ __global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_kernel(mg_fc_
 // launched one after the other with accumulate (the first one overwriting unless `accumulate`): the same additions, the same bits.
 #define MG_FC_LIST_MAX 4
 struct mg_fc_list { int32_t n, accumulate; int64_t B; double *out; mg_fc_args c[MG_FC_LIST_MAX]; };
+template <bool TABLES_LDS>
 __global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_list_kernel(const mg_fc_list L) {
+    extern __shared__ double fc_lds[];
+    if constexpr (TABLES_LDS) {
+        for (int i = 0; i < L.n; i++) mg_fc_stage_tables(L.c[i], fc_lds);
+        __syncthreads();
+    }
     const int64_t b = (int64_t)blockIdx.x * MG_FC_BLOCK + threadIdx.x;
     if (b >= L.B) return;
     double total = L.accumulate ? L.out[b] : 0.0;
     for (int i = 0; i < L.n; i++) {
-        const double e = mg_fc_evaluate(L.c[i], b);
+        const double e = mg_fc_evaluate<TABLES_LDS>(L.c[i], b, fc_lds);
         total = (i == 0 && !L.accumulate) ? e : total + e;
     }
     L.out[b] = total;
@@ -349,10 +383,48 @@ static int mg_fc_args_from_desc(const char *who, mg_primitive *p, const mg_frame
     for (int j = 0; j < n_traj; j++) {
         const mg_trajectory *t = c->trajectories[j];
         if (!t || t->prim != p) { mg_set_error("%s: trajectory %d missing or of another primitive", who, j); return MG_ERR_INVALID_ARGUMENT; }
-        a.traj[j] = {t->d_poly, t->d_arc, t->full_arc, t->n_seg, t->granularity};
+        a.traj[j] = {t->d_poly, t->d_arc, t->full_arc, t->n_seg, t->granularity, -1, -1};
         a.arc0[j] = c->arc0[j]; a.range_start[j] = c->range_start[j]; a.range_end[j] = c->range_end[j]; a.has_range[j] = c->has_range[j] ? 1 : 0;
     }
     *out = a;
+    return MG_OK;
+}
+
+// Places in LDS for the tables the constraints' walks search (shared tables once); bytes needed, or 0 when there is nothing to stage
+// or the tables do not fit (the offsets stay -1: the kernels read global memory).
+#define MG_FC_LDS_MAX (150 * 1024)
+static size_t mg_fc_place_tables(mg_fc_args *c, int n) {
+    struct placed { const double *ptr; int32_t off; };
+    placed seen[2 * MG_FC_LIST_MAX * MG_FRAME_MAX_JOINTS];
+    int n_seen = 0;
+    size_t doubles = 0;
+    auto place = [&](const double *ptr, size_t count) {
+        for (int i = 0; i < n_seen; i++) if (seen[i].ptr == ptr) return seen[i].off;
+        const int32_t off = (int32_t)doubles;
+        doubles += (count + 1) & ~(size_t)1;
+        seen[n_seen++] = {ptr, off};
+        return off;
+    };
+    for (int i = 0; i < n; i++) {
+        const bool arcs = c[i].type == MG_FRAME_LOCAL_TRAJECTORY || c[i].type == MG_FRAME_TRAJECTORY_SET;
+        for (int j = 0; j < MG_FRAME_MAX_JOINTS; j++) {
+            mg_fc_traj &t = c[i].traj[j];
+            if (!t.poly) continue;
+            t.poly_off = place(t.poly, (size_t)t.n_seg * 12 + 3);
+            t.arc_off = arcs ? place(t.arc, (size_t)t.G + 1) : -1;
+        }
+    }
+    if (doubles == 0 || doubles * 8 > MG_FC_LDS_MAX) {
+        for (int i = 0; i < n; i++) for (int j = 0; j < MG_FRAME_MAX_JOINTS; j++) c[i].traj[j].poly_off = c[i].traj[j].arc_off = -1;
+        return 0;
+    }
+    return doubles * 8;
+}
+static int mg_fc_attributes(mg_context *ctx) {
+    if (ctx->attr_traj & 8u) return MG_OK;
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frame_constraint_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frame_constraint_list_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->attr_traj |= 8u;
     return MG_OK;
 }
 
@@ -365,7 +437,11 @@ extern "C" int mg_score_frame_constraint(mg_primitive *p, const mg_frame_constra
     if (B == 0) return MG_OK;
     if (!tracks_dev || !errors_dev) { mg_set_error("mg_score_frame_constraint: NULL pointer"); return MG_ERR_INVALID_ARGUMENT; }
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
-    hipLaunchKernelGGL(mg_frame_constraint_kernel, dim3((unsigned)((B + MG_FC_BLOCK - 1) / MG_FC_BLOCK)), dim3(MG_FC_BLOCK), 0, p->ctx->stream, a);
+    const size_t lds = mg_fc_place_tables(&a, 1);
+    if (lds) { rc = mg_fc_attributes(p->ctx); if (rc != MG_OK) return rc; }
+    const dim3 grid((unsigned)((B + MG_FC_BLOCK - 1) / MG_FC_BLOCK));
+    if (lds) hipLaunchKernelGGL(mg_frame_constraint_kernel<true>, grid, dim3(MG_FC_BLOCK), lds, p->ctx->stream, a);
+    else hipLaunchKernelGGL(mg_frame_constraint_kernel<false>, grid, dim3(MG_FC_BLOCK), 0, p->ctx->stream, a);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
@@ -392,7 +468,13 @@ extern "C" int mg_score_frame_constraints(mg_primitive *p, int32_t n_constraints
                                           residuals_dev ? residuals_dev[k0 + i] : nullptr, &L.c[i]);
             if (rc != MG_OK) return rc;
         }
-        hipLaunchKernelGGL(mg_frame_constraint_list_kernel, dim3((unsigned)((B + MG_FC_BLOCK - 1) / MG_FC_BLOCK)), dim3(MG_FC_BLOCK), 0, p->ctx->stream, L);
+        const size_t lds = mg_fc_place_tables(L.c, L.n);
+        if (lds) { const int rc = mg_fc_attributes(p->ctx); if (rc != MG_OK) return rc; }
+        const dim3 grid((unsigned)((B + MG_FC_BLOCK - 1) / MG_FC_BLOCK));
+        mg_prof_begin(p->ctx, 9);
+        if (lds) hipLaunchKernelGGL(mg_frame_constraint_list_kernel<true>, grid, dim3(MG_FC_BLOCK), lds, p->ctx->stream, L);
+        else hipLaunchKernelGGL(mg_frame_constraint_list_kernel<false>, grid, dim3(MG_FC_BLOCK), 0, p->ctx->stream, L);
+        mg_prof_end(p->ctx, 9);
         MG_HIP_CHECK(hipGetLastError());
     }
     return MG_OK;
@@ -685,7 +767,9 @@ extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64
         MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_joint_tracks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         p->ctx->attr_traj |= 4u;
     }
+    mg_prof_begin(p->ctx, 8);
     hipLaunchKernelGGL(mg_joint_tracks_kernel, dim3((unsigned)B), dim3(MG_TRACK_BLOCK), lds, p->ctx->stream, a);
+    mg_prof_end(p->ctx, 8);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

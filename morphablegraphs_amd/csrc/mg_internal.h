@@ -13,7 +13,7 @@
 #define MG_ROWTILE 16       // coefficient rows per MFMA tile (M)
 #define MG_MAX_KK 16        // k-steps of 4 -> n_components <= 64 on the MFMA path
 #define MG_BLOCK 256        // threads per workgroup of the frames kernels
-#define MG_PROFILE_SLOTS 8
+#define MG_PROFILE_SLOTS 11
 
 void mg_set_error(const char *fmt, ...);
 int mg_hip_fail(hipError_t e, const char *what);

@@ -88,3 +88,63 @@ __device__ __forceinline__ double mg_traj_closest_dist(const double *__restrict_
     *min_u_io = u;
     return sqrt(d2);
 }
+
+// The same search by W consecutive lanes that hold the same q and bound (W a power of two, the group aligned in the wave); every lane
+// returns what mg_traj_closest_dist returns, bit for bit: the grid walk -- a chain of dependent evaluations, one per grid step, 6 per
+// frame for a path that moves 1/156 of the spline per frame at granularity 1000 -- becomes ONE evaluation per lane (the grid values
+// around the bound side by side, the first one that does not fall found by a ballot), the start value rides in the group's last
+// lane, the parabola's neighbours are already there.  The Newton steps (a chain by nature) are done by every lane alike.
+// For batches that do not fill the chip with one lane per candidate (the walk is latency, not throughput).
+template <int W>
+__device__ __forceinline__ double mg_traj_closest_dist_coop(const double *__restrict__ poly, int n_seg, int G, double invG, double *min_u_io, const double *q) {
+    const int lane = (int)__lane_id();
+    const int sub = lane & (W - 1), g0 = lane & ~(W - 1);
+    const double min_u = *min_u_io;
+    int k = (int)ceil(min_u * G - 1e-12);
+    k = k < G ? k : G;
+    // first window: lanes 0 .. W-2 the grid values k-1 .. k+W-3, lane W-1 the value at the bound itself
+    int base = k - 1, last = W - 2;
+    double mine;
+    {
+        int idx = base + sub;
+        idx = idx < 0 ? 0 : (idx > G ? G : idx);
+        mine = mg_traj_d2(poly, n_seg, sub == W - 1 ? min_u : idx * invG, q);
+    }
+    const double d_start = __shfl(mine, g0 + W - 1);
+    for (;;) {
+        const int idx = base + sub;
+        const double next = __shfl_down(mine, 1);
+        const bool stop = sub <= last && (idx >= G || (sub < last && next >= mine));
+        const unsigned group = (unsigned)(__ballot(stop) >> g0) & ((1u << W) - 1u) & ~((1u << (k - base)) - 1u);
+        if (group) { k = base + (__ffs(group) - 1); break; }
+        // still falling at the window's end: the next window starts one before it (the parabola wants that neighbour)
+        k = base + last;
+        base = k - 1; last = W - 1;
+        int i2 = base + sub;
+        i2 = i2 > G ? G : i2;
+        mine = mg_traj_d2(poly, n_seg, i2 * invG, q);
+    }
+    const double dk = __shfl(mine, g0 + (k - base));
+    double u = k * invG;
+    if (k > 0 && k < G) {
+        const double da = __shfl(mine, g0 + (k - base) - 1), dc = __shfl(mine, g0 + (k - base) + 1);
+        const double den = da - 2.0 * dk + dc;
+        if (den > 0.0) u = (k + 0.5 * (da - dc) / den) * invG;
+    }
+    {
+        const double lo = fmax(min_u, (k - 1) * invG), hi = fmin(1.0, (k + 1) * invG);
+        u = fmin(hi, fmax(lo, u));
+        for (int it = 0; it < 4; it++) {
+            double f0, f1, f2;
+            if (!mg_traj_d2_derivs(poly, n_seg, u, q, &f0, &f1, &f2) || !(f2 > 0.0)) break;
+            const double un = fmin(hi, fmax(lo, u - f1 / f2));
+            if (mg_traj_d2(poly, n_seg, un, q) > f0) break;
+            u = un;
+        }
+    }
+    u = fmin(1.0, fmax(min_u, u));
+    double d2 = mg_traj_d2(poly, n_seg, u, q);
+    if (d_start <= d2) { u = min_u; d2 = d_start; }
+    *min_u_io = u;
+    return sqrt(d2);
+}

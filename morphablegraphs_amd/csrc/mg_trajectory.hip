@@ -36,14 +36,24 @@ struct mg_traj_args {
 
 #define MG_TRAJ_BLOCK 64
 
+// POLY_LDS: the target spline's segment polynomials (12 n_seg + 3 doubles) are copied behind the rows and searched from there -- the walk
+// is a chain of dependent evaluations (about 17 per frame), each one a look-up of its segment: an LDS read instead of a trip to L2
+template <bool POLY_LDS>
 __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_args a) {
-    extern __shared__ double lds[];                 // [L + rows][64]: the latents, then the root coefficient rows
+    extern __shared__ double lds[];                 // [L + rows][64]: the latents, then the root coefficient rows; [12 n_seg + 3] the polynomials
     const int tid = threadIdx.x;
     const int64_t b = (int64_t)blockIdx.x * MG_TRAJ_BLOCK + tid;
     const bool valid = b < a.B;
     const int64_t bb = valid ? b : a.B - 1;
     const int rows = a.NB * 3 + 4;
     double *ls = lds, *lc = lds + (size_t)a.L * MG_TRAJ_BLOCK;
+    const double *poly = a.poly;
+    if constexpr (POLY_LDS) {
+        double *lp = lds + (a.points ? 0 : (size_t)(a.L + rows) * MG_TRAJ_BLOCK);
+        for (int e = tid; e < a.n_seg * 12 + 3; e += MG_TRAJ_BLOCK) lp[e] = a.poly[e];
+        poly = lp;
+        __syncthreads();
+    }
     if (!a.points) {
         for (int k = 0; k < a.L; k++)
             ls[k * MG_TRAJ_BLOCK + tid] = a.lat_f64 ? ((const double *)a.lat)[bb * a.ld + k] : (double)((const float *)a.lat)[bb * a.ld + k];
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
             q[2] = ac * z - as * x + tz;
             q[1] += ty;
         }
-        const double dist = mg_traj_closest_dist(a.poly, a.n_seg, G, invG, &min_u, q);   // (mg_traj_device.h; min_u moves to the point's parameter)
+        const double dist = mg_traj_closest_dist(poly, a.n_seg, G, invG, &min_u, q);   // (mg_traj_device.h; min_u moves to the point's parameter)
         sum += dist;
         if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
     }
@@ -112,6 +122,93 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
         a.out[b] = a.accumulate ? a.out[b] + e : e;
     }
 }
+
+// The same scorer with MG_TRAJ_W lanes per candidate, for batches that leave most of the chip idle at one lane per candidate (4096
+// candidates are 64 waves on 1024 SIMDs, each a chain of ~18 dependent float64 evaluations per frame): the lanes of a candidate split
+// its coefficient rows (each row the same fma chain as above), then walk the frames together -- every lane the same q, the grid values
+// of the closest-point search side by side (mg_traj_closest_dist_coop).  Same operations on the same values: the same bits.
+#define MG_TRAJ_W 8
+#define MG_TRAJ_COOP_BLOCK 64
+#define MG_TRAJ_COOP_CANDS (MG_TRAJ_COOP_BLOCK / MG_TRAJ_W)
+__global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_kernel(mg_traj_args a) {
+    extern __shared__ double lds[];                 // [CANDS][L] latents, [CANDS][rows] root coefficient rows, [12 n_seg + 3] the polynomials
+    const int tid = threadIdx.x, grp = tid / MG_TRAJ_W, sub = tid % MG_TRAJ_W;
+    const int64_t b = (int64_t)blockIdx.x * MG_TRAJ_COOP_CANDS + grp;
+    const bool valid = b < a.B;
+    const int64_t bb = valid ? b : a.B - 1;
+    const int rows = a.NB * 3 + 4;
+    double *ls = lds + (size_t)grp * a.L, *lc = lds + (size_t)MG_TRAJ_COOP_CANDS * a.L + (size_t)grp * rows;
+    double *lp = lds + (a.points ? 0 : (size_t)MG_TRAJ_COOP_CANDS * (a.L + rows));
+    for (int e = tid; e < a.n_seg * 12 + 3; e += MG_TRAJ_COOP_BLOCK) lp[e] = a.poly[e];
+    if (!a.points) {
+        for (int k = sub; k < a.L; k += MG_TRAJ_W) ls[k] = a.lat_f64 ? ((const double *)a.lat)[bb * a.ld + k] : (double)((const float *)a.lat)[bb * a.ld + k];
+        __syncthreads();
+        for (int r = sub; r < rows; r += MG_TRAJ_W) {
+            double acc = a.mean[r];
+            const double *e = a.E + (size_t)r * a.L;
+            for (int k = 0; k < a.L; k++) acc = fma(e[k], ls[k], acc);
+            lc[r] = acc;
+        }
+    }
+    __syncthreads();
+    double ac = 1.0, as = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
+    if (a.align_mode != 0) {
+        if (a.align_mode == 2) {
+            ac = a.al[0]; as = a.al[1]; ty = a.al[4];
+        } else {
+            double qw = lc[a.NB * 3 + 0], qx = lc[a.NB * 3 + 1], qy = lc[a.NB * 3 + 2], qz = lc[a.NB * 3 + 3];
+            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+            const double rx = a.al[4], ry = a.al[5], rz = a.al[6];
+            const double cx = qy * rz - qz * ry, cy = qz * rx - qx * rz, cz = qx * ry - qy * rx;
+            const double dx = qy * cz - qz * cy, dz = qx * cy - qy * cx;
+            double bx = rx + 2.0 * (qw * cx + dx), bz = rz + 2.0 * (qw * cz + dz);
+            const double bn = 1.0 / sqrt(bx * bx + bz * bz);
+            bx *= bn; bz *= bn;
+            ac = a.al[0] * bx + a.al[1] * bz;
+            as = a.al[0] * bz - a.al[1] * bx;
+        }
+        const double p0x = lc[0], p0z = lc[2];
+        tx = a.al[2] - (ac * p0x + as * p0z);
+        tz = a.al[3] - (ac * p0z - as * p0x);
+    }
+    const int G = a.G;
+    const double invG = 1.0 / (double)G;
+    double min_u = a.min_u, sum = 0.0;
+    for (int f = 0; f < a.T; f++) {
+        double q[3];
+        if (a.points) {
+            const double *pp = a.points + ((size_t)bb * a.T + f) * 3;
+            q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2];
+        } else {
+            const int i0 = a.i0[f];
+            const double *w = a.w + 4 * (size_t)f;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                double v = w[0] * lc[(i0 + 0) * 3 + d];
+                v = fma(w[1], lc[(i0 + 1) * 3 + d], v);
+                v = fma(w[2], lc[(i0 + 2) * 3 + d], v);
+                v = fma(w[3], lc[(i0 + 3) * 3 + d], v);
+                q[d] = v;
+            }
+        }
+        if (a.align_mode != 0) {
+            const double x = q[0], z = q[2];
+            q[0] = ac * x + as * z + tx;
+            q[2] = ac * z - as * x + tz;
+            q[1] += ty;
+        }
+        const double dist = mg_traj_closest_dist_coop<MG_TRAJ_W>(lp, a.n_seg, G, invG, &min_u, q);
+        sum += dist;
+        if (a.res && valid && sub == 0) a.res[b * a.T + f] = a.weight * dist;
+    }
+    if (valid && sub == 0) {
+        const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
+        a.out[b] = a.accumulate ? a.out[b] + e : e;
+    }
+}
+// one lane per candidate fills the chip from about this many candidates on (256 CUs x 4 SIMDs x 64 lanes x ~2 waves)
+#define MG_TRAJ_COOP_MAX_B 65536
 
 template <typename T>
 static int mg_traj_upload(const std::vector<T> &h, T **d) {
@@ -243,15 +340,25 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
         if (a.align_mode == 2) a.al[4] = al->position[1];
         else { a.al[4] = al->ref_dir[0]; a.al[5] = al->ref_dir[1]; a.al[6] = al->ref_dir[2]; }
     }
-    const size_t lds = (size_t)(p->L + t->rows) * MG_TRAJ_BLOCK * 8;
+    size_t lds = (size_t)(p->L + t->rows) * MG_TRAJ_BLOCK * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_score_trajectory: %d basis functions x %d components do not fit LDS", p->NB, p->L); return MG_ERR_UNSUPPORTED; }
+    const size_t poly_bytes = ((size_t)t->n_seg * 12 + 3) * 8;
+    const bool poly_lds = lds + poly_bytes <= 158 * 1024;
+    if (poly_lds) lds += poly_bytes;
     // (a property of kernel AND device: once per context, not per process -- ADVICE r3)
-    if (lds > 48 * 1024 && !(p->ctx->attr_traj & 1u)) {
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (!(p->ctx->attr_traj & 1u)) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         p->ctx->attr_traj |= 1u;
     }
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
-    hipLaunchKernelGGL(mg_trajectory_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
+    const size_t coop_lds = (size_t)MG_TRAJ_COOP_CANDS * (p->L + t->rows) * 8 + poly_bytes;
+    const bool coop = B <= MG_TRAJ_COOP_MAX_B && coop_lds <= 60 * 1024 && p->ctx->opt[MG_OPT_TRAJECTORY_LANES] != 1;
+    mg_prof_begin(p->ctx, 10);
+    if (coop) hipLaunchKernelGGL(mg_trajectory_coop_kernel, dim3((unsigned)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS)), dim3(MG_TRAJ_COOP_BLOCK), coop_lds, p->ctx->stream, a);
+    else if (poly_lds) hipLaunchKernelGGL(mg_trajectory_kernel<true>, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
+    else hipLaunchKernelGGL(mg_trajectory_kernel<false>, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
+    mg_prof_end(p->ctx, 10);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }
@@ -275,7 +382,18 @@ extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
-    hipLaunchKernelGGL(mg_trajectory_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), 0, p->ctx->stream, a);
+    const size_t poly_bytes = ((size_t)t->n_seg * 12 + 3) * 8;
+    if (!(p->ctx->attr_traj & 1u)) {
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_trajectory_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        p->ctx->attr_traj |= 1u;
+    }
+    mg_prof_begin(p->ctx, 10);
+    if (B <= MG_TRAJ_COOP_MAX_B && poly_bytes <= 60 * 1024 && p->ctx->opt[MG_OPT_TRAJECTORY_LANES] != 1)
+        hipLaunchKernelGGL(mg_trajectory_coop_kernel, dim3((unsigned)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS)), dim3(MG_TRAJ_COOP_BLOCK), poly_bytes, p->ctx->stream, a);
+    else if (poly_bytes <= 158 * 1024) hipLaunchKernelGGL(mg_trajectory_kernel<true>, dim3(grid), dim3(MG_TRAJ_BLOCK), poly_bytes, p->ctx->stream, a);
+    else hipLaunchKernelGGL(mg_trajectory_kernel<false>, dim3(grid), dim3(MG_TRAJ_BLOCK), 0, p->ctx->stream, a);
+    mg_prof_end(p->ctx, 10);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
 }

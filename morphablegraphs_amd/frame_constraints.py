@@ -256,49 +256,49 @@ def _integer_grid(prim, n):
     return g
 
 
-def _fused(prim, S, frame_list, skeleton, alignment, d_err, accumulate, residuals):
-    """The fused route; None when the list is not covered (the caller takes the chain)."""
-    from .candidate_scoring import cached_trajectory
-    track_list = frame_list
-    if not FUSED or not track_list or any(c["type"] == "frame_joint_rotation" for c in track_list):
-        return None
-    sk = _skeleton_or_root(skeleton)
-    if skeleton is None and any(j not in ("root", 0, None) for c in track_list for j in _request_of(prim, c)[1]):
-        return None                      # (the chain raises the explanatory error)
-    al_joint = 0
-    if alignment is not None:
-        j = alignment.get("joint", 0)
-        al_joint = 0 if j == _capi.MG_ALIGN_START_POSE else sk.index(j)
-    reqs, req_of = [], []
-    for c in track_list:
-        tk, joints = _request_of(prim, c)
-        key = (tk, tuple(sk.index(j) if skeleton is not None else 0 for j in joints))
-        if key not in reqs:
-            reqs.append(key)
-        req_of.append(reqs.index(key))
-    if len(reqs) > _capi.MG_TRACK_MAX_REQUESTS or any(not 1 <= len(k[1]) <= _capi.MG_FRAME_MAX_JOINTS for k in reqs):
-        return None
-    pkey = (id(prim), prim.handle.value, sk.serial, al_joint, tuple(k[1] for k in reqs))
-    plan = _PLAN_CACHE.get(pkey)
-    if plan is None or not plan.handle:
-        if len(_PLAN_CACHE) > 64:
-            for old in _PLAN_CACHE.values():
-                old.close()
-            _PLAN_CACHE.clear()
-        plan = _PLAN_CACHE[pkey] = _capi.TrackPlan(prim, sk, [list(k[1]) for k in reqs], al_joint)
-    S = _capi._latents(S)
-    n, ctx, F = len(S), prim.ctx, prim.n_canonical_frames
-    grids = [None if k[0] is None else _integer_grid(prim, k[0]) for k in reqs]
-    Ts = [prim._grid_size(g) for g in grids]
-    bufs = [ctx.upload(S)]
-    try:
-        tracks = [ctx.malloc(max(n, 1) * T * len(k[1]) * 3 * 8) for T, k in zip(Ts, reqs)]
-        bufs += tracks
-        plan.tracks_dev(bufs[0], S.dtype, n, S.shape[1], grids, tracks, alignment)
-        m = len(track_list)
+class TrackScorer(object):
+    """A list of per-frame constraints (no joint-rotation ones) made ready for batches on the device: the track plan, the grids, the
+    constraint records and the trajectories they point to.  score_dev() is the two launches; the track buffers are kept between
+    calls of the same batch size.  Raises NotImplementedError when the list is not covered (the caller takes the chain)."""
+
+    def __init__(self, prim, track_list, skeleton, alignment):
+        from .candidate_scoring import cached_trajectory
+        if not track_list or any(c["type"] == "frame_joint_rotation" for c in track_list):
+            raise NotImplementedError("joint-rotation constraints read a frame, not a track")
+        sk = _skeleton_or_root(skeleton)
+        if skeleton is None and any(j not in ("root", 0, None) for c in track_list for j in _request_of(prim, c)[1]):
+            raise NotImplementedError("per-frame constraints on other joints than the root need a skeleton")
+        al_joint = 0
+        if alignment is not None:
+            j = alignment.get("joint", 0)
+            al_joint = 0 if j == _capi.MG_ALIGN_START_POSE else sk.index(j)
+        reqs, req_of = [], []
+        for c in track_list:
+            tk, joints = _request_of(prim, c)
+            key = (tk, tuple(sk.index(j) if skeleton is not None else 0 for j in joints))
+            if key not in reqs:
+                reqs.append(key)
+            req_of.append(reqs.index(key))
+        if len(reqs) > _capi.MG_TRACK_MAX_REQUESTS or any(not 1 <= len(k[1]) <= _capi.MG_FRAME_MAX_JOINTS for k in reqs):
+            raise NotImplementedError("more than %d distinct (times, joints) requests" % _capi.MG_TRACK_MAX_REQUESTS)
+        pkey = (id(prim), prim.handle.value, sk.serial, al_joint, tuple(k[1] for k in reqs))
+        plan = _PLAN_CACHE.get(pkey)
+        if plan is None or not plan.handle:
+            if len(_PLAN_CACHE) > 64:
+                for old in _PLAN_CACHE.values():
+                    old.close()
+                _PLAN_CACHE.clear()
+            plan = _PLAN_CACHE[pkey] = _capi.TrackPlan(prim, sk, [list(k[1]) for k in reqs], al_joint)
+        self.prim, self.ctx, self.plan, self.alignment = prim, prim.ctx, plan, alignment
+        self.reqs, self.req_of = reqs, req_of
+        self.grids = [None if k[0] is None else _integer_grid(prim, k[0]) for k in reqs]
+        self.Ts = [prim._grid_size(g) for g in self.grids]
+        self._tracks, self._tracks_n, self._owned = None, -1, []
+        ctx, F = self.ctx, prim.n_canonical_frames
+        m = self.m = len(track_list)
         descs, keep, widths = (_capi.FrameConstraintDesc * m)(), [], []
         for i, c in enumerate(track_list):
-            d, T = descs[i], Ts[req_of[i]]
+            d, T = descs[i], self.Ts[req_of[i]]
             kind = c["type"]
             d.weight, d.n_joints = float(c.get("weight", 1.0)), 1
             if kind == "frame_joint_trajectory":
@@ -315,7 +315,7 @@ def _fused(prim, S, frame_list, skeleton, alignment, d_err, accumulate, residual
                 pts = np.ascontiguousarray(np.asarray(c["points"], dtype=np.float64).reshape(-1, 3))
                 d_p = ctx.upload(pts) if len(pts) else None
                 if d_p is not None:
-                    bufs.append(d_p)
+                    self._owned.append(d_p)
                 d.type, d.n_points, d.points_dev = _capi.MG_FRAME_DISCRETE_TRAJECTORY, len(pts), (d_p.ptr.value if d_p is not None else None)
                 free = set(int(a) for a in (c.get("unconstrained") or ()))
                 for a in range(3):
@@ -341,18 +341,61 @@ def _fused(prim, S, frame_list, skeleton, alignment, d_err, accumulate, residual
                 raise ValueError("unknown per-frame constraint %r" % (kind,))
             widths.append(prim.lib.mg_frame_constraint_width(C.byref(d), T))
         vp = C.c_void_p
-        dptr = (vp * m)(*[C.addressof(descs[i]) for i in range(m)])
-        tptr = (vp * m)(*[tracks[req_of[i]].ptr.value for i in range(m)])
-        tT = (C.c_int32 * m)(*[Ts[req_of[i]] for i in range(m)])
-        tJ = (C.c_int32 * m)(*[len(reqs[req_of[i]][1]) for i in range(m)])
-        res = [ctx.malloc(max(n, 1) * w * 8) for w in widths] if residuals else []
-        bufs += res
-        rptr = (vp * m)(*[r.ptr.value for r in res]) if residuals else None
-        _capi._check(prim.lib.mg_score_frame_constraints(prim.handle, m, dptr, tptr, tT, tJ, n, d_err.ptr, 1 if accumulate else 0, rptr))
-        blocks = [ctx.download(r, (n, w), np.float64) for r, w in zip(res, widths)] if residuals else None
-        ctx.synchronize()
-        return blocks if residuals else []
+        self.descs, self.keep, self.widths = descs, keep, widths
+        self.dptr = (vp * m)(*[C.addressof(descs[i]) for i in range(m)])
+        self.tT = (C.c_int32 * m)(*[self.Ts[req_of[i]] for i in range(m)])
+        self.tJ = (C.c_int32 * m)(*[len(reqs[req_of[i]][1]) for i in range(m)])
+        self.tptr = None
+
+    def _track_buffers(self, n):
+        if self._tracks_n != n:
+            self._free_tracks()
+            self._tracks = [self.ctx.malloc(max(n, 1) * T * len(k[1]) * 3 * 8) for T, k in zip(self.Ts, self.reqs)]
+            self._tracks_n = n
+            self.tptr = (C.c_void_p * self.m)(*[self._tracks[self.req_of[i]].ptr.value for i in range(self.m)])
+        return self._tracks
+
+    def _free_tracks(self):
+        for b in self._tracks or ():
+            b.free()
+        self._tracks, self._tracks_n = None, -1
+
+    def score_dev(self, lat_dev, lat_dtype, n, ld, d_err, accumulate=True, residual_devs=None):
+        """mg_joint_tracks + mg_score_frame_constraints on resident latents: the list's errors added to (or written over) d_err (n,)."""
+        tracks = self._track_buffers(n)
+        self.plan.tracks_dev(lat_dev, lat_dtype, n, ld, self.grids, tracks, self.alignment)
+        rptr = (C.c_void_p * self.m)(*[_capi._dev_ptr(r).value for r in residual_devs]) if residual_devs is not None else None
+        _capi._check(self.prim.lib.mg_score_frame_constraints(self.prim.handle, self.m, self.dptr, self.tptr, self.tT, self.tJ, n, _capi._dev_ptr(d_err),
+                                                              1 if accumulate else 0, rptr))
+
+    def close(self):
+        if self.ctx.handle:
+            self.ctx.synchronize()
+            self._free_tracks()
+            for b in self._owned:
+                b.free()
+        self._owned = []
+
+
+def _fused(prim, S, frame_list, skeleton, alignment, d_err, accumulate, residuals):
+    """The fused route; None when the list is not covered (the caller takes the chain)."""
+    if not FUSED:
+        return None
+    try:
+        scorer = TrackScorer(prim, frame_list, skeleton, alignment)
+    except NotImplementedError:
+        return None
+    S = _capi._latents(S)
+    n, ctx = len(S), prim.ctx
+    bufs = [ctx.upload(S)]
+    try:
+        res = [ctx.malloc(max(n, 1) * w * 8) for w in scorer.widths] if residuals else None
+        bufs += res or []
+        scorer.score_dev(bufs[0], S.dtype, n, S.shape[1], d_err, accumulate, res)
+        blocks = [ctx.download(r, (n, w), np.float64) for r, w in zip(res, scorer.widths)] if residuals else []
+        return blocks
     finally:
+        scorer.close()
         for b in bufs:
             b.free()
 

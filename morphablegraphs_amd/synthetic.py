@@ -95,6 +95,21 @@ def make_walk_primitive(seed=0, **kw):
     return make_primitive(seed=seed, n_components=40, n_frames=156, n_dim=79, n_gmm=8, name="walk", **kw)
 
 
+def make_path_following_primitive(seed=0):
+    """The 'walk' shape with a root path a path-following constraint meets in practice: a gentle curve the candidates
+    vary around by a few units (the plain synthetic model's root coefficients are noise of amplitude 100)."""
+    data = make_walk_primitive(seed=seed)
+    NB, D = int(data["n_basis_spatial"]), int(data["n_dim_spatial"])
+    mean = np.array(data["mean_spatial_vector"]).reshape(NB, D)
+    eig = np.array(data["eigen_vectors_spatial"]).reshape(-1, NB, D)
+    x = np.linspace(0.0, 1.0, NB)
+    mean[:, 0], mean[:, 1], mean[:, 2] = 160.0 * x, 90.0 + 2.0 * np.sin(6.0 * x), 40.0 * np.sin(2.0 * x)
+    eig[:, :, :3] *= 0.03
+    data["mean_spatial_vector"] = mean.reshape(-1).tolist()
+    data["eigen_vectors_spatial"] = eig.reshape(len(eig), -1).tolist()
+    return data
+
+
 def make_tiny_primitive(seed=1, **kw):
     """Tiny case the pure-Python oracle loops finish instantly: L=3, F=12, NB=7, D=7, K=2."""
     return make_primitive(seed=seed, n_components=3, n_frames=12, n_basis=7, n_dim=7, n_gmm=2,

@@ -1059,18 +1059,7 @@ def test_time_warped_synthesis_of_a_batch_against_the_reference():
 
 
 def _path_following_model():
-    """The 'walk' shape with a root path a path-following constraint meets in practice: a gentle curve the candidates
-    vary around by a few units (the plain synthetic model's root coefficients are noise of amplitude 100)."""
-    data = synthetic.make_walk_primitive(seed=0)
-    NB, D = 31, 79
-    mean = np.array(data["mean_spatial_vector"]).reshape(NB, D)
-    eig = np.array(data["eigen_vectors_spatial"]).reshape(40, NB, D)
-    x = np.linspace(0.0, 1.0, NB)
-    mean[:, 0], mean[:, 1], mean[:, 2] = 160.0 * x, 90.0 + 2.0 * np.sin(6.0 * x), 40.0 * np.sin(2.0 * x)
-    eig[:, :, :3] *= 0.03
-    data["mean_spatial_vector"] = mean.reshape(-1).tolist()
-    data["eigen_vectors_spatial"] = eig.reshape(40, -1).tolist()
-    return data
+    return synthetic.make_path_following_primitive(seed=0)
 
 
 def test_trajectory_constraint_on_the_root_path():

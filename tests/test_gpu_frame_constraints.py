@@ -132,6 +132,45 @@ def test_fused_track_scorer_is_the_chain_bit_for_bit(monkeypatch):
     assert np.array_equal(a, frame_constraints_errors(mp._prim, S, [root], None, None)[0])
 
 
+def test_closest_point_walk_by_eight_lanes_is_the_one_lane_walk_bit_for_bit():
+    """mg_score_trajectory / mg_score_trajectory_points give a candidate eight lanes below 65536 candidates (the grid values of the
+    search side by side, a ballot for the first that does not fall) and one lane above: the same distances and the same errors,
+    bit for bit -- coarse and fine grids (windows refilled: more than six grid steps per frame), paths that run past the
+    spline's end, a bound in mid-spline, aligned candidates, any joint's track."""
+    from morphablegraphs_amd.candidate_scoring import cached_trajectory
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=77, seed=8)
+    prim, ctx = mp._prim, mp._prim.ctx
+    frames0 = op.back_project_frames(S[0])
+    prev = op.back_project_frames(np.random.default_rng(3).standard_normal(40))[-1].copy()
+    prev[:3] = [25.0, 89.0, -12.0]
+    al = sk.alignment_to(prev, 0)
+    alignments = [None, {"joint": 0, "position": al["position"], "heading": al["heading"]},
+                  alignment_from_start_pose({"position": [3.0, 2.0, 1.0], "orientation": [0.0, 25.0, 0.0]})]
+    paths = [(frames0[::26, :3] + 0.25, 1000), (frames0[::26, :3] + 0.25, 7), (frames0[::26, :3] + 0.25, 20000),
+             (frames0[:80:16, :3] - 1.0, 1000), (np.array([[0.0, 90.0, 0.0], [60.0, 90.0, 25.0]]), 300)]
+    hand = prim.joint_tracks(sk, ["LeftHand"], S)[:, :, 0]
+
+    def both(fn):
+        out = []
+        for lanes in (0, 1):
+            ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, lanes)
+            out.append(fn())
+        ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, 0)
+        return out
+    moved = 0
+    for cps, gran in paths:
+        traj = cached_trajectory(prim, {"type": "trajectory", "control_points": cps.tolist(), "granularity": gran})
+        for alignment in alignments:
+            for min_u in (0.0, 0.37):
+                (e8, r8), (e1, r1) = both(lambda: prim.score_trajectory(traj, S, min_u, 1.3, alignment, residuals=True))
+                assert np.array_equal(r8.view(np.uint64), r1.view(np.uint64)), (gran, min_u, np.abs(r8 - r1).max())
+                assert np.array_equal(e8.view(np.uint64), e1.view(np.uint64))
+                moved += int(np.count_nonzero(np.diff(r8, axis=1)))
+        (e8, r8), (e1, r1) = both(lambda: prim.score_trajectory_points(traj, hand, 0.1, 0.7, residuals=True))
+        assert np.array_equal(r8.view(np.uint64), r1.view(np.uint64)) and np.array_equal(e8.view(np.uint64), e1.view(np.uint64))
+    assert moved > 1000
+
+
 def test_per_frame_constraints_through_the_reference_entry_points():
     """evaluate_samples_using_constraints / the sample filter / the objectives take per-frame constraints beside keyframe and
     root-trajectory ones: the errors add up constraint by constraint, the first minimum wins."""
