@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F64_MFMA_PEAK_TFLOPS = 78.6   # AMD's published MI355X float64 matrix figure (the guide has no float64 row)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_summary.json")   # tools/prof_bench.sh + tools/summarize_prof.py
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r04_summary.json", "r04_frame_constraints_summary.json")]   # tools/prof_all.sh
 METRIC = "motion-primitive samples scored+back-projected/sec; fraction of HBM roofline"
 L, F, D, NB, K = 40, 156, 79, 31, 8
 
@@ -44,14 +44,15 @@ def pmc_traffic_bytes(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units; FETCH_SIZE doubled as the gfx950
     correction for wide coalesced reads prescribes).  None when no summary is present."""
-    try:
-        with open(PMC_SUMMARY) as f:
-            summ = json.load(f)
-        for name, c in summ.get("pmc", {}).items():
-            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-    except (OSError, ValueError):
-        pass
+    for path in PMC_SUMMARIES:
+        try:
+            with open(path) as f:
+                summ = json.load(f)
+            for name, c in summ.get("pmc", {}).items():
+                if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        except (OSError, ValueError):
+            pass
     return None
 
 

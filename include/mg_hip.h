@@ -232,8 +232,9 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_TRAJECTORY_LANES   1 = one lane per candidate in the closest-point walks of mg_score_trajectory[_points] whatever the batch
  *                             (default: eight lanes per candidate up to 65536 candidates -- the same bits, a shorter chain per frame)
  *   MG_OPT_ROOT_MODE          how the float32 frames kernels compute the root-translation channels (the two forms differ in
- *                             the last bits; see mg_primitive_root_mode): 0 = what the primitive's accuracy gate says,
- *                             1 = the float64 pipeline, 2 = the mean/delta split */
+ *                             the last bits; see mg_primitive_root_mode): 0, 1 = the float64 pipeline (the default: the faster
+ *                             of the two on gfx950), 2 = the mean/delta split, 3 = the split where the primitive's accuracy gate
+ *                             allows it */
 #define MG_OPT_FORCE_VALU_SCORE 0
 #define MG_OPT_FORCE_VALU_SAMPLE 1
 #define MG_OPT_RING_SLOTS 2
@@ -357,10 +358,11 @@ int mg_primitive_info2(const mg_primitive *prim, int32_t *out4);
  *              M = the spline of mean' alone, a constant of the time grid evaluated ONCE in float64 on the host and kept as
  *              a float32 pair (Mhi, Mlo), and delta = the spline of E'.s alone, which rides in the ordinary float32 row
  *              tiles; out = Mhi + (Mlo + delta), two float32 additions.
- * The split is used when its error estimate -- (L + 8) 2^-24 max_r sqrt(sum_k E'[r][k]^2 m2[k]) over the root rows r, m2[k] the
+ * The split is an OPTION (MG_OPT_ROOT_MODE 3; it measured 82.8 us against the float64 pipeline's 78.5 us on the fused step,
+ * DESIGN.md 6.4, so the default is the float64 pipeline for every primitive); mode 3 takes it when its error estimate -- (L + 8) 2^-24 max_r sqrt(sum_k E'[r][k]^2 m2[k]) over the root rows r, m2[k] the
  * second moment of latent k under the primitive's mixture (1 without a mixture): the float32 rounding a root control point
  * of typical size can collect -- is at most 5e-6, half of the 1e-5 the float32 pose values are held to; *estimate returns
- * it.  MG_OPT_ROOT_MODE overrides the choice (tests). */
+ * it; *split returns what the context's current mode means for this primitive.  MG_OPT_ROOT_MODE 2 forces the split (tests). */
 int mg_primitive_root_mode(const mg_primitive *prim, int32_t *split, double *estimate);
 /* (K, L, L) float64, upper triangular: sklearn's precisions_cholesky_ */
 int mg_primitive_get_precisions_cholesky(const mg_primitive *prim, double *out);

@@ -27,7 +27,7 @@ MG_OPT_OPTIONS_STEP = 7      # mg_options_step: 0 = one launch per step where po
 MG_OPT_PLAIN_MALLOC = 8      # 1 = mg_device_malloc is one hipMalloc whatever the size (no placed output regions)
 MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile per workgroup, 2 = fragments resident in LDS
 MG_OPT_SCORE_KERNEL = 10     # mg_score_constraints: 0 = by batch size, 1 = a wave per 16 candidates, 2 = a wave per 64 candidates
-MG_OPT_ROOT_MODE = 11        # root channels of the float32 frames kernels: 0 = the primitive's gate, 1 = float64 pipeline, 2 = mean/delta split
+MG_OPT_ROOT_MODE = 11        # root channels of the float32 frames kernels: 0, 1 = float64 pipeline (default), 2 = mean/delta split, 3 = split where the gate allows
 MG_OPT_PLACED_HOLD = 12      # n > 0: the placement scan holds at most n candidates at once (tests)
 MG_OPT_TRAJECTORY_LANES = 13  # 1: one lane per candidate in the closest-point walks whatever the batch (A/B; default: 8 lanes up to 65536 candidates)
 MG_OPT_COUNT = 14
@@ -874,8 +874,8 @@ class Primitive(object):
 
     @property
     def root_split(self):
-        """True when the float32 frames kernels compute this primitive's root channels by the mean/delta split (the accuracy
-        gate of mg_primitive_root_mode, or MG_OPT_ROOT_MODE), False for the float64 pipeline."""
+        """True when the float32 frames kernels compute this primitive's root channels by the mean/delta split (MG_OPT_ROOT_MODE
+        2, or 3 where the accuracy gate of mg_primitive_root_mode allows it), False for the float64 pipeline (the default)."""
         split = C.c_int32()
         _check(self.lib.mg_primitive_root_mode(self.handle, C.byref(split), None))
         return bool(split.value)

@@ -194,16 +194,18 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
         err = a.weight * (T > 0 ? sum / (double)T : 0.0);
     } else if (a.type == MG_FRAME_CA_POSITION) {
         // errors[i] = _point_distance(position, joint position in frame i); error = min (global_transform_ca_constraint.py:33-39)
-        double best = INFINITY;
+        // (the minimum of the distances is the root of the minimum of their squares, exactly: sqrt is monotone and correctly rounded --
+        // one root per candidate instead of one per frame, the same bits)
+        double best2 = INFINITY;
+#pragma unroll 4
         for (int f = 0; f < a.nf; f++) {
             double d2 = 0.0;
 #pragma unroll
             for (int d = 0; d < 3; d++)
                 if (a.axis_on[d]) { const double v = a.target[d] - tr[(int64_t)f * 3 + d]; d2 += v * v; }
-            const double dist = sqrt(d2);
-            best = dist < best ? dist : best;
+            best2 = d2 < best2 ? d2 : best2;
         }
-        err = a.weight * best;
+        err = a.weight * sqrt(best2);
         if (a.res) a.res[b] = err;
     } else if (a.type == MG_FRAME_DISCRETE_TRAJECTORY) {
         // per frame the distance to the list's point of the same index, unconstrained axes zeroed, frames beyond the list 0;
@@ -521,28 +523,45 @@ struct mg_track_args {
     int32_t align_m;
 };
 
+// MG_TRACK_CANDS candidates per workgroup: an eigenvector element read from L2 (the kernel's bound: NB x n_chan x L of them per
+// workgroup) feeds that many fma chains.
 #define MG_TRACK_BLOCK 128
+#define MG_TRACK_CANDS 4
 __global__ __launch_bounds__(MG_TRACK_BLOCK) void mg_joint_tracks_kernel(const mg_track_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *cp = (double *)smem;                    // [NB][n_chan] control points of the kept channels
-    double *s = cp + (size_t)a.NB * a.n_chan;       // [L]
-    double *al = s + a.L;                           // [8]: c, s, tx, tz, ty, aw, ay
-    int *slot = (int *)(al + 8);                    // [D]
-    const int64_t b = blockIdx.x;
+    const int ncp = a.NB * a.n_chan;
+    double *cp_all = (double *)smem;                            // [CANDS][NB][n_chan] control points of the kept channels
+    double *s_all = cp_all + (size_t)MG_TRACK_CANDS * ncp;      // [CANDS][L]
+    double *al_all = s_all + (size_t)MG_TRACK_CANDS * a.L;      // [CANDS][8]: c, s, tx, tz, ty, aw, ay
+    int *slot = (int *)(al_all + MG_TRACK_CANDS * 8);           // [D]
+    const int64_t b0 = (int64_t)blockIdx.x * MG_TRACK_CANDS;
     const int tid = threadIdx.x, nc = a.n_chan, D = a.D, R = a.R, L = a.L;
-    for (int k = tid; k < L; k += MG_TRACK_BLOCK) s[k] = a.lat_f64 ? ((const double *)a.lat)[b * a.ld + k] : (double)((const float *)a.lat)[b * a.ld + k];
+    for (int e = tid; e < MG_TRACK_CANDS * L; e += MG_TRACK_BLOCK) {
+        const int c = e / L, k = e - c * L;
+        const int64_t bb = b0 + c < a.B ? b0 + c : a.B - 1;     // (a short last group repeats the last candidate; nothing of it is written)
+        s_all[e] = a.lat_f64 ? ((const double *)a.lat)[bb * a.ld + k] : (double)((const float *)a.lat)[bb * a.ld + k];
+    }
     for (int d = tid; d < D; d += MG_TRACK_BLOCK) slot[d] = a.slot[d];
     __syncthreads();
-    for (int e = tid; e < a.NB * nc; e += MG_TRACK_BLOCK) {
+    for (int e = tid; e < ncp; e += MG_TRACK_BLOCK) {
         const int i = e / nc, q = e - i * nc;
         const int r = i * D + a.chan[q];
-        double acc = a.mean[r];
-        for (int k = 0; k < L; k++) acc = fma(a.Et64[(size_t)k * R + r], s[k], acc);
-        cp[e] = acc;
+        double acc[MG_TRACK_CANDS];
+#pragma unroll
+        for (int c = 0; c < MG_TRACK_CANDS; c++) acc[c] = a.mean[r];
+        for (int k = 0; k < L; k++) {
+            const double ev = a.Et64[(size_t)k * R + r];
+#pragma unroll
+            for (int c = 0; c < MG_TRACK_CANDS; c++) acc[c] = fma(ev, s_all[c * L + k], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < MG_TRACK_CANDS; c++) cp_all[(size_t)c * ncp + e] = acc[c];
     }
     __syncthreads();
-    if (tid == 0 && a.align_mode != 0) {
+    if (tid < MG_TRACK_CANDS && a.align_mode != 0) {
         // the candidate's aligning transform from its FIRST control point (a clamped spline's value at t = 0)
+        const double *cp = cp_all + (size_t)tid * ncp;
+        double *al = al_all + tid * 8;
         auto ch0 = [&](int ch) { return cp[slot[ch]]; };
         const double p0x = ch0(0), p0z = ch0(2);
         double c, sn, ty;
@@ -580,13 +599,16 @@ __global__ __launch_bounds__(MG_TRACK_BLOCK) void mg_joint_tracks_kernel(const m
     }
     __syncthreads();
     const bool aligned = a.align_mode != 0;
-    const double ac = al[0], as = al[1], tx = al[2], tz = al[3], ty = al[4], qaw = al[5], qay = al[6];
+    const int n_here = a.B - b0 < MG_TRACK_CANDS ? (int)(a.B - b0) : MG_TRACK_CANDS;
     for (int rq = 0; rq < a.n_requests; rq++) {
         const int T = a.T[rq], j0 = a.req_joint0[rq], J = a.req_joint0[rq + 1] - j0;
         const int32_t *i0 = a.i0[rq];
         const double *w = a.w[rq];
-        double *out = a.out[rq] + b * (int64_t)T * J * 3;
-        for (int e = tid; e < T * J; e += MG_TRACK_BLOCK) {
+        for (int ce = tid; ce < n_here * T * J; ce += MG_TRACK_BLOCK) {
+            const int c = ce / (T * J), e = ce - c * (T * J);
+            const double *cp = cp_all + (size_t)c * ncp, *al = al_all + c * 8;
+            const double ac = al[0], as = al[1], tx = al[2], tz = al[3], ty = al[4], qaw = al[5], qay = al[6];
+            double *out = a.out[rq] + (b0 + c) * (int64_t)T * J * 3;
             const int f = e / J, j = e - f * J;
             const double *wf = w + 4 * (size_t)f;
             const double *cf = cp + (size_t)i0[f] * nc;
@@ -760,7 +782,7 @@ extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64
         a.h0 = al->heading[0] / hn; a.h1 = al->heading[1] / hn; a.px = al->position[0]; a.py = al->position[1]; a.pz = al->position[2];
         for (int e = 0; e < 3; e++) a.ref[e] = al->ref_dir[e];
     }
-    const size_t lds = ((size_t)p->NB * pl->n_chan + p->L + 8) * 8 + (size_t)p->D * 4 + 16;
+    const size_t lds = (size_t)MG_TRACK_CANDS * ((size_t)p->NB * pl->n_chan + p->L + 8) * 8 + (size_t)p->D * 4 + 16;
     if (lds > 160 * 1024 - 64) { mg_set_error("mg_joint_tracks: %d basis functions x %d channels do not fit LDS", p->NB, pl->n_chan); return MG_ERR_UNSUPPORTED; }
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
     if (lds > 48 * 1024 && !(p->ctx->attr_traj & 4u)) {
@@ -768,7 +790,7 @@ extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64
         p->ctx->attr_traj |= 4u;
     }
     mg_prof_begin(p->ctx, 8);
-    hipLaunchKernelGGL(mg_joint_tracks_kernel, dim3((unsigned)B), dim3(MG_TRACK_BLOCK), lds, p->ctx->stream, a);
+    hipLaunchKernelGGL(mg_joint_tracks_kernel, dim3((unsigned)((B + MG_TRACK_CANDS - 1) / MG_TRACK_CANDS)), dim3(MG_TRACK_BLOCK), lds, p->ctx->stream, a);
     mg_prof_end(p->ctx, 8);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;

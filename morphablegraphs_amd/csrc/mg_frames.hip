@@ -32,7 +32,9 @@ int mg_setup_kernel_attributes(mg_context *) {
 
 bool mg_frames_root_split(const mg_primitive *p) {
     const int want = p->ctx->opt[MG_OPT_ROOT_MODE];
-    return want == 2 || (want == 0 && p->root_split);
+    // the float64 pipeline unless asked: the split measured SLOWER on the kernels it was meant to speed up (the sweep
+    // waves are issue-bound, its two extra additions and table reads cost more than wave 0's float64 stage, which is off the critical path)
+    return want == 2 || (want == 3 && p->root_split);
 }
 
 // LDS of the fused mixture scoring: two term buffers and two exp buffers of [K][16] float64

@@ -46,6 +46,31 @@ __device__ __forceinline__ bool mg_traj_d2_derivs(const double *poly, int n_seg,
     return true;
 }
 
+// Up to four Newton steps on the squared distance inside the bracket [lo, hi] of the grid minimum (one-sided at the ends of the
+// range), from *u_io clamped into it: the bracket's local minimum to rounding; a step that does not lower the distance ends the
+// refinement.  Returns the squared distance at the refined *u_io.  The search's statement evaluates the distance at a trial point and,
+// when the step is taken, the distance and its derivatives there again: mg_traj_d2_derivs' f0 IS mg_traj_d2's value, operation for
+// operation ((x^2 + y^2) + z^2 of the same Horner forms; no contraction), so one evaluation per step serves both -- the walk is a chain
+// of dependent evaluations, and this halves its Newton part.
+__device__ __forceinline__ double mg_traj_refine(const double *poly, int n_seg, double lo, double hi, double *u_io, const double *q) {
+    double u = fmin(hi, fmax(lo, *u_io));
+    double f0, f1, f2;
+    bool ok = mg_traj_d2_derivs(poly, n_seg, u, q, &f0, &f1, &f2);
+    if (!ok) f0 = mg_traj_d2(poly, n_seg, u, q);           // past the last segment: the last control point's distance, no derivatives
+    for (int it = 0; it < 4; it++) {
+        if (!ok || !(f2 > 0.0)) break;
+        const double un = fmin(hi, fmax(lo, u - f1 / f2));
+        if (un == u) break;                                 // a fixed point: every further step would repeat this one
+        double g0, g1, g2;
+        const bool okn = mg_traj_d2_derivs(poly, n_seg, un, q, &g0, &g1, &g2);
+        if (!okn) g0 = mg_traj_d2(poly, n_seg, un, q);
+        if (g0 > f0) break;
+        u = un; ok = okn; f0 = g0; f1 = g1; f2 = g2;
+    }
+    *u_io = u;
+    return f0;
+}
+
 // The distance from q to the closest point of the spline whose parameter is at or after *min_u, and that parameter back in *min_u
 // (the bound of the next frame's search): on the grid u_k = k / G walk forward from the bound while the squared distance falls,
 // refine by the parabola through the three values around the minimum, then by up to four Newton steps inside that bracket
@@ -70,20 +95,9 @@ __device__ __forceinline__ double mg_traj_closest_dist(const double *__restrict_
         const double den = da - 2.0 * dk + dc;
         if (den > 0.0) u = (k + 0.5 * (da - dc) / den) * invG;
     }
-    {   // up to four Newton steps on the squared distance inside the bracket of the grid minimum (one-sided at the ends of the
-        // range): the bracket's local minimum to rounding; a step that does not lower the distance ends the refinement
-        const double lo = fmax(min_u, (k - 1) * invG), hi = fmin(1.0, (k + 1) * invG);
-        u = fmin(hi, fmax(lo, u));
-        for (int it = 0; it < 4; it++) {
-            double f0, f1, f2;
-            if (!mg_traj_d2_derivs(a.poly, a.n_seg, u, q, &f0, &f1, &f2) || !(f2 > 0.0)) break;
-            const double un = fmin(hi, fmax(lo, u - f1 / f2));
-            if (mg_traj_d2(a.poly, a.n_seg, un, q) > f0) break;
-            u = un;
-        }
-    }
-    u = fmin(1.0, fmax(min_u, u));
-    double d2 = mg_traj_d2(a.poly, a.n_seg, u, q);
+    double d2 = mg_traj_refine(a.poly, a.n_seg, fmax(min_u, (k - 1) * invG), fmin(1.0, (k + 1) * invG), &u, q);
+    const double uc = fmin(1.0, fmax(min_u, u));            // (the bracket lies inside [min_u, 1]: a no-op kept from the statement of the search)
+    if (uc != u) { u = uc; d2 = mg_traj_d2(a.poly, a.n_seg, u, q); }
     if (d_start <= d2) { u = min_u; d2 = d_start; }
     *min_u_io = u;
     return sqrt(d2);
@@ -131,19 +145,9 @@ __device__ __forceinline__ double mg_traj_closest_dist_coop(const double *__rest
         const double den = da - 2.0 * dk + dc;
         if (den > 0.0) u = (k + 0.5 * (da - dc) / den) * invG;
     }
-    {
-        const double lo = fmax(min_u, (k - 1) * invG), hi = fmin(1.0, (k + 1) * invG);
-        u = fmin(hi, fmax(lo, u));
-        for (int it = 0; it < 4; it++) {
-            double f0, f1, f2;
-            if (!mg_traj_d2_derivs(poly, n_seg, u, q, &f0, &f1, &f2) || !(f2 > 0.0)) break;
-            const double un = fmin(hi, fmax(lo, u - f1 / f2));
-            if (mg_traj_d2(poly, n_seg, un, q) > f0) break;
-            u = un;
-        }
-    }
-    u = fmin(1.0, fmax(min_u, u));
-    double d2 = mg_traj_d2(poly, n_seg, u, q);
+    double d2 = mg_traj_refine(poly, n_seg, fmax(min_u, (k - 1) * invG), fmin(1.0, (k + 1) * invG), &u, q);
+    const double uc = fmin(1.0, fmax(min_u, u));
+    if (uc != u) { u = uc; d2 = mg_traj_d2(poly, n_seg, u, q); }
     if (d_start <= d2) { u = min_u; d2 = d_start; }
     *min_u_io = u;
     return sqrt(d2);

@@ -102,11 +102,12 @@ class COraclePrimitive(object):
         return out
 
     def frames_f32model(self, S, tp=None, root_split=None):
-        """root_split: None = the mode the contract's accuracy gate prescribes for this primitive."""
+        """root_split: None / False = the float64 pipeline for the root channels (the library's default), True = the mean/delta
+        split (MG_OPT_ROOT_MODE 2, or 3 where self.root_split -- the contract's accuracy gate -- allows it)."""
         S = _d(np.atleast_2d(S))   # float32 callers pass exactly representable values
         tp = self.canonical_time_function() if tp is None else _d(np.atleast_1d(tp))
         out = np.empty((S.shape[0], len(tp), self.D), dtype=np.float32)
-        split = self.root_split if root_split is None else bool(root_split)
+        split = bool(root_split)
         lib().orc_back_project_frames_f32model_mode(_ptr(self.E, _dp), _ptr(self.mean, _dp), _ptr(self.tm, _dp),
                                                     self.NB, self.D, self.L, _ptr(self.knots, _dp), _ptr(tp, _dp), len(tp),
                                                     _ptr(S, _dp), C.c_int64(S.shape[0]), C.c_int64(S.shape[1]),

@@ -1515,12 +1515,14 @@ def test_lds_resident_mixture_kernel_is_bit_identical(ctx, case):
 # The root channels' two modes (include/mg_hip.h, mg_primitive_root_mode): float64 pipeline and mean/delta split
 # ---------------------------------------------------------------------------------------------------------------------
 def test_root_mode_gate_agrees_with_the_oracle(ctx, golden_case):
-    """The accuracy gate is part of the float32 contract: the library and the oracle's restatement of it pick the same mode
-    for every golden primitive (and every other test's cp.frames_f32model(S) relies on that)."""
+    """The accuracy gate of the optional mean/delta split is part of the float32 contract: under MG_OPT_ROOT_MODE 3 the library
+    and the oracle's restatement of the gate pick the same mode for every golden primitive; the default is the float64 pipeline."""
     name, data, g = golden_case
     prim = _capi.Primitive(ctx, data)
     cp = c_oracle.COraclePrimitive(data)
     np.testing.assert_allclose(prim.root_split_estimate, cp.root_split_estimate, rtol=1e-12)
+    assert prim.root_split is False
+    ctx.set_option(_capi.MG_OPT_ROOT_MODE, 3)
     assert prim.root_split == cp.root_split, name
     ctx.set_option(_capi.MG_OPT_ROOT_MODE, 1)
     assert prim.root_split is False
@@ -1578,7 +1580,7 @@ def test_root_modes_bit_exact_on_every_kernel(ctx, golden_case, mode):
 @pytest.mark.parametrize("B", [17, 1000, 8192 + 5])
 def test_root_split_where_the_gate_allows_it(ctx, B):
     """A 'walk'-sized primitive whose root translation varies little between candidates (root rows of the eigenvectors not
-    scaled up): the gate picks the split by itself; results are bit for bit the oracle's model, within the north-star
+    scaled up): under MG_OPT_ROOT_MODE 3 the gate picks the split; results are bit for bit the oracle's model, within the north-star
     tolerance of the float64 frames (the reference's arithmetic, device float64 kernel pinned by the golden tests), the same
     from all three kernels and from the fused step."""
     data = synthetic.make_walk_primitive(seed=3, realistic=False)
@@ -1587,12 +1589,14 @@ def test_root_split_where_the_gate_allows_it(ctx, B):
     data["mean_spatial_vector"] = m.reshape(-1).tolist()
     prim = _capi.Primitive(ctx, data)
     cp = c_oracle.COraclePrimitive(data)
+    assert prim.root_split is False
+    ctx.set_option(_capi.MG_OPT_ROOT_MODE, 3)
     assert cp.root_split and prim.root_split and prim.root_split_estimate <= 5e-6
     rng = np.random.default_rng(B)
     for dtype in (np.float32, np.float64):
         S = (2.2 * rng.standard_normal((B, 40))).astype(dtype)   # the spread of the primitive's mixture (second moment ~5)
         n_model = min(B, 300)
-        model = cp.frames_f32model(S[:n_model].astype(np.float64))
+        model = cp.frames_f32model(S[:n_model].astype(np.float64), root_split=True)
         ref = prim.back_project_frames_f64(S[:n_model].astype(np.float64))
         direct = prim.back_project_frames(S[:n_model], path=_capi.MG_PATH_DIRECT)
         np.testing.assert_array_equal(_bits(direct), _bits(model))

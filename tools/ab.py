@@ -3,7 +3,7 @@
 SAME output buffer, variants interleaved round by round (cdna_hip_programming.md, methodology rule 24).
 
     python3 tools/ab.py VARIANT [VARIANT ...] [--rounds 6] [--steps 300] [--plain] [--two-launch]
-    VARIANT = path/to/lib.so[:debug_flags[:kernel[:window[:arena_MiB[:root]]]]]   root: MG_OPT_ROOT_MODE (0 gate, 1 float64, 2 split); kernel: 0 = by batch size, 1 = tile-major, 2 = chunk-stationary;
+    VARIANT = path/to/lib.so[:debug_flags[:kernel[:window[:arena_MiB[:root]]]]]   root: MG_OPT_ROOT_MODE (0, 1 float64, 2 split, 3 gate); kernel: 0 = by batch size, 1 = tile-major, 2 = chunk-stationary;
               window: MG_OPT_CHUNK_WINDOW (basis functions per time chunk, 0 = the planner's choice)
               e.g.  morphablegraphs_amd/csrc/libmg_hip.so  build/lib_x.so::1  dbg.so:1  dbg.so:512:2  lib.so::2:7
 

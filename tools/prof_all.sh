@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/<tag>_* is made from, on the GPU box, summarised there (the raw rocprofv3 output is too large to travel back):
 #   tools/prof_all.sh <tag>   ->  gpurun_out/profiles_<tag>/   (copy into profiles/)
-tag=${1:-r03}
+tag=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
@@ -11,7 +11,8 @@ cp $(find $R/gpurun_out/prof_$tag/trace -name '*kernel_stats.csv' | head -1) $O/
 grep -h "^{\"metric\"" $R/gpurun_out/prof_$tag/trace.log | tail -1 > $O/${tag}_bench_under_rocprof.json
 rm -rf $R/gpurun_out/prof_$tag
 bash $R/tools/prof_configs.sh $tag > $O/prof_configs.log 2>&1 || { tail -5 $O/prof_configs.log; exit 1; }
-for cfg in graph optimizer; do
+python3 $R/tools/summarize_prof.py $R/gpurun_out/prof_${tag}_frame_constraints $O/${tag}_frame_constraints_summary.json > /dev/null
+for cfg in graph optimizer frame_constraints; do
   cp $(find $R/gpurun_out/prof_${tag}_$cfg/trace -name '*kernel_stats.csv' | head -1) $O/${tag}_${cfg}_kernel_stats.csv
   cp $R/gpurun_out/prof_${tag}_$cfg/bench.json $O/${tag}_${cfg}_bench_under_rocprof.json
   rm -rf $R/gpurun_out/prof_${tag}_$cfg
