@@ -64,7 +64,10 @@ struct mg_fused_devcounts {       // what mg_options_counts_kernel leaves for th
     int32_t tile_end[MG_FUSED_MAX_OPTIONS];
 };
 
-struct mg_fused_partial { double v; int64_t i; };
+// A workgroup's first minimum AND that candidate's latent vector: published with agent-scope stores (write-through), read by the
+// option's last workgroup with agent-scope loads -- no release / acquire fence anywhere (an agent-scope release writes back the
+// XCD's whole L2, into which the step has just written 10 MB of candidates: 1068 of them per step were the kernel's latency chain)
+struct mg_fused_partial { double v; int64_t i; double row[4 * MG_MAX_KK]; };
 
 // The component counts of a step drawn ON THE DEVICE (mg_options_step_device_counts): a multinomial(n, weights) draw per option
 // as the histogram of n categorical draws, keyed by the option's seed --
@@ -252,29 +255,39 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
         mg_min_combine(best, bi, ov, (int64_t)oi);
     }
     if (lane == 0) { sv[wave] = best; si[wave] = bi; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's candidates and errors have left the CU
     __syncthreads();
     const int nwg = dyn.wg0[k + 1] - dyn.wg0[k];
+    // the workgroup's first minimum (every thread: four combines from LDS); the wave whose tile holds that row publishes its latent
+    // vector from the tile it still has in LDS (a workgroup without a finite error publishes the block's first row if it holds it: what
+    // a step without any finite error returns)
+    best = sv[0]; bi = si[0];
+    for (int w = 1; w < 4; w++) mg_min_combine(best, bi, sv[w], si[w]);
+    {
+        const int64_t pub = bi != INT64_MAX ? bi : row_lo;
+        const int64_t row0 = row_c + (t - tile_c) * 16;
+        const int64_t row_end = rows_next < row0 + 16 ? rows_next : row0 + 16;   // (a component's last tile may be short: the next rows are another tile's)
+        if (active && pub >= row0 && pub < row_end && lane < Lg)
+            __hip_atomic_store(&partials[wg].row[lane], zt[(int)(pub - row0) * ZS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid == 0) {
-        for (int w = 1; w < 4; w++) mg_min_combine(best, bi, sv[w], si[w]);
-        partials[wg].v = best;
-        partials[wg].i = bi;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&partials[wg].v, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partials[wg].i, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also this wave's candidates and errors; the write-through stores above are complete)
+    __syncthreads();
+    if (tid == 0) {
         const int old = __hip_atomic_fetch_add(&counters[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (old == nwg - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
-    // the option's last workgroup: every other one has published its partial and its candidates
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // the option's last workgroup: every other one has published its partial
     best = INFINITY; bi = INT64_MAX;
     for (int w = tid; w < nwg; w += 256) {
-        const mg_fused_partial p = partials[dyn.wg0[k] + w];
-        mg_min_combine(best, bi, p.v, p.i);
+        const mg_fused_partial *pp = &partials[dyn.wg0[k] + w];
+        const double pv = __hip_atomic_load(&pp->v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t pi = __hip_atomic_load(&pp->i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mg_min_combine(best, bi, pv, pi);
     }
     for (int off = 32; off > 0; off >>= 1) {
         const double ov = __shfl_down(best, off, 64);
@@ -285,28 +298,41 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 4; w++) mg_min_combine(best, bi, sv[w], si[w]);
+        si[1] = bi;                                  // the winner as the workgroups published it (INT64_MAX: none was finite)
         if (bi == INT64_MAX || bi < row_lo || bi >= row_hi) { bi = row_lo; best = INFINITY; }   // (an index outside the block cannot happen; never gather out of bounds)
         ((int64_t *)o.result)[0] = bi;
         ((double *)o.result)[1] = best;
-        if (o.result_host) { ((int64_t *)o.result_host)[0] = bi; ((double *)o.result_host)[1] = best; }
+        if (o.result_host) {    // (system-scope stores: straight to the pinned record, complete when vmcnt says so -- no fence below)
+            __hip_atomic_store((int64_t *)o.result_host, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store((double *)o.result_host + 1, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         si[0] = bi;
         counters[k] = 0;   // ready for the next launch (stream ordered)
     }
     __syncthreads();
-    const int64_t idx = si[0];
+    // whose row: the workgroup that published the winner's index (no finite error anywhere: the first workgroup, which then published
+    // the block's first row)
+    const int64_t widx = si[1];
+    if (tid == 0) s_last = 0;
+    __syncthreads();
+    if (widx != INT64_MAX)
+        for (int w = tid; w < nwg; w += 256)
+            if (__hip_atomic_load(&partials[dyn.wg0[k] + w].i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == widx) s_last = w;
+    __syncthreads();
+    const mg_fused_partial *win = &partials[dyn.wg0[k] + s_last];
     double *row = (double *)((char *)o.result + 16);
     double *row_h = o.result_host ? (double *)((char *)o.result_host + 16) : nullptr;
     for (int i = tid; i < Lg; i += 256) {
-        const double v = X_F64 ? ((const double *)o.x)[(idx - row_lo) * ld + i] : (double)((const float *)o.x)[(idx - row_lo) * ld + i];
+        const double v = __hip_atomic_load(&win->row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         row[i] = v;
-        if (row_h) row_h[i] = v;
+        if (row_h) __hip_atomic_store(row_h + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (dyn.flags_host) {   // the record is complete on the host before its flag says so
+    if (dyn.flags_host) {   // the record is complete on the host before its flag says so: every thread's record stores have been
+        // acknowledged (vmcnt) before the barrier, the flag leaves after it -- a system-scope release fence here would write back
+        // the whole L2 (the step's candidates) first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __threadfence_system();
-            __hip_atomic_store(dyn.flags_host + k, dyn.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (tid == 0) __hip_atomic_store(dyn.flags_host + k, dyn.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
