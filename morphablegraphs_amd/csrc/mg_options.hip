@@ -114,21 +114,17 @@ __global__ __launch_bounds__(256) void mg_options_counts_kernel(const mg_fused_s
         if (lane == 0) below[wave][c] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-        int64_t tiles = 0;
-        int prev = 0;
-        for (int c = 0; c < MG_SAMPLE_ARG_K; c++) {
-            int cnt = 0;
-            if (c < K) {
-                const int cumc = c < K - 1 ? below[0][c] + below[1][c] + below[2][c] + below[3][c] : (int)n;
-                cnt = cumc - prev;
-                prev = cumc;
-            }
-            dc->counts[k][c] = cnt;
-            if (counts_host) counts_host[k * MG_SAMPLE_ARG_K + c] = cnt;
-            tiles += (cnt + 15) / 16;
-        }
-        dc->tile_end[k] = (int32_t)tiles;
+    if (tid < MG_SAMPLE_ARG_K) {
+        // lane c: component c's count; ONE 64-byte store to the device copy and one to the pinned host copy (sixteen 4-byte stores to
+        // pinned memory in a row from one lane were most of this kernel's 9.3 us: each is a transaction the kernel's end waits for)
+        const int c = tid;
+        auto cum_at = [&](int q) { return q < 0 ? 0 : (q < K - 1 ? below[0][q] + below[1][q] + below[2][q] + below[3][q] : (int)n); };
+        const int cnt = c < K ? cum_at(c) - cum_at(c - 1) : 0;
+        dc->counts[k][c] = cnt;
+        if (counts_host) counts_host[k * MG_SAMPLE_ARG_K + c] = cnt;
+        int tiles = (cnt + 15) / 16;
+        for (int off = 8; off > 0; off >>= 1) tiles += __shfl_down(tiles, off, 16);
+        if (c == 0) dc->tile_end[k] = tiles;
     }
 }
 

@@ -6,6 +6,7 @@ import numpy as np
 from morphablegraphs_amd import _capi, synthetic
 from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
 N = int(os.environ.get("N", "4096"))
+DEVC = os.environ.get("DEVC", "1") == "1"     # component counts drawn on the device (bench.py --config graph does)
 prims = synthetic.make_graph_primitives(int(os.environ.get("NOPT", "16")))
 names = [p["name"] for p in prims]
 cons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]},
@@ -13,12 +14,12 @@ cons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weig
 for path in (sys.argv[1:] or [None]):
     ctx = _capi.Context(0, lib=_capi.load_library(os.path.abspath(path))) if path else _capi.Context(0)
     pset = HipPrimitiveSet(prims, context=ctx)
-    for i in range(100): pset.evaluate_options_on_device(names, cons, N, seed=i)
+    for i in range(100): pset.evaluate_options_on_device(names, cons, N, seed=i, device_counts=DEVC)
     t0 = time.perf_counter()
-    for i in range(1000): pset.evaluate_options_on_device(names, cons, N, seed=i)
+    for i in range(1000): pset.evaluate_options_on_device(names, cons, N, seed=i, device_counts=DEVC)
     wall = (time.perf_counter() - t0) / 1000 * 1e6
     ctx.profile_reset(); ctx.profile_enable(1)
-    for i in range(200): pset.evaluate_options_on_device(names, cons, N, seed=i)
+    for i in range(200): pset.evaluate_options_on_device(names, cons, N, seed=i, device_counts=DEVC)
     ctx.profile_enable(0)
     ms, cnt = ctx.profile_get("options_step")
     print("%-28s step %.1f us, fused kernel %.1f us (%d launches)" % (path or "default", wall, 1e3 * ms / max(cnt, 1), cnt), flush=True)
