@@ -272,6 +272,7 @@ struct mg_objective_args {
     mg_score_args sa;            // sa.out unused
     const double *Wpack, *bpad;  // [RT][KK][64], [RT*16]
     int32_t RT, rows, wave_doubles;   // wave_doubles: the wave's LDS buffer (terms + exponentials, then reused for channels + residuals)
+    int32_t pair_doubles;             // > 0: a second channel buffer per wave behind the sixteen wave buffers -- the residuals of TWO tiles in one pass
     double error_scale, quality_scale;
     double *err_out, *obj_out;   // (B) float64 each, or NULL
 };
@@ -307,6 +308,14 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
     for (int e = tid; e < K * JT * 16; e += 1024) lds_c[e] = -mP[e];
     __syncthreads();
     mg_lds_f64 *terms = lds_w + (size_t)wave * (SCORE ? oa.wave_doubles : 2 * K * 16), *exps = terms + K * 16;
+    // SCORE, pairs: the residual lanes are the kernel's vector work (a direction residual is five roots, six divisions and an arc cosine
+    // in float64; vector work on a SIMD takes the matrix pipe's issue slots) and a tile fills 16 n of a wave's 64 lanes.  A wave therefore
+    // parks the channels of every other tile in a second buffer and scores two tiles' candidates in one pass: half the instructions.
+    double *vals_b = SCORE && oa.pair_doubles > 0 ? (double *)(lds_w + (size_t)16 * oa.wave_doubles + (size_t)wave * oa.pair_doubles) : nullptr;
+    bool pending = false;
+    double r_a = 0.0;
+    int64_t b0_a = 0;
+    int ncand_a = 0;
     // tile t of the launch: workgroup t % grid, wave (t / grid) % 16 -- consecutive tiles go to different CUs.  (Requesting the
     // next tile's latents a tile ahead changes nothing: the other three waves of the SIMD cover the load.)
     for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += (int64_t)gridDim.x * 16) {
@@ -348,7 +357,8 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
         if constexpr (SCORE) {
             // the wave's buffer again, now for the tile's pose channels and residuals (LDS serves a wave's requests in order)
             const int RT = oa.RT, rows = oa.rows, vs = rows + 1, n = oa.sa.n;   // (only the rows in use are kept: sixteen waves share the LDS)
-            double *vals = (double *)terms, *resid = vals + 16 * vs;
+            const bool park = vals_b != nullptr && !pending && tile + (int64_t)gridDim.x * 16 < n_tiles;   // another tile follows: score the two together
+            double *vals = park ? vals_b : (double *)terms, *resid = (double *)terms + 16 * vs;           // resid: [2][n][16]
             for (int rt = 0; rt < RT; rt++) {
                 const double *wp = oa.Wpack + ((size_t)rt * KK) * 64 + lane;
                 const double c0 = oa.bpad[rt * 16 + cl];
@@ -360,22 +370,39 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
                     for (int rr = 0; rr < 4; rr++) vals[(g + 4 * rr) * vs + rt * 16 + cl] = acc[rr];
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (int e = lane; e < 16 * n; e += 64) {
-                const int cand = e & 15, c = e >> 4;
-                const double *v = vals + cand * vs;
-                resid[c * 16 + cand] = mg_constraint_residual<true>(oa.sa, c, [&](int row) { return v[row]; }, b0 + cand);
+            if (park) {
+                pending = true; r_a = r; b0_a = b0; ncand_a = ncand;
+                continue;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < ncand) {
-                double err = 0.0;
-                for (int c = 0; c < n; c++) err += resid[c * 16 + lane];
-                if (oa.err_out) oa.err_out[b0 + lane] = err;
-                if (oa.obj_out) {
-                    const double e_part = oa.error_scale * err, q_part = -r * oa.quality_scale;   // (rounded separately, like the host's array arithmetic)
-                    oa.obj_out[b0 + lane] = e_part + q_part;
+            const int per = 16 * n, items = pending ? 2 * per : per;      // the parked tile's candidates first, then this tile's
+            for (int e = lane; e < items; e += 64) {
+                const int second = (pending && e >= per) ? 1 : 0, rem = e - second * per;
+                const int cand = rem & 15, c = rem >> 4;
+                const bool from_b = pending && !second;
+                const double *v = (from_b ? vals_b : (const double *)terms) + cand * vs;
+                resid[(second * n + c) * 16 + cand] = mg_constraint_residual<true>(oa.sa, c, [&](int row) { return v[row]; }, (from_b ? b0_a : b0) + cand);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                const int second = (pending && lane >= 16) ? 1 : 0, cand = lane & 15;
+                const bool mine_a = pending && !second;
+                const int nc = mine_a ? ncand_a : ncand;
+                // (the log-likelihood of candidate `cand` sits in lane cand: r of this tile, r_a of the parked one)
+                const double lp_b = __shfl(r, cand), lp_a = __shfl(r_a, cand);
+                if (lane < (pending ? 32 : 16) && cand < nc) {
+                    const int64_t bb = (mine_a ? b0_a : b0) + cand;
+                    const double lp = mine_a ? lp_a : lp_b;
+                    double err = 0.0;
+                    for (int c = 0; c < n; c++) err += resid[(second * n + c) * 16 + cand];
+                    if (oa.err_out) oa.err_out[bb] = err;
+                    if (oa.obj_out) {
+                        const double e_part = oa.error_scale * err, q_part = -lp * oa.quality_scale;   // (rounded separately, like the host's array arithmetic)
+                        oa.obj_out[bb] = e_part + q_part;
+                    }
                 }
             }
+            pending = false;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the next tile's terms land in the same buffer
         }
     }
@@ -390,7 +417,7 @@ static int mg_gmm_lds_nf(int KK, int JT) {
 // B = 8192 9.9 / 15.6, 16384 16.6 / 16.9, 32768 30.2 / 24.8, 65536 51.0 / 38.9, 131072 91.0 / 67.4)
 #define MG_GMM_LDS_MIN_B 20480
 static int mg_objective_wave_doubles(const mg_primitive *p, const mg_constraint_set *cs) {
-    return std::max(2 * p->K * 16, 16 * (cs->rows + 1) + 16 * std::max(cs->n, 1));   // channels [16][rows + 1], residuals [n][16]
+    return std::max(2 * p->K * 16, 16 * (cs->rows + 1) + 32 * std::max(cs->n, 1));   // channels [16][rows + 1], residuals [2][n][16]
 }
 template <int KK>
 static int mg_launch_gmm_lds_kk(mg_primitive *p, const void *x, int xdt, int64_t B, int64_t ld, void *out, int odt,
@@ -402,13 +429,17 @@ static int mg_launch_gmm_lds_kk(mg_primitive *p, const void *x, int xdt, int64_t
     mg_objective_args oa;
     memset(&oa, 0, sizeof(oa));
     const int wave_doubles = cs ? mg_objective_wave_doubles(p, cs) : 2 * p->K * 16;
-    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(KK, a.JT) * 64 + (size_t)p->K * a.JT * 16 + (size_t)16 * wave_doubles) * 8;
+    size_t lds = ((size_t)p->K * mg_gmm_lds_nf(KK, a.JT) * 64 + (size_t)p->K * a.JT * 16 + (size_t)16 * wave_doubles) * 8;
+    const int pair_doubles = cs ? 16 * (cs->rows + 1) : 0;
+    const bool pairs = cs && lds + (size_t)16 * pair_doubles * 8 <= 160 * 1024;   // room for the second channel buffers: two tiles per residual pass
+    if (pairs) lds += (size_t)16 * pair_doubles * 8;
     if (cs) {
         mg_score_args &sa = oa.sa;
         sa.W = cs->d_W; sa.bias = cs->d_bias; sa.par = cs->d_par; sa.woff = cs->d_woff; sa.chain = cs->d_chain; sa.choff = cs->d_choff;
         sa.align = cs->d_align; sa.align_cand = nullptr; sa.pose = cs->d_pose; sa.lat = x; sa.out = nullptr; sa.res = nullptr; sa.B = B; sa.ld = ld;
         sa.n = cs->n; sa.nch = cs->nch; sa.L = p->L;
         oa.Wpack = cs->d_Wpack; oa.bpad = cs->d_bpad; oa.RT = cs->RT; oa.rows = cs->rows; oa.wave_doubles = wave_doubles;
+        oa.pair_doubles = pairs ? pair_doubles : 0;
         oa.error_scale = error_scale; oa.quality_scale = quality_scale; oa.err_out = err_out; oa.obj_out = obj_out;
     }
     // every CU gets a workgroup as soon as there are that many tiles: the tiles of a workgroup run side by side on its sixteen
