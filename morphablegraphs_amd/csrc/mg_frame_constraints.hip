@@ -459,16 +459,33 @@ extern "C" int mg_score_frame_constraints(mg_primitive *p, int32_t n_constraints
     if (B > 0 && !errors_dev) { mg_set_error("mg_score_frame_constraints: errors_dev is NULL"); return MG_ERR_INVALID_ARGUMENT; }
     if (n_constraints == 0 || B == 0) return MG_OK;
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
-    for (int k0 = 0; k0 < n_constraints; k0 += MG_FC_LIST_MAX) {
-        mg_fc_list L = {};
-        L.n = std::min(MG_FC_LIST_MAX, n_constraints - k0);
-        L.accumulate = (accumulate || k0 > 0) ? 1 : 0;
-        L.B = B; L.out = errors_dev;
-        for (int i = 0; i < L.n; i++) {
-            if (!tracks_dev[k0 + i]) { mg_set_error("mg_score_frame_constraints: tracks of constraint %d are NULL", k0 + i); return MG_ERR_INVALID_ARGUMENT; }
-            int rc = mg_fc_args_from_desc("mg_score_frame_constraints", p, constraints[k0 + i], tracks_dev[k0 + i], B, n_times[k0 + i], n_joints[k0 + i],
-                                          residuals_dev ? residuals_dev[k0 + i] : nullptr, &L.c[i]);
+    // Groups of up to MG_FC_LIST_MAX constraints per launch, in list order.  A joint's TrajectoryConstraint below 65 536 candidates is a
+    // launch of its own: mg_score_trajectory_points walks with eight lanes per candidate there (half the time of this scorer's one lane),
+    // and adds the same number at the same place in the sum -- the groups around it accumulate in order.
+    bool any = accumulate != 0;
+    int k0 = 0;
+    while (k0 < n_constraints) {
+        const mg_frame_constraint_desc *c0 = constraints[k0];
+        if (c0 && c0->type == MG_FRAME_JOINT_TRAJECTORY && B <= 65536 && n_joints[k0] == 1 && c0->trajectories[0] && tracks_dev[k0]) {
+            const int rc = mg_score_trajectory_points(p, c0->trajectories[0], tracks_dev[k0], B, n_times[k0], c0->start_arc, c0->weight, errors_dev, any ? 1 : 0,
+                                                      residuals_dev ? residuals_dev[k0] : nullptr);
             if (rc != MG_OK) return rc;
+            any = true;
+            k0++;
+            continue;
+        }
+        mg_fc_list L = {};
+        L.accumulate = any ? 1 : 0;
+        L.B = B; L.out = errors_dev;
+        while (L.n < MG_FC_LIST_MAX && k0 + L.n < n_constraints) {
+            const int i = k0 + L.n;
+            const mg_frame_constraint_desc *c = constraints[i];
+            if (L.n > 0 && c && c->type == MG_FRAME_JOINT_TRAJECTORY && B <= 65536) break;     // (the next group's business)
+            if (!tracks_dev[i]) { mg_set_error("mg_score_frame_constraints: tracks of constraint %d are NULL", i); return MG_ERR_INVALID_ARGUMENT; }
+            int rc = mg_fc_args_from_desc("mg_score_frame_constraints", p, c, tracks_dev[i], B, n_times[i], n_joints[i],
+                                          residuals_dev ? residuals_dev[i] : nullptr, &L.c[L.n]);
+            if (rc != MG_OK) return rc;
+            L.n++;
         }
         const size_t lds = mg_fc_place_tables(L.c, L.n);
         if (lds) { const int rc = mg_fc_attributes(p->ctx); if (rc != MG_OK) return rc; }
@@ -478,6 +495,8 @@ extern "C" int mg_score_frame_constraints(mg_primitive *p, int32_t n_constraints
         else hipLaunchKernelGGL(mg_frame_constraint_list_kernel<false>, grid, dim3(MG_FC_BLOCK), 0, p->ctx->stream, L);
         mg_prof_end(p->ctx, 9);
         MG_HIP_CHECK(hipGetLastError());
+        any = true;
+        k0 += L.n;
     }
     return MG_OK;
 }
