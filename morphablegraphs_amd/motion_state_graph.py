@@ -510,9 +510,13 @@ class HipPrimitiveSet(object):
                 return options[int(np.argmin(errs))], results
         for k, st in enumerate(steps):   # the component counts, in option order, from NumPy's global stream
             plan["counts"][k, :len(st[8])] = multinomial(n, st[8])
+        if any(cs is None for cs in csets) and plan["one_context"] and steps:
+            mixed = self._mixed_step(plan, steps, csets, general, n, seed, dtype, code)
+            if mixed is not None:
+                return options[int(np.argmin([mixed[nm][1] for nm in options]))], mixed
         if any(cs is None for cs in csets):
-            # at least one option needs the general chain: the whole step goes option by option (same draws: the sampler is keyed
-            # by seed + option index and the counts above)
+            # at least one option needs the general chain and the mixed step does not cover it: the whole step goes option by option
+            # (same draws: the sampler is keyed by seed + option index and the counts above)
             from .candidate_scoring import sample_rows_and_first_minimum
             results = {}
             for k, (name, node, prim, ctx, d_x, d_e, d_r, L, pvals) in enumerate(steps):
@@ -550,6 +554,71 @@ class HipPrimitiveSet(object):
                 results[name] = (raw[16:].view(np.float64).astype(dtype).astype(np.float64), err)
         errors = [results[n][1] for n in options]
         return options[int(np.argmin(errors))], results
+
+    def _mixed_step(self, plan, steps, csets, general, n, seed, dtype, code):
+        """A planner step in which some options carry trajectory or per-frame constraints (csets[k] is None for them): ONE launch
+        still draws every option's candidates and scores their KEYFRAME constraints (mg_options_step, component counts already in
+        the plan); the options with more then add the rest to their errors where the launch left them -- one launch per root
+        trajectory, two per list of per-frame constraints (mg_joint_tracks + mg_score_frame_constraints) -- and take their own first
+        minimum (one launch, one small read-back).  The additions are the general chain's, in its order: the same errors and
+        winners, bit for bit (round 3 ran such a step option by option: sampler, scorer, ... per option).  None: not covered (an
+        option without keyframe constraints, a trajectory aligned by another node than the root) -- the caller goes option by option."""
+        from .candidate_scoring import cached_constraint_set, cached_trajectory, split_trajectories
+        from .frame_constraints import TrackScorer, split_frame_constraints, add_frame_constraints_dev
+        extras, sets = {}, list(csets)
+        for k, st in enumerate(steps):
+            if sets[k] is not None:
+                continue
+            form, alignment, sk = general[k]
+            fused, frames = split_frame_constraints(form)
+            keyframes, trajectories = split_trajectories(fused)
+            if not keyframes:
+                return None
+            if alignment is not None and trajectories and alignment.get("joint", 0) not in (0, _capi.MG_ALIGN_START_POSE):
+                return None
+            sets[k] = cached_constraint_set(st[2], keyframes, sk, alignment)
+            extras[k] = (trajectories, frames, alignment, sk)
+        m, stride, host = len(steps), plan["stride"], plan["host"]
+        for k, cs in enumerate(sets):
+            plan["csets"][k] = cs.handle.value
+        np.add(plan["karange"], np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out=plan["seeds_np"])
+        rc = plan["lib"].mg_options_step(m, plan["prims"], plan["csets"], n, plan["cnts"], plan["seeds"], plan["xs"], code, plan["lds"],
+                                         plan["errs"], plan["shared_ptr"], stride, plan["host_ptr"])
+        if rc == -4:      # MG_ERR_UNSUPPORTED: an option the one-launch kernel does not take
+            return None
+        if rc != 0:
+            _capi._check(rc)
+        rec = host[:m * stride].copy().reshape(m, stride)
+        errs = rec[:, 8:16].copy().view(np.float64)[:, 0].tolist()
+        lat = rec[:, 16:].copy().view(np.float64)
+        results = {st[0]: (lat[k, :st[7]], errs[k]) for k, st in enumerate(steps) if k not in extras}
+        scorers = plan.setdefault("track_scorers", {})
+        for k, (trajectories, frames, alignment, sk) in extras.items():
+            name, node, prim, ctx, d_x, d_e, d_r, L, pvals = steps[k]
+            for c in trajectories:
+                prim.score_trajectory_dev(cached_trajectory(prim, c), d_x, dtype, n, L, d_e, c.get("min_u", 0.0), c.get("weight", 1.0), alignment, accumulate=True)
+            if frames:
+                key = (k, _cs._freeze(frames), _cs._freeze(alignment), None if sk is None else sk.serial)
+                scorer = scorers.get(key)
+                if scorer is None:
+                    if len(scorers) > 64:
+                        for old in scorers.values():
+                            if old:
+                                old.close()
+                        scorers.clear()
+                    try:
+                        scorer = TrackScorer(prim, frames, sk, alignment)
+                    except NotImplementedError:
+                        scorer = False        # (a joint-rotation constraint, more than four requests: the frames chain)
+                    scorers[key] = scorer
+                if scorer:
+                    scorer.score_dev(d_x, dtype, n, L, d_e, accumulate=True)
+                else:
+                    add_frame_constraints_dev(prim, ctx.download(d_x, (n, L), dtype), frames, sk, alignment, d_e, accumulate=True)
+            idx, err = ctx.argmin_first(d_e, n, np.float64)
+            row = ctx.download(d_x.ptr.value + idx * L * np.dtype(dtype).itemsize, (L,), dtype)
+            results[name] = (row.astype(np.float64), err)
+        return results
 
     def options_step_rows(self, cmd, row_begin, row_end, skeleton=None):
         """One rank's share of a sharded planner step (distributed._cmd_options_step): the global rows [row_begin, row_end) of

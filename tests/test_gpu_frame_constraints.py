@@ -258,10 +258,11 @@ def test_arc_length_look_up_on_the_device_against_the_reference_vectors():
             b.free()
 
 
-def test_planner_step_scores_options_with_per_frame_constraints_by_the_general_chain():
+def test_planner_step_scores_options_with_per_frame_constraints_like_the_general_chain():
     """evaluate_options_on_device is one launch for keyframe constraints; an option that carries a trajectory or per-frame
-    constraint sends the step through the general chain option by option -- the same draws (component counts in option order from
-    NumPy's stream, sampler keyed by seed + option index), so every option's answer is what sample_and_evaluate_on_device gives."""
+    constraint adds those to the errors that launch left on the device and takes its own first minimum (round 3: the whole step
+    went option by option) -- the same draws (component counts in option order from NumPy's stream, sampler keyed by seed + option
+    index) and the same additions in the same order, so every option's answer is what sample_and_evaluate_on_device gives."""
     from morphablegraphs_amd.candidate_scoring import sample_and_evaluate_on_device
     from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
     prims = synthetic.make_graph_primitives(3)
@@ -276,7 +277,13 @@ def test_planner_step_scores_options_with_per_frame_constraints_by_the_general_c
                                        {"type": "trajectory", "control_points": [[0.0, 0.0, 0.0], [5.0, 0.0, 2.0], [12.0, 0.0, 3.0]], "min_u": 0.0, "weight": 0.5,
                                         "granularity": 1000}]
     np.random.seed(17)
+    pset.ctx.profile_reset(); pset.ctx.profile_enable(1)
     best, res = pset.evaluate_options_on_device(names, cons, n_samples=777, seed=40)
+    # round 4: ONE launch still samples every option and scores its keyframe constraints (no sampler, no scorer launch per option);
+    # the options with more add a launch per root trajectory and two per list of per-frame constraints
+    assert pset.ctx.profile_get(7)[1] == 1 and pset.ctx.profile_get(4)[1] == 0 and pset.ctx.profile_get(2)[1] == 0
+    assert pset.ctx.profile_get("joint_tracks")[1] >= 1 and pset.ctx.profile_get("frame_constraints")[1] >= 1
+    pset.ctx.profile_enable(0)
     np.random.seed(17)
     for k, nm in enumerate(names):
         lat, err = sample_and_evaluate_on_device(pset.nodes[nm], cons[nm], 777, seed=40 + k)
