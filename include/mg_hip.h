@@ -433,6 +433,14 @@ void mg_trajectory_destroy(mg_trajectory *trajectory);
 int mg_score_trajectory(mg_primitive *prim, const mg_trajectory *trajectory, const mg_time_grid *grid, const void *latents_dev,
                         int latent_dtype, int64_t n_samples, int64_t ld, double min_u, double weight, const mg_alignment_desc *alignment,
                         double *errors_dev, int accumulate, double *residuals_dev);
+/* n such scorers of the same batch size in ONE launch -- a planner step scores every option's candidates against the option's own
+ * trajectory (reference graph_walk_planner.py:184-226 with a TrajectoryConstraint in every option's constraint list): 4096
+ * candidates fill a quarter of the chip, sixteen launches in a row take sixteen times one, side by side they take four.  The
+ * primitives must share a context; canonical grids; no residual vectors; alignments: NULL, or n records of which any may be NULL.
+ * The same results as n calls of mg_score_trajectory, which this falls back to where the eight-lane walk does not apply. */
+int mg_score_trajectories(int32_t n, mg_primitive *const *prims, const mg_trajectory *const *trajectories, const void *const *latents_dev,
+                          int latent_dtype, int64_t n_samples, const int64_t *ld, const double *min_u, const double *weight,
+                          const mg_alignment_desc *const *alignments, double *const *errors_dev, int accumulate);
 
 /* The same search for positions the caller supplies: points_dev (n_samples, n_times, 3) float64 -- one joint's track from
  * mg_back_project_frames_f64 + mg_joint_positions, aligned by the caller -- for TrajectoryConstraint on joints other than the

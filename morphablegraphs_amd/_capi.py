@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_root_mode", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host", "mg_time_function_sample", "mg_back_project_frames_at",
-    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_score_trajectory_points", "mg_joint_positions",
+    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_score_trajectories", "mg_score_trajectory_points", "mg_joint_positions",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
@@ -256,6 +256,7 @@ def load_library(path=None):
         "mg_trajectory_create": [vp, vp, i32, i32, C.POINTER(vp)],
         "mg_joint_positions": [vp, vp, vp, i32, vp, i64, i32, vp],
         "mg_score_trajectory": [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, i32, vp],
+        "mg_score_trajectories": [i32, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, i32],
         "mg_score_trajectory_points": [vp, vp, vp, i64, i32, dbl, dbl, vp, i32, vp],
         "mg_align_frames": [vp, vp, i64, i32, vp, i32, C.POINTER(AlignmentDesc)],
         "mg_frame_constraint_width": [C.POINTER(FrameConstraintDesc), i32],
@@ -905,6 +906,20 @@ class Primitive(object):
         _check(self.lib.mg_score_trajectory(self.handle, trajectory.handle, self._grid_handle(grid), _dev_ptr(lat_dev), code, int(n), int(ld),
                                             float(min_u), float(weight), C.byref(al) if al is not None else None, _dev_ptr(errors_dev),
                                             1 if accumulate else 0, _dev_ptr(residuals_dev) if residuals_dev is not None else None))
+
+    @staticmethod
+    def score_trajectories_dev(prims, trajectories, lat_devs, lat_dtype, n, lds, err_devs, min_us, weights, alignments=None, accumulate=False):
+        """mg_score_trajectories: the k-th primitive's n resident candidates against the k-th trajectory, all in one launch (primitives of
+        one context); err_devs[k] (n,) float64 written or added to."""
+        m = len(prims)
+        vp = C.c_void_p
+        keep = [ConstraintSet._marshal_alignment(a, None) if a is not None else None for a in (alignments or [None] * m)]
+        al = (vp * m)(*[(C.addressof(a) if a is not None else None) for a in keep]) if alignments is not None else None
+        code = MG_F64 if np.dtype(lat_dtype) == np.float64 else MG_F32
+        _check(prims[0].lib.mg_score_trajectories(m, (vp * m)(*[p.handle.value for p in prims]), (vp * m)(*[t.handle.value for t in trajectories]),
+                                                  (vp * m)(*[_dev_ptr(x).value for x in lat_devs]), code, int(n), (C.c_int64 * m)(*[int(x) for x in lds]),
+                                                  (C.c_double * m)(*[float(x) for x in min_us]), (C.c_double * m)(*[float(x) for x in weights]), al,
+                                                  (vp * m)(*[_dev_ptr(x).value for x in err_devs]), 1 if accumulate else 0))
 
     def score_trajectory(self, trajectory, S, min_u=0.0, weight=1.0, alignment=None, residuals=False, grid=None):
         """(n,) float64 errors = weight * average distance of the root path to the trajectory; with residuals=True also

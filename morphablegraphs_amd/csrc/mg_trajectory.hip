@@ -14,6 +14,7 @@
 // 172 + 8 bytes per candidate: arithmetic / latency bound, a scoring kernel beside mg_score_constraints.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -130,10 +131,10 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
 #define MG_TRAJ_W 8
 #define MG_TRAJ_COOP_BLOCK 64
 #define MG_TRAJ_COOP_CANDS (MG_TRAJ_COOP_BLOCK / MG_TRAJ_W)
-__global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_kernel(mg_traj_args a) {
-    extern __shared__ double lds[];                 // [CANDS][L] latents, [CANDS][rows] root coefficient rows, [12 n_seg + 3] the polynomials
+__device__ __forceinline__ void mg_trajectory_coop_body(const mg_traj_args &a, const int64_t block, double *lds) {
+    // lds: [CANDS][L] latents, [CANDS][rows] root coefficient rows, [12 n_seg + 3] the polynomials
     const int tid = threadIdx.x, grp = tid / MG_TRAJ_W, sub = tid % MG_TRAJ_W;
-    const int64_t b = (int64_t)blockIdx.x * MG_TRAJ_COOP_CANDS + grp;
+    const int64_t b = block * MG_TRAJ_COOP_CANDS + grp;
     const bool valid = b < a.B;
     const int64_t bb = valid ? b : a.B - 1;
     const int rows = a.NB * 3 + 4;
@@ -206,6 +207,21 @@ __global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_kernel(
         const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
         a.out[b] = a.accumulate ? a.out[b] + e : e;
     }
+}
+__global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_kernel(mg_traj_args a) {
+    extern __shared__ double lds[];
+    mg_trajectory_coop_body(a, blockIdx.x, lds);
+}
+// Several scorers in ONE launch (mg_score_trajectories): a planner step scores every option's candidates against the option's own
+// trajectory -- 4096 candidates at eight lanes each fill a quarter of the chip and take 0.4 ms, sixteen such launches one after the
+// other 7 ms; side by side they take what the chip's four quarters take.
+#define MG_TRAJ_MULTI_MAX 16
+struct mg_traj_multi { int32_t n; int32_t wg0[MG_TRAJ_MULTI_MAX + 1]; mg_traj_args a[MG_TRAJ_MULTI_MAX]; };
+__global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_multi_kernel(const mg_traj_multi m) {
+    extern __shared__ double lds[];
+    int k = 0;
+    while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) k++;
+    mg_trajectory_coop_body(m.a[k], (int64_t)blockIdx.x - m.wg0[k], lds);
 }
 // one lane per candidate fills the chip from about this many candidates on (256 CUs x 4 SIMDs x 64 lanes x ~2 waves)
 #define MG_TRAJ_COOP_MAX_B 65536
@@ -309,19 +325,18 @@ extern "C" int mg_trajectory_create(mg_primitive *p, const double *cp, int32_t n
     return MG_OK;
 }
 
-extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, const mg_time_grid *g, const void *lat, int dt, int64_t B,
-                                   int64_t ld, double min_u, double weight, const mg_alignment_desc *al, double *errors_dev,
-                                   int accumulate, double *residuals_dev) {
+// arguments of one scorer, validated (who: the entry point's name for the message)
+static int mg_traj_fill_args(const char *who, mg_primitive *p, const mg_trajectory *t, const mg_time_grid *g, const void *lat, int dt, int64_t B,
+                             int64_t ld, double min_u, double weight, const mg_alignment_desc *al, double *errors_dev,
+                             int accumulate, double *residuals_dev, mg_traj_args *out) {
     if (!p || !t || t->prim != p || B < 0 || (dt != MG_F32 && dt != MG_F64) || ld < p->L || !(min_u >= 0.0 && min_u <= 1.0) ||
         !std::isfinite(weight)) {
-        mg_set_error("mg_score_trajectory: bad arguments (trajectory of another primitive, ld < n_components, min_u outside [0, 1] ...)");
+        mg_set_error("%s: bad arguments (trajectory of another primitive, ld < n_components, min_u outside [0, 1] ...)", who);
         return MG_ERR_INVALID_ARGUMENT;
     }
     if (!g) g = p->canonical;
-    if (g->prim != p) { mg_set_error("mg_score_trajectory: grid belongs to another primitive"); return MG_ERR_INVALID_ARGUMENT; }
-    if (B == 0) return MG_OK;
-    if (!lat || !errors_dev) { mg_set_error("mg_score_trajectory: NULL pointer"); return MG_ERR_INVALID_ARGUMENT; }
-    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
+    if (g->prim != p) { mg_set_error("%s: grid belongs to another primitive", who); return MG_ERR_INVALID_ARGUMENT; }
+    if (B > 0 && (!lat || !errors_dev)) { mg_set_error("%s: NULL pointer", who); return MG_ERR_INVALID_ARGUMENT; }
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = lat; a.i0 = g->d_i0; a.w = g->d_w; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = ld; a.T = g->T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = dt == MG_F64 ? 1 : 0;
@@ -330,9 +345,9 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     for (double &v : a.al) v = 0.0;
     if (al) {
         const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
-        if (!(hn > 0.0) || !std::isfinite(hn)) { mg_set_error("mg_score_trajectory: heading is zero or not finite"); return MG_ERR_INVALID_ARGUMENT; }
+        if (!(hn > 0.0) || !std::isfinite(hn)) { mg_set_error("%s: heading is zero or not finite", who); return MG_ERR_INVALID_ARGUMENT; }
         if (al->joint != 0 && al->joint != MG_ALIGN_START_POSE) {
-            mg_set_error("mg_score_trajectory: only the root joint or a start pose can be the aligning reference here (joint %d)", al->joint);
+            mg_set_error("%s: only the root joint or a start pose can be the aligning reference here (joint %d)", who, al->joint);
             return MG_ERR_UNSUPPORTED;
         }
         a.align_mode = al->joint == MG_ALIGN_START_POSE ? 2 : 1;
@@ -340,6 +355,17 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
         if (a.align_mode == 2) a.al[4] = al->position[1];
         else { a.al[4] = al->ref_dir[0]; a.al[5] = al->ref_dir[1]; a.al[6] = al->ref_dir[2]; }
     }
+    *out = a;
+    return MG_OK;
+}
+
+extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, const mg_time_grid *g, const void *lat, int dt, int64_t B,
+                                   int64_t ld, double min_u, double weight, const mg_alignment_desc *al, double *errors_dev,
+                                   int accumulate, double *residuals_dev) {
+    mg_traj_args a;
+    { const int rc = mg_traj_fill_args("mg_score_trajectory", p, t, g, lat, dt, B, ld, min_u, weight, al, errors_dev, accumulate, residuals_dev, &a); if (rc != MG_OK) return rc; }
+    if (B == 0) return MG_OK;
+    MG_HIP_CHECK(hipSetDevice(p->ctx->device));
     size_t lds = (size_t)(p->L + t->rows) * MG_TRAJ_BLOCK * 8;
     if (lds > 150 * 1024) { mg_set_error("mg_score_trajectory: %d basis functions x %d components do not fit LDS", p->NB, p->L); return MG_ERR_UNSUPPORTED; }
     const size_t poly_bytes = ((size_t)t->n_seg * 12 + 3) * 8;
@@ -360,6 +386,58 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     else hipLaunchKernelGGL(mg_trajectory_kernel<false>, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
     mg_prof_end(p->ctx, 10);
     MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// n scorers of the same batch size side by side in one launch (canonical grids, no residual vectors): option k's candidates
+// lat_dev[k] (B, ld[k]) against trajectories[k], errors_dev[k] written or added to.  alignments: NULL, or n records of which any may be
+// NULL.  Where the eight-lane walk does not apply (more than 65 536 candidates, MG_OPT_TRAJECTORY_LANES 1, rows that do not fit) the
+// scorers are launched one after the other -- the same results either way.
+extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, const mg_trajectory *const *trajectories, const void *const *lat_dev, int dt,
+                                     int64_t B, const int64_t *ld, const double *min_u, const double *weight, const mg_alignment_desc *const *alignments,
+                                     double *const *errors_dev, int accumulate) {
+    if (n < 0 || (n > 0 && (!prims || !trajectories || !lat_dev || !ld || !min_u || !weight || !errors_dev))) {
+        mg_set_error("mg_score_trajectories: bad arguments");
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return MG_OK;
+    for (int k = 0; k < n; k++)
+        if (!prims[k] || prims[k]->ctx != prims[0]->ctx) { mg_set_error("mg_score_trajectories: the primitives must share one context"); return MG_ERR_INVALID_ARGUMENT; }
+    mg_context *ctx = prims[0]->ctx;
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    bool together = B > 0 && B <= MG_TRAJ_COOP_MAX_B && ctx->opt[MG_OPT_TRAJECTORY_LANES] != 1 && n > 1;
+    size_t lds = 0;
+    for (int k = 0; k < n && together; k++) {
+        if (!trajectories[k]) { mg_set_error("mg_score_trajectories: trajectory %d is NULL", k); return MG_ERR_INVALID_ARGUMENT; }
+        const size_t need = (size_t)MG_TRAJ_COOP_CANDS * (prims[k]->L + trajectories[k]->rows) * 8 + ((size_t)trajectories[k]->n_seg * 12 + 3) * 8;
+        if (need > 60 * 1024) together = false;
+        lds = std::max(lds, need);
+    }
+    if (!together) {
+        for (int k = 0; k < n; k++) {
+            const int rc = mg_score_trajectory(prims[k], trajectories[k], nullptr, lat_dev[k], dt, B, ld[k], min_u[k], weight[k], alignments ? alignments[k] : nullptr,
+                                               errors_dev[k], accumulate, nullptr);
+            if (rc != MG_OK) return rc;
+        }
+        return MG_OK;
+    }
+    const int per = (int)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS);
+    for (int k0 = 0; k0 < n; k0 += MG_TRAJ_MULTI_MAX) {
+        mg_traj_multi m;
+        memset(&m, 0, sizeof(m));
+        m.n = std::min(MG_TRAJ_MULTI_MAX, n - k0);
+        for (int i = 0; i < m.n; i++) {
+            const int k = k0 + i;
+            const int rc = mg_traj_fill_args("mg_score_trajectories", prims[k], trajectories[k], nullptr, lat_dev[k], dt, B, ld[k], min_u[k], weight[k],
+                                             alignments ? alignments[k] : nullptr, errors_dev[k], accumulate, nullptr, &m.a[i]);
+            if (rc != MG_OK) return rc;
+            m.wg0[i + 1] = m.wg0[i] + per;
+        }
+        mg_prof_begin(ctx, 10);
+        hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
+        mg_prof_end(ctx, 10);
+        MG_HIP_CHECK(hipGetLastError());
+    }
     return MG_OK;
 }
 

@@ -593,10 +593,17 @@ class HipPrimitiveSet(object):
         lat = rec[:, 16:].copy().view(np.float64)
         results = {st[0]: (lat[k, :st[7]], errs[k]) for k, st in enumerate(steps) if k not in extras}
         scorers = plan.setdefault("track_scorers", {})
+        # the options' trajectory constraints round by round (the j-th of every option that has one): ONE launch per round
+        # (mg_score_trajectories) -- an option's own additions stay in its list's order
+        for j in range(max(len(e[0]) for e in extras.values())):
+            ks = [k for k, e in extras.items() if len(e[0]) > j]
+            cj = [extras[k][0][j] for k in ks]
+            _capi.Primitive.score_trajectories_dev([steps[k][2] for k in ks], [cached_trajectory(steps[k][2], c) for k, c in zip(ks, cj)],
+                                                   [steps[k][4] for k in ks], dtype, n, [steps[k][7] for k in ks], [steps[k][5] for k in ks],
+                                                   [c.get("min_u", 0.0) for c in cj], [c.get("weight", 1.0) for c in cj],
+                                                   [extras[k][2] for k in ks], accumulate=True)
         for k, (trajectories, frames, alignment, sk) in extras.items():
             name, node, prim, ctx, d_x, d_e, d_r, L, pvals = steps[k]
-            for c in trajectories:
-                prim.score_trajectory_dev(cached_trajectory(prim, c), d_x, dtype, n, L, d_e, c.get("min_u", 0.0), c.get("weight", 1.0), alignment, accumulate=True)
             if frames:
                 key = (k, _cs._freeze(frames), _cs._freeze(alignment), None if sk is None else sk.serial)
                 scorer = scorers.get(key)

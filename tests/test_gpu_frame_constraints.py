@@ -171,6 +171,44 @@ def test_closest_point_walk_by_eight_lanes_is_the_one_lane_walk_bit_for_bit():
     assert moved > 1000
 
 
+def test_trajectory_scorers_side_by_side_are_the_single_launches():
+    """mg_score_trajectories: the options of a planner step, each with its own primitive, candidates and trajectory, in one launch
+    -- errors equal to the single launches' bit for bit, written or added to, local, aligned to a previous frame and to a start
+    pose mixed in one call, 20 scorers (more than one launch holds)."""
+    from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
+    prims = synthetic.make_graph_primitives(5)
+    pset = HipPrimitiveSet(prims, separate_streams=False)
+    ctx = pset.ctx
+    rng = np.random.default_rng(12)
+    n = 333
+    ps, trs, xs, es, lds_, min_us, ws, als, ref = [], [], [], [], [], [], [], [], []
+    for i in range(20):
+        p = pset.nodes[prims[i % 5]["name"]]._prim
+        L = p.n_gmm_dims
+        S = rng.standard_normal((n, L)).astype(np.float32)
+        path = p.back_project_frames_f64(S[:1].astype(np.float64)[:, :p.n_components])[0][::9, :3] + rng.standard_normal(3)
+        t = _capi.Trajectory(p, path, 500 + 100 * i)
+        al = [None, {"joint": 0, "position": [1.0, 2.0, 3.0], "heading": [0.6, 0.8]}, alignment_from_start_pose({"position": [3.0, 2.0, 1.0], "orientation": [0.0, 25.0, 0.0]})][i % 3]
+        d_x, d_e = ctx.upload(S), ctx.upload(np.full(n, 0.5 + i))
+        ps.append(p); trs.append(t); xs.append(d_x); es.append(d_e); lds_.append(L); min_us.append(0.1 * (i % 4)); ws.append(1.0 + 0.25 * i); als.append(al)
+        d_r = ctx.upload(np.full(n, 0.5 + i))
+        p.score_trajectory_dev(t, d_x, np.float32, n, L, d_r, min_us[-1], ws[-1], al, accumulate=True)
+        ref.append(ctx.download(d_r, (n,), np.float64))
+        d_r.free()
+    _capi.Primitive.score_trajectories_dev(ps, trs, xs, np.float32, n, lds_, es, min_us, ws, als, accumulate=True)
+    for i in range(20):
+        got = ctx.download(es[i], (n,), np.float64)
+        assert np.array_equal(got.view(np.uint64), ref[i].view(np.uint64)), i
+    _capi.Primitive.score_trajectories_dev(ps[:3], trs[:3], xs[:3], np.float32, n, lds_[:3], es[:3], min_us[:3], ws[:3], None, accumulate=False)
+    for i in range(3):
+        d_r = ctx.malloc(n * 8)
+        ps[i].score_trajectory_dev(trs[i], xs[i], np.float32, n, lds_[i], d_r, min_us[i], ws[i], None, accumulate=False)
+        assert np.array_equal(ctx.download(es[i], (n,), np.float64), ctx.download(d_r, (n,), np.float64))
+        d_r.free()
+    for b in xs + es:
+        b.free()
+
+
 def test_per_frame_constraints_through_the_reference_entry_points():
     """evaluate_samples_using_constraints / the sample filter / the objectives take per-frame constraints beside keyframe and
     root-trajectory ones: the errors add up constraint by constraint, the first minimum wins."""
