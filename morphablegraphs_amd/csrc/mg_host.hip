@@ -1348,6 +1348,20 @@ extern "C" int mg_gmm_sample(mg_primitive *p, int64_t n, const int64_t *counts, 
 }
 
 // ---- constraint sets ---------------------------------------------------------------------
+// A constraint's row of the scorers' parameter table: {type, weight, target[3], ref_dir[3]}.  For the direction constraint the row
+// carries what its residual derives from the target alone -- the unit target (tx, tz) and sqrt(tx^2 + tz^2) -- computed here once per
+// set instead of by every lane for every candidate: the residual's own statements (mg_score_device.h), correctly rounded IEEE
+// square roots and divisions on both sides, no contraction: the same bits.
+static void mg_constraint_par_row(const mg_keyframe_constraint &c, double *q) {
+    q[0] = (double)c.type; q[1] = c.weight_factor;
+    for (int i = 0; i < 3; i++) { q[2 + i] = c.target[i]; q[5 + i] = c.ref_dir[i]; }
+    if (c.type == MG_CONSTRAINT_DIRECTION_2D) {
+        const double tn = std::sqrt(c.target[0] * c.target[0] + c.target[1] * c.target[1]);
+        const double tx = c.target[0] / tn, tz = c.target[1] / tn;
+        q[2] = tx; q[3] = tz; q[4] = std::sqrt(tx * tx + tz * tz);
+    }
+}
+
 extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_desc *sk, const mg_keyframe_constraint *cons,
                                              int32_t n, const mg_pose_constraint *poses, int32_t n_poses,
                                              const mg_alignment_desc *al, mg_constraint_set **out) {
@@ -1564,8 +1578,7 @@ extern "C" int mg_constraint_set_create_full(mg_primitive *p, const mg_skeleton_
             for (int d = 0; d < nch; d++) fill_row(r0 + d, d);
         }
         double *q = &par[(size_t)c * 8];
-        q[0] = (double)cons[c].type; q[1] = cons[c].weight_factor;
-        for (int i = 0; i < 3; i++) { q[2 + i] = cons[c].target[i]; q[5 + i] = cons[c].ref_dir[i]; }
+        mg_constraint_par_row(cons[c], q);
         if (cons[c].type == MG_CONSTRAINT_POSE) q[2] = (double)pose_off[(size_t)c];
     }
     std::vector<double> align;
@@ -1644,9 +1657,7 @@ extern "C" int mg_constraint_set_update(mg_constraint_set *cs, const mg_keyframe
     }
     std::vector<double> values((size_t)n * 8 + 7, 0.0);   // par [n][8], then entries 1..7 of the alignment record
     for (int c = 0; c < n; c++) {
-        double *q = &values[(size_t)c * 8];
-        q[0] = (double)cons[c].type; q[1] = cons[c].weight_factor;
-        for (int i = 0; i < 3; i++) { q[2 + i] = cons[c].target[i]; q[5 + i] = cons[c].ref_dir[i]; }
+        mg_constraint_par_row(cons[c], &values[(size_t)c * 8]);
     }
     if (al) {
         const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);

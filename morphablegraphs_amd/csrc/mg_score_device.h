@@ -309,11 +309,12 @@ __device__ __forceinline__ double mg_constraint_residual(const mg_score_args &a,
     const double lx = (1.0 - s2 * (qy * qy + qz * qz)) * rx + s2 * (qx * qy - qz * qw) * ry + s2 * (qx * qz + qy * qw) * rz;
     const double lz = s2 * (qx * qz - qy * qw) * rx + s2 * (qy * qz + qx * qw) * ry + (1.0 - s2 * (qx * qx + qy * qy)) * rz;
     const double px = a.align ? al.c * lx + al.s * lz : lx, pz = a.align ? al.c * lz - al.s * lx : lz;
-    const double tn = sqrt(par[2] * par[2] + par[3] * par[3]);
-    const double tx = par[2] / tn, tz = par[3] / tn;
+    // par[2..4]: the unit target (tx, tz) = target / |target| and sqrt(tx^2 + tz^2), made on the host by these very statements
+    // (mg_constraint_par_row): tn = sqrt(t0^2 + t1^2), tx = t0 / tn, tz = t1 / tn
+    const double tx = par[2], tz = par[3];
     const double mn = sqrt(px * px + pz * pz);
     const double mx = px / mn, mz = pz / mn;
-    double cosang = (tx * mx + tz * mz) / (sqrt(tx * tx + tz * tz) * sqrt(mx * mx + mz * mz));
+    double cosang = (tx * mx + tz * mz) / (par[4] * sqrt(mx * mx + mz * mz));
     cosang = fmin(1.0, fmax(cosang, -1.0));
     return par[1] * fabs(acos(cosang) * (180.0 / M_PI));
 }
