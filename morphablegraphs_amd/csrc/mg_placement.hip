@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <map>
 #include <vector>
+#include <hip/hip_ext.h>
 
 #include "mg_internal.h"
 
@@ -82,22 +83,26 @@ int mg_probe_placement(mg_context *ctx, void *buf, int64_t bytes, double *ratio,
     if (ntiles < 64) { *ratio = 1.0; *pattern_us = 0.0; return MG_OK; }
     const size_t n4 = (size_t)ntiles * 16 * (size_t)cand_bytes / 16;
     const int grid = std::min(ntiles * MG_PP_NCH, std::max(1, ctx->n_cu));
-    hipEvent_t ev[3];
-    for (auto &e : ev) MG_HIP_CHECK(hipEventCreate(&e));
+    // Every launch carries its own start / stop events (attached to the dispatch: the packet's own timestamps), and the kernels'
+    // durations are summed -- not the time between two markers around a row of launches: under a tracing profiler every launch gap
+    // grows by microseconds, a marker-to-marker measurement then calls every buffer slow and the arena picks the other kernel.
     hipStream_t st = ctx->stream;
     const int warm = 2, reps = 6;
-    auto pattern = [&] { hipLaunchKernelGGL(mg_placement_pattern_kernel, dim3(grid), dim3(512), 0, st, (float *)buf, ntiles); };
-    auto fill = [&] { hipLaunchKernelGGL(mg_placement_fill_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (f32x4p *)buf, n4); };
-    for (int i = 0; i < warm; i++) { fill(); pattern(); }
-    hipError_t e = hipEventRecord(ev[0], st);
-    for (int i = 0; i < reps && e == hipSuccess; i++) fill();
-    if (e == hipSuccess) e = hipEventRecord(ev[1], st);
-    for (int i = 0; i < reps && e == hipSuccess; i++) pattern();
-    if (e == hipSuccess) e = hipEventRecord(ev[2], st);
-    if (e == hipSuccess) e = hipEventSynchronize(ev[2]);
+    hipEvent_t ev[4 * reps];
+    for (auto &e : ev) MG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
+    auto pattern = [&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(mg_placement_pattern_kernel, dim3(grid), dim3(512), 0, st, a, b, 0, (float *)buf, ntiles); };
+    auto fill = [&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(mg_placement_fill_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, b, 0, (f32x4p *)buf, n4); };
+    for (int i = 0; i < warm; i++) { fill(nullptr, nullptr); pattern(nullptr, nullptr); }
+    for (int i = 0; i < reps; i++) fill(ev[2 * i], ev[2 * i + 1]);
+    for (int i = 0; i < reps; i++) pattern(ev[2 * reps + 2 * i], ev[2 * reps + 2 * i + 1]);
+    hipError_t e = hipStreamSynchronize(st);
     float ms_fill = 0.f, ms_pat = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms_fill, ev[0], ev[1]);
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms_pat, ev[1], ev[2]);
+    for (int i = 0; i < reps && e == hipSuccess; i++) {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        ms_fill += ms;
+        if (e == hipSuccess) { e = hipEventElapsedTime(&ms, ev[2 * reps + 2 * i], ev[2 * reps + 2 * i + 1]); ms_pat += ms; }
+    }
     if (e == hipSuccess) e = hipGetLastError();
     for (auto &x : ev) (void)hipEventDestroy(x);
     if (e != hipSuccess) return mg_hip_fail(e, "mg_probe_placement");
