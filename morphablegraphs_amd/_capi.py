@@ -810,8 +810,10 @@ class TrackPlan(object):
 
 class Primitive(object):
     """Device-resident constants of one motion primitive, built from the reference's JSON dict."""
+    _serials = itertools.count(1)
 
     def __init__(self, ctx, data):
+        self.serial = next(Primitive._serials)   # a stable identity for caches (id() and the handle's address can both be reused)
         self.ctx = ctx
         self.lib = ctx.lib
         eig = np.ascontiguousarray(np.asarray(data["eigen_vectors_spatial"], dtype=np.float64))

@@ -197,7 +197,7 @@ _TRAJ_CACHE = []   # [(key, _capi.Trajectory)]: a planner scores against the sam
 
 
 def cached_trajectory(prim, c):
-    key = (id(prim), prim.handle.value, _freeze(c["control_points"]), int(c.get("granularity", 1000)))
+    key = (prim.serial, prim.handle.value, _freeze(c["control_points"]), int(c.get("granularity", 1000)))
     for i, (k, t) in enumerate(_TRAJ_CACHE):
         if k == key and t.handle:
             _TRAJ_CACHE.append(_TRAJ_CACHE.pop(i))
@@ -317,7 +317,7 @@ def _structure_key(prim, clist, skeleton, alignment=None):
                    _freeze(c) if c["type"] == "pose" else None) for c in clist)
     # (a Skeleton carries a serial number: id() of a collected one can be handed to a new object)
     sk = None if skeleton is None else getattr(skeleton, "serial", id(skeleton))
-    return (id(prim), prim.handle.value, sk, items, None if alignment is None else _flat(alignment.get("joint", 0)))
+    return (prim.serial, prim.handle.value, sk, items, None if alignment is None else _flat(alignment.get("joint", 0)))
 
 
 def _values_key(clist, alignment):

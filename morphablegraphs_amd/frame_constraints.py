@@ -247,7 +247,7 @@ def _request_of(prim, c):
 
 
 def _integer_grid(prim, n):
-    key = (id(prim), prim.handle.value, n)
+    key = (prim.serial, prim.handle.value, n)
     g = _GRID_CACHE.get(key)
     if g is None or not g.handle:
         if len(_GRID_CACHE) > 64:
@@ -281,7 +281,7 @@ class TrackScorer(object):
             req_of.append(reqs.index(key))
         if len(reqs) > _capi.MG_TRACK_MAX_REQUESTS or any(not 1 <= len(k[1]) <= _capi.MG_FRAME_MAX_JOINTS for k in reqs):
             raise NotImplementedError("more than %d distinct (times, joints) requests" % _capi.MG_TRACK_MAX_REQUESTS)
-        pkey = (id(prim), prim.handle.value, sk.serial, al_joint, tuple(k[1] for k in reqs))
+        pkey = (prim.serial, prim.handle.value, sk.serial, al_joint, tuple(k[1] for k in reqs))
         plan = _PLAN_CACHE.get(pkey)
         if plan is None or not plan.handle:
             if len(_PLAN_CACHE) > 64:
