@@ -75,6 +75,13 @@ __device__ __forceinline__ double mg_traj_refine(const double *poly, int n_seg, 
 // (the bound of the next frame's search): on the grid u_k = k / G walk forward from the bound while the squared distance falls,
 // refine by the parabola through the three values around the minimum, then by up to four Newton steps inside that bracket
 // (oracle/mg_oracle.py closest_point_walk; trajectory_constraint.py:113-131 bounds the search the same way).
+// WAVE_HELP (only where all 64 lanes of the wave reach the call together): a lane whose walk has not ended after MG_TRAJ_WALK_ALONE
+// steps gets the whole wave -- the next 64 grid values side by side for ITS point, the first that does not fall found by a ballot --
+// lane by lane.  With one lane per candidate a wave walks as long as its longest lane: candidates far from the spline (hundreds of
+// grid steps in one frame) cost every other lane of the wave that time; helped, such a walk is a few rounds.  The same grid values
+// in the same comparisons: the same k, the same bits.
+#define MG_TRAJ_WALK_ALONE 16
+template <bool WAVE_HELP = false>
 __device__ __forceinline__ double mg_traj_closest_dist(const double *__restrict__ poly, int n_seg, int G, double invG, double *min_u_io, const double *q) {
     const double min_u = *min_u_io;
     struct { const double *poly; int n_seg; } a = {poly, n_seg};
@@ -83,11 +90,45 @@ __device__ __forceinline__ double mg_traj_closest_dist(const double *__restrict_
     k = k < G ? k : G;
     double dk = mg_traj_d2(a.poly, a.n_seg, k * invG, q);
     const double d_start = mg_traj_d2(a.poly, a.n_seg, min_u, q);
-    while (k < G) {
-        const double dn = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
-        if (dn >= dk) break;
-        k++;
-        dk = dn;
+    if constexpr (!WAVE_HELP) {
+        while (k < G) {
+            const double dn = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
+            if (dn >= dk) break;
+            k++;
+            dk = dn;
+        }
+    } else {
+        bool done = false;
+        for (int step = 0; step < MG_TRAJ_WALK_ALONE && !done; step++) {
+            if (k >= G) { done = true; break; }
+            const double dn = mg_traj_d2(a.poly, a.n_seg, (k + 1) * invG, q);
+            if (dn >= dk) done = true;
+            else { k++; dk = dn; }
+        }
+        const int lane = (int)__lane_id();
+        unsigned long long pend = __ballot(!done);
+        while (pend) {                                   // (uniform: every lane runs every helped lane's rounds)
+            const int src = __ffsll((long long)pend) - 1;
+            const double qs[3] = {__shfl(q[0], src), __shfl(q[1], src), __shfl(q[2], src)};
+            int ks = __shfl(k, src);
+            double dks = __shfl(dk, src);
+            for (;;) {
+                const int idx = ks + 1 + lane;           // lane l: would the walk, standing at idx - 1, stop there?
+                const double val = mg_traj_d2(a.poly, a.n_seg, (idx < G ? idx : G) * invG, qs);
+                const double up = __shfl_up(val, 1);
+                const double before = lane == 0 ? dks : up;
+                const unsigned long long stop = __ballot(idx > G || val >= before);
+                if (stop) {
+                    const int first = __ffsll((long long)stop) - 1;
+                    const double dfirst = __shfl(val, first > 0 ? first - 1 : 0);
+                    if (lane == src) { k = ks + first; dk = first > 0 ? dfirst : dks; }
+                    break;
+                }
+                ks += 64;
+                dks = __shfl(val, 63);
+            }
+            pend &= pend - 1;
+        }
     }
     double u = k * invG;
     if (k > 0 && k < G) {

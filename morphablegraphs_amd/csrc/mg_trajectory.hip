@@ -13,6 +13,7 @@
 // (n_basis x 3, float64 fma chains over the latents) are staged in LDS, every frame is four taps of them.
 // 172 + 8 bytes per candidate: arithmetic / latency bound, a scoring kernel beside mg_score_constraints.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -212,6 +213,102 @@ __global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_kernel(
     extern __shared__ double lds[];
     mg_trajectory_coop_body(a, blockIdx.x, lds);
 }
+
+// One lane per candidate for batches that fill the chip that way (from ~32 768 candidates in flight: eight lanes per candidate repeat
+// the Newton steps eight times, which is what counts once every SIMD has waves to choose from) -- WITHOUT the candidate's 97
+// coefficient rows in LDS: mg_trajectory_kernel keeps them there, 50 KB per wave, three waves per CU.  A frame's position needs the four
+// control points of its knot span only, and the span moves one control point at a time: a window of 4 x 3 control points lives in
+// registers, the next control point (three fma chains over the latents, the statements of the staged form) is made when the span
+// moves (every 5.6 frames for 'walk').  LDS: the latents (20 KB per wave) and the polynomials.  Same operations, same bits.
+__device__ __forceinline__ void mg_trajectory_stream_body(const mg_traj_args &a, const int64_t block, double *lds) {
+    const int tid = threadIdx.x;
+    const int64_t b = block * MG_TRAJ_BLOCK + tid;
+    const bool valid = b < a.B;
+    const int64_t bb = valid ? b : a.B - 1;
+    double *ls = lds, *lp = lds + (size_t)a.L * MG_TRAJ_BLOCK;
+    for (int e = tid; e < a.n_seg * 12 + 3; e += MG_TRAJ_BLOCK) lp[e] = a.poly[e];
+    for (int k = 0; k < a.L; k++)
+        ls[k * MG_TRAJ_BLOCK + tid] = a.lat_f64 ? ((const double *)a.lat)[bb * a.ld + k] : (double)((const float *)a.lat)[bb * a.ld + k];
+    __syncthreads();
+    auto row = [&](int r) {
+        double acc = a.mean[r];
+        const double *e = a.E + (size_t)r * a.L;
+        for (int k = 0; k < a.L; k++) acc = fma(e[k], ls[k * MG_TRAJ_BLOCK + tid], acc);
+        return acc;
+    };
+    double ac = 1.0, as = 0.0, tx = 0.0, ty = 0.0, tz = 0.0;
+    if (a.align_mode != 0) {
+        if (a.align_mode == 2) {
+            ac = a.al[0]; as = a.al[1]; ty = a.al[4];
+        } else {
+            double qw = row(a.NB * 3 + 0), qx = row(a.NB * 3 + 1), qy = row(a.NB * 3 + 2), qz = row(a.NB * 3 + 3);
+            const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw *= inv; qx *= inv; qy *= inv; qz *= inv;
+            const double rx = a.al[4], ry = a.al[5], rz = a.al[6];
+            const double cx = qy * rz - qz * ry, cy = qz * rx - qx * rz, cz = qx * ry - qy * rx;
+            const double dx = qy * cz - qz * cy, dz = qx * cy - qy * cx;
+            double bx = rx + 2.0 * (qw * cx + dx), bz = rz + 2.0 * (qw * cz + dz);
+            const double bn = 1.0 / sqrt(bx * bx + bz * bz);
+            bx *= bn; bz *= bn;
+            ac = a.al[0] * bx + a.al[1] * bz;
+            as = a.al[0] * bz - a.al[1] * bx;
+        }
+        const double p0x = row(0), p0z = row(2);
+        tx = a.al[2] - (ac * p0x + as * p0z);
+        tz = a.al[3] - (ac * p0z - as * p0x);
+    }
+    const int G = a.G;
+    const double invG = 1.0 / (double)G;
+    double min_u = a.min_u, sum = 0.0;
+    double cw[4][3];                       // control points cur .. cur + 3 of the three root channels
+    int cur = INT_MIN;
+    for (int f = 0; f < a.T; f++) {
+        const int i0 = a.i0[f];             // (the same for every lane: the branches below are uniform)
+        if (i0 != cur) {
+            if (cur != INT_MIN && i0 == cur + 1) {
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int d = 0; d < 3; d++) cw[j][d] = cw[j + 1][d];
+#pragma unroll
+                for (int d = 0; d < 3; d++) cw[3][d] = row((i0 + 3) * 3 + d);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int d = 0; d < 3; d++) cw[j][d] = row((i0 + j) * 3 + d);
+            }
+            cur = i0;
+        }
+        const double *w = a.w + 4 * (size_t)f;
+        double q[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double v = w[0] * cw[0][d];
+            v = fma(w[1], cw[1][d], v);
+            v = fma(w[2], cw[2][d], v);
+            v = fma(w[3], cw[3][d], v);
+            q[d] = v;
+        }
+        if (a.align_mode != 0) {
+            const double x = q[0], z = q[2];
+            q[0] = ac * x + as * z + tx;
+            q[2] = ac * z - as * x + tz;
+            q[1] += ty;
+        }
+        const double dist = mg_traj_closest_dist<true>(lp, a.n_seg, G, invG, &min_u, q);   // (every lane of the wave is here: the help is legal)
+        sum += dist;
+        if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
+    }
+    if (valid) {
+        const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
+        a.out[b] = a.accumulate ? a.out[b] + e : e;
+    }
+}
+__global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_stream_kernel(mg_traj_args a) {
+    extern __shared__ double lds[];
+    mg_trajectory_stream_body(a, blockIdx.x, lds);
+}
 // Several scorers in ONE launch (mg_score_trajectories): a planner step scores every option's candidates against the option's own
 // trajectory -- 4096 candidates at eight lanes each fill a quarter of the chip and take 0.4 ms, sixteen such launches one after the
 // other 7 ms; side by side they take what the chip's four quarters take.
@@ -223,6 +320,14 @@ __global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_multi_k
     while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) k++;
     mg_trajectory_coop_body(m.a[k], (int64_t)blockIdx.x - m.wg0[k], lds);
 }
+__global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_stream_multi_kernel(const mg_traj_multi m) {
+    extern __shared__ double lds[];
+    int k = 0;
+    while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) k++;
+    mg_trajectory_stream_body(m.a[k], (int64_t)blockIdx.x - m.wg0[k], lds);
+}
+// candidates in flight up to which the eight-lane walk is the faster one (measured: tools/probes/trajectory_lanes.py)
+#define MG_TRAJ_COOP_MAX_TOTAL 28672
 // one lane per candidate fills the chip from about this many candidates on (256 CUs x 4 SIMDs x 64 lanes x ~2 waves)
 #define MG_TRAJ_COOP_MAX_B 65536
 
@@ -379,9 +484,12 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     }
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
     const size_t coop_lds = (size_t)MG_TRAJ_COOP_CANDS * (p->L + t->rows) * 8 + poly_bytes;
-    const bool coop = B <= MG_TRAJ_COOP_MAX_B && coop_lds <= 60 * 1024 && p->ctx->opt[MG_OPT_TRAJECTORY_LANES] != 1;
+    const int lanes_opt = p->ctx->opt[MG_OPT_TRAJECTORY_LANES];
+    const bool coop = coop_lds <= 60 * 1024 && lanes_opt != 1 && B <= (lanes_opt == 8 ? MG_TRAJ_COOP_MAX_B : MG_TRAJ_COOP_MAX_TOTAL);
+    const size_t stream_lds = (size_t)p->L * MG_TRAJ_BLOCK * 8 + poly_bytes;
     mg_prof_begin(p->ctx, 10);
     if (coop) hipLaunchKernelGGL(mg_trajectory_coop_kernel, dim3((unsigned)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS)), dim3(MG_TRAJ_COOP_BLOCK), coop_lds, p->ctx->stream, a);
+    else if (stream_lds <= 60 * 1024) hipLaunchKernelGGL(mg_trajectory_stream_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), stream_lds, p->ctx->stream, a);
     else if (poly_lds) hipLaunchKernelGGL(mg_trajectory_kernel<true>, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
     else hipLaunchKernelGGL(mg_trajectory_kernel<false>, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
     mg_prof_end(p->ctx, 10);
@@ -405,11 +513,16 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
         if (!prims[k] || prims[k]->ctx != prims[0]->ctx) { mg_set_error("mg_score_trajectories: the primitives must share one context"); return MG_ERR_INVALID_ARGUMENT; }
     mg_context *ctx = prims[0]->ctx;
     MG_HIP_CHECK(hipSetDevice(ctx->device));
-    bool together = B > 0 && B <= MG_TRAJ_COOP_MAX_B && ctx->opt[MG_OPT_TRAJECTORY_LANES] != 1 && n > 1;
+    const int lanes_opt = ctx->opt[MG_OPT_TRAJECTORY_LANES];
+    // eight lanes per candidate while the candidates in flight leave SIMDs idle, one lane (the streaming form) beyond
+    const bool coop = lanes_opt != 1 && B <= MG_TRAJ_COOP_MAX_B && (lanes_opt == 8 || (int64_t)n * B <= MG_TRAJ_COOP_MAX_TOTAL);
+    bool together = B > 0 && n > 1;
     size_t lds = 0;
     for (int k = 0; k < n && together; k++) {
         if (!trajectories[k]) { mg_set_error("mg_score_trajectories: trajectory %d is NULL", k); return MG_ERR_INVALID_ARGUMENT; }
-        const size_t need = (size_t)MG_TRAJ_COOP_CANDS * (prims[k]->L + trajectories[k]->rows) * 8 + ((size_t)trajectories[k]->n_seg * 12 + 3) * 8;
+        const size_t poly_bytes = ((size_t)trajectories[k]->n_seg * 12 + 3) * 8;
+        const size_t need = coop ? (size_t)MG_TRAJ_COOP_CANDS * (prims[k]->L + trajectories[k]->rows) * 8 + poly_bytes
+                                 : (size_t)prims[k]->L * MG_TRAJ_BLOCK * 8 + poly_bytes;
         if (need > 60 * 1024) together = false;
         lds = std::max(lds, need);
     }
@@ -421,7 +534,8 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
         }
         return MG_OK;
     }
-    const int per = (int)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS);
+    const int cands_per_wg = coop ? MG_TRAJ_COOP_CANDS : MG_TRAJ_BLOCK;
+    const int per = (int)((B + cands_per_wg - 1) / cands_per_wg);
     for (int k0 = 0; k0 < n; k0 += MG_TRAJ_MULTI_MAX) {
         mg_traj_multi m;
         memset(&m, 0, sizeof(m));
@@ -434,7 +548,8 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
             m.wg0[i + 1] = m.wg0[i] + per;
         }
         mg_prof_begin(ctx, 10);
-        hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
+        if (coop) hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
+        else hipLaunchKernelGGL(mg_trajectory_stream_multi_kernel, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_BLOCK), lds, ctx->stream, m);
         mg_prof_end(ctx, 10);
         MG_HIP_CHECK(hipGetLastError());
     }
@@ -467,7 +582,8 @@ extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *
         p->ctx->attr_traj |= 1u;
     }
     mg_prof_begin(p->ctx, 10);
-    if (B <= MG_TRAJ_COOP_MAX_B && poly_bytes <= 60 * 1024 && p->ctx->opt[MG_OPT_TRAJECTORY_LANES] != 1)
+    const int lanes_opt = p->ctx->opt[MG_OPT_TRAJECTORY_LANES];
+    if (poly_bytes <= 60 * 1024 && lanes_opt != 1 && B <= (lanes_opt == 8 ? MG_TRAJ_COOP_MAX_B : MG_TRAJ_COOP_MAX_TOTAL))
         hipLaunchKernelGGL(mg_trajectory_coop_kernel, dim3((unsigned)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS)), dim3(MG_TRAJ_COOP_BLOCK), poly_bytes, p->ctx->stream, a);
     else if (poly_bytes <= 158 * 1024) hipLaunchKernelGGL(mg_trajectory_kernel<true>, dim3(grid), dim3(MG_TRAJ_BLOCK), poly_bytes, p->ctx->stream, a);
     else hipLaunchKernelGGL(mg_trajectory_kernel<false>, dim3(grid), dim3(MG_TRAJ_BLOCK), 0, p->ctx->stream, a);
