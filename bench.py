@@ -700,10 +700,11 @@ def run_graph(args, emit=True):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "graph-walk planner step: 16 synthetic primitives (L 12..40, F 40..160, K 1..8) x %d device-sampled candidates each, "
                                "2 root keyframe constraints, winner per option read back (BASELINE.json configs[2]); score only, no frames written" % n,
-                   "options": len(names), "candidates_per_option": n, "launches_per_step": launches + (1 if dev_counts and fused else 0), "host_calls_per_step": 1,
+                   "options": len(names), "candidates_per_option": n, "launches_per_step": launches, "host_calls_per_step": 1,
                    "read_backs_per_step": 1,
                    "component_counts": ("drawn on the device (mg_options_step_device_counts: Philox-keyed multinomial per option, distributed like "
-                                        "numpy.random.multinomial's counts, not NumPy's stream; --host-counts keeps the host draw)") if dev_counts else
+                                        "numpy.random.multinomial's counts, not NumPy's stream; --host-counts keeps the host draw); a step's kernel draws the counts "
+                                        "of seed + 1 as well, so that this loop (seed = step number) needs the counts kernel in front only once") if dev_counts else
                                        "numpy.random.multinomial on the host, one call per option"},
         "roofline": {"bound": "mfma", "kernel": k_name, "achieved": k_flop / (k_ms * 1e-3) / 1e12 if k_ms else None,
                      "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -218,7 +218,9 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_PLACED_FAST_PCT    mg_device_malloc_placed: pattern / fill ratio (in percent) up to which a candidate counts as
  *                             fast (0 = 115); tests lower it to walk through both recipes
  *   MG_OPT_OPTIONS_STEP       mg_options_step: 0 = one launch for the whole step where every option allows it, 1 = always one
- *                             chain of launches per option (identical results; tests compare the two)
+ *                             chain of launches per option (identical results; tests compare the two), 2 = one launch, and
+ *                             mg_options_step_device_counts always draws its counts with a kernel in front (never takes the
+ *                             counts the step before drew ahead; A/B)
  *   MG_OPT_PLAIN_MALLOC       1 = mg_device_malloc is one hipMalloc whatever the size (0: buffers of 64 MiB and more are pieces
  *                             of the context's placed output regions, see mg_device_malloc)
  *   MG_OPT_GMM_KERNEL         mg_gmm_log_prob on the matrix pipe: 0 = by batch size, 1 = one 16-candidate tile per workgroup, fragments
@@ -690,8 +692,9 @@ int mg_options_step(int32_t n_options, mg_primitive *const *prims, const mg_cons
  *     u_i = (Philox4x32-10(counter = (i >> 2, 0, 0, 0x636e7473), key = seed)[i & 3] + 0.5) / 2^32,   i = 0 .. n_samples - 1
  *     counts[c] = #{i : cum[c-1] <= u_i < cum[c]}, cum = cumulative normalised weights (float64), the last component takes the rest.
  * Distributed like NumPy's counts, NOT NumPy's stream (the status of the device sampler itself); given the counts the step is the one
- * mg_options_step makes, bit for bit.  Two launches per step, no host work per option; the kernels leave the result records (and
- * the counts) in pinned host memory themselves, so results_host / counts_host cost one synchronisation and no copy.
+ * mg_options_step makes, bit for bit.  Two launches per step -- ONE when the step before, run with every seed one less, drew this step's
+ * counts ahead (its kernel always draws for seed + 1: a planner counts its steps) -- and no host work per option; the kernels leave
+ * the result records (and the counts) in pinned host memory themselves, so results_host / counts_host cost one synchronisation and no copy.
  * counts_host (may be NULL): [n_options][16] int64.  At most 24 options; MG_ERR_UNSUPPORTED where an option does not run on the
  * one-launch kernel (more than 16 components, more than 64 mixture dimensions, a VALU kernel forced): draw on the host then. */
 int mg_options_step_device_counts(int32_t n_options, mg_primitive *const *prims, const mg_constraint_set *const *csets, int64_t n_samples,

@@ -822,7 +822,10 @@ static void mg_primitive_free(mg_primitive *p) {
     delete p;
 }
 
-extern "C" void mg_primitive_destroy(mg_primitive *p) { mg_primitive_free(p); }
+extern "C" void mg_primitive_destroy(mg_primitive *p) {
+    if (p && p->ctx) p->ctx->fused_next.valid = false;   // (counts drawn ahead are keyed by the primitive's address)
+    mg_primitive_free(p);
+}
 
 extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, mg_primitive **out) {
     MG_REQUIRE(ctx && d && out, "mg_primitive_create: NULL argument");

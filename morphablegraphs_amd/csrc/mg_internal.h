@@ -72,6 +72,9 @@ struct mg_context {
     std::vector<unsigned char> fused_tab_host;
     void *fused_counters = nullptr, *fused_partials = nullptr;
     void *fused_dyn_dev = nullptr;   // a step's per-option values where the device draws the component counts itself
+    // ... two slots of them: the step's kernel also draws the counts the NEXT step will want if its seeds are this step's + 1 (a planner
+    // counts its steps), so that step needs no counts kernel in front; what was drawn for whom:
+    struct { bool valid = false; int32_t n_options = 0, slot = 0; int64_t n = 0; uint64_t seeds[24] = {0}; const void *prims[24] = {nullptr}; } fused_next;
     unsigned attr_gmm_lds = 0, attr_traj = 0;   // dynamic-LDS attributes already set for this context's device (bit per instantiation)
     unsigned long long fused_seq = 0;   // sequence number of the planner steps whose records the kernel leaves in pinned memory
     int fused_partials_n = 0;

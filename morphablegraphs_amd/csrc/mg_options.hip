@@ -82,21 +82,20 @@ struct mg_counts_args {
     uint64_t seed[MG_FUSED_MAX_OPTIONS];
     int64_t n;
 };
-__global__ __launch_bounds__(256) void mg_options_counts_kernel(const mg_fused_static *__restrict__ tab, const mg_counts_args a,
-                                                               mg_fused_devcounts *__restrict__ dc, int32_t *__restrict__ counts_host) {
-    __shared__ int below[4][MG_SAMPLE_ARG_K];
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = tab[k].K;
-    double cum[MG_SAMPLE_ARG_K];     // the thresholds in registers: +inf from K - 1 on, so that the comparisons below need no bound
+// the draw of one option's counts by a 256-thread workgroup (every thread of it must call)
+__device__ __forceinline__ void mg_counts_draw(const mg_fused_static &o, const uint64_t seed, const int64_t n, mg_fused_devcounts *__restrict__ dc, const int k,
+                                               int (*below)[MG_SAMPLE_ARG_K]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = o.K;
+    double cum[MG_SAMPLE_ARG_K];     // the thresholds in registers: never-below from K - 1 on, so that the comparisons below need no bound
 #pragma unroll
-    for (int c = 0; c < MG_SAMPLE_ARG_K; c++) cum[c] = tab[k].cumw[c];
+    for (int c = 0; c < MG_SAMPLE_ARG_K; c++) cum[c] = o.cumw[c];
 #pragma unroll
     for (int c = 0; c < MG_SAMPLE_ARG_K; c++) cum[c] = c < K - 1 ? cum[c] : -1.0;   // (u >= 0: never below)
     int lt[MG_SAMPLE_ARG_K];   // this thread's draws below cum[c]
 #pragma unroll
     for (int c = 0; c < MG_SAMPLE_ARG_K; c++) lt[c] = 0;
-    const int64_t n = a.n, groups = (n + 3) >> 2;
-    const uint64_t seed = a.seed[k];
+    const int64_t groups = (n + 3) >> 2;
     for (int64_t j = tid; j < groups; j += 256) {
         uint32_t rr[4];
         mg_philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), 0u, MG_COUNTS_TAG, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
@@ -114,23 +113,29 @@ __global__ __launch_bounds__(256) void mg_options_counts_kernel(const mg_fused_s
         if (lane == 0) below[wave][c] = v;
     }
     __syncthreads();
-    if (tid < MG_SAMPLE_ARG_K) {
-        // lane c: component c's count; ONE 64-byte store to the device copy and one to the pinned host copy (sixteen 4-byte stores to
-        // pinned memory in a row from one lane were most of this kernel's 9.3 us: each is a transaction the kernel's end waits for)
+    if (tid < MG_SAMPLE_ARG_K) {     // lane c: component c's count
         const int c = tid;
         auto cum_at = [&](int q) { return q < 0 ? 0 : (q < K - 1 ? below[0][q] + below[1][q] + below[2][q] + below[3][q] : (int)n); };
         const int cnt = c < K ? cum_at(c) - cum_at(c - 1) : 0;
         dc->counts[k][c] = cnt;
-        if (counts_host) counts_host[k * MG_SAMPLE_ARG_K + c] = cnt;
         int tiles = (cnt + 15) / 16;
         for (int off = 8; off > 0; off >>= 1) tiles += __shfl_down(tiles, off, 16);
         if (c == 0) dc->tile_end[k] = tiles;
     }
+    __syncthreads();                 // (below[] may be used again)
+}
+// ... as a launch of its own in front of the step's kernel (9.3 us, nearly all of it launch and drain: the draw is 4096 Philox
+// values per option), when the counts were not drawn by the step before (see mg_options_fused_kernel's `next`)
+__global__ __launch_bounds__(256) void mg_options_counts_kernel(const mg_fused_static *__restrict__ tab, const mg_counts_args a,
+                                                               mg_fused_devcounts *__restrict__ dc) {
+    __shared__ int below[4][MG_SAMPLE_ARG_K];
+    mg_counts_draw(tab[blockIdx.x], a.seed[blockIdx.x], a.n, dc, blockIdx.x, below);
 }
 
 template <bool X_F64, bool DYN_DEV>
 __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused_kernel(const mg_fused_static *__restrict__ tab, const mg_fused_dyn dyn_arg,
                                                               const mg_fused_devcounts *__restrict__ dyn_dev,
+                                                              mg_fused_devcounts *__restrict__ next_dev, int32_t *__restrict__ counts_host,
                                                               const int n_options, const int wave_doubles,
                                                               mg_fused_partial *__restrict__ partials, int32_t *__restrict__ counters) {
     const mg_fused_dyn &dyn = dyn_arg;   // the step's values; DYN_DEV: the component counts and the tile count come from dyn_dev
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
     __shared__ double sv[4];
     __shared__ int64_t si[4];
     __shared__ int s_last;
+    __shared__ int s_below[4][MG_SAMPLE_ARG_K];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, g = lane >> 4;
@@ -161,6 +167,13 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
 #pragma unroll
     for (int q = 0; q < MG_SAMPLE_ARG_K; q++) cnts[q] = DYN_DEV ? dyn_dev->counts[k][q] : dyn.counts[k][q];
     const int tile_end_k = DYN_DEV ? dyn_dev->tile_end[k] : dyn.tile_end[k];
+    if (DYN_DEV && counts_host && wg == dyn.wg0[k] && tid < MG_SAMPLE_ARG_K) {
+        // the counts this step is drawn with, for the host: one 64-byte system-scope store, long before the step's flags
+        int mine = cnts[0];
+#pragma unroll
+        for (int q = 1; q < MG_SAMPLE_ARG_K; q++) mine = tid == q ? cnts[q] : mine;
+        __hip_atomic_store(counts_host + k * MG_SAMPLE_ARG_K + tid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (;;) {
         int cnt = cnts[0];
 #pragma unroll
@@ -276,6 +289,12 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
         s_last = (old == nwg - 1) ? 1 : 0;
     }
     __syncthreads();
+    if (DYN_DEV && next_dev != nullptr && wg == dyn.wg0[k]) {
+        // The option's first workgroup, its own tile published, draws the counts the NEXT step will want if its seed is this one's + 1
+        // (a planner counts its steps): that step then starts without a counts kernel in front (8.5 us + the gap between two launches).
+        // Off the critical path -- the first workgroup is done long before the option's last -- and lost if the next step asks otherwise.
+        mg_counts_draw(o, dyn.seed[k] + 1, o.sa.B, next_dev, k, s_below);
+    }
     if (!s_last) return;
     // the option's last workgroup: every other one has published its partial
     best = INFINITY; bi = INT64_MAX;
@@ -333,10 +352,10 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
 }
 
 int mg_options_fused_attributes() {
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     return MG_OK;
 }
 
@@ -447,21 +466,28 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
     mg_fused_partial *part = (mg_fused_partial *)ctx->fused_partials;
     int32_t *ctr = (int32_t *)ctx->fused_counters;
     if (dev_counts) {
-        if (!ctx->fused_dyn_dev) MG_HIP_CHECK(hipMalloc(&ctx->fused_dyn_dev, sizeof(mg_fused_devcounts)));
-        mg_fused_devcounts *dd = (mg_fused_devcounts *)ctx->fused_dyn_dev;
-        hipLaunchKernelGGL(mg_options_counts_kernel, dim3(n_options), dim3(256), 0, ctx->stream, tabd, ca, dd, counts_host);
+        if (!ctx->fused_dyn_dev) MG_HIP_CHECK(hipMalloc(&ctx->fused_dyn_dev, 2 * sizeof(mg_fused_devcounts)));
+        // were this step's counts drawn by the step before?
+        auto &fn = ctx->fused_next;
+        bool hit = fn.valid && fn.n_options == n_options && fn.n == n && ctx->opt[MG_OPT_OPTIONS_STEP] != 2;
+        for (int k = 0; k < n_options && hit; k++) hit = fn.seeds[k] == seeds[k] && fn.prims[k] == (const void *)prims[k];
+        const int slot = hit ? fn.slot : 0;
+        mg_fused_devcounts *dd = (mg_fused_devcounts *)ctx->fused_dyn_dev + slot, *dnext = (mg_fused_devcounts *)ctx->fused_dyn_dev + (slot ^ 1);
+        if (!hit) hipLaunchKernelGGL(mg_options_counts_kernel, dim3(n_options), dim3(256), 0, ctx->stream, tabd, ca, dd);
+        fn.valid = true; fn.n_options = n_options; fn.n = n; fn.slot = slot ^ 1;
+        for (int k = 0; k < n_options; k++) { fn.seeds[k] = seeds[k] + 1; fn.prims[k] = (const void *)prims[k]; }
         if (xdt == MG_F64)
             hipExtLaunchKernelGGL((mg_options_fused_kernel<true, true>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
-                                  tabd, dyn, (const mg_fused_devcounts *)dd, (int)n_options, wave_doubles, part, ctr);
+                                  tabd, dyn, (const mg_fused_devcounts *)dd, dnext, counts_host, (int)n_options, wave_doubles, part, ctr);
         else
             hipExtLaunchKernelGGL((mg_options_fused_kernel<false, true>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
-                                  tabd, dyn, (const mg_fused_devcounts *)dd, (int)n_options, wave_doubles, part, ctr);
+                                  tabd, dyn, (const mg_fused_devcounts *)dd, dnext, counts_host, (int)n_options, wave_doubles, part, ctr);
     } else if (xdt == MG_F64) {
         hipExtLaunchKernelGGL((mg_options_fused_kernel<true, false>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
-                              tabd, dyn, (const mg_fused_devcounts *)nullptr, (int)n_options, wave_doubles, part, ctr);
+                              tabd, dyn, (const mg_fused_devcounts *)nullptr, (mg_fused_devcounts *)nullptr, (int32_t *)nullptr, (int)n_options, wave_doubles, part, ctr);
     } else {
         hipExtLaunchKernelGGL((mg_options_fused_kernel<false, false>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
-                              tabd, dyn, (const mg_fused_devcounts *)nullptr, (int)n_options, wave_doubles, part, ctr);
+                              tabd, dyn, (const mg_fused_devcounts *)nullptr, (mg_fused_devcounts *)nullptr, (int32_t *)nullptr, (int)n_options, wave_doubles, part, ctr);
     }
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;

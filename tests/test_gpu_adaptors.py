@@ -663,6 +663,23 @@ def test_planner_step_with_component_counts_drawn_on_the_device(monkeypatch):
         for nm in names:
             np.testing.assert_array_equal(res_h[nm][0].view(np.uint64), res[nm][0].view(np.uint64))
             assert res_h[nm][1] == res[nm][1]
+    # counts drawn AHEAD: a step's kernel draws the counts of seed + 1 as well, the next step with those seeds starts without a
+    # counts kernel -- the same counts, candidates and winners as with the kernel in front (MG_OPT_OPTIONS_STEP 2)
+    runs = {}
+    for mode in (0, 2):
+        pset.ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, mode)
+        runs[mode] = []
+        for seed in (300, 301, 302, 310, 311):
+            best, res = pset.evaluate_options_on_device(names, cons, n_samples=1500, seed=seed, device_counts=True)
+            runs[mode].append((best, {nm: (res[nm][0].copy(), res[nm][1]) for nm in names}, {k: v.copy() for k, v in pset.last_counts.items()}))
+            for k, (name, p) in enumerate(zip(names, prims)):
+                np.testing.assert_array_equal(pset.last_counts[name], orc.device_multinomial_counts(1500, p["gmm_weights"], seed + k), err_msg="%s seed %d mode %d" % (name, seed, mode))
+    pset.ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, 0)
+    for (b0, r0, c0), (b2, r2, c2) in zip(runs[0], runs[2]):
+        assert b0 == b2
+        for nm in names:
+            np.testing.assert_array_equal(r0[nm][0].view(np.uint64), r2[nm][0].view(np.uint64))
+            assert r0[nm][1] == r2[nm][1]
     # distribution: one option, many seeds
     name, p = names[0], prims[0]
     w = np.asarray(p["gmm_weights"], dtype=np.float64)

@@ -1,5 +1,6 @@
 """Planner step (BASELINE configs[2]: 16 options x 4096 candidates) on builds of libmg_hip.so: wall time per step and the
-fused kernel's own duration (dispatch events).   python3 tools/opt_step_ab.py [lib.so ...]"""
+fused kernel's own duration (dispatch events).   python3 tools/opt_step_ab.py [lib.so[@OPTIONS_STEP] ...]
+(@2: MG_OPT_OPTIONS_STEP 2 = the counts kernel in front of every step, never the counts the step before drew ahead)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,8 +12,11 @@ prims = synthetic.make_graph_primitives(int(os.environ.get("NOPT", "16")))
 names = [p["name"] for p in prims]
 cons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]},
              {"type": "direction", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [0.5, 1.0]}] for nm, p in zip(names, prims)}
-for path in (sys.argv[1:] or [None]):
+for arg in (sys.argv[1:] or [None]):
+    path, _, optstep = (arg or "").partition("@")
     ctx = _capi.Context(0, lib=_capi.load_library(os.path.abspath(path))) if path else _capi.Context(0)
+    if optstep:
+        ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, int(optstep))
     pset = HipPrimitiveSet(prims, context=ctx)
     for i in range(100): pset.evaluate_options_on_device(names, cons, N, seed=i, device_counts=DEVC)
     t0 = time.perf_counter()
@@ -22,4 +26,4 @@ for path in (sys.argv[1:] or [None]):
     for i in range(200): pset.evaluate_options_on_device(names, cons, N, seed=i, device_counts=DEVC)
     ctx.profile_enable(0)
     ms, cnt = ctx.profile_get("options_step")
-    print("%-28s step %.1f us, fused kernel %.1f us (%d launches)" % (path or "default", wall, 1e3 * ms / max(cnt, 1), cnt), flush=True)
+    print("%-28s step %.1f us, fused kernel %.1f us (%d launches)" % (arg or "default", wall, 1e3 * ms / max(cnt, 1), cnt), flush=True)

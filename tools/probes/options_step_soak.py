@@ -19,7 +19,7 @@ cons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weig
 pset = HipPrimitiveSet(prims, separate_streams=False)
 bad = 0
 for i in range(steps):
-    dev = (i % 2) == 0
+    dev = i < steps // 2 or (i % 2) == 0     # first half: every step draws its counts on the device (the step before drew them ahead)
     best, results = pset.evaluate_options_on_device(names, cons, n, seed=1000 + i, device_counts=dev)
     if i % 10 == 0 or i < 20:       # the check reads 16 x (4096 errors + candidates) back: every tenth step
         for nm in names:
