@@ -570,8 +570,10 @@ int mg_gmm_log_prob_jac(mg_primitive *prim, const void *x_dev, int x_dtype, int6
                         double *jac_dev);
 
 /* GaussianMixture.sample on the device (reference motion_primitive.py:182-189):
- * Philox4x32-10 + Cholesky; rows grouped by component like sklearn, but NOT
- * bit-compatible with sklearn's Mersenne stream (validated distributionally).
+ * Philox4x32-10 + Box-Muller + Cholesky; rows grouped by component like sklearn, but NOT
+ * bit-compatible with sklearn's Mersenne stream (validated distributionally).  The standard normals
+ * carry float32 precision (the uniforms carry 32 bits; Box-Muller on the float32 transcendental units),
+ * x = mu + z L^T is float64 arithmetic; same seed, same rows -> same bits on gfx950.
  * counts: host array (K) of rows per component summing to n_samples.
  * x_dev (n, ld) of x_dtype, component_dev (n) int32 or NULL. */
 int mg_gmm_sample(mg_primitive *prim, int64_t n_samples, const int64_t *counts, uint64_t seed,

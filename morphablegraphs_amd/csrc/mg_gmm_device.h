@@ -161,10 +161,13 @@ __device__ __forceinline__ void mg_philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 
 
-// Four standard normals for (row b, group of four q) of a sampler call: one Philox block, two Box-Muller pairs, float64.
-// u in (0, 1] for the logarithm; the angle through sincospi (no 2 pi multiplication, exact argument reduction).  Every
+// Four standard normals for (row b, group of four q) of a sampler call: one Philox block, two Box-Muller pairs (float32
+// transcendental units since round 4, see below; returned as float64).  u in (0, 1] for the logarithm; the angle in revolutions.  Every
 // device sampler -- lane per row, MFMA tiles, the one-launch planner step -- draws through this function: same seed, same
 // rows, same bits.
+#ifndef MG_NORMAL_F32
+#define MG_NORMAL_F32 1
+#endif
 __device__ __forceinline__ void mg_normal4(int64_t b, int q, uint64_t seed, double (&z)[4]) {
     uint32_t rr[4];
     mg_philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)q, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rr);
@@ -173,6 +176,16 @@ __device__ __forceinline__ void mg_normal4(int64_t b, int q, uint64_t seed, doub
     const double u2 = ((double)rr[2] + 1.0) * inv, u3 = (double)rr[3] * inv;
 #ifdef MG_BM_SKIP
     z[0] = u0; z[1] = u1; z[2] = u2; z[3] = u3;
+#elif MG_NORMAL_F32
+    // Box-Muller on the float32 transcendental units (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32, whose argument is in revolutions:
+    // no 2 pi).  The uniforms carry 32 bits, so the normals never had more than that to say; in float64 the two logarithms, two
+    // roots and two sincospi per call were ~340 vector instructions and a fifth of the planner step's kernel.  Deterministic on
+    // gfx950; the contract of the device sampler is distributional (include/mg_hip.h), the tests hold moments and identities.
+    const float m0 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf((float)u0));   // -2 ln u = -2 ln 2 log2 u
+    const float m1 = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf((float)u2));
+    const float a0 = (float)u1, a1 = (float)u3;
+    z[0] = (double)(m0 * __builtin_amdgcn_cosf(a0)); z[1] = (double)(m0 * __builtin_amdgcn_sinf(a0));
+    z[2] = (double)(m1 * __builtin_amdgcn_cosf(a1)); z[3] = (double)(m1 * __builtin_amdgcn_sinf(a1));
 #else
     const double m0 = sqrt(-2.0 * log(u0)), m1 = sqrt(-2.0 * log(u2));
     double s0, c0, s1, c1;
