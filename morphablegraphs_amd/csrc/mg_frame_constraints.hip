@@ -520,6 +520,7 @@ extern "C" int mg_score_frame_constraints(mg_primitive *p, int32_t n_constraints
 struct mg_track_plan {
     mg_primitive *prim = nullptr;
     int32_t n_requests = 0, n_chan = 0, align_m = -1;        // align_m: links of the aligning node's chain (-1: plans without alignment support)
+    int32_t align_joint = -1;                                // the node that chain belongs to
     int32_t req_joint0[MG_TRACK_MAX_REQUESTS + 1] = {0};     // request q owns records req_joint0[q] .. req_joint0[q + 1]
     double *d_records = nullptr;    // [n_joints_total][MG_TRACK_REC]
     double *d_align_rec = nullptr;  // [MG_TRACK_REC]: the aligning node's chain (quaternion channels only are read)
@@ -751,6 +752,7 @@ extern "C" int mg_track_plan_create(mg_primitive *p, const mg_skeleton_desc *sk,
             }
             arec[0] = m;
             pl->align_m = m;
+            pl->align_joint = align_joint;
         }
     }
     if (rc != MG_OK) { delete pl; return rc; }
@@ -798,6 +800,10 @@ extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64
         if (!(hn > 0.0) || !std::isfinite(hn)) { mg_set_error("mg_joint_tracks: heading is zero or not finite"); return MG_ERR_INVALID_ARGUMENT; }
         a.align_mode = al->joint == MG_ALIGN_START_POSE ? 2 : 1;
         if (a.align_mode == 1 && pl->align_m < 0) { mg_set_error("mg_joint_tracks: the plan was made without an aligning joint"); return MG_ERR_INVALID_ARGUMENT; }
+        if (a.align_mode == 1 && al->joint != pl->align_joint) {
+            mg_set_error("mg_joint_tracks: the record aligns through joint %d, the plan was made for joint %d", al->joint, pl->align_joint);
+            return MG_ERR_INVALID_ARGUMENT;
+        }
         a.h0 = al->heading[0] / hn; a.h1 = al->heading[1] / hn; a.px = al->position[0]; a.py = al->position[1]; a.pz = al->position[2];
         for (int e = 0; e < 3; e++) a.ref[e] = al->ref_dir[e];
     }

@@ -382,6 +382,54 @@ def test_frame_constraint_entry_points_refuse_bad_arguments():
     assert lib.mg_align_frames(prim.handle, d_f.ptr, 2, 4, d_v.ptr, 3, C.byref(al)) == _capi.MG_ERR_INVALID_ARGUMENT
     al.heading[0], al.heading[1] = 0.0, 0.0
     assert lib.mg_align_frames(prim.handle, d_f.ptr, 2, 4, d_v.ptr, 4, C.byref(al)) == _capi.MG_ERR_INVALID_ARGUMENT
+    # round 4's entry points: the track plan, the tracks, the list scorer, the scorers side by side
+    vp = C.c_void_p
+    skd = sk.desc()
+    h = vp()
+    one = (C.c_int32 * 1)(1)
+    hand = (C.c_int32 * 1)(sk.index("LeftHand"))
+    assert lib.mg_track_plan_create(prim.handle, C.byref(skd), 0, one, hand, 0, C.byref(h)) == _capi.MG_ERR_INVALID_ARGUMENT        # no request
+    assert lib.mg_track_plan_create(prim.handle, C.byref(skd), 5, (C.c_int32 * 5)(1, 1, 1, 1, 1), (C.c_int32 * 5)(1, 2, 3, 4, 5), 0, C.byref(h)) == _capi.MG_ERR_INVALID_ARGUMENT
+    too_many = _capi.MG_FRAME_MAX_JOINTS + 1
+    assert lib.mg_track_plan_create(prim.handle, C.byref(skd), 1, (C.c_int32 * 1)(too_many), (C.c_int32 * too_many)(*range(1, too_many + 1)), 0, C.byref(h)) == _capi.MG_ERR_INVALID_ARGUMENT   # too many joints in a request
+    assert lib.mg_track_plan_create(prim.handle, C.byref(skd), 1, one, (C.c_int32 * 1)(999), 0, C.byref(h)) == _capi.MG_ERR_INVALID_ARGUMENT   # no such joint
+    assert lib.mg_track_plan_create(prim.handle, C.byref(skd), 1, one, hand, 999, C.byref(h)) == _capi.MG_ERR_INVALID_ARGUMENT                # no such aligning joint
+    plan = _capi.TrackPlan(prim, sk, [["LeftHand"]], align_joint=0)
+    d_S, d_o = ctx.upload(S.astype(np.float32)), ctx.malloc(2 * prim.n_canonical_frames * 3 * 8)
+    grids, outs = (vp * 1)(None), (vp * 1)(d_o.ptr.value)
+    call_tracks = lambda lat, dt, n, ld, al=None, g=grids, o=outs: lib.mg_joint_tracks(plan.handle, lat, dt, n, ld, al, g, o)
+    assert call_tracks(d_S.ptr, _capi.MG_F32, 2, 40) == 0
+    assert call_tracks(None, _capi.MG_F32, 2, 40) == _capi.MG_ERR_INVALID_ARGUMENT
+    assert call_tracks(d_S.ptr, _capi.MG_F32, 2, 39) == _capi.MG_ERR_INVALID_ARGUMENT            # ld < n_components
+    assert call_tracks(d_S.ptr, 7, 2, 40) == _capi.MG_ERR_INVALID_ARGUMENT                       # no such dtype
+    assert call_tracks(d_S.ptr, _capi.MG_F32, 2, 40, o=(vp * 1)(None)) == _capi.MG_ERR_INVALID_ARGUMENT
+    foreign_grid = other._prim.time_grid(np.arange(4.0))
+    assert call_tracks(d_S.ptr, _capi.MG_F32, 2, 40, g=(vp * 1)(foreign_grid.handle)) == _capi.MG_ERR_INVALID_ARGUMENT
+    al_other = _capi.ConstraintSet._marshal_alignment({"joint": sk.index("Spine1"), "position": (0.0, 0.0, 0.0), "heading": (0.0, 1.0)}, sk)
+    assert call_tracks(d_S.ptr, _capi.MG_F32, 2, 40, al=C.byref(al_other)) == _capi.MG_ERR_INVALID_ARGUMENT   # the plan aligns through the root
+    al_zero = _capi.ConstraintSet._marshal_alignment({"joint": 0, "position": (0.0, 0.0, 0.0), "heading": (0.0, 0.0)}, sk)
+    assert call_tracks(d_S.ptr, _capi.MG_F32, 2, 40, al=C.byref(al_zero)) == _capi.MG_ERR_INVALID_ARGUMENT
+    dd = _capi.FrameConstraintDesc()
+    dd.type, dd.weight, dd.n_joints = _capi.MG_FRAME_CA_POSITION, 1.0, 1
+    dd.axis_on[0], dd.target[0] = 1, 1.0
+    dptr, tptr = (vp * 1)(C.addressof(dd)), (vp * 1)(d_o.ptr.value)
+    tT, tJ = (C.c_int32 * 1)(prim.n_canonical_frames), (C.c_int32 * 1)(1)
+    assert lib.mg_score_frame_constraints(prim.handle, 1, dptr, tptr, tT, tJ, 2, d_e.ptr, 0, None) == 0
+    assert lib.mg_score_frame_constraints(prim.handle, 1, dptr, (vp * 1)(None), tT, tJ, 2, d_e.ptr, 0, None) == _capi.MG_ERR_INVALID_ARGUMENT
+    assert lib.mg_score_frame_constraints(prim.handle, 1, dptr, tptr, tT, tJ, 2, None, 0, None) == _capi.MG_ERR_INVALID_ARGUMENT
+    assert lib.mg_score_frame_constraints(prim.handle, 1, dptr, tptr, tT, (C.c_int32 * 1)(2), 2, d_e.ptr, 0, None) == _capi.MG_ERR_INVALID_ARGUMENT
+    assert lib.mg_score_frame_constraints(prim.handle, -1, dptr, tptr, tT, tJ, 2, d_e.ptr, 0, None) == _capi.MG_ERR_INVALID_ARGUMENT
+    traj = _capi.Trajectory(prim, np.array([[0.0, 0, 0], [1.0, 0, 0], [2.0, 0, 1.0]]))
+    two = lambda prims_, trajs_: lib.mg_score_trajectories(2, (vp * 2)(*prims_), (vp * 2)(*trajs_), (vp * 2)(d_S.ptr.value, d_S.ptr.value), _capi.MG_F32, 2,
+                                                       (C.c_int64 * 2)(40, 40), (C.c_double * 2)(0.0, 0.0), (C.c_double * 2)(1.0, 1.0), None,
+                                                       (vp * 2)(d_e.ptr.value, d_e.ptr.value), 0)
+    assert two([prim.handle.value] * 2, [traj.handle.value] * 2) == 0
+    assert two([prim.handle.value] * 2, [traj.handle.value, foreign.handle.value]) == _capi.MG_ERR_INVALID_ARGUMENT      # a trajectory of another primitive
+    assert two([prim.handle.value, None], [traj.handle.value] * 2) == _capi.MG_ERR_INVALID_ARGUMENT
+    ctx.synchronize()
+    plan.close()
+    traj.close()
+    foreign_grid.close()
     foreign.close()
-    for b in (d_t, d_e, d_f, d_v):
+    for b in (d_t, d_e, d_f, d_v, d_S, d_o):
         b.free()
