@@ -474,7 +474,7 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
         const int slot = hit ? fn.slot : 0;
         mg_fused_devcounts *dd = (mg_fused_devcounts *)ctx->fused_dyn_dev + slot, *dnext = (mg_fused_devcounts *)ctx->fused_dyn_dev + (slot ^ 1);
         if (!hit) hipLaunchKernelGGL(mg_options_counts_kernel, dim3(n_options), dim3(256), 0, ctx->stream, tabd, ca, dd);
-        fn.valid = true; fn.n_options = n_options; fn.n = n; fn.slot = slot ^ 1;
+        fn.valid = false; fn.n_options = n_options; fn.n = n; fn.slot = slot ^ 1;   // (valid once the launch below has been accepted)
         for (int k = 0; k < n_options; k++) { fn.seeds[k] = seeds[k] + 1; fn.prims[k] = (const void *)prims[k]; }
         if (xdt == MG_F64)
             hipExtLaunchKernelGGL((mg_options_fused_kernel<true, true>), dim3(total_wg), dim3(256), lds, ctx->stream, timed ? ev0 : nullptr, timed ? ev1 : nullptr, 0,
@@ -490,5 +490,6 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
                               tabd, dyn, (const mg_fused_devcounts *)nullptr, (mg_fused_devcounts *)nullptr, (int32_t *)nullptr, (int)n_options, wave_doubles, part, ctr);
     }
     MG_HIP_CHECK(hipGetLastError());
+    if (dev_counts) ctx->fused_next.valid = true;
     return MG_OK;
 }
