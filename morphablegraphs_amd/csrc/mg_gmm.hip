@@ -276,13 +276,19 @@ struct mg_objective_args {
     double error_scale, quality_scale;
     double *err_out, *obj_out;   // (B) float64 each, or NULL
 };
+// Waves per workgroup: sixteen for the mixture alone (four per SIMD cover each other's fragment reads), TWELVE with SCORE: at four
+// waves per SIMD a wave has 128 registers, and the scoring's state on top of the mixture's (120) spilled 19 of them into the
+// store stream's way; at three it has 170, nothing spills, and the matrix pipe is as busy (the mixture alone runs in the same
+// 65.5 us with twelve waves; with eight it loses 5 us).  131 072 candidates: 75.5 -> 73.2 us.
+template <bool SCORE> struct mg_gmm_lds_nw { static constexpr int value = SCORE ? 12 : 16; };
 template <int KK, bool X_F64, bool OUT_F64, bool SCORE>
-__global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__restrict__ Ppack,  // [K][JT][KK][64]
+__global__ __launch_bounds__(64 * mg_gmm_lds_nw<SCORE>::value) void mg_gmm_logp_lds_kernel(const double *__restrict__ Ppack,  // [K][JT][KK][64]
                                                                const double *__restrict__ mP,     // [K][JT*16]
                                                                const double *__restrict__ cst,    // [K]
                                                                const void *__restrict__ x, void *__restrict__ out,
                                                                const mg_gmm_mfma_args a, const int64_t n_tiles, const mg_objective_args oa) {
     constexpr int JTM = (KK + 3) / 4;
+    constexpr int NW = mg_gmm_lds_nw<SCORE>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int K = a.K;
     constexpr int JT = JTM;                         // KK is the smallest even number of k-steps for L: ceil(L / 16) == JTM (checked at the launch)
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
     const int cl = lane & 15, g = lane >> 4;
     // staging: a wave copies whole 512-byte fragments (wave-uniform index arithmetic, several loads in flight)
 #pragma unroll 4
-    for (int F = wave; F < K * nf; F += 16) {
+    for (int F = wave; F < K * nf; F += NW) {
         const int k = F / nf, f = F - k * nf;
         int jt = 0, off = 0;
 #pragma unroll
@@ -305,20 +311,20 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
         }
         lds_f[F * 64 + lane] = Ppack[(((size_t)k * JT + jt) * KK + (f - off)) * 64 + lane];
     }
-    for (int e = tid; e < K * JT * 16; e += 1024) lds_c[e] = -mP[e];
+    for (int e = tid; e < K * JT * 16; e += 64 * NW) lds_c[e] = -mP[e];
     __syncthreads();
     mg_lds_f64 *terms = lds_w + (size_t)wave * (SCORE ? oa.wave_doubles : 2 * K * 16), *exps = terms + K * 16;
     // SCORE, pairs: the residual lanes are the kernel's vector work (a direction residual is five roots, six divisions and an arc cosine
     // in float64; vector work on a SIMD takes the matrix pipe's issue slots) and a tile fills 16 n of a wave's 64 lanes.  A wave therefore
     // parks the channels of every other tile in a second buffer and scores two tiles' candidates in one pass: half the instructions.
-    double *vals_b = SCORE && oa.pair_doubles > 0 ? (double *)(lds_w + (size_t)16 * oa.wave_doubles + (size_t)wave * oa.pair_doubles) : nullptr;
+    double *vals_b = SCORE && oa.pair_doubles > 0 ? (double *)(lds_w + (size_t)NW * oa.wave_doubles + (size_t)wave * oa.pair_doubles) : nullptr;
     bool pending = false;
     double r_a = 0.0;
     int64_t b0_a = 0;
     int ncand_a = 0;
     // tile t of the launch: workgroup t % grid, wave (t / grid) % 16 -- consecutive tiles go to different CUs.  (Requesting the
     // next tile's latents a tile ahead changes nothing: the other three waves of the SIMD cover the load.)
-    for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += (int64_t)gridDim.x * 16) {
+    for (int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
         const int64_t b0 = tile * 16;
         const int ncand = (int)((a.B - b0) < 16 ? (a.B - b0) : 16);
         typename mg_gmm_xt<X_F64>::type xf[KK];
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(1024) void mg_gmm_logp_lds_kernel(const double *__r
         if constexpr (SCORE) {
             // the wave's buffer again, now for the tile's pose channels and residuals (LDS serves a wave's requests in order)
             const int RT = oa.RT, rows = oa.rows, vs = rows + 1, n = oa.sa.n;   // (only the rows in use are kept: sixteen waves share the LDS)
-            const bool park = vals_b != nullptr && !pending && tile + (int64_t)gridDim.x * 16 < n_tiles;   // another tile follows: score the two together
+            const bool park = vals_b != nullptr && !pending && tile + (int64_t)gridDim.x * NW < n_tiles;   // another tile follows: score the two together
             double *vals = park ? vals_b : (double *)terms, *resid = (double *)terms + 16 * vs;           // resid: [2][n][16]
             for (int rt = 0; rt < RT; rt++) {
                 const double *wp = oa.Wpack + ((size_t)rt * KK) * 64 + lane;
@@ -429,10 +435,11 @@ static int mg_launch_gmm_lds_kk(mg_primitive *p, const void *x, int xdt, int64_t
     mg_objective_args oa;
     memset(&oa, 0, sizeof(oa));
     const int wave_doubles = cs ? mg_objective_wave_doubles(p, cs) : 2 * p->K * 16;
-    size_t lds = ((size_t)p->K * mg_gmm_lds_nf(KK, a.JT) * 64 + (size_t)p->K * a.JT * 16 + (size_t)16 * wave_doubles) * 8;
+    const int nw = cs ? mg_gmm_lds_nw<true>::value : mg_gmm_lds_nw<false>::value;
+    size_t lds = ((size_t)p->K * mg_gmm_lds_nf(KK, a.JT) * 64 + (size_t)p->K * a.JT * 16 + (size_t)nw * wave_doubles) * 8;
     const int pair_doubles = cs ? 16 * (cs->rows + 1) : 0;
-    const bool pairs = cs && lds + (size_t)16 * pair_doubles * 8 <= 160 * 1024;   // room for the second channel buffers: two tiles per residual pass
-    if (pairs) lds += (size_t)16 * pair_doubles * 8;
+    const bool pairs = cs && lds + (size_t)nw * pair_doubles * 8 <= 160 * 1024;   // room for the second channel buffers: two tiles per residual pass
+    if (pairs) lds += (size_t)nw * pair_doubles * 8;
     if (cs) {
         mg_score_args &sa = oa.sa;
         sa.W = cs->d_W; sa.bias = cs->d_bias; sa.par = cs->d_par; sa.woff = cs->d_woff; sa.chain = cs->d_chain; sa.choff = cs->d_choff;
@@ -460,8 +467,8 @@ static int mg_launch_gmm_lds_kk(mg_primitive *p, const void *x, int xdt, int64_t
         p->ctx->attr_gmm_lds |= abit;
     }
     if (cs) {   // the objective: log p in float64 (or not at all), errors and objective in float64
-        if (xf) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, true, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
-        else hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, true, true>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
+        if (xf) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, true, true>), dim3(grid), dim3(64 * nw), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
+        else hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, false, true, true>), dim3(grid), dim3(64 * nw), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
     }
     else if (xf && of) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, true, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
     else if (xf) hipLaunchKernelGGL((mg_gmm_logp_lds_kernel<KK, true, false, false>), dim3(grid), dim3(1024), lds, st, p->d_gPpack, p->d_gmPpad, p->d_gconst, x, out, a, n_tiles, oa);
@@ -481,7 +488,7 @@ bool mg_objective_can_fuse(const mg_primitive *p, const mg_constraint_set *cs) {
     if (cs->has_pose || cs->align_joint > 0) return false;
     const int JT = (p->Lg + 15) / 16;
     if (JT != (p->KKg + 3) / 4) return false;
-    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(p->KKg, JT) * 64 + (size_t)p->K * JT * 16 + (size_t)16 * mg_objective_wave_doubles(p, cs)) * 8;
+    const size_t lds = ((size_t)p->K * mg_gmm_lds_nf(p->KKg, JT) * 64 + (size_t)p->K * JT * 16 + (size_t)mg_gmm_lds_nw<true>::value * mg_objective_wave_doubles(p, cs)) * 8;
     return lds <= 160 * 1024 - 64;
 }
 int mg_launch_objective(mg_primitive *p, const mg_constraint_set *cs, const void *x, int xdt, int64_t B, int64_t ld, double error_scale,
