@@ -631,6 +631,32 @@ def test_planner_step_in_one_launch_is_bit_identical_to_the_per_option_chains(dt
             assert r1[name][1] == np.min(r1[name][2])
 
 
+def test_planner_step_at_the_size_of_configs2_returns_what_its_buffers_hold():
+    """BASELINE configs[2] at its stated size -- 16 primitives x 4096 device-sampled candidates each -- through the one-launch step,
+    several steps in a row (counts drawn ahead from the second on): every option's record is the first minimum of the errors the
+    step left on the device and that row of its candidates, the counts sum to the batch, the best option is the smallest error."""
+    prims = synthetic.make_graph_primitives(16)
+    names = [p["name"] for p in prims]
+    cons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]},
+                 {"type": "direction", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [0.5, 1.0]}] for nm, p in zip(names, prims)}
+    pset = HipPrimitiveSet(prims, separate_streams=False)
+    n = 4096
+    for step in range(4):
+        best, res = pset.evaluate_options_on_device(names, cons, n, seed=70 + step, device_counts=True)
+        errs = []
+        for nm in names:
+            prim = pset.nodes[nm]._prim
+            d_x, d_e, d_r = pset._buffers[(nm, n, np.dtype(np.float32).str)]
+            e = prim.ctx.download(d_e, (n,), np.float64)
+            x = prim.ctx.download(d_x, (n, prim.n_gmm_dims), np.float32)
+            w = int(np.argmin(e))
+            assert res[nm][1] == e[w], (step, nm)
+            np.testing.assert_array_equal(np.asarray(res[nm][0], dtype=np.float64), x[w].astype(np.float64))
+            assert pset.last_counts[nm].sum() == n and np.all(pset.last_counts[nm] >= 0)
+            errs.append(e[w])
+        assert best == names[int(np.argmin(errs))]
+
+
 def test_planner_step_with_component_counts_drawn_on_the_device(monkeypatch):
     """mg_options_step_device_counts: the counts are the ones the oracle's restatement of the device draw gives (Philox4x32-10
     keyed by seed + option index, histogram of n categorical draws), bit for bit; given those counts the step is the step

@@ -212,7 +212,7 @@ def test_time_objective_for_batches():
     node.motion_primitive._prim.close()
 
 
-@pytest.mark.parametrize("n", [17, 4099, 40000])
+@pytest.mark.parametrize("n", [17, 4099, 40000, 131072 + 5])   # (the last: BASELINE configs[4]'s iteration -- waves with two and three tiles, a ragged last one)
 def test_objective_in_one_launch_is_bit_identical_to_the_two_calls(n):
     """mg_objective_error_and_naturalness: the LDS-resident mixture kernel scores the keyframe constraints on
     the latent tile it holds and writes error_scale * error + quality_scale * (-log p).  The three outputs must be the bits of
