@@ -232,8 +232,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_PLACED_HOLD        n > 0: the placement scan holds at most n candidates at once (default: a quarter of the free memory);
  *                             tests use it to make the scan drop candidates while it runs
  *   MG_OPT_TRAJECTORY_LANES   1 = one lane per candidate in the closest-point walks of mg_score_trajectory[_points / ies] whatever the
- *                             batch, 8 = eight lanes up to 65536 candidates (default: eight lanes while at most 28672 candidates are
- *                             in flight, one beyond -- the same bits either way)
+ *                             batch, 8 / 4 = that many lanes up to 65536 candidates (default: eight lanes while at most 28672
+ *                             candidates are in flight, four up to 40960, one beyond -- the same bits in every case)
  *   MG_OPT_ROOT_MODE          how the float32 frames kernels compute the root-translation channels (the two forms differ in
  *                             the last bits; see mg_primitive_root_mode): 0, 1 = the float64 pipeline (the default: the faster
  *                             of the two on gfx950), 2 = the mean/delta split, 3 = the split where the primitive's accuracy gate

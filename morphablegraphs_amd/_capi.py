@@ -29,7 +29,7 @@ MG_OPT_GMM_KERNEL = 9        # mg_gmm_log_prob: 0 = by batch size, 1 = one tile 
 MG_OPT_SCORE_KERNEL = 10     # mg_score_constraints: 0 = by batch size, 1 = a wave per 16 candidates, 2 = a wave per 64 candidates
 MG_OPT_ROOT_MODE = 11        # root channels of the float32 frames kernels: 0, 1 = float64 pipeline (default), 2 = mean/delta split, 3 = split where the gate allows
 MG_OPT_PLACED_HOLD = 12      # n > 0: the placement scan holds at most n candidates at once (tests)
-MG_OPT_TRAJECTORY_LANES = 13  # closest-point walks: 1 = one lane per candidate whatever the batch, 8 = eight lanes up to 65536 candidates (default: eight while <= 28672 candidates are in flight)
+MG_OPT_TRAJECTORY_LANES = 13  # closest-point walks: 1 = one lane per candidate whatever the batch, 8 = eight lanes up to 65536 candidates (default: eight while <= 28672 candidates are in flight, four up to 40960)
 MG_OPT_COUNT = 14
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6

@@ -129,10 +129,13 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
 // candidates are 64 waves on 1024 SIMDs, each a chain of ~18 dependent float64 evaluations per frame): the lanes of a candidate split
 // its coefficient rows (each row the same fma chain as above), then walk the frames together -- every lane the same q, the grid values
 // of the closest-point search side by side (mg_traj_closest_dist_coop).  Same operations on the same values: the same bits.
-#define MG_TRAJ_W 8
+// (W = 8 or 4: with four lanes a window holds three grid values and a walk of six steps takes three more rounds, but the Newton steps
+// are repeated four times, not eight: measured, four lanes win only between ~28 000 and ~40 000 candidates in flight -- 762 us at
+// 32 768 against 899 with eight and 888 with one)
 #define MG_TRAJ_COOP_BLOCK 64
-#define MG_TRAJ_COOP_CANDS (MG_TRAJ_COOP_BLOCK / MG_TRAJ_W)
+template <int MG_TRAJ_W>
 __device__ __forceinline__ void mg_trajectory_coop_body(const mg_traj_args &a, const int64_t block, double *lds) {
+    constexpr int MG_TRAJ_COOP_CANDS = MG_TRAJ_COOP_BLOCK / MG_TRAJ_W;
     // lds: [CANDS][L] latents, [CANDS][rows] root coefficient rows, [12 n_seg + 3] the polynomials
     const int tid = threadIdx.x, grp = tid / MG_TRAJ_W, sub = tid % MG_TRAJ_W;
     const int64_t b = block * MG_TRAJ_COOP_CANDS + grp;
@@ -209,9 +212,10 @@ __device__ __forceinline__ void mg_trajectory_coop_body(const mg_traj_args &a, c
         a.out[b] = a.accumulate ? a.out[b] + e : e;
     }
 }
+template <int W>
 __global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_kernel(mg_traj_args a) {
     extern __shared__ double lds[];
-    mg_trajectory_coop_body(a, blockIdx.x, lds);
+    mg_trajectory_coop_body<W>(a, blockIdx.x, lds);
 }
 
 // One lane per candidate for batches that fill the chip that way (from ~32 768 candidates in flight: eight lanes per candidate repeat
@@ -314,11 +318,12 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_stream_kernel(mg_
 // other 7 ms; side by side they take what the chip's four quarters take.
 #define MG_TRAJ_MULTI_MAX 16
 struct mg_traj_multi { int32_t n; int32_t wg0[MG_TRAJ_MULTI_MAX + 1]; mg_traj_args a[MG_TRAJ_MULTI_MAX]; };
+template <int W>
 __global__ __launch_bounds__(MG_TRAJ_COOP_BLOCK) void mg_trajectory_coop_multi_kernel(const mg_traj_multi m) {
     extern __shared__ double lds[];
     int k = 0;
     while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) k++;
-    mg_trajectory_coop_body(m.a[k], (int64_t)blockIdx.x - m.wg0[k], lds);
+    mg_trajectory_coop_body<W>(m.a[k], (int64_t)blockIdx.x - m.wg0[k], lds);
 }
 __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_stream_multi_kernel(const mg_traj_multi m) {
     extern __shared__ double lds[];
@@ -326,10 +331,17 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_stream_multi_kern
     while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) k++;
     mg_trajectory_stream_body(m.a[k], (int64_t)blockIdx.x - m.wg0[k], lds);
 }
-// candidates in flight up to which the eight-lane walk is the faster one (measured: tools/probes/trajectory_lanes.py)
-#define MG_TRAJ_COOP_MAX_TOTAL 28672
-// one lane per candidate fills the chip from about this many candidates on (256 CUs x 4 SIMDs x 64 lanes x ~2 waves)
-#define MG_TRAJ_COOP_MAX_B 65536
+// Lanes per candidate for `total` candidates in flight (measured: tools/probes/trajectory_lanes.py): eight while most SIMDs would idle
+// otherwise, four in between, one (the streaming kernel) once one lane per candidate fills the chip.  MG_OPT_TRAJECTORY_LANES forces.
+#define MG_TRAJ_COOP_MAX_B 65536       // (no batch above this takes several lanes per candidate, whatever is forced)
+#define MG_TRAJ_W8_MAX_TOTAL 28672
+#define MG_TRAJ_W4_MAX_TOTAL 40960
+static int mg_traj_lanes(const mg_context *ctx, int64_t B, int64_t total) {
+    const int opt = ctx->opt[MG_OPT_TRAJECTORY_LANES];
+    if (opt == 1 || B > MG_TRAJ_COOP_MAX_B) return 1;
+    if (opt == 8 || opt == 4) return opt;
+    return total <= MG_TRAJ_W8_MAX_TOTAL ? 8 : (total <= MG_TRAJ_W4_MAX_TOTAL ? 4 : 1);
+}
 
 template <typename T>
 static int mg_traj_upload(const std::vector<T> &h, T **d) {
@@ -483,12 +495,15 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
         p->ctx->attr_traj |= 1u;
     }
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
-    const size_t coop_lds = (size_t)MG_TRAJ_COOP_CANDS * (p->L + t->rows) * 8 + poly_bytes;
-    const int lanes_opt = p->ctx->opt[MG_OPT_TRAJECTORY_LANES];
-    const bool coop = coop_lds <= 60 * 1024 && lanes_opt != 1 && B <= (lanes_opt == 8 ? MG_TRAJ_COOP_MAX_B : MG_TRAJ_COOP_MAX_TOTAL);
+    int lanes = mg_traj_lanes(p->ctx, B, B);
+    const int coop_cands = MG_TRAJ_COOP_BLOCK / std::max(lanes, 1);
+    const size_t coop_lds = (size_t)coop_cands * (p->L + t->rows) * 8 + poly_bytes;
+    if (coop_lds > 60 * 1024) lanes = 1;
     const size_t stream_lds = (size_t)p->L * MG_TRAJ_BLOCK * 8 + poly_bytes;
+    const dim3 coop_grid((unsigned)((B + coop_cands - 1) / coop_cands));
     mg_prof_begin(p->ctx, 10);
-    if (coop) hipLaunchKernelGGL(mg_trajectory_coop_kernel, dim3((unsigned)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS)), dim3(MG_TRAJ_COOP_BLOCK), coop_lds, p->ctx->stream, a);
+    if (lanes == 8) hipLaunchKernelGGL(mg_trajectory_coop_kernel<8>, coop_grid, dim3(MG_TRAJ_COOP_BLOCK), coop_lds, p->ctx->stream, a);
+    else if (lanes == 4) hipLaunchKernelGGL(mg_trajectory_coop_kernel<4>, coop_grid, dim3(MG_TRAJ_COOP_BLOCK), coop_lds, p->ctx->stream, a);
     else if (stream_lds <= 60 * 1024) hipLaunchKernelGGL(mg_trajectory_stream_kernel, dim3(grid), dim3(MG_TRAJ_BLOCK), stream_lds, p->ctx->stream, a);
     else if (poly_lds) hipLaunchKernelGGL(mg_trajectory_kernel<true>, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
     else hipLaunchKernelGGL(mg_trajectory_kernel<false>, dim3(grid), dim3(MG_TRAJ_BLOCK), lds, p->ctx->stream, a);
@@ -513,15 +528,15 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
         if (!prims[k] || prims[k]->ctx != prims[0]->ctx) { mg_set_error("mg_score_trajectories: the primitives must share one context"); return MG_ERR_INVALID_ARGUMENT; }
     mg_context *ctx = prims[0]->ctx;
     MG_HIP_CHECK(hipSetDevice(ctx->device));
-    const int lanes_opt = ctx->opt[MG_OPT_TRAJECTORY_LANES];
-    // eight lanes per candidate while the candidates in flight leave SIMDs idle, one lane (the streaming form) beyond
-    const bool coop = lanes_opt != 1 && B <= MG_TRAJ_COOP_MAX_B && (lanes_opt == 8 || (int64_t)n * B <= MG_TRAJ_COOP_MAX_TOTAL);
+    const int lanes = mg_traj_lanes(ctx, B, (int64_t)n * B);
+    const bool coop = lanes > 1;
+    const int coop_cands = MG_TRAJ_COOP_BLOCK / lanes;
     bool together = B > 0 && n > 1;
     size_t lds = 0;
     for (int k = 0; k < n && together; k++) {
         if (!trajectories[k]) { mg_set_error("mg_score_trajectories: trajectory %d is NULL", k); return MG_ERR_INVALID_ARGUMENT; }
         const size_t poly_bytes = ((size_t)trajectories[k]->n_seg * 12 + 3) * 8;
-        const size_t need = coop ? (size_t)MG_TRAJ_COOP_CANDS * (prims[k]->L + trajectories[k]->rows) * 8 + poly_bytes
+        const size_t need = coop ? (size_t)coop_cands * (prims[k]->L + trajectories[k]->rows) * 8 + poly_bytes
                                  : (size_t)prims[k]->L * MG_TRAJ_BLOCK * 8 + poly_bytes;
         if (need > 60 * 1024) together = false;
         lds = std::max(lds, need);
@@ -534,7 +549,7 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
         }
         return MG_OK;
     }
-    const int cands_per_wg = coop ? MG_TRAJ_COOP_CANDS : MG_TRAJ_BLOCK;
+    const int cands_per_wg = coop ? coop_cands : MG_TRAJ_BLOCK;
     const int per = (int)((B + cands_per_wg - 1) / cands_per_wg);
     for (int k0 = 0; k0 < n; k0 += MG_TRAJ_MULTI_MAX) {
         mg_traj_multi m;
@@ -548,7 +563,8 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
             m.wg0[i + 1] = m.wg0[i] + per;
         }
         mg_prof_begin(ctx, 10);
-        if (coop) hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
+        if (lanes == 8) hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel<8>, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
+        else if (lanes == 4) hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel<4>, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
         else hipLaunchKernelGGL(mg_trajectory_stream_multi_kernel, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_BLOCK), lds, ctx->stream, m);
         mg_prof_end(ctx, 10);
         MG_HIP_CHECK(hipGetLastError());
@@ -582,9 +598,9 @@ extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *
         p->ctx->attr_traj |= 1u;
     }
     mg_prof_begin(p->ctx, 10);
-    const int lanes_opt = p->ctx->opt[MG_OPT_TRAJECTORY_LANES];
-    if (poly_bytes <= 60 * 1024 && lanes_opt != 1 && B <= (lanes_opt == 8 ? MG_TRAJ_COOP_MAX_B : MG_TRAJ_COOP_MAX_TOTAL))
-        hipLaunchKernelGGL(mg_trajectory_coop_kernel, dim3((unsigned)((B + MG_TRAJ_COOP_CANDS - 1) / MG_TRAJ_COOP_CANDS)), dim3(MG_TRAJ_COOP_BLOCK), poly_bytes, p->ctx->stream, a);
+    const int lanes = poly_bytes <= 60 * 1024 ? mg_traj_lanes(p->ctx, B, B) : 1;
+    if (lanes == 8) hipLaunchKernelGGL(mg_trajectory_coop_kernel<8>, dim3((unsigned)((B + 7) / 8)), dim3(MG_TRAJ_COOP_BLOCK), poly_bytes, p->ctx->stream, a);
+    else if (lanes == 4) hipLaunchKernelGGL(mg_trajectory_coop_kernel<4>, dim3((unsigned)((B + 15) / 16)), dim3(MG_TRAJ_COOP_BLOCK), poly_bytes, p->ctx->stream, a);
     else if (poly_bytes <= 158 * 1024) hipLaunchKernelGGL(mg_trajectory_kernel<true>, dim3(grid), dim3(MG_TRAJ_BLOCK), poly_bytes, p->ctx->stream, a);
     else hipLaunchKernelGGL(mg_trajectory_kernel<false>, dim3(grid), dim3(MG_TRAJ_BLOCK), 0, p->ctx->stream, a);
     mg_prof_end(p->ctx, 10);

@@ -152,11 +152,12 @@ def test_closest_point_walk_by_eight_lanes_is_the_one_lane_walk_bit_for_bit():
 
     def both(fn):
         out = []
-        for lanes in (0, 1):
+        for lanes in (0, 1, 4):       # (0: eight lanes at this batch size; 1: the streaming one-lane kernel; 4: four lanes)
             ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, lanes)
             out.append(fn())
         ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, 0)
-        return out
+        assert np.array_equal(out[2][0].view(np.uint64), out[0][0].view(np.uint64)) and np.array_equal(out[2][1].view(np.uint64), out[0][1].view(np.uint64))
+        return out[:2]
     moved = 0
     for cps, gran in paths:
         traj = cached_trajectory(prim, {"type": "trajectory", "control_points": cps.tolist(), "granularity": gran})

@@ -28,22 +28,23 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
-for B in (2048, 4096, 8192, 16384, 24576, 32768, 65536, 131072):
+for B in (2048, 4096, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 131072):
     S = ctx.upload(np.random.default_rng(1).standard_normal((B, 40)).astype(np.float32))
     e = ctx.malloc(B * 8)
     out = {}
-    for lanes in (8, 1):
-        if lanes == 8 and B > 65536:
+    for lanes in (8, 4, 1):
+        if lanes != 1 and B > 65536:
             continue
         ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, lanes)
         out[lanes] = (timed(lambda: prim.score_trajectory_dev(traj, S, np.float32, B, 40, e), 20), ctx.download(e, (B,), np.float64))
-    same = 8 not in out or np.array_equal(out[8][1], out[1][1])
-    print("B = %6d: eight lanes %s us, one lane (streaming) %8.1f us, same bits %s" % (B, "%8.1f" % out[8][0] if 8 in out else "       -", out[1][0], same), flush=True)
+    same = all(np.array_equal(out[k][1], out[1][1]) for k in out)
+    print("B = %6d: eight lanes %s us, four lanes %s us, one lane (streaming) %8.1f us, same bits %s" % (
+        B, "%8.1f" % out[8][0] if 8 in out else "       -", "%8.1f" % out[4][0] if 4 in out else "       -", out[1][0], same), flush=True)
     S.free(); e.free()
 n, B = 16, 4096
 xs = [ctx.upload(np.random.default_rng(2 + i).standard_normal((B, 40)).astype(np.float32)) for i in range(n)]
 es = [ctx.malloc(B * 8) for _ in range(n)]
-for lanes in (8, 1, 0):
+for lanes in (8, 4, 1, 0):
     ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, lanes)
     t = timed(lambda: _capi.Primitive.score_trajectories_dev([prim] * n, [traj] * n, xs, np.float32, B, [40] * n, es, [0.0] * n, [1.0] * n), 20)
     print("16 scorers x 4096 side by side, MG_OPT_TRAJECTORY_LANES %d: %8.1f us" % (lanes, t), flush=True)
