@@ -508,15 +508,19 @@ int mg_align_frames(mg_primitive *prim, double *frames_dev, int64_t n_samples, i
 int mg_frame_constraint_width(const mg_frame_constraint_desc *constraint, int32_t n_times);
 int mg_score_frame_constraint(mg_primitive *prim, const mg_frame_constraint_desc *constraint, const double *tracks_dev, int64_t n_samples,
                               int32_t n_times, int32_t n_joints, double *errors_dev, int accumulate, double *residuals_dev);
-/* The per-frame constraints WITHOUT frames in memory (two launches for a whole constraint list):
+/* The per-frame constraints WITHOUT frames in memory (two launches for a whole constraint list) -- what the reference does per candidate in
+ * MotionPrimitiveConstraints.evaluate (constraints/motion_primitive_constraints.py:96-118): back-project, align to the previous frames
+ * (:106-116), then every constraint's evaluate_motion_spline over skeleton.nodes[joint].get_global_position(frame) of every frame
+ * (spatial_constraints/trajectory_constraint.py:79-121, keyframe_constraints/global_transform_ca_constraint.py:33-46, ...):
  * mg_joint_tracks: the tracks (n, T, joints, 3) float64 that mg_back_project_frames_f64 -> mg_align_frames -> mg_joint_positions give
  * through (n, T, n_dim) float64 frames -- ~98 KB of traffic per 'walk' candidate -- from ONE launch that keeps a candidate's control
  * points of the channels the joints' chains read in LDS: the same operations on the same values (bit-identical tracks), 24 bytes per
  * (candidate, time, joint) written.  A plan (mg_track_plan_create) fixes up to 4 requests = (time grid at the call, 1 .. 8 joints);
  * align_joint = the node candidates are aligned through when mg_joint_tracks gets an alignment (0: the root; -1: never aligned).
  * mg_score_frame_constraints: a LIST of constraints over those tracks in one launch per 4 constraints, errors added in list order
- * (what mg_score_frame_constraint gives called once per constraint with accumulate); residuals_dev: NULL, or one pointer (or NULL)
- * per constraint. */
+ * (what mg_score_frame_constraint gives called once per constraint with accumulate; a joint's trajectory constraint, MG_FRAME_JOINT_TRAJECTORY,
+ * below 65 536 candidates as a launch of mg_score_trajectory_points at its place in the order); residuals_dev: NULL, or one pointer (or
+ * NULL) per constraint. */
 typedef struct mg_track_plan mg_track_plan;
 int mg_track_plan_create(mg_primitive *prim, const mg_skeleton_desc *skeleton, int32_t n_requests, const int32_t *n_joints, const int32_t *joints,
                          int32_t align_joint, mg_track_plan **out);
