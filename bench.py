@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F64_MFMA_PEAK_TFLOPS = 78.6   # AMD's published MI355X float64 matrix figure (the guide has no float64 row)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r04_summary.json", "r04_frame_constraints_summary.json")]   # tools/prof_all.sh
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r04_summary.json", "r04_frame_constraints_summary.json", "r04a_summary.json")]   # tools/prof_all.sh (r04a: its counter passes ran the tile-major kernel, the one slow-class boxes get)
 METRIC = "motion-primitive samples scored+back-projected/sec; fraction of HBM roofline"
 L, F, D, NB, K = 40, 156, 79, 31, 8
 
