@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void mg_placement_fill_kernel(f32x4p *buf, siz
 // on.  (Round 3's bench met a buffer at 5.996: one threshold for both made a 0.07 % margin flip the kernel choice, and a second
 // probe of the same buffer contradict the arena.)
 #define MG_PLACED_CLASS_TBPS 5.9
+#define MG_PLACED_DEEP_CANDIDATES 160       // the default scan's last resort (see mg_region_create)
 static double mg_placement_tbps(int64_t bytes, double pattern_us) {   // 0: the probe is too small to fill the chip (or was not timed)
     const int64_t cand_bytes = (int64_t)MG_PP_T * MG_PP_D * 4;
     const int64_t ntiles = std::min<int64_t>(bytes / (16 * cand_bytes), 1 << 20);
@@ -197,8 +198,9 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
         }
         return !best_fast;
     };
+    int limit = budget;
     auto plain = [&](int count) {
-        for (int i = 0; i < count && probed < budget; i++) {
+        for (int i = 0; i < count && probed < limit; i++) {
             void *p = nullptr;
             if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return; }   // out of memory: settle for the best so far
             if (!consider(p, false)) return;
@@ -218,6 +220,20 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
                 go = consider(p, true);
             }
         if (rc == MG_OK && !best_fast) plain(budget - probed);
+    }
+    // The deep scan.  Fast-class memory is SPARSE: of 400 plain allocations of 404 MB held together on one box 14 were fast
+    // (tools/probes/deep_scan.py: the first at the 16th, seven among the 26th .. 50th, none among the 101st .. 200th), so a scan of 32
+    // misses it on one box in three -- the "slow boxes" of rounds 2-4, 0.54 of the roofline instead of 0.64.  Where the caller set no
+    // budget of its own and the first 32 candidates were all slow, the scan goes on, plain allocations only, until a fast one turns
+    // up, MG_PLACED_DEEP_CANDIDATES have been probed, or the candidates held (they must stay allocated, or the allocator hands the
+    // same memory out again) reach the hold cap: ~12 ms per candidate, once per region.
+    if (rc == MG_OK && best.p && !best_fast && max_candidates == 0 && ctx->opt[MG_OPT_PLACED_HOLD] == 0) {
+        limit = MG_PLACED_DEEP_CANDIDATES;
+        while (probed < limit && !best_fast && rc == MG_OK && (held.size() + 3) * bytes <= hold_cap) {
+            const int before = probed;
+            plain(1);
+            if (probed == before) break;        // out of memory
+        }
     }
     (void)hipStreamSynchronize(ctx->stream);
     for (const cand &c : held) drop(c);
