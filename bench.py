@@ -688,8 +688,8 @@ def run_graph(args, emit=True):
         k_flop, k_name, k_n, launches = score_flop + sample_flop, "mg_options_fused_kernel (one launch per step)", slots["options_step"][1], 1
         note = ("one launch per planner step: workgroups dealt over the options, a wave draws a 16-candidate tile (Philox + Box-Muller, x = mu + z L^T on the f64 "
                 "matrix pipe), scores it from LDS and keeps the first minimum; the last workgroup of an option reduces and copies the winner; one read-back. "
-                "The kernel is bound by its ~17 us latency chain (launch, table and fragment loads, release / counter / acquire, last-block reduction) plus ~7 us per "
-                "1024 candidates x 16 options of float64 vector work (sampler transcendental functions, residuals), not by the matrix pipe")
+                "The kernel is bound by its start-up (table and fragment loads per workgroup), the float64 vector work of the residuals and the last workgroup's "
+                "reduction, not by the matrix pipe; no fences (write-through partials), the next step's component counts drawn ahead")
     else:
         k_ms = slots["score_constraints"][0] / max(1, slots["score_constraints"][1])
         k_flop, k_name, k_n, launches = score_flop / len(names), "mg_score_mfma_kernel (one per option)", slots["score_constraints"][1], 3 * len(names)
