@@ -197,14 +197,26 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
         // (the minimum of the distances is the root of the minimum of their squares, exactly: sqrt is monotone and correctly rounded --
         // one root per candidate instead of one per frame, the same bits)
         double best2 = INFINITY;
-#pragma unroll 4
-        for (int f = 0; f < a.nf; f++) {
+        auto frame = [&](const double x, const double y, const double z) {
+            const double p[3] = {x, y, z};
             double d2 = 0.0;
 #pragma unroll
             for (int d = 0; d < 3; d++)
-                if (a.axis_on[d]) { const double v = a.target[d] - tr[(int64_t)f * 3 + d]; d2 += v * v; }
+                if (a.axis_on[d]) { const double v = a.target[d] - p[d]; d2 += v * v; }
             best2 = d2 < best2 ? d2 : best2;
+        };
+        int f = 0;
+        if ((((size_t)tr) & 15) == 0) {
+            // two frames = six doubles = three 16-byte loads (a lane reads its own candidate's 3.7 KB: wider requests, half as many)
+            const double2 *t2 = (const double2 *)tr;
+#pragma unroll 2
+            for (; f + 2 <= a.nf; f += 2) {
+                const double2 u0 = t2[(f >> 1) * 3], u1 = t2[(f >> 1) * 3 + 1], u2 = t2[(f >> 1) * 3 + 2];
+                frame(u0.x, u0.y, u1.x);
+                frame(u1.y, u2.x, u2.y);
+            }
         }
+        for (; f < a.nf; f++) frame(tr[(int64_t)f * 3], tr[(int64_t)f * 3 + 1], tr[(int64_t)f * 3 + 2]);
         err = a.weight * sqrt(best2);
         if (a.res) a.res[b] = err;
     } else if (a.type == MG_FRAME_DISCRETE_TRAJECTORY) {
