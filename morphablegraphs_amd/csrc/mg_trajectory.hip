@@ -92,11 +92,15 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
     const int G = a.G;
     const double invG = 1.0 / (double)G;
     double min_u = a.min_u, sum = 0.0;
+    // (given positions: the next frame's point is requested a frame ahead -- its trip to memory would otherwise head every frame's
+    // chain of dependent evaluations)
+    double qn[3] = {0.0, 0.0, 0.0};
+    if (a.points && a.T > 0) { const double *pp = a.points + (size_t)bb * a.T * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
     for (int f = 0; f < a.T; f++) {
         double q[3];
         if (a.points) {
-            const double *pp = a.points + ((size_t)bb * a.T + f) * 3;
-            q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2];
+            q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2];
+            if (f + 1 < a.T) { const double *pp = a.points + ((size_t)bb * a.T + f + 1) * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
         } else {
             const int i0 = a.i0[f];
             const double *w = a.w + 4 * (size_t)f;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
             q[2] = ac * z - as * x + tz;
             q[1] += ty;
         }
-        const double dist = mg_traj_closest_dist(poly, a.n_seg, G, invG, &min_u, q);   // (mg_traj_device.h; min_u moves to the point's parameter)
+        const double dist = mg_traj_closest_dist<true>(poly, a.n_seg, G, invG, &min_u, q);   // (mg_traj_device.h; min_u moves to the point's parameter; every lane of the wave is here: long walks get its help)
         sum += dist;
         if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
     }
@@ -180,11 +184,15 @@ __device__ __forceinline__ void mg_trajectory_coop_body(const mg_traj_args &a, c
     const int G = a.G;
     const double invG = 1.0 / (double)G;
     double min_u = a.min_u, sum = 0.0;
+    // (given positions: the next frame's point is requested a frame ahead -- its trip to memory would otherwise head every frame's
+    // chain of dependent evaluations)
+    double qn[3] = {0.0, 0.0, 0.0};
+    if (a.points && a.T > 0) { const double *pp = a.points + (size_t)bb * a.T * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
     for (int f = 0; f < a.T; f++) {
         double q[3];
         if (a.points) {
-            const double *pp = a.points + ((size_t)bb * a.T + f) * 3;
-            q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2];
+            q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2];
+            if (f + 1 < a.T) { const double *pp = a.points + ((size_t)bb * a.T + f + 1) * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
         } else {
             const int i0 = a.i0[f];
             const double *w = a.w + 4 * (size_t)f;
