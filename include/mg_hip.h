@@ -220,7 +220,10 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *   MG_OPT_OPTIONS_STEP       mg_options_step: 0 = one launch for the whole step where every option allows it, 1 = always one
  *                             chain of launches per option (identical results; tests compare the two), 2 = one launch, and
  *                             mg_options_step_device_counts always draws its counts with a kernel in front (never takes the
- *                             counts the step before drew ahead; A/B)
+ *                             counts the step before drew ahead; A/B), 3 = one launch with the release / acquire form of the
+ *                             kernel's publication protocol (csrc/mg_options.hip: the fence-free default leans on gfx950's
+ *                             write-through behaviour; 3 is the memory model's own protocol -- identical results, a test
+ *                             runs both)
  *   MG_OPT_PLAIN_MALLOC       1 = mg_device_malloc is one hipMalloc whatever the size (0: buffers of 64 MiB and more are pieces
  *                             of the context's placed output regions, see mg_device_malloc)
  *   MG_OPT_GMM_KERNEL         mg_gmm_log_prob on the matrix pipe: 0 = by batch size, 1 = one 16-candidate tile per workgroup, fragments

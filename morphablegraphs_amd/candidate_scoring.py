@@ -194,19 +194,45 @@ def split_trajectories(clist):
 
 
 _TRAJ_CACHE = []   # [(key, _capi.Trajectory)]: a planner scores against the same trajectory for a whole action
+_TRAJ_CACHE_SIZE = 64
 
 
-def cached_trajectory(prim, c):
+def cached_trajectory(prim, c, pin=False):
+    """The device trajectory for these control points, shared between calls.  A caller that keeps the object's HANDLE beyond the
+    call at hand (a TrackScorer's constraint records, a planner step's side-by-side launch list) asks with pin=True and hands it
+    back with release_trajectory(): a pinned trajectory is never destroyed under its holder -- when the cache lets go of it, the
+    last release closes it (the records of a cached scorer pointed at trajectories the cache had closed)."""
     key = (prim.serial, prim.handle.value, _freeze(c["control_points"]), int(c.get("granularity", 1000)))
-    for i, (k, t) in enumerate(_TRAJ_CACHE):
-        if k == key and t.handle:
+    t = None
+    for i, (k, cand) in enumerate(_TRAJ_CACHE):
+        if k == key and cand.handle:
             _TRAJ_CACHE.append(_TRAJ_CACHE.pop(i))
-            return t
-    t = _capi.Trajectory(prim, c["control_points"], c.get("granularity", 1000))
-    _TRAJ_CACHE.append((key, t))
-    while len(_TRAJ_CACHE) > 16:
-        _TRAJ_CACHE.pop(0)[1].close()
+            t = cand
+            break
+    if t is None:
+        t = _capi.Trajectory(prim, c["control_points"], c.get("granularity", 1000))
+        t.pins, t.evicted = 0, False
+        _TRAJ_CACHE.append((key, t))
+    if pin:
+        t.pins += 1
+    while len(_TRAJ_CACHE) > _TRAJ_CACHE_SIZE:
+        _drop_trajectory(_TRAJ_CACHE.pop(0)[1])
     return t
+
+
+def _drop_trajectory(t):
+    """the cache lets go of t: closed now, or by its last holder"""
+    if getattr(t, "pins", 0) > 0:
+        t.evicted = True
+    else:
+        t.close()
+
+
+def release_trajectory(t):
+    """the counterpart of cached_trajectory(..., pin=True)"""
+    t.pins -= 1
+    if t.pins <= 0 and t.evicted:
+        t.close()
 
 
 def _errors_with_trajectories_dev(prim, keyframe_list, trajectory_list, skeleton, alignment, d_S, dtype, n, ld, d_err):
@@ -369,7 +395,7 @@ def clear_constraint_cache():
     while _CSET_CACHE:
         _CSET_CACHE.popitem()[1].close()
     while _TRAJ_CACHE:
-        _TRAJ_CACHE.pop()[1].close()
+        _drop_trajectory(_TRAJ_CACHE.pop()[1])
 
 
 

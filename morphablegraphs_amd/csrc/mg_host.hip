@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <time.h>
 
 #include "mg_internal.h"
 #include <dlfcn.h>
@@ -152,6 +153,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     if (ctx->argmin_out) (void)hipFree(ctx->argmin_out);
     for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials, ctx->fused_dyn_dev}) if (q) (void)hipFree(q);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->flag_block) (void)hipHostFree(ctx->flag_block);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
     for (auto &v : ctx->vmm) mg_vmm_release(ctx, v);
     (void)hipDeviceSynchronize();   // nothing of this process is in flight when the parked address ranges go back to the runtime
@@ -2090,20 +2092,44 @@ static int mg_ctx_pinned(mg_context *ctx, size_t bytes) {
     return MG_OK;
 }
 // A planner step's results without a copy and without the runtime's synchronisation: the step's kernel writes the records into
-// pinned memory and then, per option, the step's sequence number into a flag word there (mg_options.hip); the host spins on the
+// pinned memory and then, per option, the step's sequence number into a flag word (mg_options.hip); the host spins on the
 // flags -- a few hundred nanoseconds after the last workgroup's write instead of the microseconds hipStreamSynchronize takes
-// to wake up.  Bounded: after ~2 ms of polling the stream is synchronised the ordinary way (which also surfaces a failed launch).
+// to wake up.  The flags live in a pinned block of their own (nothing else is ever written there) and are zeroed by the host
+// before every launch that will be waited for: a flag can only ever read 0 or a sequence number a kernel wrote for THIS slot.
+static int mg_ctx_flags(mg_context *ctx, size_t n, unsigned long long **out) {
+    if (ctx->flag_cap < n) {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // a kernel may still be writing the old block
+        if (ctx->flag_block) (void)hipHostFree(ctx->flag_block);
+        ctx->flag_block = nullptr; ctx->flag_cap = 0;
+        const size_t cap = std::max<size_t>(n, 64);
+        MG_HIP_CHECK(hipHostMalloc((void **)&ctx->flag_block, cap * sizeof(unsigned long long), hipHostMallocDefault));
+        ctx->flag_cap = cap;
+    }
+    // (no step is in flight here: every call that hands flags to a kernel waits for them before it returns, or fails the context's stream)
+    for (size_t k = 0; k < n; k++) ((volatile unsigned long long *)ctx->flag_block)[k] = 0ull;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    *out = ctx->flag_block;
+    return MG_OK;
+}
+// Bounded by the CLOCK: after 2 ms of polling the stream is synchronised the ordinary way (which also surfaces a failed launch
+// -- an iteration count made that wait 0.1-0.5 s).
 static int mg_wait_flags(mg_context *ctx, const volatile unsigned long long *flags, int n, unsigned long long seq) {
+    struct timespec t0 = {0, 0};
+    bool have_t0 = false, synced = false;
     for (int k = 0; k < n; k++) {
-        long spins = 0;
-        while (flags[k] != seq) {
+        unsigned spins = 0;
+        while (flags[k] != seq && !synced) {
             __builtin_ia32_pause();
-            if (++spins > 4000000L) {
+            if ((++spins & 1023u) != 0) continue;
+            struct timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (!have_t0) { t0 = t1; have_t0 = true; continue; }
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) {
                 MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                if (flags[k] != seq) { mg_set_error("mg_options_step: the step's kernel finished without writing its result records"); return MG_ERR_HIP; }
-                break;
+                synced = true;
             }
         }
+        if (flags[k] != seq) { mg_set_error("mg_options_step: the step's kernel finished without writing its result records"); return MG_ERR_HIP; }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return MG_OK;
@@ -2154,17 +2180,18 @@ extern "C" int mg_options_step_device_counts(int32_t n_options, mg_primitive *co
                      "constraint tables beyond LDS, or a VALU kernel forced): draw the counts on the host and call mg_options_step");
         return MG_ERR_UNSUPPORTED;
     }
-    const size_t rec_bytes = ((size_t)n_options * (size_t)result_stride + 63) / 64 * 64, flag_bytes = 64 * 4,
+    const size_t rec_bytes = ((size_t)n_options * (size_t)result_stride + 63) / 64 * 64,
                  cnt_bytes = (size_t)n_options * MG_SAMPLE_ARG_K * sizeof(int32_t);
     char *rec_host = nullptr;
     int32_t *cnt_host = nullptr;
     unsigned long long *flags = nullptr;
     if (results_host || counts_host) {
-        int rcp = mg_ctx_pinned(ctx, rec_bytes + flag_bytes + cnt_bytes);
+        int rcp = mg_ctx_pinned(ctx, rec_bytes + cnt_bytes);
         if (rcp != MG_OK) return rcp;
         rec_host = (char *)ctx->pinned;              // (the records are what the flags wait for: written whenever anything is wanted)
-        flags = (unsigned long long *)(rec_host + rec_bytes);
-        if (counts_host) cnt_host = (int32_t *)(rec_host + rec_bytes + flag_bytes);
+        rcp = mg_ctx_flags(ctx, (size_t)n_options, &flags);
+        if (rcp != MG_OK) return rcp;
+        if (counts_host) cnt_host = (int32_t *)(rec_host + rec_bytes);
     }
     const unsigned long long seq = ++ctx->fused_seq;
     int rc = mg_launch_options_fused(n_options, prims, csets, n, nullptr, seeds, x_dev, xdt, ld, errors_dev, results_dev, result_stride, 0, n, rec_host, cnt_host,
@@ -2213,10 +2240,11 @@ extern "C" int mg_options_step_rows(int32_t n_options, mg_primitive *const *prim
             unsigned long long *flags = nullptr;
             const size_t rec_bytes = ((size_t)n_options * (size_t)result_stride + 63) / 64 * 64;
             if (results_host) {
-                int rcp = mg_ctx_pinned(ctx, rec_bytes + (size_t)n_options * 8);
+                int rcp = mg_ctx_pinned(ctx, rec_bytes);
                 if (rcp != MG_OK) return rcp;
                 rec_host = (char *)ctx->pinned;
-                flags = (unsigned long long *)(rec_host + rec_bytes);
+                rcp = mg_ctx_flags(ctx, (size_t)n_options, &flags);
+                if (rcp != MG_OK) return rcp;
             }
             const unsigned long long seq = ++ctx->fused_seq;
             for (int k0 = 0; k0 < n_options; k0 += 24) {

@@ -88,6 +88,11 @@ struct mg_context {
     std::vector<out_region> out_regions;
     void *pinned = nullptr;         // pinned host staging block for small read-backs
     size_t pinned_bytes = 0;
+    // Completion flags of the planner step's kernel (mg_wait_flags): a pinned block of their OWN that nothing else is ever written
+    // to -- inside the staging block they sat behind the records, at an offset that moves with the option count, where an earlier
+    // step's record bytes could read as this step's sequence number.
+    unsigned long long *flag_block = nullptr;
+    size_t flag_cap = 0;            // flags
     void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
     int dist_rank = 0, dist_ranks = 1;
 };

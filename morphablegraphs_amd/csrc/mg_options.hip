@@ -57,6 +57,7 @@ struct mg_fused_dyn {             // one step: what changes every time (kernel a
     // system-scope fence, the step's sequence number into the option's flag word there (NULL: no host copy wanted)
     unsigned long long *flags_host;
     unsigned long long seq;
+    int32_t fenced;               // 1: the release / acquire form of the publication protocol (MG_OPT_OPTIONS_STEP 3; below)
 };
 
 struct mg_fused_devcounts {       // what mg_options_counts_kernel leaves for the step's main kernel (device memory)
@@ -67,6 +68,27 @@ struct mg_fused_devcounts {       // what mg_options_counts_kernel leaves for th
 // A workgroup's first minimum AND that candidate's latent vector: published with agent-scope stores (write-through), read by the
 // option's last workgroup with agent-scope loads -- no release / acquire fence anywhere (an agent-scope release writes back the
 // XCD's whole L2, into which the step has just written 10 MB of candidates: 1068 of them per step were the kernel's latency chain)
+//
+// THE PUBLICATION PROTOCOL'S CONTRACT.  What the fence-free form relies on is outside the HIP / LLVM memory model (relaxed atomics
+// order nothing by themselves); it is the behaviour of gfx950 as the AMDGPU backend's memory-model table for gfx942 / gfx950 states
+// it and as this image's toolchain compiles it -- verified on ROCm 7.2.0 (HIP 7.2, AMD clang 22), MI355X, by the parity tests, by
+// tests/test_gpu_adaptors.py::test_planner_steps_publish_complete_records_fenced_or_not (500 steps, every record checked against
+// the device buffers, the fenced form beside it) and by tools/probes/options_step_soak.py (3000 steps):
+//   (1) a relaxed atomic store at AGENT scope compiles to global_store ... sc1: it writes through the XCD's L2 to the level the
+//       agent's XCDs share (memory / MALL), it does not linger in the non-coherent L2 of the writing XCD;
+//       at SYSTEM scope (the pinned host record, the flag) to global_store ... sc0 sc1: through to the fabric;
+//   (2) vmcnt counts a store down when its write has been ACKNOWLEDGED by that level, not when it has left the CU: after
+//       s_waitcnt vmcnt(0) the wave's write-through stores are visible to every XCD (resp. the host);
+//   (3) a relaxed atomic load at agent scope compiles to global_load ... sc1: it misses the reading XCD's L2 for such lines and
+//       reads the shared level -- it cannot return a stale copy cached before the store;
+//   (4) the counter is a returning atomic add performed AT the shared level (device-scope atomics execute in the memory-side
+//       atomics unit): its order against (2) is "all of this workgroup's partial stores acknowledged, barrier, then the add";
+//       the last arrival's loads are issued after its add has returned.
+// So: partial stores acknowledged (2) -> barrier -> add (4) ... last add returns -> loads (3) see (1).  The host record the same
+// way at system scope: record stores acknowledged, barrier, flag store.  A compiler that stops mapping scopes to sc0 / sc1 this
+// way, or firmware that acknowledges write-through stores early, breaks it silently -- hence the test, and hence
+// MG_OPT_OPTIONS_STEP = 3, which runs the SAME kernel with a release fence before the add, an acquire fence after it and a
+// system-scope release before the flag (the memory model's own protocol; ~8 us slower per 16 x 4096 step, same records).
 struct mg_fused_partial { double v; int64_t i; double row[4 * MG_MAX_KK]; };
 
 // The component counts of a step drawn ON THE DEVICE (mg_options_step_device_counts): a multinomial(n, weights) draw per option
@@ -283,12 +305,14 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
         __hip_atomic_store(&partials[wg].i, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also this wave's candidates and errors; the write-through stores above are complete)
+    if (dyn.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) {
         const int old = __hip_atomic_fetch_add(&counters[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (old == nwg - 1) ? 1 : 0;
     }
     __syncthreads();
+    if (dyn.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (DYN_DEV && next_dev != nullptr && wg == dyn.wg0[k]) {
         // The option's first workgroup, its own tile published, draws the counts the NEXT step will want if its seed is this one's + 1
         // (a planner counts its steps): that step then starts without a counts kernel in front (8.5 us + the gap between two launches).
@@ -346,6 +370,7 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
         // acknowledged (vmcnt) before the barrier, the flag leaves after it -- a system-scope release fence here would write back
         // the whole L2 (the step's candidates) first
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dyn.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope
         __syncthreads();
         if (tid == 0) __hip_atomic_store(dyn.flags_host + k, dyn.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -438,6 +463,7 @@ int mg_launch_options_fused(int32_t n_options, mg_primitive *const *prims, const
     }
     dyn.row_lo = row_begin; dyn.row_hi = row_begin + row_count;
     dyn.flags_host = flags_host; dyn.seq = seq;
+    dyn.fenced = ctx->opt[MG_OPT_OPTIONS_STEP] == 3 ? 1 : 0;
     const int total_wg = dyn.wg0[n_options];
     // the static table: uploaded when it differs from the one on the device (a planner reuses its buffers and sets, so: rarely)
     const size_t tab_bytes = tab.size() * sizeof(mg_fused_static);

@@ -93,6 +93,12 @@ __global__ __launch_bounds__(MG_TW_BLOCK) void mg_timewarp_kernel(const double *
     // the samples: 0, the inverse spline at linspace(1, x[F-2], num), F - 1
     const double stop = x[F - 2];
     const double numf = rint(stop) * inv_speed;
+    // a time function that is not finite (exp() overflowed on a wild gamma) or asks for more than 2^24 samples has no row: length 0,
+    // nothing written (the conversion of such a float to int is undefined, and T = num + 2 could wrap -- ADVICE r4)
+    if (!(numf == numf) || !(fabs(stop) <= 1.0e300) || numf > 16777216.0) {
+        if (tid == 0) lens[b] = 0;
+        return;
+    }
     const int num = numf > 0.0 ? (int)numf : 0;
     const int T = num + 2;
     if (tid == 0) lens[b] = T <= t_cap ? T : -T;   // (negative: the caller's rows are too short; nothing else is written)
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(MG_FA_BLOCK) void mg_frames_at_kernel(const double 
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
     const int T = lens ? lens[b] : t_cap;
-    if (T <= 0) return;
+    if (T <= 0 || T > t_cap) return;     // (a length beyond the rows' capacity would overrun w / i0 and the row in `out`: the row is skipped)
     for (int k = tid; k < L; k += MG_FA_BLOCK) s[k] = LAT_F64 ? ((const double *)lat)[b * ld + k] : (double)((const float *)lat)[b * ld + k];
     __syncthreads();
     for (int r = tid; r < R; r += MG_FA_BLOCK) {

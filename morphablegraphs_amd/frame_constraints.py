@@ -262,7 +262,14 @@ class TrackScorer(object):
     calls of the same batch size.  Raises NotImplementedError when the list is not covered (the caller takes the chain)."""
 
     def __init__(self, prim, track_list, skeleton, alignment):
-        from .candidate_scoring import cached_trajectory
+        from .candidate_scoring import cached_trajectory as _cached
+
+        def cached_trajectory(p, c):
+            # pinned: this scorer's records carry the trajectory's raw handle for as long as the scorer lives (close() releases)
+            t = _cached(p, c, pin=True)
+            self.keep.append(t)
+            return t
+        self.keep, self._owned, self._tracks, self._tracks_n = [], [], None, -1
         if not track_list or any(c["type"] == "frame_joint_rotation" for c in track_list):
             raise NotImplementedError("joint-rotation constraints read a frame, not a track")
         sk = _skeleton_or_root(skeleton)
@@ -285,26 +292,36 @@ class TrackScorer(object):
         plan = _PLAN_CACHE.get(pkey)
         if plan is None or not plan.handle:
             if len(_PLAN_CACHE) > 64:
-                for old in _PLAN_CACHE.values():
-                    old.close()
-                _PLAN_CACHE.clear()
+                _PLAN_CACHE.clear()       # (not closed here: a live scorer may hold one; the last reference closes it)
             plan = _PLAN_CACHE[pkey] = _capi.TrackPlan(prim, sk, [list(k[1]) for k in reqs], al_joint)
         self.prim, self.ctx, self.plan, self.alignment = prim, prim.ctx, plan, alignment
         self.reqs, self.req_of = reqs, req_of
         self.grids = [None if k[0] is None else _integer_grid(prim, k[0]) for k in reqs]
         self.Ts = [prim._grid_size(g) for g in self.grids]
-        self._tracks, self._tracks_n, self._owned = None, -1, []
         ctx, F = self.ctx, prim.n_canonical_frames
         m = self.m = len(track_list)
-        descs, keep, widths = (_capi.FrameConstraintDesc * m)(), [], []
+        descs, widths = (_capi.FrameConstraintDesc * m)(), []
+        try:
+            self._fill(prim, track_list, descs, widths, cached_trajectory, ctx, F, req_of)
+        except Exception:
+            self.close()
+            raise
+        vp = C.c_void_p
+        self.descs, self.widths = descs, widths
+        self.dptr = (vp * m)(*[C.addressof(descs[i]) for i in range(m)])
+        self.tT = (C.c_int32 * m)(*[self.Ts[req_of[i]] for i in range(m)])
+        self.tJ = (C.c_int32 * m)(*[len(reqs[req_of[i]][1]) for i in range(m)])
+        self.tptr = None
+
+    def _fill(self, prim, track_list, descs, widths, cached_trajectory, ctx, F, req_of):
         for i, c in enumerate(track_list):
             d, T = descs[i], self.Ts[req_of[i]]
             kind = c["type"]
             d.weight, d.n_joints = float(c.get("weight", 1.0)), 1
             if kind == "frame_joint_trajectory":
-                keep.append(cached_trajectory(prim, {"type": "trajectory", "control_points": c["control_points"], "granularity": c.get("granularity", 1000)}))
+                t = cached_trajectory(prim, {"type": "trajectory", "control_points": c["control_points"], "granularity": c.get("granularity", 1000)})
                 d.type, d.start_arc = _capi.MG_FRAME_JOINT_TRAJECTORY, float(c.get("min_u", 0.0))
-                d.trajectories[0] = keep[-1].handle.value
+                d.trajectories[0] = t.handle.value
             elif kind == "frame_ca_position":
                 d.type, d.n_frames = _capi.MG_FRAME_CA_POSITION, int(c.get("n_frames", F))
                 for a in range(3):
@@ -321,9 +338,9 @@ class TrackScorer(object):
                 for a in range(3):
                     d.axis_on[a] = 0 if a in free else 1
             elif kind == "frame_local_trajectory":
-                keep.append(cached_trajectory(prim, {"type": "trajectory", "control_points": c["control_points"], "granularity": c.get("granularity", 1000)}))
+                t = cached_trajectory(prim, {"type": "trajectory", "control_points": c["control_points"], "granularity": c.get("granularity", 1000)})
                 d.type, d.n_frames, d.start_arc = _capi.MG_FRAME_LOCAL_TRAJECTORY, int(c.get("n_frames", F)), float(c.get("start_t", 0.0))
-                d.trajectories[0] = keep[-1].handle.value
+                d.trajectories[0] = t.handle.value
             elif kind == "frame_trajectory_set":
                 joints = list(c["joints"])
                 if len(c["trajectories"]) != len(joints):
@@ -331,8 +348,8 @@ class TrackScorer(object):
                 d.type, d.n_frames, d.n_joints = _capi.MG_FRAME_TRAJECTORY_SET, int(c.get("n_frames", F)), len(joints)
                 arcs = c.get("arc_lengths", [0.0] * len(joints))
                 for j, t in enumerate(c["trajectories"]):
-                    keep.append(cached_trajectory(prim, {"type": "trajectory", "control_points": t["control_points"], "granularity": t.get("granularity", 1000)}))
-                    d.trajectories[j] = keep[-1].handle.value
+                    tr = cached_trajectory(prim, {"type": "trajectory", "control_points": t["control_points"], "granularity": t.get("granularity", 1000)})
+                    d.trajectories[j] = tr.handle.value
                     d.arc0[j] = float(arcs[j])
                     rs, re = t.get("range_start"), t.get("range_end")
                     d.has_range[j] = 0 if rs is None else 1
@@ -340,12 +357,6 @@ class TrackScorer(object):
             else:
                 raise ValueError("unknown per-frame constraint %r" % (kind,))
             widths.append(prim.lib.mg_frame_constraint_width(C.byref(d), T))
-        vp = C.c_void_p
-        self.descs, self.keep, self.widths = descs, keep, widths
-        self.dptr = (vp * m)(*[C.addressof(descs[i]) for i in range(m)])
-        self.tT = (C.c_int32 * m)(*[self.Ts[req_of[i]] for i in range(m)])
-        self.tJ = (C.c_int32 * m)(*[len(reqs[req_of[i]][1]) for i in range(m)])
-        self.tptr = None
 
     def _track_buffers(self, n):
         if self._tracks_n != n:
@@ -360,8 +371,14 @@ class TrackScorer(object):
             b.free()
         self._tracks, self._tracks_n = None, -1
 
+    def valid(self):
+        """everything the records point to is still alive (a cleared cache or a closed primitive takes it away)"""
+        return bool(self.plan.handle) and all(t.handle for t in self.keep) and all(g is None or g.handle for g in self.grids)
+
     def score_dev(self, lat_dev, lat_dtype, n, ld, d_err, accumulate=True, residual_devs=None):
         """mg_joint_tracks + mg_score_frame_constraints on resident latents: the list's errors added to (or written over) d_err (n,)."""
+        if not self.valid():
+            raise _capi.MGError("TrackScorer: a trajectory or plan it points to has been closed (its primitive or the caches were cleared)")
         tracks = self._track_buffers(n)
         self.plan.tracks_dev(lat_dev, lat_dtype, n, ld, self.grids, tracks, self.alignment)
         rptr = (C.c_void_p * self.m)(*[_capi._dev_ptr(r).value for r in residual_devs]) if residual_devs is not None else None
@@ -375,6 +392,10 @@ class TrackScorer(object):
             for b in self._owned:
                 b.free()
         self._owned = []
+        from .candidate_scoring import release_trajectory
+        for t in self.keep:
+            release_trajectory(t)
+        self.keep = []
 
 
 def _fused(prim, S, frame_list, skeleton, alignment, d_err, accumulate, residuals):
@@ -402,21 +423,42 @@ def _fused(prim, S, frame_list, skeleton, alignment, d_err, accumulate, residual
 
 def add_frame_constraints_dev(prim, S, frame_list, skeleton, alignment, d_err, accumulate=True, residuals=False):
     """Add the per-frame constraints' weighted errors of candidates S (host latents) to d_err (n,) float64 on the device (accumulate
-    False: the first one overwrites).  Returns the list of residual blocks (n, m_c) when residuals is set."""
-    on_tracks = [i for i, c in enumerate(frame_list) if c["type"] != "frame_joint_rotation"]
-    fused = _fused(prim, S, [frame_list[i] for i in on_tracks], skeleton, alignment, d_err, accumulate, residuals) if on_tracks else None
-    rest = list(range(len(frame_list))) if fused is None else [i for i in range(len(frame_list)) if i not in on_tracks]
+    False: the first one overwrites).  Returns the list of residual blocks (n, m_c) when residuals is set.
+    The additions happen in the LIST's order, as the reference's loop makes them (motion_primitive_constraints.py:117-121): runs
+    of consecutive track constraints go through the fused route (two launches per run), a joint-rotation constraint -- which reads
+    a frame, not a track -- through the chain at its place in the list (tracks first, rotations last changed the
+    float64 summation order of mixed lists)."""
+    runs, i = [], 0
+    while i < len(frame_list):
+        j = i
+        if frame_list[i]["type"] != "frame_joint_rotation":
+            while j < len(frame_list) and frame_list[j]["type"] != "frame_joint_rotation":
+                j += 1
+            runs.append((True, list(range(i, j))))
+        else:
+            j = i + 1
+            runs.append((False, [i]))
+        i = j
     blocks = [None] * len(frame_list)
-    if fused is not None and residuals:
-        for i, b in zip(on_tracks, fused):
-            blocks[i] = b
-    if rest:
-        batch = _Batch(prim, S, skeleton, alignment)
-        try:
-            for k, i in enumerate(rest):
-                blocks[i] = _add_frame_constraint(batch, frame_list[i], d_err, accumulate or fused is not None or k > 0, residuals)
+    batch, first = None, not accumulate
+    try:
+        for on_tracks, idx in runs:
+            fused = _fused(prim, S, [frame_list[i] for i in idx], skeleton, alignment, d_err, not first, residuals) if on_tracks else None
+            if fused is not None:
+                if residuals:
+                    for i, b in zip(idx, fused):
+                        blocks[i] = b
+                first = False
+                continue
+            if batch is None:
+                batch = _Batch(prim, S, skeleton, alignment)
+            for i in idx:
+                blocks[i] = _add_frame_constraint(batch, frame_list[i], d_err, not first, residuals)
+                first = False
+        if batch is not None:
             batch.ctx.synchronize()
-        finally:
+    finally:
+        if batch is not None:
             batch.close()
     return blocks if residuals else None
 

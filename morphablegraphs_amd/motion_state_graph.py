@@ -563,8 +563,9 @@ class HipPrimitiveSet(object):
         minimum (one launch, one small read-back).  The additions are the general chain's, in its order: the same errors and
         winners, bit for bit (round 3 ran such a step option by option: sampler, scorer, ... per option).  None: not covered (an
         option without keyframe constraints, a trajectory aligned by another node than the root) -- the caller goes option by option."""
-        from .candidate_scoring import cached_constraint_set, cached_trajectory, split_trajectories
+        from .candidate_scoring import cached_constraint_set, cached_trajectory, release_trajectory, split_trajectories
         from .frame_constraints import TrackScorer, split_frame_constraints, add_frame_constraints_dev
+        plan["whole"] = None          # this step rewrites plan["csets"]: the whole-step shortcut must not score against them
         extras, sets = {}, list(csets)
         for k, st in enumerate(steps):
             if sets[k] is not None:
@@ -598,15 +599,24 @@ class HipPrimitiveSet(object):
         for j in range(max(len(e[0]) for e in extras.values())):
             ks = [k for k, e in extras.items() if len(e[0]) > j]
             cj = [extras[k][0][j] for k in ks]
-            _capi.Primitive.score_trajectories_dev([steps[k][2] for k in ks], [cached_trajectory(steps[k][2], c) for k, c in zip(ks, cj)],
-                                                   [steps[k][4] for k in ks], dtype, n, [steps[k][7] for k in ks], [steps[k][5] for k in ks],
-                                                   [c.get("min_u", 0.0) for c in cj], [c.get("weight", 1.0) for c in cj],
-                                                   [extras[k][2] for k in ks], accumulate=True)
+            # (pinned while the list is built and enqueued: more distinct trajectories than the cache holds must not close the first)
+            trs = [cached_trajectory(steps[k][2], c, pin=True) for k, c in zip(ks, cj)]
+            try:
+                _capi.Primitive.score_trajectories_dev([steps[k][2] for k in ks], trs,
+                                                       [steps[k][4] for k in ks], dtype, n, [steps[k][7] for k in ks], [steps[k][5] for k in ks],
+                                                       [c.get("min_u", 0.0) for c in cj], [c.get("weight", 1.0) for c in cj],
+                                                       [extras[k][2] for k in ks], accumulate=True)
+            finally:
+                for t in trs:
+                    release_trajectory(t)
         for k, (trajectories, frames, alignment, sk) in extras.items():
             name, node, prim, ctx, d_x, d_e, d_r, L, pvals = steps[k]
             if frames:
                 key = (k, _cs._freeze(frames), _cs._freeze(alignment), None if sk is None else sk.serial)
                 scorer = scorers.get(key)
+                if scorer and not scorer.valid():      # a cache was cleared under it
+                    scorer.close()
+                    scorer = None
                 if scorer is None:
                     if len(scorers) > 64:
                         for old in scorers.values():
@@ -641,6 +651,7 @@ class HipPrimitiveSet(object):
         if not plan["one_context"]:
             raise NotImplementedError("sharded planner steps need all primitives in one context")
         m, stride, host = len(steps), plan["stride"], plan["host"]
+        plan["whole"] = None          # plan["csets"] and the seeds are rewritten below
         for k, st in enumerate(steps):
             name = st[0]
             cs = cached_constraint_set(st[2], cmd["constraints"][name], skeleton, cmd["alignments"][name])

@@ -657,6 +657,52 @@ def test_planner_step_at_the_size_of_configs2_returns_what_its_buffers_hold():
         assert best == names[int(np.argmin(errs))]
 
 
+def test_planner_steps_publish_complete_records_fenced_or_not():
+    """The one-launch planner step publishes its partials and its host records WITHOUT memory fences (csrc/mg_options.hip, "THE
+    PUBLICATION PROTOCOL'S CONTRACT": write-through stores + vmcnt + barrier + counter).  500 steps of BASELINE configs[2]'s shape
+    (16 options x 4096, counts drawn on the device a step ahead): after EVERY step every option's record equals the first minimum of
+    the errors the step left on the device and that row of its candidates -- a torn or stale record, or a winner reduced from
+    partials that had not arrived, fails here.  The option count changes between steps (16, 8, 16, 5, ...) so that the records'
+    layout in the pinned block moves (completion flags used to sit behind the records, where an earlier step's bytes
+    could read as this step's sequence number).  Once more with the release / acquire form of the same kernel
+    (MG_OPT_OPTIONS_STEP 3): identical records."""
+    prims = synthetic.make_graph_primitives(16)
+    names = [p["name"] for p in prims]
+    cons = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]},
+                 {"type": "direction", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [0.5, 1.0]}] for nm, p in zip(names, prims)}
+    pset = HipPrimitiveSet(prims, separate_streams=False)
+    n = 4096
+    subsets = [names, names[:8], names, names[3:8], names[:12]]
+
+    def run(steps, check_every):
+        out = []
+        for step in range(steps):
+            opts = subsets[step % len(subsets)] if step % 7 == 6 else names
+            best, res = pset.evaluate_options_on_device(opts, {nm: cons[nm] for nm in opts}, n, seed=9000 + step, device_counts=True)
+            out.append((best, [(nm, res[nm][1], np.asarray(res[nm][0]).tobytes()) for nm in opts]))
+            if step % check_every:
+                continue
+            errs = []
+            for nm in opts:
+                prim = pset.nodes[nm]._prim
+                d_x, d_e, d_r = pset._buffers[(nm, n, np.dtype(np.float32).str)]
+                e = prim.ctx.download(d_e, (n,), np.float64)
+                w = int(np.argmin(e))
+                assert res[nm][1] == e[w], (step, nm, res[nm][1], e[w])
+                x = prim.ctx.download(d_x.ptr.value + w * prim.n_gmm_dims * 4, (prim.n_gmm_dims,), np.float32)
+                np.testing.assert_array_equal(np.asarray(res[nm][0], dtype=np.float64), x.astype(np.float64), err_msg="step %d %s" % (step, nm))
+                errs.append(e[w])
+            assert best == opts[int(np.argmin(errs))]
+        return out
+    free = run(500, 1)
+    pset.ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, 3)
+    try:
+        fenced = run(60, 1)
+    finally:
+        pset.ctx.set_option(_capi.MG_OPT_OPTIONS_STEP, 0)
+    assert fenced == free[:60]
+
+
 def test_planner_step_with_component_counts_drawn_on_the_device(monkeypatch):
     """mg_options_step_device_counts: the counts are the ones the oracle's restatement of the device draw gives (Philox4x32-10
     keyed by seed + option index, histogram of n categorical draws), bit for bit; given those counts the step is the step

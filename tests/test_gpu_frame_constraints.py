@@ -434,3 +434,67 @@ def test_frame_constraint_entry_points_refuse_bad_arguments():
     foreign.close()
     for b in (d_t, d_e, d_f, d_v, d_S, d_o):
         b.free()
+
+
+def test_cached_track_scorers_keep_their_trajectories_alive():
+    """a TrackScorer's records carry raw mg_trajectory handles; the trajectory cache holds a bounded number of
+    entries and closes what it evicts.  More distinct (primitive, trajectory) pairs than the cache holds, across scorers that stay
+    alive: every scorer still scores what it scored when it was new (its trajectories are pinned), and once the scorers are closed
+    the evicted trajectories go."""
+    from morphablegraphs_amd import candidate_scoring as cs, frame_constraints as fc
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=17, seed=8)
+    prim, ctx = mp._prim, mp._prim.ctx
+    frames0 = op.back_project_frames(S[0])
+    hand = np.array([orc.joint_global_position(f, joints, animated, "LeftHand") for f in frames0])
+    n_scorers = cs._TRAJ_CACHE_SIZE + 9
+    lists = [[{"type": "frame_joint_trajectory", "joint": "LeftHand", "control_points": (hand[::22] + np.array([0.1 * k, 0.0, -0.05 * k])).tolist(),
+               "min_u": 0.0, "granularity": 1000, "weight": 1.0},
+              {"type": "frame_local_trajectory", "joint": "Hips", "control_points": (frames0[::20, :3] + np.array([0.02 * k, 0.0, 0.5])).tolist(),
+               "granularity": 1000, "start_t": 1.0, "n_frames": op.n_canonical_frames, "weight": 0.5}] for k in range(n_scorers)]
+    lat = S.astype(np.float32)
+    d_S, d_e = ctx.upload(lat), ctx.malloc(len(S) * 8)
+    scorers, first = [], []
+    try:
+        for cl in lists:
+            sc = fc.TrackScorer(prim, cl, sk, None)
+            sc.score_dev(d_S, lat.dtype, len(S), lat.shape[1], d_e, accumulate=False)
+            first.append(ctx.download(d_e, (len(S),), np.float64))
+            scorers.append(sc)
+        assert len(cs._TRAJ_CACHE) <= cs._TRAJ_CACHE_SIZE
+        kept = [t for sc in scorers for t in sc.keep]
+        assert all(t.handle for t in kept) and sum(1 for t in kept if t.evicted) >= 2 * 9
+        for sc, want in zip(scorers, first):       # every scorer again, the oldest ones long after the cache dropped their entries
+            assert sc.valid()
+            sc.score_dev(d_S, lat.dtype, len(S), lat.shape[1], d_e, accumulate=False)
+            np.testing.assert_array_equal(ctx.download(d_e, (len(S),), np.float64).view(np.uint64), want.view(np.uint64))
+        # and they are what the chain gives
+        total = frame_constraints_errors(prim, lat, lists[0], sk, None)[0]
+        np.testing.assert_array_equal(total.view(np.uint64), first[0].view(np.uint64))
+    finally:
+        for sc in scorers:
+            sc.close()
+        d_S.free(); d_e.free()
+    assert all((not t.handle) for t in kept if t.evicted)          # the last holder closed what the cache had let go of
+    # a cleared cache under a live scorer: the scorer says so instead of launching on dangling pointers
+    sc = fc.TrackScorer(prim, lists[0], sk, None)
+    cs.clear_constraint_cache()
+    assert sc.valid()           # pinned: still alive
+    sc.close()
+
+
+def test_mixed_lists_add_in_list_order():
+    """A joint-rotation constraint BETWEEN track constraints: the additions happen in the list's order (two fused runs around the
+    rotation's chain launch), so the sum has the bits of the chain that adds one constraint after the other."""
+    from morphablegraphs_amd import frame_constraints as fc
+    orc, data, mp, op, joints, animated, sk, S = _setup(n=21, seed=5)
+    cl = _constraints(op, orc, S, joints, animated)
+    mixed = [cl[1], cl[5], cl[0], cl[2], cl[6], cl[3]]
+    total, blocks = frame_constraints_errors(mp._prim, S, mixed, sk, None)
+    fc.FUSED = False
+    try:
+        total_c, blocks_c = frame_constraints_errors(mp._prim, S, mixed, sk, None)
+    finally:
+        fc.FUSED = True
+    for b, bc in zip(blocks, blocks_c):
+        assert np.array_equal(b.view(np.uint64), bc.view(np.uint64))
+    assert np.array_equal(total.view(np.uint64), total_c.view(np.uint64))
