@@ -236,7 +236,14 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
  *                             tests use it to make the scan drop candidates while it runs
  *   MG_OPT_TRAJECTORY_LANES   1 = one lane per candidate in the closest-point walks of mg_score_trajectory[_points / ies] whatever the
  *                             batch, 8 / 4 = that many lanes up to 65536 candidates (default: eight lanes while at most 28672
- *                             candidates are in flight, four up to 40960, one beyond -- the same bits in every case)
+ *                             candidates are in flight, four up to 40960, one beyond -- the same bits in every case); only with
+ *                             MG_OPT_TRAJECTORY_SEARCH = 1 (the reference's search is one lane per candidate)
+ *   MG_OPT_TRAJECTORY_SEARCH  the closest-point search of the trajectory constraints (mg_score_trajectory[_points / ies], the scorer's
+ *                             MG_FRAME_JOINT_TRAJECTORY): 0 = the reference's -- scipy's L-BFGS-B with a forward-difference gradient
+ *                             (parameterized_spline.py:303-322) restated for one bounded variable, held to vectors the reference's own
+ *                             function produced (tests/golden/trajectory_closest_point.npz) --, 1 = the monotone grid walk + Newton
+ *                             refinement of rounds 2-4 (the first local minimum at or after the bound: the same point where the
+ *                             distance has one basin ahead of the bound, another one where it has several)
  *   MG_OPT_ROOT_MODE          how the float32 frames kernels compute the root-translation channels (the two forms differ in
  *                             the last bits; see mg_primitive_root_mode): 0, 1 = the float64 pipeline (the default: the faster
  *                             of the two on gfx950), 2 = the mean/delta split, 3 = the split where the primitive's accuracy gate
@@ -255,7 +262,8 @@ int mg_context_set_reserved_cus(mg_context *ctx, int32_t n);
 #define MG_OPT_ROOT_MODE 11
 #define MG_OPT_PLACED_HOLD 12
 #define MG_OPT_TRAJECTORY_LANES 13
-#define MG_OPT_COUNT 14
+#define MG_OPT_TRAJECTORY_SEARCH 14
+#define MG_OPT_COUNT 15
 int mg_context_set_option(mg_context *ctx, int32_t option, int32_t value);
 /* Between _begin and _end every device constant the library uploads for this context (primitives and their
  * canonical grids: a graph's whole set of motion primitives) is bump-allocated from blocks of `block_bytes`
@@ -430,12 +438,13 @@ int mg_joint_positions(mg_context *ctx, const mg_skeleton_desc *skeleton, const 
  * errors_dev (B) float64: written, or added to with accumulate != 0 (the sum MotionPrimitiveConstraints.evaluate forms);
  * residuals_dev: NULL or (B, T) float64 = weight * distance per sample.  alignment: NULL (local coordinates), the
  * previous-frame record with the ROOT as aligning node, or a start-pose record.
- * The reference searches with scipy's L-BFGS-B from the lower bound; here: grid walk (u = k / granularity), parabola through the
- * three grid points around the minimum, then Newton steps on the squared distance inside that bracket -- deterministic, the
- * local minimum of the first basin at or after the bound to rounding (mg_trajectory.hip).  PARITY UNPINNED for the search (the
- * reference function does not run on the installed NumPy); tests hold the device to "frame by frame never farther from the root
- * than the restated L-BFGS-B search from the same bound" and to a closed-form case on a straight line; the spline itself is
- * pinned by tests/golden/trajectory_spline.npz. */
+ * The reference searches with scipy's L-BFGS-B from the lower bound (parameterized_spline.py:303-322); so does the device: L-BFGS-B 3.0
+ * restated for one bounded variable (csrc/mg_traj_device.h), PINNED by tests/golden/trajectory_closest_point.npz -- 26 chains of 156
+ * frames the reference's own function produced --: |u - u_ref| <= 2e-6 of the parameter range and |d - d_ref| <= 1e-6 max(1, d_ref) per
+ * frame (measured 1.7e-7 / 2e-9; the forward-difference gradient with h = 1e-8 sets what two correct implementations can agree to).
+ * MG_OPT_TRAJECTORY_SEARCH = 1 selects the deterministic walk of rounds 2-4 instead (grid walk u = k / granularity, parabola, Newton
+ * steps: the local minimum of the first basin at or after the bound; 25 x faster; the reference's result where the distance has one
+ * basin ahead of the bound).  The spline itself is pinned by tests/golden/trajectory_spline.npz. */
 typedef struct mg_trajectory mg_trajectory;
 int mg_trajectory_create(mg_primitive *prim, const double *control_points, int32_t n_points, int32_t granularity, mg_trajectory **out);
 void mg_trajectory_destroy(mg_trajectory *trajectory);
@@ -456,6 +465,16 @@ int mg_score_trajectories(int32_t n, mg_primitive *const *prims, const mg_trajec
  * root (trajectory_constraint.py:95-121 over skeleton.nodes[joint].get_global_position(frame)). */
 int mg_score_trajectory_points(mg_primitive *prim, const mg_trajectory *trajectory, const double *points_dev, int64_t n_samples, int32_t n_times,
                                double min_u, double weight, double *errors_dev, int accumulate, double *residuals_dev);
+
+/* ParameterizedSpline.find_closest_point_fast (constraints/spatial_constraints/splines/parameterized_spline.py:303-322) for a batch of
+ * point sequences, chained the way TrajectoryConstraint.get_residual_vector chains it (trajectory_constraint.py:103-113: every
+ * frame's search is bounded below by, and started at, the parameter the previous frame's search returned; the first by min_u):
+ * points_dev (n_samples, n_times, 3) float64 -> params_dev (n_samples, n_times) the spline parameter of every frame's point,
+ * distances_dev (n_samples, n_times) its distance to the frame's position (either may be NULL).  The search is the reference's
+ * (MG_OPT_TRAJECTORY_SEARCH 0, the default: scipy's L-BFGS-B restated) or the monotone walk (1).  Pinned by
+ * tests/golden/trajectory_closest_point.npz, which the reference's own function produced. */
+int mg_trajectory_closest_points(mg_primitive *prim, const mg_trajectory *trajectory, const double *points_dev, int64_t n_samples, int32_t n_times,
+                                 double min_u, double *params_dev, double *distances_dev);
 
 /* Constraints that walk a joint through EVERY frame of a candidate (mg_frame_constraints.hip), on float64 frames and joint tracks
  * that are on the device already (mg_back_project_frames_f64, mg_joint_positions):

@@ -30,7 +30,8 @@ MG_OPT_SCORE_KERNEL = 10     # mg_score_constraints: 0 = by batch size, 1 = a wa
 MG_OPT_ROOT_MODE = 11        # root channels of the float32 frames kernels: 0, 1 = float64 pipeline (default), 2 = mean/delta split, 3 = split where the gate allows
 MG_OPT_PLACED_HOLD = 12      # n > 0: the placement scan holds at most n candidates at once (tests)
 MG_OPT_TRAJECTORY_LANES = 13  # closest-point walks: 1 = one lane per candidate whatever the batch, 8 = eight lanes up to 65536 candidates (default: eight while <= 28672 candidates are in flight, four up to 40960)
-MG_OPT_COUNT = 14
+MG_OPT_TRAJECTORY_SEARCH = 14  # closest-point search of the trajectory constraints: 0 = the reference's (scipy L-BFGS-B restated for one variable), 1 = the monotone walk of rounds 2-4
+MG_OPT_COUNT = 15
 MG_CONSTRAINT_POSITION, MG_CONSTRAINT_DIRECTION_2D, MG_CONSTRAINT_JOINT_POSITION = 0, 1, 2
 MG_CONSTRAINT_JOINT_MIDPOINT, MG_CONSTRAINT_JOINT_ORIENTATION, MG_CONSTRAINT_LOOK_AT, MG_CONSTRAINT_POSE = 3, 4, 5, 6
 MG_CONSTRAINT_VALUE_POSITION, MG_CONSTRAINT_VALUE_HEADING = 7, 8   # values of the aligned motion, not errors (chained graph-walk steps)
@@ -46,7 +47,7 @@ EXPORTED_SYMBOLS = [
     "mg_memset", "mg_profile_enable", "mg_profile_reset", "mg_profile_get", "mg_profile_get_samples",
     "mg_primitive_create", "mg_primitive_destroy", "mg_primitive_info", "mg_primitive_info2", "mg_primitive_root_mode", "mg_primitive_get_precisions_cholesky",
     "mg_time_function_canonical", "mg_time_function_canonical_host", "mg_time_function_sample", "mg_back_project_frames_at",
-    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_score_trajectories", "mg_score_trajectory_points", "mg_joint_positions",
+    "mg_trajectory_create", "mg_trajectory_destroy", "mg_score_trajectory", "mg_score_trajectories", "mg_score_trajectory_points", "mg_trajectory_closest_points", "mg_joint_positions",
     "mg_time_grid_create", "mg_time_grid_destroy", "mg_primitive_canonical_grid", "mg_time_grid_size",
     "mg_time_grid_get_tables",
     "mg_back_project_frames", "mg_back_project_frames_f64", "mg_back_project_coeffs", "mg_spline_evaluate",
@@ -258,6 +259,7 @@ def load_library(path=None):
         "mg_score_trajectory": [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, i32, vp],
         "mg_score_trajectories": [i32, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, i32],
         "mg_score_trajectory_points": [vp, vp, vp, i64, i32, dbl, dbl, vp, i32, vp],
+        "mg_trajectory_closest_points": [vp, vp, vp, i64, i32, dbl, vp, vp],
         "mg_align_frames": [vp, vp, i64, i32, vp, i32, C.POINTER(AlignmentDesc)],
         "mg_frame_constraint_width": [C.POINTER(FrameConstraintDesc), i32],
         "mg_score_frame_constraint": [vp, C.POINTER(FrameConstraintDesc), vp, i64, i32, i32, vp, i32, vp],
@@ -958,6 +960,20 @@ class Primitive(object):
             return ctx.download(d_o, (n, T, len(idx), 3), np.float64)
         finally:
             for b in (d_S, d_f, d_o):
+                b.free()
+
+    def trajectory_closest_points(self, trajectory, points, min_u=0.0):
+        """mg_trajectory_closest_points: points (n, T, 3) float64 -> (parameters (n, T), distances (n, T)): the reference's
+        find_closest_point_fast chained frame to frame (trajectory_constraint.py:103-113) for every row."""
+        P = np.ascontiguousarray(points, dtype=np.float64)
+        n, T = P.shape[0], P.shape[1]
+        ctx = self.ctx
+        d_p, d_u, d_d = ctx.upload(P), ctx.malloc(max(n * T, 1) * 8), ctx.malloc(max(n * T, 1) * 8)
+        try:
+            _check(self.lib.mg_trajectory_closest_points(self.handle, trajectory.handle, d_p.ptr, n, T, float(min_u), d_u.ptr, d_d.ptr))
+            return ctx.download(d_u, (n, T), np.float64), ctx.download(d_d, (n, T), np.float64)
+        finally:
+            for b in (d_p, d_u, d_d):
                 b.free()
 
     def score_trajectory_points(self, trajectory, points, min_u=0.0, weight=1.0, residuals=False):

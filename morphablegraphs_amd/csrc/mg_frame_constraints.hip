@@ -112,6 +112,7 @@ struct mg_fc_args {
     const double *points;
     int64_t B;
     int32_t T, J, type, nf, n_points, accumulate, quat_channel;
+    int32_t search;              // MG_FRAME_JOINT_TRAJECTORY: 0 the reference's search, 1 the monotone walk (MG_OPT_TRAJECTORY_SEARCH)
     double weight, start_arc;
     double target[3];
     int32_t axis_on[3];
@@ -187,7 +188,7 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
         for (int f = 0; f < T; f++) {
             const double *pp = tr + (int64_t)f * 3;
             const double q[3] = {pp[0], pp[1], pp[2]};
-            const double dist = mg_traj_closest_dist(poly, t.n_seg, t.G, invG, &min_u, q);
+            const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(poly, t.n_seg, &min_u, q) : mg_traj_closest_dist(poly, t.n_seg, t.G, invG, &min_u, q);
             sum += dist;
             if (a.res) a.res[b * T + f] = a.weight * dist;
         }
@@ -362,6 +363,7 @@ static int mg_fc_args_from_desc(const char *who, mg_primitive *p, const mg_frame
     a.tracks = tracks_dev; a.out = nullptr; a.res = residuals_dev; a.B = B; a.T = T; a.J = J; a.type = c->type; a.accumulate = 0;
     a.weight = c->weight; a.start_arc = c->start_arc; a.points = c->points_dev; a.n_points = c->n_points; a.quat_channel = c->quat_channel;
     a.nf = c->n_frames > 0 && c->n_frames < T ? c->n_frames : T;
+    a.search = p->ctx->opt[MG_OPT_TRAJECTORY_SEARCH] == 1 ? 1 : 0;
     for (int d = 0; d < 3; d++) { a.target[d] = c->target[d]; a.axis_on[d] = c->axis_on[d] ? 1 : 0; }
     int n_traj = 0;
     switch (c->type) {

@@ -6,7 +6,11 @@
 
 #include <cmath>
 
-__device__ __forceinline__ void mg_traj_point(const double *__restrict__ poly, int n_seg, double u, double *p) {
+// (the reference search and what it evaluates also compile for the host: tests/lbfgsb_host_check.cpp runs the device's very
+// statements on the golden tracks without a GPU -- test infrastructure, never linked into the library)
+#define MG_HD __host__ __device__
+
+MG_HD __forceinline__ void mg_traj_point(const double *__restrict__ poly, int n_seg, double u, double *p) {
     const double scaled = n_seg * u;
     int index = (int)floor(scaled);
     index = index < n_seg ? index : n_seg;
@@ -20,7 +24,7 @@ __device__ __forceinline__ void mg_traj_point(const double *__restrict__ poly, i
 #pragma unroll
     for (int d = 0; d < 3; d++) p[d] = ((A[d] * t + A[3 + d]) * t + A[6 + d]) * t + A[9 + d];
 }
-__device__ __forceinline__ double mg_traj_d2(const double *poly, int n_seg, double u, const double *q) {
+MG_HD __forceinline__ double mg_traj_d2(const double *poly, int n_seg, double u, const double *q) {
     double p[3];
     mg_traj_point(poly, n_seg, u, p);
     const double x = p[0] - q[0], y = p[1] - q[1], z = p[2] - q[2];
@@ -192,4 +196,222 @@ __device__ __forceinline__ double mg_traj_closest_dist_coop(const double *__rest
     if (d_start <= d2) { u = min_u; d2 = d_start; }
     *min_u_io = u;
     return sqrt(d2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// THE REFERENCE'S SEARCH (round 5).  ParameterizedSpline.find_closest_point_fast (splines/parameterized_spline.py:303-322) is
+// scipy.optimize.minimize(distance, [min_u], method="L-BFGS-B", bounds=[(min_u, 1)]) with a forward-difference gradient.  That is not
+// a local search: its first step goes to the far bound and the More'-Thuente line search interpolates back from there, so which
+// local minimum of the distance a frame lands in -- and with it the bound of every later frame -- is decided by that algorithm's own
+// arithmetic.  Measured against vectors the reference's function produced (tests/golden/trajectory_closest_point.npz), the monotone
+// walk above ends up to 0.9 of the parameter range away on 12 of 26 tracks; L-BFGS-B 3.0 restated for ONE bounded variable
+// reproduces all 26 chains to 2e-7 of the parameter (oracle/mg_oracle.py lbfgsb_1d, which documents the restatement routine by
+// routine and is held to scipy itself).  What follows is that restatement on the device:
+//   * objective f(u) = |P(u) - q| (the reference's dist_objective: a norm, not its square), gradient (f(u + h) - f(u)) / h with
+//     h = 1e-8, turned around where u + h would leave [lb, 1] (scipy _numdiff.approx_derivative, 2-point, abs_step, bounds);
+//   * mainlb for n = 1: the limited-memory matrix is the scalar theta = y'y / s'y (any BFGS update in one dimension gives B = y / s),
+//     the generalised Cauchy point is clamp(u - g / theta), a free Cauchy point is the model's minimiser already (subsm: rounding only);
+//   * formk's verdict: the routine that prepares subsm fails ("nonpositive definiteness ... refresh the lbfgs memory and restart
+//     the iteration") when its incrementally kept matrix is stale, which for one variable is: the variable ENTERED the free set in
+//     this iteration and at least two pairs are stored (the iteration before had its Cauchy point on a bound, skipped formk, and
+//     the row of the pair before it was never written).  The oracle transcribes formk's bookkeeping and both Cholesky steps in full;
+//     the rule agreed with it in all of 108 000 calls (1 900 failures) of a randomised campaign and on every golden track.  In
+//     exact arithmetic the stale matrix could still factorise when the newest curvature estimate is below about half the oldest
+//     stored one: not observed, and a restart only changes the path to the same local minimum;
+//   * lnsrlb + dcsrch + dcstep (ftol 1e-3, gtol 0.9, xtol 0.1, at most 20 evaluations), the two convergence tests (projected gradient
+//     <= 1e-5, relative reduction <= 1e7 eps), the curvature test of the update (s'y > eps |g'd| stp).
+// Attainable agreement: the forward difference amplifies the last bit of f by 1e8, so two correct implementations agree to ~1e-8 in
+// u per search and -- rarely, 0.2 % of single searches against scipy -- stop one iteration apart (|du| < 1e-5).
+// One lane per candidate; ~7 spline evaluations per frame on average (2 where the bound holds the point, up to ~70).
+MG_HD __forceinline__ double mg_traj_dist(const double *poly, int n_seg, double u, const double *q) {
+    return sqrt(mg_traj_d2(poly, n_seg, u, q));
+}
+// f and the forward-difference gradient at x (scipy: fun_and_grad)
+MG_HD __forceinline__ void mg_lb_fg(const double *poly, int n_seg, const double *q, double lb, double x, double *f, double *g) {
+    const double f0 = mg_traj_dist(poly, n_seg, x, q);
+    double h = 1.0e-8;
+    const double lower = x - lb, upper = 1.0 - x;
+    if (x + h < lb || x + h > 1.0) {
+        if (fabs(h) <= fmax(lower, upper)) h = -h;
+        else if (upper >= lower) h = upper;
+        else h = -lower;
+    }
+    const double x1 = x + h;
+    const double f1 = mg_traj_dist(poly, n_seg, x1, q);
+    *f = f0;
+    *g = (f1 - f0) / (x1 - x);
+}
+// MINPACK-2 dcstep: the safeguarded cubic / quadratic step and the update of the interval of uncertainty.  The routine's four cases
+// (higher value; lower value and derivatives of opposite sign; lower value, same sign, smaller derivative; lower value, same sign,
+// derivative not smaller) share one shape -- theta, s, gamma = s sqrt(.), r = p / q, a cubic and a quadratic candidate -- with
+// different operands: written as ONE path over selected operands (every value the statements of the case at hand would compute, bit for
+// bit: a quotient of two negated operands is the same quotient), a wave whose lanes sit in different cases runs it once instead of
+// four times (8 divisions and a root instead of up to 28 and 4).
+MG_HD __forceinline__ void mg_lb_dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy, double &stp, const double fp, const double dp,
+                                        bool &brackt, const double stpmin, const double stpmax) {
+    const double sgnd = dp * (dx / fabs(dx));
+    const int cs = fp > fx ? 1 : (sgnd < 0.0 ? 2 : (fabs(dp) < fabs(dx) ? 3 : 4));
+    const bool c4 = cs == 4;
+    const double stA = c4 ? sty : stx, fA = c4 ? fy : fx, dA = c4 ? dy : dx;     // (case 4 interpolates between stp and sty)
+    const double theta = 3.0 * (fA - fp) / (stp - stA) + dA + dp;
+    const double s = fmax(fabs(theta), fmax(fabs(dA), fabs(dp)));
+    double arg = (theta / s) * (theta / s) - (dA / s) * (dp / s);
+    if (cs == 3) arg = fmax(0.0, arg);
+    double gamma = s * sqrt(arg);
+    if (cs == 1 ? stp < stx : stp > stA) gamma = -gamma;
+    const double u = cs == 1 ? dx : dp;
+    const double p = (gamma - u) + theta;
+    const double q = cs == 3 ? (gamma + (dx - dp)) + gamma : ((gamma - u) + gamma) + (cs == 1 ? dp : dA);
+    const double r = p / q;
+    double stpc = cs == 1 ? stx + r * (stp - stx) : stp + r * (stA - stp);
+    if (cs == 3 && !(r < 0.0 && gamma != 0.0)) stpc = stp > stx ? stpmax : stpmin;
+    const double q1 = (fx - fp) / (stp - stx);
+    const double stpq = cs == 1 ? stx + ((dx / (q1 + dx)) / 2.0) * (stp - stx) : stp + (dp / (dp - dx)) * (stx - stp);
+    double stpf;
+    if (cs == 1) stpf = fabs(stpc - stx) < fabs(stpq - stx) ? stpc : stpc + (stpq - stpc) / 2.0;
+    else if (cs == 2) stpf = fabs(stpc - stp) > fabs(stpq - stp) ? stpc : stpq;
+    else if (cs == 3) {
+        if (brackt) {
+            stpf = fabs(stpc - stp) < fabs(stpq - stp) ? stpc : stpq;
+            stpf = stp > stx ? fmin(stp + 0.66 * (sty - stp), stpf) : fmax(stp + 0.66 * (sty - stp), stpf);
+        } else {
+            stpf = fabs(stpc - stp) > fabs(stpq - stp) ? stpc : stpq;
+            stpf = fmin(stpmax, stpf);
+            stpf = fmax(stpmin, stpf);
+        }
+    } else stpf = brackt ? stpc : (stp > stx ? stpmax : stpmin);
+    if (cs <= 2) brackt = true;
+    if (fp > fx) { sty = stp; fy = fp; dy = dp; }
+    else {
+        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+        stx = stp; fx = fp; dx = dp;
+    }
+    stp = stpf;
+}
+// The distance from q to the spline point the reference's search settles on, its parameter back in *min_u_io (the next frame's bound
+// and start).  oracle/mg_oracle.py closest_point_lbfgsb, statement for statement (with formk's verdict by the rule above) -- as ONE
+// flat loop whose every trip is one evaluation of (f, g) followed by the bookkeeping that decides the next point: written as the
+// algorithm's nested loops (iterations around line-search trials) a wave runs, per frame, the SUM over iterations of the longest line
+// search any of its 64 lanes has in that iteration; flat, it runs the longest lane's total (12.3 -> 10.5 ms per 4096 candidates x 156
+// frames; what is left is one wave's chain of dependent float64 instructions: ~34 trips per frame for the slowest of 64 lanes --
+// the reference's line searches that end at the noise floor after 20 trials --, each ~500 instructions at ~10 cycles).
+MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_seg, double *min_u_io, const double *q) {
+    const double lb = *min_u_io, ub = 1.0;
+    const double epsmch = 2.220446049250313e-16, pgtol = 1.0e-5, factr = 1.0e7;
+    const double ftol = 1.0e-3, gtol = 0.9, xtol = 0.1, stpmin = 0.0;
+    double x = lb, f = 0.0, g = 0.0;
+    // the iteration's state
+    double t = 0.0, r_ = 0.0, fold = 0.0, d = 0.0, z = 0.0, stpmx = 0.0, gdold = 0.0, theta = 1.0;
+    // the line search's state
+    double stp = 1.0, finit = 0.0, ginit = 0.0, gtest = 0.0, width = 0.0, width1 = 0.0;
+    double stx = 0.0, fx = 0.0, gx = 0.0, sty = 0.0, fy = 0.0, gy = 0.0, stmin = 0.0, stmax = 0.0;
+    int col = 0, itr = 0, nit = 0, ifun = 0, stage = 1;
+    bool was_free = true, brackt = false, searching = false, done = false;
+    auto projgr = [&](double xx, double gg) { return fabs(gg < 0.0 ? fmax(xx - ub, gg) : fmin(xx - lb, gg)); };
+    while (!done) {
+        double fn, gn;
+        mg_lb_fg(poly, n_seg, q, lb, x, &fn, &gn);
+        bool start = false;                 // set up a new iteration (Cauchy point, line search) from (x, f, g)
+        if (!searching) {                   // the start point
+            f = fn; g = gn;
+            if (lb == ub || projgr(x, g) <= pgtol) done = true;     // (lb == ub: minimize() returns the bound without a search)
+            else start = true;
+        } else {                            // a trial point of the line search: dcsrch's re-entry
+            f = fn; g = gn;
+            const double gd = g * d;
+            const double ftest = finit + stp * gtest;
+            if (stage == 1 && f <= ftest && gd >= 0.0) stage = 2;
+            bool ended = false;
+            if (brackt && (stp <= stmin || stp >= stmax)) ended = true;
+            if (brackt && stmax - stmin <= xtol * stmax) ended = true;
+            if (stp == stpmx && f <= ftest && gd <= gtest) ended = true;
+            if (stp == stpmin && (f > ftest || gd >= gtest)) ended = true;
+            if (f <= ftest && fabs(gd) <= gtol * (-ginit)) ended = true;
+            if (ended) {                    // NEW_X
+                searching = false;
+                itr++; nit++;
+                if (projgr(x, g) <= pgtol || fold - f <= epsmch * factr * fmax(fabs(fold), fmax(fabs(f), 1.0)) || nit >= 15000) done = true;
+                else {
+                    const double y = g - r_, rr = y * y;
+                    double dr, dd;
+                    if (stp == 1.0) { dr = gd - gdold; dd = -gdold; }
+                    else { dr = (gd - gdold) * stp; dd = -gdold * stp; }
+                    if (!(dr <= epsmch * dd)) { col = col < 10 ? col + 1 : 10; theta = rr / dr; }     // (else: the update is skipped, the model stays)
+                    start = true;
+                }
+            } else {
+                if (stage == 1 && f <= fx && f > ftest) {
+                    const double fm = f - stp * gtest, gm = gd - gtest;
+                    double fxm = fx - stx * gtest, fym = fy - sty * gtest, gxm = gx - gtest, gym = gy - gtest;
+                    mg_lb_dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, brackt, stmin, stmax);
+                    fx = fxm + stx * gtest; fy = fym + sty * gtest; gx = gxm + gtest; gy = gym + gtest;
+                } else {
+                    mg_lb_dcstep(stx, fx, gx, sty, fy, gy, stp, f, gd, brackt, stmin, stmax);
+                }
+                if (brackt) {
+                    if (fabs(sty - stx) >= 0.66 * width1) stp = stx + 0.5 * (sty - stx);
+                    width1 = width;
+                    width = fabs(sty - stx);
+                }
+                if (brackt) { stmin = fmin(stx, sty); stmax = fmax(stx, sty); }
+                else { stmin = stp + 1.1 * (stp - stx); stmax = stp + 4.0 * (stp - stx); }
+                stp = fmax(stp, stpmin);
+                stp = fmin(stp, stpmx);
+                if ((brackt && (stp <= stmin || stp >= stmax)) || (brackt && stmax - stmin <= xtol * stmax)) stp = stx;
+                ifun++;
+                if (ifun - 1 >= 20) {       // the line search gave up: back to the iteration's start point
+                    x = t; g = r_; f = fold;
+                    searching = false;
+                    if (col == 0) done = true;                       // abnormal termination in the line search
+                    else { col = 0; theta = 1.0; start = true; }
+                } else x = stp == 1.0 ? z : stp * d + t;
+            }
+        }
+        while (start) {                     // (at most three passes: a formk restart, a restart after a non-descent direction)
+            start = false;
+            // cauchy
+            const double neggi = -g;
+            const double tl = x - lb, tu = ub - x;
+            const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
+            const bool fixed = (xlower && neggi <= 0.0) || (!xlower && xupper && neggi >= 0.0);
+            bool fr;
+            if (fixed || neggi == 0.0) { z = x; fr = !fixed; }
+            else {
+                const double f1 = -neggi * neggi, f2 = -theta * f1;
+                double dtm = -f1 / f2;
+                const double tbreak = neggi < 0.0 ? tl / (-neggi) : tu / neggi;
+                if (dtm < tbreak) { if (dtm <= 0.0) dtm = 0.0; z = x + dtm * neggi; fr = true; }
+                else { z = neggi > 0.0 ? ub : lb; fr = false; }
+            }
+            // freev + formk's verdict
+            const bool entered = itr > 0 && fr && !was_free;
+            was_free = fr;
+            if (fr && entered && col >= 2) { col = 0; theta = 1.0; start = true; continue; }
+            d = z - x;
+            // lnsrlb
+            if (itr == 0) stpmx = 1.0;
+            else {
+                stpmx = 1.0e10;
+                if (d < 0.0) { const double a2 = lb - x; if (a2 >= 0.0) stpmx = 0.0; else if (d * stpmx < a2) stpmx = a2 / d; }
+                else if (d > 0.0) { const double a2 = ub - x; if (a2 <= 0.0) stpmx = 0.0; else if (d * stpmx > a2) stpmx = a2 / d; }
+            }
+            t = x; r_ = g; fold = f;
+            const double gd = g * d;
+            gdold = gd;
+            if (gd >= 0.0) {                // not a descent direction: restart without memory, or give up
+                if (col == 0) { done = true; break; }
+                col = 0; theta = 1.0; start = true;
+                continue;
+            }
+            // dcsrch, START
+            stp = 1.0; brackt = false; stage = 1; ifun = 1;
+            finit = f; ginit = gd; gtest = ftol * ginit;
+            width = stpmx - stpmin; width1 = width / 0.5;
+            stx = 0.0; fx = finit; gx = ginit; sty = 0.0; fy = finit; gy = ginit; stmin = 0.0; stmax = stp + 4.0 * stp;
+            searching = true;
+            x = z;                          // (stp = 1)
+        }
+    }
+    *min_u_io = x;
+    return f;
 }

@@ -3,11 +3,13 @@
 // per frame of the motion the distance from the root position to the closest point of a Catmull-Rom spline
 // (splines/catmull_rom_spline.py:118-168) whose parameter is at or after the previous frame's; the constraint's error is
 // the average over the frames.  The reference finds that point with scipy's L-BFGS-B started at the lower bound
-// (splines/parameterized_spline.py:303-322; the function raises ValueError under NumPy >= 1.24, so PARITY UNPINNED);
-// here the search is deterministic: on the grid u_k = k / granularity walk forward from the bound while the distance
-// falls, refine by the parabola through the three squared distances around the minimum, then by Newton steps on the
-// squared distance inside that bracket (oracle: oracle/mg_oracle.py closest_point_walk).  The result is the local
-// minimum of the first basin at or after the bound; tests hold it to "never farther than the restated L-BFGS-B search".
+// (splines/parameterized_spline.py:303-322).  Round 5: PINNED -- the reference's own function produced
+// tests/golden/trajectory_closest_point.npz (with a size-1-array shim for NumPy >= 1.24, oracle/gen_golden.py), and the search here
+// IS that algorithm restated for one bounded variable (mg_traj_device.h: mg_traj_closest_lbfgsb; why nothing less reproduces the
+// reference is told there).  The deterministic walk of rounds 2-4 -- on the grid u_k = k / granularity forward from the bound while
+// the distance falls, parabola, Newton steps: the local minimum of the first basin at or after the bound -- stays as
+// MG_OPT_TRAJECTORY_SEARCH = 1: equal to the reference where the distance has one basin ahead of the bound (smooth path following),
+// up to 0.9 of the parameter range away from it where it has several.
 //
 // One thread per candidate (the search is a chain over the frames): the candidate's root coefficient rows
 // (n_basis x 3, float64 fma chains over the latents) are staged in LDS, every frame is four taps of them.
@@ -34,6 +36,8 @@ struct mg_traj_args {
     double al[7];   // heading (x, z) or (cos, sin); landing (x, z); ref_dir (3) or height
     const double *points;   // NULL, or (B, T, 3): the positions to follow the trajectory with, given instead of derived from the
                             // candidates' root rows (any joint's track from mg_joint_positions; already aligned by the caller)
+    double *res_u;          // NULL, or (B, T): the parameter the search settles on in every frame (mg_trajectory_closest_points)
+    int32_t search;         // 0: the reference's search (L-BFGS-B restated, mg_traj_closest_lbfgsb), 1: the monotone walk (MG_OPT_TRAJECTORY_SEARCH)
 };
 
 #define MG_TRAJ_BLOCK 64
@@ -119,11 +123,13 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
             q[2] = ac * z - as * x + tz;
             q[1] += ty;
         }
-        const double dist = mg_traj_closest_dist<true>(poly, a.n_seg, G, invG, &min_u, q);   // (mg_traj_device.h; min_u moves to the point's parameter; every lane of the wave is here: long walks get its help)
+        // (mg_traj_device.h; min_u moves to the point's parameter; every lane of the wave is here: the walk's long searches get its help)
+        const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(poly, a.n_seg, &min_u, q) : mg_traj_closest_dist<true>(poly, a.n_seg, G, invG, &min_u, q);
         sum += dist;
         if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
+        if (a.res_u && valid) a.res_u[b * a.T + f] = min_u;
     }
-    if (valid) {
+    if (valid && a.out) {
         const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
         a.out[b] = a.accumulate ? a.out[b] + e : e;
     }
@@ -214,8 +220,9 @@ __device__ __forceinline__ void mg_trajectory_coop_body(const mg_traj_args &a, c
         const double dist = mg_traj_closest_dist_coop<MG_TRAJ_W>(lp, a.n_seg, G, invG, &min_u, q);
         sum += dist;
         if (a.res && valid && sub == 0) a.res[b * a.T + f] = a.weight * dist;
+        if (a.res_u && valid && sub == 0) a.res_u[b * a.T + f] = min_u;
     }
-    if (valid && sub == 0) {
+    if (valid && sub == 0 && a.out) {
         const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
         a.out[b] = a.accumulate ? a.out[b] + e : e;
     }
@@ -308,7 +315,7 @@ __device__ __forceinline__ void mg_trajectory_stream_body(const mg_traj_args &a,
             q[2] = ac * z - as * x + tz;
             q[1] += ty;
         }
-        const double dist = mg_traj_closest_dist<true>(lp, a.n_seg, G, invG, &min_u, q);   // (every lane of the wave is here: the help is legal)
+        const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(lp, a.n_seg, &min_u, q) : mg_traj_closest_dist<true>(lp, a.n_seg, G, invG, &min_u, q);   // (every lane of the wave is here: the help is legal)
         sum += dist;
         if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
     }
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_stream_multi_kern
 #define MG_TRAJ_W4_MAX_TOTAL 40960
 static int mg_traj_lanes(const mg_context *ctx, int64_t B, int64_t total) {
     const int opt = ctx->opt[MG_OPT_TRAJECTORY_LANES];
+    if (ctx->opt[MG_OPT_TRAJECTORY_SEARCH] != 1) return 1;    // the reference's search is one chain of evaluations: nothing for more lanes to do
     if (opt == 1 || B > MG_TRAJ_COOP_MAX_B) return 1;
     if (opt == 8 || opt == 4) return opt;
     return total <= MG_TRAJ_W8_MAX_TOTAL ? 8 : (total <= MG_TRAJ_W4_MAX_TOTAL ? 4 : 1);
@@ -465,7 +473,8 @@ static int mg_traj_fill_args(const char *who, mg_primitive *p, const mg_trajecto
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = lat; a.i0 = g->d_i0; a.w = g->d_w; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = ld; a.T = g->T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = dt == MG_F64 ? 1 : 0;
-    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = nullptr;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = nullptr; a.res_u = nullptr;
+    a.search = p->ctx->opt[MG_OPT_TRAJECTORY_SEARCH] == 1 ? 1 : 0;
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
     if (al) {
@@ -583,19 +592,20 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
 // The same search for positions the caller supplies: points_dev (B, T, 3) float64 (e.g. one joint's track from mg_joint_positions,
 // aligned by the caller) -- TrajectoryConstraint for joints other than the root (trajectory_constraint.py:95-121 with
 // skeleton.nodes[joint].get_global_position(frame)).
-extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *t, const double *points_dev, int64_t B, int32_t T, double min_u,
-                                          double weight, double *errors_dev, int accumulate, double *residuals_dev) {
+static int mg_traj_points_launch(const char *who, mg_primitive *p, const mg_trajectory *t, const double *points_dev, int64_t B, int32_t T, double min_u,
+                                 double weight, double *errors_dev, int accumulate, double *residuals_dev, double *params_dev) {
     if (!p || !t || t->prim != p || B < 0 || T < 1 || !(min_u >= 0.0 && min_u <= 1.0) || !std::isfinite(weight)) {
-        mg_set_error("mg_score_trajectory_points: bad arguments");
+        mg_set_error("%s: bad arguments", who);
         return MG_ERR_INVALID_ARGUMENT;
     }
     if (B == 0) return MG_OK;
-    if (!points_dev || !errors_dev) { mg_set_error("mg_score_trajectory_points: NULL pointer"); return MG_ERR_INVALID_ARGUMENT; }
+    if (!points_dev || (!errors_dev && !params_dev && !residuals_dev)) { mg_set_error("%s: NULL pointer", who); return MG_ERR_INVALID_ARGUMENT; }
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = nullptr; a.i0 = nullptr; a.w = nullptr; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = 0; a.T = T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = 1;
-    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = points_dev;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = points_dev; a.res_u = params_dev;
+    a.search = p->ctx->opt[MG_OPT_TRAJECTORY_SEARCH] == 1 ? 1 : 0;
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
     const int grid = (int)((B + MG_TRAJ_BLOCK - 1) / MG_TRAJ_BLOCK);
@@ -614,4 +624,18 @@ extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *
     mg_prof_end(p->ctx, 10);
     MG_HIP_CHECK(hipGetLastError());
     return MG_OK;
+}
+extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *t, const double *points_dev, int64_t B, int32_t T, double min_u,
+                                          double weight, double *errors_dev, int accumulate, double *residuals_dev) {
+    if (B > 0 && !errors_dev) { mg_set_error("mg_score_trajectory_points: NULL pointer"); return MG_ERR_INVALID_ARGUMENT; }
+    return mg_traj_points_launch("mg_score_trajectory_points", p, t, points_dev, B, T, min_u, weight, errors_dev, accumulate, residuals_dev, nullptr);
+}
+// ParameterizedSpline.find_closest_point_fast (splines/parameterized_spline.py:303-322) for a batch of point sequences, chained the way
+// TrajectoryConstraint.get_residual_vector chains it (trajectory_constraint.py:103-113: every frame's search is bounded below by, and
+// started at, the previous frame's parameter): params_dev (B, T) the parameter of every frame's point, distances_dev (B, T) its
+// distance (either may be NULL).
+extern "C" int mg_trajectory_closest_points(mg_primitive *p, const mg_trajectory *t, const double *points_dev, int64_t B, int32_t T, double min_u,
+                                            double *params_dev, double *distances_dev) {
+    if (B > 0 && !params_dev && !distances_dev) { mg_set_error("mg_trajectory_closest_points: nothing to write"); return MG_ERR_INVALID_ARGUMENT; }
+    return mg_traj_points_launch("mg_trajectory_closest_points", p, t, points_dev, B, T, min_u, 1.0, nullptr, 0, distances_dev, params_dev);
 }

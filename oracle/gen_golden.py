@@ -203,12 +203,8 @@ def run_walk_32_case(ref, name, data, seed):
 def run_trajectory_spline_case(name):
     """The spline under a TrajectoryConstraint (reference constraints/spatial_constraints/splines/{parameterized_spline,
     catmull_rom_spline,arc_length_map}.py, which need only numpy / scipy / matplotlib): points at given parameters and the
-    arc length of the granularity-1000 table.  (find_closest_point_fast itself raises ValueError under the installed NumPy:
-    the closest-point search has no vector.)"""
-    pkg = types.ModuleType("mg_ref_splines")
-    pkg.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints/splines"]
-    sys.modules["mg_ref_splines"] = pkg
-    ps = importlib.import_module("mg_ref_splines.parameterized_spline")
+    arc length of the granularity-1000 table.  (The closest-point search: run_closest_point_case.)"""
+    ps = import_reference_splines()
     rng = np.random.default_rng(77)
     out = {}
     for ci, n_points in enumerate((2, 5, 9)):
@@ -231,6 +227,212 @@ def run_trajectory_spline_case(name):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def import_reference_splines():
+    """reference constraints/spatial_constraints/splines/*.py through a stub parent package (numpy / scipy / matplotlib only)"""
+    if "mg_ref_splines" not in sys.modules:
+        pkg = types.ModuleType("mg_ref_splines")
+        pkg.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints/splines"]
+        sys.modules["mg_ref_splines"] = pkg
+    return importlib.import_module("mg_ref_splines.parameterized_spline")
+
+
+class scalar_spline_parameter(object):
+    """The ONE shim of the closest-point vectors, for the duration of the calls: scipy's L-BFGS-B hands the objective its
+    parameter as a 1-element ndarray, and CatmullRomSpline.query_point_by_parameter (catmull_rom_spline.py:148-165) builds
+    [u**3, u**2, u, 1] from it -- a ragged list that NumPy >= 1.24 refuses to turn into an array (older NumPy made an object
+    array and the dot products went through).  The wrapper unwraps a size-1 array to the float it holds before the reference's
+    own, unmodified method runs; nothing else is touched (the same kind of shim as np.linspace's int(num) for the time-warp
+    vectors, run_time_case)."""
+
+    def __enter__(self):
+        self.cr = importlib.import_module("mg_ref_splines.catmull_rom_spline")
+        self.orig = self.cr.CatmullRomSpline.query_point_by_parameter
+        orig = self.orig
+
+        def unwrapped(spline, u):
+            if isinstance(u, np.ndarray) and u.size == 1:
+                u = float(u.reshape(-1)[0])
+            return orig(spline, u)
+        self.cr.CatmullRomSpline.query_point_by_parameter = unwrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.cr.CatmullRomSpline.query_point_by_parameter = self.orig
+
+
+def closest_point_tracks(rng, cps, walk_paths):
+    """The joint tracks a case's spline is searched from: (name, track (T, 3), min_u at the first frame)"""
+    cps = np.asarray(cps, dtype=np.float64)
+    T = 156
+    s = np.linspace(0.0, 1.0, T)
+    chord = cps[0][None, :] + s[:, None] * (cps[-1] - cps[0])[None, :]
+    span = float(np.linalg.norm(cps[-1] - cps[0]))
+    wob = np.column_stack([0.03 * span * np.sin(7.0 * s), np.zeros(T), 0.04 * span * np.cos(5.0 * s)])
+    tracks = [("near", chord + wob + rng.normal(0.0, 0.002 * span, (T, 3)) * np.array([1.0, 0.0, 1.0]), 0.0),
+              # a hand: off the spline's plane, swinging in y, slower than the spline is long
+              ("hand", cps[0][None, :] + 0.7 * s[:, None] * (cps[-1] - cps[0])[None, :] + np.column_stack(
+                  [0.05 * span * np.sin(11.0 * s), 90.0 + 12.0 * np.sin(9.0 * s), 0.05 * span * np.sin(13.0 * s + 1.0)]), 0.0),
+              # far from the spline (several spans to its side)
+              ("far", chord + np.array([0.0, 0.0, 4.0 * span])[None, :] + wob, 0.0),
+              # beyond the end: the track runs on for half a span past the last control point (the parameter meets its bound 1)
+              ("beyond", cps[0][None, :] + 1.5 * s[:, None] * (cps[-1] - cps[0])[None, :] + 0.5 * wob, 0.0),
+              # a later start on the spline, the track starting where the spline is at about a third
+              ("late_start", cps[0][None, :] + (0.3 + 0.7 * s)[:, None] * (cps[-1] - cps[0])[None, :] + wob, 0.3),
+              # a track that runs BACKWARDS along the spline: the bound (the previous frame's parameter) holds the point
+              ("backwards", chord[::-1] + 0.5 * wob, 0.25)]
+    for k, path in enumerate(walk_paths):
+        tracks.append(("walk%d" % k, path, 0.0))
+    return tracks
+
+
+def run_closest_point_case(name):
+    """ParameterizedSpline.find_closest_point_fast (splines/parameterized_spline.py:303-322: scipy L-BFGS-B on the distance over
+    the spline parameter, bounds [min_u, 1], started at min_u), chained frame to frame exactly as
+    TrajectoryConstraint.get_residual_vector does (trajectory_constraint.py:93-116: target, u = find_closest_point_fast(joint_position,
+    min_u); errors[index] = norm(joint_position - target); min_u = u, starting from min_arc_length / full_arc_length) -- that class
+    itself cannot be imported (its module pulls anim_utils through discrete_trajectory_constraint.py), so the six lines of its loop
+    are restated here around the reference's own search.  Splines of 2, 5 and 9 control points; tracks near, far, beyond the
+    end, with a late start, running backwards, a hand off the plane, and the root paths of the golden walks (walk_seed0) beside
+    splines laid through them.  Per frame: parameter u, target point, distance."""
+    ps = import_reference_splines()
+    rng = np.random.default_rng(505)
+    walk = np.load(os.path.join(OUT_DIR, "walk_seed0.npz"))
+    walk_paths = [np.ascontiguousarray(walk["frames"][b][:, :3]) for b in range(2)]
+    out = {"n_cases": np.int64(4)}
+    with scalar_spline_parameter():
+        for ci, n_points in enumerate((2, 5, 9, 7)):
+            if ci < 3:
+                cps = np.cumsum(np.column_stack([rng.uniform(20, 60, n_points), np.zeros(n_points), rng.uniform(-40, 40, n_points)]), axis=0)
+                paths = []
+            else:          # a spline laid through points of a golden walk's root path, displaced sideways: path following
+                p0 = walk_paths[0]
+                cps = p0[::26].copy()[:n_points]
+                cps[:, 0] += np.linspace(0.0, 6.0, len(cps))
+                cps[:, 2] -= np.linspace(0.0, 4.0, len(cps))
+                paths = walk_paths
+            sp = ps.ParameterizedSpline(cps.tolist(), ps.SPLINE_TYPE_CATMULL_ROM)
+            out["control_points_%d" % ci] = cps
+            out["full_arc_length_%d" % ci] = np.float64(sp.full_arc_length)
+            tracks = closest_point_tracks(rng, cps, paths)
+            out["track_names_%d" % ci] = np.array([t[0] for t in tracks])
+            for ti, (tname, track, min_u0) in enumerate(tracks):
+                track = np.ascontiguousarray(track, dtype=np.float64)
+                us, targets, dists = np.empty(len(track)), np.empty((len(track), 3)), np.empty(len(track))
+                min_u = min_u0                                    # trajectory_constraint.py:103 (min_arc_length / full_arc_length)
+                for index, joint_position in enumerate(track):    # :104-113
+                    target, u = sp.find_closest_point_fast(joint_position, min_u)
+                    dists[index] = np.linalg.norm(joint_position - target)
+                    us[index], targets[index] = float(np.ravel(u)[0]), target
+                    min_u = u
+                out["track_%d_%d" % (ci, ti)] = track
+                out["min_u0_%d_%d" % (ci, ti)] = np.float64(min_u0)
+                out["u_%d_%d" % (ci, ti)] = us
+                out["target_%d_%d" % (ci, ti)] = targets
+                out["distance_%d_%d" % (ci, ti)] = dists
+                # single searches from the SAME lower bound in every frame (no chain): bound = the chain's previous parameter
+                # is what the vectors above hold; here from a fixed bound, for the search alone
+                fixed = np.array([float(np.ravel(sp.find_closest_point_fast(p, min_u0)[1])[0]) for p in track[::13]])
+                out["u_fixed_bound_%d_%d" % (ci, ti)] = fixed
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+class _TrackNode(object):
+    def __init__(self, track):
+        self.track = track
+
+    def get_global_position(self, frame, use_cache=False):
+        return self.track[int(frame[0])].copy()
+
+
+class _TrackSkeleton(object):
+    """INPUT DATA in the shape the reference's classes ask their skeleton argument for: joint -> its global position per frame.
+    A "frame" is the 1-element array [frame index]; nodes[joint].get_global_position(frame) returns the given position."""
+
+    def __init__(self, tracks):
+        self.nodes = {j: _TrackNode(np.asarray(t, dtype=np.float64)) for j, t in tracks.items()}
+
+    def clear_cached_global_matrices(self):
+        pass
+
+
+class _IndexSpline(object):
+    """aligned_spline for LocalTrajectoryConstraint.get_positions_from_spline: evaluate(idx) -> the frame token of frame idx"""
+
+    def evaluate(self, idx):
+        return np.array([float(idx)])
+
+
+def run_per_frame_classes_case(name):
+    """LocalTrajectoryConstraint (keyframe_constraints/local_trajectory_constraint.py:45-78) and TrajectorySetConstraint
+    (trajectory_set_constraint.py:41-104), the reference's unmodified files imported through stub parent packages that supply only
+    the label constants of spatial_constraints/__init__.py; their skeleton is an ARGUMENT: a duck-typed object that returns given
+    joint tracks (input data, stored in the fixture).  Trajectories: the reference's ParameterizedSpline."""
+    ps = import_reference_splines()
+    pkg = types.ModuleType("mg_ref_spatial")
+    pkg.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints"]
+    for label in ("TRAJECTORY", "KEYFRAME_POSITION", "KEYFRAME_DIR_2D", "KEYFRAME_POSE", "TWO_HAND_POSITION", "TRAJECTORY_SET", "KEYFRAME_LOOK_AT",
+                  "KEYFRAME_FEET", "CA_CONSTRAINT", "KEYFRAME_RELATIVE_POSITION"):
+        setattr(pkg, "SPATIAL_CONSTRAINT_TYPE_" + label, label.lower())
+    pkg.__all__ = [k for k in vars(pkg) if k.startswith("SPATIAL_")]
+    sys.modules["mg_ref_spatial"] = pkg
+    kf = types.ModuleType("mg_ref_spatial.keyframe_constraints")
+    kf.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints/keyframe_constraints"]
+    sys.modules["mg_ref_spatial.keyframe_constraints"] = kf
+    ltc = importlib.import_module("mg_ref_spatial.keyframe_constraints.local_trajectory_constraint")
+    tsc = importlib.import_module("mg_ref_spatial.trajectory_set_constraint")
+    rng = np.random.default_rng(606)
+    T = 60
+    s = np.linspace(0.0, 1.0, T)
+    out = {}
+    import contextlib
+    import io
+    for ci, n_points in enumerate((2, 5, 9)):
+        cps = np.cumsum(np.column_stack([rng.uniform(20, 60, n_points), rng.uniform(-3, 3, n_points), rng.uniform(-40, 40, n_points)]), axis=0)
+        cps2 = cps + np.array([5.0, 40.0, -8.0])
+        traj, traj2 = ps.ParameterizedSpline(cps.tolist(), ps.SPLINE_TYPE_CATMULL_ROM), ps.ParameterizedSpline(cps2.tolist(), ps.SPLINE_TYPE_CATMULL_ROM)
+        span = cps[-1] - cps[0]
+        hips = cps[0][None, :] + (0.9 * s)[:, None] * span[None, :] + np.column_stack([2.0 * np.sin(9 * s), 0.5 * np.cos(4 * s), 3.0 * np.sin(6 * s + 0.5)])
+        hand = hips + np.column_stack([4.0 * np.cos(12 * s), 40.0 + 6.0 * np.sin(10 * s), 5.0 * np.sin(8 * s)])
+        sk = _TrackSkeleton({"Hips": hips, "LeftHand": hand})
+        frames = [np.array([float(i)]) for i in range(T)]
+        out["control_points_%d" % ci], out["control_points2_%d" % ci] = cps, cps2
+        out["hips_%d" % ci], out["hand_%d" % ci] = hips, hand
+        # LocalTrajectoryConstraint: arc length walked from start_t, squared xz distance per frame, summed
+        for si, (start_t, nf) in enumerate(((0.0, T), (0.4 * traj.full_arc_length, 37))):
+            desc = {"canonical_keyframe": 0, "semanticAnnotation": {"keyframeLabel": "none"}, "trajectory": traj, "start_t": start_t,
+                    "n_canonical_frames": nf, "joint_name": "Hips"}
+            c = ltc.LocalTrajectoryConstraint(sk, desc, 1.0, 1.0)
+            out["local_start_t_%d_%d" % (ci, si)] = np.float64(start_t)
+            out["local_n_frames_%d_%d" % (ci, si)] = np.int64(nf)
+            out["local_residuals_%d_%d" % (ci, si)] = np.asarray(c.get_residual_vector_spline(_IndexSpline()), dtype=np.float64)
+            out["local_error_%d_%d" % (ci, si)] = np.float64(c.evaluate_motion_spline(_IndexSpline()))
+        # TrajectorySetConstraint: two joints, active ranges, start arc lengths
+        full1, full2 = traj.full_arc_length, traj2.full_arc_length
+        set_cases = [(((None, None), (None, None)), (0.0, 0.0)),                           # no active range: all residuals stay 0
+                     (((0.0, 1.0e9), (None, None)), (3.0, 1.0)),                           # one trajectory always active
+                     (((0.2 * full1, 0.7 * full1), (5.0, 0.5 * full2)), (3.0, 1.0))]       # ranges entered and left on the way
+        for si, (ranges, arcs) in enumerate(set_cases):
+            for t, r in zip((traj, traj2), ranges):
+                t.range_start, t.range_end = r[0], r[1]
+                t.is_active = (lambda tt: (lambda a: tt.range_start is not None and tt.range_start <= a <= tt.range_end))(t)   # trajectory_constraint.py:150-151
+            c = tsc.TrajectorySetConstraint([traj, traj2], ["Hips", "LeftHand"], sk, 1.0, 1.0)
+            c.set_number_of_canonical_frames(T)
+            c.joint_arc_lengths = np.array(arcs, dtype=np.float64)
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = np.asarray(c.get_residual_vector(frames), dtype=np.float64)
+                err = c.evaluate_motion_sample(frames)
+            out["set_ranges_%d_%d" % (ci, si)] = np.array([[np.nan if v is None else v for v in r] for r in ranges], dtype=np.float64)
+            out["set_arc_lengths_%d_%d" % (ci, si)] = np.asarray(c.joint_arc_lengths, dtype=np.float64)
+            out["set_residuals_%d_%d" % (ci, si)] = res
+            out["set_error_%d_%d" % (ci, si)] = np.float64(err)
+    out["n_cases"] = np.int64(3)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref = import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -238,6 +440,10 @@ def main():
         timed = synthetic.make_primitive(seed=13, n_components=12, n_frames=60, n_dim=15, n_gmm=3, name="timed",
                                          n_time_components=3, n_basis_time=8)
         run_time_case(ref, "time_model", timed, 9, 41)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "round5":       # the fixtures added in round 5
+        run_closest_point_case("trajectory_closest_point")
+        run_per_frame_classes_case("per_frame_classes")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "round4":       # the fixtures added in round 4
         run_optimizer_drivers_case("optimizer_drivers")
@@ -270,6 +476,8 @@ def main():
     run_trajectory_spline_case("trajectory_spline")
     run_optimizer_drivers_case("optimizer_drivers")
     run_walk_32_case(ref, "walk_32", walk, 17)
+    run_closest_point_case("trajectory_closest_point")
+    run_per_frame_classes_case("per_frame_classes")
 
 
 if __name__ == "__main__":

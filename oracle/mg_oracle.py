@@ -419,9 +419,9 @@ def catmull_rom_full_arc_length(control_points, granularity=1000):
 
 def closest_point_from(control_points, point, min_u):
     """ParameterizedSpline.find_closest_point_fast (splines/parameterized_spline.py:303-322): L-BFGS-B on the distance over
-    the spline parameter, bounds [min_u, 1], started AT min_u.  PARITY UNPINNED: the reference function raises ValueError
-    under the installed NumPy (its weight vector [x**3, x**2, x, 1] is ragged when scipy hands over x as a 1-element array),
-    so there is no vector of it; this is the same call with the parameter unwrapped to a float."""
+    the spline parameter, bounds [min_u, 1], started AT min_u -- the reference's call itself, through the installed scipy, with the
+    parameter unwrapped to a float (under NumPy >= 1.24 the reference's weight vector [x**3, x**2, x, 1] is ragged when scipy hands
+    over x as a 1-element array).  PINNED by tests/golden/trajectory_closest_point.npz (the reference's own run: 2e-7)."""
     from scipy.optimize import minimize
     target = np.asarray(point, dtype=np.float64)
 
@@ -441,6 +441,458 @@ def trajectory_residuals(root_path, control_points, min_u=0.0):
         errors[f] = np.linalg.norm(np.asarray(p, dtype=np.float64) - target)
         min_u = u
     return errors
+
+
+# ---- scipy's L-BFGS-B for ONE bounded variable, restated -------------------------------------------------------------
+# ParameterizedSpline.find_closest_point_fast is scipy.optimize.minimize(method="L-BFGS-B", bounds=[(min_u, 1)]) with a
+# forward-difference gradient: not a local search -- its first step goes to the far bound and the More'-Thuente line search
+# interpolates back from there, so WHICH local minimum of the distance a frame lands in is decided by that algorithm's own
+# arithmetic (measured on tests/golden/trajectory_closest_point.npz: a monotone local walk ends up to 0.9 of the parameter range
+# away from the reference on 12 of 26 tracks).  Results identical to the reference's therefore need the algorithm itself:
+# L-BFGS-B 3.0 (Byrd, Lu, Nocedal, Zhu 1995; Morales, Nocedal 2011; the reference pins scipy 1.2.1 -- Fortran --, 1.15.3 -- the C
+# translation -- is installed and scipy 1.7.1 -- Fortran -- sits in the image's conda tree: both behave alike on every case tried)
+# specialised to n = 1:
+#   * the limited-memory matrix collapses to the scalar theta = y'y / s'y = y / s (any BFGS update in one dimension gives
+#     B = y / s, whatever the history), so the generalised Cauchy point is clamp(x - g / theta) and, where it is interior, it IS the
+#     model's minimiser: the subspace minimisation (subsm) moves it by rounding noise only and is left out;
+#   * what cannot be left out is formk's BOOKKEEPING: the routine that prepares subsm keeps the matrix WN1 up to date
+#     incrementally (a new row per accepted pair, corrections when a variable enters or leaves the free set) and is only called in
+#     iterations whose Cauchy point is free; an iteration whose Cauchy point sits on a bound skips it, its pair's row is never
+#     written and the "leaves the free set" correction never applied -- the next call then factorises a wrong matrix, its
+#     Cholesky step usually fails ("nonpositive definiteness in formk; refresh the lbfgs memory and restart the iteration"), and
+#     the restart throws the curvature away (theta = 1: the next step goes to a bound again).  With one variable that happens in
+#     about one search in eight, so _FormK below transcribes the bookkeeping and the two factorizations for n = 1.
+# Third-party algorithm, published: routines mainlb, projgr, cauchy, freev, formk, matupd, lnsrlb, dpofa of L-BFGS-B 3.0 / LINPACK,
+# dcsrch, dcstep of MINPACK-2; scipy's wrapper: optimize/_lbfgsb_py.py (_minimize_lbfgsb), optimize/_numdiff.py
+# (approx_derivative, 2-point, abs_step = 1e-8, _adjust_scheme_to_bounds), optimize/_minimize.py
+# (_optimize_result_for_equal_bounds).  PINNED: against scipy itself on random problems (tests/test_oracle_golden.py: parameter,
+# iteration count, exit reason) and, chained, against tests/golden/trajectory_closest_point.npz, which the reference's own
+# find_closest_point_fast produced.
+_LB_EPSMCH = 2.220446049250313e-16
+_LB_M = 10
+
+
+class _FormK(object):
+    """formk's state for one variable: WN1's three blocks (1-based, m = 10), and the two Cholesky steps' verdict."""
+
+    def __init__(self):
+        m = _LB_M
+        self.A = [[0.0] * (m + 1) for _ in range(m + 1)]      # block (1,1): Y'ZZ'Y      (lower triangle used)
+        self.C = [[0.0] * (m + 1) for _ in range(m + 1)]      # block (2,2): S'AA'S      (lower triangle used)
+        self.Bm = [[0.0] * (m + 1) for _ in range(m + 1)]     # block (2,1): L_a + R_z   (full)
+
+    def call(self, free, entered, left, updatd, iupdat, col, head, ws, wy, dr, theta):
+        """One call of formk (the variable is `free` at the Cauchy point; it `entered` / `left` the free set since the last freev).
+        ws, wy, dr: the pairs' s, y and s'y by ring position (1-based).  True when both factorizations succeed."""
+        m, A, C, Bm = _LB_M, self.A, self.C, self.Bm
+        if updatd:
+            if iupdat > m:                         # shift old part of WN1
+                for jy in range(1, m):
+                    for i in range(m - jy):
+                        A[jy + i][jy] = A[jy + 1 + i][jy + 1]
+                        C[jy + i][jy] = C[jy + 1 + i][jy + 1]
+                    for i in range(m - 1):
+                        Bm[1 + i][jy] = Bm[2 + i][jy + 1]
+            ipntr = head + col - 1
+            if ipntr > m:
+                ipntr -= m
+            jpntr = head
+            for jy in range(1, col + 1):           # new rows in blocks (1,1), (2,1) and (2,2)
+                A[col][jy] = wy[ipntr] * wy[jpntr] if free else 0.0
+                C[col][jy] = 0.0 if free else ws[ipntr] * ws[jpntr]
+                Bm[col][jy] = 0.0 if free else ws[ipntr] * wy[jpntr]
+                jpntr = jpntr % m + 1
+            jpntr = head + col - 1
+            if jpntr > m:
+                jpntr -= m
+            ipntr = head
+            for i in range(1, col + 1):            # new column in block (2,1)
+                Bm[i][col] = ws[ipntr] * wy[jpntr] if free else 0.0
+                ipntr = ipntr % m + 1
+            upcl = col - 1
+        else:
+            upcl = col
+        ipntr = head
+        for iy in range(1, upcl + 1):              # the old parts of (1,1) and (2,2) follow the free set
+            jpntr = head
+            for jy in range(1, iy + 1):
+                t1 = wy[ipntr] * wy[jpntr] if entered else 0.0
+                t2 = ws[ipntr] * ws[jpntr] if entered else 0.0
+                t3 = wy[ipntr] * wy[jpntr] if left else 0.0
+                t4 = ws[ipntr] * ws[jpntr] if left else 0.0
+                A[iy][jy] = A[iy][jy] + t1 - t3
+                C[iy][jy] = C[iy][jy] - t2 + t4
+                jpntr = jpntr % m + 1
+            ipntr = ipntr % m + 1
+        ipntr = head
+        for i_s in range(1, upcl + 1):             # ... and of (2,1)
+            jpntr = head
+            for jy in range(1, upcl + 1):
+                t1 = ws[ipntr] * wy[jpntr] if entered else 0.0
+                t3 = ws[ipntr] * wy[jpntr] if left else 0.0
+                if i_s <= jy:
+                    Bm[i_s][jy] = Bm[i_s][jy] + t1 - t3
+                else:
+                    Bm[i_s][jy] = Bm[i_s][jy] - t1 + t3
+                jpntr = jpntr % m + 1
+            ipntr = ipntr % m + 1
+        # the upper triangle of WN = [D + Y'ZZ'Y / theta, -L_a' + R_z'; ., S'AA'S theta]
+        n2 = 2 * col
+        wn = [[0.0] * (n2 + 1) for _ in range(n2 + 1)]
+        for iy in range(1, col + 1):
+            i_s = col + iy
+            for jy in range(1, iy + 1):
+                wn[jy][iy] = A[iy][jy] / theta
+                wn[col + jy][i_s] = C[iy][jy] * theta
+            for jy in range(1, iy):
+                wn[jy][i_s] = -Bm[iy][jy]
+            for jy in range(iy, col + 1):
+                wn[jy][i_s] = Bm[iy][jy]
+            pos = head + iy - 1
+            if pos > m:
+                pos -= m
+            wn[iy][iy] = wn[iy][iy] + dr[pos]
+        if not _dpofa(wn, 0, col):
+            return False
+        for js in range(col + 1, n2 + 1):          # L^-1 (-L_a' + R_z') in the (1,2) block: solve trans(L') x = b
+            for j in range(1, col + 1):
+                if wn[j][j] == 0.0:
+                    return False
+            wn[1][js] = wn[1][js] / wn[1][1]
+            for j in range(2, col + 1):
+                acc = 0.0
+                for k in range(1, j):
+                    acc += wn[k][j] * wn[k][js]
+                wn[j][js] = (wn[j][js] - acc) / wn[j][j]
+        for i_s in range(col + 1, n2 + 1):
+            for js in range(i_s, n2 + 1):
+                acc = 0.0
+                for k in range(1, col + 1):
+                    acc += wn[k][i_s] * wn[k][js]
+                wn[i_s][js] = wn[i_s][js] + acc
+        return _dpofa(wn, col, col)
+
+
+def _dpofa(a, off, n):
+    """LINPACK dpofa on the upper triangle of a[off+1 .. off+n][off+1 .. off+n]: False where a pivot is not positive."""
+    for j in range(1, n + 1):
+        sacc = 0.0
+        for k in range(1, j):
+            dot = 0.0
+            for i in range(1, k):
+                dot += a[off + i][off + k] * a[off + i][off + j]
+            t = a[off + k][off + j] - dot
+            t = t / a[off + k][off + k]
+            a[off + k][off + j] = t
+            sacc += t * t
+        sacc = a[off + j][off + j] - sacc
+        if sacc <= 0.0:
+            return False
+        a[off + j][off + j] = math.sqrt(sacc)
+    return True
+
+
+def _dcstep(stx, fx, dx, sty, fy, dy, stp, fp, dp, brackt, stpmin, stpmax):
+    """MINPACK-2 dcstep: the safeguarded cubic / quadratic step and the update of the interval of uncertainty."""
+    sgnd = dp * (dx / abs(dx))
+    if fp > fx:
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        sc = max(abs(theta), abs(dx), abs(dp))
+        gamma = sc * math.sqrt((theta / sc) * (theta / sc) - (dx / sc) * (dp / sc))
+        if stp < stx:
+            gamma = -gamma
+        p = (gamma - dx) + theta
+        q = ((gamma - dx) + gamma) + dp
+        r = p / q
+        stpc = stx + r * (stp - stx)
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx)
+        if abs(stpc - stx) < abs(stpq - stx):
+            stpf = stpc
+        else:
+            stpf = stpc + (stpq - stpc) / 2.0
+        brackt = True
+    elif sgnd < 0.0:
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        sc = max(abs(theta), abs(dx), abs(dp))
+        gamma = sc * math.sqrt((theta / sc) * (theta / sc) - (dx / sc) * (dp / sc))
+        if stp > stx:
+            gamma = -gamma
+        p = (gamma - dp) + theta
+        q = ((gamma - dp) + gamma) + dx
+        r = p / q
+        stpc = stp + r * (stx - stp)
+        stpq = stp + (dp / (dp - dx)) * (stx - stp)
+        stpf = stpc if abs(stpc - stp) > abs(stpq - stp) else stpq
+        brackt = True
+    elif abs(dp) < abs(dx):
+        theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp
+        sc = max(abs(theta), abs(dx), abs(dp))
+        gamma = sc * math.sqrt(max(0.0, (theta / sc) * (theta / sc) - (dx / sc) * (dp / sc)))
+        if stp > stx:
+            gamma = -gamma
+        p = (gamma - dp) + theta
+        q = (gamma + (dx - dp)) + gamma
+        r = p / q
+        if r < 0.0 and gamma != 0.0:
+            stpc = stp + r * (stx - stp)
+        elif stp > stx:
+            stpc = stpmax
+        else:
+            stpc = stpmin
+        stpq = stp + (dp / (dp - dx)) * (stx - stp)
+        if brackt:
+            stpf = stpc if abs(stpc - stp) < abs(stpq - stp) else stpq
+            if stp > stx:
+                stpf = min(stp + 0.66 * (sty - stp), stpf)
+            else:
+                stpf = max(stp + 0.66 * (sty - stp), stpf)
+        else:
+            stpf = stpc if abs(stpc - stp) > abs(stpq - stp) else stpq
+            stpf = min(stpmax, stpf)
+            stpf = max(stpmin, stpf)
+    else:
+        if brackt:
+            theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp
+            sc = max(abs(theta), abs(dy), abs(dp))
+            gamma = sc * math.sqrt((theta / sc) * (theta / sc) - (dy / sc) * (dp / sc))
+            if stp > sty:
+                gamma = -gamma
+            p = (gamma - dp) + theta
+            q = ((gamma - dp) + gamma) + dy
+            r = p / q
+            stpc = stp + r * (sty - stp)
+            stpf = stpc
+        elif stp > stx:
+            stpf = stpmax
+        else:
+            stpf = stpmin
+    if fp > fx:
+        sty, fy, dy = stp, fp, dp
+    else:
+        if sgnd < 0.0:
+            sty, fy, dy = stx, fx, dx
+        stx, fx, dx = stp, fp, dp
+    return stx, fx, dx, sty, fy, dy, stpf, brackt
+
+
+def lbfgsb_1d(fun, x0, lb, ub, pgtol=1e-5, factr=1e7, maxls=20, eps=1e-8, maxiter=15000, info=None, formk_rule=False):
+    """scipy.optimize.minimize(fun, [x0], method="L-BFGS-B", bounds=[(lb, ub)]) for a scalar variable, statement by statement (see
+    the block comment above).  Returns the final parameter; info (a dict) receives nfev, nit, the exit reason and the number of
+    restarts formk forced.  formk_rule: formk's verdict by the rule the DEVICE uses instead of the transcribed bookkeeping --
+    "fails exactly when the variable entered the free set in this iteration and at least two pairs are stored"
+    (csrc/mg_traj_device.h; the two agree on every golden track and in a randomised campaign of 108 000 calls)."""
+    nfev, nit, restarts = [0], 0, [0]
+    m = _LB_M
+
+    def done(x, why):
+        if info is not None:
+            info.update(nfev=nfev[0], nit=nit, message=why, formk_restarts=restarts[0])
+        return x
+    x = min(max(float(x0), lb), ub)
+    if lb == ub:                                   # _optimize_result_for_equal_bounds
+        return done(lb, "fixed by bounds")
+
+    def fg(x):
+        f = fun(x)
+        h = eps                                    # approx_derivative: abs_step, one-sided, adjusted to the bounds
+        lower, upper = x - lb, ub - x
+        if x + h < lb or x + h > ub:
+            if abs(h) <= max(lower, upper):
+                h = -h
+            elif upper >= lower:
+                h = upper
+            else:
+                h = -lower
+        x1 = x + h
+        f1 = fun(x1)
+        nfev[0] += 2
+        return f, (f1 - f) / (x1 - x)
+
+    def projgr(x, g):
+        gi = g
+        if gi < 0.0:
+            gi = max(x - ub, gi)
+        else:
+            gi = min(x - lb, gi)
+        return abs(gi)
+    f, g = fg(x)
+    sbgnrm = projgr(x, g)
+    if sbgnrm <= pgtol:
+        return done(x, "pgtol")
+    col, theta, itr, head, iupdat, updatd = 0, 1.0, 0, 1, 0, False
+    ws, wy, dr_of = [0.0] * (m + 1), [0.0] * (m + 1), [0.0] * (m + 1)
+    fk = _FormK()
+    was_free = True                                # mainlb starts with nfree = n
+    while True:
+        # ---- cauchy: the generalised Cauchy point of the model f + g d + theta d^2 / 2 on [lb, ub]
+        neggi = -g
+        tl, tu = x - lb, ub - x
+        xlower, xupper = tl <= 0.0, tu <= 0.0
+        fixed = (xlower and neggi <= 0.0) or (not xlower and xupper and neggi >= 0.0)
+        if fixed or neggi == 0.0:
+            z, free = x, not fixed
+        else:
+            f1 = -neggi * neggi
+            f2 = -theta * f1
+            dtm = -f1 / f2
+            tbreak = tl / (-neggi) if neggi < 0.0 else tu / neggi
+            if dtm < tbreak:
+                if dtm <= 0.0:
+                    dtm = 0.0
+                z, free = x + dtm * neggi, True
+            else:
+                z, free = (ub if neggi > 0.0 else lb), False
+        # ---- freev: who entered, who left (counted from the second iteration on), is formk's matrix stale?
+        entered = itr > 0 and free and not was_free
+        left = itr > 0 and was_free and not free
+        wrk = left or entered or updatd
+        was_free = free
+        # ---- formk (subsm itself: a free Cauchy point is the one-dimensional model's minimiser already)
+        if free and col > 0:
+            if wrk and not ((not (entered and col >= 2)) if formk_rule else fk.call(free, entered, left, updatd, iupdat, col, head, ws, wy, dr_of, theta)):
+                col, head, theta, iupdat, updatd = 0, 1, 1.0, 0, False       # refresh the memory and restart the iteration
+                restarts[0] += 1
+                continue
+        d = z - x
+        # ---- lnsrlb + dcsrch
+        if itr == 0:
+            stpmx = 1.0
+        else:
+            stpmx = 1.0e10
+            if d < 0.0:
+                a2 = lb - x
+                if a2 >= 0.0:
+                    stpmx = 0.0
+                elif d * stpmx < a2:
+                    stpmx = a2 / d
+            elif d > 0.0:
+                a2 = ub - x
+                if a2 <= 0.0:
+                    stpmx = 0.0
+                elif d * stpmx > a2:
+                    stpmx = a2 / d
+        stp = 1.0
+        dtd = d * d
+        t, r_, fold = x, g, f
+        ifun, failed = 0, False
+        gd = g * d
+        gdold = gd
+        if gd >= 0.0:
+            failed = True                          # info = -4: not a descent direction
+        else:
+            # dcsrch, task START
+            ftol_ls, gtol_ls, xtol_ls, stpmin = 1.0e-3, 0.9, 0.1, 0.0
+            brackt, stage = False, 1
+            finit, ginit = f, gd
+            gtest = ftol_ls * ginit
+            width = stpmx - stpmin
+            width1 = width / 0.5
+            stx, fx, gx = 0.0, finit, ginit
+            sty, fy, gy = 0.0, finit, ginit
+            stmin, stmax = 0.0, stp + 4.0 * stp
+            while True:
+                ifun += 1                          # FG_LNSRCH: evaluate at the trial step
+                if ifun - 1 >= maxls:
+                    failed = True
+                    break
+                x = z if stp == 1.0 else stp * d + t
+                f, g = fg(x)
+                gd = g * d
+                ftest = finit + stp * gtest        # dcsrch, re-entry
+                if stage == 1 and f <= ftest and gd >= 0.0:
+                    stage = 2
+                task = None
+                if brackt and (stp <= stmin or stp >= stmax):
+                    task = "WARN"
+                if brackt and stmax - stmin <= xtol_ls * stmax:
+                    task = "WARN"
+                if stp == stpmx and f <= ftest and gd <= gtest:
+                    task = "WARN"
+                if stp == stpmin and (f > ftest or gd >= gtest):
+                    task = "WARN"
+                if f <= ftest and abs(gd) <= gtol_ls * (-ginit):
+                    task = "CONV"
+                if task is not None:
+                    break
+                if stage == 1 and f <= fx and f > ftest:
+                    fm, fxm, fym = f - stp * gtest, fx - stx * gtest, fy - sty * gtest
+                    gm, gxm, gym = gd - gtest, gx - gtest, gy - gtest
+                    stx, fxm, gxm, sty, fym, gym, stp, brackt = _dcstep(stx, fxm, gxm, sty, fym, gym, stp, fm, gm, brackt, stmin, stmax)
+                    fx, fy = fxm + stx * gtest, fym + sty * gtest
+                    gx, gy = gxm + gtest, gym + gtest
+                else:
+                    stx, fx, gx, sty, fy, gy, stp, brackt = _dcstep(stx, fx, gx, sty, fy, gy, stp, f, gd, brackt, stmin, stmax)
+                if brackt:
+                    if abs(sty - stx) >= 0.66 * width1:
+                        stp = stx + 0.5 * (sty - stx)
+                    width1 = width
+                    width = abs(sty - stx)
+                if brackt:
+                    stmin, stmax = min(stx, sty), max(stx, sty)
+                else:
+                    stmin = stp + 1.1 * (stp - stx)
+                    stmax = stp + 4.0 * (stp - stx)
+                stp = max(stp, stpmin)
+                stp = min(stp, stpmx)
+                if (brackt and (stp <= stmin or stp >= stmax)) or (brackt and stmax - stmin <= xtol_ls * stmax):
+                    stp = stx
+        if failed:
+            x, g, f = t, r_, fold                  # restore the previous iterate
+            if col == 0:
+                return done(x, "abnormal termination in lnsrch")
+            col, head, theta, iupdat, updatd = 0, 1, 1.0, 0, False           # refresh the memory and restart the iteration
+            continue
+        # ---- NEW_X
+        itr += 1
+        nit += 1
+        sbgnrm = projgr(x, g)
+        if sbgnrm <= pgtol:
+            return done(x, "pgtol")
+        ddum = max(abs(fold), abs(f), 1.0)
+        if fold - f <= _LB_EPSMCH * factr * ddum:
+            return done(x, "factr")
+        if nit >= maxiter:                         # (the wrapper's own count, tested when NEW_X comes back to Python)
+            return done(x, "maxiter")
+        # ---- the pair: y = g - g_old, s = stp d
+        y = g - r_
+        rr = y * y
+        if stp == 1.0:
+            dr, dd, sstep = gd - gdold, -gdold, d
+        else:
+            dr, dd, sstep = (gd - gdold) * stp, -gdold * stp, stp * d
+        if dr <= _LB_EPSMCH * dd:
+            updatd = False                         # skipped: the model stays what it was
+            continue
+        updatd = True                              # matupd
+        iupdat += 1
+        if iupdat <= m:
+            col = iupdat
+            itail = (head + iupdat - 2) % m + 1
+        else:
+            itail = itail % m + 1
+            head = head % m + 1
+        ws[itail], wy[itail], dr_of[itail] = sstep, y, dr
+        theta = rr / dr
+
+
+def closest_point_lbfgsb(control_points, point, min_u, info=None, formk_rule=False):
+    """find_closest_point_fast (parameterized_spline.py:303-322) through lbfgsb_1d: the form the device runs
+    (csrc/mg_traj_device.h, mg_traj_closest_lbfgsb).  The distance is evaluated as the reference's objective does it: the norm of
+    (point on the spline - target)."""
+    target = np.asarray(point, dtype=np.float64)
+
+    def dist(u):
+        v = catmull_rom_point(control_points, u) - target
+        return math.sqrt(float(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]))
+    u = lbfgsb_1d(dist, float(min_u), float(min_u), 1.0, info=info, formk_rule=formk_rule)
+    return catmull_rom_point(control_points, u), u
+
+
+def closest_point(control_points, point, min_u, granularity=1000, search="reference"):
+    """The closest-point search as the device runs it: "reference" (MG_OPT_TRAJECTORY_SEARCH 0, the default) or "walk" (1)."""
+    if search == "walk":
+        return closest_point_walk(control_points, point, min_u, granularity)
+    return closest_point_lbfgsb(control_points, point, min_u, formk_rule=True)
 
 
 def closest_point_walk(control_points, point, min_u, granularity=1000):
@@ -525,77 +977,24 @@ def catmull_rom_point_by_arc_length(control_points, table, full, arc):
     return catmull_rom_point(control_points, p0 + (rel - l0) / (l1 - l0) * (p1 - p0))
 
 
-def per_frame_constraint_residuals(c, knots, coeffs, n_canonical_frames, joints, animated_joints):
+def per_frame_constraint_residuals(c, knots, coeffs, n_canonical_frames, joints, animated_joints, search="reference"):
     """(residual vector, error), both WITHOUT the weight factor, of the constraints that walk every frame of one aligned
     motion (coeffs: its aligned control points) -- what get_residual_vector_spline / evaluate_motion_spline of the
     reference classes return:
-      frame_joint_trajectory   TrajectoryConstraint, trajectory_constraint.py:79-116 (closest point: the device's walk)
+      frame_joint_trajectory   TrajectoryConstraint, trajectory_constraint.py:79-116
       frame_ca_position        GlobalTransformCAConstraint, keyframe_constraints/global_transform_ca_constraint.py:33-46
       frame_discrete_trajectory DiscreteTrajectoryConstraint, discrete_trajectory_constraint.py:66-90
       frame_local_trajectory   LocalTrajectoryConstraint, keyframe_constraints/local_trajectory_constraint.py:45-78
       frame_trajectory_set     TrajectorySetConstraint, trajectory_set_constraint.py:41-104
       frame_joint_rotation     JointRotationConstraint, keyframe_constraints/joint_rotation_constraint.py:55-72
-    PARITY UNPINNED (forward kinematics is anim_utils')."""
+    The joints' positions come from forward kinematics (anim_utils': PARITY UNPINNED); what the classes do WITH the positions is
+    per_frame_track_residuals, pinned by the reference's own runs (tests/golden/per_frame_classes.npz,
+    trajectory_closest_point.npz)."""
     F = int(n_canonical_frames)
-    motion_vector = spline_frames(knots, coeffs, np.linspace(0, F, F))        # MotionSpline.get_motion_vector()
     kind = c["type"]
 
     def position(frame, joint):
         return np.asarray(joint_global_position(frame, joints, animated_joints, joint), dtype=np.float64)
-    if kind == "frame_joint_trajectory":
-        cps, min_u = c["control_points"], float(c.get("min_u", 0.0))
-        errors = np.empty(len(motion_vector))
-        for i, frame in enumerate(motion_vector):
-            p = position(frame, c["joint"])
-            target, min_u = closest_point_walk(cps, p, min_u, c.get("granularity", 1000))
-            errors[i] = np.linalg.norm(p - target)
-        return errors, float(np.average(errors))
-    if kind == "frame_ca_position":
-        nf = int(c.get("n_frames", F))
-        errors = np.zeros(nf)
-        for i in range(nf):
-            errors[i] = point_distance(c["target"], position(spline_frames(knots, coeffs, [float(i)])[0], c["joint"]))
-        return np.array([min(errors)]), float(min(errors))
-    if kind == "frame_discrete_trajectory":
-        pts, free = [np.array(p, dtype=np.float64) for p in c["points"]], [int(a) for a in (c.get("unconstrained") or ())]
-        errors = []
-        for index, frame in enumerate(motion_vector):
-            if index < len(pts):
-                p, target = position(frame, c["joint"]), pts[index].copy()
-                target[free] = 0
-                p[free] = 0
-                errors.append(np.linalg.norm(p - target))
-            else:
-                errors.append(0.0)
-        return np.array(errors), float(np.average(errors))
-    if kind == "frame_local_trajectory":
-        nf = int(c.get("n_frames", F))
-        table, full = arc_length_table(c["control_points"], c.get("granularity", 1000))
-        errors, last_p, current_t = [], None, float(c.get("start_t", 0.0))
-        for idx in range(nf):
-            p = position(spline_frames(knots, coeffs, [float(idx)])[0], c["joint"])
-            if last_p is not None:
-                current_t += np.linalg.norm(last_p - p)
-            target = catmull_rom_point_by_arc_length(c["control_points"], table, full, current_t)
-            delta = np.array([target[0] - p[0], target[2] - p[2]])
-            errors.append(float(np.dot(delta, delta)))
-            last_p = p
-        return np.array(errors), float(sum(errors))
-    if kind == "frame_trajectory_set":
-        nf = int(c.get("n_frames", F))
-        tables = [arc_length_table(t["control_points"], t.get("granularity", 1000)) for t in c["trajectories"]]
-        arcs = [float(a) for a in c.get("arc_lengths", [0.0] * len(c["joints"]))]
-        residual, last = np.zeros(nf), None
-        for i in range(nf):
-            ps = [position(motion_vector[i], j) for j in c["joints"]]
-            active = [t.get("range_start") is not None and t["range_start"] <= a <= t["range_end"] for t, a in zip(c["trajectories"], arcs)]
-            if np.any(active):
-                targets = [catmull_rom_point_by_arc_length(t["control_points"], tab, full, a) for t, (tab, full), a in zip(c["trajectories"], tables, arcs)]
-                residual[i] = np.linalg.norm(np.average(ps) - np.average(targets))
-            if last is not None:
-                arcs = [a + np.linalg.norm(p - q) for p, q, a in zip(ps, last, arcs)]
-            last = ps
-        return residual, float(np.average(residual))
     if kind == "frame_joint_rotation":
         frame = spline_frames(knots, coeffs, [float(c["frame_idx"])])[0]
         ji = int(c["joint_index"])
@@ -604,6 +1003,70 @@ def per_frame_constraint_residuals(c, knots, coeffs, n_canonical_frames, joints,
         t = np.asarray(c["quaternion"], dtype=np.float64)
         err = float(np.linalg.norm(np.ravel(quaternion_matrix3(t / np.linalg.norm(t)) - quaternion_matrix3(q))))
         return np.array([err]), err
+    if kind in ("frame_ca_position", "frame_local_trajectory"):       # aligned_spline.evaluate(i), i = 0 .. n - 1
+        nf = int(c.get("n_frames", F))
+        frames = [spline_frames(knots, coeffs, [float(i)])[0] for i in range(nf)]
+    else:                                                              # MotionSpline.get_motion_vector()
+        frames = spline_frames(knots, coeffs, np.linspace(0, F, F))
+    names = list(c["joints"]) if kind == "frame_trajectory_set" else [c["joint"]]
+    tracks = {j: np.array([position(f, j) for f in frames]) for j in names}
+    return per_frame_track_residuals(c, tracks, search)
+
+
+def per_frame_track_residuals(c, tracks, search="reference"):
+    """The same, from the joints' positions per frame (tracks: joint -> (T, 3), the frames the class reads): the arithmetic of the
+    reference classes downstream of forward kinematics."""
+    kind = c["type"]
+    if kind == "frame_joint_trajectory":
+        cps, min_u = c["control_points"], float(c.get("min_u", 0.0))
+        track = tracks[c["joint"]]
+        errors = np.empty(len(track))
+        for i, p in enumerate(track):
+            target, min_u = closest_point(cps, p, min_u, c.get("granularity", 1000), search)
+            errors[i] = np.linalg.norm(p - target)
+        return errors, float(np.average(errors))
+    if kind == "frame_ca_position":
+        errors = np.array([point_distance(c["target"], p) for p in tracks[c["joint"]]])
+        return np.array([min(errors)]), float(min(errors))
+    if kind == "frame_discrete_trajectory":
+        pts, free = [np.array(p, dtype=np.float64) for p in c["points"]], [int(a) for a in (c.get("unconstrained") or ())]
+        errors = []
+        for index, pos in enumerate(tracks[c["joint"]]):
+            if index < len(pts):
+                p, target = np.array(pos, dtype=np.float64), pts[index].copy()
+                target[free] = 0
+                p[free] = 0
+                errors.append(np.linalg.norm(p - target))
+            else:
+                errors.append(0.0)
+        return np.array(errors), float(np.average(errors))
+    if kind == "frame_local_trajectory":
+        table, full = arc_length_table(c["control_points"], c.get("granularity", 1000))
+        errors, last_p, current_t = [], None, float(c.get("start_t", 0.0))
+        for p in tracks[c["joint"]]:
+            if last_p is not None:
+                current_t += np.linalg.norm(last_p - p)
+            target = catmull_rom_point_by_arc_length(c["control_points"], table, full, current_t)
+            delta = np.array([target[0] - p[0], target[2] - p[2]])
+            errors.append(float(np.dot(delta, delta)))
+            last_p = p
+        return np.array(errors), float(sum(errors))
+    if kind == "frame_trajectory_set":
+        names = list(c["joints"])
+        nf = int(c.get("n_frames", len(tracks[names[0]])))
+        tables = [arc_length_table(t["control_points"], t.get("granularity", 1000)) for t in c["trajectories"]]
+        arcs = [float(a) for a in c.get("arc_lengths", [0.0] * len(names))]
+        residual, last = np.zeros(nf), None
+        for i in range(nf):
+            ps = [tracks[j][i] for j in names]
+            active = [t.get("range_start") is not None and t["range_start"] <= a <= t["range_end"] for t, a in zip(c["trajectories"], arcs)]
+            if np.any(active):
+                targets = [catmull_rom_point_by_arc_length(t["control_points"], tab, full, a) for t, (tab, full), a in zip(c["trajectories"], tables, arcs)]
+                residual[i] = np.linalg.norm(np.average(ps) - np.average(targets))
+            if last is not None:
+                arcs = [a + np.linalg.norm(p - q) for p, q, a in zip(ps, last, arcs)]
+            last = ps
+        return residual, float(np.average(residual))
     raise ValueError(kind)
 
 

@@ -56,10 +56,12 @@ def _check(mp, op, S, clist, sk, joints, animated, alignment, **oracle_alignment
     for c, b, br in zip(clist, blocks, blocks_ref):
         assert b.shape == br.shape, (c["type"], b.shape, br.shape)
         scale = max(1.0, np.abs(br).max())
-        # float64 end to end; the trajectory search carries the device walk's 1e-9 (tests/test_gpu_adaptors.py)
-        tol = 1e-8 if c["type"] == "frame_joint_trajectory" else 1e-9
+        # float64 end to end; the trajectory search carries its stated tolerance (tests/test_gpu_closest_point.py: the forward
+        # difference's noise)
+        tol = 2e-6 if c["type"] == "frame_joint_trajectory" else 1e-9
         assert np.abs(b - br).max() <= tol * scale, (c["type"], np.abs(b - br).max(), scale)
-    np.testing.assert_allclose(total, total_ref, rtol=1e-8, atol=1e-8)
+    loose = any(c["type"] == "frame_joint_trajectory" for c in clist)
+    np.testing.assert_allclose(total, total_ref, rtol=2e-6 if loose else 1e-8, atol=1e-8)
     return total
 
 
@@ -93,7 +95,7 @@ def test_per_frame_constraints_on_aligned_candidates():
         t, _ = op.frame_constraint_errors(S[b:b + 1], clist, joints, animated, start_pose={"position": list(sp["position"]), "orientation": list(sp["orientation"])})
         total_ref.append(t[0])
     total, _ = frame_constraints_errors(mp._prim, S, clist, sk, alignment_from_start_pose(sp))
-    np.testing.assert_allclose(total, total_ref, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(total, total_ref, rtol=2e-6, atol=1e-8)
 
 
 def test_fused_track_scorer_is_the_chain_bit_for_bit(monkeypatch):
@@ -152,10 +154,14 @@ def test_closest_point_walk_by_eight_lanes_is_the_one_lane_walk_bit_for_bit():
 
     def both(fn):
         out = []
-        for lanes in (0, 1, 4):       # (0: eight lanes at this batch size; 1: the streaming one-lane kernel; 4: four lanes)
-            ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, lanes)
-            out.append(fn())
-        ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, 0)
+        ctx.set_option(_capi.MG_OPT_TRAJECTORY_SEARCH, 1)       # (the lanes are the monotone walk's: the reference's search is one chain)
+        try:
+            for lanes in (0, 1, 4):       # (0: eight lanes at this batch size; 1: the streaming one-lane kernel; 4: four lanes)
+                ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, lanes)
+                out.append(fn())
+        finally:
+            ctx.set_option(_capi.MG_OPT_TRAJECTORY_LANES, 0)
+            ctx.set_option(_capi.MG_OPT_TRAJECTORY_SEARCH, 0)
         assert np.array_equal(out[2][0].view(np.uint64), out[0][0].view(np.uint64)) and np.array_equal(out[2][1].view(np.uint64), out[0][1].view(np.uint64))
         return out[:2]
     moved = 0
@@ -180,6 +186,15 @@ def test_trajectory_scorers_side_by_side_are_the_single_launches():
     prims = synthetic.make_graph_primitives(5)
     pset = HipPrimitiveSet(prims, separate_streams=False)
     ctx = pset.ctx
+    for search in (0, 1):
+        ctx.set_option(_capi.MG_OPT_TRAJECTORY_SEARCH, search)
+        try:
+            _side_by_side(pset, prims, ctx)
+        finally:
+            ctx.set_option(_capi.MG_OPT_TRAJECTORY_SEARCH, 0)
+
+
+def _side_by_side(pset, prims, ctx):
     rng = np.random.default_rng(12)
     n = 333
     ps, trs, xs, es, lds_, min_us, ws, als, ref = [], [], [], [], [], [], [], [], []
@@ -227,12 +242,12 @@ def test_per_frame_constraints_through_the_reference_entry_points():
     for path in paths:
         min_u, walk = 0.0, []
         for p in path:
-            pt, min_u = orc.closest_point_walk(root_traj["control_points"], p, min_u)
+            pt, min_u = orc.closest_point(root_traj["control_points"], p, min_u)
             walk.append(np.linalg.norm(p - pt))
         ref_traj.append(np.mean(walk))
     want = ref_key + np.array(ref_traj) + ref_frames
     got = errors_of_samples(mp._prim, clist, sk, None, S)
-    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-8)      # (the trajectory searches' stated tolerance)
 
     class Cons(object):
         constraints = clist
@@ -240,11 +255,11 @@ def test_per_frame_constraints_through_the_reference_entry_points():
         is_local = True
     best, err = evaluate_samples_using_constraints(S, mp, Cons())
     np.testing.assert_array_equal(best, S[int(np.argmin(want))])
-    assert abs(err - want.min()) <= 1e-8 * max(1.0, want.min())
-    np.testing.assert_allclose(HipSampleFilter.score_samples(mp, S, Cons(), skeleton=sk), want, rtol=1e-8, atol=1e-8)
+    assert abs(err - want.min()) <= 2e-6 * max(1.0, want.min())
+    np.testing.assert_allclose(HipSampleFilter.score_samples(mp, S, Cons(), skeleton=sk), want, rtol=2e-6, atol=1e-8)
     # the optimiser's objectives: the residual vector carries the per-frame blocks behind the fused ones
     from morphablegraphs_amd import objective_functions as of
-    np.testing.assert_allclose(of.obj_spatial_error_sum(S[2], (mp, Cons(), None, 1.0, 1.0)), want[2], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(of.obj_spatial_error_sum(S[2], (mp, Cons(), None, 1.0, 1.0)), want[2], rtol=2e-6, atol=1e-8)
     r = of.obj_spatial_error_residual_vector(S[2], (mp, Cons(), None, 1.0, 1.0, 2.0))
     fblocks = frame_constraints_errors(mp._prim, S[2:3], frames, sk, None)[1]
     n_frame_entries = sum(b.shape[1] for b in fblocks)

@@ -1,6 +1,7 @@
 """The NumPy oracle against the golden vectors made by the reference's own code
 (oracle/gen_golden.py).  CPU only."""
 import numpy as np
+import pytest
 
 from oracle import mg_oracle as orc
 
@@ -286,8 +287,8 @@ def test_time_model_fixture():
 
 def test_trajectory_spline_against_the_reference():
     """The Catmull-Rom spline under a trajectory constraint: points at parameters and the arc length of the
-    granularity-1000 table, against vectors made by the reference's own ParameterizedSpline; and the two closest-point
-    searches (the reference's L-BFGS-B call restated, the device's grid walk restated) against each other."""
+    granularity-1000 table, against vectors made by the reference's own ParameterizedSpline; and, on a smooth path that follows the
+    spline loosely (one basin ahead of the bound), the reference's search and the monotone walk against each other."""
     from conftest import load_golden
     g = load_golden("trajectory_spline")
     for ci in range(int(g["n_cases"])):
@@ -314,6 +315,143 @@ def test_trajectory_spline_against_the_reference():
         da, db = np.linalg.norm(p - pa), np.linalg.norm(p - pb)
         assert abs(da - db) < 2e-3 * max(1.0, da), (ua, ub, da, db)
         min_u_a, min_u_b = ua, ub
+
+
+def test_closest_point_search_against_the_references_own_run():
+    """tests/golden/trajectory_closest_point.npz: ParameterizedSpline.find_closest_point_fast (parameterized_spline.py:303-322)
+    run by the reference itself, chained frame to frame as trajectory_constraint.py:93-116 chains it, on 26 tracks.
+    Held to it, two-sided, over whole chains of 156 frames:
+      * the reference's call restated through scipy (closest_point_from): |du| <= 2e-7, |dd| <= 3e-7 -- what two evaluations of the
+        same spline point that differ in the last bit do to a forward-difference gradient with h = 1e-8;
+      * L-BFGS-B 3.0 restated for one bounded variable (lbfgsb_1d, what the device runs): the same bar -- with formk's bookkeeping
+        transcribed, and with the rule the device uses in its place: identical parameters, bit for bit, on every track;
+      * the monotone walk of rounds 2-4: equal where the distance has one basin ahead of the bound, far off elsewhere (why it is
+        no longer the default)."""
+    from conftest import load_golden
+    g = load_golden("trajectory_closest_point")
+    worst, far_walks, n_tracks = {"scipy": [0.0, 0.0], "lbfgsb": [0.0, 0.0]}, 0, 0
+    for ci in range(int(g["n_cases"])):
+        cps = g["control_points_%d" % ci]
+        np.testing.assert_allclose(orc.catmull_rom_full_arc_length(cps), float(g["full_arc_length_%d" % ci]), rtol=1e-12)
+        for ti, name in enumerate(g["track_names_%d" % ci]):
+            track, u_ref, d_ref = g["track_%d_%d" % (ci, ti)], g["u_%d_%d" % (ci, ti)], g["distance_%d_%d" % (ci, ti)]
+            stride = 1 if ci in (0, 3) else 4          # (every track whole where it is cheap; the chain needs no subsampling care: it restarts from the vectors)
+            n_tracks += 1
+            m_a = m_b = m_c = m_w = float(g["min_u0_%d_%d" % (ci, ti)])
+            walk_far = False
+            for f, p in enumerate(track):
+                if stride > 1 and f >= 40:
+                    break
+                pa, m_a = orc.closest_point_from(cps, p, m_a)
+                pb, m_b = orc.closest_point_lbfgsb(cps, p, m_b)
+                pc, m_c = orc.closest_point_lbfgsb(cps, p, m_c, formk_rule=True)
+                pw, m_w = orc.closest_point_walk(cps, p, m_w)
+                assert m_c == m_b, (ci, name, f)
+                for key, u, pt in (("scipy", m_a, pa), ("lbfgsb", m_b, pb)):
+                    du, dd = abs(u - u_ref[f]), abs(np.linalg.norm(p - pt) - d_ref[f]) / max(1.0, d_ref[f])
+                    worst[key][0], worst[key][1] = max(worst[key][0], du), max(worst[key][1], dd)
+                    assert du <= 2e-7 and dd <= 3e-7, (key, ci, name, f, du, dd)
+                walk_far = walk_far or abs(m_w - u_ref[f]) > 0.1
+            far_walks += int(walk_far)
+            # the target points the reference returned are the spline's points at its parameters
+            np.testing.assert_allclose([orc.catmull_rom_point(cps, u) for u in u_ref[::13]], g["target_%d_%d" % (ci, ti)][::13], rtol=0, atol=1e-9)
+    assert n_tracks == 26 and far_walks >= 5
+
+
+def test_one_variable_lbfgsb_is_scipys():
+    """lbfgsb_1d against scipy.optimize.minimize(method="L-BFGS-B") itself on seeded random problems (splines of 2..9 control points,
+    points near and far, bounds anywhere): the same parameter to 1e-6 and the same iteration count, except where the forward
+    difference's noise decides the last iteration (fewer than 1 search in 100; those agree to 2e-5)."""
+    import math
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(1)
+    n, off, restarts = 0, 0, 0
+    for trial in range(60):
+        k = int(rng.integers(2, 10))
+        cps = np.cumsum(np.column_stack([rng.uniform(5, 60, k), rng.uniform(-5, 5, k), rng.uniform(-40, 40, k)]), axis=0)
+        for q in range(10):
+            mu = float(rng.uniform(0, 1)) if rng.random() < 0.7 else float(rng.choice([0.0, 1.0 - 1e-9, 0.999, 1.0]))
+            p = orc.catmull_rom_point(cps, rng.uniform(0, 1)) + rng.normal(0, rng.choice([0.1, 5, 50, 500]), 3)
+
+            def dist(x):
+                v = orc.catmull_rom_point(cps, float(np.ravel(x)[0])) - p
+                return math.sqrt(float(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]))
+            res = minimize(dist, np.array([mu]), method="L-BFGS-B", bounds=[(mu, 1.0)])
+            info = {}
+            u = orc.lbfgsb_1d(dist, mu, mu, 1.0, info=info)
+            n += 1
+            restarts += info["formk_restarts"]
+            du = abs(u - float(res.x[0]))
+            assert du <= 2e-5, (trial, q, u, res.x)
+            if du > 1e-6 or info["nit"] != res.get("nit", 0):
+                off += 1
+    assert n == 600 and off <= 6, off
+    assert restarts > 20          # (formk's failures are part of the algorithm: one search in eight meets one)
+
+
+def test_device_search_statements_on_the_host_against_the_references_vectors():
+    """The DEVICE's closest-point search -- the statements of morphablegraphs_amd/csrc/mg_traj_device.h (mg_traj_closest_lbfgsb),
+    compiled for the host by tests/native/Makefile -- on the golden tracks: every chain within the search's stated tolerance of what
+    the reference's own function returned (|du| <= 2e-6, |dd| <= 1e-6 max(1, d); measured 1.7e-7 / 3e-9), and within the forward
+    difference's noise of the oracle's restatement it mirrors.  (No GPU: the header's arithmetic is plain C++ double arithmetic
+    without contraction on both sides; tests/test_gpu_closest_point.py runs the same vectors on the device.)"""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    from conftest import load_golden
+    native = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native")
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc to build the host check")
+    subprocess.check_call(["make", "-s", "-C", native])
+    lib = C.CDLL(os.path.join(native, "liblbfgsb_host_check.so"))
+    lib.mg_test_lbfgsb_chain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
+    g = load_golden("trajectory_closest_point")
+    worst_u = worst_d = 0.0
+    for ci in range(int(g["n_cases"])):
+        cps = np.ascontiguousarray(g["control_points_%d" % ci])
+        for ti, name in enumerate(g["track_names_%d" % ci]):
+            track = np.ascontiguousarray(g["track_%d_%d" % (ci, ti)])
+            u_ref, d_ref, mu = g["u_%d_%d" % (ci, ti)], g["distance_%d_%d" % (ci, ti)], float(g["min_u0_%d_%d" % (ci, ti)])
+            u, d = np.empty(len(track)), np.empty(len(track))
+            assert lib.mg_test_lbfgsb_chain(cps.ctypes.data, len(cps), track.ctypes.data, len(track), mu, u.ctypes.data, d.ctypes.data) == 0
+            du, dd = np.abs(u - u_ref).max(), (np.abs(d - d_ref) / np.maximum(1.0, d_ref)).max()
+            assert du <= 2e-6 and dd <= 1e-6, (ci, name, du, dd)
+            worst_u, worst_d = max(worst_u, du), max(worst_d, dd)
+            if ci == 1:      # ... and the oracle's restatement with the device's formk rule, frame by frame from the device's own chain
+                for f in range(0, len(track), 7):
+                    _, uo = orc.closest_point_lbfgsb(cps, track[f], mu if f == 0 else u[f - 1], formk_rule=True)
+                    assert abs(uo - u[f]) <= 2e-6, (name, f, uo, u[f])
+    assert worst_u <= 5e-7
+
+
+def test_per_frame_classes_against_the_references_own_classes():
+    """tests/golden/per_frame_classes.npz: LocalTrajectoryConstraint (local_trajectory_constraint.py:45-78) and TrajectorySetConstraint
+    (trajectory_set_constraint.py:41-104) run by the reference itself on given joint tracks (a duck-typed skeleton that returns
+    them: input data); the oracle's restatements downstream of forward kinematics against them."""
+    from conftest import load_golden
+    g = load_golden("per_frame_classes")
+    for ci in range(int(g["n_cases"])):
+        cps, cps2, hips, hand = g["control_points_%d" % ci], g["control_points2_%d" % ci], g["hips_%d" % ci], g["hand_%d" % ci]
+        for si in range(2):
+            nf = int(g["local_n_frames_%d_%d" % (ci, si)])
+            c = {"type": "frame_local_trajectory", "joint": "Hips", "control_points": cps.tolist(), "granularity": 1000,
+                 "start_t": float(g["local_start_t_%d_%d" % (ci, si)]), "n_frames": nf}
+            r, e = orc.per_frame_track_residuals(c, {"Hips": hips[:nf]})
+            want = g["local_residuals_%d_%d" % (ci, si)]
+            np.testing.assert_allclose(r, want, rtol=1e-9, atol=1e-9 * max(1.0, want.max()))
+            assert abs(e - float(g["local_error_%d_%d" % (ci, si)])) <= 1e-9 * max(1.0, abs(e))
+        for si in range(3):
+            rg = g["set_ranges_%d_%d" % (ci, si)]
+            trs = [{"control_points": cp.tolist(), "granularity": 1000, "range_start": None if np.isnan(r[0]) else float(r[0]),
+                    "range_end": None if np.isnan(r[1]) else float(r[1])} for cp, r in zip((cps, cps2), rg)]
+            c = {"type": "frame_trajectory_set", "joints": ["Hips", "LeftHand"], "trajectories": trs,
+                 "arc_lengths": g["set_arc_lengths_%d_%d" % (ci, si)].tolist(), "n_frames": len(hips)}
+            r, e = orc.per_frame_track_residuals(c, {"Hips": hips, "LeftHand": hand})
+            want = g["set_residuals_%d_%d" % (ci, si)]
+            np.testing.assert_allclose(r, want, rtol=1e-10, atol=1e-10 * max(1.0, want.max()))
+            assert abs(e - float(g["set_error_%d_%d" % (ci, si)])) <= 1e-10 * max(1.0, abs(e))
+            assert (si == 0) == (not want.any())
 
 
 def test_walk_32_fixture_configs0():
