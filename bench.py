@@ -13,8 +13,8 @@ and every step ends with the RCCL all-gather of the scores.
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (child
 processes, before anything touches a GPU) and forwards rank 0's JSON line.  One JSON line on rank 0.
 Everything on the device goes through libmg_hip.so (ctypes C-ABI): buffers, the stream, the kernels
-and -- by default -- the collective (mg_dist_*: RCCL loaded by the library, the unique id handed over
-through a file); `--collective torch` keeps torch.distributed's communicator for comparison.
+and the collective (mg_dist_*: RCCL loaded by the library, the unique id handed over through a file).  No tensor
+framework anywhere in this file: under `python -m torch.distributed.run` only the environment variables it sets are read.
 `--config graph` (BASELINE configs[2]: 16 primitives x 4096 candidates per planner step) and
 `--config optimizer` (configs[4] per iteration on one GPU: 131072 candidates, score only) are the
 other two single-GPU workloads, each with its own roofline.
@@ -50,7 +50,7 @@ def pmc_traffic_bytes(kernel_substr):
                 summ = json.load(f)
             for name, c in summ.get("pmc", {}).items():
                 if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, os.path.join("profiles", os.path.basename(path))
         except (OSError, ValueError):
             pass
     return None
@@ -162,42 +162,24 @@ def run_walk(args, rank, local_rank, world):
     rdv = FileRendezvous(rank, world) if world > 1 else None
     B = int(args.batch)
     per_cand, consts, bytes_launch = algorithmic_bytes(B)
-    use_torch = world > 1 and args.collective == "torch"
-    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")   # "gloo": the torch collective on CPU tensors (rehearsal)
     if dry:
         # no GPU in this process: the launcher, the rendezvous, the timing protocol and the JSON contract are
         # exercised with a stand-in step; `value` means nothing and the line says so
-        if use_torch:
-            import torch
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo")
         scores = np.full((B,), float(rank), dtype=np.float32)
 
         def step():
             time.sleep(2e-4)
 
         def gather():
-            if use_torch:
-                out = torch.empty((world * B,), dtype=torch.float32)
-                dist.all_gather_into_tensor(out, torch.from_numpy(scores))
-                return out.numpy()
             return np.concatenate([np.frombuffer(b, dtype=np.float32) for b in rdv.all_gather(scores.tobytes())])
 
         def barrier():
             if world > 1:
-                if use_torch:
-                    dist.barrier()
-                else:
-                    rdv.all_gather(b"b")
+                rdv.all_gather(b"b")
 
         def max_over_ranks(x):
             if world == 1:
                 return x
-            if use_torch:
-                t = torch.tensor([x], dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return float(t.item())
             return max(float(np.frombuffer(b, dtype=np.float64)[0]) for b in rdv.all_gather(np.array([x]).tobytes()))
         for _ in range(args.warmup):
             step()
@@ -210,15 +192,13 @@ def run_walk(args, rank, local_rank, world):
         elapsed = max_over_ranks(time.perf_counter() - t0)
         if world > 1:
             assert gathered.shape == (world * B,) and all(gathered[r * B] == r for r in range(world))
-        if use_torch:
-            dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": world * B * args.steps / elapsed, "unit": "samples/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "dry_run": True,
                               "config": {"workload": "DRY RUN (no GPU): launcher, rendezvous and timing protocol only", "candidates_per_gpu": B,
-                                         "global_candidates": world * B, "collective": "file rendezvous" if not use_torch else "torch.distributed gloo"}}))
+                                         "global_candidates": world * B, "collective": "file rendezvous"}}))
         return 0
 
     ensure_built()
@@ -226,77 +206,48 @@ def run_walk(args, rank, local_rank, world):
     from morphablegraphs_amd.distributed import first_min_argmin
     from morphablegraphs_amd.gaussian_mixture import sample_like_sklearn
     data = synthetic.make_walk_primitive(seed=0)
-    torch = dist = None
-    if use_torch:
-        import torch
-        import torch.distributed as dist
-        n_dev = torch.cuda.device_count()
     dev_index = local_rank   # one rank per GPU of the node
-    if os.environ.get("MG_BENCH_OVERSUBSCRIBE") and not use_torch:   # rehearsal on a box with fewer GPUs than ranks: ranks share devices
-        import torch as _t
-        dev_index = local_rank % max(1, _t.cuda.device_count())
-    collective_note = None
+    if os.environ.get("MG_BENCH_OVERSUBSCRIBE"):   # rehearsal on a box with fewer GPUs than ranks: the ranks share that many devices
+        dev_index = local_rank % max(1, int(os.environ["MG_BENCH_OVERSUBSCRIBE"]))
     rccl_info = None
-    if not use_torch:
+    try:
+        ctx = _capi.Context(dev_index)
+    except _capi.MGError as e:
+        raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback (%s)" % e)
+    if world > 1:
+        # The library's own RCCL communicator (librccl loaded by libmg_hip, the unique id handed over through the file
+        # rendezvous).  Preflight first (what can fail on one rank alone), then the collective set-up; the ranks tell each other
+        # how it went.  If it cannot be set up on ANY rank the run ends with the reason on every rank.
+        uid, err = b"", b""
         try:
-            ctx = _capi.Context(dev_index)
-        except _capi.MGError as e:
-            raise SystemExit("bench.py needs an MI355X per rank; there is no CPU fallback (%s)" % e)
-        if world > 1:
-            # The library's own RCCL communicator (librccl loaded by libmg_hip, the unique id handed over through the file
-            # rendezvous).  Preflight first (what can fail on one rank alone), then the collective set-up; the ranks tell each other
-            # how it went.  If it cannot be set up on ANY rank the run ends with the reason -- unless --collective-fallback torch
-            # asks for the tensor framework's communicator instead (then every rank switches, and the line says so).
-            uid, err = b"", b""
+            ctx.dist_preflight()
+            if rank == 0:
+                uid = ctx.dist_unique_id()
+        except Exception as e:   # noqa: BLE001 -- whatever went wrong, the other ranks must hear of it
+            err = ("rank %d: %s" % (rank, e)).encode()[:300]
+        errs = [e for e in rdv.all_gather(err) if e]
+        uid, err0 = rdv.all_gather(uid)[0], (errs[0] if errs else b"")
+        err = b""
+        if not err0:
             try:
-                ctx.dist_preflight()
-                if rank == 0:
-                    uid = ctx.dist_unique_id()
-            except Exception as e:   # noqa: BLE001 -- whatever went wrong, the other ranks must hear of it
-                err = ("rank %d: %s" % (rank, e)).encode()[:300]
+                ctx.dist_init(rank, world, uid)
+            except Exception as e:   # noqa: BLE001
+                err = ("rank %d: mg_dist_init: %s" % (rank, e)).encode()[:300]
             errs = [e for e in rdv.all_gather(err) if e]
-            uid, err0 = rdv.all_gather(uid)[0], (errs[0] if errs else b"")
-            err = b""
-            if not err0:
-                try:
-                    ctx.dist_init(rank, world, uid)
-                except Exception as e:   # noqa: BLE001
-                    err = ("rank %d: mg_dist_init: %s" % (rank, e)).encode()[:300]
-                errs = [e for e in rdv.all_gather(err) if e]
-                err0 = errs[0] if errs else b""
-                if err0:
-                    try:
-                        ctx.dist_finalize()
-                    except Exception:   # noqa: BLE001
-                        pass
+            err0 = errs[0] if errs else b""
             if err0:
-                collective_note = "mg_dist_* could not be set up (%s)" % err0.decode(errors="replace")
-                if args.collective_fallback != "torch":
-                    if rank == 0:
-                        print("bench.py: %s; no fallback was asked for (--collective-fallback torch)" % collective_note, file=sys.stderr)
-                    raise SystemExit(4)
-                collective_note += ": torch.distributed's communicator instead (--collective-fallback torch)"
-                if rank == 0:
-                    print("bench.py: " + collective_note, file=sys.stderr)
-                ctx.close()
-                use_torch = True
-                import torch
-                import torch.distributed as dist
-                n_dev = torch.cuda.device_count()
-            else:
-                rccl_info = ctx.dist_info()
+                try:
+                    ctx.dist_finalize()
+                except Exception:   # noqa: BLE001
+                    pass
+        if err0:
+            if rank == 0:
+                print("bench.py: mg_dist_* could not be set up (%s); the run ends here (there is no other carrier of the collective)" % err0.decode(errors="replace"),
+                      file=sys.stderr)
+            raise SystemExit(4)
+        rccl_info = ctx.dist_info()
     if world > 1 and os.environ.get("MG_RDV_DIR"):      # tell the launcher's watchdog: this rank is through the set-up
         open(os.path.join(os.environ["MG_RDV_DIR"], "joined.%d" % rank), "w").close()
-    if use_torch:
-        torch.cuda.set_device(dev_index % n_dev)
-        stream = torch.cuda.Stream(device=dev_index % n_dev)
-        torch.cuda.set_stream(stream)
-        ctx = _capi.Context(dev_index % n_dev, stream=stream.cuda_stream)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index % n_dev))
-        else:
-            dist.init_process_group(backend)
     prim = _capi.Primitive(ctx, data)
     if args.frames_kernel:
         ctx.set_option(_capi.MG_OPT_FRAMES_KERNEL, args.frames_kernel)
@@ -323,11 +274,6 @@ def run_walk(args, rank, local_rank, world):
     fill_us = probe["pattern_us"] / probe["ratio"] if probe["ratio"] > 0 else None
     logps = [ctx.malloc(B * 4) for _ in range(2)]
     gathereds = [ctx.malloc(world * B * 4) for _ in range(2)] if world > 1 else None
-    if use_torch:
-        t_logps = [torch.empty((B,), dtype=torch.float32, device="cuda") for _ in range(2)]
-        gdev = "cuda" if backend == "nccl" else "cpu"
-        t_gath = [torch.empty((world * B,), dtype=torch.float32, device=gdev) for _ in range(2)]
-        works = [None, None]
     scalar_dev = ctx.malloc(8)
     scalars_dev = ctx.malloc(8 * max(world, 1))
     step_no = [0]
@@ -335,13 +281,7 @@ def run_walk(args, rank, local_rank, world):
     def step():
         b = step_no[0] & 1
         step_no[0] += 1
-        if use_torch:
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
-            lp_ptr = t_logps[b].data_ptr()
-        else:
-            lp_ptr = logps[b].ptr.value
+        lp_ptr = logps[b].ptr.value
         if args.two_launch:
             prim.back_project_frames_dev(S, np.float32, B, L, frames, path=_capi.MG_PATH_MFMA)
             prim.gmm_log_prob_dev(S, np.float32, B, L, lp_ptr, np.float32)
@@ -349,39 +289,20 @@ def run_walk(args, rank, local_rank, world):
             # mg_step_frames_and_logp: one launch, the mixture is scored inside the frames kernel
             prim.step_frames_and_logp_dev(S, np.float32, B, L, frames, lp_ptr)
         if world > 1:
-            if use_torch:
-                if backend == "nccl":
-                    works[b] = dist.all_gather_into_tensor(t_gath[b], t_logps[b], async_op=True)
-                else:
-                    dist.all_gather_into_tensor(t_gath[b], t_logps[b].cpu())
-            else:
-                ctx.dist_all_gather(logps[b], gathereds[b], B, np.float32)   # RCCL on the kernels' stream, stream ordered
+            ctx.dist_all_gather(logps[b], gathereds[b], B, np.float32)   # RCCL on the kernels' stream, stream ordered
 
     def sync():
-        if use_torch:
-            for b in range(2):
-                if works[b] is not None:
-                    works[b].wait()
-                    works[b] = None
-            torch.cuda.synchronize()
         ctx.synchronize()
 
     def barrier():
         sync()
         if world > 1:
-            if use_torch:
-                dist.barrier()
-            else:
-                ctx.dist_all_gather(scalar_dev, scalars_dev, 1, np.float64)
+            ctx.dist_all_gather(scalar_dev, scalars_dev, 1, np.float64)
         sync()
 
     def max_over_ranks(x):
         if world == 1:
             return x
-        if use_torch:
-            t = torch.tensor([x], dtype=torch.float64, device=gdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
         ctx.lib.mg_memcpy_h2d(ctx.handle, scalar_dev.ptr, np.array([x], dtype=np.float64).ctypes.data, 8)
         ctx.dist_all_gather(scalar_dev, scalars_dev, 1, np.float64)
         return float(ctx.download(scalars_dev, (world,), np.float64).max())
@@ -393,24 +314,30 @@ def run_walk(args, rank, local_rank, world):
     for _ in range(args.warmup):
         step()
     barrier()
-    # timing events ride on the kernel's own dispatch (hipExtLaunchKernel: no marker packets, the duration is the kernel's
-    # own); they still cost ~4 us of step time each, so a long run samples every 8th launch, the driver's 20 steps every second one
-    # and only the shortest runs time them all
-    interval = max(1, args.event_interval) if args.event_interval else (1 if args.steps <= 8 else (2 if args.steps <= 64 else 8))
+    # THE TIMED REGION: exactly K steps between barrier + synchronise, nothing else in it -- no timing events, no profiling
+    # (round 4 bracketed every second launch with dispatch events inside this region: ~4 us each, 11.5 us of step - kernel on the
+    # driver's box).  Five such windows back to back; the headline is the MEDIAN window (one hiccup of a shared box cannot move it),
+    # all five are in the line (`ms_per_step_windows`).  The kernel's own duration comes from a SECOND pass of K steps with a
+    # dispatch-attached event pair on every launch.
+    windows = []
+    for _ in range(5 if not args.single_window else 1):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        windows.append(max_over_ranks(time.perf_counter() - t0))
+    elapsed = float(np.median(windows))
+    interval = max(1, args.event_interval) if args.event_interval else 1
     if not args.no_profile_events:
         ctx.profile_reset()
         ctx.profile_enable(interval)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if not args.no_profile_events:
+        for _ in range(args.steps):
+            step()
+        barrier()
         ctx.profile_enable(False)
-    elapsed = max_over_ranks(elapsed)
     last = (step_no[0] - 1) & 1
     gather_us = None
-    if world > 1 and not use_torch:
+    if world > 1:
         # the collective alone: 200 all-gathers of the step's size back to back on the kernels' stream, nothing else running
         for _ in range(20):
             ctx.dist_all_gather(logps[0], gathereds[0], B, np.float32)
@@ -420,16 +347,15 @@ def run_walk(args, rank, local_rank, world):
             ctx.dist_all_gather(logps[0], gathereds[0], B, np.float32)
         sync()
         gather_us = max_over_ranks(1e6 * (time.perf_counter() - tg) / 200)
-    if world > 1:
         # every rank holds the same global score vector: the graph-walk argmin needs no further exchange
-        g_host = t_gath[last].float().cpu().numpy() if use_torch else ctx.download(gathereds[last], (world * B,), np.float32)
+        g_host = ctx.download(gathereds[last], (world * B,), np.float32)
         best_idx, best_val = first_min_argmin(-g_host)   # most likely candidate
     frames_ms, frames_n = ctx.profile_get("frames")
     gmm_ms, gmm_n = ctx.profile_get("gmm_log_prob")
 
     # sanity: the timed work produced real output
     row = ctx.download(frames.ptr.value + (B // 2) * F * D * 4 + (F - 1) * D * 4, (4,), np.float32)
-    lp_host = t_logps[last].cpu().numpy()[:8] if use_torch else ctx.download(logps[last], (8,), np.float32)
+    lp_host = ctx.download(logps[last], (8,), np.float32)
     if not np.isfinite(float(row.sum()) + float(lp_host.sum())):
         raise SystemExit("non-finite output")
 
@@ -449,12 +375,13 @@ def run_walk(args, rank, local_rank, world):
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "untimed_steps": args.warmup + args.ramp_steps,
+            "ms_per_step_windows": {"n": len(windows), "steps_each": args.steps, "min": 1e3 * min(windows) / args.steps, "median": 1e3 * elapsed / args.steps,
+                                    "max": 1e3 * max(windows) / args.steps, "all": [round(1e3 * w / args.steps, 6) for w in windows],
+                                    "headline": "the median window; no timing events inside any window"},
             "config": {"workload": "walk primitive L=40 F=156 D=79 NB=31 GMM k=8, batch=%d candidates/GPU "
                                    "(BASELINE.json configs[%d])" % (B, 1 if world == 1 else 3),
                        "candidates_per_gpu": B, "global_candidates": world * B,
-                       "collective": ("all_gather(logp) every step, %s" % ("RCCL through mg_dist_all_gather on the kernels' stream" if not use_torch
-                                      else "torch.distributed %s (double-buffered, overlapped)" % backend)) if world > 1 else "none",
-                       "collective_fallback": collective_note,
+                       "collective": "all_gather(logp) every step, RCCL through mg_dist_all_gather on the kernels' stream" if world > 1 else "none",
                        "rccl": ({"ranks_seen_by_rccl": rccl_info["ranks"], "rank0_device": rccl_info["device"],
                                  "all_gather_alone_us": round(gather_us, 2) if gather_us is not None else None,
                                  "all_gather_bytes_per_rank": 4 * B} if rccl_info else None),
@@ -468,12 +395,15 @@ def run_walk(args, rank, local_rank, world):
             # E, mean, basis, mixture constants); stand-alone frames kernel: latents + frames (+ E, mean, basis)
             k_bytes = (B * (4 * L + 4 * F * D) + 4 * (NB * D * L + NB * D + 4 * F)) if args.two_launch else bytes_launch
             achieved = k_bytes / (avg_ms * 1e-3) / 1e9
-            traffic = pmc_traffic_bytes(kernel_name) if B == 8192 else None
+            traffic = pmc_traffic_bytes(kernel_name) if B == 8192 else None       # (bytes, the file they were read from)
             result["roofline"] = {
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/r03_summary.json), not measured in this run" if traffic else None,
+                "traffic": traffic[0] if traffic else None,
+                "traffic_source": ("committed rocprofv3 --pmc passes of this command (%s), not measured in this run" % traffic[1]) if traffic else None,
                 "avg_kernel_ms": avg_ms, "launches_timed": frames_n, "event_interval": interval,
+                "kernel_events": "a second pass of %d steps after the timed windows, a dispatch-attached event pair on every %s launch" % (args.steps, "" if interval == 1 else "%d-th" % interval),
+                "step_minus_kernel_us": 1e3 * (1e3 * elapsed / args.steps - avg_ms),
                 "algorithmic_bytes_per_launch": k_bytes, "launches_per_step": 2 if args.two_launch else 1,
                 "gmm_kernel_avg_ms": (gmm_ms / gmm_n) if gmm_n else None,
                 "step_algorithmic_bytes": bytes_launch, "step_achieved_GBps": bytes_launch / (elapsed / args.steps) / 1e9,
@@ -544,11 +474,9 @@ def run_walk(args, rank, local_rank, world):
     for buf in [S, frames, scalar_dev, scalars_dev] + logps + (gathereds or []):
         buf.free()
     prim.close()
-    if world > 1 and not use_torch:
+    if world > 1:
         ctx.dist_finalize()
     ctx.close()
-    if use_torch:
-        dist.destroy_process_group()
     if rank == 0:
         if world == 1 and not args.no_extra_configs and B == 8192 and args.dry_run is False:
             # BASELINE configs[2] and configs[4] on this GPU, a few hundred steps each, under keys of their own (the headline keys
@@ -862,6 +790,43 @@ def run_frame_constraints(args, emit=True):
     alg = B * (4 * L + T * J * 24 + 8)
     chain_bytes = B * (4 * L + 2 * 8 * F * D + 2 * T * J * 24 + 8)
     k_ms = per_kernel["joint_tracks"]
+    # The roofline entry describes the step's DOMINANT kernel by time (round 4 named mg_joint_tracks against HBM while 76 % of the step
+    # was the closest-point kernel: VERDICT r4).  That kernel moves ~1 MB: neither HBM nor the matrix pipe bounds it.  It is one
+    # scalar float64 search per candidate and frame (the reference's L-BFGS-B, csrc/mg_traj_device.h), one lane per candidate: a wave
+    # issues the union of its 64 lanes' paths, trip after trip -- bound by the float64 VALU issue rate of the ONE wave a SIMD holds
+    # (a wave64 float64 instruction occupies the SIMD's 16 lanes for 4 cycles), on as many SIMDs as the batch has waves.
+    dom = max((k for k in per_kernel if per_kernel[k]), key=lambda k: per_kernel[k])
+    kernel_names = {"trajectory": "mg_trajectory_stream_kernel", "joint_tracks": "mg_joint_tracks_kernel", "frame_constraints": "mg_frame_constraint_list_kernel"}
+    roofline = {"kernel": kernel_names[dom], "avg_kernel_ms": per_kernel[dom], "per_kernel_avg_us": {k: (1e3 * v if v is not None else None) for k, v in per_kernel.items()},
+                "traffic": (pmc_traffic_bytes(kernel_names[dom]) or (None,))[0]}
+    if dom == "trajectory":
+        CLOCK_GHZ, SIMDS, ISSUE_CYCLES = 2.4, 1024, 4.0
+        INSTR_PER_TRIP = 1262        # the search's loop body in this build's code object (llvm-objdump: 1262 instructions, 592 of them *_f64; tools/kernel_resources.sh)
+        root = prim.joint_tracks(sk, [joints[0][0]], S_host)[:, :, 0]                       # the root paths the searches follow
+        _, _, evals = prim.trajectory_closest_points(traj, root, 0.0, evaluations=True)     # (f, g) evaluations of every frame's search
+        waves = (B + 63) // 64
+        per_wave = np.array([evals[w * 64:(w + 1) * 64].max(axis=0).sum() for w in range(waves)], dtype=np.float64)   # a wave runs its slowest lane's trips, frame by frame
+        trips_per_frame = float(per_wave.max()) / F
+        cycles_per_frame = per_kernel[dom] * 1e-3 * CLOCK_GHZ * 1e9 / F
+        issued = float(per_wave.sum()) * INSTR_PER_TRIP                                      # an upper estimate: every trip issues the whole loop body
+        peak = SIMDS * CLOCK_GHZ * 1e9 / ISSUE_CYCLES
+        roofline.update({
+            "bound": "valu-f64-issue", "unit": "wave-instructions/s", "achieved": issued / (per_kernel[dom] * 1e-3), "peak": peak,
+            "frac": issued / (per_kernel[dom] * 1e-3) / peak,
+            "waves": waves, "waves_per_simd": waves / float(SIMDS), "frames": F,
+            "evaluations_per_frame": {"mean_per_candidate": float(evals.mean()), "slowest_lane_of_the_slowest_wave": trips_per_frame},
+            "cycles_per_frame": cycles_per_frame, "cycles_per_trip": cycles_per_frame / trips_per_frame,
+            "issue_limited_cycles_per_trip": INSTR_PER_TRIP * ISSUE_CYCLES,
+            "note": "the reference's closest-point search (scipy L-BFGS-B restated, one lane per candidate): per frame a wave runs the trips of its slowest lane; a trip is "
+                    "one (f, g) evaluation + the line search's bookkeeping, ~%d instructions issued at %d cycles each by the ONE wave its SIMD holds.  The wave is issue "
+                    "bound (cycles_per_trip vs issue_limited_cycles_per_trip); the chip is %d waves on %d SIMDs.  HBM and MFMA rooflines do not apply (%.1f MB per step).  "
+                    "MG_OPT_TRAJECTORY_SEARCH 1 (the monotone walk, eight lanes per candidate) takes ~0.4 ms for the same step and differs from the reference where "
+                    "the distance has several basins" % (INSTR_PER_TRIP, int(ISSUE_CYCLES), waves, SIMDS, 1.1)})
+    else:
+        roofline.update({"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k_ms else None, "algorithmic_bytes": alg,
+                         "note": "mg_joint_tracks moves %d bytes per candidate where the chain moved %d, and is bound by the L2 reads of the eigenvector rows its control points "
+                                 "are made from, not by HBM" % (alg // B, chain_bytes // B)})
     result = {
         "metric": METRIC, "value": B * args.steps / elapsed, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -873,13 +838,7 @@ def run_frame_constraints(args, emit=True):
                                       "what": "mg_back_project_frames_f64 -> mg_joint_positions -> mg_score_frame_constraint with %d-byte float64 frames per candidate in "
                                               "memory (round 3's route, kept as the fallback); host-side latents uploaded per call" % (8 * F * D),
                                       "same_bits": same, "algorithmic_bytes": chain_bytes}},
-        "roofline": {"bound": "hbm", "kernel": "mg_joint_tracks_kernel", "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k_ms else None, "traffic": pmc_traffic_bytes("mg_joint_tracks_kernel"),
-                     "algorithmic_bytes": alg, "avg_kernel_ms": k_ms,
-                     "per_kernel_avg_us": {k: (1e3 * v if v is not None else None) for k, v in per_kernel.items()},
-                     "note": "the step's time is the two closest-point / minimum walks (one lane per candidate, a chain of dependent float64 evaluations per frame: "
-                             "latency bound, neither HBM nor the matrix pipe); mg_joint_tracks moves %d bytes per candidate where the chain moved %d, and is bound "
-                             "by the L2 reads of the eigenvector rows its control points are made from, not by HBM" % (alg // B, chain_bytes // B)},
+        "roofline": roofline,
     }
     if emit:
         print(json.dumps(result))
@@ -901,9 +860,7 @@ def main():
                     help="walk = BASELINE configs[1] / [3] (the headline); graph = configs[2]; optimizer = configs[4] per iteration on one GPU; "
                          "frame_constraints = candidates against constraints that walk every frame (a root trajectory + a hand position)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--collective-fallback", choices=("none", "torch"), default="none",
-                    help="N > 1: what to do when the library's own RCCL communicator cannot be set up on some rank: none = end the run with the reason "
-                         "(default), torch = every rank switches to torch.distributed's communicator")
+    ap.add_argument("--single-window", action="store_true", help="time one window of K steps instead of five (the headline is then that window)")
     ap.add_argument("--host-counts", action="store_true", help="--config graph: component counts from numpy.random.multinomial on the host (one call per option) instead of the device draw")
     ap.add_argument("--no-placement-compare", action="store_true", help="skip the steps on a second library buffer and on a foreign hipMalloc after the timed region (profiling runs)")
     ap.add_argument("--no-extra-configs", action="store_true", help="do not attach the graph / optimizer configurations to the default line")
@@ -913,14 +870,11 @@ def main():
                     help="MG_OPT_FRAMES_KERNEL: 0 = the library's choice, 1 = tile-major, 2 = chunk-stationary (A/B runs)")
     ap.add_argument("--no-profile-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--event-interval", type=int, default=0,
-                    help="every n-th launch of the timed region carries HIP start/stop events attached to the dispatch "
-                         "(0: every launch up to 8 steps, every second one up to 64, else every 8th)")
+                    help="every n-th launch of the events pass (after the timed windows) carries HIP start/stop events attached to the dispatch (0 = every launch)")
     ap.add_argument("--ramp-steps", type=int, default=1500,
                     help="untimed steps before the warm-up that let the chip reach its steady clock (~0.13 s; reported in config)")
     ap.add_argument("--output-alloc", choices=("placed", "plain"), default="placed",
                     help="placed: the library's allocator for large outputs (mg_device_malloc_placed); plain: one hipMalloc")
-    ap.add_argument("--collective", choices=("mg", "torch"), default="mg",
-                    help="N > 1: mg = RCCL through the library's mg_dist_* entry points (no torch); torch = torch.distributed")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: exercise the launcher, the rendezvous and the JSON contract with a stand-in step (CPU tests)")
     args = ap.parse_args()

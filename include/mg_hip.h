@@ -470,11 +470,12 @@ int mg_score_trajectory_points(mg_primitive *prim, const mg_trajectory *trajecto
  * point sequences, chained the way TrajectoryConstraint.get_residual_vector chains it (trajectory_constraint.py:103-113: every
  * frame's search is bounded below by, and started at, the parameter the previous frame's search returned; the first by min_u):
  * points_dev (n_samples, n_times, 3) float64 -> params_dev (n_samples, n_times) the spline parameter of every frame's point,
- * distances_dev (n_samples, n_times) its distance to the frame's position (either may be NULL).  The search is the reference's
+ * distances_dev (n_samples, n_times) its distance to the frame's position, evaluations_dev (n_samples, n_times) int32 the (f, g)
+ * evaluations the frame's search took (scipy's nfev / 2; 0 with the monotone walk) -- any may be NULL.  The search is the reference's
  * (MG_OPT_TRAJECTORY_SEARCH 0, the default: scipy's L-BFGS-B restated) or the monotone walk (1).  Pinned by
  * tests/golden/trajectory_closest_point.npz, which the reference's own function produced. */
 int mg_trajectory_closest_points(mg_primitive *prim, const mg_trajectory *trajectory, const double *points_dev, int64_t n_samples, int32_t n_times,
-                                 double min_u, double *params_dev, double *distances_dev);
+                                 double min_u, double *params_dev, double *distances_dev, int32_t *evaluations_dev);
 
 /* Constraints that walk a joint through EVERY frame of a candidate (mg_frame_constraints.hip), on float64 frames and joint tracks
  * that are on the device already (mg_back_project_frames_f64, mg_joint_positions):

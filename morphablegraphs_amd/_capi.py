@@ -259,7 +259,7 @@ def load_library(path=None):
         "mg_score_trajectory": [vp, vp, vp, vp, i32, i64, i64, dbl, dbl, vp, vp, i32, vp],
         "mg_score_trajectories": [i32, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, i32],
         "mg_score_trajectory_points": [vp, vp, vp, i64, i32, dbl, dbl, vp, i32, vp],
-        "mg_trajectory_closest_points": [vp, vp, vp, i64, i32, dbl, vp, vp],
+        "mg_trajectory_closest_points": [vp, vp, vp, i64, i32, dbl, vp, vp, vp],
         "mg_align_frames": [vp, vp, i64, i32, vp, i32, C.POINTER(AlignmentDesc)],
         "mg_frame_constraint_width": [C.POINTER(FrameConstraintDesc), i32],
         "mg_score_frame_constraint": [vp, C.POINTER(FrameConstraintDesc), vp, i64, i32, i32, vp, i32, vp],
@@ -962,19 +962,26 @@ class Primitive(object):
             for b in (d_S, d_f, d_o):
                 b.free()
 
-    def trajectory_closest_points(self, trajectory, points, min_u=0.0):
+    def trajectory_closest_points(self, trajectory, points, min_u=0.0, evaluations=False):
         """mg_trajectory_closest_points: points (n, T, 3) float64 -> (parameters (n, T), distances (n, T)): the reference's
-        find_closest_point_fast chained frame to frame (trajectory_constraint.py:103-113) for every row."""
+        find_closest_point_fast chained frame to frame (trajectory_constraint.py:103-113) for every row; evaluations: also the
+        (f, g) evaluations every search took (n, T) int32."""
         P = np.ascontiguousarray(points, dtype=np.float64)
         n, T = P.shape[0], P.shape[1]
         ctx = self.ctx
         d_p, d_u, d_d = ctx.upload(P), ctx.malloc(max(n * T, 1) * 8), ctx.malloc(max(n * T, 1) * 8)
+        d_n = ctx.malloc(max(n * T, 1) * 4) if evaluations else None
         try:
-            _check(self.lib.mg_trajectory_closest_points(self.handle, trajectory.handle, d_p.ptr, n, T, float(min_u), d_u.ptr, d_d.ptr))
-            return ctx.download(d_u, (n, T), np.float64), ctx.download(d_d, (n, T), np.float64)
+            if d_n is not None:
+                _check(self.lib.mg_memset(ctx.handle, d_n.ptr, 0, max(n * T, 1) * 4))
+            _check(self.lib.mg_trajectory_closest_points(self.handle, trajectory.handle, d_p.ptr, n, T, float(min_u), d_u.ptr, d_d.ptr,
+                                                         d_n.ptr if d_n is not None else None))
+            out = (ctx.download(d_u, (n, T), np.float64), ctx.download(d_d, (n, T), np.float64))
+            return out + (ctx.download(d_n, (n, T), np.int32),) if evaluations else out
         finally:
-            for b in (d_p, d_u, d_d):
-                b.free()
+            for b in (d_p, d_u, d_d, d_n):
+                if b is not None:
+                    b.free()
 
     def score_trajectory_points(self, trajectory, points, min_u=0.0, weight=1.0, residuals=False):
         """mg_score_trajectory_points: points (n, T, 3) float64 followed along the trajectory instead of the root path."""

@@ -295,7 +295,7 @@ MG_HD __forceinline__ void mg_lb_dcstep(double &stx, double &fx, double &dx, dou
 // search any of its 64 lanes has in that iteration; flat, it runs the longest lane's total (12.3 -> 10.5 ms per 4096 candidates x 156
 // frames; what is left is one wave's chain of dependent float64 instructions: ~34 trips per frame for the slowest of 64 lanes --
 // the reference's line searches that end at the noise floor after 20 trials --, each ~500 instructions at ~10 cycles).
-MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_seg, double *min_u_io, const double *q) {
+MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_seg, double *min_u_io, const double *q, int *n_trips = nullptr) {
     const double lb = *min_u_io, ub = 1.0;
     const double epsmch = 2.220446049250313e-16, pgtol = 1.0e-5, factr = 1.0e7;
     const double ftol = 1.0e-3, gtol = 0.9, xtol = 0.1, stpmin = 0.0;
@@ -308,8 +308,10 @@ MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_se
     int col = 0, itr = 0, nit = 0, ifun = 0, stage = 1;
     bool was_free = true, brackt = false, searching = false, done = false;
     auto projgr = [&](double xx, double gg) { return fabs(gg < 0.0 ? fmax(xx - ub, gg) : fmin(xx - lb, gg)); };
+    int trips = 0;
     while (!done) {
         double fn, gn;
+        trips++;
         mg_lb_fg(poly, n_seg, q, lb, x, &fn, &gn);
         bool start = false;                 // set up a new iteration (Cauchy point, line search) from (x, f, g)
         if (!searching) {                   // the start point
@@ -413,5 +415,6 @@ MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_se
         }
     }
     *min_u_io = x;
+    if (n_trips) *n_trips = trips;      // (f, g) evaluations of this search: scipy's nfev / 2
     return f;
 }

@@ -37,6 +37,7 @@ struct mg_traj_args {
     const double *points;   // NULL, or (B, T, 3): the positions to follow the trajectory with, given instead of derived from the
                             // candidates' root rows (any joint's track from mg_joint_positions; already aligned by the caller)
     double *res_u;          // NULL, or (B, T): the parameter the search settles on in every frame (mg_trajectory_closest_points)
+    int32_t *res_n;         // NULL, or (B, T): the (f, g) evaluations every frame's search took (the reference's search only)
     int32_t search;         // 0: the reference's search (L-BFGS-B restated, mg_traj_closest_lbfgsb), 1: the monotone walk (MG_OPT_TRAJECTORY_SEARCH)
 };
 
@@ -124,7 +125,9 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
             q[1] += ty;
         }
         // (mg_traj_device.h; min_u moves to the point's parameter; every lane of the wave is here: the walk's long searches get its help)
-        const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(poly, a.n_seg, &min_u, q) : mg_traj_closest_dist<true>(poly, a.n_seg, G, invG, &min_u, q);
+        int trips = 0;
+        const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(poly, a.n_seg, &min_u, q, &trips) : mg_traj_closest_dist<true>(poly, a.n_seg, G, invG, &min_u, q);
+        if (a.res_n && valid) a.res_n[b * a.T + f] = trips;
         sum += dist;
         if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
         if (a.res_u && valid) a.res_u[b * a.T + f] = min_u;
@@ -473,7 +476,7 @@ static int mg_traj_fill_args(const char *who, mg_primitive *p, const mg_trajecto
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = lat; a.i0 = g->d_i0; a.w = g->d_w; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = ld; a.T = g->T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = dt == MG_F64 ? 1 : 0;
-    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = nullptr; a.res_u = nullptr;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = nullptr; a.res_u = nullptr; a.res_n = nullptr;
     a.search = p->ctx->opt[MG_OPT_TRAJECTORY_SEARCH] == 1 ? 1 : 0;
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
@@ -593,18 +596,18 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
 // aligned by the caller) -- TrajectoryConstraint for joints other than the root (trajectory_constraint.py:95-121 with
 // skeleton.nodes[joint].get_global_position(frame)).
 static int mg_traj_points_launch(const char *who, mg_primitive *p, const mg_trajectory *t, const double *points_dev, int64_t B, int32_t T, double min_u,
-                                 double weight, double *errors_dev, int accumulate, double *residuals_dev, double *params_dev) {
+                                 double weight, double *errors_dev, int accumulate, double *residuals_dev, double *params_dev, int32_t *evals_dev = nullptr) {
     if (!p || !t || t->prim != p || B < 0 || T < 1 || !(min_u >= 0.0 && min_u <= 1.0) || !std::isfinite(weight)) {
         mg_set_error("%s: bad arguments", who);
         return MG_ERR_INVALID_ARGUMENT;
     }
     if (B == 0) return MG_OK;
-    if (!points_dev || (!errors_dev && !params_dev && !residuals_dev)) { mg_set_error("%s: NULL pointer", who); return MG_ERR_INVALID_ARGUMENT; }
+    if (!points_dev || (!errors_dev && !params_dev && !residuals_dev && !evals_dev)) { mg_set_error("%s: NULL pointer", who); return MG_ERR_INVALID_ARGUMENT; }
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = nullptr; a.i0 = nullptr; a.w = nullptr; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = 0; a.T = T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = 1;
-    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = points_dev; a.res_u = params_dev;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = points_dev; a.res_u = params_dev; a.res_n = evals_dev;
     a.search = p->ctx->opt[MG_OPT_TRAJECTORY_SEARCH] == 1 ? 1 : 0;
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
@@ -633,9 +636,10 @@ extern "C" int mg_score_trajectory_points(mg_primitive *p, const mg_trajectory *
 // ParameterizedSpline.find_closest_point_fast (splines/parameterized_spline.py:303-322) for a batch of point sequences, chained the way
 // TrajectoryConstraint.get_residual_vector chains it (trajectory_constraint.py:103-113: every frame's search is bounded below by, and
 // started at, the previous frame's parameter): params_dev (B, T) the parameter of every frame's point, distances_dev (B, T) its
-// distance (either may be NULL).
+// distance, evaluations_dev (B, T) int32 the (f, g) evaluations the frame's search took -- scipy's nfev / 2; the reference's search
+// only -- (any may be NULL).
 extern "C" int mg_trajectory_closest_points(mg_primitive *p, const mg_trajectory *t, const double *points_dev, int64_t B, int32_t T, double min_u,
-                                            double *params_dev, double *distances_dev) {
-    if (B > 0 && !params_dev && !distances_dev) { mg_set_error("mg_trajectory_closest_points: nothing to write"); return MG_ERR_INVALID_ARGUMENT; }
-    return mg_traj_points_launch("mg_trajectory_closest_points", p, t, points_dev, B, T, min_u, 1.0, nullptr, 0, distances_dev, params_dev);
+                                            double *params_dev, double *distances_dev, int32_t *evaluations_dev) {
+    if (B > 0 && !params_dev && !distances_dev && !evaluations_dev) { mg_set_error("mg_trajectory_closest_points: nothing to write"); return MG_ERR_INVALID_ARGUMENT; }
+    return mg_traj_points_launch("mg_trajectory_closest_points", p, t, points_dev, B, T, min_u, 1.0, nullptr, 0, distances_dev, params_dev, evaluations_dev);
 }

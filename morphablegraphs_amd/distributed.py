@@ -6,7 +6,8 @@ on GPUs, gloo in the CPU tests) followed by the reference's first-minimum argmin
 (reference motion_primitive_generator.py:251-257).  The carrier is the library's own RCCL entry points
 (mg_all_gather_scores / mg_sharded_best_candidate over a _capi.Context after dist_init; MgCommunicator for the product seam) or,
 for CPU rehearsals and ranks that share a GPU, files (FileCommunicator).  This package imports no tensor framework: the
-framework-collective rehearsal of the same exchange lives with the tests (tests/framework_collective_helpers.py).
+framework-collective rehearsal of the same exchange lives with the tests (tests/test_distributed_gloo.py injects a gloo-backed
+communicator into THIS module's commands).
 The scores come from the scorer callable (libmg_hip on a GPU box).
 """
 import json

@@ -1,6 +1,6 @@
 """bench.py's N > 1 plumbing without a GPU (--dry-run): typed as `python bench.py --gpus 2` it must launch its own
 ranks and print exactly one JSON line; launched the driver's way (torch.distributed.run) it must read the ranks from
-the environment; both carriers of the collective (file rendezvous of the torch-free path, torch.distributed gloo)."""
+the environment.  bench.py carries no tensor framework (a test keeps it so): the dry run's exchange goes through the file rendezvous."""
 import json
 import os
 import socket
@@ -26,10 +26,13 @@ def _run(cmd, env=None, timeout=240):
     return p.stdout.decode()
 
 
-@pytest.mark.parametrize("collective", ["mg", "torch"])
-def test_gpus_n_typed_as_is_launches_its_own_ranks(collective):
-    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run", "--batch", "64",
-                "--collective", collective], env={"MG_BENCH_BACKEND": "gloo"})
+def test_bench_carries_no_tensor_framework():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in src and "torch.cuda" not in src and "torch.distributed." not in src.replace("torch.distributed.run", "")
+
+
+def test_gpus_n_typed_as_is_launches_its_own_ranks():
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run", "--batch", "64"])
     lines = _json_lines(out)
     assert len(lines) == 1, out
     r = lines[0]
@@ -72,25 +75,17 @@ def test_a_dead_rank_ends_the_launch_instead_of_hanging_it():
 
 
 @pytest.mark.gpu
-def test_collective_set_up_failure_ends_the_run_or_falls_back_when_asked():
+def test_collective_set_up_failure_ends_the_run_with_the_reason():
     """Two ranks on ONE GPU: RCCL refuses the second rank of a device, so mg_dist_init fails -- on both ranks; they tell each other
-    through the file rendezvous.  By default the run ends with the reason (no tensor framework on the product's path); with
-    --collective-fallback torch every rank switches to torch.distributed's communicator (gloo here, the CPU rehearsal backend)
-    and the line says so.  What an 8-GPU node would do if the library's own communicator could not be set up there."""
+    through the file rendezvous and the run ends with the reason (there is no other carrier of the collective in bench.py).  What an
+    8-GPU node would do if the library's own communicator could not be set up there."""
     base = [sys.executable, "bench.py", "--gpus", "2", "--steps", "30", "--warmup", "3", "--ramp-steps", "30", "--no-cpu-baseline",
             "--no-extra-configs", "--no-placement-compare"]
-    env = dict(os.environ, MG_BENCH_OVERSUBSCRIBE="1", MG_BENCH_BACKEND="gloo")
+    env = dict(os.environ, MG_BENCH_OVERSUBSCRIBE="1")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     p = subprocess.run(base, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400)
-    assert p.returncode != 0 and b"could not be set up" in p.stderr and b"--collective-fallback torch" in p.stderr and not _json_lines(p.stdout.decode())
-    out = _run(base + ["--collective-fallback", "torch"], env={"MG_BENCH_OVERSUBSCRIBE": "1", "MG_BENCH_BACKEND": "gloo"}, timeout=400)
-    lines = _json_lines(out)
-    assert len(lines) == 1
-    r = lines[0]
-    assert r["n_gpus"] == 2 and r["config"]["global_candidates"] == 2 * r["config"]["candidates_per_gpu"]
-    assert "torch.distributed gloo" in r["config"]["collective"] and "mg_dist_init" in r["config"]["collective_fallback"]
-    assert r["value"] > 0
+    assert p.returncode != 0 and b"could not be set up" in p.stderr and not _json_lines(p.stdout.decode())
 
 
 def test_ranks_that_never_join_the_communicator_end_the_launch(tmp_path):
