@@ -185,12 +185,18 @@ __device__ __forceinline__ double mg_fc_evaluate(const mg_fc_args &a, const int6
         const double invG = 1.0 / (double)t.G;
         const double *poly = mg_fc_poly<TABLES_LDS>(t, lds);
         double min_u = a.start_arc, sum = 0.0;       // (start_arc carries the constraint's min_u)
-        for (int f = 0; f < T; f++) {
-            const double *pp = tr + (int64_t)f * 3;
-            const double q[3] = {pp[0], pp[1], pp[2]};
-            const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(poly, t.n_seg, &min_u, q) : mg_traj_closest_dist(poly, t.n_seg, t.G, invG, &min_u, q);
-            sum += dist;
-            if (a.res) a.res[b * T + f] = a.weight * dist;
+        if (a.search == 0) {                         // the reference's search: this lane's frames at its own pace (mg_traj_chain)
+            mg_traj_chain(poly, t.n_seg, T, min_u,
+                          [&](int f, double *q) { const double *pp = tr + (int64_t)f * 3; q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2]; },
+                          [&](int f, double dist, double, int) { sum += dist; if (a.res) a.res[b * T + f] = a.weight * dist; });
+        } else {
+            for (int f = 0; f < T; f++) {
+                const double *pp = tr + (int64_t)f * 3;
+                const double q[3] = {pp[0], pp[1], pp[2]};
+                const double dist = mg_traj_closest_dist(poly, t.n_seg, t.G, invG, &min_u, q);
+                sum += dist;
+                if (a.res) a.res[b * T + f] = a.weight * dist;
+            }
         }
         err = a.weight * (T > 0 ? sum / (double)T : 0.0);
     } else if (a.type == MG_FRAME_CA_POSITION) {

@@ -154,6 +154,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     for (void *q : {ctx->fused_tab_dev, ctx->fused_counters, ctx->fused_partials, ctx->fused_dyn_dev}) if (q) (void)hipFree(q);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->flag_block) (void)hipHostFree(ctx->flag_block);
+    if (ctx->traj_paths) (void)hipFree(ctx->traj_paths);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
     for (auto &v : ctx->vmm) mg_vmm_release(ctx, v);
     (void)hipDeviceSynchronize();   // nothing of this process is in flight when the parked address ranges go back to the runtime

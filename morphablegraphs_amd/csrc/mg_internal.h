@@ -93,6 +93,8 @@ struct mg_context {
     // step's record bytes could read as this step's sequence number.
     unsigned long long *flag_block = nullptr;
     size_t flag_cap = 0;            // flags
+    void *traj_paths = nullptr;     // mg_score_trajectory[ies]: the candidates' root paths (B, T, 3) float64 for the reference's search
+    size_t traj_paths_bytes = 0;    // (kept between calls, grown on demand, freed with the context)
     void *rccl_comm = nullptr;      // ncclComm_t after mg_dist_init
     int dist_rank = 0, dist_ranks = 1;
 };

@@ -288,28 +288,36 @@ MG_HD __forceinline__ void mg_lb_dcstep(double &stx, double &fx, double &dx, dou
     }
     stp = stpf;
 }
-// The distance from q to the spline point the reference's search settles on, its parameter back in *min_u_io (the next frame's bound
-// and start).  oracle/mg_oracle.py closest_point_lbfgsb, statement for statement (with formk's verdict by the rule above) -- as ONE
-// flat loop whose every trip is one evaluation of (f, g) followed by the bookkeeping that decides the next point: written as the
-// algorithm's nested loops (iterations around line-search trials) a wave runs, per frame, the SUM over iterations of the longest line
-// search any of its 64 lanes has in that iteration; flat, it runs the longest lane's total (12.3 -> 10.5 ms per 4096 candidates x 156
-// frames; what is left is one wave's chain of dependent float64 instructions: ~34 trips per frame for the slowest of 64 lanes --
-// the reference's line searches that end at the noise floor after 20 trials --, each ~500 instructions at ~10 cycles).
-MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_seg, double *min_u_io, const double *q, int *n_trips = nullptr) {
-    const double lb = *min_u_io, ub = 1.0;
-    const double epsmch = 2.220446049250313e-16, pgtol = 1.0e-5, factr = 1.0e7;
-    const double ftol = 1.0e-3, gtol = 0.9, xtol = 0.1, stpmin = 0.0;
-    double x = lb, f = 0.0, g = 0.0;
-    // the iteration's state
-    double t = 0.0, r_ = 0.0, fold = 0.0, d = 0.0, z = 0.0, stpmx = 0.0, gdold = 0.0, theta = 1.0;
-    // the line search's state
-    double stp = 1.0, finit = 0.0, ginit = 0.0, gtest = 0.0, width = 0.0, width1 = 0.0;
-    double stx = 0.0, fx = 0.0, gx = 0.0, sty = 0.0, fy = 0.0, gy = 0.0, stmin = 0.0, stmax = 0.0;
-    int col = 0, itr = 0, nit = 0, ifun = 0, stage = 1;
-    bool was_free = true, brackt = false, searching = false, done = false;
-    auto projgr = [&](double xx, double gg) { return fabs(gg < 0.0 ? fmax(xx - ub, gg) : fmin(xx - lb, gg)); };
-    int trips = 0;
-    while (!done) {
+// One search of the reference's (oracle/mg_oracle.py closest_point_lbfgsb, statement for statement, with formk's verdict by the rule
+// above) as a STATE MACHINE: begin(), then trip() until done -- every trip is one evaluation of (f, g) followed by the bookkeeping
+// that decides the next point.  Two things make that form the device's: (i) written as the algorithm's nested loops (iterations around
+// line-search trials) a wave runs the SUM over iterations of the longest line search any of its 64 lanes has; flat, the longest lane's
+// total; (ii) a lane's frames chain only through its OWN bound, so with the state in a struct the lanes of a wave need not walk the
+// frames in step (mg_traj_chain below): a wave then runs its slowest lane's total over all frames (~1.6 x the mean) instead of the
+// sum over frames of each frame's slowest lane (8.7 x the mean: the reference's line searches that end at the noise floor after 20
+// trials are rare per lane and frame but present in nearly every frame of SOME lane of 64).  Nested loops 12.3 ms, flat per frame 10.5 ms,
+// lanes out of step 5.2 ms per 4096 candidates x 156 frames; what is left is the slowest candidate's own chain: ~2500 trips of ~1260
+// instructions, issued at 4 cycles each by the one wave its SIMD holds.
+struct mg_lb_search {
+    double lb, x, f, g;
+    double t, r_, fold, d, z, stpmx, gdold, theta;                                                  // the iteration
+    double stp, finit, ginit, gtest, width, width1, stx, fx, gx, sty, fy, gy, stmin, stmax;         // the line search
+    int col, itr, nit, ifun, stage, trips;
+    bool was_free, brackt, searching, done;
+
+    MG_HD __forceinline__ void begin(double min_u) {
+        lb = min_u; x = min_u; f = 0.0; g = 0.0;
+        t = r_ = fold = d = z = stpmx = gdold = 0.0; theta = 1.0;
+        stp = 1.0; finit = ginit = gtest = width = width1 = stx = fx = gx = sty = fy = gy = stmin = stmax = 0.0;
+        col = itr = nit = ifun = trips = 0; stage = 1;
+        was_free = true; brackt = false; searching = false; done = false;
+    }
+    MG_HD __forceinline__ double projgr(double xx, double gg) const { return fabs(gg < 0.0 ? fmax(xx - 1.0, gg) : fmin(xx - lb, gg)); }
+
+    MG_HD __forceinline__ void trip(const double *poly, int n_seg, const double *q) {
+        const double ub = 1.0;
+        const double epsmch = 2.220446049250313e-16, pgtol = 1.0e-5, factr = 1.0e7;
+        const double ftol = 1.0e-3, gtol = 0.9, xtol = 0.1, stpmin = 0.0;
         double fn, gn;
         trips++;
         mg_lb_fg(poly, n_seg, q, lb, x, &fn, &gn);
@@ -414,7 +422,33 @@ MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_se
             x = z;                          // (stp = 1)
         }
     }
-    *min_u_io = x;
-    if (n_trips) *n_trips = trips;      // (f, g) evaluations of this search: scipy's nfev / 2
-    return f;
+};
+// The distance from q to the spline point the reference's search settles on, its parameter back in *min_u_io (the next frame's bound
+// and start); n_trips: the (f, g) evaluations the search took (scipy's nfev / 2).
+MG_HD __forceinline__ double mg_traj_closest_lbfgsb(const double *poly, int n_seg, double *min_u_io, const double *q, int *n_trips = nullptr) {
+    mg_lb_search s;
+    s.begin(*min_u_io);
+    while (!s.done) s.trip(poly, n_seg, q);
+    *min_u_io = s.x;
+    if (n_trips) *n_trips = s.trips;
+    return s.f;
+}
+// TrajectoryConstraint.get_residual_vector's chain over a lane's own T positions (trajectory_constraint.py:103-113): getq(f, q) hands
+// over frame f's position, emit(f, distance, parameter, trips) takes every frame's result in frame order.  The lanes of a wave are
+// NOT held in step: a lane whose search is done moves on to its next frame while its neighbours are still searching.
+template <typename GetQ, typename Emit>
+MG_HD __forceinline__ void mg_traj_chain(const double *poly, int n_seg, int T, double min_u, GetQ getq, Emit emit) {
+    mg_lb_search s;
+    double q[3] = {0.0, 0.0, 0.0};
+    int f = 0;
+    if (T > 0) { getq(0, q); s.begin(min_u); }
+    while (f < T) {
+        s.trip(poly, n_seg, q);
+        if (s.done) {
+            emit(f, s.f, s.x, s.trips);
+            min_u = s.x;
+            f++;
+            if (f < T) { getq(f, q); s.begin(min_u); }
+        }
+    }
 }

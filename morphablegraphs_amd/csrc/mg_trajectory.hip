@@ -38,6 +38,8 @@ struct mg_traj_args {
                             // candidates' root rows (any joint's track from mg_joint_positions; already aligned by the caller)
     double *res_u;          // NULL, or (B, T): the parameter the search settles on in every frame (mg_trajectory_closest_points)
     int32_t *res_n;         // NULL, or (B, T): the (f, g) evaluations every frame's search took (the reference's search only)
+    double *paths;          // the reference's search on candidates' root paths: (B, T, 3) scratch the kernel writes the paths to first (a lane
+                            // then searches ITS frames at its own pace, mg_traj_chain)
     int32_t search;         // 0: the reference's search (L-BFGS-B restated, mg_traj_closest_lbfgsb), 1: the monotone walk (MG_OPT_TRAJECTORY_SEARCH)
 };
 
@@ -97,26 +99,16 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
     const int G = a.G;
     const double invG = 1.0 / (double)G;
     double min_u = a.min_u, sum = 0.0;
-    // (given positions: the next frame's point is requested a frame ahead -- its trip to memory would otherwise head every frame's
-    // chain of dependent evaluations)
-    double qn[3] = {0.0, 0.0, 0.0};
-    if (a.points && a.T > 0) { const double *pp = a.points + (size_t)bb * a.T * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
-    for (int f = 0; f < a.T; f++) {
-        double q[3];
-        if (a.points) {
-            q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2];
-            if (f + 1 < a.T) { const double *pp = a.points + ((size_t)bb * a.T + f + 1) * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
-        } else {
-            const int i0 = a.i0[f];
-            const double *w = a.w + 4 * (size_t)f;
+    auto position = [&](int f, double *q) {        // the candidate's root position in frame f, aligned
+        const int i0 = a.i0[f];
+        const double *w = a.w + 4 * (size_t)f;
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                double v = w[0] * lc[((i0 + 0) * 3 + d) * MG_TRAJ_BLOCK + tid];
-                v = fma(w[1], lc[((i0 + 1) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
-                v = fma(w[2], lc[((i0 + 2) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
-                v = fma(w[3], lc[((i0 + 3) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
-                q[d] = v;
-            }
+        for (int d = 0; d < 3; d++) {
+            double v = w[0] * lc[((i0 + 0) * 3 + d) * MG_TRAJ_BLOCK + tid];
+            v = fma(w[1], lc[((i0 + 1) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+            v = fma(w[2], lc[((i0 + 2) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+            v = fma(w[3], lc[((i0 + 3) * 3 + d) * MG_TRAJ_BLOCK + tid], v);
+            q[d] = v;
         }
         if (a.align_mode != 0) {
             const double x = q[0], z = q[2];
@@ -124,13 +116,36 @@ __global__ __launch_bounds__(MG_TRAJ_BLOCK) void mg_trajectory_kernel(mg_traj_ar
             q[2] = ac * z - as * x + tz;
             q[1] += ty;
         }
-        // (mg_traj_device.h; min_u moves to the point's parameter; every lane of the wave is here: the walk's long searches get its help)
-        int trips = 0;
-        const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(poly, a.n_seg, &min_u, q, &trips) : mg_traj_closest_dist<true>(poly, a.n_seg, G, invG, &min_u, q);
-        if (a.res_n && valid) a.res_n[b * a.T + f] = trips;
-        sum += dist;
-        if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
-        if (a.res_u && valid) a.res_u[b * a.T + f] = min_u;
+    };
+    if (a.search == 0) {
+        // the reference's search: every lane walks ITS frames at its own pace (mg_traj_chain); the positions come from the caller's
+        // points or, for the root path, are evaluated per lane from the rows in LDS
+        const double *pts = a.points ? a.points + (size_t)bb * a.T * 3 : nullptr;
+        mg_traj_chain(poly, a.n_seg, valid ? a.T : 0, a.min_u,
+                      [&](int f, double *q) { if (pts) { q[0] = pts[3 * f]; q[1] = pts[3 * f + 1]; q[2] = pts[3 * f + 2]; } else position(f, q); },
+                      [&](int f, double dist, double u, int trips) {
+                          sum += dist;
+                          if (a.res) a.res[b * a.T + f] = a.weight * dist;
+                          if (a.res_u) a.res_u[b * a.T + f] = u;
+                          if (a.res_n) a.res_n[b * a.T + f] = trips;
+                      });
+    } else {
+        // (given positions: the next frame's point is requested a frame ahead -- its trip to memory would otherwise head every frame's
+        // chain of dependent evaluations)
+        double qn[3] = {0.0, 0.0, 0.0};
+        if (a.points && a.T > 0) { const double *pp = a.points + (size_t)bb * a.T * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
+        for (int f = 0; f < a.T; f++) {
+            double q[3];
+            if (a.points) {
+                q[0] = qn[0]; q[1] = qn[1]; q[2] = qn[2];
+                if (f + 1 < a.T) { const double *pp = a.points + ((size_t)bb * a.T + f + 1) * 3; qn[0] = pp[0]; qn[1] = pp[1]; qn[2] = pp[2]; }
+            } else position(f, q);
+            // (mg_traj_device.h; min_u moves to the point's parameter; every lane of the wave is here: the walk's long searches get its help)
+            const double dist = mg_traj_closest_dist<true>(poly, a.n_seg, G, invG, &min_u, q);
+            sum += dist;
+            if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
+            if (a.res_u && valid) a.res_u[b * a.T + f] = min_u;
+        }
     }
     if (valid && a.out) {
         const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
@@ -284,7 +299,7 @@ __device__ __forceinline__ void mg_trajectory_stream_body(const mg_traj_args &a,
     double min_u = a.min_u, sum = 0.0;
     double cw[4][3];                       // control points cur .. cur + 3 of the three root channels
     int cur = INT_MIN;
-    for (int f = 0; f < a.T; f++) {
+    auto position = [&](int f, double *q) {  // frame f's aligned root position (called with f ascending, the same f in every lane)
         const int i0 = a.i0[f];             // (the same for every lane: the branches below are uniform)
         if (i0 != cur) {
             if (cur != INT_MIN && i0 == cur + 1) {
@@ -303,7 +318,6 @@ __device__ __forceinline__ void mg_trajectory_stream_body(const mg_traj_args &a,
             cur = i0;
         }
         const double *w = a.w + 4 * (size_t)f;
-        double q[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             double v = w[0] * cw[0][d];
@@ -318,9 +332,31 @@ __device__ __forceinline__ void mg_trajectory_stream_body(const mg_traj_args &a,
             q[2] = ac * z - as * x + tz;
             q[1] += ty;
         }
-        const double dist = a.search == 0 ? mg_traj_closest_lbfgsb(lp, a.n_seg, &min_u, q) : mg_traj_closest_dist<true>(lp, a.n_seg, G, invG, &min_u, q);   // (every lane of the wave is here: the help is legal)
-        sum += dist;
-        if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
+    };
+    if (a.search == 0) {
+        // the reference's search: first the whole path, frame by frame with the window in registers (the lanes in step), into the
+        // caller's scratch; then every lane searches ITS frames at its own pace (a lane reads back what it wrote itself)
+        double *mine = a.paths + (size_t)bb * a.T * 3;
+        if (valid)
+            for (int f = 0; f < a.T; f++) {
+                double q[3];
+                position(f, q);
+                mine[3 * f] = q[0]; mine[3 * f + 1] = q[1]; mine[3 * f + 2] = q[2];
+            }
+        mg_traj_chain(lp, a.n_seg, valid ? a.T : 0, a.min_u,
+                      [&](int f, double *q) { q[0] = mine[3 * f]; q[1] = mine[3 * f + 1]; q[2] = mine[3 * f + 2]; },
+                      [&](int f, double dist, double u, int trips) {
+                          sum += dist;
+                          if (a.res) a.res[b * a.T + f] = a.weight * dist;
+                      });
+    } else {
+        for (int f = 0; f < a.T; f++) {
+            double q[3];
+            position(f, q);
+            const double dist = mg_traj_closest_dist<true>(lp, a.n_seg, G, invG, &min_u, q);   // (every lane of the wave is here: the help is legal)
+            sum += dist;
+            if (a.res && valid) a.res[b * a.T + f] = a.weight * dist;
+        }
     }
     if (valid) {
         const double e = a.weight * (a.T > 0 ? sum / (double)a.T : 0.0);
@@ -360,6 +396,20 @@ static int mg_traj_lanes(const mg_context *ctx, int64_t B, int64_t total) {
     if (opt == 1 || B > MG_TRAJ_COOP_MAX_B) return 1;
     if (opt == 8 || opt == 4) return opt;
     return total <= MG_TRAJ_W8_MAX_TOTAL ? 8 : (total <= MG_TRAJ_W4_MAX_TOTAL ? 4 : 1);
+}
+
+// the context's buffer for the candidates' root paths (the reference's search in the streaming kernels): grown on demand, stream ordered
+static int mg_traj_paths(mg_context *ctx, size_t bytes, double **out) {
+    if (ctx->traj_paths_bytes < bytes) {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // a launch may still be reading the old one
+        if (ctx->traj_paths) (void)hipFree(ctx->traj_paths);
+        ctx->traj_paths = nullptr; ctx->traj_paths_bytes = 0;
+        const size_t want = std::max<size_t>(bytes, (size_t)16 << 20);
+        MG_HIP_CHECK(hipMalloc(&ctx->traj_paths, want));
+        ctx->traj_paths_bytes = want;
+    }
+    *out = (double *)ctx->traj_paths;
+    return MG_OK;
 }
 
 template <typename T>
@@ -476,7 +526,7 @@ static int mg_traj_fill_args(const char *who, mg_primitive *p, const mg_trajecto
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = lat; a.i0 = g->d_i0; a.w = g->d_w; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = ld; a.T = g->T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = dt == MG_F64 ? 1 : 0;
-    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = nullptr; a.res_u = nullptr; a.res_n = nullptr;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = nullptr; a.res_u = nullptr; a.res_n = nullptr; a.paths = nullptr;
     a.search = p->ctx->opt[MG_OPT_TRAJECTORY_SEARCH] == 1 ? 1 : 0;
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
@@ -521,6 +571,7 @@ extern "C" int mg_score_trajectory(mg_primitive *p, const mg_trajectory *t, cons
     if (coop_lds > 60 * 1024) lanes = 1;
     const size_t stream_lds = (size_t)p->L * MG_TRAJ_BLOCK * 8 + poly_bytes;
     const dim3 coop_grid((unsigned)((B + coop_cands - 1) / coop_cands));
+    if (lanes == 1 && stream_lds <= 60 * 1024 && a.search == 0) { const int rcp = mg_traj_paths(p->ctx, (size_t)B * a.T * 24, &a.paths); if (rcp != MG_OK) return rcp; }
     mg_prof_begin(p->ctx, 10);
     if (lanes == 8) hipLaunchKernelGGL(mg_trajectory_coop_kernel<8>, coop_grid, dim3(MG_TRAJ_COOP_BLOCK), coop_lds, p->ctx->stream, a);
     else if (lanes == 4) hipLaunchKernelGGL(mg_trajectory_coop_kernel<4>, coop_grid, dim3(MG_TRAJ_COOP_BLOCK), coop_lds, p->ctx->stream, a);
@@ -582,6 +633,15 @@ extern "C" int mg_score_trajectories(int32_t n, mg_primitive *const *prims, cons
             if (rc != MG_OK) return rc;
             m.wg0[i + 1] = m.wg0[i] + per;
         }
+        if (!coop && m.a[0].search == 0) {      // the streaming kernels' root paths: one block of the context's buffer per scorer
+            size_t off = 0;
+            double *base = nullptr;
+            for (int i = 0; i < m.n; i++) off += (size_t)B * m.a[i].T * 3;
+            const int rcp = mg_traj_paths(ctx, off * 8, &base);
+            if (rcp != MG_OK) return rcp;
+            off = 0;
+            for (int i = 0; i < m.n; i++) { m.a[i].paths = base + off; off += (size_t)B * m.a[i].T * 3; }
+        }
         mg_prof_begin(ctx, 10);
         if (lanes == 8) hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel<8>, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
         else if (lanes == 4) hipLaunchKernelGGL(mg_trajectory_coop_multi_kernel<4>, dim3((unsigned)m.wg0[m.n]), dim3(MG_TRAJ_COOP_BLOCK), lds, ctx->stream, m);
@@ -607,7 +667,7 @@ static int mg_traj_points_launch(const char *who, mg_primitive *p, const mg_traj
     mg_traj_args a;
     a.poly = t->d_poly; a.E = t->d_E; a.mean = t->d_mean; a.lat = nullptr; a.i0 = nullptr; a.w = nullptr; a.out = errors_dev; a.res = residuals_dev;
     a.B = B; a.ld = 0; a.T = T; a.L = p->L; a.NB = p->NB; a.n_seg = t->n_seg; a.G = t->granularity; a.lat_f64 = 1;
-    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = points_dev; a.res_u = params_dev; a.res_n = evals_dev;
+    a.accumulate = accumulate ? 1 : 0; a.min_u = min_u; a.weight = weight; a.points = points_dev; a.res_u = params_dev; a.res_n = evals_dev; a.paths = nullptr;
     a.search = p->ctx->opt[MG_OPT_TRAJECTORY_SEARCH] == 1 ? 1 : 0;
     a.align_mode = 0;
     for (double &v : a.al) v = 0.0;
