@@ -166,6 +166,9 @@ extern "C" int mg_debug_dump_stamps(void) {
 #ifndef MG_SWEEP_FAST
 #define MG_SWEEP_FAST 1      // the lean loop over a chunk's full trips (see the chunk-stationary kernel)
 #endif
+#ifndef MG_GMM_PAIR_LOADS
+#define MG_GMM_PAIR_LOADS 0   // the fused mixture's component fragments two components per round of loads (A/B: tools/build_variant.sh)
+#endif
 #define MG_FUSE_MAX_KK 10   // fused mixture scoring: k-steps (4 latent components each) that fit the register budget
 #define MG_WS_NPW 4      // producer waves
 #define MG_WS_NCW 8      // consumer waves, two candidates each
@@ -451,12 +454,29 @@ __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const doubl
             mg_gmm_load_x<KK, LAT_F64>(xa, lat, ba, na, ld, L, cl, g);
             mg_gmm_load_x<KK, LAT_F64>(xb, lat, bb, nb, ld, L, cl, g);
         }
+#if MG_GMM_PAIR_LOADS
+        // two components' fragments requested together: in the tail every load waits behind the store stream's queue, so a round of
+        // loads is a round trip of microseconds -- one round for a wave's two components (K = 8) instead of two
+        for (int k = pw; k < gK; k += 2 * MG_WS_NPW) {
+            const int k2 = k + MG_WS_NPW;
+            mg_gmm_frag<KK> f, f2;
+            mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl);
+            if (k2 < gK) mg_gmm_load_component<KK>(f2, gPpack, gmP, gcst, k2, gJT, lane, cl);
+            mg_gmm_apply_component(f, k, gJT, xa, gterms, cl, g);
+            if (has_b) mg_gmm_apply_component(f, k, gJT, xb, gterms + gK * 16, cl, g);
+            if (k2 < gK) {
+                mg_gmm_apply_component(f2, k2, gJT, xa, gterms, cl, g);
+                if (has_b) mg_gmm_apply_component(f2, k2, gJT, xb, gterms + gK * 16, cl, g);
+            }
+        }
+#else
         for (int k = pw; k < gK; k += MG_WS_NPW) {
             mg_gmm_frag<KK> f;
             mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl);
             mg_gmm_apply_component(f, k, gJT, xa, gterms, cl, g);
             if (has_b) mg_gmm_apply_component(f, k, gJT, xb, gterms + gK * 16, cl, g);
         }
+#endif
     }
     mg_publish(prog + 16, pw, lane, group + 1);   // gdone[pw]
 }

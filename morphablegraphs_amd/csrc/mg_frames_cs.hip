@@ -37,6 +37,9 @@
 #ifndef MG_CS_NSP
 #define MG_CS_NSP 4      // how many of the sweep waves (the first ones, which sweep fastest) produce row tiles as well
 #endif
+#ifndef MG_CS_GMM_EARLY
+#define MG_CS_GMM_EARLY 0   // 1: the fused mixture's first group of tiles is scored while the pipeline fills (below), not in the tail -- A/B only: SLOWER
+#endif
 #define MG_CS_BLOCK (64 * (MG_CS_NPW + MG_CS_NCW))
 template <int KK> struct mg_cs_cfg {
     static constexpr int TPWP = 120 / KK < 17 ? 120 / KK : 17;   // row tiles a row producer keeps in registers (TPWP * KK VGPRs)
@@ -241,6 +244,25 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 if (e0 + i * MEAN_NTH < n_mean) lds_mean[e0 + i * MEAN_NTH] = mv[i];
             for (int e = e0 + 6 * MEAN_NTH; e < n_mean; e += MEAN_NTH) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // (windows beyond 6 * MEAN_NTH rows)
             mg_publish(prog + MG_CS_PROG_MEAN, cj - MG_CS_NSP, lane, 1);
+        }
+        if constexpr (FUSE_GMM && MG_CS_GMM_EARLY) {
+            // Round 5's structural attempt, kept for A/B (tools/build_variant.sh x -DMG_CS_GMM_EARLY=1): the mixture while the pipeline
+            // fills.  In the tail (the default) the mixture costs what a launch of its own costs -- the frames alone 69.3 us, the mixture
+            // kernel alone 11.2 us, fused 78.5-82 us: four waves' chains of float64 MFMAs behind 90 KB of fragment loads that wait in
+            // the CU's memory queue behind the last unit's stores.  The four sweep waves that produce nothing are idle until the first
+            // unit is in LDS (~8 us after entry, the HBM idle): here they score the workgroup's first two tiles then, at the lowest
+            // priority.  MEASURED SLOWER: 83.9 against 78.5 us in one process on one buffer (tools/ab.py) -- the fragment loads delay the
+            // row fragments, the float64 MFMAs the first unit, and every microsecond of the first unit is a microsecond of the kernel.
+            // (Two more attempts at the tail's round trips: both components of a wave requested at once, MG_GMM_PAIR_LOADS: 73 spilled
+            // registers, 89.8 us; a component held in the idle sweep waves' registers from the start: 38 spilled, 87.4 us.)
+            if (!producing) {
+                __builtin_amdgcn_s_setprio(0);
+                mg_lds_int *gprog = prog + MG_CS_PROG_GMM;
+                const int gw = cj - MG_CS_NSP;
+                mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, gw, lane, 0);
+                if (gw < 2) mg_fused_gmm_finish(gprog, logp, a.B, a.n_tiles, gK, gw, lane, 0);
+                __builtin_amdgcn_s_setprio(3);
+            }
         }
         const int nql = (D - nroot + 3) >> 2;             // quad lanes per sample
         const int gl = nql + 1;                           // + the root lane
@@ -726,8 +748,10 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     }
     if (FUSE_GMM && wave < MG_WS_NPW) {   // the mixture: the four producer waves, as in the tile-major kernel
         mg_lds_int *gprog = prog + MG_CS_PROG_GMM;
-        mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
-        if (wave < 2) mg_fused_gmm_finish(gprog, logp, a.B, a.n_tiles, gK, wave, lane, 0);
+        if constexpr (!MG_CS_GMM_EARLY) {
+            mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
+            if (wave < 2) mg_fused_gmm_finish(gprog, logp, a.B, a.n_tiles, gK, wave, lane, 0);
+        }
         const int64_t my_tiles = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x - (int64_t)blockIdx.x * a.n_tiles / gridDim.x;
         if (my_tiles > 2) {
             mg_wait_producers(gprog + 24, 1);   // gfin[0], gfin[1]: both term buffers are free again
