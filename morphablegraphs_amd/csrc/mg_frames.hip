@@ -58,7 +58,7 @@ bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_
 // scan found nothing better; a whole box can be like that -- the tile-major kernel is the faster one for the large outputs the class
 // exists for ('walk', us per step, chunk-stationary / tile-major: B = 8192 95.8 / 93.1 on a slow buffer and 78.4 / 82.8 on a fast
 // one in the same process; B = 16 384 195.2 / 186.4 slow), so there the batch-size rule gives way.
-int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused, const void *out) {
+int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused, const void *out, bool lat_f64) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t units = n_tiles * g->n_chunks;
     const int64_t grid0 = std::min<int64_t>(units, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
@@ -66,8 +66,12 @@ int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_
     const int want = p->ctx->opt[MG_OPT_FRAMES_KERNEL];
     bool cs = g->cs_ok && grid_cs >= g->n_chunks && grid_cs <= 4096 &&
               (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
+    // (the instantiations whose wave 0 does not fit the register budget -- 61 .. 64 latents; float64 latents from 53 on -- spill inside
+    // the unit loop, where scratch traffic queues behind the store stream: those shapes stay with the tile-major kernel unless asked for)
+    const bool cs_spills = p->KK >= 16 || (lat_f64 && p->KK >= 14);
     if (want == 2 && !cs) return -1;
     if (want == 1) cs = false;
+    else if (want == 0 && cs_spills) cs = false;
     else if (want == 0) cs = cs && units >= 2 * grid0 && mg_output_class(p->ctx, out) != 0;
     return cs ? 2 : 1;
 }
@@ -101,7 +105,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
     for (int i = 0; i < MG_ARG_CHUNKS; i++) a.ck[i] = i < g->n_chunks ? g->chunks[i] : mg_chunk{};
     a.cs_magic = a.cs_per = a.cs_rem = 0;
     const bool lf = (ldt == MG_F64);
-    const int which = mg_frames_kernel_choice(p, g, B, logp != nullptr, out);
+    const int which = mg_frames_kernel_choice(p, g, B, logp != nullptr, out, lf);
     if (which < 0) {
         mg_set_error("mg_back_project_frames: the chunk-stationary kernel does not cover this shape (window of %d row tiles, %d bytes of LDS)",
                      g->max_tiles, g->cs_lds_bytes);

@@ -578,7 +578,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             rpp[t] = Erpack + ((size_t)(ck.rrt0 + tc) * KK) * 64 + lane;
         }
         // the root rows' float64 fragments stay in registers as well where the budget allows (6 KK VGPRs)
-        constexpr bool RR = KK <= 10;
+        constexpr bool RR = KK <= (LAT_F64 ? 8 : 10);   // (float64 latents double wave 0's latent-tile registers: the root fragments stream then)
         double rp_reg[3][RR ? KK : 1];
         if (RR) {
 #pragma unroll
@@ -688,19 +688,22 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                     for (int t = 0; t < 3; t++)
                         racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp_reg[t][RR ? q2 : 0], (double)s64frag[q2], racc[t], 0, 0, 0);
             } else {
-                constexpr int KH = KK / 2;
+                // the root rows' fragments streamed from L2 in groups of CH k-steps (a half of them up to 12 k-steps; four at a time
+                // beyond: 3 x KK / 2 float64 fragments beside wave 0's other k-step arrays spilled 14-29 registers inside the unit loop
+                // for 53 .. 64 latents -- round 4's code-object metadata)
+                constexpr int CH = KK <= 12 ? KK / 2 : 4;
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    double rp[3][KH];
+                for (int h0 = 0; h0 < KK; h0 += CH) {
+                    double rp[3][CH];
 #pragma unroll
                     for (int t = 0; t < 3; t++)
 #pragma unroll
-                        for (int q2 = 0; q2 < KH; q2++) rp[t][q2] = rpp[t][(h * KH + q2) * 64];
+                        for (int q2 = 0; q2 < CH; q2++) rp[t][q2] = rpp[t][(h0 + q2 < KK ? h0 + q2 : KK - 1) * 64];
 #pragma unroll
-                    for (int q2 = 0; q2 < KH; q2++)
+                    for (int q2 = 0; q2 < CH; q2++)
 #pragma unroll
                         for (int t = 0; t < 3; t++)
-                            racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q2], (double)s64frag[h * KH + q2], racc[t], 0, 0, 0);
+                            if (h0 + q2 < KK) racc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[t][q2], (double)s64frag[h0 + q2 < KK ? h0 + q2 : KK - 1], racc[t], 0, 0, 0);
                 }
             }
             MG_SUB_STAMP(12, u, 1);

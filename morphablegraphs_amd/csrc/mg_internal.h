@@ -239,7 +239,7 @@ struct mg_constraint_set {
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
                           int prof_slot = -1, int prof_slot2 = -1);   // prof_slot >= 0: the launch carries its own timing events
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B);
-int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused, const void *out = nullptr);
+int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_t B, bool fused, const void *out = nullptr, bool lat_f64 = false);
 int mg_output_class(mg_context *ctx, const void *p);   // mg_placement.hip: 1 fast, 0 slow (a piece of a placed region), -1 not the arena's
 int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused);
 int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int which);
