@@ -557,6 +557,24 @@ int mg_score_frame_constraints(mg_primitive *prim, int32_t n_constraints, const 
                                const int32_t *n_times, const int32_t *n_joints, int64_t n_samples, double *errors_dev, int accumulate,
                                double *const *residuals_dev);
 
+/* A planner step's per-frame constraint lists AND the options' first minima, for options whose candidates and errors are on the device
+ * already (mg_options_step drew them and scored their keyframe constraints, mg_score_trajectories added their root trajectories) -- the
+ * reference scores every option's whole constraint list inside one planner step (motion_generator/graph_walk_planner.py:184-226,
+ * constraints/motion_primitive_constraints.py:100-122): TWO launches whatever the number of options (every option's joint tracks;
+ * every option's list + its first minimum under mg_argmin_first's rule) and one read-back of the result records.
+ *   plans[k]: NULL for an option without a per-frame list (its first minimum is still taken); grids, tracks_dev:
+ *   [n_options][MG_TRACK_MAX_REQUESTS] (unused requests NULL; grids NULL = the canonical grid); constraints: [n_options][MG_FRAME_LIST_MAX],
+ *   n_constraints[k] <= MG_FRAME_LIST_MAX of them used (no MG_FRAME_JOINT_ROTATION: it reads a frame), request_of[k][i]: the plan's request
+ *   whose tracks constraint i reads; errors_dev[k] (n_samples) float64: read, added to, written back; results_dev: record k at
+ *   k * result_stride = {int64 index, float64 error, float64 latent[n_gmm_dims]}; results_host: NULL or where the records are copied.
+ * The additions are mg_joint_tracks + mg_score_frame_constraints' per option, in list order: the same errors, the same winners. */
+#define MG_TRACK_MAX_REQUESTS 4
+#define MG_FRAME_LIST_MAX 4
+int mg_options_frame_lists(int32_t n_options, mg_primitive *const *prims, mg_track_plan *const *plans, const void *const *latents_dev, int latent_dtype,
+                           int64_t n_samples, const int64_t *ld, const mg_alignment_desc *const *alignments, const mg_time_grid *const *grids,
+                           double *const *tracks_dev, const int32_t *n_constraints, const mg_frame_constraint_desc *const *constraints,
+                           const int32_t *request_of, double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host);
+
 /* ---- hot path, device pointers ------------------------------------------------------ */
 
 /* MotionPrimitive.back_project(s, False).get_motion_vector() for a batch

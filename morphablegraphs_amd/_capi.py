@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "mg_spline_evaluate_host", "mg_gmm_log_prob_host", "mg_gmm_sample_host", "mg_score_constraints_host",
     "mg_score_constraint_residuals", "mg_objective_error_and_naturalness", "mg_gmm_log_prob_jac", "mg_score_constraint_residuals_host",
     "mg_gmm_log_prob_jac_host", "mg_constraint_set_create_fk", "mg_constraint_set_create_aligned", "mg_constraint_set_create_full", "mg_constraint_set_update", "mg_best_candidate", "mg_best_candidate_host",
-    "mg_align_frames", "mg_frame_constraint_width", "mg_score_frame_constraint", "mg_score_frame_constraints", "mg_track_plan_create", "mg_track_plan_destroy", "mg_joint_tracks",
+    "mg_align_frames", "mg_frame_constraint_width", "mg_score_frame_constraint", "mg_score_frame_constraints", "mg_options_frame_lists", "mg_track_plan_create", "mg_track_plan_destroy", "mg_joint_tracks",
     "mg_score_constraint_residuals_chained", "mg_option_step", "mg_options_step", "mg_options_step_device_counts", "mg_option_step_rows", "mg_options_step_rows", "mg_gmm_sample_rows", "mg_dist_broadcast",
 ]
 
@@ -103,6 +103,7 @@ MG_FRAME_CA_POSITION, MG_FRAME_DISCRETE_TRAJECTORY, MG_FRAME_LOCAL_TRAJECTORY, M
 MG_FRAME_JOINT_TRAJECTORY = 6      # a TrajectoryConstraint on any joint as a member of a constraint list (start_arc = its min_u)
 MG_FRAME_MAX_JOINTS = 8
 MG_TRACK_MAX_REQUESTS = 4
+MG_FRAME_LIST_MAX = 4        # per-frame constraints of one option in mg_options_frame_lists
 
 
 class FrameConstraintDesc(C.Structure):   # struct mg_frame_constraint_desc
@@ -306,6 +307,7 @@ def load_library(path=None):
         "mg_track_plan_create": [vp, vp, i32, vp, vp, i32, C.POINTER(vp)],
         "mg_joint_tracks": [vp, vp, i32, i64, i64, vp, vp, vp],
         "mg_score_frame_constraints": [vp, i32, vp, vp, vp, vp, i64, vp, i32, vp],
+        "mg_options_frame_lists": [i32, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp],
         "mg_options_step": [i32, vp, vp, i64, vp, vp, vp, i32, vp, vp, vp, i64, vp],
         "mg_options_step_device_counts": [i32, vp, vp, i64, vp, vp, i32, vp, vp, vp, i64, vp, vp],
         "mg_gmm_log_prob_jac": [vp, vp, i32, i64, i64, vp],

@@ -12,6 +12,7 @@
 // Oracle: oracle/mg_oracle.py per_frame_constraint_residuals.  PARITY UNPINNED where anim_utils' forward kinematics is involved;
 // the arc-length look-up is pinned (tests/golden/trajectory_spline.npz through the oracle's restatement).
 #include <cmath>
+#include <cstring>
 
 #include <algorithm>
 #include <new>
@@ -351,6 +352,88 @@ __global__ __launch_bounds__(MG_FC_BLOCK) void mg_frame_constraint_list_kernel(c
     L.out[b] = total;
 }
 
+#define MG_OPT_LISTS_MAX 24
+struct mg_opt_wgs { int32_t n; int32_t wg0[MG_OPT_LISTS_MAX + 1]; };
+// A planner step's per-frame lists, every option's in ONE launch, and the options' first minima with them (round 5; reference
+// motion_generator/graph_walk_planner.py:184-226 scores every option's whole constraint list inside one step).  Workgroups
+// [wg0[k], wg0[k + 1]) take option k: a lane adds its candidate's list (an empty list: nothing to add) to the error the launches before
+// left in errors[k] -- the single launches' additions in their order, the same bits -- and the option's first minimum is taken right
+// here: lanes -> wave -> one {value, index} per workgroup in global memory; the workgroup whose arrival is the option's last (a fence,
+// a counter) combines them under the total order (smaller value, then smaller index; NaN and +inf never win; nothing finite: index 0,
+// +inf -- mg_argmin_kernel's rule), writes {index, error} and copies the winning candidate behind them.  Release / acquire fences here:
+// 64 workgroups per option, not the one-launch step's thousand.
+struct mg_opt_list_entry {
+    mg_fc_list L;
+    const void *x;          // the option's candidates (B, ld)
+    int64_t ld;
+    int32_t x_f64, Lw;      // Lw: columns of the winner that go into the record
+    char *result;           // {int64 index, float64 error, float64 latent[Lw]}
+};
+struct mg_min_partial { double v; int64_t i; };
+template <bool TABLES_LDS>
+__global__ __launch_bounds__(MG_FC_BLOCK) void mg_options_lists_kernel(const mg_opt_list_entry *__restrict__ tab, const mg_opt_wgs w, mg_min_partial *__restrict__ partials,
+                                                                      int32_t *__restrict__ counters) {
+    extern __shared__ double fc_lds[];
+    int k = 0;
+    while (k + 1 < w.n && (int)blockIdx.x >= w.wg0[k + 1]) k++;
+    const mg_opt_list_entry &o = tab[k];
+    const mg_fc_list &L = o.L;
+    if constexpr (TABLES_LDS) {
+        for (int i = 0; i < L.n; i++) mg_fc_stage_tables(L.c[i], fc_lds);
+        __syncthreads();
+    }
+    const int lane = threadIdx.x;
+    const int64_t b = ((int64_t)blockIdx.x - w.wg0[k]) * MG_FC_BLOCK + lane;
+    double best = INFINITY;
+    int64_t bi = INT64_MAX;
+    if (b < L.B) {
+        double total = L.accumulate ? L.out[b] : 0.0;
+        for (int i = 0; i < L.n; i++) {
+            const double e = mg_fc_evaluate<TABLES_LDS>(L.c[i], b, fc_lds);
+            total = (i == 0 && !L.accumulate) ? e : total + e;
+        }
+        if (L.n > 0) L.out[b] = total;
+        if (total < INFINITY) { best = total; bi = b; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const long long oi = __shfl_down((long long)bi, off, 64);
+        mg_min_combine(best, bi, ov, (int64_t)oi);
+    }
+    const int nwg = w.wg0[k + 1] - w.wg0[k];
+    int last = 0;
+    if (lane == 0) {
+        partials[blockIdx.x].v = best;
+        partials[blockIdx.x].i = bi;
+        __threadfence();                                              // release: the partial (and this workgroup's errors) before the count
+        last = atomicAdd(&counters[k], 1) == nwg - 1 ? 1 : 0;
+    }
+    last = __shfl(last, 0, 64);
+    if (!last) return;
+    __threadfence();                                                  // acquire: every other workgroup's partial
+    best = INFINITY; bi = INT64_MAX;
+    for (int q = lane; q < nwg; q += 64) {
+        const volatile mg_min_partial *pp = &partials[w.wg0[k] + q];
+        mg_min_combine(best, bi, pp->v, pp->i);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(best, off, 64);
+        const long long oi = __shfl_down((long long)bi, off, 64);
+        mg_min_combine(best, bi, ov, (int64_t)oi);
+    }
+    best = __shfl(best, 0, 64);
+    bi = (int64_t)__shfl((long long)bi, 0, 64);
+    if (bi == INT64_MAX) { bi = 0; best = INFINITY; }
+    if (lane == 0) {
+        ((int64_t *)o.result)[0] = bi;
+        ((double *)o.result)[1] = best;
+        counters[k] = 0;                                              // ready for the next launch (stream ordered)
+    }
+    double *row = (double *)(o.result + 16);
+    for (int i = lane; i < o.Lw; i += 64)
+        row[i] = o.x_f64 ? ((const double *)o.x)[bi * o.ld + i] : (double)((const float *)o.x)[bi * o.ld + i];
+}
+
 extern "C" int mg_frame_constraint_width(const mg_frame_constraint_desc *c, int32_t n_times) {
     if (!c) return 0;
     switch (c->type) {
@@ -446,6 +529,7 @@ static int mg_fc_attributes(mg_context *ctx) {
     if (ctx->attr_traj & 8u) return MG_OK;
     MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frame_constraint_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_frame_constraint_list_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_options_lists_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ctx->attr_traj |= 8u;
     return MG_OK;
 }
@@ -567,14 +651,13 @@ struct mg_track_args {
 // workgroup) feeds that many fma chains.
 #define MG_TRACK_BLOCK 128
 #define MG_TRACK_CANDS 4
-__global__ __launch_bounds__(MG_TRACK_BLOCK) void mg_joint_tracks_kernel(const mg_track_args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void mg_joint_tracks_body(const mg_track_args &a, const int64_t block, unsigned char *smem) {
     const int ncp = a.NB * a.n_chan;
     double *cp_all = (double *)smem;                            // [CANDS][NB][n_chan] control points of the kept channels
     double *s_all = cp_all + (size_t)MG_TRACK_CANDS * ncp;      // [CANDS][L]
     double *al_all = s_all + (size_t)MG_TRACK_CANDS * a.L;      // [CANDS][8]: c, s, tx, tz, ty, aw, ay
     int *slot = (int *)(al_all + MG_TRACK_CANDS * 8);           // [D]
-    const int64_t b0 = (int64_t)blockIdx.x * MG_TRACK_CANDS;
+    const int64_t b0 = block * MG_TRACK_CANDS;
     const int tid = threadIdx.x, nc = a.n_chan, D = a.D, R = a.R, L = a.L;
     for (int e = tid; e < MG_TRACK_CANDS * L; e += MG_TRACK_BLOCK) {
         const int c = e / L, k = e - c * L;
@@ -699,6 +782,19 @@ __global__ __launch_bounds__(MG_TRACK_BLOCK) void mg_joint_tracks_kernel(const m
     }
 }
 
+__global__ __launch_bounds__(MG_TRACK_BLOCK) void mg_joint_tracks_kernel(const mg_track_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mg_joint_tracks_body(a, blockIdx.x, smem);
+}
+// The tracks of SEVERAL options' candidates in one launch (a planner step: every option its own primitive, plan and candidates): the
+// per-option arguments sit in a device table, workgroups [wg0[k], wg0[k + 1]) belong to option k.
+__global__ __launch_bounds__(MG_TRACK_BLOCK) void mg_joint_tracks_multi_kernel(const mg_track_args *__restrict__ tab, const mg_opt_wgs w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int k = 0;
+    while (k + 1 < w.n && (int)blockIdx.x >= w.wg0[k + 1]) k++;
+    mg_joint_tracks_body(tab[k], (int64_t)blockIdx.x - w.wg0[k], smem);
+}
+
 extern "C" void mg_track_plan_destroy(mg_track_plan *pl) {
     if (!pl) return;
     if (pl->prim) { (void)hipSetDevice(pl->prim->ctx->device); (void)hipStreamSynchronize(pl->prim->ctx->stream); }
@@ -796,13 +892,12 @@ extern "C" int mg_track_plan_create(mg_primitive *p, const mg_skeleton_desc *sk,
 
 // grids[q] (NULL = the canonical grid) and tracks_dev[q] (n, T_q, n_joints[q], 3) float64 per request; alignment NULL = local
 // coordinates, else the record mg_constraint_set_create_aligned takes (joint must be the plan's align_joint, or MG_ALIGN_START_POSE).
-extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64_t B, int64_t ld, const mg_alignment_desc *al,
-                               const mg_time_grid *const *grids, double *const *tracks_dev) {
-    if (!pl || !pl->prim || !grids || !tracks_dev) { mg_set_error("mg_joint_tracks: bad arguments"); return MG_ERR_INVALID_ARGUMENT; }
+static int mg_track_fill_args(const char *who, mg_track_plan *pl, const void *lat, int dt, int64_t B, int64_t ld, const mg_alignment_desc *al,
+                              const mg_time_grid *const *grids, double *const *tracks_dev, mg_track_args *out, size_t *lds_out) {
+    if (!pl || !pl->prim || !grids || !tracks_dev) { mg_set_error("%s: bad arguments", who); return MG_ERR_INVALID_ARGUMENT; }
     mg_primitive *p = pl->prim;
-    if (B < 0 || B >= ((int64_t)1 << 31) || (dt != MG_F32 && dt != MG_F64) || ld < p->L) { mg_set_error("mg_joint_tracks: bad batch (ld %lld < %d components?)", (long long)ld, p->L); return MG_ERR_INVALID_ARGUMENT; }
-    if (B == 0) return MG_OK;
-    if (!lat) { mg_set_error("mg_joint_tracks: latents are NULL"); return MG_ERR_INVALID_ARGUMENT; }
+    if (B < 0 || B >= ((int64_t)1 << 31) || (dt != MG_F32 && dt != MG_F64) || ld < p->L) { mg_set_error("%s: bad batch (ld %lld < %d components?)", who, (long long)ld, p->L); return MG_ERR_INVALID_ARGUMENT; }
+    if (B > 0 && !lat) { mg_set_error("%s: latents are NULL", who); return MG_ERR_INVALID_ARGUMENT; }
     mg_track_args a = {};
     a.Et64 = p->d_Et64; a.mean = p->d_mean; a.lat = lat; a.B = B; a.ld = ld; a.L = p->L; a.R = p->R; a.D = p->D; a.NB = p->NB; a.lat_f64 = dt == MG_F64 ? 1 : 0;
     a.n_requests = pl->n_requests; a.n_chan = pl->n_chan; a.records = pl->d_records; a.align_rec = pl->d_align_rec; a.chan = pl->d_chan; a.slot = pl->d_slot;
@@ -810,33 +905,169 @@ extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64
     for (int q = 0; q <= pl->n_requests; q++) a.req_joint0[q] = pl->req_joint0[q];
     for (int q = 0; q < pl->n_requests; q++) {
         const mg_time_grid *g = grids[q] ? grids[q] : p->canonical;
-        if (g->prim != p) { mg_set_error("mg_joint_tracks: grid %d belongs to another primitive", q); return MG_ERR_INVALID_ARGUMENT; }
-        if (!tracks_dev[q] || g->T < 1) { mg_set_error("mg_joint_tracks: request %d has no output or an empty grid", q); return MG_ERR_INVALID_ARGUMENT; }
+        if (g->prim != p) { mg_set_error("%s: grid %d belongs to another primitive", who, q); return MG_ERR_INVALID_ARGUMENT; }
+        if (!tracks_dev[q] || g->T < 1) { mg_set_error("%s: request %d has no output or an empty grid", who, q); return MG_ERR_INVALID_ARGUMENT; }
         a.T[q] = g->T; a.i0[q] = g->d_i0; a.w[q] = g->d_w; a.out[q] = tracks_dev[q];
     }
     a.align_mode = 0;
     if (al) {
         const double hn = std::sqrt(al->heading[0] * al->heading[0] + al->heading[1] * al->heading[1]);
-        if (!(hn > 0.0) || !std::isfinite(hn)) { mg_set_error("mg_joint_tracks: heading is zero or not finite"); return MG_ERR_INVALID_ARGUMENT; }
+        if (!(hn > 0.0) || !std::isfinite(hn)) { mg_set_error("%s: heading is zero or not finite", who); return MG_ERR_INVALID_ARGUMENT; }
         a.align_mode = al->joint == MG_ALIGN_START_POSE ? 2 : 1;
-        if (a.align_mode == 1 && pl->align_m < 0) { mg_set_error("mg_joint_tracks: the plan was made without an aligning joint"); return MG_ERR_INVALID_ARGUMENT; }
+        if (a.align_mode == 1 && pl->align_m < 0) { mg_set_error("%s: the plan was made without an aligning joint", who); return MG_ERR_INVALID_ARGUMENT; }
         if (a.align_mode == 1 && al->joint != pl->align_joint) {
-            mg_set_error("mg_joint_tracks: the record aligns through joint %d, the plan was made for joint %d", al->joint, pl->align_joint);
+            mg_set_error("%s: the record aligns through joint %d, the plan was made for joint %d", who, al->joint, pl->align_joint);
             return MG_ERR_INVALID_ARGUMENT;
         }
         a.h0 = al->heading[0] / hn; a.h1 = al->heading[1] / hn; a.px = al->position[0]; a.py = al->position[1]; a.pz = al->position[2];
         for (int e = 0; e < 3; e++) a.ref[e] = al->ref_dir[e];
     }
     const size_t lds = (size_t)MG_TRACK_CANDS * ((size_t)p->NB * pl->n_chan + p->L + 8) * 8 + (size_t)p->D * 4 + 16;
-    if (lds > 160 * 1024 - 64) { mg_set_error("mg_joint_tracks: %d basis functions x %d channels do not fit LDS", p->NB, pl->n_chan); return MG_ERR_UNSUPPORTED; }
+    if (lds > 160 * 1024 - 64) { mg_set_error("%s: %d basis functions x %d channels do not fit LDS", who, p->NB, pl->n_chan); return MG_ERR_UNSUPPORTED; }
+    *out = a;
+    *lds_out = lds;
+    return MG_OK;
+}
+static int mg_track_attributes(mg_context *ctx) {
+    if (ctx->attr_traj & 4u) return MG_OK;
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_joint_tracks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_joint_tracks_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->attr_traj |= 4u;
+    return MG_OK;
+}
+
+extern "C" int mg_joint_tracks(mg_track_plan *pl, const void *lat, int dt, int64_t B, int64_t ld, const mg_alignment_desc *al,
+                               const mg_time_grid *const *grids, double *const *tracks_dev) {
+    mg_track_args a;
+    size_t lds = 0;
+    { const int rc = mg_track_fill_args("mg_joint_tracks", pl, lat, dt, B, ld, al, grids, tracks_dev, &a, &lds); if (rc != MG_OK) return rc; }
+    if (B == 0) return MG_OK;
+    mg_primitive *p = pl->prim;
     MG_HIP_CHECK(hipSetDevice(p->ctx->device));
-    if (lds > 48 * 1024 && !(p->ctx->attr_traj & 4u)) {
-        MG_HIP_CHECK(hipFuncSetAttribute((const void *)mg_joint_tracks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        p->ctx->attr_traj |= 4u;
-    }
+    if (lds > 48 * 1024) { const int rc = mg_track_attributes(p->ctx); if (rc != MG_OK) return rc; }
     mg_prof_begin(p->ctx, 8);
     hipLaunchKernelGGL(mg_joint_tracks_kernel, dim3((unsigned)((B + MG_TRACK_CANDS - 1) / MG_TRACK_CANDS)), dim3(MG_TRACK_BLOCK), lds, p->ctx->stream, a);
     mg_prof_end(p->ctx, 8);
     MG_HIP_CHECK(hipGetLastError());
+    return MG_OK;
+}
+
+// One planner step's per-frame constraint lists and first minima (mg_options_lists_kernel above), for options whose candidates and
+// errors are on the device already (mg_options_step drew them and scored their keyframe constraints; mg_score_trajectories added the
+// root trajectories): TWO launches whatever the number of options -- every option's joint tracks (mg_joint_tracks_multi_kernel), then
+// every option's list + its first minimum -- and one read-back of the result records.
+//   plans[k]: NULL for an option without a per-frame list (its first minimum is still taken); grids / tracks_dev: [n_options][MG_TRACK_MAX_REQUESTS]
+//   (unused requests NULL); constraints: [n_options][MG_FRAME_LIST_MAX], n_constraints[k] of them used, request_of[k][i]: the plan's
+//   request whose tracks constraint i reads; errors_dev[k] (n_samples) float64: read, added to, written back;
+//   results_dev: record k at k * result_stride: {int64 index, float64 error, float64 latent[n_gmm_dims]}; results_host: NULL or where they are copied.
+// The additions are mg_joint_tracks + mg_score_frame_constraints' per option, in the list's order: the same errors, the same winners.
+extern "C" int mg_options_frame_lists(int32_t n_options, mg_primitive *const *prims, mg_track_plan *const *plans, const void *const *lat_dev, int dt, int64_t B,
+                                      const int64_t *ld, const mg_alignment_desc *const *alignments, const mg_time_grid *const *grids, double *const *tracks_dev,
+                                      const int32_t *n_constraints, const mg_frame_constraint_desc *const *constraints, const int32_t *request_of,
+                                      double *const *errors_dev, void *results_dev, int64_t result_stride, void *results_host) {
+    if (n_options < 1 || n_options > MG_OPT_LISTS_MAX || !prims || !lat_dev || !ld || !n_constraints || !errors_dev || !results_dev || B < 1 ||
+        B >= ((int64_t)1 << 31) || (dt != MG_F32 && dt != MG_F64)) {
+        mg_set_error("mg_options_frame_lists: bad arguments (1 .. %d options)", MG_OPT_LISTS_MAX);
+        return MG_ERR_INVALID_ARGUMENT;
+    }
+    mg_context *ctx = prims[0] ? prims[0]->ctx : nullptr;
+    for (int k = 0; k < n_options; k++) {
+        if (!prims[k] || prims[k]->ctx != ctx || !lat_dev[k] || !errors_dev[k] || ld[k] < prims[k]->Lg || n_constraints[k] < 0 || n_constraints[k] > MG_FC_LIST_MAX ||
+            result_stride < 16 + 8 * (int64_t)prims[k]->Lg || result_stride % 8 != 0) {
+            mg_set_error("mg_options_frame_lists: option %d: NULL pointer, another context, ld / result_stride too small, or more than %d constraints", k, MG_FC_LIST_MAX);
+            return MG_ERR_INVALID_ARGUMENT;
+        }
+        if (n_constraints[k] > 0 && (!plans || !plans[k] || plans[k]->prim != prims[k] || !grids || !tracks_dev || !constraints || !request_of)) {
+            mg_set_error("mg_options_frame_lists: option %d has constraints but no plan of its primitive (or no grids / tracks / constraints)", k);
+            return MG_ERR_INVALID_ARGUMENT;
+        }
+    }
+    MG_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<mg_track_args> targs;
+    std::vector<mg_opt_list_entry> lists((size_t)n_options);
+    mg_opt_wgs tw = {}, lw = {};
+    size_t t_lds = 0, l_lds = 0;
+    bool tables_ok = true;
+    const int wg_per = (int)((B + MG_FC_BLOCK - 1) / MG_FC_BLOCK), twg_per = (int)((B + MG_TRACK_CANDS - 1) / MG_TRACK_CANDS);
+    for (int k = 0; k < n_options; k++) {
+        mg_opt_list_entry &o = lists[(size_t)k];
+        memset(&o, 0, sizeof(o));
+        o.L.n = n_constraints[k]; o.L.accumulate = 1; o.L.B = B; o.L.out = errors_dev[k];
+        o.x = lat_dev[k]; o.ld = ld[k]; o.x_f64 = dt == MG_F64 ? 1 : 0; o.Lw = prims[k]->Lg; o.result = (char *)results_dev + (size_t)k * result_stride;
+        if (n_constraints[k] > 0) {
+            mg_track_plan *pl = plans[k];
+            mg_track_args a;
+            size_t lds = 0;
+            int rc = mg_track_fill_args("mg_options_frame_lists", pl, lat_dev[k], dt, B, ld[k], alignments ? alignments[k] : nullptr,
+                                        grids + (size_t)k * MG_TRACK_MAX_REQUESTS, tracks_dev + (size_t)k * MG_TRACK_MAX_REQUESTS, &a, &lds);
+            if (rc != MG_OK) return rc;
+            targs.push_back(a);
+            t_lds = std::max(t_lds, lds);
+            tw.wg0[tw.n + 1] = tw.wg0[tw.n] + twg_per;
+            tw.n++;
+            for (int i = 0; i < n_constraints[k]; i++) {
+                const int q = request_of[(size_t)k * MG_FC_LIST_MAX + i];
+                if (q < 0 || q >= pl->n_requests) { mg_set_error("mg_options_frame_lists: option %d constraint %d reads request %d of %d", k, i, q, pl->n_requests); return MG_ERR_INVALID_ARGUMENT; }
+                rc = mg_fc_args_from_desc("mg_options_frame_lists", prims[k], constraints[(size_t)k * MG_FC_LIST_MAX + i], a.out[q], B, a.T[q],
+                                          pl->req_joint0[q + 1] - pl->req_joint0[q], nullptr, &o.L.c[i]);
+                if (rc != MG_OK) return rc;
+            }
+            const size_t lds_l = mg_fc_place_tables(o.L.c, o.L.n);
+            bool has_tables = false;
+            for (int i = 0; i < o.L.n; i++)
+                for (int j = 0; j < MG_FRAME_MAX_JOINTS; j++) has_tables = has_tables || o.L.c[i].traj[j].poly != nullptr;
+            if (lds_l == 0 && has_tables) tables_ok = false;     // (one option's tables do not fit LDS: every option reads global memory)
+            l_lds = std::max(l_lds, lds_l);
+        }
+        lw.wg0[k + 1] = lw.wg0[k] + wg_per;
+    }
+    lw.n = n_options;
+    if (!tables_ok)
+        for (auto &o : lists)
+            for (int i = 0; i < o.L.n; i++)
+                for (int j = 0; j < MG_FRAME_MAX_JOINTS; j++) o.L.c[i].traj[j].poly_off = o.L.c[i].traj[j].arc_off = -1;
+    // the device tables, the partials and the counters: the context's, grown on demand
+    const size_t t_bytes = targs.size() * sizeof(mg_track_args), l_bytes = lists.size() * sizeof(mg_opt_list_entry);
+    const size_t p_bytes = (size_t)lw.wg0[n_options] * sizeof(mg_min_partial), c_off = (t_bytes + l_bytes + p_bytes + 255) / 256 * 256;
+    const size_t need = c_off + MG_OPT_LISTS_MAX * sizeof(int32_t);
+    if (ctx->lists_bytes < need) {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->lists_dev) (void)hipFree(ctx->lists_dev);
+        ctx->lists_dev = nullptr; ctx->lists_bytes = 0;
+        const size_t want = std::max<size_t>(need, (size_t)256 << 10);
+        MG_HIP_CHECK(hipMalloc(&ctx->lists_dev, want));
+        MG_HIP_CHECK(hipMemset(ctx->lists_dev, 0, want));     // (the counters start at zero; their place moves with the sizes, so: all of it)
+        ctx->lists_bytes = want; ctx->lists_counters_off = 0;
+    }
+    if (ctx->lists_counters_off != c_off) {                   // the counters' place moved: zero them there (stream ordered, before the launch)
+        MG_HIP_CHECK(hipMemsetAsync((char *)ctx->lists_dev + c_off, 0, MG_OPT_LISTS_MAX * sizeof(int32_t), ctx->stream));
+        ctx->lists_counters_off = c_off;
+    }
+    char *base = (char *)ctx->lists_dev;
+    if (t_bytes) MG_HIP_CHECK(hipMemcpyAsync(base, targs.data(), t_bytes, hipMemcpyHostToDevice, ctx->stream));
+    MG_HIP_CHECK(hipMemcpyAsync(base + t_bytes, lists.data(), l_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (tw.n > 0) {
+        if (t_lds > 48 * 1024) { const int rc = mg_track_attributes(ctx); if (rc != MG_OK) return rc; }
+        mg_prof_begin(ctx, 8);
+        hipLaunchKernelGGL(mg_joint_tracks_multi_kernel, dim3((unsigned)tw.wg0[tw.n]), dim3(MG_TRACK_BLOCK), t_lds, ctx->stream, (const mg_track_args *)base, tw);
+        mg_prof_end(ctx, 8);
+        MG_HIP_CHECK(hipGetLastError());
+    }
+    if (l_lds && tables_ok) { const int rc = mg_fc_attributes(ctx); if (rc != MG_OK) return rc; }
+    mg_prof_begin(ctx, 9);
+    if (l_lds && tables_ok)
+        hipLaunchKernelGGL(mg_options_lists_kernel<true>, dim3((unsigned)lw.wg0[n_options]), dim3(MG_FC_BLOCK), l_lds, ctx->stream,
+                           (const mg_opt_list_entry *)(base + t_bytes), lw, (mg_min_partial *)(base + t_bytes + l_bytes), (int32_t *)(base + c_off));
+    else
+        hipLaunchKernelGGL(mg_options_lists_kernel<false>, dim3((unsigned)lw.wg0[n_options]), dim3(MG_FC_BLOCK), 0, ctx->stream,
+                           (const mg_opt_list_entry *)(base + t_bytes), lw, (mg_min_partial *)(base + t_bytes + l_bytes), (int32_t *)(base + c_off));
+    mg_prof_end(ctx, 9);
+    MG_HIP_CHECK(hipGetLastError());
+    if (results_host) {
+        MG_HIP_CHECK(hipMemcpyAsync(results_host, results_dev, (size_t)n_options * result_stride, hipMemcpyDeviceToHost, ctx->stream));
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    } else {
+        MG_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // (the argument tables above were copied from this call's own host vectors)
+    }
     return MG_OK;
 }

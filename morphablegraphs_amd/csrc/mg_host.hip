@@ -155,6 +155,7 @@ extern "C" void mg_context_destroy(mg_context *ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->flag_block) (void)hipHostFree(ctx->flag_block);
     if (ctx->traj_paths) (void)hipFree(ctx->traj_paths);
+    if (ctx->lists_dev) (void)hipFree(ctx->lists_dev);
     for (auto &b : ctx->arena) (void)hipFree(b.base);
     for (auto &v : ctx->vmm) mg_vmm_release(ctx, v);
     (void)hipDeviceSynchronize();   // nothing of this process is in flight when the parked address ranges go back to the runtime

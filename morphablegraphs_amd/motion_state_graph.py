@@ -321,6 +321,55 @@ def constraint_fingerprint(clist):
         return None
 
 
+def _options_frame_lists(plan, steps, fast, extras, n, dtype):
+    """mg_options_frame_lists for the options in `fast` [(k, TrackScorer | None)]: [(index, error, winning latent as float64)]."""
+    import ctypes as C
+    vp, m = C.c_void_p, len(fast)
+    R, Q = _capi.MG_TRACK_MAX_REQUESTS, _capi.MG_FRAME_LIST_MAX
+    prims, plans, lats, errs = (vp * m)(), (vp * m)(), (vp * m)(), (vp * m)()
+    lds, ncons = (C.c_int64 * m)(), (C.c_int32 * m)()
+    grids, tracks, cons = (vp * (m * R))(), (vp * (m * R))(), (vp * (m * Q))()
+    req_of = (C.c_int32 * (m * Q))()
+    als, al_ptrs = [], (vp * m)()
+    ctx = steps[fast[0][0]][3]
+    for j, (k, scorer) in enumerate(fast):
+        name, node, prim, _, d_x, d_e, d_r, L, pvals = steps[k]
+        prims[j], lats[j], errs[j], lds[j] = prim.handle, _capi._dev_ptr(d_x), _capi._dev_ptr(d_e), L
+        alignment, sk = extras[k][2], extras[k][3]
+        if scorer is not None:
+            if not scorer.valid():
+                raise _capi.MGError("a track scorer's plan or trajectories were closed under it")
+            plans[j], ncons[j] = scorer.plan.handle, scorer.m
+            bufs = scorer._track_buffers(n)
+            for q, (g, b) in enumerate(zip(scorer.grids, bufs)):
+                grids[j * R + q] = g.handle if g is not None else None
+                tracks[j * R + q] = _capi._dev_ptr(b)
+            for i in range(scorer.m):
+                cons[j * Q + i] = C.addressof(scorer.descs[i])
+                req_of[j * Q + i] = scorer.req_of[i]
+            if alignment is not None:
+                al = _capi.ConstraintSet._marshal_alignment(alignment, scorer.plan.skeleton)
+                als.append(al)
+                al_ptrs[j] = C.addressof(al)
+    L_max = max(steps[k][7] for k, _ in fast)
+    stride = 16 + 8 * L_max
+    key = ("frame_lists_results", m, stride)
+    bufs = plan.get(key)
+    if bufs is None:
+        bufs = plan[key] = (ctx.malloc(m * stride), np.empty(m * stride, dtype=np.uint8))
+    d_res, host = bufs
+    code = _capi.MG_F64 if np.dtype(dtype) == np.float64 else _capi.MG_F32
+    _capi._check(ctx.lib.mg_options_frame_lists(m, prims, plans, lats, code, n, lds, al_ptrs, grids, tracks, ncons, cons, req_of, errs, d_res.ptr, stride,
+                                                 host.ctypes.data_as(vp)))
+    rec = host.reshape(m, stride)
+    out = []
+    for j in range(m):
+        idx = int(rec[j, 0:8].view(np.int64)[0])
+        err = float(rec[j, 8:16].view(np.float64)[0])
+        out.append((idx, err, rec[j, 16:].view(np.float64).copy()))
+    return out
+
+
 class HipPrimitiveSet(object):
     """separate_streams: every primitive gets its own libmg_hip context, i.e. its own HIP stream, so that the small,
     latency-bound launches of different options overlap on the GPU (evaluate_options_on_device)."""
@@ -609,8 +658,13 @@ class HipPrimitiveSet(object):
             finally:
                 for t in trs:
                     release_trajectory(t)
+        # the options' per-frame lists and first minima: every option's joint tracks in ONE launch, every option's list + first minimum
+        # in a second one, one read-back (mg_options_frame_lists; round 4: two launches per option + a first-minimum launch and two
+        # synchronising reads per option).  An option whose list the call does not take (a joint-rotation constraint, more than four
+        # constraints or requests) goes the per-option way below.
+        fast, slow = [], []
         for k, (trajectories, frames, alignment, sk) in extras.items():
-            name, node, prim, ctx, d_x, d_e, d_r, L, pvals = steps[k]
+            scorer = None
             if frames:
                 key = (k, _cs._freeze(frames), _cs._freeze(alignment), None if sk is None else sk.serial)
                 scorer = scorers.get(key)
@@ -624,14 +678,25 @@ class HipPrimitiveSet(object):
                                 old.close()
                         scorers.clear()
                     try:
-                        scorer = TrackScorer(prim, frames, sk, alignment)
+                        scorer = TrackScorer(steps[k][2], frames, sk, alignment)
                     except NotImplementedError:
                         scorer = False        # (a joint-rotation constraint, more than four requests: the frames chain)
                     scorers[key] = scorer
-                if scorer:
-                    scorer.score_dev(d_x, dtype, n, L, d_e, accumulate=True)
-                else:
-                    add_frame_constraints_dev(prim, ctx.download(d_x, (n, L), dtype), frames, sk, alignment, d_e, accumulate=True)
+            if (not frames or (scorer and scorer.m <= _capi.MG_FRAME_LIST_MAX)) and plan["one_context"]:
+                fast.append((k, scorer if frames else None))
+            else:
+                slow.append((k, scorer))
+        if fast:
+            out = _options_frame_lists(plan, steps, fast, extras, n, dtype)
+            for (k, _), (idx, err, row) in zip(fast, out):
+                results[steps[k][0]] = (row[:steps[k][7]].copy(), err)
+        for k, scorer in slow:
+            trajectories, frames, alignment, sk = extras[k]
+            name, node, prim, ctx, d_x, d_e, d_r, L, pvals = steps[k]
+            if scorer:
+                scorer.score_dev(d_x, dtype, n, L, d_e, accumulate=True)
+            else:
+                add_frame_constraints_dev(prim, ctx.download(d_x, (n, L), dtype), frames, sk, alignment, d_e, accumulate=True)
             idx, err = ctx.argmin_first(d_e, n, np.float64)
             row = ctx.download(d_x.ptr.value + idx * L * np.dtype(dtype).itemsize, (L,), dtype)
             results[name] = (row.astype(np.float64), err)

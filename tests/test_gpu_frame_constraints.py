@@ -513,3 +513,53 @@ def test_mixed_lists_add_in_list_order():
     for b, bc in zip(blocks, blocks_c):
         assert np.array_equal(b.view(np.uint64), bc.view(np.uint64))
     assert np.array_equal(total.view(np.uint64), total_c.view(np.uint64))
+
+
+def test_planner_step_with_per_frame_lists_is_four_launches():
+    """A planner step whose options carry root trajectories AND per-frame lists: one launch draws and keyframe-
+    scores every option (mg_options_step), one scores the options' trajectories side by side (mg_score_trajectories), one makes every
+    option's joint tracks and one adds every option's list and takes every option's first minimum (mg_options_frame_lists) -- four
+    launches whatever the number of options, the winners those of the per-option general chain (sample_and_evaluate_on_device), bit
+    for bit; an option the fast form does not take (a joint-rotation constraint in its list) goes the per-option way in the same step."""
+    from morphablegraphs_amd.candidate_scoring import sample_and_evaluate_on_device
+    from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet
+    prims = synthetic.make_graph_primitives(6)
+    names = [p["name"] for p in prims]
+    joints, animated = synthetic.make_skeleton()
+    sk = _capi.Skeleton(joints, animated)
+    pset = HipPrimitiveSet(prims)
+    cons = {}
+    for i, (nm, p) in enumerate(zip(names, prims)):
+        F = p["n_canonical_frames"]
+        clist = [{"type": "position", "t": float(F - 1), "weight": 1.0, "target": [10.0, None, 5.0]}]
+        if i != 1:
+            clist.append({"type": "trajectory", "control_points": [[0.0, 0.0, 0.0], [5.0 + i, 0.0, 2.0], [12.0, 0.0, 3.0 + i]], "min_u": 0.0, "weight": 0.5, "granularity": 1000})
+        if i in (0, 2, 3):
+            clist.append({"type": "frame_ca_position", "joint": "LeftHand", "target": [3.0 + i, None, -2.0], "n_frames": F, "weight": 2.0})
+        if i == 3:
+            clist.append({"type": "frame_discrete_trajectory", "joint": "RightFoot", "points": [[0.1 * f, 5.0, 0.2 * f] for f in range(F // 2)], "unconstrained": [1], "weight": 0.4})
+            clist.append({"type": "frame_joint_trajectory", "joint": "LeftHand", "control_points": [[0.0, 90.0, 0.0], [20.0, 95.0, 5.0], [40.0, 90.0, 12.0]], "min_u": 0.0,
+                          "granularity": 1000, "weight": 0.3})
+        if i == 4:
+            clist.append({"type": "frame_joint_rotation", "joint_index": 3, "quaternion": [0.9, 0.1, -0.3, 0.2], "frame_idx": 7.0, "weight": 0.6})
+        cons[nm] = clist
+
+    class Cons(object):
+        def __init__(self, cl):
+            self.constraints, self.hip_skeleton, self.is_local = cl, sk, True
+    wrapped = {nm: Cons(cons[nm]) for nm in names}
+    for n_samples in (777, 4096):
+        np.random.seed(17)
+        pset.ctx.profile_reset(); pset.ctx.profile_enable(1)
+        best, res = pset.evaluate_options_on_device(names, wrapped, n_samples=n_samples, seed=40)
+        counts = {slot: pset.ctx.profile_get(slot)[1] for slot in ("options_step", "trajectory", "joint_tracks", "frame_constraints")}
+        pset.ctx.profile_enable(0)
+        # option 4's joint-rotation constraint takes the frames chain (its own launches); everything else: one launch per kind
+        assert counts["options_step"] == 1 and counts["trajectory"] == 1 and counts["joint_tracks"] == 1, counts
+        assert counts["frame_constraints"] <= 2, counts
+        np.random.seed(17)
+        for k, nm in enumerate(names):
+            lat, err = sample_and_evaluate_on_device(pset.nodes[nm], wrapped[nm], n_samples, seed=40 + k)
+            np.testing.assert_array_equal(res[nm][0], lat, err_msg=nm)
+            assert res[nm][1] == err, (nm, res[nm][1], err)
+        assert best == names[int(np.argmin([res[nm][1] for nm in names]))]

@@ -13,11 +13,14 @@ from morphablegraphs_amd import _capi, synthetic  # noqa: E402
 from morphablegraphs_amd.motion_state_graph import HipPrimitiveSet  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+search = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # MG_OPT_TRAJECTORY_SEARCH: 0 the reference's search (default), 1 the monotone walk
 n = 4096
 prims = synthetic.make_graph_primitives(16)
 names = [p["name"] for p in prims]
 joints, animated = synthetic.make_skeleton()
 pset = HipPrimitiveSet(prims, separate_streams=False)
+pset.ctx.set_option(_capi.MG_OPT_TRAJECTORY_SEARCH, search)
+print("MG_OPT_TRAJECTORY_SEARCH = %d (%s)" % (search, "the reference's search" if search == 0 else "the monotone walk"))
 sk = _capi.Skeleton(joints, animated)
 traj = {"type": "trajectory", "control_points": [[0.0, 0.0, 0.0], [5.0, 0.0, 2.0], [12.0, 0.0, 3.0], [20.0, 0.0, 3.0]], "min_u": 0.0, "weight": 0.5, "granularity": 1000}
 base = {nm: [{"type": "position", "t": float(p["n_canonical_frames"] - 1), "weight": 1.0, "target": [10.0, None, 5.0]}] for nm, p in zip(names, prims)}
