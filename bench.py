@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F64_MFMA_PEAK_TFLOPS = 78.6   # AMD's published MI355X float64 matrix figure (the guide has no float64 row)
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r04_summary.json", "r04_frame_constraints_summary.json", "r04a_summary.json")]   # tools/prof_all.sh (r04a: its counter passes ran the tile-major kernel, the one slow-class boxes get)
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r05_summary.json", "r05_frame_constraints_summary.json", "r04a_summary.json")]   # tools/prof_all.sh (r04a: its counter passes ran the tile-major kernel, the one slow-class boxes get)
 METRIC = "motion-primitive samples scored+back-projected/sec; fraction of HBM roofline"
 L, F, D, NB, K = 40, 156, 79, 31, 8
 
@@ -819,9 +819,10 @@ def run_frame_constraints(args, emit=True):
             "issue_limited_cycles_per_trip": INSTR_PER_TRIP * ISSUE_CYCLES,
             "note": "the reference's closest-point search (scipy L-BFGS-B restated, one lane per candidate): per frame a wave runs the trips of its slowest lane; a trip is "
                     "one (f, g) evaluation + the line search's bookkeeping, ~%d instructions issued at %d cycles each by the ONE wave its SIMD holds.  The wave is issue "
-                    "bound (cycles_per_trip vs issue_limited_cycles_per_trip); the chip is %d waves on %d SIMDs.  HBM and MFMA rooflines do not apply (%.1f MB per step).  "
+                    "bound (cycles_per_trip vs issue_limited_cycles_per_trip); the chip is %d waves on %d SIMDs.  HBM and MFMA rooflines do not apply (%.0f MB of HBM traffic per launch, "
+                    "most of it the candidates' root paths staged for the search: 8 ms at the kernel's pace would move 60 GB).  "
                     "MG_OPT_TRAJECTORY_SEARCH 1 (the monotone walk, eight lanes per candidate) takes ~0.4 ms for the same step and differs from the reference where "
-                    "the distance has several basins" % (INSTR_PER_TRIP, int(ISSUE_CYCLES), waves, SIMDS, 1.1)})
+                    "the distance has several basins" % (INSTR_PER_TRIP, int(ISSUE_CYCLES), waves, SIMDS, (roofline["traffic"] or 3.2e7) / 1e6)})
     else:
         roofline.update({"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k_ms else None, "algorithmic_bytes": alg,

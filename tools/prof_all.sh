@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/<tag>_* is made from, on the GPU box, summarised there (the raw rocprofv3 output is too large to travel back):
 #   tools/prof_all.sh <tag>   ->  gpurun_out/profiles_<tag>/   (copy into profiles/)
-tag=${1:-r04}
+tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O

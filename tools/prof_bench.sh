@@ -2,7 +2,7 @@
 # Profile bench.py on the GPU box: kernel trace + PMC passes (each in its own run).
 # usage: tools/prof_bench.sh <tag> [extra bench args]
 set -o pipefail
-tag=${1:-r04}; shift
+tag=${1:-r05}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

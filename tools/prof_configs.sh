@@ -3,7 +3,7 @@
 # HBM-traffic counters of the per-frame constraints' kernels (new route and the chain it replaces run in the same command).
 # usage: tools/prof_configs.sh <tag>
 set -o pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 for cfg in graph optimizer frame_constraints; do
   out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_$cfg

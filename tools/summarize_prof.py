@@ -13,7 +13,10 @@ def main(d, out):
         for k, v in agg.items():
             v2 = v[len(v) // 10:]  # drop warm-up launches
             res["kernels"][k[:90]] = {"launches": len(v), "avg_us": sum(v2) / len(v2), "min_us": min(v), "max_us": max(v)}
-            if len(v) >= 2000:   # bench.py's timed region: its last 2000 launches (before them: placement probes, warm-up)
+            if len(v) >= 12000:   # bench.py's default run since round 5: five timed windows of 2000 steps, then the events pass of 2000 (before them: probes, ramp, warm-up)
+                res["kernels"][k[:90]]["timed_windows_avg_us"] = sum(v[-12000:-2000]) / 10000.0
+                res["kernels"][k[:90]]["events_pass_avg_us"] = sum(v[-2000:]) / 2000.0
+            elif len(v) >= 2000:
                 res["kernels"][k[:90]]["timed_region_avg_us"] = sum(v[-2000:]) / 2000.0
     for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         agg = defaultdict(lambda: defaultdict(list))
