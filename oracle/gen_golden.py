@@ -370,16 +370,7 @@ def run_per_frame_classes_case(name):
     the label constants of spatial_constraints/__init__.py; their skeleton is an ARGUMENT: a duck-typed object that returns given
     joint tracks (input data, stored in the fixture).  Trajectories: the reference's ParameterizedSpline."""
     ps = import_reference_splines()
-    pkg = types.ModuleType("mg_ref_spatial")
-    pkg.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints"]
-    for label in ("TRAJECTORY", "KEYFRAME_POSITION", "KEYFRAME_DIR_2D", "KEYFRAME_POSE", "TWO_HAND_POSITION", "TRAJECTORY_SET", "KEYFRAME_LOOK_AT",
-                  "KEYFRAME_FEET", "CA_CONSTRAINT", "KEYFRAME_RELATIVE_POSITION"):
-        setattr(pkg, "SPATIAL_CONSTRAINT_TYPE_" + label, label.lower())
-    pkg.__all__ = [k for k in vars(pkg) if k.startswith("SPATIAL_")]
-    sys.modules["mg_ref_spatial"] = pkg
-    kf = types.ModuleType("mg_ref_spatial.keyframe_constraints")
-    kf.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints/keyframe_constraints"]
-    sys.modules["mg_ref_spatial.keyframe_constraints"] = kf
+    _stub_spatial_packages()
     ltc = importlib.import_module("mg_ref_spatial.keyframe_constraints.local_trajectory_constraint")
     tsc = importlib.import_module("mg_ref_spatial.trajectory_set_constraint")
     rng = np.random.default_rng(606)
@@ -433,6 +424,148 @@ def run_per_frame_classes_case(name):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def _stub_spatial_packages():
+    """Stub parents for the reference's constraints/spatial_constraints files: only the label constants of its __init__.py."""
+    pkg = types.ModuleType("mg_ref_spatial")
+    pkg.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints"]
+    for label in ("TRAJECTORY", "KEYFRAME_POSITION", "KEYFRAME_DIR_2D", "KEYFRAME_POSE", "TWO_HAND_POSITION", "TRAJECTORY_SET", "KEYFRAME_LOOK_AT",
+                  "KEYFRAME_FEET", "CA_CONSTRAINT", "KEYFRAME_RELATIVE_POSITION"):
+        setattr(pkg, "SPATIAL_CONSTRAINT_TYPE_" + label, label.lower())
+    pkg.__all__ = [k for k in vars(pkg) if k.startswith("SPATIAL_")]
+    sys.modules["mg_ref_spatial"] = pkg
+    kf = types.ModuleType("mg_ref_spatial.keyframe_constraints")
+    kf.__path__ = ["/root/reference/morphablegraphs/constraints/spatial_constraints/keyframe_constraints"]
+    sys.modules["mg_ref_spatial.keyframe_constraints"] = kf
+
+
+class _FKNode(object):
+    def __init__(self, orc, joints, animated, name):
+        self.orc, self.joints, self.animated, self.name = orc, joints, animated, name
+
+    def get_global_position(self, frame, use_cache=False):
+        return self.orc.joint_global_position(np.asarray(frame, dtype=np.float64), self.joints, self.animated, self.name)
+
+
+class _FKSkeleton(object):
+    """The skeleton ARGUMENT of the keyframe classes: nodes[joint].get_global_position(frame) by the oracle's forward kinematics over
+    synthetic.make_skeleton() (anim_utils, whose skeleton the reference would pass, is absent: the FK stays SELF-DEFINED; what this
+    fixture pins is the classes' own arithmetic on the joint positions, which it also stores)."""
+
+    def __init__(self, orc, joints, animated):
+        self.nodes = {j[0]: _FKNode(orc, joints, animated, j[0]) for j in joints}
+
+
+def run_keyframe_classes_case(ref, name):
+    """TwoHandConstraintSet (keyframe_constraints/two_hand_constraint.py:33-93) and FeetConstraint (feet_constraint.py:30-55), the
+    reference's unmodified files, on the reference's own MotionSpline objects (MotionPrimitive.back_project(s, False) of the walk
+    model); evaluate_motion_spline / get_residual_vector_spline per candidate."""
+    from oracle import mg_oracle as orc
+    import contextlib
+    import io
+    _stub_spatial_packages()
+    th = importlib.import_module("mg_ref_spatial.keyframe_constraints.two_hand_constraint")
+    ft = importlib.import_module("mg_ref_spatial.keyframe_constraints.feet_constraint")
+    data = synthetic.make_walk_primitive(seed=0)
+    joints, animated = synthetic.make_skeleton()
+    sk = _FKSkeleton(orc, joints, animated)
+    mp = ref.MotionPrimitive(None)
+    mp._initialize_from_json(data)
+    np.random.seed(77)
+    S = mp.sample_low_dimensional_vector(10)
+    splines = [mp.back_project(s, use_time_parameters=False) for s in S]
+    out = dict(S=S, digest=np.array(model_digest(data)))
+    hands = [("LeftHand", "RightHand"), ("LeftHand_EndSite", "RightHand_EndSite")]
+    two_hand = [(100, 0.5, [[30.0, 95.0, 10.0], [-20.0, 99.0, 14.0]], hands[0]),
+                (0, 1.0, [[45.0, 120.0, -3.0], [-44.0, 118.0, 2.0]], hands[1]),
+                (155, 2.0, [[10.0, 60.0, 30.0], [10.5, 60.0, 30.0]], hands[0])]            # targets half a unit apart
+    for ci, (key, w, positions, names) in enumerate(two_hand):
+        desc = {"canonical_keyframe": key, "semanticAnnotation": {"keyframeLabel": "none"}, "positions": [np.array(p) for p in positions],
+                "orientations": [None, None], "joint": list(names), "n_canonical_frames": int(data["n_canonical_frames"])}
+        c = th.TwoHandConstraintSet(sk, desc, 1.0, w)
+        out["two_hand_keyframe_%d" % ci], out["two_hand_weight_%d" % ci] = np.int64(key), np.float64(w)
+        out["two_hand_positions_%d" % ci], out["two_hand_joints_%d" % ci] = np.asarray(positions, dtype=np.float64), np.array(names)
+        out["two_hand_residuals_%d" % ci] = np.array([c.get_residual_vector_spline(sp) for sp in splines], dtype=np.float64)
+        out["two_hand_error_%d" % ci] = np.array([c.evaluate_motion_spline(sp) for sp in splines], dtype=np.float64)
+        out["two_hand_hand_positions_%d" % ci] = np.array([c._get_global_hand_positions(sp.evaluate(key)) for sp in splines], dtype=np.float64)
+        assert c.get_length_of_residual_vector() == 3
+    feet = [(30, 1.0, [9.0, 3.0, 20.0], [-9.0, 2.0, 5.0]), (120, 1.5, [12.0, 0.0, 80.0], [-6.0, 10.0, 60.0])]
+    for ci, (key, w, left, right) in enumerate(feet):
+        desc = {"canonical_keyframe": key, "semanticAnnotation": {"keyframeLabel": "none"}, "left": np.array(left), "right": np.array(right)}
+        c = ft.FeetConstraint(sk, desc, 1.0, w)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out["feet_residuals_spline_%d" % ci] = np.array([c.get_residual_vector_spline(sp) for sp in splines], dtype=np.float64)   # ONE entry: left + right
+            out["feet_residuals_%d" % ci] = np.array([c.get_residual_vector(sp.evaluate(key)) for sp in splines], dtype=np.float64)
+            out["feet_error_%d" % ci] = np.array([c.evaluate_motion_spline(sp) for sp in splines], dtype=np.float64)
+        out["feet_keyframe_%d" % ci], out["feet_weight_%d" % ci] = np.int64(key), np.float64(w)
+        out["feet_left_%d" % ci], out["feet_right_%d" % ci] = np.asarray(left, dtype=np.float64), np.asarray(right, dtype=np.float64)
+    out["n_two_hand"], out["n_feet"] = np.int64(len(two_hand)), np.int64(len(feet))
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+class _TimeNode(object):
+    """graph.nodes[key] for TimeConstraints: back_project_time_function as the reference's wrapper forwards it on the legacy branch
+    (motion_primitive_wrapper.py:233-237; the wrapper imports anim_utils, absent) -- the reference MotionPrimitive's own
+    _back_transform_gamma_to_canonical_time_function on the time part of the vector."""
+
+    def __init__(self, mp):
+        self.mp = mp
+
+    def back_project_time_function(self, s_vec):
+        return self.mp._back_transform_gamma_to_canonical_time_function(np.asarray(s_vec)[self.mp.get_n_spatial_components():])
+
+    def get_gaussian_mixture_model(self):
+        # time_constraints.py:95 indexes the return value of score(X): sklearn's old GMM.score returned the per-sample
+        # log-likelihoods, GaussianMixture.score returns their mean as a scalar (IndexError on every sklearn >= 0.20).  The
+        # reference's line runs here unmodified over the mixture's per-sample scores.
+        return _Bag(score=self.mp.gaussian_mixture_model.score_samples)
+
+
+class _Bag(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def run_time_constraints_case(ref, name, data):
+    """TimeConstraints (constraints/time_constraints.py:25-110), the reference's unmodified file, over a three-step graph walk on
+    the time_model fixture's primitive; the walk's steps take that fixture's sampled vectors S[0..2] as parameters."""
+    import contextlib
+    import io
+    pkg = types.ModuleType("mg_ref_constraints")
+    pkg.__path__ = ["/root/reference/morphablegraphs/constraints"]
+    sys.modules["mg_ref_constraints"] = pkg
+    tc_mod = importlib.import_module("mg_ref_constraints.time_constraints")
+    mp = ref.MotionPrimitive(None)
+    mp._initialize_from_json(data)
+    n_s, n_t, F = mp.get_n_spatial_components(), mp.get_n_time_components(), mp.get_n_canonical_frames()
+    np.random.seed(41)                                                   # run_time_case's seed: the same S
+    base = mp.sample_low_dimensional_vector(9)[:3]
+    steps = [_Bag(node_key="tm", parameters=np.array(b), n_spatial_components=n_s, n_time_components=n_t) for b in base]
+    walk = _Bag(steps=steps)
+    graph = _Bag(nodes={"tm": _TimeNode(mp)}, skeleton=_Bag(frame_time=0.02))
+    rng = np.random.default_rng(4)
+    out = dict(base=base, frame_time=np.float64(0.02), digest=np.array(model_digest(data)))
+    cases = [(1, 3, [(0, F // 2, 1.1), (1, F - 1, 3.9), (2, 5, 4.2), (5, 1, 1.0), (1, F + 3, 2.0)]),
+             (0, 3, [(0, 0, 0.3), (2, F - 1, 3.0)]),
+             (2, 3, [(0, 17, 2.9)])]
+    for ci, (start, end, constraint_list) in enumerate(cases):
+        tc = tc_mod.TimeConstraints(graph, walk, start, end, constraint_list)
+        S = 0.5 * rng.standard_normal((6, (end - start) * n_t))
+        with contextlib.redirect_stdout(io.StringIO()):
+            err = np.array([tc.evaluate_graph_walk(s, graph, walk) for s in S], dtype=np.float64)
+        ll = np.array([tc.get_average_loglikelihood(s, graph, walk) for s in S], dtype=np.float64)
+        out["start_step_%d" % ci], out["end_step_%d" % ci] = np.int64(start), np.int64(end)
+        out["constraint_list_%d" % ci] = np.asarray(constraint_list, dtype=np.float64)
+        out["S_%d" % ci], out["error_%d" % ci], out["loglikelihood_%d" % ci] = S, err, ll
+        out["start_keyframe_%d" % ci] = np.float64(tc.start_keyframe)
+        out["initial_guess_%d" % ci] = np.asarray(tc.get_initial_guess(walk), dtype=np.float64)
+    out["n_cases"] = np.int64(len(cases))
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     ref = import_reference()
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -440,6 +573,12 @@ def main():
         timed = synthetic.make_primitive(seed=13, n_components=12, n_frames=60, n_dim=15, n_gmm=3, name="timed",
                                          n_time_components=3, n_basis_time=8)
         run_time_case(ref, "time_model", timed, 9, 41)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "round5b":      # round 5, second batch: the keyframe classes and the time constraints
+        run_keyframe_classes_case(ref, "keyframe_classes")
+        timed = synthetic.make_primitive(seed=13, n_components=12, n_frames=60, n_dim=15, n_gmm=3, name="timed",
+                                         n_time_components=3, n_basis_time=8)
+        run_time_constraints_case(ref, "time_constraints", timed)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "round5":       # the fixtures added in round 5
         run_closest_point_case("trajectory_closest_point")

@@ -301,6 +301,46 @@ def two_hand_residuals(frame, joints, animated_joints, joint_names, positions):
     return [float(np.linalg.norm(center - (left + 0.5 * delta))), float(np.linalg.norm(p0 - left)), float(np.linalg.norm(p1 - right))]
 
 
+def feet_residuals(frame, joints, animated_joints, left, right, weight_factor=1.0):
+    """FeetConstraint.get_residual_vector (feet_constraint.py:47-51): distance of each foot to its target, the constraint's own
+    weight factor applied INSIDE (the caller multiplies once more); get_residual_vector_spline is the ONE entry [left + right]."""
+    lp = joint_global_position(frame, joints, animated_joints, "LeftFoot")
+    rp = joint_global_position(frame, joints, animated_joints, "RightFoot")
+    return [float(np.linalg.norm(np.asarray(left, dtype=np.float64) - lp)) * weight_factor,
+            float(np.linalg.norm(np.asarray(right, dtype=np.float64) - rp)) * weight_factor]
+
+
+def time_constraints_start_keyframe(time_functions_before):
+    """TimeConstraints._get_start_frame (time_constraints.py:32-39): the last entries of the time functions of the steps before
+    start_step, summed."""
+    start = 0
+    for tf in time_functions_before:
+        start += tf[-1]
+    return start
+
+
+def time_constraints_error(time_functions, constraint_list, start_keyframe, frame_time):
+    """TimeConstraints.evaluate_graph_walk / calculate_constraint_error (time_constraints.py:40-50, 68-91) on the time functions
+    of the steps start_step .. end_step: frames counted up to the constrained step's keyframe (int(t[key]) + 1 of them in that
+    step), squared difference to the desired time; 0 when the keyframe is beyond the step's time function, 10000 when the
+    constrained step is beyond the walk."""
+    error_sum = 0.0
+    for step_index, keyframe_index, desired_time in constraint_list:
+        n_frames, error = start_keyframe, 10000.0
+        for k, tf in enumerate(time_functions):
+            if k < int(step_index):
+                n_frames += tf[-1]
+                continue
+            if int(keyframe_index) >= len(tf):
+                error = 0.0
+            else:
+                n_frames += int(tf[int(keyframe_index)]) + 1
+                error = (desired_time - n_frames * frame_time) ** 2
+            break
+        error_sum += error
+    return error_sum
+
+
 def node_heading(frame, joints, animated_joints, joint, ref_dir=(0.0, 0.0, 1.0)):
     """What anim_utils' get_global_node_orientation_vector is documented to return: unit (x, z) of the node's global
     rotation applied to ref_dir (SELF-DEFINED, anim_utils absent)."""

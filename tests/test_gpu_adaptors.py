@@ -927,6 +927,53 @@ def test_reference_shaped_hand_constraints_through_the_objectives():
     np.testing.assert_array_equal(best, S[int(np.argmin(expect.sum(axis=1)))])
 
 
+def test_keyframe_classes_against_the_references_own_classes():
+    """tests/golden/keyframe_classes.npz: TwoHandConstraintSet and FeetConstraint run by the reference itself on its own motion
+    splines of the walk model (forward kinematics: the oracle's).  Objects with those classes' attributes go through the
+    objectives; the entries are the reference's get_residual_vector_spline values times the weight factor, as
+    MotionPrimitiveConstraints.get_residual_vector (motion_primitive_constraints.py:140-146) and .evaluate (:118-121) apply it."""
+    from conftest import load_golden
+    from morphablegraphs_amd import objective_functions as of
+    g = load_golden("keyframe_classes")
+    joints, animated = synthetic.make_skeleton()
+    hip_sk = _capi.Skeleton(joints, animated)
+    data = synthetic.make_walk_primitive(seed=0)
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "leftStance", "mm": data})
+    S = np.ascontiguousarray(g["S"])
+
+    class RefSkeleton(object):
+        root, aligning_root_node, aligning_root_dir = "Hips", "Hips", (0.0, 0.0, 1.0)
+
+    class Obj(object):
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    cons, expect = [], []
+    for ci in range(int(g["n_two_hand"])):
+        w = float(g["two_hand_weight_%d" % ci])
+        cons.append(Obj(canonical_keyframe=int(g["two_hand_keyframe_%d" % ci]), weight_factor=w, skeleton=RefSkeleton(),
+                        positions=[p for p in g["two_hand_positions_%d" % ci]], orientations=[None, None],
+                        joint_names=[str(n) for n in g["two_hand_joints_%d" % ci]]))
+        expect.append(w * g["two_hand_residuals_%d" % ci])
+    for ci in range(int(g["n_feet"])):
+        w = float(g["feet_weight_%d" % ci])
+        cons.append(Obj(canonical_keyframe=int(g["feet_keyframe_%d" % ci]), weight_factor=w, skeleton=RefSkeleton(),
+                        left=g["feet_left_%d" % ci], right=g["feet_right_%d" % ci]))
+        expect.append(w * g["feet_residuals_spline_%d" % ci])
+    expect = np.hstack(expect)
+    assert expect.shape == (len(S), 3 * int(g["n_two_hand"]) + int(g["n_feet"]))
+    c = Obj(constraints=cons, min_error=None, evaluations=0, is_local=True, skeleton=RefSkeleton(), hip_skeleton=hip_sk, start_pose=None)
+    res = of.obj_spatial_error_residual_vector(S, (node, c, None, 1.0, 1.0, 1.0))
+    np.testing.assert_allclose(res[:, :expect.shape[1]], expect, rtol=1e-9, atol=1e-8)
+    assert not res[:, expect.shape[1]:].any()
+    total = sum(float(g["two_hand_weight_%d" % ci]) * g["two_hand_error_%d" % ci] for ci in range(int(g["n_two_hand"]))) + \
+        sum(float(g["feet_weight_%d" % ci]) * g["feet_error_%d" % ci] for ci in range(int(g["n_feet"])))
+    np.testing.assert_allclose(of.obj_spatial_error_sum(S, (node, c, None)), total, rtol=1e-9, atol=1e-8)
+    best, err = evaluate_samples_using_constraints(S, node, c)
+    np.testing.assert_array_equal(best, S[int(np.argmin(total))])
+
+
 def test_cluster_tree_training_data_in_batches():
     """The data-producing half of ClusterTreeBuilder (reference construction/cluster_tree_builder.py:159-192,
     293-301): threshold filter, best-of-2n by the reference's heap slice, back projection at the integer canonical

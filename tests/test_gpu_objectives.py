@@ -212,6 +212,36 @@ def test_time_objective_for_batches():
     node.motion_primitive._prim.close()
 
 
+def test_time_constraints_against_the_references_own_class():
+    """tests/golden/time_constraints.npz: TimeConstraints run by the reference itself (time_constraints.py:25-110) over a
+    three-step walk on the time_model primitive -- start frame, initial guess, the error of every candidate, the average
+    log-likelihood (its [0] on the mixture's score read as the old per-sample score, see oracle/gen_golden.py)."""
+    from conftest import golden_model, load_golden
+    data, gm = golden_model("time_model")
+    g = load_golden("time_constraints")
+    n_s, n_t = int(gm["n_spatial_components"]), int(gm["n_time_components"])
+    node = HipMotionStateGraphNode()
+    node.init_from_dict("walk", {"name": "tm", "mm": data})
+
+    class Walk(object):
+        pass
+    walk = Walk()
+    walk.steps = [_Step(node.node_key, b, n_s, n_t, None) for b in g["base"]]
+    graph = _Graph({node.node_key: node}, _Skeleton("Hips", frame_time=float(g["frame_time"])), None)
+    for ci in range(int(g["n_cases"])):
+        clist = [(int(r[0]), int(r[1]), float(r[2])) for r in g["constraint_list_%d" % ci]]
+        tc = of.HipTimeConstraints(graph, walk, int(g["start_step_%d" % ci]), int(g["end_step_%d" % ci]), clist)
+        assert abs(tc.start_keyframe - float(g["start_keyframe_%d" % ci])) <= 1e-9
+        np.testing.assert_array_equal(tc.get_initial_guess(walk), g["initial_guess_%d" % ci])
+        S = g["S_%d" % ci]
+        want_e, want_l = g["error_%d" % ci], g["loglikelihood_%d" % ci]
+        np.testing.assert_allclose(tc.evaluate_graph_walk(S, graph, walk), want_e, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(tc.get_average_loglikelihood(S, graph, walk), want_l, rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(of.obj_time_error_sum(S, (graph, walk, tc, 2.0, 0.3)), 2.0 * want_e - 0.3 * want_l, rtol=1e-9, atol=1e-8)
+        assert abs(tc.evaluate_graph_walk(S[0], graph, walk) - want_e[0]) <= 1e-9 * max(1.0, want_e[0])      # one candidate: a float
+    node.motion_primitive._prim.close()
+
+
 @pytest.mark.parametrize("n", [17, 4099, 40000, 131072 + 5])   # (the last: BASELINE configs[4]'s iteration -- waves with two and three tiles, a ragged last one)
 def test_objective_in_one_launch_is_bit_identical_to_the_two_calls(n):
     """mg_objective_error_and_naturalness: the LDS-resident mixture kernel scores the keyframe constraints on

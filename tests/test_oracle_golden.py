@@ -454,6 +454,71 @@ def test_per_frame_classes_against_the_references_own_classes():
             assert (si == 0) == (not want.any())
 
 
+def test_keyframe_classes_against_the_references_own_classes():
+    """tests/golden/keyframe_classes.npz: TwoHandConstraintSet (two_hand_constraint.py:33-93) and FeetConstraint
+    (feet_constraint.py:30-55) run by the reference itself on its own MotionSpline objects of the walk model (forward kinematics:
+    the oracle's, SELF-DEFINED -- the fixture stores the hand positions it produced); the oracle's restatements on the oracle's
+    frames against them."""
+    from conftest import load_golden
+    from morphablegraphs_amd import synthetic
+    g = load_golden("keyframe_classes")
+    data = synthetic.make_walk_primitive(seed=0)
+    joints, animated = synthetic.make_skeleton()
+    op = orc.OraclePrimitive(data)
+    S = g["S"]
+    coeffs = [op.back_project_spatial_coeffs(s) for s in S]
+    for ci in range(int(g["n_two_hand"])):
+        key, names, positions = float(g["two_hand_keyframe_%d" % ci]), [str(n) for n in g["two_hand_joints_%d" % ci]], g["two_hand_positions_%d" % ci]
+        want, hands = g["two_hand_residuals_%d" % ci], g["two_hand_hand_positions_%d" % ci]
+        for b in range(len(S)):
+            frame = orc.spline_frames(op.knots, coeffs[b], [key])[0]
+            for k in range(2):
+                np.testing.assert_allclose(orc.joint_global_position(frame, joints, animated, names[k]), hands[b, k], rtol=0, atol=1e-9)
+            r = orc.two_hand_residuals(frame, joints, animated, names, positions)
+            np.testing.assert_allclose(r, want[b], rtol=1e-10, atol=1e-9)
+            assert abs(sum(r) - g["two_hand_error_%d" % ci][b]) <= 1e-9 * max(1.0, sum(r))
+    for ci in range(int(g["n_feet"])):
+        key, w = float(g["feet_keyframe_%d" % ci]), float(g["feet_weight_%d" % ci])
+        for b in range(len(S)):
+            frame = orc.spline_frames(op.knots, coeffs[b], [key])[0]
+            r = orc.feet_residuals(frame, joints, animated, g["feet_left_%d" % ci], g["feet_right_%d" % ci], w)
+            np.testing.assert_allclose(r, g["feet_residuals_%d" % ci][b], rtol=1e-10, atol=1e-9)
+            assert abs(sum(r) - g["feet_residuals_spline_%d" % ci][b, 0]) <= 1e-9 * max(1.0, sum(r))
+            assert abs(sum(r) - g["feet_error_%d" % ci][b]) <= 1e-9 * max(1.0, sum(r))
+
+
+def test_time_constraints_against_the_references_own_class():
+    """tests/golden/time_constraints.npz: TimeConstraints (time_constraints.py:25-110) run by the reference itself over a
+    three-step walk on the time_model primitive (oracle/gen_golden.py run_time_constraints_case); the oracle's restatement over
+    the oracle's canonical time functions and mixture against it."""
+    from conftest import golden_model, load_golden
+    data, gm = golden_model("time_model")
+    g = load_golden("time_constraints")
+    assert str(g["digest"]) == str(gm["digest"])
+    np.testing.assert_array_equal(g["base"], gm["S"][:3])
+    op = orc.OraclePrimitive(data)
+    op.init_time_model(data)
+    n_s, n_t = int(gm["n_spatial_components"]), int(gm["n_time_components"])
+    base, frame_time = g["base"], float(g["frame_time"])
+    varied = 0
+    for ci in range(int(g["n_cases"])):
+        start, end = int(g["start_step_%d" % ci]), int(g["end_step_%d" % ci])
+        before = [op.back_transform_gamma_to_canonical_time_function(base[i][n_s:]) for i in range(start)]
+        start_keyframe = orc.time_constraints_start_keyframe(before)
+        assert abs(start_keyframe - float(g["start_keyframe_%d" % ci])) <= 1e-9
+        np.testing.assert_array_equal(np.concatenate([base[i][n_s:] for i in range(start, end)]), g["initial_guess_%d" % ci])
+        clist = [tuple(row) for row in g["constraint_list_%d" % ci]]
+        for b, s in enumerate(g["S_%d" % ci]):
+            tfs = [op.back_transform_gamma_to_canonical_time_function(s[k * n_t:(k + 1) * n_t]) for k in range(end - start)]
+            e = orc.time_constraints_error(tfs, clist, start_keyframe, frame_time)
+            want = float(g["error_%d" % ci][b])
+            assert abs(e - want) <= 1e-9 * max(1.0, abs(want)), (ci, b, e, want)
+            ll = np.mean([op.score_samples(np.concatenate([base[start + k][:n_s], s[k * n_t:(k + 1) * n_t]])[None, :])[0] for k in range(end - start)])
+            assert abs(ll - float(g["loglikelihood_%d" % ci][b])) <= 1e-9 * max(1.0, abs(ll))
+        varied += len(np.unique(np.round(g["error_%d" % ci], 9))) > 1
+    assert varied >= 2                                                   # the candidates' time functions do move the error
+
+
 def test_walk_32_fixture_configs0():
     """BASELINE configs[0] at its stated size: one 'walk' primitive, 32 latent samples (the reference drew and back-projected them:
     oracle/gen_golden.py run_walk_32_case) -- the oracle's NumPy path and the C restatement against the reference's frames."""
