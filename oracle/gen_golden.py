@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 from morphablegraphs_amd import synthetic  # noqa: E402
 
 REF_DIR = "/root/reference/morphablegraphs/motion_model"
-OUT_DIR = os.path.join(ROOT, "tests", "golden")
+OUT_DIR = os.environ.get("MG_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # (MG_GOLDEN_OUT: oracle/check_golden.py regenerates beside, then compares)
 
 
 def import_reference():

@@ -1,5 +1,7 @@
 """The NumPy oracle against the golden vectors made by the reference's own code
 (oracle/gen_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -540,3 +542,15 @@ def test_walk_32_fixture_configs0():
     np.testing.assert_allclose(cp.log_prob_f64(S), g["logp"], rtol=1e-9, atol=1e-7)
     m32 = cp.frames_f32model(S)[:, rows].astype(np.float64)
     assert np.all(np.abs(m32 - want) <= 1e-5 + 2.0 ** -24 * np.abs(want))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/morphablegraphs"), reason="the reference is only in the build container")
+def test_fixtures_reproduce_from_the_reference():
+    """Every tests/golden/*.npz regenerated from /root/reference by oracle/gen_golden.py (oracle/check_golden.py): each array
+    equal to the committed one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "check_golden.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "13 fixture(s) regenerated, 0 array(s) differ" in r.stdout, r.stdout
