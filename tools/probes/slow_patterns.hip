@@ -9,6 +9,7 @@
 //   6  a plain fill
 //   7  units dealt round robin: at any time the chip writes one compact window of 64 tiles (50 MB) that moves through the buffer
 //   8  wave-level regions in address order: the 2048 waves write 2048 consecutive (candidate, chunk) regions = one contiguous 25 MB window
+//  10  chunk-stationary order with the four chunk workgroups of a tile block on one XCD (round 5); 11: that map writing owned 128 B granules
 //   9  the same with 4 KB per wave at a time (the 2048 waves write one contiguous 8 MB window: a fill with this kernel's instruction shape)
 // usage: slow_patterns [reps]
 #include <hip/hip_runtime.h>
@@ -42,6 +43,24 @@ __global__ __launch_bounds__(1024) void pattern(float *out, int ntiles) {
             if (tile >= ntiles) break;
             for (int f0 = 0; f0 < NF; f0 += 3)
                 for (int half = 0; half < 2; half++) rows3(out, (size_t)tile * 16 + wave + 8 * half, chunk, f0, lane);
+        }
+        return;
+    }
+    if (MODE == 10 || MODE == 11) {   // chunk-stationary, the four chunk workgroups of a tile block on ONE XCD (workgroups go to XCD blockIdx % 8)
+        const int x = blockIdx.x % 8, r = blockIdx.x / 8, chunk = r % NCH, q = x + 8 * (r / NCH), nq = gridDim.x / NCH, tper = (ntiles + nq - 1) / nq;
+        for (int s = 0; s < tper; s++) {
+            const int tile = q * tper + s;
+            if (tile >= ntiles) break;
+            if (MODE == 10) {
+                for (int f0 = 0; f0 < NF; f0 += 3)
+                    for (int half = 0; half < 2; half++) rows3(out, (size_t)tile * 16 + wave + 8 * half, chunk, f0, lane);
+            } else {   // 11: the same map, regions as granule-owning aligned blocks (what the map can reach at best)
+                for (int half = 0; half < 2; half++) {
+                    const size_t b0 = (((size_t)tile * 16 + wave + 8 * half) * T + (size_t)chunk * NF) * D * 4;
+                    const size_t b = b0 / 128 * 128, e = (b0 + (size_t)NF * D * 4) / 128 * 128;
+                    for (size_t p = b + lane * 16; p < e; p += 1024) { const f4 v = {0.f, 0.f, 0.f, 0.f}; *(f4 *)((char *)out + p) = v; }
+                }
+            }
         }
         return;
     }
@@ -119,6 +138,8 @@ static float time_mode(int mode, float *buf, int ntiles, size_t bytes, int reps)
             case 7: pattern<7><<<256, 512>>>(buf, ntiles); break;
             case 8: pattern<8><<<256, 512>>>(buf, ntiles); break;
             case 9: pattern<9><<<256, 512>>>(buf, ntiles); break;
+            case 10: pattern<10><<<256, 512>>>(buf, ntiles); break;
+            case 11: pattern<11><<<256, 512>>>(buf, ntiles); break;
             default: fill<<<(unsigned)((bytes / 16 + 255) / 256), 256>>>((f4 *)buf, bytes / 16); break;
         }
     };
@@ -147,13 +168,17 @@ int main(int argc, char **argv) {
         else if (!is_slow && !fast) fast = p;
         else held.push_back(p);
     }
-    const char *names[10] = {"tile-major replica (two candidates alternating)", "... one candidate after the other", "chunk-stationary order",
+    const char *names[12] = {"tile-major replica (two candidates alternating)", "... one candidate after the other", "chunk-stationary order",
                             "16 waves, one candidate each", "regions as aligned 1 KB blocks", "whole rows per wave (49 KB contiguous)", "plain fill",
-                            "units round robin (50 MB window)", "wave regions in address order (25 MB window)", "4 KB per wave in address order (8 MB window)"};
-    printf("%-52s %10s %10s\n", "us per launch", fast ? "fast buf" : "(none)", slow ? "slow buf" : "(none)");
-    for (int m = 0; m < 10; m++) {
+                            "units round robin (50 MB window)", "wave regions in address order (25 MB window)", "4 KB per wave in address order (8 MB window)",
+                            "chunk-stationary, a tile block's 4 chunks on one XCD", "... the same map, regions as owned 128 B granules"};
+    float *contig = nullptr;   // physically contiguous memory (round 5): the slowest class of all for the pattern, at the fill's rate for a fill
+    if (hipExtMallocWithFlags((void **)&contig, bytes, hipDeviceMallocContiguous) != hipSuccess) contig = nullptr;
+    printf("%-52s %10s %10s %10s\n", "us per launch", fast ? "fast buf" : "(none)", slow ? "slow buf" : "(none)", contig ? "contiguous" : "(none)");
+    for (int m = 0; m < 12; m++) {
         const float a = fast ? time_mode(m, fast, ntiles, bytes, reps) : 0.f, b = slow ? time_mode(m, slow, ntiles, bytes, reps) : 0.f;
-        printf("%-52s %10.1f %10.1f\n", names[m], a, b);
+        const float c = contig ? time_mode(m, contig, ntiles, bytes, reps) : 0.f;
+        printf("%-52s %10.1f %10.1f %10.1f\n", names[m], a, b, c);
     }
     return 0;
 }
