@@ -39,6 +39,11 @@ bool mg_frames_root_split(const mg_primitive *p) {
 
 // LDS of the fused mixture scoring: two term buffers and two exp buffers of [K][16] float64
 static int mg_fused_gmm_lds(const mg_primitive *p) { return 4 * p->K * 16 * 8; }
+// ... and, in the chunk-stationary kernel, what its start-up stages for the tail: the workgroup's (first) two latent tiles as float32 A fragments [2][KK][64]
+static int mg_fused_gmm_lds_cs(const mg_primitive *p) {   // + the components' C-in rows [K][JT*16] and constants [K], float64
+    const int JT = (int)((p->Lg + 15) / 16);
+    return mg_fused_gmm_lds(p) + 2 * p->KK * 64 * 4 + (p->K * JT * 16 + (p->K + 1) / 2 * 2) * 8;
+}
 
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
@@ -65,7 +70,7 @@ int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_
     const int64_t grid_cs = grid0 / g->n_chunks * g->n_chunks;   // whole workgroups per chunk
     const int want = p->ctx->opt[MG_OPT_FRAMES_KERNEL];
     bool cs = g->cs_ok && grid_cs >= g->n_chunks && grid_cs <= 4096 &&
-              (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
+              (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds_cs(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
     // (the instantiations whose wave 0 does not fit the register budget -- 61 .. 64 latents; float64 latents from 53 on -- spill inside
     // the unit loop, where scratch traffic queues behind the store stream: those shapes stay with the tile-major kernel unless asked for)
     const bool cs_spills = p->KK >= 16 || (lat_f64 && p->KK >= 14);
@@ -82,7 +87,7 @@ int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int 
 }
 
 int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused) {
-    return (which == 2 ? g->cs_lds_bytes : g->lds_bytes) + (fused ? mg_fused_gmm_lds(p) : 0);
+    return which == 2 ? g->cs_lds_bytes + (fused ? mg_fused_gmm_lds_cs(p) : 0) : g->lds_bytes + (fused ? mg_fused_gmm_lds(p) : 0);
 }
 
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
@@ -120,7 +125,7 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
         return MG_ERR_UNSUPPORTED;
     }
     if (cs) lds = g->cs_lds_bytes;
-    if (logp) lds += mg_fused_gmm_lds(p);
+    if (logp) lds += cs ? mg_fused_gmm_lds_cs(p) : mg_fused_gmm_lds(p);
     const int grid = mg_frames_grid(p, g, B, which);
     if (cs) {
         const int Q = grid / g->n_chunks;

@@ -107,7 +107,7 @@ extern "C" int mg_debug_dump_stamps(void) {
         printf("chunk-stationary kernel, workgroup 0: per unit, us after the first stamp: work begins / ends\n");
         for (int w = 0; w < 16; w++) {   // rows 12..15: sub-phases of wave 0 (latents staged / root chains done, root image written / taps done)
             printf("wave %2d:", w);
-            for (int u = 0; u < 32 && (w >= 14 ? u < 4 : un[w][u][1] != 0); u++) printf(" %5.1f/%5.1f", (un[w][u][0] - u0) / 100.0, (un[w][u][1] - u0) / 100.0);
+            for (int u = 0; u < (w >= 14 ? 4 : 32); u++) if (w >= 14 || un[w][u][1] != 0) printf(" %5.1f/%5.1f", (un[w][u][0] - u0) / 100.0, (un[w][u][1] - u0) / 100.0);
             printf("\n");
         }
     }
@@ -462,11 +462,12 @@ __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const doubl
             mg_gmm_frag<KK> f, f2;
             mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl);
             if (k2 < gK) mg_gmm_load_component<KK>(f2, gPpack, gmP, gcst, k2, gJT, lane, cl);
-            mg_gmm_apply_component(f, k, gJT, xa, gterms, cl, g);
-            if (has_b) mg_gmm_apply_component(f, k, gJT, xb, gterms + gK * 16, cl, g);
+            typedef typename mg_gmm_xt<LAT_F64>::type XT;
+            mg_gmm_apply_component<KK, XT, true>(f, k, gJT, xa, gterms, cl, g);
+            if (has_b) mg_gmm_apply_component<KK, XT, true>(f, k, gJT, xb, gterms + gK * 16, cl, g);
             if (k2 < gK) {
-                mg_gmm_apply_component(f2, k2, gJT, xa, gterms, cl, g);
-                if (has_b) mg_gmm_apply_component(f2, k2, gJT, xb, gterms + gK * 16, cl, g);
+                mg_gmm_apply_component<KK, XT, true>(f2, k2, gJT, xa, gterms, cl, g);
+                if (has_b) mg_gmm_apply_component<KK, XT, true>(f2, k2, gJT, xb, gterms + gK * 16, cl, g);
             }
         }
 #else
@@ -479,6 +480,35 @@ __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const doubl
 #endif
     }
     mg_publish(prog + 16, pw, lane, group + 1);   // gdone[pw]
+}
+
+// The chunk-stationary kernel's form for float32 latents (round 5): the group's two latent tiles wait in LDS since start-up (gx, [2][KK][64]
+// float32 A fragments; mpl, cstl: the components' C-in rows and constants -- all staged by the sweep waves that produce nothing), so a producer wave has the registers to request BOTH of its
+// components at once -- one round trip through a memory pipe that the last unit's stores keep full (~5 us each, measured: the tail's two
+// dependent rounds were 13.3 us) instead of two.  Same components per wave, same arithmetic per (tile, component): the same bits.
+template <int KK>
+__device__ __forceinline__ void mg_fused_gmm_terms_ldsx(mg_lds_int *prog, const double *__restrict__ gPpack, const mg_lds_f32 *gx, const mg_lds_f64 *mpl,
+                                                        const mg_lds_f64 *cstl, int n_tiles, int gK, int gJT, int pw, int lane) {
+    const int cl = lane & 15, g = lane >> 4;
+    mg_lds_f64 *gterms = (mg_lds_f64 *)(prog + 32);   // [2][K*16]
+    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x;
+    const int64_t gt1 = ((int64_t)blockIdx.x + 1) * n_tiles / gridDim.x;
+    if (gt0 < gt1) {
+        const bool has_b = gt0 + 1 < gt1;
+        for (int k = pw; k < gK; k += 2 * MG_WS_NPW) {
+            const int k2 = k + MG_WS_NPW;
+            mg_gmm_frag<KK> f, f2;
+            mg_gmm_load_pf<KK>(f, gPpack, k, gJT, lane);
+            if (k2 < gK) mg_gmm_load_pf<KK>(f2, gPpack, k2, gJT, lane);
+            mg_gmm_apply_component_ldsx<KK>(f, k, gJT, gx, lane, mpl, cstl, gterms, cl, g);
+            if (has_b) mg_gmm_apply_component_ldsx<KK>(f, k, gJT, gx + KK * 64, lane, mpl, cstl, gterms + gK * 16, cl, g);
+            if (k2 < gK) {
+                mg_gmm_apply_component_ldsx<KK>(f2, k2, gJT, gx, lane, mpl, cstl, gterms, cl, g);
+                if (has_b) mg_gmm_apply_component_ldsx<KK>(f2, k2, gJT, gx + KK * 64, lane, mpl, cstl, gterms + gK * 16, cl, g);
+            }
+        }
+    }
+    mg_publish(prog + 16, pw, lane, 1);   // gdone[pw]
 }
 
 __device__ __forceinline__ void mg_fused_gmm_finish(mg_lds_int *prog, float *__restrict__ logp, int64_t B, int n_tiles, int gK,

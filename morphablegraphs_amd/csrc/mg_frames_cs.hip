@@ -40,6 +40,15 @@
 #ifndef MG_CS_GMM_EARLY
 #define MG_CS_GMM_EARLY 0   // 1: the fused mixture's first group of tiles is scored while the pipeline fills (below), not in the tail -- A/B only: SLOWER
 #endif
+#ifndef MG_CS_STORE_THROTTLE
+#define MG_CS_STORE_THROTTLE -1   // >= 0 (A/B only): the sweep waits after each trip of its lean loop until at most so many of the wave's stores are in flight
+#endif
+#ifndef MG_CS_THROTTLE_LAST_ONLY
+#define MG_CS_THROTTLE_LAST_ONLY 1   // ... in the workgroup's last unit only (while the mixture's loads share the CU's memory pipe with it)
+#endif
+#ifndef MG_CS_GMM_LDSX
+#define MG_CS_GMM_LDSX 1   // float32 latents: the mixture's two latent tiles staged in LDS at start-up, both components of a producer wave requested at once
+#endif
 #define MG_CS_BLOCK (64 * (MG_CS_NPW + MG_CS_NCW))
 template <int KK> struct mg_cs_cfg {
     static constexpr int TPWP = 120 / KK < 17 ? 120 / KK : 17;   // row tiles a row producer keeps in registers (TPWP * KK VGPRs)
@@ -63,6 +72,9 @@ int mg_cs_max_tiles(int KK) {
 #define MG_CS_PROG_MEAN 24   // [24..27]: mean' of the window's rows copied by sweep wave 4 + MG_CS_NSP + i
 #define MG_CS_PROG_GMM 32
 #define MG_CS_PROG_INTS 64
+// the staged latent tiles of the fused mixture: behind its term and exp buffers ([4][K*16] float64 after the 64 counters)
+__device__ __forceinline__ mg_lds_f32 *mg_cs_gmm_x(mg_lds_int *prog, int gK) { return (mg_lds_f32 *)((mg_lds_f64 *)(prog + MG_CS_PROG_INTS) + 4 * gK * 16); }
+__device__ __forceinline__ mg_lds_f64 *mg_cs_gmm_mp(mg_lds_int *prog, int gK, int KK) { return (mg_lds_f64 *)(mg_cs_gmm_x(prog, gK) + 2 * KK * 64); }   // [K][JT*16], then [K]
 __device__ __forceinline__ void mg_cs_wait_produced(const mg_lds_int *prog, int target) {   // the producing waves: 0 .. 3 + MG_CS_NSP
     for (;;) {
         const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
@@ -175,6 +187,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool GMM_LDSX = FUSE_GMM && !LAT_F64 && MG_CS_GMM_LDSX && !MG_CS_GMM_EARLY && MG_CS_NCW - MG_CS_NSP == 4;   // (four staging waves)
     if (wave == 0) MG_SUB_STAMP(14, 0, 0);
     // Kernel arguments: left alone, the compiler fetches each where a role first uses it -- a dependent trip to memory per
     // 64-byte line of the argument block (wave 0 alone made eight in a row before it had issued its loads, 4.8 us after entry).
@@ -228,11 +241,31 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         constexpr int MEAN_NTH = 64 * (MG_CS_NCW - MG_CS_NSP);
         const int n_mean = ck.ntiles * 16, e0 = tid - 64 * (MG_CS_NPW + MG_CS_NSP);
         float mv[6];
+        // ... and two of them stage the latent tiles of the workgroup's mixture scoring (MG_CS_GMM_LDSX, float32 latents): requested with mean'
+        [[maybe_unused]] float gxv[KK];
+        [[maybe_unused]] const int gx_tile = cj - MG_CS_NSP;   // 0, 1: the group's first / second tile
+        [[maybe_unused]] bool gx_on = false;
+        [[maybe_unused]] double gmv[6];
         if (!producing) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const int e = e0 + i * MEAN_NTH;
                 mv[i] = mean32[(size_t)ck.rt0 * 16 + (e < n_mean ? e : n_mean - 1)];
+            }
+            if constexpr (GMM_LDSX) {
+                const int64_t gt0 = (int64_t)blockIdx.x * a.n_tiles / gridDim.x, gt1 = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x;
+                gx_on = gx_tile < 2 && gt0 + gx_tile < gt1;   // (wave-uniform)
+                if (gx_on) {
+                    const int64_t b0 = (gt0 + gx_tile) * MG_NCAND;
+                    mg_gmm_load_x<KK, false>(gxv, lat, b0, (int)((a.B - b0) < MG_NCAND ? (a.B - b0) : MG_NCAND), a.ld, L, cl, g);
+                }
+                const int n_mp = gK * gJT * 16;              // the third such wave: the components' C-in rows; the fourth: their constants
+                if (gx_tile == 2) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) gmv[i] = gmP[min(lane + 64 * i, n_mp - 1)];
+                } else if (gx_tile == 3) {
+                    gmv[0] = gcst[min(lane, gK - 1)];
+                }
             }
         }
         mg_lds_barrier();
@@ -243,6 +276,23 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             for (int i = 0; i < 6; i++)
                 if (e0 + i * MEAN_NTH < n_mean) lds_mean[e0 + i * MEAN_NTH] = mv[i];
             for (int e = e0 + 6 * MEAN_NTH; e < n_mean; e += MEAN_NTH) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // (windows beyond 6 * MEAN_NTH rows)
+            if constexpr (GMM_LDSX) {   // before the publication every producer wave waits for (mg_cs_wait_mean): whoever has seen it sees the tiles
+                if (gx_on) {
+                    mg_lds_f32 *gx = mg_cs_gmm_x(prog, gK) + gx_tile * KK * 64;
+#pragma unroll
+                    for (int kk = 0; kk < KK; kk++) gx[kk * 64 + lane] = gxv[kk];
+                }
+                const int n_mp = gK * gJT * 16;
+                mg_lds_f64 *mpl = mg_cs_gmm_mp(prog, gK, KK);
+                if (gx_tile == 2) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+                        if (lane + 64 * i < n_mp) mpl[lane + 64 * i] = gmv[i];
+                    for (int e = lane + 64 * 6; e < n_mp; e += 64) mpl[e] = gmP[e];   // (more than 384 entries: K * JT > 24)
+                } else if (gx_tile == 3) {
+                    if (lane < gK) mpl[n_mp + lane] = gmv[0];
+                }
+            }
             mg_publish(prog + MG_CS_PROG_MEAN, cj - MG_CS_NSP, lane, 1);
         }
         if constexpr (FUSE_GMM && MG_CS_GMM_EARLY) {
@@ -310,6 +360,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             MG_STAMP(1);
             MG_UNIT_STAMP(u, 0);
             const int slot = u & 1;
+            [[maybe_unused]] const bool throttle_now = FUSE_GMM && u == n_units - 1;
             const unsigned char *img = smem + (size_t)slot * buf_bytes;
             const float *lds_ro = (const float *)(ro_base + (size_t)slot * RO_BYTES);
             const bool has1 = cj + 8 < ncand;
@@ -350,6 +401,9 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                             if (has1) {
                                 mg_store4_s(pa1, lane_out_b, v1a);
                                 mg_store4_s(pa1 + (size_t)rpi * D, lane_out_b, v1b);
+                            }
+                            if constexpr (MG_CS_STORE_THROTTLE >= 0) {   // A/B only: at most so many stores of this wave in flight (see the macro)
+                                if (!MG_CS_THROTTLE_LAST_ONLY || throttle_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MG_CS_STORE_THROTTLE) : "memory");
                             }
                         }
                     } else {
@@ -752,8 +806,17 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     if (FUSE_GMM && wave < MG_WS_NPW) {   // the mixture: the four producer waves, as in the tile-major kernel
         mg_lds_int *gprog = prog + MG_CS_PROG_GMM;
         if constexpr (!MG_CS_GMM_EARLY) {
-            mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
+            MG_UNIT_STAMP(29, 0);   // (diagnostic build: the tail's timeline in rows "unit" 29 .. 30 of the producer waves)
+            if constexpr (GMM_LDSX) {
+                if (wave == 0) mg_cs_wait_mean(prog);   // (the row producers did at start-up; long since true)
+                mg_fused_gmm_terms_ldsx<KK>(gprog, gPpack, mg_cs_gmm_x(prog, gK), mg_cs_gmm_mp(prog, gK, KK), mg_cs_gmm_mp(prog, gK, KK) + gK * gJT * 16, a.n_tiles,
+                                            gK, gJT, wave, lane);
+            } else
+                mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
+            MG_UNIT_STAMP(29, 1);
+            MG_UNIT_STAMP(30, 0);
             if (wave < 2) mg_fused_gmm_finish(gprog, logp, a.B, a.n_tiles, gK, wave, lane, 0);
+            MG_UNIT_STAMP(30, 1);
         }
         const int64_t my_tiles = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x - (int64_t)blockIdx.x * a.n_tiles / gridDim.x;
         if (my_tiles > 2) {

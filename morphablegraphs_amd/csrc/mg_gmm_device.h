@@ -9,6 +9,7 @@
 
 typedef double mg_f64x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) double mg_lds_f64;   // explicit LDS pointers: ds_* ops, 32-bit addresses
+typedef __attribute__((address_space(3))) float mg_lds_f32;
 
 // A/B fragments of a 16-candidate latent tile for the 16x16x4 MFMAs: lane l supplies
 // element [candidate = l & 15][k = 4*kk + (l >> 4)], 0 outside the tile / the latent dimension.
@@ -112,7 +113,9 @@ __device__ __forceinline__ void mg_gmm_finish_component(const mg_f64x4 (&acc)[JT
 
 // The component applied to a 16-candidate latent tile by one wave:
 // terms[k*16 + cand] = cst_k - 0.5 |x P_k - mu_k P_k|^2, the column tiles' accumulator chains interleaved.
-template <int KK, typename T>
+// WIDEN_AT_USE: the latent is widened again at every call (an opaque copy first), so that a caller that applies several components to
+// several tiles keeps its tiles in float32 registers instead of the compiler's hoisted float64 copies (the same conversions, the same bits).
+template <int KK, typename T, bool WIDEN_AT_USE = false>
 __device__ __forceinline__ void mg_gmm_apply_component(const mg_gmm_frag<KK> &f, int k, int JT, const T (&xf)[KK],
                                                        mg_lds_f64 *terms, int cl, int g) {
     constexpr int JTM = mg_gmm_frag<KK>::JTM;
@@ -120,11 +123,53 @@ __device__ __forceinline__ void mg_gmm_apply_component(const mg_gmm_frag<KK> &f,
 #pragma unroll
     for (int jt = 0; jt < JTM; jt++) acc[jt] = {f.c0[jt], f.c0[jt], f.c0[jt], f.c0[jt]};
 #pragma unroll
-    for (int kk = 0; kk < KK; kk++)
+    for (int kk = 0; kk < KK; kk++) {
+        T xv = xf[kk];
+        if constexpr (WIDEN_AT_USE) asm volatile("" : "+v"(xv));
+        const double xd = (double)xv;
 #pragma unroll
         for (int jt = 0; jt < JTM; jt++)
-            if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xf[kk], f.pf[jt][kk], acc[jt], 0, 0, 0);
+            if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd, f.pf[jt][kk], acc[jt], 0, 0, 0);
+    }
     mg_gmm_finish_component<JTM>(acc, JT, f.cst, k, terms, cl, g);
+}
+
+// The same with the latent tile's float32 A fragments in LDS ([KK][64], lane-major: what mg_gmm_load_x returns, stored as it is) and the
+// components' C-in rows and constants in LDS as well (mpl = mP as it lies in memory, [K][JT*16]; cstl [K]): between two components a wave
+// holds nothing but the fragments of P.  Same conversions, same MFMA order: the same bits.
+template <int KK>
+__device__ __forceinline__ void mg_gmm_load_pf(mg_gmm_frag<KK> &f, const double *__restrict__ Ppack, int k, int JT, int lane) {
+    constexpr int JTM = mg_gmm_frag<KK>::JTM;
+#pragma unroll
+    for (int jt = 0; jt < JTM; jt++) {
+        const int jtc = jt < JT ? jt : JT - 1;
+        const double *pp = Ppack + (((size_t)k * JT + jtc) * KK) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++)
+            if (kk < 4 * (jt + 1)) f.pf[jt][kk] = pp[kk * 64];
+    }
+}
+template <int KK>
+__device__ __forceinline__ void mg_gmm_apply_component_ldsx(const mg_gmm_frag<KK> &f, int k, int JT, const mg_lds_f32 *x, int lane,
+                                                            const mg_lds_f64 *mpl, const mg_lds_f64 *cstl, mg_lds_f64 *terms, int cl, int g) {
+    constexpr int JTM = mg_gmm_frag<KK>::JTM;
+    mg_f64x4 acc[JTM];
+    float xv[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) xv[kk] = x[kk * 64 + lane];
+#pragma unroll
+    for (int jt = 0; jt < JTM; jt++) {
+        const double c0 = -mpl[(k * JT + (jt < JT ? jt : JT - 1)) * 16 + cl];
+        acc[jt] = {c0, c0, c0, c0};
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) {
+        const double xd = (double)xv[kk];
+#pragma unroll
+        for (int jt = 0; jt < JTM; jt++)
+            if (kk < 4 * (jt + 1)) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd, f.pf[jt][kk], acc[jt], 0, 0, 0);
+    }
+    mg_gmm_finish_component<JTM>(acc, JT, cstl[k], k, terms, cl, g);
 }
 
 // exp(term - max over the components of the same candidate) of entry e = k*16 + cand
