@@ -45,6 +45,9 @@ static int mg_fused_gmm_lds_cs(const mg_primitive *p) {   // + the components' C
     return mg_fused_gmm_lds(p) + 2 * p->KK * 64 * 4 + (p->K * JT * 16 + (p->K + 1) / 2 * 2) * 8;
 }
 
+// the staged form of the chunk-stationary kernel's mixture tail where its extra LDS fits (otherwise the tail loads everything itself, as before)
+static bool mg_fused_gmm_staged(const mg_primitive *p, const mg_time_grid *g) { return g->cs_lds_bytes + mg_fused_gmm_lds_cs(p) <= 160 * 1024; }
+
 bool mg_frames_can_fuse_gmm(const mg_primitive *p, const mg_time_grid *g, int64_t B) {
     const int64_t n_tiles = (B + MG_NCAND - 1) / MG_NCAND;
     const int64_t grid = std::min<int64_t>(n_tiles * g->n_chunks, std::max(1, p->ctx->n_cu - p->ctx->reserved_cus));
@@ -70,7 +73,7 @@ int mg_frames_kernel_choice(const mg_primitive *p, const mg_time_grid *g, int64_
     const int64_t grid_cs = grid0 / g->n_chunks * g->n_chunks;   // whole workgroups per chunk
     const int want = p->ctx->opt[MG_OPT_FRAMES_KERNEL];
     bool cs = g->cs_ok && grid_cs >= g->n_chunks && grid_cs <= 4096 &&
-              (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds_cs(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
+              (!fused || (g->cs_lds_bytes + mg_fused_gmm_lds(p) <= 160 * 1024 && (n_tiles + grid_cs - 1) / grid_cs <= 4));
     // (the instantiations whose wave 0 does not fit the register budget -- 61 .. 64 latents; float64 latents from 53 on -- spill inside
     // the unit loop, where scratch traffic queues behind the store stream: those shapes stay with the tile-major kernel unless asked for)
     const bool cs_spills = p->KK >= 16 || (lat_f64 && p->KK >= 14);
@@ -87,7 +90,8 @@ int mg_frames_grid(const mg_primitive *p, const mg_time_grid *g, int64_t B, int 
 }
 
 int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which, bool fused) {
-    return which == 2 ? g->cs_lds_bytes + (fused ? mg_fused_gmm_lds_cs(p) : 0) : g->lds_bytes + (fused ? mg_fused_gmm_lds(p) : 0);
+    if (which == 2) return g->cs_lds_bytes + (fused ? (mg_fused_gmm_staged(p, g) ? mg_fused_gmm_lds_cs(p) : mg_fused_gmm_lds(p)) : 0);
+    return g->lds_bytes + (fused ? mg_fused_gmm_lds(p) : 0);
 }
 
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
@@ -125,7 +129,8 @@ int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *la
         return MG_ERR_UNSUPPORTED;
     }
     if (cs) lds = g->cs_lds_bytes;
-    if (logp) lds += cs ? mg_fused_gmm_lds_cs(p) : mg_fused_gmm_lds(p);
+    a.gmm_staged = cs && logp && mg_fused_gmm_staged(p, g) ? 1 : 0;
+    if (logp) lds += a.gmm_staged ? mg_fused_gmm_lds_cs(p) : mg_fused_gmm_lds(p);
     const int grid = mg_frames_grid(p, g, B, which);
     if (cs) {
         const int Q = grid / g->n_chunks;

@@ -254,13 +254,14 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             }
             if constexpr (GMM_LDSX) {
                 const int64_t gt0 = (int64_t)blockIdx.x * a.n_tiles / gridDim.x, gt1 = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x;
-                gx_on = gx_tile < 2 && gt0 + gx_tile < gt1;   // (wave-uniform)
+                gx_on = a.gmm_staged && gx_tile < 2 && gt0 + gx_tile < gt1;   // (wave-uniform)
                 if (gx_on) {
                     const int64_t b0 = (gt0 + gx_tile) * MG_NCAND;
                     mg_gmm_load_x<KK, false>(gxv, lat, b0, (int)((a.B - b0) < MG_NCAND ? (a.B - b0) : MG_NCAND), a.ld, L, cl, g);
                 }
                 const int n_mp = gK * gJT * 16;              // the third such wave: the components' C-in rows; the fourth: their constants
-                if (gx_tile == 2) {
+                if (!a.gmm_staged) {
+                } else if (gx_tile == 2) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) gmv[i] = gmP[min(lane + 64 * i, n_mp - 1)];
                 } else if (gx_tile == 3) {
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 }
                 const int n_mp = gK * gJT * 16;
                 mg_lds_f64 *mpl = mg_cs_gmm_mp(prog, gK, KK);
-                if (gx_tile == 2) {
+                if (!a.gmm_staged) {
+                } else if (gx_tile == 2) {
 #pragma unroll
                     for (int i = 0; i < 6; i++)
                         if (lane + 64 * i < n_mp) mpl[lane + 64 * i] = gmv[i];
@@ -807,10 +809,14 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         mg_lds_int *gprog = prog + MG_CS_PROG_GMM;
         if constexpr (!MG_CS_GMM_EARLY) {
             MG_UNIT_STAMP(29, 0);   // (diagnostic build: the tail's timeline in rows "unit" 29 .. 30 of the producer waves)
-            if constexpr (GMM_LDSX) {
-                if (wave == 0) mg_cs_wait_mean(prog);   // (the row producers did at start-up; long since true)
-                mg_fused_gmm_terms_ldsx<KK>(gprog, gPpack, mg_cs_gmm_x(prog, gK), mg_cs_gmm_mp(prog, gK, KK), mg_cs_gmm_mp(prog, gK, KK) + gK * gJT * 16, a.n_tiles,
-                                            gK, gJT, wave, lane);
+            bool staged = false;
+            if constexpr (GMM_LDSX) staged = a.gmm_staged != 0;   // (uniform: where the staged tables did not fit LDS the tail loads everything itself)
+            if (staged) {
+                if constexpr (GMM_LDSX) {
+                    if (wave == 0) mg_cs_wait_mean(prog);   // (the row producers did at start-up; long since true)
+                    mg_fused_gmm_terms_ldsx<KK>(gprog, gPpack, mg_cs_gmm_x(prog, gK), mg_cs_gmm_mp(prog, gK, KK), mg_cs_gmm_mp(prog, gK, KK) + gK * gJT * 16,
+                                                a.n_tiles, gK, gJT, wave, lane);
+                }
             } else
                 mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
             MG_UNIT_STAMP(29, 1);

@@ -713,6 +713,43 @@ def test_chunk_stationary_kernel_is_bit_identical(ctx, B):
     prim.close()
 
 
+@pytest.mark.parametrize("shape", [dict(n_components=40, n_frames=156, n_dim=79, n_gmm=16), dict(n_components=40, n_frames=156, n_dim=79, n_gmm=1),
+                                   dict(n_components=24, n_frames=60, n_dim=79, n_gmm=3), dict(n_components=13, n_frames=47, n_dim=15, n_gmm=5),
+                                   dict(n_components=33, n_frames=97, n_dim=79, n_gmm=11)])
+def test_fused_tail_with_staged_mixture_constants(ctx, shape):
+    """The chunk-stationary kernel's mixture tail for float32 latents (round 5): the workgroup's two latent tiles, the components'
+    C-in rows and constants staged in LDS at start-up by the four sweep waves that produce nothing, both components of a producer
+    wave requested at once.  Mixtures of 1 .. 16 components (more C-in entries than one pass of the staging wave; an odd count: a
+    wave with one component only), latent counts that are no multiple of four, one and two tiles per workgroup and workgroups without
+    any: log p bit for bit the stand-alone kernel's, frames the tile-major kernel's; float64 latents keep the unstaged form."""
+    data = synthetic.make_primitive(seed=77, name="tail", **shape)
+    prim = _capi.Primitive(ctx, data)
+    if not prim.mfma_supported:
+        prim.close()
+        pytest.skip("no LDS-staged kernel for this shape")
+    F, D, L = shape["n_frames"], shape["n_dim"], shape["n_components"]
+    rng = np.random.default_rng(5)
+    ran = 0
+    for B in (16, 1000, 4099, 8192):
+        for dtype in (np.float32, np.float64):
+            S = rng.standard_normal((B, L)).astype(dtype)
+            _set_frames_kernel(ctx, 1)
+            tm = prim.back_project_frames(S, path=_capi.MG_PATH_MFMA)
+            _set_frames_kernel(ctx, 2)
+            try:
+                frames, logp = _fused_step(ctx, prim, S, F, D)
+            except _capi.MGError as e:
+                assert e.status == -4, e          # MG_ERR_UNSUPPORTED: the shape is the tile-major kernel's
+                continue
+            ran += 1
+            np.testing.assert_array_equal(_bits(frames), _bits(tm), err_msg="B=%d %s" % (B, dtype))
+            np.testing.assert_array_equal(logp, prim.gmm_log_prob(S, dtype=np.float32), err_msg="B=%d %s" % (B, dtype))
+    _set_frames_kernel(ctx, 0)
+    prim.close()
+    if not ran:
+        pytest.skip("the chunk-stationary kernel does not cover this shape")
+
+
 def test_chunk_stationary_kernel_on_the_golden_shapes_and_other_grids(ctx, golden_case):
     """Every golden shape the chunk-stationary kernel covers (the others must say MG_ERR_UNSUPPORTED, never run
     something else): canonical grid against the reference's frames, and evaluation grids with fractional, repeated,
