@@ -78,6 +78,34 @@ __device__ unsigned long long mg_dbg_units[16][32][2];  // chunk-stationary kern
         }                                                                \
     } while (0)
 
+// Light stamps (MG_DEBUG_FLAGS & 32768, without 16): a handful of 100 MHz clock reads per wave kept in scalar registers and written ONCE when the wave
+// ends -- no store inside the kernel's life, so the timeline is the product kernel's (the per-unit stamps above put global stores into the producers).
+__device__ unsigned long long mg_dbg_lite[2][16][8];   // [workgroup 0 / workgroup 131][wave][stamp]
+#define MG_LITE_DECL unsigned long long lite_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MG_LITE(i_) do { if (a.debug & 32768) lite_[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MG_LITE_DUMP                                                                                              \
+    do {                                                                                                          \
+        if ((a.debug & 32768) && (blockIdx.x == 0 || blockIdx.x == 131) && lane == 0)                             \
+            for (int i_ = 0; i_ < 8; i_++) mg_dbg_lite[blockIdx.x ? 1 : 0][wave][i_] = lite_[i_];                 \
+    } while (0)
+extern "C" int mg_debug_dump_lite(void) {
+    static unsigned long long h[2][16][8], zero[2][16][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(mg_dbg_lite), sizeof(h)) != hipSuccess) return -1;
+    for (int w2 = 0; w2 < 2; w2++) {
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < 12; w++) if (h[w2][w][0] && h[w2][w][0] < t0) t0 = h[w2][w][0];
+        printf("light stamps, workgroup %d, us after its first wave's entry: [0] entry; producers (waves 0-3): [1] tail begins [3] terms done [4] log-sum-exp done;\n"
+               "  sweep waves: [1] first sweep begins [2] last sweep begins [4] last sweep ends\n", w2 ? 131 : 0);
+        for (int w = 0; w < 12; w++) {
+            printf("  wave %2d:", w);
+            for (int i = 0; i < 5; i++) printf(" %7.2f", h[w2][w][i] ? (h[w2][w][i] - t0) / 100.0 : -1.0);
+            printf("\n");
+        }
+    }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mg_dbg_lite), zero, sizeof(zero));
+    return 0;
+}
+
 extern "C" int mg_debug_dump_stamps(void) {
     unsigned long long h[16][10];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(mg_dbg_stamps), sizeof(h)) != hipSuccess) return -1;
@@ -122,6 +150,9 @@ extern "C" int mg_debug_dump_stamps(void) {
 #else
 #define MG_DBG(bits) 0
 #endif
+#define MG_LITE_DECL
+#define MG_LITE(i_) do { } while (0)
+#define MG_LITE_DUMP do { } while (0)
 #define MG_STAMP_DECL
 #define MG_STAMP(ph) do { } while (0)
 #define MG_STAMP_DUMP do { } while (0)

@@ -187,6 +187,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MG_LITE_DECL
+    MG_LITE(0);
     constexpr bool GMM_LDSX = FUSE_GMM && !LAT_F64 && MG_CS_GMM_LDSX && !MG_CS_GMM_EARLY && MG_CS_NCW - MG_CS_NSP == 4;   // (four staging waves)
     if (wave == 0) MG_SUB_STAMP(14, 0, 0);
     // Kernel arguments: left alone, the compiler fetches each where a role first uses it -- a dependent trip to memory per
@@ -361,6 +363,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             mg_cs_wait_produced(prog, u + 1);
             MG_STAMP(1);
             MG_UNIT_STAMP(u, 0);
+            if (u == 0) MG_LITE(1);
+            if (u == n_units - 1) MG_LITE(2);
             const int slot = u & 1;
             [[maybe_unused]] const bool throttle_now = FUSE_GMM && u == n_units - 1;
             const unsigned char *img = smem + (size_t)slot * buf_bytes;
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             }
             MG_STAMP(4);
             MG_UNIT_STAMP(u, 1);
+            if (u == n_units - 1) MG_LITE(4);
             mg_publish(prog + MG_CS_PROG_SWEPT, cj, lane, u + 1);
             MG_STAMP(5);
             if (u + 1 < n_units && producing) {
@@ -537,6 +542,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             }
         }
         MG_STAMP_DUMP;
+        MG_LITE_DUMP;
     } else if (wave != 0) {
         // ================= row producers (waves 1..3): TPWP row tiles each, the fragments in registers =================
         const int pw = wave - 1;
@@ -809,6 +815,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         mg_lds_int *gprog = prog + MG_CS_PROG_GMM;
         if constexpr (!MG_CS_GMM_EARLY) {
             MG_UNIT_STAMP(29, 0);   // (diagnostic build: the tail's timeline in rows "unit" 29 .. 30 of the producer waves)
+            MG_LITE(1);
             bool staged = false;
             if constexpr (GMM_LDSX) staged = a.gmm_staged != 0;   // (uniform: where the staged tables did not fit LDS the tail loads everything itself)
             if (staged) {
@@ -820,9 +827,12 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             } else
                 mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
             MG_UNIT_STAMP(29, 1);
+            MG_LITE(3);
             MG_UNIT_STAMP(30, 0);
             if (wave < 2) mg_fused_gmm_finish(gprog, logp, a.B, a.n_tiles, gK, wave, lane, 0);
             MG_UNIT_STAMP(30, 1);
+            MG_LITE(4);
+            MG_LITE_DUMP;
         }
         const int64_t my_tiles = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x - (int64_t)blockIdx.x * a.n_tiles / gridDim.x;
         if (my_tiles > 2) {

@@ -22,7 +22,8 @@ out = ctx.malloc(B * 156 * 79 * 4) if os.environ.get("PLAIN") else ctx.malloc_pl
 print("output:", out.placement)
 logp = ctx.malloc(B * 4)
 for flags in (sys.argv[1:] or ["0"]):
-    os.environ["MG_DEBUG_FLAGS"] = str(int(flags) | 16)
+    lite = bool(int(flags) & 32768)   # light stamps: the product kernel's timeline (no stamp stores inside the kernel's life)
+    os.environ["MG_DEBUG_FLAGS"] = str(int(flags) if lite else int(flags) | 16)
     for _ in range(200):
         if os.environ.get("FUSED", "1") != "0":
             prim.step_frames_and_logp_dev(S, np.float32, B, 40, out, logp)
@@ -40,5 +41,8 @@ for flags in (sys.argv[1:] or ["0"]):
     ms, n = ctx.profile_get("frames")
     ctx.profile_enable(False)
     print("==== MG_DEBUG_FLAGS = %s (+16): kernel %.2f us by its dispatch's own events (%d launches)" % (flags, 1e3 * ms / max(n, 1), n), flush=True)
-    lib.mg_debug_dump_stamps()
+    if lite:
+        lib.mg_debug_dump_lite()
+    else:
+        lib.mg_debug_dump_stamps()
     sys.stdout.flush()
