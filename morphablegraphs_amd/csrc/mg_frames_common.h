@@ -95,10 +95,10 @@ extern "C" int mg_debug_dump_lite(void) {
         unsigned long long t0 = ~0ull;
         for (int w = 0; w < 12; w++) if (h[w2][w][0] && h[w2][w][0] < t0) t0 = h[w2][w][0];
         printf("light stamps, workgroup %d, us after its first wave's entry: [0] entry; producers (waves 0-3): [1] tail begins [3] terms done [4] log-sum-exp done;\n"
-               "  sweep waves: [1] first sweep begins [2] last sweep begins [4] last sweep ends\n", w2 ? 131 : 0);
+               "  [5] barrier passed [6] first unit begins (wave 0: its latent tile is published) [7] first unit published; sweep waves: [1] first sweep begins [2] last sweep begins [4] last sweep ends\n", w2 ? 131 : 0);
         for (int w = 0; w < 12; w++) {
             printf("  wave %2d:", w);
-            for (int i = 0; i < 5; i++) printf(" %7.2f", h[w2][w][i] ? (h[w2][w][i] - t0) / 100.0 : -1.0);
+            for (int i = 0; i < 8; i++) printf(" %7.2f", h[w2][w][i] ? (h[w2][w][i] - t0) / 100.0 : -1.0);
             printf("\n");
         }
     }

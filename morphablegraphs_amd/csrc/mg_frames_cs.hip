@@ -279,7 +279,9 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             for (int i = 0; i < 6; i++)
                 if (e0 + i * MEAN_NTH < n_mean) lds_mean[e0 + i * MEAN_NTH] = mv[i];
             for (int e = e0 + 6 * MEAN_NTH; e < n_mean; e += MEAN_NTH) lds_mean[e] = mean32[(size_t)ck.rt0 * 16 + e];   // (windows beyond 6 * MEAN_NTH rows)
-            if constexpr (GMM_LDSX) {   // before the publication every producer wave waits for (mg_cs_wait_mean): whoever has seen it sees the tiles
+            mg_publish(prog + MG_CS_PROG_MEAN, cj - MG_CS_NSP, lane, 1);   // (the first unit waits for this: nothing of the mixture's in front of it)
+            MG_LITE(5);
+            if constexpr (GMM_LDSX) {   // the mixture's tables, with a flag of their own (prog + MG_CS_PROG_GMM + 20 + i) that the tail waits for
                 if (gx_on) {
                     mg_lds_f32 *gx = mg_cs_gmm_x(prog, gK) + gx_tile * KK * 64;
 #pragma unroll
@@ -296,8 +298,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 } else if (gx_tile == 3) {
                     if (lane < gK) mpl[n_mp + lane] = gmv[0];
                 }
+                if (a.gmm_staged) mg_publish(prog + MG_CS_PROG_GMM + 20, gx_tile, lane, 1);
             }
-            mg_publish(prog + MG_CS_PROG_MEAN, cj - MG_CS_NSP, lane, 1);
         }
         if constexpr (FUSE_GMM && MG_CS_GMM_EARLY) {
             // Round 5's structural attempt, kept for A/B (tools/build_variant.sh x -DMG_CS_GMM_EARLY=1): the mixture while the pipeline
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         const int pw = wave - 1;
         float ef[TPWP][KK];
         mg_lds_barrier();
+        MG_LITE(5);
         MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 0);
         mg_cs_load_fragments<KK, TPWP>(ef, ep, ck, pw, NRP, lane);   // in tile order: the first unit's MFMAs start as its first fragments land
         if (MG_DBG(32)) {   // when do the fragments land?
@@ -555,6 +558,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 1);
         }
         mg_cs_wait_mean(prog);
+        MG_LITE(2);
         MG_STAMP_DECL
         for (int u = 0; u < n_units; u++) {
             MG_STAMP(0);
@@ -562,12 +566,14 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             mg_cs_wait_latents(prog, u + 1);
             MG_STAMP(5);
             MG_UNIT_STAMP(u, 0);
+            if (u == 0) MG_LITE(6);
             if (!MG_DBG(1))
                 mg_cs_produce<KK, TPWP>(ef, lds_latb + (u & 1) * KK * 64, lds_mean, (float *)(smem + (size_t)(u & 1) * buf_bytes), stride, pw, NRP, nt_p,
                                         lane, cl, g);
             MG_STAMP(2);
             MG_UNIT_STAMP(u, 1);
             mg_publish(prog, wave, lane, u + 1);
+            if (u == 0) MG_LITE(7);
             MG_STAMP(4);
             if (MG_DBG(2048)) {   // experiment: what would streaming five more row tiles' fragments per unit from L2 cost?
                 for (int i = 0; i < 5; i++) {
@@ -664,6 +670,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         const int ti_v = i0tab[ck.t0 + tl];
         mg_lds_barrier();
         MG_SUB_STAMP(15, 1, 0);
+        MG_LITE(5);
         // LDS offsets of the root stage, every access unconditional: what must not count reads a zero (lds_rmean[63]), what must
         // not land goes to a spare slot (the padding double of a candidate's root image row; the fourth float of a root output)
         double *rs = (double *)rs_base;
@@ -724,6 +731,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             // fragments still being issued and hold this wave up; there it goes out after the root stage
             if (!FIRST) load_latents(s64next, u + 1);
             MG_SUB_STAMP(12, u, 0);
+            if (u == 0) MG_LITE(6);
             if (MG_DBG(1024)) {   // ablation: no root stage
                 if (FIRST) { park_tables(); load_latents(s64next, 1); }
                 MG_STAMP(3); mg_publish(prog, wave, lane, u + 1); MG_STAMP(4);
@@ -802,6 +810,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             MG_STAMP(3);
             MG_UNIT_STAMP(u, 1);
             MG_SUB_STAMP(13, u, 1);
+            if (u == 0) MG_LITE(7);
             mg_publish(prog, wave, lane, u + 1);
             if (FIRST) load_latents(s64next, 1);
             MG_STAMP(4);
@@ -820,7 +829,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
             if constexpr (GMM_LDSX) staged = a.gmm_staged != 0;   // (uniform: where the staged tables did not fit LDS the tail loads everything itself)
             if (staged) {
                 if constexpr (GMM_LDSX) {
-                    if (wave == 0) mg_cs_wait_mean(prog);   // (the row producers did at start-up; long since true)
+                    mg_wait_producers(gprog + 20, 1);   // the four staging waves' flags (long since set)
                     mg_fused_gmm_terms_ldsx<KK>(gprog, gPpack, mg_cs_gmm_x(prog, gK), mg_cs_gmm_mp(prog, gK, KK), mg_cs_gmm_mp(prog, gK, KK) + gK * gJT * 16,
                                                 a.n_tiles, gK, gJT, wave, lane);
                 }
