@@ -6,6 +6,10 @@ tag=${1:-r05}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# The library sets this itself when it is loaded -- but under rocprofv3 the profiler's own library has initialised the HIP runtime before
+# python starts, and the runtime reads the variable then: without the export the profiled kernels fetch their arguments from host memory
+# (+1.6 us on the frames kernel) and the trace is not the product's.
+export HIP_FORCE_DEV_KERNARG=1
 # the default bench.py command (steps 2000, warmup 200, HIP-event bracketing on), minus the CPU baseline leg
 B="$GRAFT_REPO_ROOT/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-extra-configs --no-placement-compare $@"
 # the counter passes slow the placement probe down, the arena then calls the buffer slow-class and the library would pick the tile-major

@@ -5,6 +5,10 @@
 set -o pipefail
 tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
+# The library sets this itself when it is loaded -- but under rocprofv3 the profiler's own library has initialised the HIP runtime before
+# python starts, and the runtime reads the variable then: without the export the profiled kernels fetch their arguments from host memory
+# (+1.6 us on the frames kernel) and the trace is not the product's.
+export HIP_FORCE_DEV_KERNARG=1
 for cfg in graph optimizer frame_constraints; do
   out=$GRAFT_REPO_ROOT/gpurun_out/prof_${tag}_$cfg
   mkdir -p $out
