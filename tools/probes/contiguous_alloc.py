@@ -11,11 +11,14 @@ hip.hipFree.argtypes = [C.c_void_p]
 ctx = _capi.Context(0)
 nbytes = int(sys.argv[1]) if len(sys.argv) > 1 else 8192 * 156 * 79 * 4
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+FLAGS = [int(x, 0) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0x4]   # hipDeviceMallocContiguous 0x4, Finegrained 0x1, Uncached 0x3
+NAMES = {0x4: "contiguous", 0x1: "finegrained", 0x3: "uncached"}
 held = []
 for i in range(2 * n):
     p = C.c_void_p()
-    kind = "contiguous" if i % 2 else "plain"
-    rc = hip.hipExtMallocWithFlags(C.byref(p), nbytes, 0x4) if i % 2 else hip.hipMalloc(C.byref(p), nbytes)
+    flag = FLAGS[(i // 2) % len(FLAGS)]
+    kind = NAMES.get(flag, hex(flag)) if i % 2 else "plain"
+    rc = hip.hipExtMallocWithFlags(C.byref(p), nbytes, flag) if i % 2 else hip.hipMalloc(C.byref(p), nbytes)
     if rc != 0:
         print("%2d %-10s allocation failed: hip status %d" % (i, kind, rc), flush=True)
         continue
