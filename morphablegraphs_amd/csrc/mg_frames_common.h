@@ -520,15 +520,19 @@ __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const doubl
 // dependent rounds were 13.3 us) instead of two.  Same components per wave, same arithmetic per (tile, component): the same bits.
 template <int KK>
 __device__ __forceinline__ void mg_fused_gmm_terms_ldsx(mg_lds_int *prog, const double *__restrict__ gPpack, const mg_lds_f32 *gx, const mg_lds_f64 *mpl,
-                                                        const mg_lds_f64 *cstl, int n_tiles, int gK, int gJT, int pw, int lane) {
+                                                        const mg_lds_f64 *cstl, int n_tiles, int gK, int gJT, int pw, int lane, bool early) {
     const int cl = lane & 15, g = lane >> 4;
     mg_lds_f64 *gterms = (mg_lds_f64 *)(prog + 32);   // [2][K*16]
     const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x;
     const int64_t gt1 = ((int64_t)blockIdx.x + 1) * n_tiles / gridDim.x;
     if (gt0 < gt1) {
         const bool has_b = gt0 + 1 < gt1;
-        for (int k = pw; k < gK; k += 2 * MG_WS_NPW) {
-            const int k2 = k + MG_WS_NPW;
+        // this wave's components: pw, pw + 4, pw + 8, pw + 12 -- without pw + 4 where the start-up has scored components 4 .. 7 already (early)
+        int ks[4], nk = 0;
+        for (int k = pw; k < gK; k += MG_WS_NPW)
+            if (!(early && k >= MG_WS_NPW && k < 2 * MG_WS_NPW)) ks[nk++] = k;
+        for (int i = 0; i < nk; i += 2) {
+            const int k = ks[i], k2 = i + 1 < nk ? ks[i + 1] : gK;
             mg_gmm_frag<KK> f, f2;
             mg_gmm_load_pf<KK>(f, gPpack, k, gJT, lane);
             if (k2 < gK) mg_gmm_load_pf<KK>(f2, gPpack, k2, gJT, lane);
@@ -541,6 +545,20 @@ __device__ __forceinline__ void mg_fused_gmm_terms_ldsx(mg_lds_int *prog, const 
         }
     }
     mg_publish(prog + 16, pw, lane, 1);   // gdone[pw]
+}
+
+// Start-up half of the staged form (MG_CS_GMM_EARLY_HALF): sweep wave 4 + MG_CS_NSP + i, idle until the first unit is in LDS, scores component 4 + i on the
+// workgroup's two latent tiles -- its fragments requested before the start-up barrier, the matrix pipes still idle (the row producers wait for their
+// eigenvector fragments) -- and leaves the terms where the tail's log-sum-exp finds them.  Same device code per (tile, component): the same bits.
+template <int KK>
+__device__ __forceinline__ void mg_fused_gmm_early_component(mg_lds_int *prog, const mg_gmm_frag<KK> &f, int k, const mg_lds_f32 *gx, const mg_lds_f64 *mpl,
+                                                             const mg_lds_f64 *cstl, int n_tiles, int gK, int gJT, int lane) {
+    const int cl = lane & 15, g = lane >> 4;
+    mg_lds_f64 *gterms = (mg_lds_f64 *)(prog + 32);   // [2][K*16]
+    const int64_t gt0 = (int64_t)blockIdx.x * n_tiles / gridDim.x;
+    const int64_t gt1 = ((int64_t)blockIdx.x + 1) * n_tiles / gridDim.x;
+    mg_gmm_apply_component_ldsx<KK>(f, k, gJT, gx, lane, mpl, cstl, gterms, cl, g);
+    if (gt0 + 1 < gt1) mg_gmm_apply_component_ldsx<KK>(f, k, gJT, gx + KK * 64, lane, mpl, cstl, gterms + gK * 16, cl, g);
 }
 
 __device__ __forceinline__ void mg_fused_gmm_finish(mg_lds_int *prog, float *__restrict__ logp, int64_t B, int n_tiles, int gK,

@@ -46,6 +46,9 @@
 #ifndef MG_CS_THROTTLE_LAST_ONLY
 #define MG_CS_THROTTLE_LAST_ONLY 1   // ... in the workgroup's last unit only (while the mixture's loads share the CU's memory pipe with it)
 #endif
+#ifndef MG_CS_GMM_EARLY_HALF
+#define MG_CS_GMM_EARLY_HALF 1   // with the staged tail: components 4 .. 7 are scored at start-up by the four sweep waves that produce nothing
+#endif
 #ifndef MG_CS_GMM_LDSX
 #define MG_CS_GMM_LDSX 1   // float32 latents: the mixture's two latent tiles staged in LDS at start-up, both components of a producer wave requested at once
 #endif
@@ -75,6 +78,13 @@ int mg_cs_max_tiles(int KK) {
 // the staged latent tiles of the fused mixture: behind its term and exp buffers ([4][K*16] float64 after the 64 counters)
 __device__ __forceinline__ mg_lds_f32 *mg_cs_gmm_x(mg_lds_int *prog, int gK) { return (mg_lds_f32 *)((mg_lds_f64 *)(prog + MG_CS_PROG_INTS) + 4 * gK * 16); }
 __device__ __forceinline__ mg_lds_f64 *mg_cs_gmm_mp(mg_lds_int *prog, int gK, int KK) { return (mg_lds_f64 *)(mg_cs_gmm_x(prog, gK) + 2 * KK * 64); }   // [K][JT*16], then [K]
+// MG_CS_GMM_EARLY_HALF: are components 4 .. 7 scored at start-up?  Where the workgroup has BOTH tiles of a mixture group (uniform over the workgroup; the
+// start-up waves and the tail ask the same question).  Measured, one process and one buffer each: B = 8192 -0.3 us (four boxes: +0.3, -0.7, -0.5, -0.3),
+// 12 000 -0.9, 16 384 -1.0 -- and with ONE tile per workgroup +0.6 (B = 2048) / +0.9 us (4096): the start-up pays the same and the tail has half to gain.
+__device__ __forceinline__ bool mg_cs_gmm_early(const mg_frames_args &a) {
+    const int64_t gt0 = (int64_t)blockIdx.x * a.n_tiles / gridDim.x, gt1 = ((int64_t)blockIdx.x + 1) * a.n_tiles / gridDim.x;
+    return a.gmm_staged && gt0 + 1 < gt1;
+}
 __device__ __forceinline__ void mg_cs_wait_produced(const mg_lds_int *prog, int target) {   // the producing waves: 0 .. 3 + MG_CS_NSP
     for (;;) {
         const i32x4 v = *(const volatile mg_lds_i32x4 *)prog;
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
     MG_LITE_DECL
     MG_LITE(0);
     constexpr bool GMM_LDSX = FUSE_GMM && !LAT_F64 && MG_CS_GMM_LDSX && !MG_CS_GMM_EARLY && MG_CS_NCW - MG_CS_NSP == 4;   // (four staging waves)
+    constexpr bool GMM_HALF = GMM_LDSX && MG_CS_GMM_EARLY_HALF && MG_WS_NPW == 4;
     if (wave == 0) MG_SUB_STAMP(14, 0, 0);
     // Kernel arguments: left alone, the compiler fetches each where a role first uses it -- a dependent trip to memory per
     // 64-byte line of the argument block (wave 0 alone made eight in a row before it had issued its loads, 4.8 us after entry).
@@ -248,6 +259,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         [[maybe_unused]] const int gx_tile = cj - MG_CS_NSP;   // 0, 1: the group's first / second tile
         [[maybe_unused]] bool gx_on = false;
         [[maybe_unused]] double gmv[6];
+        [[maybe_unused]] mg_gmm_frag<KK> epf;
+        [[maybe_unused]] bool early_on = false;
         if (!producing) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -268,6 +281,10 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                     for (int i = 0; i < 6; i++) gmv[i] = gmP[min(lane + 64 * i, n_mp - 1)];
                 } else if (gx_tile == 3) {
                     gmv[0] = gcst[min(lane, gK - 1)];
+                }
+                if constexpr (GMM_HALF) {
+                    early_on = mg_cs_gmm_early(a) && 4 + gx_tile < gK;
+                    if (early_on) mg_gmm_load_pf<KK>(epf, gPpack, 4 + gx_tile, gJT, lane);
                 }
             }
         }
@@ -299,6 +316,16 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                     if (lane < gK) mpl[n_mp + lane] = gmv[0];
                 }
                 if (a.gmm_staged) mg_publish(prog + MG_CS_PROG_GMM + 20, gx_tile, lane, 1);
+                if constexpr (GMM_HALF) {
+                    if (early_on) {
+                        __builtin_amdgcn_s_setprio(0);   // (below wave 0's root chains and everything else of the first unit)
+                        mg_wait_producers(prog + MG_CS_PROG_GMM + 20, 1);   // all four waves' tables are in LDS
+                        mg_fused_gmm_early_component<KK>(prog + MG_CS_PROG_GMM, epf, 4 + gx_tile, mg_cs_gmm_x(prog, gK), mg_cs_gmm_mp(prog, gK, KK),
+                                                         mg_cs_gmm_mp(prog, gK, KK) + gK * gJT * 16, a.n_tiles, gK, gJT, lane);
+                        __builtin_amdgcn_s_setprio(3);
+                    }
+                    if (a.gmm_staged) mg_publish(prog + MG_CS_PROG_GMM + 28, gx_tile, lane, 1);   // this wave's early terms (if any) are written
+                }
             }
         }
         if constexpr (FUSE_GMM && MG_CS_GMM_EARLY) {
@@ -831,7 +858,8 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 if constexpr (GMM_LDSX) {
                     mg_wait_producers(gprog + 20, 1);   // the four staging waves' flags (long since set)
                     mg_fused_gmm_terms_ldsx<KK>(gprog, gPpack, mg_cs_gmm_x(prog, gK), mg_cs_gmm_mp(prog, gK, KK), mg_cs_gmm_mp(prog, gK, KK) + gK * gJT * 16,
-                                                a.n_tiles, gK, gJT, wave, lane);
+                                                a.n_tiles, gK, gJT, wave, lane, GMM_HALF && mg_cs_gmm_early(a));
+                    if constexpr (GMM_HALF) mg_wait_producers(gprog + 28, 1);   // the start-up's terms (set long ago)
                 }
             } else
                 mg_fused_gmm_terms<KK, LAT_F64>(gprog, gPpack, gmP, gcst, lat, a.B, a.ld, L, a.n_tiles, gK, gJT, wave, lane, 0);
