@@ -534,8 +534,8 @@ __device__ __forceinline__ void mg_fused_gmm_terms_ldsx(mg_lds_int *prog, const 
         for (int i = 0; i < nk; i += 2) {
             const int k = ks[i], k2 = i + 1 < nk ? ks[i + 1] : gK;
             mg_gmm_frag<KK> f, f2;
-            mg_gmm_load_pf<KK>(f, gPpack, k, gJT, lane);
-            if (k2 < gK) mg_gmm_load_pf<KK>(f2, gPpack, k2, gJT, lane);
+            mg_gmm_load_pf2<KK>(f, gPpack, gK, k, gJT, lane);
+            if (k2 < gK) mg_gmm_load_pf2<KK>(f2, gPpack, gK, k2, gJT, lane);
             mg_gmm_apply_component_ldsx<KK>(f, k, gJT, gx, lane, mpl, cstl, gterms, cl, g);
             if (has_b) mg_gmm_apply_component_ldsx<KK>(f, k, gJT, gx + KK * 64, lane, mpl, cstl, gterms + gK * 16, cl, g);
             if (k2 < gK) {

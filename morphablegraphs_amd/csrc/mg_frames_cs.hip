@@ -284,7 +284,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
                 }
                 if constexpr (GMM_HALF) {
                     early_on = mg_cs_gmm_early(a) && 4 + gx_tile < gK;
-                    if (early_on) mg_gmm_load_pf<KK>(epf, gPpack, 4 + gx_tile, gJT, lane);
+                    if (early_on) mg_gmm_load_pf2<KK>(epf, gPpack, gK, 4 + gx_tile, gJT, lane);
                 }
             }
         }

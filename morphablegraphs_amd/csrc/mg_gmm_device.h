@@ -137,6 +137,26 @@ __device__ __forceinline__ void mg_gmm_apply_component(const mg_gmm_frag<KK> &f,
 // The same with the latent tile's float32 A fragments in LDS ([KK][64], lane-major: what mg_gmm_load_x returns, stored as it is) and the
 // components' C-in rows and constants in LDS as well (mpl = mP as it lies in memory, [K][JT*16]; cstl [K]): between two components a wave
 // holds nothing but the fragments of P.  Same conversions, same MFMA order: the same bits.
+// ... from the paired copy behind Ppack ([K][JT][KK/2][64][2], mg_host.hip): two blocks per 16-byte load
+template <int KK>
+__device__ __forceinline__ void mg_gmm_load_pf2(mg_gmm_frag<KK> &f, const double *__restrict__ Ppack, int K, int k, int JT, int lane) {
+    static_assert(KK % 2 == 0, "k-steps come in pairs");
+    typedef double mg_f64x2 __attribute__((ext_vector_type(2)));
+    constexpr int JTM = mg_gmm_frag<KK>::JTM;
+    const mg_f64x2 *P2 = (const mg_f64x2 *)(Ppack + (size_t)K * JT * KK * 64);
+#pragma unroll
+    for (int jt = 0; jt < JTM; jt++) {
+        const int jtc = jt < JT ? jt : JT - 1;
+        const mg_f64x2 *pp = P2 + (((size_t)k * JT + jtc) * (KK / 2)) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KK / 2; q++)
+            if (2 * q < 4 * (jt + 1)) {
+                const mg_f64x2 v = pp[q * 64];
+                f.pf[jt][2 * q] = v[0];
+                f.pf[jt][2 * q + 1] = v[1];
+            }
+    }
+}
 template <int KK>
 __device__ __forceinline__ void mg_gmm_load_pf(mg_gmm_frag<KK> &f, const double *__restrict__ Ppack, int k, int JT, int lane) {
     constexpr int JTM = mg_gmm_frag<KK>::JTM;

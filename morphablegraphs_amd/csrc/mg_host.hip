@@ -1034,6 +1034,17 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
             }
             if (rc == MG_OK) rc = mg_upload(ctx, cpack, &p->d_gcholpack);
             if (rc == MG_OK) rc = mg_upload(ctx, meanpad, &p->d_gmeanpad);
+            {   // ... followed by the same fragments with the k-steps in PAIRS per lane, [K][JT][KK/2][64][2]: one 16-byte load per lane fetches two blocks
+                // (the fused step's staged tail and its start-up half: half the load instructions through a CU's address unit, csrc/mg_gmm_device.h)
+                const size_t n1 = ppack.size();
+                ppack.resize(2 * n1, 0.0);
+                for (int k = 0; k < K; k++)
+                    for (int jt = 0; jt < JT; jt++)
+                        for (int q = 0; q < KK / 2; q++)
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int h = 0; h < 2; h++)
+                                    ppack[n1 + ((((size_t)k * JT + jt) * (KK / 2) + q) * 64 + lane) * 2 + h] = ppack[((((size_t)k * JT + jt) * KK) + 2 * q + h) * 64 + lane];
+            }
             if (rc == MG_OK) rc = mg_upload(ctx, ppack, &p->d_gPpack);
             if (rc == MG_OK) rc = mg_upload(ctx, ptpack, &p->d_gPTpack);
             if (rc == MG_OK) rc = mg_upload(ctx, mpad, &p->d_gmPpad);
