@@ -363,7 +363,7 @@ def run_walk(args, rank, local_rank, world):
     if rank == 0:
         value = world * B * args.steps / elapsed
         placement = {"allocator": "one hipMalloc (MG_OPT_PLAIN_MALLOC)" if args.output_alloc == "plain" else "the library's placed output regions (mg_device_malloc / mg_device_malloc_placed: every buffer of 64 MiB and more, "
-                                  "the *_host entry points' scratch included, is a piece of a region that went through the placement probe; scan of 32 candidates, up to 160 when those were all slow, a quarter of the free memory held at most)",
+                                  "the *_host entry points' scratch included, is a piece of a region that went through the placement probe; scan of 32 candidates, up to 400 when those were all slow -- six tenths of the free memory held while that runs)",
                      "candidates_probed": frames.placement["probed"] if frames.placement else 0, "alloc_seconds": round(alloc_s, 4),
                      "pattern_over_fill": round(probe["ratio"], 4)}
         # the class is the arena's: decided once from the scan's own measurement and kept (mg_device_placement_info); the probe

@@ -302,8 +302,9 @@ int mg_context_output_bytes(mg_context *ctx, int64_t *reserved, int64_t *in_use,
 int mg_device_malloc_chunked(mg_context *ctx, int64_t bytes, int64_t chunk_bytes, void **out_dev);
 /* mg_device_malloc's placed path with an explicit budget and a report.  max_candidates <= 0: the default scan (16 plain
  * allocations, then -- unless max_candidates == 1 -- twelve assembled from physical chunks of 32 / 8 / 2 MiB, then plain
- * again, 32 in all -- and, when those were all slow, on with plain allocations up to 160 candidates or a quarter of the free
- * memory held: fast-class memory is sparse, about one 404 MB allocation in thirty, and a scan of 32 misses it on one box in three;
+ * again, 32 in all, at most a quarter of the free memory held -- and, when those were all slow, on with plain allocations up to
+ * 400 candidates or six tenths of the free memory held while the scan runs: fast-class memory is sparse, about one 404 MB
+ * allocation in thirty, and comes in clusters of the allocation order (on one box the first was the 181st candidate);
  * ~12 ms per candidate, once per region; max_candidates > 0 is an exact budget without that); if nothing is fast the best
  * candidate of all is returned.  info (may be NULL): [0] candidates probed BY
  * THIS CALL (0: the piece came from a region the context already had), [1] pattern time / fill time of the region, [2] its

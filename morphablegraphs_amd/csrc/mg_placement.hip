@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void mg_placement_fill_kernel(f32x4p *buf, siz
 // on.  (Round 3's bench met a buffer at 5.996: one threshold for both made a 0.07 % margin flip the kernel choice, and a second
 // probe of the same buffer contradict the arena.)
 #define MG_PLACED_CLASS_TBPS 5.9
-#define MG_PLACED_DEEP_CANDIDATES 160       // the default scan's last resort (see mg_region_create)
+#define MG_PLACED_DEEP_CANDIDATES 400       // the default scan's last resort (see mg_region_create)
 static double mg_placement_tbps(int64_t bytes, double pattern_us) {   // 0: the probe is too small to fill the chip (or was not timed)
     const int64_t cand_bytes = (int64_t)MG_PP_T * MG_PP_D * 4;
     const int64_t ntiles = std::min<int64_t>(bytes / (16 * cand_bytes), 1 << 20);
@@ -227,8 +227,13 @@ static int mg_region_create(mg_context *ctx, size_t bytes, size_t probe_bytes, i
     // budget of its own and the first 32 candidates were all slow, the scan goes on, plain allocations only, until a fast one turns
     // up, MG_PLACED_DEEP_CANDIDATES have been probed, or the candidates held (they must stay allocated, or the allocator hands the
     // same memory out again) reach the hold cap: ~12 ms per candidate, once per region.
+    // (Round 5: fast-class memory comes in CLUSTERS of the allocation order -- on a box whose first 180 candidates were all slow, 19 of the next 45 were
+    // fast, 26 of 600 in all (profiles/r05_frames/deep_scan_600.log) -- and a limit of 160 candidates / a quarter of the memory stopped just short of
+    // them on one process in ten (step 94 instead of 77 us).  The deep scan now goes to 400 candidates and may hold six tenths of the free memory while
+    // it runs -- for seconds, once per region; everything but the winner is released before it returns.)
     if (rc == MG_OK && best.p && !best_fast && max_candidates == 0 && ctx->opt[MG_OPT_PLACED_HOLD] == 0) {
         limit = MG_PLACED_DEEP_CANDIDATES;
+        hold_cap = std::max<size_t>(hold_cap, free_b / 10 * 6);
         while (probed < limit && !best_fast && rc == MG_OK && (held.size() + 3) * bytes <= hold_cap) {
             const int before = probed;
             plain(1);
