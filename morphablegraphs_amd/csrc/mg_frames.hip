@@ -97,6 +97,7 @@ int mg_frames_lds_bytes(const mg_primitive *p, const mg_time_grid *g, int which,
 int mg_launch_frames_mfma(mg_primitive *p, const mg_time_grid *g, const void *lat, int ldt, int64_t B, int64_t ld, float *out, float *logp,
                           int prof_slot, int prof_slot2) {
     mg_frames_args a;
+    a.rt_total = p->RT;
     a.B = B; a.ld = ld; a.T = g->T; a.D = p->D; a.Dp = p->Dp; a.cshift = p->cshift; a.L = p->L; a.nroot = p->nroot;
     a.n_chunks = g->n_chunks; a.stride = g->stride; a.max_wi = g->max_wi; a.max_nt = g->max_nt; a.nbuf = g->nbuf;
     a.debug = 0;

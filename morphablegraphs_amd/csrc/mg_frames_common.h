@@ -25,6 +25,7 @@ struct mg_frames_args {
                      // 128 = no chunk rotation, 256 = no tile-round rotation, 512 = row producers without E' loads, 1024 = wave 0 idle
     int32_t nbuf;    // LDS ring depth (2 or 3)
     int32_t max_tiles;   // row tiles of the widest chunk window (chunk-stationary kernel: sizes its mean' window in LDS)
+    int32_t rt_total;    // row tiles of the primitive's whole eigenvector image (the chunk-stationary kernel's quad copy lies behind the pair image: + rt_total * KK * 64 floats)
     int32_t gmm_staged;  // chunk-stationary kernel, fused mixture: its latent tiles, C-in rows and constants have room in LDS (staged at start-up, MG_CS_GMM_LDSX)
     int32_t cs_magic, cs_per, cs_rem;   // chunk-stationary kernel: workgroup w -> (chunk, block) without a division: q = (w * cs_magic) >> 20;
                                         // cs_per tiles per workgroup of a chunk, the first cs_rem one more

@@ -46,6 +46,9 @@
 #ifndef MG_CS_THROTTLE_LAST_ONLY
 #define MG_CS_THROTTLE_LAST_ONLY 1   // ... in the workgroup's last unit only (while the mixture's loads share the CU's memory pipe with it)
 #endif
+#ifndef MG_CS_QUAD_FRAGMENTS
+#define MG_CS_QUAD_FRAGMENTS 1   // the one-time eigenvector fragment loads from the quad copy of the image: 16-byte loads
+#endif
 #ifndef MG_CS_GMM_EARLY_HALF
 #define MG_CS_GMM_EARLY_HALF 1   // with the staged tail: components 4 .. 7 are scored at start-up by the four sweep waves that produce nothing
 #endif
@@ -160,7 +163,28 @@ __device__ __forceinline__ void mg_cs_produce(const float (&ef)[NT][KK], const f
     }
 }
 template <int KK, int NT>
-__device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const float2 *ep, const mg_chunk &ck, int first, int step, int lane) {
+__device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const float2 *ep, const mg_chunk &ck, int first, int step, int lane, [[maybe_unused]] int rt_total) {
+#if MG_CS_QUAD_FRAGMENTS
+    // from the quad copy behind the pair image (mg_host.hip): per tile [KK / 4][64][4] floats, then [64][2] for the last pair: 16-byte loads
+    const float *eq = (const float *)ep + (size_t)rt_total * KK * 64;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int t = first + step * i;
+        const int tc = t < ck.ntiles ? t : ck.ntiles - 1;   // clamp: redundant but in bounds
+        const float *p = eq + (size_t)(ck.rt0 + tc) * KK * 64;
+#pragma unroll
+        for (int q = 0; q < KK / 4; q++) {
+            const f32x4 v = *(const f32x4 *)(p + ((size_t)q * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) ef[i][4 * q + e] = v[e];
+        }
+        if constexpr (KK % 4 == 2) {
+            const float2 v = *(const float2 *)(p + (size_t)(KK / 4) * 256 + (size_t)lane * 2);
+            ef[i][KK - 2] = v.x;
+            ef[i][KK - 1] = v.y;
+        }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < NT; i++) {
         const int t = first + step * i;
@@ -173,6 +197,7 @@ __device__ __forceinline__ void mg_cs_load_fragments(float (&ef)[NT][KK], const 
             ef[i][2 * q2 + 1] = v.y;
         }
     }
+#endif
 }
 
 template <int KK, bool LAT_F64, bool FUSE_GMM, bool SPLIT>
@@ -290,7 +315,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         }
         mg_lds_barrier();
         if (producing) {
-            mg_cs_load_fragments<KK, TPWS>(ef, ep, ck, nt_p + cj, MG_CS_NSP, lane);   // in flight across barrier B
+            mg_cs_load_fragments<KK, TPWS>(ef, ep, ck, nt_p + cj, MG_CS_NSP, lane, a.rt_total);   // in flight across barrier B
         } else {
 #pragma unroll
             for (int i = 0; i < 6; i++)
@@ -579,7 +604,7 @@ __global__ __launch_bounds__(MG_CS_BLOCK) void mg_frames_cs_kernel(
         mg_lds_barrier();
         MG_LITE(5);
         MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 0);
-        mg_cs_load_fragments<KK, TPWP>(ef, ep, ck, pw, NRP, lane);   // in tile order: the first unit's MFMAs start as its first fragments land
+        mg_cs_load_fragments<KK, TPWP>(ef, ep, ck, pw, NRP, lane, a.rt_total);   // in tile order: the first unit's MFMAs start as its first fragments land
         if (MG_DBG(32)) {   // when do the fragments land?
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             MG_SUB_STAMP(14 + (wave == 1 ? 1 : 0), wave == 1 ? 0 : 1, 1);

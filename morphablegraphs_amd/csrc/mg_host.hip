@@ -947,6 +947,21 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                         float v = (i < NB && dd >= 0 && dd < D && k < L) ? (float)p->Es[((size_t)i * D + dd) * L + k] : 0.0f;
                         pack[(((size_t)rt * (KK / 2) + kk / 2) * 64 + lane) * 2 + (kk & 1)] = v;
                     }
+            {   // ... followed by a second copy for the chunk-stationary kernel's one-time fragment loads: per tile the k-steps in QUADS per lane ([q][64][4],
+                // q < KK / 4), then the remaining pair ([64][2]) where KK is no multiple of four -- 16-byte loads, 3 instead of 5 instructions per tile at
+                // KK = 10 through a CU's address unit while the whole chip fetches its windows at once (csrc/mg_frames_cs.hip, mg_cs_load_fragments)
+                const size_t n1 = pack.size();
+                pack.resize(2 * n1, 0.0f);
+                for (int rt = 0; rt < p->RT; rt++)
+                    for (int kk = 0; kk < KK; kk++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            const float v = pack[(((size_t)rt * (KK / 2) + kk / 2) * 64 + lane) * 2 + (kk & 1)];
+                            const int q = kk / 4, nq = KK / 4;
+                            const size_t tile = n1 + (size_t)rt * KK * 64;
+                            if (q < nq) pack[tile + ((size_t)q * 64 + lane) * 4 + (kk & 3)] = v;
+                            else pack[tile + (size_t)nq * 256 + (size_t)lane * 2 + (kk & 1)] = v;
+                        }
+            }
             rc = mg_upload(ctx, pack, &p->d_Epack);
         }
     }
