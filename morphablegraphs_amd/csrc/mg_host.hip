@@ -1047,6 +1047,16 @@ extern "C" int mg_primitive_create(mg_context *ctx, const mg_primitive_desc *d, 
                                 cpack[((((size_t)k * JT + it) * KK) + kk) * 64 + lane] = chol[(size_t)k * Lg * Lg + (size_t)i * L + j];
                         }
             }
+            {   // ... followed by the same fragments with the k-steps in pairs per lane ([K][JT][KK/2][64][2]): 16-byte loads in the planner step's sampler
+                const size_t n1 = cpack.size();
+                cpack.resize(2 * n1, 0.0);
+                for (int k = 0; k < K; k++)
+                    for (int it = 0; it < JT; it++)
+                        for (int q = 0; q < KK / 2; q++)
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int h = 0; h < 2; h++)
+                                    cpack[n1 + ((((size_t)k * JT + it) * (KK / 2) + q) * 64 + lane) * 2 + h] = cpack[((((size_t)k * JT + it) * KK) + 2 * q + h) * 64 + lane];
+            }
             if (rc == MG_OK) rc = mg_upload(ctx, cpack, &p->d_gcholpack);
             if (rc == MG_OK) rc = mg_upload(ctx, meanpad, &p->d_gmeanpad);
             {   // ... followed by the same fragments with the k-steps in PAIRS per lane, [K][JT][KK/2][64][2]: one 16-byte load per lane fetches two blocks

@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256) void mg_options_counts_kernel(const mg_fused_s
     mg_counts_draw(tab[blockIdx.x], a.seed[blockIdx.x], a.n, dc, blockIdx.x, below);
 }
 
+#ifndef MG_OPT_PAIRED_FRAGMENTS
+#define MG_OPT_PAIRED_FRAGMENTS 1
+#endif
 template <bool X_F64, bool DYN_DEV>
 __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused_kernel(const mg_fused_static *__restrict__ tab, const mg_fused_dyn dyn_arg,
                                                               const mg_fused_devcounts *__restrict__ dyn_dev,
@@ -228,12 +231,25 @@ __global__ __launch_bounds__(256, MG_FUSED_WAVES_PER_SIMD) void mg_options_fused
 #pragma unroll
         for (int it = 0; it < MG_MAX_KK / 4; it++) {
             if (it < JT) {
-                const double *cp = o.cpack + (((size_t)c * JT + it) * KKg) * 64 + lane;
                 const double m = o.meanpad[((size_t)c * JT + it) * 16 + cl];
                 mg_f64x4 acc = {m, m, m, m};
+#if MG_OPT_PAIRED_FRAGMENTS
+                // (the paired copy behind the image, mg_host.hip: one 16-byte load per two k-steps; KKg is even, 4 (it + 1) a multiple of four)
+                typedef double mg_f64x2 __attribute__((ext_vector_type(2)));
+                const mg_f64x2 *cp2 = (const mg_f64x2 *)(o.cpack + (size_t)K * JT * KKg * 64) + (((size_t)c * JT + it) * (KKg / 2)) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < MG_MAX_KK / 2; q++)
+                    if (2 * q < KKg && 2 * q < 4 * (it + 1)) {
+                        const mg_f64x2 v = cp2[q * 64];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[2 * q], v[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[2 * q + 1], v[1], acc, 0, 0, 0);
+                    }
+#else
+                const double *cp = o.cpack + (((size_t)c * JT + it) * KKg) * 64 + lane;
 #pragma unroll
                 for (int kk = 0; kk < MG_MAX_KK; kk++)
                     if (kk < KKg && kk < 4 * (it + 1)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[kk], cp[kk * 64], acc, 0, 0, 0);
+#endif
                 const int i = 16 * it + cl;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
