@@ -493,8 +493,8 @@ __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const doubl
         for (int k = pw; k < gK; k += 2 * MG_WS_NPW) {
             const int k2 = k + MG_WS_NPW;
             mg_gmm_frag<KK> f, f2;
-            mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl);
-            if (k2 < gK) mg_gmm_load_component<KK>(f2, gPpack, gmP, gcst, k2, gJT, lane, cl);
+            mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl, gK);
+            if (k2 < gK) mg_gmm_load_component<KK>(f2, gPpack, gmP, gcst, k2, gJT, lane, cl, gK);
             typedef typename mg_gmm_xt<LAT_F64>::type XT;
             mg_gmm_apply_component<KK, XT, true>(f, k, gJT, xa, gterms, cl, g);
             if (has_b) mg_gmm_apply_component<KK, XT, true>(f, k, gJT, xb, gterms + gK * 16, cl, g);
@@ -506,7 +506,7 @@ __device__ __forceinline__ void mg_fused_gmm_terms(mg_lds_int *prog, const doubl
 #else
         for (int k = pw; k < gK; k += MG_WS_NPW) {
             mg_gmm_frag<KK> f;
-            mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl);
+            mg_gmm_load_component<KK>(f, gPpack, gmP, gcst, k, gJT, lane, cl, gK);
             mg_gmm_apply_component(f, k, gJT, xa, gterms, cl, g);
             if (has_b) mg_gmm_apply_component(f, k, gJT, xb, gterms + gK * 16, cl, g);
         }

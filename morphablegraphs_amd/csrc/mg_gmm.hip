@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void mg_gmm_logp_mfma_kernel(const double *__r
     mg_gmm_load_x<KK, X_F64>(xf, x, b0, ncand, a.ld, a.L, cl, g);
     for (int k = wave; k < a.K; k += 4) {
         mg_gmm_frag<KK> f;
-        mg_gmm_load_component<KK>(f, Ppack, mP, cst, k, a.JT, lane, cl);
+        mg_gmm_load_component<KK>(f, Ppack, mP, cst, k, a.JT, lane, cl, a.K);
         mg_gmm_apply_component(f, k, a.JT, xf, lds_t, cl, g);
     }
     __syncthreads();
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void mg_gmm_jac_mfma_kernel(const double *__re
     mg_gmm_load_x<KK, X_F64>(xf, x, b0, ncand, a.ld, a.L, cl, g);
     for (int k = wave; k < a.K; k += 4) {
         mg_gmm_frag<KK> f;
-        mg_gmm_load_component<KK>(f, Ppack, mP, cst, k, a.JT, lane, cl);
+        mg_gmm_load_component<KK>(f, Ppack, mP, cst, k, a.JT, lane, cl, a.K);
         mg_f64x4 acc[JTM];
 #pragma unroll
         for (int jt = 0; jt < JTM; jt++) acc[jt] = {f.c0[jt], f.c0[jt], f.c0[jt], f.c0[jt]};

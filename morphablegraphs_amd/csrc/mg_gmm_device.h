@@ -54,18 +54,26 @@ struct mg_gmm_frag {
 
 template <int KK>
 __device__ __forceinline__ void mg_gmm_load_component(mg_gmm_frag<KK> &f,
-                                                      const double *__restrict__ Ppack,  // [K][JT][KK][64]
+                                                      const double *__restrict__ Ppack,  // [K][JT][KK][64], then the same in pairs per lane [K][JT][KK/2][64][2]
                                                       const double *__restrict__ mP,     // [K][JT*16]
                                                       const double *__restrict__ cst,    // [K]
-                                                      int k, int JT, int lane, int cl) {
+                                                      int k, int JT, int lane, int cl, int K) {
+    static_assert(KK % 2 == 0, "k-steps come in pairs");
+    typedef double mg_f64x2 __attribute__((ext_vector_type(2)));
     constexpr int JTM = mg_gmm_frag<KK>::JTM;
+    // the fragments of P from the paired copy behind the image (mg_host.hip): one 16-byte load per two k-steps, half the load instructions
+    const mg_f64x2 *P2 = (const mg_f64x2 *)(Ppack + (size_t)K * JT * KK * 64);
 #pragma unroll
     for (int jt = 0; jt < JTM; jt++) {
         const int jtc = jt < JT ? jt : JT - 1;
-        const double *pp = Ppack + (((size_t)k * JT + jtc) * KK) * 64 + lane;
+        const mg_f64x2 *pp = P2 + (((size_t)k * JT + jtc) * (KK / 2)) * 64 + lane;
 #pragma unroll
-        for (int kk = 0; kk < KK; kk++)
-            if (kk < 4 * (jt + 1)) f.pf[jt][kk] = pp[kk * 64];
+        for (int q = 0; q < KK / 2; q++)
+            if (2 * q < 4 * (jt + 1)) {
+                const mg_f64x2 v = pp[q * 64];
+                f.pf[jt][2 * q] = v[0];
+                f.pf[jt][2 * q + 1] = v[1];
+            }
         f.c0[jt] = -mP[((size_t)k * JT + jtc) * 16 + cl];
     }
     f.cst = cst[k];
