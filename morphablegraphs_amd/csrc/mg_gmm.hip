@@ -300,16 +300,21 @@ __global__ __launch_bounds__(64 * mg_gmm_lds_nw<SCORE>::value) void mg_gmm_logp_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = lane & 15, g = lane >> 4;
     // staging: a wave copies whole 512-byte fragments (wave-uniform index arithmetic, several loads in flight)
+    // (from the paired copy behind the image, mg_host.hip: two k-steps per 16-byte load; a column tile's count of k-steps is even, so is nf)
+    typedef double mg_f64x2 __attribute__((ext_vector_type(2)));
+    const mg_f64x2 *P2 = (const mg_f64x2 *)(Ppack + (size_t)K * JT * KK * 64);
 #pragma unroll 4
-    for (int F = wave; F < K * nf; F += NW) {
-        const int k = F / nf, f = F - k * nf;
+    for (int F2 = wave; F2 < K * nf / 2; F2 += NW) {
+        const int F = 2 * F2, k = F / nf, f = F - k * nf;
         int jt = 0, off = 0;
 #pragma unroll
         for (int j = 0; j < JTM - 1; j++) {
             const int n = (4 * (j + 1) < KK) ? 4 * (j + 1) : KK;
             if (f >= off + n) { off += n; jt = j + 1; }
         }
-        lds_f[F * 64 + lane] = Ppack[(((size_t)k * JT + jt) * KK + (f - off)) * 64 + lane];
+        const mg_f64x2 v = P2[(((size_t)k * JT + jt) * (KK / 2) + (f - off) / 2) * 64 + lane];
+        lds_f[F * 64 + lane] = v[0];
+        lds_f[(F + 1) * 64 + lane] = v[1];
     }
     for (int e = tid; e < K * JT * 16; e += 64 * NW) lds_c[e] = -mP[e];
     __syncthreads();
